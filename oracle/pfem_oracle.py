@@ -1,0 +1,319 @@
+"""ctypes/numpy front-end of the CPU oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module (it is the checker, never the thing measured or shipped).
+
+* ``liboracle.so``        -- oracle/pfem_oracle.c, the C restatement (always available)
+* ``_ref/libpfem_ref.so`` -- the reference's own Fortran element routines compiled in place
+  with flang (optional: built only where /root/reference exists; see oracle/Makefile)
+
+Array conventions follow the Fortran drivers (column-major == SoA):
+``xyz`` is ``(ndim, nNode)`` C-contiguous, ``conn`` / ``edof`` are ``(npElem|nsize, nElem)``
+C-contiguous int32, 0-based, ``-1`` marks a Dirichlet dof.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import gzip
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+POISSON_TRIA, POISSON_TET, ELAST_TET, POISSON_TRIA_INLINE = 1, 2, 3, 4
+NPELEM = {POISSON_TRIA: 3, POISSON_TET: 4, ELAST_TET: 4, POISSON_TRIA_INLINE: 3}
+NDOF = {POISSON_TRIA: 1, POISSON_TET: 1, ELAST_TET: 3, POISSON_TRIA_INLINE: 1}
+NDIM = {POISSON_TRIA: 2, POISSON_TET: 3, ELAST_TET: 3, POISSON_TRIA_INLINE: 2}
+
+# REAL(4) literals of the drivers widened to double
+F32 = lambda v: float(np.float32(v))  # noqa: E731
+POISSON_ELEMDATA = np.array([1.0, 1.0, 1.0])                     # tetrapoissonparallelimpl1.F:822
+ELAST_ELEMDATA = np.array([F32(240.565), F32(0.3), 1.0, F32(0.1), 0.0, 0.0])  # tetraelasticity...F:895-899
+TIMEDATA = np.array([0.0, 1.0, 0.0])                             # :823
+
+
+def build(ref: bool = True) -> None:
+    """Compile liboracle.so (and _ref when the reference tree + flang exist)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    if ref and os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+_lib = None
+_ref = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build(ref=False)
+        _lib = C.CDLL(path)
+    return _lib
+
+
+def ref_lib():
+    """The flang-compiled reference routines, or None when not built."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(_HERE, "_ref", "libpfem_ref.so")
+        if not os.path.exists(path):
+            return None
+        _ref = C.CDLL(path)
+    return _ref
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+# ----------------------------------------------------------------------------
+# mesh files and structured generator
+# ----------------------------------------------------------------------------
+def _open(path):
+    return gzip.open(path, "rt") if str(path).endswith(".gz") else open(path, "rt")
+
+
+@dataclass
+class Mesh:
+    xyz: np.ndarray        # (ndim, nNode) float64
+    conn: np.ndarray       # (npElem, nElem) int32, 0-based OLD numbering
+    bc_node: np.ndarray    # (nDBC,) int32 0-based
+    bc_dof: np.ndarray     # (nDBC,) int32 0-based
+    bc_val: np.ndarray     # (nDBC,) float64
+
+    @property
+    def nNode(self):
+        return self.xyz.shape[1]
+
+    @property
+    def nElem(self):
+        return self.conn.shape[1]
+
+
+def read_mesh(prefix: str) -> Mesh:
+    """Read ``<prefix>-nodes.dat[.gz]``, ``-elems``, ``-DirichBC`` (1-based ASCII)."""
+    def find(kind):
+        for ext in (".dat.gz", ".dat"):
+            if os.path.exists(prefix + "-" + kind + ext):
+                return prefix + "-" + kind + ext
+        raise FileNotFoundError(prefix + "-" + kind)
+    with _open(find("nodes")) as f:
+        nodes = np.loadtxt(f, ndmin=2)
+    with _open(find("elems")) as f:
+        elems = np.loadtxt(f, dtype=np.int64, ndmin=2)
+    with _open(find("DirichBC")) as f:
+        bcs = np.loadtxt(f, ndmin=2)
+    xyz = np.ascontiguousarray(nodes[:, 1:].T)
+    conn = np.ascontiguousarray((elems[:, 1:] - 1).T.astype(np.int32))
+    return Mesh(xyz, conn, (bcs[:, 0] - 1).astype(np.int32), (bcs[:, 1] - 1).astype(np.int32),
+                bcs[:, 2].copy())
+
+
+def gen_box_tets(x0, x1, nEx, y0, y1, nEy, z0, z1, nEz, bc_mode=0, ndof=1) -> Mesh:
+    """genTetra.cpp restated (oracle/pfem_oracle.c: orc_gen_box_tets)."""
+    nNode = (nEx + 1) * (nEy + 1) * (nEz + 1)
+    nElem = 6 * nEx * nEy * nEz
+    xyz = np.empty((3, nNode))
+    conn = np.empty((4, nElem), dtype=np.int32)
+    n = C.c_int64(0)
+    args = (C.c_double(x0), C.c_double(x1), C.c_int(nEx), C.c_double(y0), C.c_double(y1), C.c_int(nEy),
+            C.c_double(z0), C.c_double(z1), C.c_int(nEz), C.c_int(bc_mode), C.c_int(ndof))
+    rc = lib().orc_gen_box_tets(*args, None, None, C.byref(n), None, None, None)
+    assert rc == 0
+    bn = np.empty(n.value, np.int32); bd = np.empty(n.value, np.int32); bv = np.empty(n.value)
+    rc = lib().orc_gen_box_tets(*args, _p(xyz), _p(conn), C.byref(n), _p(bn), _p(bd), _p(bv))
+    assert rc == 0
+    return Mesh(xyz, conn, bn, bd, bv)
+
+
+# ----------------------------------------------------------------------------
+# element routines
+# ----------------------------------------------------------------------------
+def eval_elems(kind, xyz, conn, elemData, timeData=TIMEDATA):
+    """Ke (nElem, nsize, nsize) [K[e].T is the Fortran Klocal -> we return K[e][i,j]=Klocal(i,j)],
+    Fe (nElem, nsize)."""
+    xyz = _f64(xyz); conn = _i32(conn)
+    nElem = conn.shape[1]; nNode = xyz.shape[1]
+    ns = NPELEM[kind] * NDOF[kind]
+    K = np.empty((nElem, ns, ns)); F = np.empty((nElem, ns))
+    ed = _f64(np.resize(elemData, 6) if len(elemData) < 6 else elemData)
+    rc = lib().orc_eval_elems(C.c_int(kind), C.c_int64(nElem), _p(conn), C.c_int64(nNode), _p(xyz),
+                              _p(ed), _p(_f64(timeData)), _p(K), _p(F))
+    if rc:
+        raise RuntimeError(f"oracle element evaluation failed rc={rc}")
+    return K.transpose(0, 2, 1).copy(), F          # column-major blocks -> [i,j]
+
+
+def ref_eval_elems(kind, xyz, conn, elemData, timeData=TIMEDATA):
+    """Same through the flang-compiled reference routines (oracle/_ref)."""
+    L = ref_lib()
+    if L is None:
+        raise RuntimeError("oracle/_ref/libpfem_ref.so not built")
+    xyz = _f64(xyz); conn = _i32(conn)
+    nElem = conn.shape[1]
+    ns = NPELEM[kind] * NDOF[kind]
+    g = [np.ascontiguousarray(xyz[d][conn].T) for d in range(NDIM[kind])]   # (nElem, npElem)
+    K = np.empty((nElem, ns, ns)); F = np.empty((nElem, ns))
+    ed = _f64(elemData); td = _f64(timeData)
+    if kind == POISSON_TET:
+        L.ref_poisson_tet_batch(C.c_int64(nElem), _p(g[0]), _p(g[1]), _p(g[2]), _p(ed), _p(td), _p(K), _p(F))
+    elif kind == ELAST_TET:
+        L.ref_elast_tet_batch(C.c_int64(nElem), _p(g[0]), _p(g[1]), _p(g[2]), _p(ed), _p(td), _p(K), _p(F))
+    elif kind == POISSON_TRIA:
+        L.ref_poisson_tria_batch(C.c_int64(nElem), _p(g[0]), _p(g[1]), _p(ed), _p(td), _p(K), _p(F))
+    else:
+        raise ValueError(kind)
+    return K.transpose(0, 2, 1).copy(), F
+
+
+# ----------------------------------------------------------------------------
+# bookkeeping
+# ----------------------------------------------------------------------------
+@dataclass
+class DofMap:
+    node_map_get_old: np.ndarray
+    node_map_get_new: np.ndarray
+    NodeDofArrayNew: np.ndarray     # (nNode, ndof) 0-based, -1 = Dirichlet
+    solnApplied: np.ndarray         # (nNode*ndof,) indexed by NEW node*ndof+d
+    node_start: np.ndarray
+    node_end: np.ndarray
+    row_start: np.ndarray
+    row_end: np.ndarray
+    size_global: int
+
+
+def dof_numbering(nNode, ndof, bc_node, bc_dof, bc_val, nParts=1, node_proc_id=None) -> DofMap:
+    old = np.empty(nNode, np.int32); new = np.empty(nNode, np.int32)
+    nda = np.empty((nNode, ndof), np.int32); sa = np.empty(nNode * ndof)
+    ns = np.zeros(nParts, np.int64); ne = np.zeros(nParts, np.int64)
+    rs = np.zeros(nParts, np.int64); re = np.zeros(nParts, np.int64)
+    sg = C.c_int64(0)
+    npid = None if node_proc_id is None else _i32(node_proc_id)
+    rc = lib().orc_dof_numbering(C.c_int64(nNode), C.c_int(ndof), C.c_int64(len(bc_node)), _p(_i32(bc_node)),
+                                 _p(_i32(bc_dof)), _p(_f64(bc_val)), C.c_int(nParts), _p(npid), _p(old), _p(new),
+                                 _p(nda), _p(sa), _p(ns), _p(ne), _p(rs), _p(re), C.byref(sg))
+    assert rc == 0, rc
+    return DofMap(old, new, nda, sa, ns, ne, rs, re, sg.value)
+
+
+def elem_dof_array(conn_new, NodeDofArrayNew):
+    conn_new = _i32(conn_new)
+    npE, nElem = conn_new.shape
+    ndof = NodeDofArrayNew.shape[1]
+    edof = np.empty((npE * ndof, nElem), np.int32)
+    lib().orc_elem_dof_array(C.c_int64(nElem), C.c_int(npE), C.c_int(ndof), _p(conn_new),
+                             _p(_i32(NodeDofArrayNew)), _p(edof))
+    return edof
+
+
+def assy_for_soln(NodeDofArrayNew):
+    nNode, ndof = NodeDofArrayNew.shape
+    n = int((NodeDofArrayNew >= 0).sum())
+    out = np.empty(n, np.int32)
+    lib().orc_assy_for_soln(C.c_int64(nNode), C.c_int(ndof), _p(_i32(NodeDofArrayNew)), _p(out))
+    return out
+
+
+# ----------------------------------------------------------------------------
+# pattern, assembly, solve
+# ----------------------------------------------------------------------------
+def csr_pattern(edof, N):
+    edof = _i32(edof)
+    nsize, nElem = edof.shape
+    rowptr = np.empty(N + 1, np.int64)
+    rc = lib().orc_csr_pattern(C.c_int64(nElem), C.c_int(nsize), _p(edof), C.c_int64(N), _p(rowptr), None)
+    assert rc == 0
+    cols = np.empty(rowptr[-1], np.int32)
+    rc = lib().orc_csr_pattern(C.c_int64(nElem), C.c_int(nsize), _p(edof), C.c_int64(N), _p(rowptr), _p(cols))
+    assert rc == 0
+    return rowptr, cols
+
+
+def assemble(kind, xyz_new, conn_new, edof, solnApplied, elemData, N, rowptr, cols,
+             timeData=TIMEDATA, elem_proc_id=None, part=0):
+    xyz_new = _f64(xyz_new); conn_new = _i32(conn_new); edof = _i32(edof)
+    vals = np.zeros(len(cols)); rhs = np.zeros(N)
+    ed = _f64(np.resize(elemData, 6) if len(elemData) < 6 else elemData)
+    epid = None if elem_proc_id is None else _i32(elem_proc_id)
+    rc = lib().orc_assemble(C.c_int(kind), C.c_int64(conn_new.shape[1]), _p(conn_new), C.c_int64(xyz_new.shape[1]),
+                            _p(xyz_new), _p(edof), _p(_f64(solnApplied)), _p(ed), _p(_f64(timeData)),
+                            _p(epid), C.c_int(part), C.c_int64(N), _p(rowptr), _p(cols), _p(vals), _p(rhs))
+    if rc:
+        raise RuntimeError(f"oracle assembly failed rc={rc}")
+    return vals, rhs
+
+
+def spmv(rowptr, cols, vals, x):
+    N = len(rowptr) - 1
+    y = np.empty(N)
+    lib().orc_spmv(C.c_int64(N), _p(rowptr), _p(cols), _p(vals), _p(_f64(x)), _p(y))
+    return y
+
+
+def pcg_jacobi(rowptr, cols, vals, b, rtol=1e-5, abstol=1e-50, dtol=1e5, maxits=10000, hist_len=0):
+    N = len(rowptr) - 1
+    x = np.empty(N)
+    its = C.c_int(0); reason = C.c_int(0); rn = C.c_double(0)
+    hist = np.zeros(max(hist_len, 1))
+    rc = lib().orc_pcg_jacobi(C.c_int64(N), _p(rowptr), _p(cols), _p(vals), _p(_f64(b)), _p(x),
+                              C.c_double(rtol), C.c_double(abstol), C.c_double(dtol), C.c_int(maxits),
+                              C.byref(its), C.byref(reason), C.byref(rn), _p(hist), C.c_int(hist_len))
+    assert rc == 0
+    return x, its.value, reason.value, rn.value, hist[:min(hist_len, its.value + 1)]
+
+
+# ----------------------------------------------------------------------------
+# the whole path, as the driver runs it on one or several ranks
+# ----------------------------------------------------------------------------
+@dataclass
+class Problem:
+    kind: int
+    mesh: Mesh
+    dm: DofMap
+    xyz_new: np.ndarray
+    conn_new: np.ndarray
+    edof: np.ndarray
+    rowptr: np.ndarray
+    cols: np.ndarray
+    vals: np.ndarray
+    rhs: np.ndarray
+    elemData: np.ndarray
+
+
+def setup_problem(kind, mesh: Mesh, elemData=None, nParts=1, node_proc_id=None) -> Problem:
+    """tetrapoissonparallelimpl1.F:316-884 on one process (all elements assembled)."""
+    if elemData is None:
+        elemData = ELAST_ELEMDATA if kind == ELAST_TET else POISSON_ELEMDATA
+    ndof = NDOF[kind]
+    dm = dof_numbering(mesh.nNode, ndof, mesh.bc_node, mesh.bc_dof, mesh.bc_val, nParts, node_proc_id)
+    conn_new = dm.node_map_get_new[mesh.conn].astype(np.int32)
+    xyz_new = np.ascontiguousarray(mesh.xyz[:, dm.node_map_get_old])
+    edof = elem_dof_array(conn_new, dm.NodeDofArrayNew)
+    rowptr, cols = csr_pattern(edof, dm.size_global)
+    vals, rhs = assemble(kind, xyz_new, conn_new, edof, dm.solnApplied, elemData, dm.size_global, rowptr, cols)
+    return Problem(kind, mesh, dm, xyz_new, conn_new, edof, rowptr, cols, vals, rhs, np.asarray(elemData))
+
+
+def full_solution(prob: Problem, u_free):
+    """solnVTK of the driver (:914-941): values by OLD node id, (nNode, ndof)."""
+    ndof = NDOF[prob.kind]
+    dm = prob.dm
+    full = dm.solnApplied.reshape(-1, ndof).copy()           # NEW order, Dirichlet values
+    assy = assy_for_soln(dm.NodeDofArrayNew)
+    full.reshape(-1)[assy] = u_free
+    out = np.empty_like(full)
+    out[dm.node_map_get_old] = full
+    return out
