@@ -1,0 +1,256 @@
+/*
+ * pfem_amd.h -- C ABI of the MI355X-native implicit-FEM hot path that replaces, for
+ * PFEMFort's drivers, the per-element stiffness routines, the PETSc Mat/Vec assembly
+ * calls and Module_SolverPetsc's KSP solve.
+ *
+ * Every entry point is extern "C", takes plain pointers and sizes, returns an int
+ * error code (PFEM_OK == 0) and never throws, exits or STOPs: the Fortran wrappers
+ *  print and STOP on a nonzero code exactly where the reference
+ * STOPs / CHKERRQs.  The caller owns all host arrays; the library owns all device
+ * memory behind the opaque pfem_solver handle.  A handle is not thread-safe; use
+ * one handle per process (= per GPU), as the reference uses one PetscSolver per rank.
+ *
+ * Citations are file:line of the reference (chennachaos/PFEMFort) interface that
+ * each entry point replaces.
+ *
+ * Array conventions are those of the Fortran drivers (column-major == SoA):
+ *   coords(nNode,ndim)         -> xyz  [d*nNode + n]
+ *   elemNodeConn(nElem,npElem) -> conn [i*nElem + e]   0-based node ids
+ *   ElemDofArray(nElem,nsize)  -> edof [i*nElem + e]   0-based GLOBAL dof ids, -1 = Dirichlet
+ *   Klocal(nsize,nsize)        -> K[i + nsize*j]       column-major
+ */
+#ifndef PFEM_AMD_H
+#define PFEM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFEM_VERSION 100
+
+/* ---- error codes -------------------------------------------------------- */
+#define PFEM_OK 0
+#define PFEM_ERR_ARG 1        /* bad argument                                        */
+#define PFEM_ERR_STATE 2      /* call out of order (currentStatus, solverpetsc.F:415,441) */
+#define PFEM_ERR_NEG_JAC 3    /* STOP " Negative Jacobian ..." elementutilitiespoisson.F:157 */
+#define PFEM_ERR_HIP 4        /* a HIP runtime call failed (pfem_last_error_string)  */
+#define PFEM_ERR_NOGPU 5      /* no gfx950 device visible: the product has no CPU path */
+#define PFEM_ERR_NOMEM 6
+#define PFEM_ERR_DIVERGED 7   /* KSPConvergedReason < 0 (solverpetsc.F:481-483)      */
+#define PFEM_ERR_PATTERN 8    /* ADD_VALUES into a slot outside the inserted pattern  */
+#define PFEM_ERR_COMM 9       /* the all-reduce hook reported an error                */
+
+/* ---- element kinds ------------------------------------------------------ */
+#define PFEM_POISSON_TRIA 1        /* StiffnessResidualPoissonLinearTria  elementutilitiespoisson.F:23   */
+#define PFEM_POISSON_TET 2         /* StiffnessResidualPoissonLinearTetra elementutilitiespoisson.F:107  */
+#define PFEM_ELAST_TET 3           /* StiffnessResidualElasticityLinearTetra elementutilitieselasticity3D.F:248 */
+#define PFEM_POISSON_TRIA_INLINE 4 /* inline area*B*B^T of triapoissonserialimpl1.F:573-594             */
+
+/* ---- solver status (solverpetsc.F:64-68) -------------------------------- */
+#define PFEM_SOLVER_EMPTY 1
+#define PFEM_PATTERN_OK 2
+#define PFEM_INIT_OK 3
+#define PFEM_ASSEMBLY_OK 4
+#define PFEM_FACTORISE_OK 5
+
+/* ---- InsertMode (PETSc INSERT_VALUES / ADD_VALUES) ---------------------- */
+#define PFEM_INSERT_VALUES 1
+#define PFEM_ADD_VALUES 2
+
+typedef struct pfem_solver pfem_solver;
+
+/* ========================================================================= */
+/* 0. library / device                                                        */
+/* ========================================================================= */
+int pfem_version(void);
+const char *pfem_strerror(int code);
+const char *pfem_last_error_string(void);
+/* number of visible HIP devices (0 without a GPU; never an error) */
+int pfem_device_count(int *n);
+int pfem_device_info(int device, char *name, int name_len, int *compute_units,
+                     int64_t *hbm_bytes, int *clock_khz);
+
+/* ========================================================================= */
+/* 1. per-element routines, host, one element per call.                       */
+/*    This is the call surface of MODULE ElementUtilitiesPoisson /            */
+/*    ElementUtilitiesElasticity3D: the unchanged drivers call them once per  */
+/*    element and read Klocal back on the host for the Dirichlet lifting      */
+/*    (tetrapoissonparallelimpl1.F:841-870), so by construction they are host */
+/*    functions.  They share one source (csrc/pfem_elem.hpp) with the device  */
+/*    kernels used by pfem_assemble().                                        */
+/* ========================================================================= */
+/* elementutilitiespoisson.F:23-101 */
+int pfem_poisson_tria_ke(const double xNode[3], const double yNode[3],
+                         const double *elemData /*kx,ky*/, const double *timeData /*(2)=af*/,
+                         const double valC[3], double K[9], double F[3]);
+/* elementutilitiespoisson.F:107-193 */
+int pfem_poisson_tet_ke(const double xNode[4], const double yNode[4], const double zNode[4],
+                        const double *elemData /*kx,ky,kz*/, const double *timeData,
+                        const double valC[4], double K[16], double F[4]);
+/* elementutilitieselasticity3D.F:248-393 (intended semantics, DESIGN.md "deviations") */
+int pfem_elast_tet_ke(const double xNode[4], const double yNode[4], const double zNode[4],
+                      const double *elemData /*E,nu,thick,bx,by,bz*/, const double *timeData,
+                      const double valC[12], double K[144], double F[12]);
+
+/* ========================================================================= */
+/* 2. driver bookkeeping, host, integer-exact (tetrapoissonparallelimpl1.F)   */
+/* ========================================================================= */
+/* genTetra.cpp:152-216,247-323,348-525 -- structured box, 6 tets per hex.
+ * kz0/kz1 select the hex layers [kz0,kz1) to emit elements for (0,nEz = all);
+ * nodes are always the full grid.  bc_mode 0: u=x^2+y^2+z^2 on all six faces
+ * (float coordinates, %.8f text round trip); bc_mode 1: clamp the plane y=y0
+ * (all ndof dofs, value 0).  Pass NULL output arrays to query *nDBC only.      */
+int pfem_gen_box_tets(double x0, double x1, int nEx, double y0, double y1, int nEy,
+                      double z0, double z1, int nEz, int kz0, int kz1, int bc_mode,
+                      int ndof, double *xyz, int32_t *conn, int64_t *nDBC,
+                      int32_t *bc_node, int32_t *bc_dof, double *bc_val);
+
+/* :316-367 + :393-679.  0-based everywhere.  nParts==1 -> identity maps.
+ * node_start/node_end/row_start/row_end have nParts entries, ends exclusive.   */
+int pfem_dof_numbering(int64_t nNode, int ndof, int64_t nDBC, const int32_t *dbc_node,
+                       const int32_t *dbc_dof, const double *dbc_val, int nParts,
+                       const int32_t *node_proc_id, int32_t *node_map_get_old,
+                       int32_t *node_map_get_new, int32_t *NodeDofArrayNew,
+                       double *solnApplied, int64_t *node_start, int64_t *node_end,
+                       int64_t *row_start, int64_t *row_end, int64_t *size_global);
+/* :698-713 */
+int pfem_elem_dof_array(int64_t nElem, int npElem, int ndof, const int32_t *conn_new,
+                        const int32_t *NodeDofArrayNew, int32_t *edof);
+/* :722-734 */
+int pfem_assy_for_soln(int64_t nNode, int ndof, const int32_t *NodeDofArrayNew,
+                       int32_t *assyForSoln);
+/* Stand-in for METIS_PartMeshNodal (:464; METIS is a third-party dependency that is
+ * not part of the reference tree): deterministic partition of a pfem_gen_box_tets
+ * mesh into nParts slabs of hex layers along z; a node belongs to the lowest part
+ * among the elements that touch it.  Any other partitioner's
+ * (elem_proc_id,node_proc_id) can be fed to pfem_dof_numbering instead.        */
+int pfem_partition_box_slabs(int nEx, int nEy, int nEz, int nParts,
+                             int32_t *elem_proc_id, int32_t *node_proc_id);
+
+/* ========================================================================= */
+/* 3. the solver object == TYPE PetscSolver (solverpetsc.F:72-105)            */
+/* ========================================================================= */
+/* initialise(size_local,size_global,diag_nnz,offdiag_nnz) solverpetsc.F:116-214.
+ * row_start = first global row owned by this rank (PETSc derives it from the
+ * size_local of the lower ranks; pass 0 on one rank).  diag_nnz/offdiag_nnz are
+ * accepted for call compatibility and ignored: the pattern is computed exactly.
+ * device < 0 -> current HIP device.  Fails with PFEM_ERR_NOGPU without a GPU.   */
+int pfem_solver_create(pfem_solver **s, int64_t size_local, int64_t size_global,
+                       int64_t row_start, const int *diag_nnz, const int *offdiag_nnz,
+                       int device);
+/* free  solverpetsc.F:254-278 */
+int pfem_solver_destroy(pfem_solver *s);
+/* launch everything on this hipStream_t (e.g. torch's current stream); NULL -> own stream */
+int pfem_solver_set_stream(pfem_solver *s, void *hip_stream);
+/* KSPSetFromOptions / petsc_options.dat stand-in (tetrapoissonparallelimpl1.F:168,
+ * solverpetsc.F:198): PETSc defaults are rtol 1e-5, abstol 1e-50, dtol 1e5, maxits 1e4 */
+int pfem_solver_set_tolerances(pfem_solver *s, double rtol, double abstol, double dtol, int maxits);
+int pfem_solver_status(pfem_solver *s, int *currentStatus);
+/* setZero  solverpetsc.F:222-246: finalises the inserted pattern, zeroes values + rhs */
+int pfem_solver_set_zero(pfem_solver *s);
+/* printInfo solverpetsc.F:286-320 (writes nRow, nnz, storage to stdout) */
+int pfem_solver_print_info(pfem_solver *s);
+
+/* MatSetValues(mtx,m,idxm,n,idxn,v,mode) as called at tetrapoissonparallelimpl1.F:798,851:
+ * global 0-based indices, negative rows/cols ignored, v read ROW-major (PETSc).
+ * INSERT before set_zero records the pattern; ADD after it accumulates on the host
+ * staging copy, uploaded by solve (compat path for the unchanged drivers).       */
+int pfem_mat_set_values(pfem_solver *s, int m, const int *idxm, int n, const int *idxn,
+                        const double *v, int mode);
+/* VecSetValues(rhsVec,n,idx,v,mode) :880; negative indices ignored (solverpetsc.F:142) */
+int pfem_vec_set_values(pfem_solver *s, int n, const int *idx, const double *v, int mode);
+/* assembleMatrix / assembleVector / assembleMatrixAndVector solverpetsc.F:328-401 */
+int pfem_solver_assemble_matrix_and_vector(pfem_solver *s, int n, const int *rows,
+                                           const int *cols, const double *K /*col-major*/,
+                                           const double *F);
+
+/* factorise solverpetsc.F:409-423 (status check only, as in the reference) */
+int pfem_solver_factorise(pfem_solver *s);
+/* solve solverpetsc.F:431-490: final assembly, zero initial guess, Jacobi-PCG on the GPU.
+ * reason follows KSPConvergedReason (2 rtol, 3 atol, -3 its, -4 dtol, -7/-8 indefinite).
+ * Returns PFEM_OK also when reason < 0 ("Divergence." is printed by the caller).   */
+int pfem_solver_solve(pfem_solver *s, int *its, int *reason, double *rnorm);
+/* factoriseAndSolve solverpetsc.F:498-509 */
+int pfem_solver_factorise_and_solve(pfem_solver *s, int *its, int *reason, double *rnorm);
+/* VecGetArray on solnVec: the size_local owned entries, device -> host */
+int pfem_solver_get_solution(pfem_solver *s, double *x_owned);
+/* residual-norm history ||M^-1 r_k||, k = 0..its (up to n entries) */
+int pfem_solver_get_history(pfem_solver *s, double *hist, int n, int *n_written);
+
+/* ========================================================================= */
+/* 4. batched device path: the element loop of the drivers as ONE call        */
+/*    (tetrapoissonparallelimpl1.F:786-884, tetraelasticityparallelimpl1.F:   */
+/*    906-965, triapoissonserialimpl1.F:559-650)                              */
+/* ========================================================================= */
+/* Upload this rank's elements (those with elem_proc_id == rank): connectivity in the
+ * NEW numbering, coordinates of all nodes in NEW order, ElemDofArray rows (GLOBAL
+ * dof ids; ids outside [row_start,row_start+size_local) become ghost columns/rows
+ * of the sub-assembled local matrix), solnApplied by NEW node*ndof+d.            */
+int pfem_mesh_upload(pfem_solver *s, int kind, int64_t nElem, const int32_t *conn,
+                     int64_t nNode, const double *xyz, const int32_t *edof,
+                     const double *solnApplied);
+/* Pattern-initialisation loop :786-802 on the device (symbolic phase). */
+int pfem_pattern_build(pfem_solver *s);
+/* setZero + element loop :817-884 on the device: Ke/Fe, Dirichlet lifting,
+ * atomic scatter into the device matrix and rhs.                                */
+int pfem_assemble(pfem_solver *s, const double *elemData, const double *timeData);
+/* Per-element Ke/Fe of the uploaded mesh as computed by the DEVICE kernel (parity
+ * inspection): K_out[e*nsize*nsize + i + nsize*j], F_out[e*nsize + i].           */
+int pfem_eval_elems(pfem_solver *s, const double *elemData, const double *timeData,
+                    double *K_out, double *F_out);
+
+/* ---- inspection / export (device -> host) -------------------------------- */
+/* local matrix dimensions: n_local = owned + ghost rows, nnz of the pattern      */
+int pfem_matrix_info(pfem_solver *s, int64_t *n_owned, int64_t *n_local, int64_t *nnz,
+                     int64_t *stored_entries);
+/* global dof id of every local row (owned first, then ghosts ascending) */
+int pfem_get_local_to_global(pfem_solver *s, int64_t *gid);
+/* CSR of the LOCAL (sub-assembled) matrix, local column ids, columns ascending */
+int pfem_get_csr(pfem_solver *s, int64_t *rowptr, int32_t *cols, double *vals);
+int pfem_get_rhs(pfem_solver *s, double *rhs_local);
+/* y = A_local x (both length n_local, host arrays): one launch of the CG SpMV kernel */
+int pfem_spmv(pfem_solver *s, const double *x, double *y);
+/* time `reps` back-to-back SpMV launches with HIP events on the solver's stream */
+int pfem_bench_spmv(pfem_solver *s, int reps, double *ms_per_launch);
+
+/* Timings of the last calls, measured with HIP events on the solver's stream [ms]. */
+typedef struct pfem_timings {
+    double pattern_ms;      /* pfem_pattern_build                                  */
+    double assemble_ms;     /* pfem_assemble (reference timer :826 -> :893)        */
+    double solve_ms;        /* pfem_solver_solve (reference timer :898 -> :902)    */
+    double spmv_ms_total;   /* sum of the SpMV launches inside the last solve      */
+    int64_t spmv_launches;  /* number of SpMV launches inside the last solve       */
+    double upload_ms;       /* pfem_mesh_upload (PCIe, host wall clock)            */
+} pfem_timings;
+int pfem_get_timings(pfem_solver *s, pfem_timings *t);
+/* record an event pair around every SpMV launch of the next solves (bench.py) */
+int pfem_solver_profile_spmv(pfem_solver *s, int enable);
+
+/* ========================================================================= */
+/* 5. multi-GPU: one process per GPU, sub-assembled interface rows            */
+/*    (replaces MatAssembly stash + VecScatter + VecDot MPI_Allreduce inside   */
+/*    KSPSolve, solverpetsc.F:447-476)                                        */
+/* ========================================================================= */
+/* In-place SUM all-reduce of `count` doubles at DEVICE pointer `buf`, enqueued on
+ * `hip_stream`; returns 0 on success.  The Python host binds torch.distributed
+ * (backend "nccl" == RCCL over xGMI); a Fortran/MPI host can bind MPI_Allreduce.  */
+typedef int (*pfem_allreduce_fn)(void *ctx, void *buf, int64_t count, void *hip_stream);
+int pfem_solver_set_comm(pfem_solver *s, int rank, int nranks, pfem_allreduce_fn fn, void *ctx);
+/* Interface plan: the n_shared GLOBAL dof ids (ascending) this rank touches that are
+ * also touched by another rank, and the slot of each in the packed global interface
+ * vector of n_iface_global entries (identical numbering on every rank).           */
+int pfem_solver_set_interface(pfem_solver *s, int64_t n_shared, const int64_t *shared_gid,
+                              const int32_t *shared_slot, int64_t n_iface_global);
+/* Exchange buffer to all-reduce in (device pointer, >= n_iface_global+4 doubles), e.g.
+ * the storage of a torch tensor so the hook can hand the tensor to torch.distributed. */
+int pfem_solver_set_exchange_buffer(pfem_solver *s, void *device_buf, int64_t capacity);
+/* ghost dof ids (ascending) of the uploaded mesh: two-call (ghost_gid NULL -> count) */
+int pfem_get_ghosts(pfem_solver *s, int64_t *n_ghost, int64_t *ghost_gid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFEM_AMD_H */

@@ -1,0 +1,139 @@
+"""ctypes binding of libpfem_amd.so (include/pfem_amd.h).
+
+The library is the product: there is no Python/CPU fallback for any device entry point.
+Loading fails loudly if the shared object has not been built (``python -c "import
+__graft_entry__ as g; g.build()"`` or ``make -C pfemfort_amd/csrc``), and every solver
+call raises :class:`PfemError` carrying the C error code and the library's message.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpfem_amd.so")
+
+# error codes (include/pfem_amd.h)
+OK, ERR_ARG, ERR_STATE, ERR_NEG_JAC, ERR_HIP, ERR_NOGPU, ERR_NOMEM, ERR_DIVERGED, ERR_PATTERN, ERR_COMM = range(10)
+# element kinds
+POISSON_TRIA, POISSON_TET, ELAST_TET, POISSON_TRIA_INLINE = 1, 2, 3, 4
+# solver status (solverpetsc.F:64-68)
+SOLVER_EMPTY, PATTERN_OK, INIT_OK, ASSEMBLY_OK, FACTORISE_OK = 1, 2, 3, 4, 5
+INSERT_VALUES, ADD_VALUES = 1, 2
+
+NPELEM = {POISSON_TRIA: 3, POISSON_TET: 4, ELAST_TET: 4, POISSON_TRIA_INLINE: 3}
+NDOF = {POISSON_TRIA: 1, POISSON_TET: 1, ELAST_TET: 3, POISSON_TRIA_INLINE: 1}
+NDIM = {POISSON_TRIA: 2, POISSON_TET: 3, ELAST_TET: 3, POISSON_TRIA_INLINE: 2}
+
+
+class PfemError(RuntimeError):
+    def __init__(self, code: int, where: str, detail: str = ""):
+        self.code = code
+        msg = f"{where}: error {code} ({_strerror(code)})"
+        if detail:
+            msg += f" -- {detail}"
+        super().__init__(msg)
+
+
+class Timings(C.Structure):
+    _fields_ = [("pattern_ms", C.c_double), ("assemble_ms", C.c_double), ("solve_ms", C.c_double),
+                ("spmv_ms_total", C.c_double), ("spmv_launches", C.c_int64), ("upload_ms", C.c_double)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+_P = C.c_void_p
+_I, _L, _D = C.c_int, C.c_int64, C.c_double
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors the header 1:1
+SIGNATURES = {
+    "pfem_version": [],
+    "pfem_strerror": [_I],
+    "pfem_last_error_string": [],
+    "pfem_device_count": [_P],
+    "pfem_device_info": [_I, _P, _I, _P, _P, _P],
+    "pfem_poisson_tria_ke": [_P] * 7,
+    "pfem_poisson_tet_ke": [_P] * 8,
+    "pfem_elast_tet_ke": [_P] * 8,
+    "pfem_gen_box_tets": [_D, _D, _I, _D, _D, _I, _D, _D, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "pfem_dof_numbering": [_L, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "pfem_elem_dof_array": [_L, _I, _I, _P, _P, _P],
+    "pfem_assy_for_soln": [_L, _I, _P, _P],
+    "pfem_partition_box_slabs": [_I, _I, _I, _I, _P, _P],
+    "pfem_solver_create": [_P, _L, _L, _L, _P, _P, _I],
+    "pfem_solver_destroy": [_P],
+    "pfem_solver_set_stream": [_P, _P],
+    "pfem_solver_set_tolerances": [_P, _D, _D, _D, _I],
+    "pfem_solver_status": [_P, _P],
+    "pfem_solver_set_zero": [_P],
+    "pfem_solver_print_info": [_P],
+    "pfem_mat_set_values": [_P, _I, _P, _I, _P, _P, _I],
+    "pfem_vec_set_values": [_P, _I, _P, _P, _I],
+    "pfem_solver_assemble_matrix_and_vector": [_P, _I, _P, _P, _P, _P],
+    "pfem_solver_factorise": [_P],
+    "pfem_solver_solve": [_P, _P, _P, _P],
+    "pfem_solver_factorise_and_solve": [_P, _P, _P, _P],
+    "pfem_solver_get_solution": [_P, _P],
+    "pfem_solver_get_history": [_P, _P, _I, _P],
+    "pfem_mesh_upload": [_P, _I, _L, _P, _L, _P, _P, _P],
+    "pfem_pattern_build": [_P],
+    "pfem_assemble": [_P, _P, _P],
+    "pfem_eval_elems": [_P, _P, _P, _P, _P],
+    "pfem_matrix_info": [_P, _P, _P, _P, _P],
+    "pfem_get_local_to_global": [_P, _P],
+    "pfem_get_csr": [_P, _P, _P, _P],
+    "pfem_get_rhs": [_P, _P],
+    "pfem_spmv": [_P, _P, _P],
+    "pfem_bench_spmv": [_P, _I, _P],
+    "pfem_get_timings": [_P, _P],
+    "pfem_solver_profile_spmv": [_P, _I],
+    "pfem_solver_set_comm": [_P, _I, _I, ALLREDUCE_FN, _P],
+    "pfem_solver_set_interface": [_P, _L, _P, _P, _L],
+    "pfem_solver_set_exchange_buffer": [_P, _P, _L],
+    "pfem_get_ghosts": [_P, _P, _P],
+}
+_RESTYPES = {"pfem_strerror": C.c_char_p, "pfem_last_error_string": C.c_char_p}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libpfem_amd.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'). pfemfort_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is missing
+            fn.argtypes = args
+            fn.restype = _RESTYPES.get(name, C.c_int)
+        _lib = L
+    return _lib
+
+
+def _strerror(code: int) -> str:
+    try:
+        return lib().pfem_strerror(code).decode()
+    except Exception:  # pragma: no cover
+        return "?"
+
+
+def check(rc: int, where: str) -> None:
+    if rc != OK:
+        raise PfemError(rc, where, lib().pfem_last_error_string().decode())
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(lib().pfem_device_count(C.byref(n)), "pfem_device_count")
+    return n.value
+
+
+def device_info(device: int = 0) -> dict:
+    name = C.create_string_buffer(256)
+    cu = C.c_int(0); mem = C.c_int64(0); clk = C.c_int(0)
+    check(lib().pfem_device_info(device, name, 256, C.byref(cu), C.byref(mem), C.byref(clk)), "pfem_device_info")
+    return {"name": name.value.decode(), "compute_units": cu.value, "hbm_bytes": mem.value, "clock_khz": clk.value}

@@ -1,0 +1,1140 @@
+// pfem_device.hip -- the solver object behind the C ABI: device memory, symbolic and
+// numeric assembly launches, the Jacobi-PCG driver loop and the interface exchange.
+//
+// Replaces, for the PFEMFort drivers, PETSc's Mat/Vec/KSP objects inside
+// Module_SolverPetsc (solverpetsc.F) and the element loops of the drivers
+// (tetrapoissonparallelimpl1.F:786-884, tetraelasticityparallelimpl1.F:906-965).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <chrono>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pfem_internal.hpp"
+#include "pfem_kernels.hpp"
+
+using namespace pfem;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+namespace {
+thread_local std::string g_last_error;
+}
+void pfem::set_last_error(const std::string &msg) { g_last_error = msg; }
+
+#define PFEM_HIP(call)                                                                       \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            set_last_error(std::string(#call) + ": " + hipGetErrorString(e_) + " (" +        \
+                           __FILE__ + ":" + std::to_string(__LINE__) + ")");                 \
+            return PFEM_ERR_HIP;                                                             \
+        }                                                                                    \
+    } while (0)
+
+#define PFEM_TRY(call)                 \
+    do {                               \
+        int rc_ = (call);              \
+        if (rc_ != PFEM_OK) return rc_; \
+    } while (0)
+
+extern "C" int pfem_version(void) { return PFEM_VERSION; }
+
+extern "C" const char *pfem_strerror(int code)
+{
+    switch (code) {
+    case PFEM_OK: return "ok";
+    case PFEM_ERR_ARG: return "invalid argument";
+    case PFEM_ERR_STATE: return "call out of order for the solver status";
+    case PFEM_ERR_NEG_JAC: return "Negative Jacobian for an element";
+    case PFEM_ERR_HIP: return "HIP runtime error";
+    case PFEM_ERR_NOGPU: return "no HIP device available (this library has no CPU path)";
+    case PFEM_ERR_NOMEM: return "out of memory";
+    case PFEM_ERR_DIVERGED: return "Divergence.";
+    case PFEM_ERR_PATTERN: return "ADD_VALUES outside the inserted nonzero pattern";
+    case PFEM_ERR_COMM: return "all-reduce hook failed";
+    }
+    return "unknown error";
+}
+
+extern "C" const char *pfem_last_error_string(void) { return g_last_error.c_str(); }
+
+extern "C" int pfem_device_count(int *n)
+{
+    if (!n) return PFEM_ERR_ARG;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) { (void)hipGetLastError(); c = 0; }
+    *n = c;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_device_info(int device, char *name, int name_len, int *compute_units,
+                                int64_t *hbm_bytes, int *clock_khz)
+{
+    int c = 0;
+    pfem_device_count(&c);
+    if (c == 0) return PFEM_ERR_NOGPU;
+    if (device < 0 || device >= c) return PFEM_ERR_ARG;
+    hipDeviceProp_t prop;
+    PFEM_HIP(hipGetDeviceProperties(&prop, device));
+    if (name && name_len > 0) {
+        std::snprintf(name, static_cast<size_t>(name_len), "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = static_cast<int64_t>(prop.totalGlobalMem);
+    if (clock_khz) *clock_khz = prop.clockRate;
+    return PFEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// device buffers
+// ---------------------------------------------------------------------------
+namespace {
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    int alloc(size_t count)
+    {
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_last_error("hipMalloc of " + std::to_string(count * sizeof(T)) + " bytes failed: " + hipGetErrorString(e));
+            p = nullptr;
+            return PFEM_ERR_NOMEM;
+        }
+        n = count;
+        return PFEM_OK;
+    }
+};
+
+inline unsigned grid_for(int64_t n) { return static_cast<unsigned>(std::max<int64_t>(1, (n + kBlock - 1) / kBlock)); }
+inline unsigned vec_grid(int64_t n) { return static_cast<unsigned>(std::min<int64_t>(kMaxGrid, std::max<int64_t>(1, (n + kBlock - 1) / kBlock))); }
+inline unsigned spmv_grid(int64_t n_slices)
+{
+    int64_t groups = (n_slices + 3) / 4;
+    int64_t g = std::min<int64_t>(kMaxGrid, std::max<int64_t>(1, groups));
+    if (g >= kXcds) g -= g % kXcds;
+    return static_cast<unsigned>(g);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// the solver object
+// ---------------------------------------------------------------------------
+struct pfem_solver {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int status = PFEM_SOLVER_EMPTY;
+
+    int64_t n_owned = 0, size_global = 0, row_start = 0;
+    double rtol = 1e-5, abstol = 1e-50, dtol = 1e5;
+    int maxits = 10000;
+
+    // mesh
+    MeshDev mesh{};
+    bool have_mesh = false;
+    DevBuf<int32_t> d_conn, d_edof;
+    DevBuf<double> d_xyz, d_soln;
+
+    // local numbering
+    int64_t n_loc = 0, n_ghost = 0;
+    std::vector<int64_t> ghost_gid;
+
+    // matrix
+    bool have_pattern = false;
+    int64_t nnz = 0, n_slices = 0, stored = 0;
+    DevBuf<int64_t> d_rowptr, d_slice_off;
+    DevBuf<int32_t> d_rowlen, d_cols;
+    DevBuf<double> d_vals;
+
+    // vectors
+    DevBuf<double> d_rhs, d_x, d_r, d_p, d_w, d_dinv;
+    bool rhs_summed = false;
+
+    // CG state
+    DevBuf<double> d_part;     // 3 * kMaxGrid partial sums
+    DevBuf<CgCtl> d_ctl;
+    DevBuf<double> d_hist;
+    DevBuf<int> d_err;
+    CgCtl *h_ctl = nullptr;    // pinned
+    int *h_err = nullptr;      // pinned
+    int last_its = 0, last_reason = 0;
+    double last_rnorm = 0.0;
+    int hist_cap = 0;
+
+    // compat (host staging of MatSetValues / VecSetValues)
+    std::vector<uint64_t> h_keys;
+    std::vector<int64_t> h_rowptr;
+    std::vector<int32_t> h_cols;
+    std::vector<double> h_vals, h_rhs;
+    bool host_values_dirty = false;
+
+    // comm
+    int rank = 0, nranks = 1;
+    pfem_allreduce_fn allreduce = nullptr;
+    void *comm_ctx = nullptr;
+    int64_t n_shared = 0, n_iface = 0;
+    DevBuf<int32_t> d_shared_lidx, d_shared_slot;
+    double *xbuf = nullptr;       // exchange buffer (device), capacity >= n_iface + 4
+    int64_t xbuf_cap = 0;
+    DevBuf<double> d_xbuf_own;
+
+    // timing
+    pfem_timings tm{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool profile_spmv = false;
+    std::vector<hipEvent_t> spmv_events;
+
+    SellDev sell() const
+    {
+        SellDev A;
+        A.n_rows = n_loc;
+        A.n_slices = n_slices;
+        A.slice_off = d_slice_off.p;
+        A.rowlen = d_rowlen.p;
+        A.cols = d_cols.p;
+        A.vals = d_vals.p;
+        return A;
+    }
+};
+
+namespace {
+
+int use_device(pfem_solver *s)
+{
+    PFEM_HIP(hipSetDevice(s->device));
+    return PFEM_OK;
+}
+
+int check_kernel(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_error(std::string(what) + ": " + hipGetErrorString(e));
+        return PFEM_ERR_HIP;
+    }
+    return PFEM_OK;
+}
+
+// elapsed ms between ev0 and ev1 after a stream sync
+int elapsed(pfem_solver *s, double *ms)
+{
+    PFEM_HIP(hipEventSynchronize(s->ev1));
+    float f = 0.f;
+    PFEM_HIP(hipEventElapsedTime(&f, s->ev0, s->ev1));
+    *ms = f;
+    return PFEM_OK;
+}
+
+int fetch_err(pfem_solver *s, int *err)
+{
+    PFEM_HIP(hipMemcpyAsync(s->h_err, s->d_err.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    *err = *s->h_err;
+    return PFEM_OK;
+}
+
+}  // namespace
+
+extern "C" int pfem_solver_create(pfem_solver **out, int64_t size_local, int64_t size_global,
+                                  int64_t row_start, const int *diag_nnz, const int *offdiag_nnz,
+                                  int device)
+{
+    (void)diag_nnz; (void)offdiag_nnz;   // pattern is computed exactly (header comment)
+    if (!out || size_local < 0 || size_global < size_local || row_start < 0 ||
+        row_start + size_local > size_global || size_global > INT32_MAX)
+        return PFEM_ERR_ARG;
+    int count = 0;
+    pfem_device_count(&count);
+    if (count == 0) {
+        set_last_error("pfem_solver_create: no HIP device visible; libpfem_amd has no CPU fallback");
+        return PFEM_ERR_NOGPU;
+    }
+    if (device < 0) PFEM_HIP(hipGetDevice(&device));
+    if (device >= count) return PFEM_ERR_ARG;
+    pfem_solver *s = new (std::nothrow) pfem_solver();
+    if (!s) return PFEM_ERR_NOMEM;
+    s->device = device;
+    s->n_owned = size_local;
+    s->size_global = size_global;
+    s->row_start = row_start;
+    s->n_loc = size_local;
+    int rc = PFEM_OK;
+    auto fail = [&](int code) { pfem_solver_destroy(s); return code; };
+    if (hipSetDevice(device) != hipSuccess) return fail(PFEM_ERR_HIP);
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return fail(PFEM_ERR_HIP);
+    s->own_stream = true;
+    if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) return fail(PFEM_ERR_HIP);
+    if (hipHostMalloc(reinterpret_cast<void **>(&s->h_ctl), sizeof(CgCtl)) != hipSuccess) return fail(PFEM_ERR_NOMEM);
+    if (hipHostMalloc(reinterpret_cast<void **>(&s->h_err), sizeof(int)) != hipSuccess) return fail(PFEM_ERR_NOMEM);
+    if ((rc = s->d_part.alloc(3 * kMaxGrid)) || (rc = s->d_ctl.alloc(1)) || (rc = s->d_err.alloc(1))) return fail(rc);
+    if (hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream) != hipSuccess) return fail(PFEM_ERR_HIP);
+    s->status = PFEM_SOLVER_EMPTY;   // solverpetsc.F:212
+    *out = s;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_destroy(pfem_solver *s)
+{
+    if (!s) return PFEM_OK;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (hipEvent_t e : s->spmv_events) (void)hipEventDestroy(e);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->h_ctl) (void)hipHostFree(s->h_ctl);
+    if (s->h_err) (void)hipHostFree(s->h_err);
+    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_set_stream(pfem_solver *s, void *hip_stream)
+{
+    if (!s) return PFEM_ERR_ARG;
+    PFEM_TRY(use_device(s));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    if (s->own_stream) { (void)hipStreamDestroy(s->stream); s->own_stream = false; }
+    if (hip_stream) {
+        s->stream = static_cast<hipStream_t>(hip_stream);
+    } else {
+        PFEM_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        s->own_stream = true;
+    }
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_set_tolerances(pfem_solver *s, double rtol, double abstol, double dtol, int maxits)
+{
+    if (!s || rtol < 0 || abstol < 0 || dtol <= 0 || maxits < 0) return PFEM_ERR_ARG;
+    s->rtol = rtol; s->abstol = abstol; s->dtol = dtol; s->maxits = maxits;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_status(pfem_solver *s, int *st)
+{
+    if (!s || !st) return PFEM_ERR_ARG;
+    *st = s->status;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_profile_spmv(pfem_solver *s, int enable)
+{
+    if (!s) return PFEM_ERR_ARG;
+    s->profile_spmv = enable != 0;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_get_timings(pfem_solver *s, pfem_timings *t)
+{
+    if (!s || !t) return PFEM_ERR_ARG;
+    *t = s->tm;
+    return PFEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// mesh upload
+// ---------------------------------------------------------------------------
+extern "C" int pfem_mesh_upload(pfem_solver *s, int kind, int64_t nElem, const int32_t *conn,
+                                int64_t nNode, const double *xyz, const int32_t *edof,
+                                const double *solnApplied)
+{
+    if (!s || !kind_valid(kind) || nElem < 0 || nNode < 1 || !conn || !xyz || !edof || !solnApplied)
+        return PFEM_ERR_ARG;
+    PFEM_TRY(use_device(s));
+    const auto t0 = std::chrono::steady_clock::now();
+    MeshDev &m = s->mesh;
+    m.kind = kind;
+    m.npe = kind_npelem(kind);
+    m.ndof = kind_ndof(kind);
+    m.nsize = m.npe * m.ndof;
+    m.ndim = kind_ndim(kind);
+    m.nElem = nElem;
+    m.nNode = nNode;
+    const int64_t ndofs = static_cast<int64_t>(m.nsize) * nElem;
+
+    // ghost dofs: global ids outside the owned row block (multi-rank only)
+    s->ghost_gid.clear();
+    const int64_t lo = s->row_start, hi = s->row_start + s->n_owned;
+    for (int64_t i = 0; i < ndofs; ++i) {
+        const int32_t g = edof[i];
+        if (g < -1 || g >= s->size_global) return PFEM_ERR_ARG;
+        if (g >= 0 && (g < lo || g >= hi)) s->ghost_gid.push_back(g);
+    }
+    std::sort(s->ghost_gid.begin(), s->ghost_gid.end());
+    s->ghost_gid.erase(std::unique(s->ghost_gid.begin(), s->ghost_gid.end()), s->ghost_gid.end());
+    s->n_ghost = static_cast<int64_t>(s->ghost_gid.size());
+    s->n_loc = s->n_owned + s->n_ghost;
+    if (s->n_loc > INT32_MAX) return PFEM_ERR_ARG;
+
+    PFEM_TRY(s->d_conn.alloc(static_cast<size_t>(m.npe) * nElem));
+    PFEM_TRY(s->d_edof.alloc(static_cast<size_t>(ndofs)));
+    PFEM_TRY(s->d_xyz.alloc(static_cast<size_t>(m.ndim) * nNode));
+    PFEM_TRY(s->d_soln.alloc(static_cast<size_t>(m.ndof) * nNode));
+    PFEM_HIP(hipMemcpyAsync(s->d_conn.p, conn, sizeof(int32_t) * m.npe * nElem, hipMemcpyHostToDevice, s->stream));
+    PFEM_HIP(hipMemcpyAsync(s->d_edof.p, edof, sizeof(int32_t) * ndofs, hipMemcpyHostToDevice, s->stream));
+    PFEM_HIP(hipMemcpyAsync(s->d_xyz.p, xyz, sizeof(double) * m.ndim * nNode, hipMemcpyHostToDevice, s->stream));
+    PFEM_HIP(hipMemcpyAsync(s->d_soln.p, solnApplied, sizeof(double) * m.ndof * nNode, hipMemcpyHostToDevice, s->stream));
+    if (s->n_ghost > 0 || s->row_start > 0) {
+        DevBuf<int64_t> d_ghost;
+        PFEM_TRY(d_ghost.alloc(static_cast<size_t>(s->n_ghost)));
+        if (s->n_ghost)
+            PFEM_HIP(hipMemcpyAsync(d_ghost.p, s->ghost_gid.data(), sizeof(int64_t) * s->n_ghost, hipMemcpyHostToDevice, s->stream));
+        hipLaunchKernelGGL(k_localize_dofs, dim3(grid_for(ndofs)), dim3(kBlock), 0, s->stream, s->d_edof.p, ndofs,
+                           s->row_start, s->n_owned, d_ghost.p, s->n_ghost);
+        PFEM_TRY(check_kernel("k_localize_dofs"));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+    }
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    m.conn = s->d_conn.p;
+    m.edof = s->d_edof.p;
+    m.xyz = s->d_xyz.p;
+    m.soln = s->d_soln.p;
+    s->have_mesh = true;
+    s->have_pattern = false;
+    s->tm.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return PFEM_OK;
+}
+
+extern "C" int pfem_get_ghosts(pfem_solver *s, int64_t *n_ghost, int64_t *ghost_gid)
+{
+    if (!s || !n_ghost) return PFEM_ERR_ARG;
+    if (!s->have_mesh) return PFEM_ERR_STATE;
+    *n_ghost = s->n_ghost;
+    if (ghost_gid) std::copy(s->ghost_gid.begin(), s->ghost_gid.end(), ghost_gid);
+    return PFEM_OK;
+}
+
+extern "C" int pfem_get_local_to_global(pfem_solver *s, int64_t *gid)
+{
+    if (!s || !gid) return PFEM_ERR_ARG;
+    for (int64_t i = 0; i < s->n_owned; ++i) gid[i] = s->row_start + i;
+    std::copy(s->ghost_gid.begin(), s->ghost_gid.end(), gid + s->n_owned);
+    return PFEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// symbolic phase: sorted unique (row,col) keys -> wave-sliced CSR
+// ---------------------------------------------------------------------------
+namespace {
+
+int alloc_vectors(pfem_solver *s)
+{
+    const size_t n = static_cast<size_t>(s->n_loc);
+    PFEM_TRY(s->d_rhs.alloc(n));
+    PFEM_TRY(s->d_x.alloc(n));
+    PFEM_TRY(s->d_r.alloc(n));
+    PFEM_TRY(s->d_p.alloc(n));
+    PFEM_TRY(s->d_w.alloc(n));
+    PFEM_TRY(s->d_dinv.alloc(n));
+    PFEM_HIP(hipMemsetAsync(s->d_rhs.p, 0, n * sizeof(double), s->stream));
+    PFEM_HIP(hipMemsetAsync(s->d_x.p, 0, n * sizeof(double), s->stream));
+    return PFEM_OK;
+}
+
+// keys: device array of `nkeys` (row<<32|col) keys, kNoKey = ignore.  Consumed.
+int pattern_from_keys(pfem_solver *s, DevBuf<uint64_t> &keys, int64_t nkeys)
+{
+    if (nkeys > INT_MAX) {
+        set_last_error("pattern_from_keys: more than 2^31-1 element-matrix entries on one device");
+        return PFEM_ERR_ARG;
+    }
+    const int64_t n = s->n_loc;
+    int bits = 1;
+    while ((1LL << bits) < std::max<int64_t>(n, 2)) ++bits;
+    const int end_bit = std::min(64, 32 + bits);
+    DevBuf<uint64_t> sorted;
+    DevBuf<int> d_num;
+    DevBuf<char> temp;
+    PFEM_TRY(sorted.alloc(static_cast<size_t>(nkeys)));
+    PFEM_TRY(d_num.alloc(1));
+    size_t tb = 0;
+    const int ni = static_cast<int>(nkeys);
+    PFEM_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, keys.p, sorted.p, ni, 0, end_bit, s->stream));
+    PFEM_TRY(temp.alloc(tb));
+    PFEM_HIP(hipcub::DeviceRadixSort::SortKeys(temp.p, tb, keys.p, sorted.p, ni, 0, end_bit, s->stream));
+    size_t tb2 = 0;
+    PFEM_HIP(hipcub::DeviceSelect::Unique(nullptr, tb2, sorted.p, keys.p, d_num.p, ni, s->stream));
+    if (tb2 > tb) { PFEM_HIP(hipStreamSynchronize(s->stream)); PFEM_TRY(temp.alloc(tb2)); }
+    PFEM_HIP(hipcub::DeviceSelect::Unique(temp.p, tb2, sorted.p, keys.p, d_num.p, ni, s->stream));
+    int num = 0;
+    PFEM_HIP(hipMemcpyAsync(&num, d_num.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    sorted.release();
+    int64_t nnz = num;
+    if (nnz > 0) {   // drop the collapsed sentinel, if any
+        uint64_t last = 0;
+        PFEM_HIP(hipMemcpy(&last, keys.p + (nnz - 1), sizeof(uint64_t), hipMemcpyDeviceToHost));
+        if (last == kNoKey) --nnz;
+    }
+    s->nnz = nnz;
+    s->n_slices = (n + 63) / 64;
+
+    PFEM_TRY(s->d_rowptr.alloc(static_cast<size_t>(n) + 1));
+    PFEM_TRY(s->d_rowlen.alloc(static_cast<size_t>(std::max<int64_t>(n, 1))));
+    PFEM_TRY(s->d_slice_off.alloc(static_cast<size_t>(s->n_slices) + 1));
+    DevBuf<int64_t> slice_entries;
+    PFEM_TRY(slice_entries.alloc(static_cast<size_t>(s->n_slices) + 1));
+    hipLaunchKernelGGL(k_row_bounds, dim3(grid_for(std::max<int64_t>(nnz, n + 1))), dim3(kBlock), 0, s->stream,
+                       keys.p, nnz, n, s->d_rowptr.p);
+    PFEM_TRY(check_kernel("k_row_bounds"));
+    hipLaunchKernelGGL(k_slice_sizes, dim3(grid_for(s->n_slices * 64)), dim3(kBlock), 0, s->stream, s->d_rowptr.p, n,
+                       s->n_slices, s->d_rowlen.p, slice_entries.p);
+    PFEM_TRY(check_kernel("k_slice_sizes"));
+    size_t tb3 = 0;
+    const int nsl = static_cast<int>(s->n_slices + 1);
+    PFEM_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, slice_entries.p, s->d_slice_off.p, nsl, s->stream));
+    if (tb3 > temp.n) { PFEM_HIP(hipStreamSynchronize(s->stream)); PFEM_TRY(temp.alloc(tb3)); }
+    PFEM_HIP(hipcub::DeviceScan::ExclusiveSum(temp.p, tb3, slice_entries.p, s->d_slice_off.p, nsl, s->stream));
+    int64_t stored = 0;
+    PFEM_HIP(hipMemcpyAsync(&stored, s->d_slice_off.p + s->n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    s->stored = stored;
+    PFEM_TRY(s->d_cols.alloc(static_cast<size_t>(stored)));
+    PFEM_TRY(s->d_vals.alloc(static_cast<size_t>(stored)));
+    hipLaunchKernelGGL(k_fill_sell, dim3(grid_for(s->n_slices * 64)), dim3(kBlock), 0, s->stream, keys.p, s->d_rowptr.p, n,
+                       s->n_slices, s->d_slice_off.p, s->d_cols.p);
+    PFEM_TRY(check_kernel("k_fill_sell"));
+    PFEM_HIP(hipMemsetAsync(s->d_vals.p, 0, sizeof(double) * static_cast<size_t>(std::max<int64_t>(stored, 1)), s->stream));
+    PFEM_TRY(alloc_vectors(s));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    keys.release();
+    s->have_pattern = true;
+    s->rhs_summed = false;
+    s->status = PFEM_PATTERN_OK;
+    return PFEM_OK;
+}
+
+}  // namespace
+
+extern "C" int pfem_pattern_build(pfem_solver *s)
+{
+    if (!s) return PFEM_ERR_ARG;
+    if (!s->have_mesh) return PFEM_ERR_STATE;
+    PFEM_TRY(use_device(s));
+    const MeshDev &m = s->mesh;
+    const int64_t nkeys = static_cast<int64_t>(m.nsize) * m.nsize * m.nElem;
+    DevBuf<uint64_t> keys;
+    PFEM_TRY(keys.alloc(static_cast<size_t>(std::max<int64_t>(nkeys, 1))));
+    PFEM_HIP(hipEventRecord(s->ev0, s->stream));
+    if (m.nElem > 0) {
+        hipLaunchKernelGGL(k_emit_keys, dim3(grid_for(m.nElem)), dim3(kBlock), 0, s->stream, m, keys.p);
+        PFEM_TRY(check_kernel("k_emit_keys"));
+    }
+    PFEM_TRY(pattern_from_keys(s, keys, nkeys));
+    PFEM_HIP(hipEventRecord(s->ev1, s->stream));
+    PFEM_TRY(elapsed(s, &s->tm.pattern_ms));
+    return PFEM_OK;
+}
+
+extern "C" int pfem_matrix_info(pfem_solver *s, int64_t *n_owned, int64_t *n_local, int64_t *nnz,
+                                int64_t *stored_entries)
+{
+    if (!s) return PFEM_ERR_ARG;
+    if (n_owned) *n_owned = s->n_owned;
+    if (n_local) *n_local = s->n_loc;
+    if (nnz) *nnz = s->have_pattern ? s->nnz : 0;
+    if (stored_entries) *stored_entries = s->have_pattern ? s->stored : 0;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_print_info(pfem_solver *s)
+{
+    if (!s) return PFEM_ERR_ARG;
+    std::printf(" pfem solver:  nRow = %12lld  (local %lld owned + %lld ghost)\n", static_cast<long long>(s->size_global),
+                static_cast<long long>(s->n_owned), static_cast<long long>(s->n_ghost));
+    std::printf("               nnz  = %12lld  stored (wave-sliced) = %lld  status = %d\n",
+                static_cast<long long>(s->nnz), static_cast<long long>(s->stored), s->status);
+    return PFEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// numeric phase
+// ---------------------------------------------------------------------------
+namespace {
+
+ElemPrm make_prm(const double *elemData, const double *timeData, int kind)
+{
+    ElemPrm p{};
+    const int ned = kind == PFEM_ELAST_TET ? 6 : (kind == PFEM_POISSON_TET ? 3 : 2);
+    for (int i = 0; i < ned; ++i) p.ed[i] = elemData ? elemData[i] : 0.0;
+    p.af = timeData ? timeData[1] : 1.0;
+    return p;
+}
+
+int zero_values(pfem_solver *s)
+{
+    PFEM_HIP(hipMemsetAsync(s->d_vals.p, 0, sizeof(double) * static_cast<size_t>(std::max<int64_t>(s->stored, 1)), s->stream));
+    PFEM_HIP(hipMemsetAsync(s->d_rhs.p, 0, sizeof(double) * static_cast<size_t>(std::max<int64_t>(s->n_loc, 1)), s->stream));
+    s->rhs_summed = false;
+    return PFEM_OK;
+}
+
+}  // namespace
+
+extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const double *timeData)
+{
+    if (!s) return PFEM_ERR_ARG;
+    if (!s->have_mesh || !s->have_pattern) return PFEM_ERR_STATE;
+    const MeshDev &m = s->mesh;
+    if (m.kind != PFEM_POISSON_TRIA_INLINE && !elemData) return PFEM_ERR_ARG;
+    PFEM_TRY(use_device(s));
+    const ElemPrm prm = make_prm(elemData, timeData, m.kind);
+    PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
+    PFEM_HIP(hipEventRecord(s->ev0, s->stream));
+    PFEM_TRY(zero_values(s));                 // setZero, solverpetsc.F:222-246
+    if (m.nElem > 0) {
+        const dim3 grid(grid_for(m.nElem)), block(kBlock);
+        SellDev A = s->sell();
+        switch (m.kind) {
+        case PFEM_POISSON_TET:
+            hipLaunchKernelGGL(k_assemble_scalar<PFEM_POISSON_TET>, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, s->d_err.p);
+            break;
+        case PFEM_POISSON_TRIA:
+            hipLaunchKernelGGL(k_assemble_scalar<PFEM_POISSON_TRIA>, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, s->d_err.p);
+            break;
+        case PFEM_POISSON_TRIA_INLINE:
+            hipLaunchKernelGGL(k_assemble_scalar<PFEM_POISSON_TRIA_INLINE>, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, s->d_err.p);
+            break;
+        case PFEM_ELAST_TET:
+            hipLaunchKernelGGL(k_assemble_elast, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, s->d_err.p);
+            break;
+        }
+        PFEM_TRY(check_kernel("k_assemble"));
+    }
+    PFEM_HIP(hipEventRecord(s->ev1, s->stream));
+    int err = 0;
+    PFEM_TRY(fetch_err(s, &err));
+    PFEM_TRY(elapsed(s, &s->tm.assemble_ms));
+    if (err) return err;
+    s->host_values_dirty = false;
+    s->status = PFEM_ASSEMBLY_OK;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_eval_elems(pfem_solver *s, const double *elemData, const double *timeData,
+                               double *K_out, double *F_out)
+{
+    if (!s || !K_out || !F_out) return PFEM_ERR_ARG;
+    if (!s->have_mesh) return PFEM_ERR_STATE;
+    PFEM_TRY(use_device(s));
+    const MeshDev &m = s->mesh;
+    const ElemPrm prm = make_prm(elemData, timeData, m.kind);
+    const size_t nk = static_cast<size_t>(m.nElem) * m.nsize * m.nsize, nf = static_cast<size_t>(m.nElem) * m.nsize;
+    DevBuf<double> dK, dF;
+    PFEM_TRY(dK.alloc(nk));
+    PFEM_TRY(dF.alloc(nf));
+    PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
+    if (m.nElem > 0) {
+        hipLaunchKernelGGL(k_eval_elems, dim3(grid_for(m.nElem)), dim3(kBlock), 0, s->stream, m, prm, dK.p, dF.p, s->d_err.p);
+        PFEM_TRY(check_kernel("k_eval_elems"));
+    }
+    PFEM_HIP(hipMemcpyAsync(K_out, dK.p, nk * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipMemcpyAsync(F_out, dF.p, nf * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    int err = 0;
+    PFEM_TRY(fetch_err(s, &err));
+    return err;
+}
+
+extern "C" int pfem_get_csr(pfem_solver *s, int64_t *rowptr, int32_t *cols, double *vals)
+{
+    if (!s) return PFEM_ERR_ARG;
+    if (!s->have_pattern) return PFEM_ERR_STATE;
+    PFEM_TRY(use_device(s));
+    if (rowptr)
+        PFEM_HIP(hipMemcpyAsync(rowptr, s->d_rowptr.p, sizeof(int64_t) * (s->n_loc + 1), hipMemcpyDeviceToHost, s->stream));
+    if (cols || vals) {
+        DevBuf<int32_t> dc;
+        DevBuf<double> dv;
+        if (cols) PFEM_TRY(dc.alloc(static_cast<size_t>(s->nnz)));
+        if (vals) PFEM_TRY(dv.alloc(static_cast<size_t>(s->nnz)));
+        if (s->n_loc > 0) {
+            hipLaunchKernelGGL(k_sell_to_csr, dim3(grid_for(s->n_loc)), dim3(kBlock), 0, s->stream, s->sell(), s->d_rowptr.p,
+                               cols ? dc.p : nullptr, vals ? dv.p : nullptr);
+            PFEM_TRY(check_kernel("k_sell_to_csr"));
+        }
+        if (cols) PFEM_HIP(hipMemcpyAsync(cols, dc.p, sizeof(int32_t) * s->nnz, hipMemcpyDeviceToHost, s->stream));
+        if (vals) PFEM_HIP(hipMemcpyAsync(vals, dv.p, sizeof(double) * s->nnz, hipMemcpyDeviceToHost, s->stream));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+    }
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    return PFEM_OK;
+}
+
+extern "C" int pfem_get_rhs(pfem_solver *s, double *rhs_local)
+{
+    if (!s || !rhs_local) return PFEM_ERR_ARG;
+    if (!s->have_pattern) return PFEM_ERR_STATE;
+    PFEM_TRY(use_device(s));
+    PFEM_HIP(hipMemcpyAsync(rhs_local, s->d_rhs.p, sizeof(double) * s->n_loc, hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    return PFEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// SpMV entry points
+// ---------------------------------------------------------------------------
+extern "C" int pfem_spmv(pfem_solver *s, const double *x, double *y)
+{
+    if (!s || !x || !y) return PFEM_ERR_ARG;
+    if (!s->have_pattern) return PFEM_ERR_STATE;
+    PFEM_TRY(use_device(s));
+    const size_t nb = sizeof(double) * static_cast<size_t>(s->n_loc);
+    PFEM_HIP(hipMemcpyAsync(s->d_p.p, x, nb, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_spmv<false>, dim3(spmv_grid(s->n_slices)), dim3(kBlock), 0, s->stream, s->sell(), s->d_p.p, s->d_w.p,
+                       static_cast<int64_t>(0), static_cast<double *>(nullptr), static_cast<const CgCtl *>(nullptr));
+    PFEM_TRY(check_kernel("k_spmv"));
+    PFEM_HIP(hipMemcpyAsync(y, s->d_w.p, nb, hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    return PFEM_OK;
+}
+
+extern "C" int pfem_bench_spmv(pfem_solver *s, int reps, double *ms_per_launch)
+{
+    if (!s || reps < 1 || !ms_per_launch) return PFEM_ERR_ARG;
+    if (!s->have_pattern) return PFEM_ERR_STATE;
+    PFEM_TRY(use_device(s));
+    const dim3 grid(spmv_grid(s->n_slices)), block(kBlock);
+    // warm-up launch, then `reps` timed ones with x = rhs (any resident vector)
+    hipLaunchKernelGGL(k_spmv<false>, grid, block, 0, s->stream, s->sell(), s->d_rhs.p, s->d_w.p, static_cast<int64_t>(0),
+                       static_cast<double *>(nullptr), static_cast<const CgCtl *>(nullptr));
+    PFEM_HIP(hipEventRecord(s->ev0, s->stream));
+    for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL(k_spmv<false>, grid, block, 0, s->stream, s->sell(), s->d_rhs.p, s->d_w.p, static_cast<int64_t>(0),
+                           static_cast<double *>(nullptr), static_cast<const CgCtl *>(nullptr));
+    PFEM_HIP(hipEventRecord(s->ev1, s->stream));
+    PFEM_TRY(check_kernel("k_spmv"));
+    double ms = 0;
+    PFEM_TRY(elapsed(s, &ms));
+    *ms_per_launch = ms / reps;
+    return PFEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// multi-GPU plumbing
+// ---------------------------------------------------------------------------
+extern "C" int pfem_solver_set_comm(pfem_solver *s, int rank, int nranks, pfem_allreduce_fn fn, void *ctx)
+{
+    if (!s || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !fn)) return PFEM_ERR_ARG;
+    s->rank = rank;
+    s->nranks = nranks;
+    s->allreduce = fn;
+    s->comm_ctx = ctx;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_set_exchange_buffer(pfem_solver *s, void *device_buf, int64_t capacity)
+{
+    if (!s || (device_buf && capacity < 4)) return PFEM_ERR_ARG;
+    s->xbuf = static_cast<double *>(device_buf);
+    s->xbuf_cap = device_buf ? capacity : 0;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_set_interface(pfem_solver *s, int64_t n_shared, const int64_t *shared_gid,
+                                         const int32_t *shared_slot, int64_t n_iface_global)
+{
+    if (!s || n_shared < 0 || n_iface_global < n_shared || (n_shared && (!shared_gid || !shared_slot)))
+        return PFEM_ERR_ARG;
+    if (!s->have_mesh) return PFEM_ERR_STATE;   // local numbering must exist
+    PFEM_TRY(use_device(s));
+    std::vector<int32_t> lidx(static_cast<size_t>(n_shared));
+    const int64_t lo = s->row_start, hi = s->row_start + s->n_owned;
+    for (int64_t i = 0; i < n_shared; ++i) {
+        const int64_t g = shared_gid[i];
+        if (shared_slot[i] < 0 || shared_slot[i] >= n_iface_global) return PFEM_ERR_ARG;
+        if (g >= lo && g < hi) { lidx[i] = static_cast<int32_t>(g - lo); continue; }
+        auto it = std::lower_bound(s->ghost_gid.begin(), s->ghost_gid.end(), g);
+        if (it == s->ghost_gid.end() || *it != g) return PFEM_ERR_ARG;   // not a dof of this rank
+        lidx[i] = static_cast<int32_t>(s->n_owned + (it - s->ghost_gid.begin()));
+    }
+    PFEM_TRY(s->d_shared_lidx.alloc(static_cast<size_t>(n_shared)));
+    PFEM_TRY(s->d_shared_slot.alloc(static_cast<size_t>(n_shared)));
+    if (n_shared) {
+        PFEM_HIP(hipMemcpy(s->d_shared_lidx.p, lidx.data(), sizeof(int32_t) * n_shared, hipMemcpyHostToDevice));
+        PFEM_HIP(hipMemcpy(s->d_shared_slot.p, shared_slot, sizeof(int32_t) * n_shared, hipMemcpyHostToDevice));
+    }
+    s->n_shared = n_shared;
+    s->n_iface = n_iface_global;
+    return PFEM_OK;
+}
+
+namespace {
+
+int ensure_xbuf(pfem_solver *s)
+{
+    const int64_t need = s->n_iface + 4;
+    if (s->xbuf && s->xbuf_cap >= need) return PFEM_OK;
+    if (s->xbuf && !s->d_xbuf_own.p) {
+        set_last_error("exchange buffer too small for the interface plan");
+        return PFEM_ERR_ARG;
+    }
+    PFEM_TRY(s->d_xbuf_own.alloc(static_cast<size_t>(need)));
+    s->xbuf = s->d_xbuf_own.p;
+    s->xbuf_cap = need;
+    return PFEM_OK;
+}
+
+int call_hook(pfem_solver *s, double *buf, int64_t count)
+{
+    if (s->allreduce(s->comm_ctx, buf, count, s->stream) != 0) {
+        set_last_error("all-reduce hook returned nonzero");
+        return PFEM_ERR_COMM;
+    }
+    return PFEM_OK;
+}
+
+// v[shared] <- sum over ranks of v[shared]; optionally carries n_extra scalars reduced
+// from partial arrays in buf[n_iface + j]
+int interface_sum(pfem_solver *s, double *v, const double *part0, const double *part1, int nparts, int n_extra,
+                  const CgCtl *ctl)
+{
+    double *buf = s->xbuf;
+    PFEM_HIP(hipMemsetAsync(buf, 0, sizeof(double) * static_cast<size_t>(s->n_iface + n_extra), s->stream));
+    const unsigned gb = grid_for(s->n_shared) + 1;
+    hipLaunchKernelGGL(k_pack, dim3(gb), dim3(kBlock), 0, s->stream, v, s->d_shared_lidx.p, s->d_shared_slot.p, s->n_shared, buf,
+                       s->n_iface, part0, part1, nparts, n_extra, ctl);
+    PFEM_TRY(check_kernel("k_pack"));
+    PFEM_TRY(call_hook(s, buf, s->n_iface + n_extra));
+    if (s->n_shared > 0) {
+        hipLaunchKernelGGL(k_unpack, dim3(grid_for(s->n_shared)), dim3(kBlock), 0, s->stream, v, s->d_shared_lidx.p,
+                           s->d_shared_slot.p, s->n_shared, buf, ctl);
+        PFEM_TRY(check_kernel("k_unpack"));
+    }
+    return PFEM_OK;
+}
+
+// two scalars reduced from partial arrays -> all-reduce -> buf2[0..1]
+int scalar_sum2(pfem_solver *s, const double *part0, const double *part1, int nparts, const CgCtl *ctl)
+{
+    double *buf2 = s->xbuf + s->n_iface + 2;
+    PFEM_HIP(hipMemsetAsync(buf2, 0, 2 * sizeof(double), s->stream));
+    hipLaunchKernelGGL(k_pack, dim3(1), dim3(kBlock), 0, s->stream, static_cast<const double *>(nullptr),
+                       static_cast<const int32_t *>(nullptr), static_cast<const int32_t *>(nullptr), static_cast<int64_t>(0),
+                       buf2, static_cast<int64_t>(0), part0, part1, nparts, 2, ctl);
+    PFEM_TRY(check_kernel("k_pack(scalars)"));
+    return call_hook(s, buf2, 2);
+}
+
+// ---------------------------------------------------------------------------
+// Jacobi-preconditioned CG on the device (KSPSolve, solverpetsc.F:476)
+// ---------------------------------------------------------------------------
+int run_pcg(pfem_solver *s)
+{
+    const int64_t n = s->n_loc;
+    const bool multi = s->nranks > 1;
+    const unsigned gv = vec_grid(n), gs = spmv_grid(s->n_slices);
+    const dim3 block(kBlock);
+    SellDev A = s->sell();
+    double *part_pw = s->d_part.p, *part_rz = s->d_part.p + kMaxGrid, *part_zz = s->d_part.p + 2 * kMaxGrid;
+    CgCtl *ctl = s->d_ctl.p;
+    if (multi) PFEM_TRY(ensure_xbuf(s));
+    if (s->hist_cap < s->maxits + 2) {
+        PFEM_TRY(s->d_hist.alloc(static_cast<size_t>(s->maxits) + 2));
+        s->hist_cap = s->maxits + 2;
+    }
+    PFEM_HIP(hipMemsetAsync(ctl, 0, sizeof(CgCtl), s->stream));
+
+    // Jacobi: dinv = 1 / diag(A); interface diagonals and rhs are summed over the ranks
+    if (n > 0) {
+        hipLaunchKernelGGL(k_extract_diag, dim3(grid_for(n)), block, 0, s->stream, A, s->d_dinv.p);
+        PFEM_TRY(check_kernel("k_extract_diag"));
+    }
+    if (multi) {
+        PFEM_TRY(interface_sum(s, s->d_dinv.p, nullptr, nullptr, 0, 0, nullptr));
+        if (!s->rhs_summed) {
+            PFEM_TRY(interface_sum(s, s->d_rhs.p, nullptr, nullptr, 0, 0, nullptr));
+            s->rhs_summed = true;
+        }
+    }
+    if (n > 0) {
+        hipLaunchKernelGGL(k_invert, dim3(grid_for(n)), block, 0, s->stream, s->d_dinv.p, n);
+        PFEM_TRY(check_kernel("k_invert"));
+    }
+
+    hipLaunchKernelGGL(k_cg_init, dim3(gv), block, 0, s->stream, n, s->n_owned, s->d_rhs.p, s->d_dinv.p, s->d_x.p, s->d_r.p,
+                       s->d_p.p, part_rz, part_zz);
+    PFEM_TRY(check_kernel("k_cg_init"));
+    const double *red2 = nullptr;
+    if (multi) {
+        PFEM_TRY(scalar_sum2(s, part_rz, part_zz, static_cast<int>(gv), nullptr));
+        red2 = s->xbuf + s->n_iface + 2;
+    }
+    hipLaunchKernelGGL(k_cg_start, dim3(1), block, 0, s->stream, ctl, part_rz, part_zz, static_cast<int>(gv), red2, s->rtol,
+                       s->abstol, s->dtol, s->d_hist.p);
+    PFEM_TRY(check_kernel("k_cg_start"));
+
+    static const int chunk_env = [] { const char *e = std::getenv("PFEM_CG_CHUNK"); return e ? std::atoi(e) : 0; }();
+    const int chunk = chunk_env > 0 ? chunk_env : 32;
+    size_t ev_used = 0;
+    int it = 0;
+    CgCtl h{};
+    for (;;) {
+        PFEM_HIP(hipMemcpyAsync(s->h_ctl, ctl, sizeof(CgCtl), hipMemcpyDeviceToHost, s->stream));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+        h = *s->h_ctl;
+        if (h.flag != 0) break;
+        if (it >= s->maxits) { h.flag = -3; break; }   // maxits == 0
+        const int it_end = std::min(it + chunk, s->maxits);
+        for (; it < it_end; ++it) {
+            // w = A p, partial (p, A_loc p) over ALL local rows (sub-assembled identity)
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (s->profile_spmv && ev_used + 2 <= 8192) {
+                if (s->spmv_events.size() < ev_used + 2) {
+                    hipEvent_t a, b;
+                    PFEM_HIP(hipEventCreate(&a));
+                    PFEM_HIP(hipEventCreate(&b));
+                    s->spmv_events.push_back(a);
+                    s->spmv_events.push_back(b);
+                }
+                e0 = s->spmv_events[ev_used];
+                e1 = s->spmv_events[ev_used + 1];
+                ev_used += 2;
+                PFEM_HIP(hipEventRecord(e0, s->stream));
+            }
+            hipLaunchKernelGGL(k_spmv<true>, dim3(gs), block, 0, s->stream, A, s->d_p.p, s->d_w.p, n, part_pw, ctl);
+            if (e1) PFEM_HIP(hipEventRecord(e1, s->stream));
+            const double *red_pw = nullptr;
+            if (multi) {
+                PFEM_TRY(interface_sum(s, s->d_w.p, part_pw, nullptr, static_cast<int>(gs), 1, ctl));
+                red_pw = s->xbuf + s->n_iface;
+            }
+            hipLaunchKernelGGL(k_cg_update, dim3(gv), block, 0, s->stream, ctl, it, n, s->n_owned, part_pw, static_cast<int>(gs),
+                               red_pw, s->d_p.p, s->d_w.p, s->d_dinv.p, s->d_x.p, s->d_r.p, part_rz, part_zz);
+            if (multi) PFEM_TRY(scalar_sum2(s, part_rz, part_zz, static_cast<int>(gv), ctl));
+            hipLaunchKernelGGL(k_cg_direction, dim3(gv), block, 0, s->stream, ctl, it, n, part_rz, part_zz, static_cast<int>(gv),
+                               red2, s->d_r.p, s->d_dinv.p, s->d_p.p, s->d_hist.p, s->hist_cap, s->maxits);
+        }
+        PFEM_TRY(check_kernel("pcg iteration"));
+    }
+    s->last_its = h.its;
+    s->last_reason = (h.flag == 2 && h.rn <= s->abstol) ? 3 : h.flag;
+    s->last_rnorm = h.rn;
+    s->tm.spmv_ms_total = 0.0;
+    s->tm.spmv_launches = 0;
+    // only launches that did work count (the tail of the last chunk exits at the flag test)
+    const size_t live = std::min(ev_used / 2, static_cast<size_t>(h.its));
+    for (size_t k = 0; k < live; ++k) {
+        float f = 0.f;
+        PFEM_HIP(hipEventElapsedTime(&f, s->spmv_events[2 * k], s->spmv_events[2 * k + 1]));
+        s->tm.spmv_ms_total += f;
+        ++s->tm.spmv_launches;
+    }
+    return PFEM_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// compat path: MatSetValues / VecSetValues staged on the host
+// ---------------------------------------------------------------------------
+extern "C" int pfem_mat_set_values(pfem_solver *s, int m, const int *idxm, int n, const int *idxn,
+                                   const double *v, int mode)
+{
+    if (!s || m < 0 || n < 0 || (m && !idxm) || (n && !idxn) || (mode != PFEM_INSERT_VALUES && mode != PFEM_ADD_VALUES))
+        return PFEM_ERR_ARG;
+    if (s->nranks > 1 || s->have_mesh) {
+        set_last_error("the MatSetValues compat path is single-rank and exclusive with pfem_mesh_upload/pfem_assemble");
+        return PFEM_ERR_STATE;
+    }
+    if (s->status == PFEM_SOLVER_EMPTY) {
+        // pattern recording (the INSERT_VALUES loop, tetrapoissonparallelimpl1.F:791-802)
+        for (int i = 0; i < m; ++i) {
+            if (idxm[i] < 0) continue;
+            if (idxm[i] >= s->size_global) return PFEM_ERR_ARG;
+            for (int j = 0; j < n; ++j) {
+                if (idxn[j] < 0) continue;
+                if (idxn[j] >= s->size_global) return PFEM_ERR_ARG;
+                s->h_keys.push_back((static_cast<uint64_t>(static_cast<uint32_t>(idxm[i])) << 32) | static_cast<uint32_t>(idxn[j]));
+            }
+        }
+        return PFEM_OK;
+    }
+    if (!v) return PFEM_ERR_ARG;
+    if (s->h_rowptr.empty()) return PFEM_ERR_STATE;
+    for (int i = 0; i < m; ++i) {
+        if (idxm[i] < 0) continue;
+        const int64_t r = idxm[i];
+        if (r >= s->size_global) return PFEM_ERR_ARG;
+        const int32_t *cb = s->h_cols.data() + s->h_rowptr[r], *ce = s->h_cols.data() + s->h_rowptr[r + 1];
+        for (int j = 0; j < n; ++j) {
+            if (idxn[j] < 0) continue;
+            const int32_t *p = std::lower_bound(cb, ce, idxn[j]);
+            if (p == ce || *p != idxn[j]) return PFEM_ERR_PATTERN;
+            double &dst = s->h_vals[static_cast<size_t>(p - s->h_cols.data())];
+            const double val = v[static_cast<size_t>(i) * n + j];      // PETSc reads v row-major
+            if (mode == PFEM_ADD_VALUES) dst += val; else dst = val;
+        }
+    }
+    s->host_values_dirty = true;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_vec_set_values(pfem_solver *s, int n, const int *idx, const double *v, int mode)
+{
+    if (!s || n < 0 || (n && (!idx || !v)) || (mode != PFEM_INSERT_VALUES && mode != PFEM_ADD_VALUES)) return PFEM_ERR_ARG;
+    if (s->have_mesh) { set_last_error("VecSetValues compat path is not available once a mesh is uploaded (batched mode)"); return PFEM_ERR_STATE; }
+    if (s->h_rhs.empty() && s->size_global > 0) s->h_rhs.assign(static_cast<size_t>(s->size_global), 0.0);
+    for (int i = 0; i < n; ++i) {
+        if (idx[i] < 0) continue;                       // VEC_IGNORE_NEGATIVE_INDICES
+        if (idx[i] >= s->size_global) return PFEM_ERR_ARG;
+        if (mode == PFEM_ADD_VALUES) s->h_rhs[idx[i]] += v[i]; else s->h_rhs[idx[i]] = v[i];
+    }
+    s->host_values_dirty = true;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_assemble_matrix_and_vector(pfem_solver *s, int n, const int *rows, const int *cols,
+                                                      const double *K, const double *F)
+{
+    // per-entry MatSetValue(R(ii), C(jj), K(ii,jj)) / VecSetValue loops, solverpetsc.F:378-401
+    if (!s || n < 0 || (n && (!rows || !cols))) return PFEM_ERR_ARG;
+    if (K) {
+        std::vector<double> rowmajor(static_cast<size_t>(n) * n);
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) rowmajor[static_cast<size_t>(i) * n + j] = K[i + static_cast<size_t>(n) * j];
+        PFEM_TRY(pfem_mat_set_values(s, n, rows, n, cols, rowmajor.data(), PFEM_ADD_VALUES));
+    }
+    if (F) PFEM_TRY(pfem_vec_set_values(s, n, rows, F, PFEM_ADD_VALUES));
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_set_zero(pfem_solver *s)
+{
+    if (!s) return PFEM_ERR_ARG;
+    PFEM_TRY(use_device(s));
+    const bool compat = !s->have_mesh;      // pattern/values arrive through MatSetValues
+    if (!s->have_pattern) {
+        if (compat) {
+            if (s->h_keys.empty() && s->size_global > 0) return PFEM_ERR_STATE;
+            // MatAssembly of the INSERT_VALUES pass: finalise the recorded pattern on the device
+            s->n_loc = s->n_owned;
+            DevBuf<uint64_t> keys;
+            const int64_t nk = static_cast<int64_t>(s->h_keys.size());
+            PFEM_TRY(keys.alloc(static_cast<size_t>(std::max<int64_t>(nk, 1))));
+            if (nk) PFEM_HIP(hipMemcpy(keys.p, s->h_keys.data(), sizeof(uint64_t) * nk, hipMemcpyHostToDevice));
+            std::vector<uint64_t>().swap(s->h_keys);
+            PFEM_TRY(pattern_from_keys(s, keys, nk));
+        } else {
+            PFEM_TRY(pfem_pattern_build(s));
+        }
+    }
+    if (compat) {
+        // host CSR mirror for the ADD_VALUES binary search (PETSc does the same per row)
+        if (s->h_rowptr.empty()) {
+            s->h_rowptr.resize(static_cast<size_t>(s->n_loc) + 1);
+            s->h_cols.resize(static_cast<size_t>(s->nnz));
+            PFEM_TRY(pfem_get_csr(s, s->h_rowptr.data(), s->h_cols.data(), nullptr));
+        }
+        s->h_vals.assign(static_cast<size_t>(s->nnz), 0.0);
+        s->h_rhs.assign(static_cast<size_t>(s->size_global), 0.0);
+    }
+    PFEM_TRY(zero_values(s));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    s->host_values_dirty = false;
+    s->status = PFEM_INIT_OK;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_factorise(pfem_solver *s)
+{
+    if (!s) return PFEM_ERR_ARG;
+    if (s->status != PFEM_ASSEMBLY_OK) {    // solverpetsc.F:415-419
+        set_last_error("Assemble matrix first before solving it!");
+        return PFEM_ERR_STATE;
+    }
+    s->status = PFEM_FACTORISE_OK;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_solve(pfem_solver *s, int *its, int *reason, double *rnorm)
+{
+    if (!s) return PFEM_ERR_ARG;
+    if (s->status != PFEM_FACTORISE_OK) {   // solverpetsc.F:441-445
+        set_last_error("Factorise matrix first before solving it!");
+        return PFEM_ERR_STATE;
+    }
+    if (!s->have_pattern) return PFEM_ERR_STATE;
+    PFEM_TRY(use_device(s));
+    PFEM_HIP(hipEventRecord(s->ev0, s->stream));
+    if (s->host_values_dirty && !s->have_mesh) {
+        // MatAssemblyBegin/End + VecAssemblyBegin/End (solverpetsc.F:447-468): push the
+        // host-staged values to the device
+        if (!s->h_rowptr.empty()) {
+            DevBuf<double> dv;
+            PFEM_TRY(dv.alloc(static_cast<size_t>(s->nnz)));
+            PFEM_HIP(hipMemcpyAsync(dv.p, s->h_vals.data(), sizeof(double) * s->nnz, hipMemcpyHostToDevice, s->stream));
+            hipLaunchKernelGGL(k_csr_vals_to_sell, dim3(grid_for(s->n_loc)), dim3(kBlock), 0, s->stream, s->sell(), s->d_rowptr.p, dv.p);
+            PFEM_TRY(check_kernel("k_csr_vals_to_sell"));
+            PFEM_HIP(hipStreamSynchronize(s->stream));
+        }
+        if (!s->h_rhs.empty()) {
+            PFEM_HIP(hipMemcpyAsync(s->d_rhs.p, s->h_rhs.data(), sizeof(double) * s->n_loc, hipMemcpyHostToDevice, s->stream));
+            PFEM_HIP(hipStreamSynchronize(s->stream));
+        }
+        s->host_values_dirty = false;
+    }
+    PFEM_TRY(run_pcg(s));
+    PFEM_HIP(hipEventRecord(s->ev1, s->stream));
+    PFEM_TRY(elapsed(s, &s->tm.solve_ms));
+    if (its) *its = s->last_its;
+    if (reason) *reason = s->last_reason;
+    if (rnorm) *rnorm = s->last_rnorm;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_factorise_and_solve(pfem_solver *s, int *its, int *reason, double *rnorm)
+{
+    if (!s) return PFEM_ERR_ARG;
+    if (!s->have_pattern) return PFEM_ERR_STATE;
+    s->status = PFEM_ASSEMBLY_OK;           // solverpetsc.F:504
+    PFEM_TRY(pfem_solver_factorise(s));
+    return pfem_solver_solve(s, its, reason, rnorm);
+}
+
+extern "C" int pfem_solver_get_solution(pfem_solver *s, double *x_owned)
+{
+    if (!s || !x_owned) return PFEM_ERR_ARG;
+    if (!s->have_pattern) return PFEM_ERR_STATE;
+    PFEM_TRY(use_device(s));
+    PFEM_HIP(hipMemcpyAsync(x_owned, s->d_x.p, sizeof(double) * s->n_owned, hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_get_history(pfem_solver *s, double *hist, int n, int *n_written)
+{
+    if (!s || !hist || n < 0 || !n_written) return PFEM_ERR_ARG;
+    PFEM_TRY(use_device(s));
+    const int avail = std::min({n, s->last_its + 1, s->hist_cap});
+    if (avail > 0) {
+        PFEM_HIP(hipMemcpyAsync(hist, s->d_hist.p, sizeof(double) * avail, hipMemcpyDeviceToHost, s->stream));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+    }
+    *n_written = std::max(avail, 0);
+    return PFEM_OK;
+}

@@ -1,0 +1,288 @@
+// pfem_host.cpp -- host side of the C ABI: per-element compat entry points and the
+// integer bookkeeping of the PFEMFort drivers (mesh generation, Dirichlet/DOF
+// numbering, partition renumbering).  No device code here; these functions work
+// without a GPU and are exercised by the CPU test-suite against the oracle.
+#include "pfem_internal.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace pfem;
+
+// ---------------------------------------------------------------------------
+// 1. per-element compat surface
+// ---------------------------------------------------------------------------
+extern "C" int pfem_poisson_tria_ke(const double xNode[3], const double yNode[3],
+                                    const double *elemData, const double *timeData,
+                                    const double valC[3], double K[9], double F[3])
+{
+    if (!xNode || !yNode || !elemData || !timeData || !valC || !K || !F) return PFEM_ERR_ARG;
+    return poisson_tria(xNode, yNode, elemData[0], elemData[1], timeData[1], valC, K, F)
+               ? PFEM_OK : PFEM_ERR_NEG_JAC;
+}
+
+extern "C" int pfem_poisson_tet_ke(const double xNode[4], const double yNode[4],
+                                   const double zNode[4], const double *elemData,
+                                   const double *timeData, const double valC[4], double K[16],
+                                   double F[4])
+{
+    if (!xNode || !yNode || !zNode || !elemData || !timeData || !valC || !K || !F) return PFEM_ERR_ARG;
+    return poisson_tet(xNode, yNode, zNode, elemData[0], elemData[1], elemData[2], timeData[1],
+                       valC, K, F) ? PFEM_OK : PFEM_ERR_NEG_JAC;
+}
+
+extern "C" int pfem_elast_tet_ke(const double xNode[4], const double yNode[4],
+                                 const double zNode[4], const double *elemData,
+                                 const double *timeData, const double valC[12], double K[144],
+                                 double F[12])
+{
+    (void)timeData; (void)valC;  // strain/stress from valC never reach Ke/Fe (:327-355)
+    if (!xNode || !yNode || !zNode || !elemData || !K || !F) return PFEM_ERR_ARG;
+    const double bf[3] = {elemData[3], elemData[4], elemData[5]};
+    return elast_tet(xNode, yNode, zNode, elemData[0], elemData[1], bf, K, F) ? PFEM_OK
+                                                                            : PFEM_ERR_NEG_JAC;
+}
+
+// ---------------------------------------------------------------------------
+// 2. structured box mesh (genTetra.cpp)
+// ---------------------------------------------------------------------------
+namespace {
+
+// The solver only ever sees what it reads back from the "%.8f" text files
+// (genTetra.cpp:187-189, 514-516), so coordinates and BC values go through the
+// same decimal round trip.
+double text_round8(double v)
+{
+    char buf[64];
+    std::snprintf(buf, sizeof buf, "%.8f", v);
+    return std::strtod(buf, nullptr);
+}
+
+// xx = x0; repeat: use xx; xx += dx   (genTetra.cpp:194-216)
+std::vector<double> axis_accumulate(double a0, double a1, int nE)
+{
+    std::vector<double> t(static_cast<size_t>(nE) + 1);
+    const double d = (a1 - a0) / nE;
+    double v = a0;
+    for (int i = 0; i <= nE; ++i) { t[i] = v; v += d; }
+    return t;
+}
+
+}  // namespace
+
+extern "C" int pfem_gen_box_tets(double x0, double x1, int nEx, double y0, double y1, int nEy,
+                                 double z0, double z1, int nEz, int kz0, int kz1, int bc_mode,
+                                 int ndof, double *xyz, int32_t *conn, int64_t *nDBC,
+                                 int32_t *bc_node, int32_t *bc_dof, double *bc_val)
+{
+    if (nEx < 1 || nEy < 1 || nEz < 1 || ndof < 1 || !nDBC) return PFEM_ERR_ARG;
+    if (kz0 < 0 || kz1 > nEz || kz0 > kz1) return PFEM_ERR_ARG;
+    const int nNx = nEx + 1, nNy = nEy + 1, nNz = nEz + 1;
+    const int64_t plane = static_cast<int64_t>(nNx) * nNy;
+    const int64_t nNode = plane * nNz;
+    if (nNode > INT32_MAX) return PFEM_ERR_ARG;
+    const std::vector<double> xs = axis_accumulate(x0, x1, nEx), ys = axis_accumulate(y0, y1, nEy),
+                              zs = axis_accumulate(z0, z1, nEz);
+
+    if (xyz) {
+        std::vector<double> xr(nNx), yr(nNy), zr(nNz);
+        for (int i = 0; i < nNx; ++i) xr[i] = text_round8(xs[i]);
+        for (int j = 0; j < nNy; ++j) yr[j] = text_round8(ys[j]);
+        for (int k = 0; k < nNz; ++k) zr[k] = text_round8(zs[k]);
+        double *X = xyz, *Y = xyz + nNode, *Z = xyz + 2 * nNode;
+#pragma omp parallel for schedule(static)
+        for (int k = 0; k < nNz; ++k)
+            for (int j = 0; j < nNy; ++j) {
+                const int64_t base = plane * k + static_cast<int64_t>(nNx) * j;
+                for (int i = 0; i < nNx; ++i) {
+                    X[base + i] = xr[i];
+                    Y[base + i] = yr[j];
+                    Z[base + i] = zr[k];
+                }
+            }
+    }
+
+    if (conn) {
+        // hex corner ids pts[0..7] and the fixed 6-tet split of genTetra.cpp:263-322
+        static const int split[6][4] = {{0, 1, 3, 5}, {0, 3, 2, 5}, {2, 3, 7, 5},
+                                        {4, 6, 7, 2}, {4, 7, 5, 2}, {0, 4, 5, 2}};
+        const int64_t nElem = 6LL * nEx * nEy * (kz1 - kz0);
+#pragma omp parallel for schedule(static)
+        for (int k = kz0; k < kz1; ++k)
+            for (int j = 0; j < nEy; ++j)
+                for (int i = 0; i < nEx; ++i) {
+                    const int64_t hex = (static_cast<int64_t>(k - kz0) * nEy + j) * nEx + i;
+                    const int64_t lo = plane * k + static_cast<int64_t>(nNx) * j + i;
+                    const int64_t c[8] = {lo, lo + 1, lo + nNx, lo + nNx + 1,
+                                          lo + plane, lo + plane + 1, lo + plane + nNx,
+                                          lo + plane + nNx + 1};
+                    for (int t = 0; t < 6; ++t)
+                        for (int a = 0; a < 4; ++a)
+                            conn[a * nElem + 6 * hex + t] = static_cast<int32_t>(c[split[t][a]]);
+                }
+    }
+
+    // Dirichlet list: ascending unique node ids (sort+unique, genTetra.cpp:505-506)
+    int64_t cnt = 0;
+    for (int k = 0; k < nNz; ++k)
+        for (int j = 0; j < nNy; ++j) {
+            const bool edge_row = (k == 0 || k == nNz - 1 || j == 0 || j == nNy - 1);
+            for (int i = 0; i < nNx; ++i) {
+                const bool on = bc_mode == 0 ? (edge_row || i == 0 || i == nNx - 1) : (j == 0);
+                if (!on) continue;
+                if (bc_node) {
+                    const int64_t node = plane * k + static_cast<int64_t>(nNx) * j + i;
+                    double val = 0.0;
+                    if (bc_mode == 0) {
+                        // vtkPoints stores float; GetPoint widens back (genTetra.cpp:512-520)
+                        const double cx = static_cast<double>(static_cast<float>(xs[i]));
+                        const double cy = static_cast<double>(static_cast<float>(ys[j]));
+                        const double cz = static_cast<double>(static_cast<float>(zs[k]));
+                        val = text_round8(cx * cx + cy * cy + cz * cz);
+                    }
+                    for (int d = 0; d < ndof; ++d) {
+                        bc_node[cnt + d] = static_cast<int32_t>(node);
+                        bc_dof[cnt + d] = d;
+                        bc_val[cnt + d] = val;
+                    }
+                }
+                cnt += ndof;
+            }
+        }
+    *nDBC = cnt;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_partition_box_slabs(int nEx, int nEy, int nEz, int nParts,
+                                        int32_t *elem_proc_id, int32_t *node_proc_id)
+{
+    if (nEx < 1 || nEy < 1 || nEz < 1 || nParts < 1 || nParts > nEz) return PFEM_ERR_ARG;
+    std::vector<int32_t> layer_part(nEz);
+    for (int p = 0; p < nParts; ++p) {
+        const int lo = static_cast<int>(static_cast<int64_t>(p) * nEz / nParts);
+        const int hi = static_cast<int>(static_cast<int64_t>(p + 1) * nEz / nParts);
+        for (int k = lo; k < hi; ++k) layer_part[k] = p;
+    }
+    if (elem_proc_id) {
+        const int64_t per_layer = 6LL * nEx * nEy;
+        for (int k = 0; k < nEz; ++k)
+            std::fill(elem_proc_id + per_layer * k, elem_proc_id + per_layer * (k + 1), layer_part[k]);
+    }
+    if (node_proc_id) {
+        // node plane k is touched by hex layers k-1 and k: the lowest part wins
+        const int64_t plane = static_cast<int64_t>(nEx + 1) * (nEy + 1);
+        for (int k = 0; k <= nEz; ++k)
+            std::fill(node_proc_id + plane * k, node_proc_id + plane * (k + 1),
+                      layer_part[k > 0 ? k - 1 : 0]);
+    }
+    return PFEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// 3. Dirichlet bookkeeping and (re)numbering (tetrapoissonparallelimpl1.F)
+// ---------------------------------------------------------------------------
+extern "C" int pfem_dof_numbering(int64_t nNode, int ndof, int64_t nDBC, const int32_t *dbc_node,
+                                  const int32_t *dbc_dof, const double *dbc_val, int nParts,
+                                  const int32_t *node_proc_id, int32_t *node_map_get_old,
+                                  int32_t *node_map_get_new, int32_t *NodeDofArrayNew,
+                                  double *solnApplied, int64_t *node_start, int64_t *node_end,
+                                  int64_t *row_start, int64_t *row_end, int64_t *size_global)
+{
+    if (nNode < 1 || ndof < 1 || nParts < 1 || !node_map_get_old || !node_map_get_new ||
+        !NodeDofArrayNew || !solnApplied || !node_start || !node_end || !row_start || !row_end ||
+        !size_global || (nDBC > 0 && (!dbc_node || !dbc_dof || !dbc_val)) ||
+        (nParts > 1 && !node_proc_id))
+        return PFEM_ERR_ARG;
+    const int64_t nd = nNode * ndof;
+
+    // NodeTypeOld / solnApplied at OLD ids (:341-355)
+    std::vector<uint8_t> constrained_old(nd, 0);
+    std::fill(solnApplied, solnApplied + nd, 0.0);
+    for (int64_t b = 0; b < nDBC; ++b) {
+        if (dbc_node[b] < 0 || dbc_node[b] >= nNode || dbc_dof[b] < 0 || dbc_dof[b] >= ndof)
+            return PFEM_ERR_ARG;
+        const int64_t slot = static_cast<int64_t>(dbc_node[b]) * ndof + dbc_dof[b];
+        constrained_old[slot] = 1;
+        solnApplied[slot] = dbc_val[b];
+    }
+
+    if (nParts == 1) {  // :402-421
+        for (int64_t n = 0; n < nNode; ++n) node_map_get_old[n] = node_map_get_new[n] = static_cast<int32_t>(n);
+        node_start[0] = 0;
+        node_end[0] = nNode;
+    } else {
+        // NEW numbering = ranks concatenated, ascending OLD id inside a rank
+        // (locally_owned_nodes + MPI_Allgatherv, :541-566): a stable counting sort.
+        std::vector<int64_t> first(static_cast<size_t>(nParts) + 1, 0);
+        for (int64_t n = 0; n < nNode; ++n) {
+            const int32_t p = node_proc_id[n];
+            if (p < 0 || p >= nParts) return PFEM_ERR_ARG;
+            ++first[p + 1];
+        }
+        for (int p = 0; p < nParts; ++p) first[p + 1] += first[p];
+        for (int p = 0; p < nParts; ++p) { node_start[p] = first[p]; node_end[p] = first[p + 1]; }
+        std::vector<int64_t> cursor(first.begin(), first.end() - 1);
+        for (int64_t n = 0; n < nNode; ++n) {
+            const int64_t nn = cursor[node_proc_id[n]]++;
+            node_map_get_old[nn] = static_cast<int32_t>(n);
+            node_map_get_new[n] = static_cast<int32_t>(nn);     // :588-595
+        }
+        // BC values re-entered at NEW ids; the OLD-id entries are not cleared (:668-677)
+        for (int64_t b = 0; b < nDBC; ++b)
+            solnApplied[static_cast<int64_t>(node_map_get_new[dbc_node[b]]) * ndof + dbc_dof[b]] = dbc_val[b];
+    }
+
+    // free dofs numbered in NEW node order (:357-367 / :601-612)
+    int64_t next = 0;
+    for (int64_t nn = 0; nn < nNode; ++nn) {
+        const int64_t old = node_map_get_old[nn];
+        for (int d = 0; d < ndof; ++d)
+            NodeDofArrayNew[nn * ndof + d] = constrained_old[old * ndof + d] ? -1 : static_cast<int32_t>(next++);
+    }
+    if (next > INT32_MAX) return PFEM_ERR_ARG;
+    *size_global = next;
+
+    // contiguous row block per rank (:622-636); an empty block sits at the previous end
+    int64_t prev_end = 0;
+    for (int p = 0; p < nParts; ++p) {
+        int64_t lo = -1, hi = -1;
+        for (int64_t nn = node_start[p]; nn < node_end[p] && lo < 0; ++nn)
+            for (int d = 0; d < ndof; ++d)
+                if (NodeDofArrayNew[nn * ndof + d] >= 0) { lo = NodeDofArrayNew[nn * ndof + d]; break; }
+        for (int64_t nn = node_end[p] - 1; nn >= node_start[p] && hi < 0; --nn)
+            for (int d = ndof - 1; d >= 0; --d)
+                if (NodeDofArrayNew[nn * ndof + d] >= 0) { hi = NodeDofArrayNew[nn * ndof + d] + 1; break; }
+        if (lo < 0) { lo = prev_end; hi = prev_end; }
+        row_start[p] = lo;
+        row_end[p] = hi;
+        prev_end = hi;
+    }
+    return PFEM_OK;
+}
+
+extern "C" int pfem_elem_dof_array(int64_t nElem, int npElem, int ndof, const int32_t *conn_new,
+                                   const int32_t *NodeDofArrayNew, int32_t *edof)
+{
+    if (nElem < 0 || npElem < 1 || ndof < 1 || !conn_new || !NodeDofArrayNew || !edof) return PFEM_ERR_ARG;
+    for (int i = 0; i < npElem; ++i)
+        for (int d = 0; d < ndof; ++d) {
+            const int32_t *c = conn_new + static_cast<int64_t>(i) * nElem;
+            int32_t *o = edof + static_cast<int64_t>(i * ndof + d) * nElem;
+#pragma omp parallel for schedule(static)
+            for (int64_t e = 0; e < nElem; ++e) o[e] = NodeDofArrayNew[static_cast<int64_t>(c[e]) * ndof + d];
+        }
+    return PFEM_OK;
+}
+
+extern "C" int pfem_assy_for_soln(int64_t nNode, int ndof, const int32_t *NodeDofArrayNew,
+                                  int32_t *assyForSoln)
+{
+    if (nNode < 0 || ndof < 1 || !NodeDofArrayNew || !assyForSoln) return PFEM_ERR_ARG;
+    int64_t k = 0;
+    for (int64_t s = 0; s < nNode * ndof; ++s)
+        if (NodeDofArrayNew[s] >= 0) assyForSoln[k++] = static_cast<int32_t>(s);
+    return PFEM_OK;
+}

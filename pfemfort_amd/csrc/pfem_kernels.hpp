@@ -1,0 +1,611 @@
+// pfem_kernels.hpp -- gfx950 device kernels of the hot path (included once by pfem_device.hip).
+//
+// Data layout in HBM (all SoA, coalesced in the element / row index):
+//   mesh     conn[a][e] int32, edof[i][e] int32 (LOCAL dof ids, -1 = Dirichlet),
+//            xyz[d][n] f64, solnApplied[n*ndof+d] f64
+//   matrix   wave-sliced CSR ("SELL-64"): rows are grouped in slices of 64 (one
+//            wavefront); inside a slice entry k of lane l sits at
+//            slice_off[s] + 64*k + l, so one wave-wide load of entry k is 512 B (f64
+//            values) / 256 B (int32 columns) contiguous.  Columns ascending per row,
+//            rows padded to the slice width with (col = own row, val = 0).
+//   vectors  f64[n_local], owned rows first, ghost rows after.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "pfem_elem.hpp"
+
+namespace pfem {
+
+constexpr int kBlock = 256;        // 4 wavefronts
+constexpr int kMaxGrid = 2048;     // 8 blocks per CU x 256 CUs; also the partial-sum capacity
+constexpr int kXcds = 8;
+
+struct MeshDev {
+    int kind, npe, ndof, nsize, ndim;
+    int64_t nElem, nNode;
+    const int32_t *conn;
+    const int32_t *edof;
+    const double *xyz;
+    const double *soln;
+};
+
+struct SellDev {
+    int64_t n_rows;       // n_local
+    int64_t n_slices;
+    const int64_t *slice_off;  // [n_slices+1], in entries
+    const int32_t *rowlen;     // [n_rows]
+    const int32_t *cols;
+    double *vals;
+};
+
+struct ElemPrm {
+    double ed[6];   // elemData
+    double af;      // timeData(2)
+};
+
+// ---------------------------------------------------------------------------
+// wave / block reductions (wave = 64 lanes)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// Sum over the 256 threads of the block; result valid in every thread.  `sm` has
+// >= 4 doubles.  Fixed association order -> bitwise reproducible.
+__device__ __forceinline__ double block_sum(double v, double *sm)
+{
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) sm[w] = v;
+    __syncthreads();
+    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+// Every block sums the same `n` per-block partials in the same order, so all blocks
+// (and all runs) obtain the same bits without a separate reduction launch.
+__device__ __forceinline__ double sum_partials(const double *part, int n, double *sm)
+{
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += kBlock) a += part[i];
+    return block_sum(a, sm);
+}
+
+// ---------------------------------------------------------------------------
+// symbolic phase
+// ---------------------------------------------------------------------------
+constexpr uint64_t kNoKey = ~0ull;
+
+// (row,col) key of every element-matrix entry: the INSERT_VALUES pass of
+// tetrapoissonparallelimpl1.F:791-802, negative indices ignored.
+__global__ void __launch_bounds__(kBlock) k_emit_keys(MeshDev m, uint64_t *keys)
+{
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (e >= m.nElem) return;
+    int32_t dof[12];
+    for (int i = 0; i < m.nsize; ++i) dof[i] = m.edof[i * m.nElem + e];
+    for (int i = 0; i < m.nsize; ++i)
+        for (int j = 0; j < m.nsize; ++j) {
+            const bool ok = dof[i] >= 0 && dof[j] >= 0;
+            keys[(static_cast<int64_t>(i) * m.nsize + j) * m.nElem + e] =
+                ok ? (static_cast<uint64_t>(static_cast<uint32_t>(dof[i])) << 32) | static_cast<uint32_t>(dof[j])
+                   : kNoKey;
+        }
+}
+
+// rowptr from the sorted unique keys (rows without entries get empty ranges)
+__global__ void __launch_bounds__(kBlock) k_row_bounds(const uint64_t *keys, int64_t nnz, int64_t n_rows,
+                                                        int64_t *rowptr)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (nnz == 0) {
+        if (i <= n_rows) rowptr[i] = 0;
+        return;
+    }
+    if (i >= nnz) return;
+    const int64_t r = static_cast<int64_t>(keys[i] >> 32);
+    const int64_t rp = i ? static_cast<int64_t>(keys[i - 1] >> 32) : -1;
+    for (int64_t rr = rp + 1; rr <= r; ++rr) rowptr[rr] = i;
+    if (i == nnz - 1)
+        for (int64_t rr = r + 1; rr <= n_rows; ++rr) rowptr[rr] = nnz;
+}
+
+// per-slice padded size in entries (64 * max row length); one thread per slice
+__global__ void __launch_bounds__(kBlock) k_slice_sizes(const int64_t *rowptr, int64_t n_rows, int64_t n_slices,
+                                                         int32_t *rowlen, int64_t *slice_entries)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    int len = 0;
+    if (r < n_rows) {
+        len = static_cast<int>(rowptr[r + 1] - rowptr[r]);
+        rowlen[r] = len;
+    }
+    // wave == slice: max over the 64 lanes
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_xor(len, o, 64));
+    const int64_t s = r >> 6;
+    if ((threadIdx.x & 63) == 0 && s < n_slices) slice_entries[s] = 64LL * len;
+    if (r == 0) slice_entries[n_slices] = 0;
+}
+
+__global__ void __launch_bounds__(kBlock) k_fill_sell(const uint64_t *keys, const int64_t *rowptr, int64_t n_rows,
+                                                       int64_t n_slices, const int64_t *slice_off, int32_t *cols)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t s = r >> 6;
+    if (s >= n_slices) return;
+    const int64_t off = slice_off[s] + (r & 63);
+    const int width = static_cast<int>((slice_off[s + 1] - slice_off[s]) >> 6);
+    int64_t p0 = 0;
+    int len = 0;
+    if (r < n_rows) { p0 = rowptr[r]; len = static_cast<int>(rowptr[r + 1] - p0); }
+    const int32_t pad = r < n_rows ? static_cast<int32_t>(r) : 0;
+    for (int k = 0; k < width; ++k)
+        cols[off + 64LL * k] = k < len ? static_cast<int32_t>(keys[p0 + k] & 0xffffffffu) : pad;
+}
+
+// global -> local dof ids (multi-rank): owned rows [row_start,row_start+n_owned) first,
+// ghosts after, ascending global id
+__global__ void __launch_bounds__(kBlock) k_localize_dofs(int32_t *edof, int64_t count, int64_t row_start,
+                                                           int64_t n_owned, const int64_t *ghost_gid, int64_t n_ghost)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= count) return;
+    const int64_t g = edof[i];
+    if (g < 0) return;
+    if (g >= row_start && g < row_start + n_owned) { edof[i] = static_cast<int32_t>(g - row_start); return; }
+    int64_t lo = 0, hi = n_ghost;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ghost_gid[mid] < g) lo = mid + 1; else hi = mid; }
+    edof[i] = static_cast<int32_t>(n_owned + lo);
+}
+
+// ---------------------------------------------------------------------------
+// numeric assembly: one thread per element
+// ---------------------------------------------------------------------------
+// slot of (row,col) in the wave-sliced storage, -1 if not in the pattern
+__device__ __forceinline__ int64_t find_slot(const SellDev &A, int row, int col)
+{
+    const int64_t base = A.slice_off[row >> 6] + (row & 63);
+    int lo = 0, hi = A.rowlen[row] - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const int c = A.cols[base + (static_cast<int64_t>(mid) << 6)];
+        if (c == col) return base + (static_cast<int64_t>(mid) << 6);
+        if (c < col) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+
+__device__ __forceinline__ void add_f64(double *p, double v)
+{
+    // hardware global_atomic_add_f64 (-munsafe-fp-atomics), device scope
+    atomicAdd(p, v);
+}
+
+// Poisson tet / tria (1 dof per node): Ke + Fe, Dirichlet lifting, scatter.
+//   MatSetValues reads the column-major Klocal row-major, i.e. entry (row_i,col_j)
+//   receives Klocal(j,i) (tetrapoissonparallelimpl1.F:851); lifting :859-870;
+//   VecSetValues :880.
+template <int KIND>
+__global__ void __launch_bounds__(kBlock) k_assemble_scalar(MeshDev m, SellDev A, double *rhs, ElemPrm prm, int *err)
+{
+    constexpr int NPE = (KIND == PFEM_POISSON_TET) ? 4 : 3;
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (e >= m.nElem) return;
+    int nd[NPE], dof[NPE];
+    double x[NPE], y[NPE], z[NPE];
+#pragma unroll
+    for (int a = 0; a < NPE; ++a) {
+        nd[a] = m.conn[a * m.nElem + e];
+        dof[a] = m.edof[a * m.nElem + e];
+    }
+#pragma unroll
+    for (int a = 0; a < NPE; ++a) {
+        x[a] = m.xyz[nd[a]];
+        y[a] = m.xyz[m.nNode + nd[a]];
+        z[a] = (KIND == PFEM_POISSON_TET) ? m.xyz[2 * m.nNode + nd[a]] : 0.0;
+    }
+    double K[NPE * NPE], F[NPE];
+    const double valC[4] = {0.0, 0.0, 0.0, 0.0};   // drivers pass valC = 0 (:824)
+    bool ok;
+    if constexpr (KIND == PFEM_POISSON_TET)
+        ok = poisson_tet(x, y, z, prm.ed[0], prm.ed[1], prm.ed[2], prm.af, valC, K, F);
+    else if constexpr (KIND == PFEM_POISSON_TRIA)
+        ok = poisson_tria(x, y, prm.ed[0], prm.ed[1], prm.af, valC, K, F);
+    else
+        ok = poisson_tria_inline(x, y, K, F);
+    if (!ok) { atomicMax(err, PFEM_ERR_NEG_JAC); return; }
+#pragma unroll
+    for (int i = 0; i < NPE; ++i)
+        if (dof[i] < 0) {
+            const double fact = m.soln[nd[i]];
+#pragma unroll
+            for (int j = 0; j < NPE; ++j)
+                if (dof[j] >= 0) F[j] = F[j] - K[j + NPE * i] * fact;
+        }
+#pragma unroll
+    for (int i = 0; i < NPE; ++i) {
+        if (dof[i] < 0) continue;
+#pragma unroll
+        for (int j = 0; j < NPE; ++j) {
+            if (dof[j] < 0) continue;
+            const int64_t s = find_slot(A, dof[i], dof[j]);
+            if (s < 0) { atomicMax(err, PFEM_ERR_PATTERN); continue; }
+            add_f64(&A.vals[s], K[j + NPE * i]);
+        }
+        add_f64(&rhs[dof[i]], F[i]);
+    }
+}
+
+// Linear elasticity tet (3 dofs per node).  The 12x12 Ke is never materialised: the
+// B^T (D B) contraction is streamed as sixteen 3x3 node blocks from registers
+// (pfem_elem.hpp: elast_block) straight into lifting + scatter.  A node's free dofs
+// are consecutive global ids, hence consecutive entries of a sorted row, so one
+// binary search per (row, node) serves up to three columns.
+__global__ void __launch_bounds__(kBlock) k_assemble_elast(MeshDev m, SellDev A, double *rhs, ElemPrm prm, int *err)
+{
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (e >= m.nElem) return;
+    int nd[4], dof[12];
+    double x[4], y[4], z[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) nd[a] = m.conn[a * m.nElem + e];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) dof[i] = m.edof[i * m.nElem + e];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        x[a] = m.xyz[nd[a]];
+        y[a] = m.xyz[m.nNode + nd[a]];
+        z[a] = m.xyz[2 * m.nNode + nd[a]];
+    }
+    TetGeom g;
+    tet_geometry(x, y, z, g);
+    if (g.jac < 0.0) { atomicMax(err, PFEM_ERR_NEG_JAC); return; }
+    const double dvol = kGaussWtTet * g.jac;
+    const ElastMat mat = elast_material(prm.ed[0], prm.ed[1]);
+    double F[12];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const double b4 = dvol * 0.25;
+        F[3 * a + 0] = 0.0 + b4 * prm.ed[3];
+        F[3 * a + 1] = 0.0 + b4 * prm.ed[4];
+        F[3 * a + 2] = 0.0 + b4 * prm.ed[5];
+    }
+    // Dirichlet values of the constrained dofs (solnApplied(elemDofGlobal), :938-950)
+    double fact[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) fact[i] = dof[i] < 0 ? m.soln[3LL * nd[i / 3] + i % 3] : 0.0;
+
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            double blk[3][3];
+            elast_block(g, mat, dvol, a, b, blk);   // blk[p][q] = Klocal(3a+p, 3b+q)
+            // lifting: Flocal(3a+p) -= Klocal(3a+p, 3b+q) * u_D(3b+q), q ascending
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (dof[3 * b + q] < 0) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        if (dof[3 * a + p] >= 0) F[3 * a + p] = F[3 * a + p] - blk[p][q] * fact[3 * b + q];
+                }
+            // MatSetValues row-major read: entry (row = dof(3b+q), col = dof(3a+p)) += Klocal(3a+p,3b+q)
+            int firstp = -1;
+#pragma unroll
+            for (int p = 2; p >= 0; --p)
+                if (dof[3 * a + p] >= 0) firstp = p;
+            if (firstp < 0) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int row = dof[3 * b + q];
+                if (row < 0) continue;
+                int64_t s = find_slot(A, row, dof[3 * a + firstp]);
+                if (s < 0) { atomicMax(err, PFEM_ERR_PATTERN); continue; }
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    if (dof[3 * a + p] < 0) continue;
+                    add_f64(&A.vals[s], blk[p][q]);
+                    s += 64;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+        if (dof[i] >= 0) add_f64(&rhs[dof[i]], F[i]);
+}
+
+// Parity inspection: Ke/Fe of every element exactly as the assembly kernels compute them.
+__global__ void __launch_bounds__(kBlock) k_eval_elems(MeshDev m, ElemPrm prm, double *Kout, double *Fout, int *err)
+{
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (e >= m.nElem) return;
+    double x[4], y[4], z[4];
+    for (int a = 0; a < m.npe; ++a) {
+        const int n = m.conn[a * m.nElem + e];
+        x[a] = m.xyz[n];
+        y[a] = m.xyz[m.nNode + n];
+        z[a] = m.ndim == 3 ? m.xyz[2 * m.nNode + n] : 0.0;
+    }
+    const double valC[4] = {0.0, 0.0, 0.0, 0.0};
+    double *K = Kout + e * m.nsize * m.nsize, *F = Fout + e * m.nsize;
+    bool ok = false;
+    switch (m.kind) {
+    case PFEM_POISSON_TET: ok = poisson_tet(x, y, z, prm.ed[0], prm.ed[1], prm.ed[2], prm.af, valC, K, F); break;
+    case PFEM_POISSON_TRIA: ok = poisson_tria(x, y, prm.ed[0], prm.ed[1], prm.af, valC, K, F); break;
+    case PFEM_POISSON_TRIA_INLINE: ok = poisson_tria_inline(x, y, K, F); break;
+    case PFEM_ELAST_TET: {
+        const double bf[3] = {prm.ed[3], prm.ed[4], prm.ed[5]};
+        ok = elast_tet(x, y, z, prm.ed[0], prm.ed[1], bf, K, F);
+        break;
+    }
+    }
+    if (!ok) atomicMax(err, PFEM_ERR_NEG_JAC);
+}
+
+// ---------------------------------------------------------------------------
+// matrix utilities
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_sell_to_csr(SellDev A, const int64_t *rowptr, int32_t *cols, double *vals)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (r >= A.n_rows) return;
+    const int64_t base = A.slice_off[r >> 6] + (r & 63);
+    const int64_t p0 = rowptr[r];
+    const int len = A.rowlen[r];
+    for (int k = 0; k < len; ++k) {
+        if (cols) cols[p0 + k] = A.cols[base + 64LL * k];
+        if (vals) vals[p0 + k] = A.vals[base + 64LL * k];
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_csr_vals_to_sell(SellDev A, const int64_t *rowptr, const double *vals)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (r >= A.n_rows) return;
+    const int64_t base = A.slice_off[r >> 6] + (r & 63);
+    const int64_t p0 = rowptr[r];
+    const int len = A.rowlen[r];
+    for (int k = 0; k < len; ++k) A.vals[base + 64LL * k] = vals[p0 + k];
+}
+
+__global__ void __launch_bounds__(kBlock) k_extract_diag(SellDev A, double *diag)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (r >= A.n_rows) return;
+    const int64_t s = find_slot(A, static_cast<int>(r), static_cast<int>(r));
+    diag[r] = s >= 0 ? A.vals[s] : 0.0;
+}
+
+__global__ void __launch_bounds__(kBlock) k_invert(double *d, int64_t n)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n) d[i] = 1.0 / d[i];
+}
+
+// ---------------------------------------------------------------------------
+// SpMV  y = A x  on the wave-sliced storage: one lane per row, one wave per slice.
+// The roofline kernel: per row it streams 12 B per stored entry (f64 value + int32
+// column), gathers x through L1/L2 (banded reuse) and writes 8 B.
+//
+// Work distribution is XCD-aware: the dispatcher places block b on XCD b % 8, so
+// block b works on the (b % 8)-th contiguous eighth of the slices; the x-gather
+// window of an XCD then stays inside its private 4 MiB L2.
+// With WITH_DOT the kernel also emits the per-block partial of x.y over rows
+// < n_dot (CG's (p, Ap)).
+// ---------------------------------------------------------------------------
+struct CgCtl {            // device-resident control block of the CG iteration
+    double beta[2];       // (r,z) ping-pong by iteration parity
+    double rn0, ttol;     // ||z0||, max(rtol*rn0, abstol)
+    double rn;            // last preconditioned residual norm
+    double dtol;
+    int flag;             // 0 = running, else KSPConvergedReason
+    int its;              // iterations completed
+};
+
+template <bool WITH_DOT>
+__global__ void __launch_bounds__(kBlock) k_spmv(SellDev A, const double *__restrict__ x, double *__restrict__ y,
+                                                  int64_t n_dot, double *partial, const CgCtl *ctl)
+{
+    __shared__ double sm[4];
+    if (WITH_DOT && ctl->flag != 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // XCD-aware slice-group assignment (group = 4 slices = one block iteration)
+    const int64_t groups = (A.n_slices + 3) >> 2;
+    int64_t g_lo, g_hi, g_step, g_first;
+    if (gridDim.x >= kXcds && (gridDim.x % kXcds) == 0) {
+        const int xcd = blockIdx.x % kXcds, bi = blockIdx.x / kXcds, nb = gridDim.x / kXcds;
+        g_lo = groups * xcd / kXcds;
+        g_hi = groups * (xcd + 1) / kXcds;
+        g_first = g_lo + bi;
+        g_step = nb;
+    } else {
+        g_lo = 0; g_hi = groups; g_first = blockIdx.x; g_step = gridDim.x;
+    }
+    (void)g_lo;
+    double dot = 0.0;
+    for (int64_t g = g_first; g < g_hi; g += g_step) {
+        const int64_t s = (g << 2) + wave;
+        if (s >= A.n_slices) continue;
+        const int64_t off = A.slice_off[s];
+        const int width = static_cast<int>((A.slice_off[s + 1] - off) >> 6);
+        const int32_t *__restrict__ cp = A.cols + off + lane;
+        const double *__restrict__ vp = A.vals + off + lane;
+        double acc = 0.0;
+        int k = 0;
+        for (; k + 4 <= width; k += 4) {
+            const int c0 = cp[64 * k], c1 = cp[64 * (k + 1)], c2 = cp[64 * (k + 2)], c3 = cp[64 * (k + 3)];
+            const double v0 = vp[64 * k], v1 = vp[64 * (k + 1)], v2 = vp[64 * (k + 2)], v3 = vp[64 * (k + 3)];
+            const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+            acc = __builtin_fma(v0, x0, acc);
+            acc = __builtin_fma(v1, x1, acc);
+            acc = __builtin_fma(v2, x2, acc);
+            acc = __builtin_fma(v3, x3, acc);
+        }
+        for (; k < width; ++k) acc = __builtin_fma(vp[64 * k], x[cp[64 * k]], acc);
+        const int64_t row = (s << 6) + lane;
+        if (row < A.n_rows) {
+            y[row] = acc;
+            if (WITH_DOT && row < n_dot) dot = __builtin_fma(x[row], acc, dot);
+        }
+    }
+    if (WITH_DOT) {
+        const double t = block_sum(dot, sm);
+        if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Jacobi-PCG vector kernels (PETSc KSPCG semantics)
+// ---------------------------------------------------------------------------
+// x = 0, r = b, p = z = r*dinv; partials of (r,z) and (z,z) over the owned rows.
+__global__ void __launch_bounds__(kBlock) k_cg_init(int64_t n, int64_t n_owned, const double *__restrict__ b,
+                                                     const double *__restrict__ dinv, double *__restrict__ x,
+                                                     double *__restrict__ r, double *__restrict__ p,
+                                                     double *part_rz, double *part_zz)
+{
+    __shared__ double sm[4];
+    double rz = 0.0, zz = 0.0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const double ri = b[i], zi = ri * dinv[i];
+        x[i] = 0.0;
+        r[i] = ri;
+        p[i] = zi;
+        if (i < n_owned) { rz = __builtin_fma(ri, zi, rz); zz = __builtin_fma(zi, zi, zz); }
+    }
+    const double a = block_sum(rz, sm), c = block_sum(zz, sm);
+    if (threadIdx.x == 0) { part_rz[blockIdx.x] = a; part_zz[blockIdx.x] = c; }
+}
+
+// one block: finish the initial reductions, set tolerances (KSPConvergedDefault)
+__global__ void __launch_bounds__(kBlock) k_cg_start(CgCtl *ctl, const double *part_rz, const double *part_zz, int nparts,
+                                                      const double *reduced /*[rz,zz] or null*/, double rtol, double abstol,
+                                                      double dtol, double *hist)
+{
+    __shared__ double sm[4];
+    double rz, zz;
+    if (reduced) { rz = reduced[0]; zz = reduced[1]; }
+    else { rz = sum_partials(part_rz, nparts, sm); zz = sum_partials(part_zz, nparts, sm); }
+    if (threadIdx.x == 0) {
+        const double rn0 = sqrt(zz);
+        ctl->beta[0] = rz;
+        ctl->beta[1] = 0.0;
+        ctl->rn0 = rn0;
+        ctl->rn = rn0;
+        ctl->ttol = fmax(rtol * rn0, abstol);
+        ctl->dtol = dtol;
+        ctl->its = 0;
+        ctl->flag = (rn0 <= abstol) ? 3 : ((rz < 0.0) ? -8 : 0);
+        hist[0] = rn0;
+    }
+}
+
+// alpha = beta/(p,w); x += alpha p; r -= alpha w; partials of (r,z), (z,z), z = r*dinv
+__global__ void __launch_bounds__(kBlock) k_cg_update(CgCtl *ctl, int it, int64_t n, int64_t n_owned,
+                                                       const double *part_pw, int nparts, const double *reduced_pw,
+                                                       const double *__restrict__ p, const double *__restrict__ w,
+                                                       const double *__restrict__ dinv, double *__restrict__ x,
+                                                       double *__restrict__ r, double *part_rz, double *part_zz)
+{
+    __shared__ double sm[4];
+    if (ctl->flag != 0) return;
+    const double pw = reduced_pw ? *reduced_pw : sum_partials(part_pw, nparts, sm);
+    if (!(pw > 0.0)) {                      // KSP_DIVERGED_INDEFINITE_MAT
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->its = it; }
+        part_rz[blockIdx.x] = 0.0; part_zz[blockIdx.x] = -1.0;   // signals breakdown to k_cg_direction
+        return;
+    }
+    const double alpha = ctl->beta[it & 1] / pw;
+    double rz = 0.0, zz = 0.0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        x[i] = __builtin_fma(alpha, p[i], x[i]);
+        const double ri = __builtin_fma(-alpha, w[i], r[i]);
+        r[i] = ri;
+        const double zi = ri * dinv[i];
+        if (i < n_owned) { rz = __builtin_fma(ri, zi, rz); zz = __builtin_fma(zi, zi, zz); }
+    }
+    const double a = block_sum(rz, sm), c = block_sum(zz, sm);
+    if (threadIdx.x == 0) { part_rz[blockIdx.x] = a; part_zz[blockIdx.x] = c; }
+}
+
+// finish (r,z), ||z||; convergence test; p = z + (beta_new/beta) p
+__global__ void __launch_bounds__(kBlock) k_cg_direction(CgCtl *ctl, int it, int64_t n, const double *part_rz,
+                                                          const double *part_zz, int nparts, const double *reduced,
+                                                          const double *__restrict__ r, const double *__restrict__ dinv,
+                                                          double *__restrict__ p, double *hist, int hist_cap, int maxits)
+{
+    __shared__ double sm[4];
+    if (ctl->flag != 0) return;
+    double rz, zz;
+    if (reduced) { rz = reduced[0]; zz = reduced[1]; }
+    else { rz = sum_partials(part_rz, nparts, sm); zz = sum_partials(part_zz, nparts, sm); }
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    if (zz < 0.0) {                          // breakdown flagged by k_cg_update
+        if (lead) { ctl->flag = -7; ctl->its = it + 1; }
+        return;
+    }
+    const double rn = sqrt(zz);
+    const double beta_old = ctl->beta[it & 1];
+    int flag = 0;
+    if (rn <= ctl->ttol) flag = 2;           // KSP_CONVERGED_RTOL (or ATOL, resolved on the host)
+    else if (rn >= ctl->dtol * ctl->rn0) flag = -4;
+    else if (rz < 0.0) flag = -8;            // KSP_DIVERGED_INDEFINITE_PC
+    else if (it + 1 >= maxits) flag = -3;
+    if (lead) {
+        ctl->beta[(it + 1) & 1] = rz;
+        ctl->rn = rn;
+        ctl->its = it + 1;
+        if (it + 1 < hist_cap) hist[it + 1] = rn;
+        // written last: other blocks of THIS launch read only beta[it&1]/ttol/dtol/rn0
+    }
+    if (flag != 0) {
+        // every block reaches the same decision from the same bits; flag is published for
+        // the kernels of the following launches
+        if (lead) ctl->flag = flag;
+        return;
+    }
+    const double bb = rz / beta_old;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * kBlock)
+        p[i] = __builtin_fma(bb, p[i], r[i] * dinv[i]);
+}
+
+// ---------------------------------------------------------------------------
+// interface exchange (multi-GPU, sub-assembled rows)
+// ---------------------------------------------------------------------------
+// buf[slot] = v[lidx]; the extra block reduces `n_extra` partial arrays into buf[n_iface+j]
+__global__ void __launch_bounds__(kBlock) k_pack(const double *__restrict__ v, const int32_t *__restrict__ lidx,
+                                                  const int32_t *__restrict__ slot, int64_t n_shared, double *buf,
+                                                  int64_t n_iface, const double *part0, const double *part1, int nparts,
+                                                  int n_extra, const CgCtl *ctl)
+{
+    __shared__ double sm[4];
+    if (ctl && ctl->flag != 0) return;
+    if (blockIdx.x == gridDim.x - 1) {
+        if (n_extra > 0) { const double a = sum_partials(part0, nparts, sm); if (threadIdx.x == 0) buf[n_iface] = a; }
+        if (n_extra > 1) { const double a = sum_partials(part1, nparts, sm); if (threadIdx.x == 0) buf[n_iface + 1] = a; }
+        return;
+    }
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (v && i < n_shared) buf[slot[i]] = v[lidx[i]];
+}
+
+__global__ void __launch_bounds__(kBlock) k_unpack(double *__restrict__ v, const int32_t *__restrict__ lidx,
+                                                    const int32_t *__restrict__ slot, int64_t n_shared, const double *buf,
+                                                    const CgCtl *ctl)
+{
+    if (ctl && ctl->flag != 0) return;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n_shared) v[lidx[i]] = buf[slot[i]];
+}
+
+}  // namespace pfem

@@ -1,0 +1,146 @@
+"""The reference's driver programs on top of the C ABI.
+
+``tetrapoissonparallelimpl1`` / ``tetraelasticityparallelimpl1`` / ``triapoissonserialimpl1``
+follow the PROGRAMs of the same name step by step (file:line cited inline): read or take a
+mesh, Dirichlet bookkeeping, (re)numbering, ElemDofArray, pattern, element loop, solve,
+gather.  Two element-loop modes:
+
+* ``mode="batched"`` (default): the element loop is one device call (``pfem_assemble``).
+* ``mode="compat"``: the loop is spelled out exactly like the Fortran -- one
+  ``StiffnessResidual*`` call per element, ``MatSetValues`` / ``VecSetValues`` with
+  ADD_VALUES, Dirichlet lifting on the host -- and only the solve runs on the GPU.  This
+  is what an unchanged Fortran driver does through the Fortran shim.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib as L
+from . import host as H
+from .solver import ADD_VALUES, INSERT_VALUES, PetscSolver
+
+
+@dataclass
+class Result:
+    kind: int
+    mesh: H.Mesh
+    dm: H.DofMap
+    solver: PetscSolver
+    soln_free: np.ndarray            # solution by free dof (NEW numbering), what temp.dat lists
+    solnVTK: np.ndarray              # (nNode, ndof) by OLD node id, Dirichlet values filled in
+    its: int
+    reason: int
+    rnorm: float
+    timers: dict = field(default_factory=dict)
+
+    def temp_dat(self):
+        """Rows of the reference's ``temp.dat`` dump (tetrapoissonparallelimpl1.F:935-942):
+        (ii, old node id, value), 1-based like the file (ndof=1) ."""
+        assy = H.assy_for_soln(self.dm.NodeDofArrayNew)
+        ndof = self.dm.NodeDofArrayNew.shape[1]
+        if ndof == 1:
+            ind = self.dm.node_map_get_old[assy] + 1
+        else:   # tetraelasticityparallelimpl1.F:1034-1050
+            ind = self.dm.node_map_get_old[assy // ndof] * ndof + assy % ndof + 1
+        return np.arange(1, len(assy) + 1), ind, self.soln_free
+
+
+def _setup(kind, mesh: H.Mesh, nParts=1, node_proc_id=None):
+    ndof = L.NDOF[kind]
+    # NodeTypeOld / solnApplied / NodeDofArray*, node maps  (:316-367, :393-679)
+    dm = H.dof_numbering(mesh.nNode, ndof, mesh.bc_node, mesh.bc_dof, mesh.bc_val, nParts, node_proc_id)
+    conn_new = dm.node_map_get_new[mesh.conn].astype(np.int32)           # :659-664
+    xyz_new = np.ascontiguousarray(mesh.xyz[:, dm.node_map_get_old])     # coords(node_map_get_old(.)) :832-838
+    edof = H.elem_dof_array(conn_new, dm.NodeDofArrayNew)                # :698-713
+    return dm, conn_new, xyz_new, edof
+
+
+def _finish(kind, mesh, dm, solver, its, reason, rnorm, timers, u_free):
+    ndof = L.NDOF[kind]
+    full = dm.solnApplied.reshape(-1, ndof).copy()                       # :914-918 applied BC values
+    assy = H.assy_for_soln(dm.NodeDofArrayNew)                           # :722-734
+    full.reshape(-1)[assy] = u_free                                      # :936-941
+    solnVTK = np.empty_like(full)
+    solnVTK[dm.node_map_get_old] = full
+    return Result(kind, mesh, dm, solver, u_free, solnVTK, its, reason, rnorm, timers)
+
+
+def _run(kind, mesh, elemData, timeData, mode, rtol, maxits, verbose):
+    dm, conn_new, xyz_new, edof = _setup(kind, mesh)
+    N = dm.size_global
+    nsize = edof.shape[0]
+    ndof = L.NDOF[kind]
+    timers = {}
+    solver = PetscSolver()
+    n1 = min(50, N)                                                      # :762-773 (accepted, unused)
+    solver.initialise(N, N, np.full(N, n1, np.int32), np.full(N, min(25, N), np.int32))   # :779
+    solver.setTolerances(rtol=rtol, maxits=maxits)
+    if mode == "batched":
+        solver.uploadMesh(kind, conn_new, xyz_new, edof, dm.solnApplied)
+        solver.buildPattern()                                            # :786-802
+        t0 = time.perf_counter()                                         # tstart :826
+        solver.assemble(elemData, timeData)                              # setZero :817 + loop :828-884
+        timers["assembly_s"] = time.perf_counter() - t0                  # :893
+    elif mode == "compat":
+        Kzero = np.zeros(nsize * nsize)
+        for e in range(mesh.nElem):                                      # LoopElem :791-802
+            f = edof[:, e]
+            solver.MatSetValues(f, f, Kzero, INSERT_VALUES)
+        solver.setZero()                                                 # :817
+        valC = np.zeros(nsize)
+        t0 = time.perf_counter()
+        for e in range(mesh.nElem):                                      # :828-884
+            nd = conn_new[:, e]
+            xN, yN = xyz_new[0, nd], xyz_new[1, nd]
+            if kind == L.POISSON_TET:
+                K, F = H.StiffnessResidualPoissonLinearTetra(xN, yN, xyz_new[2, nd], elemData, timeData, valC)
+            elif kind == L.ELAST_TET:
+                K, F = H.StiffnessResidualElasticityLinearTetra(xN, yN, xyz_new[2, nd], elemData, timeData, valC)
+            elif kind == L.POISSON_TRIA:
+                K, F = H.StiffnessResidualPoissonLinearTria(xN, yN, elemData, timeData, valC)
+            else:
+                raise ValueError("compat mode needs a module element routine")
+            f = edof[:, e]
+            solver.MatSetValues(f, f, K.ravel(order="F"), ADD_VALUES)    # Fortran memory, read row-major
+            for ii in range(nsize):                                      # LoopI/LoopJ :859-870
+                if f[ii] == -1:
+                    fact = dm.solnApplied[nd[ii // ndof] * ndof + ii % ndof]
+                    for jj in range(nsize):
+                        if f[jj] != -1:
+                            F[jj] = F[jj] - K[jj, ii] * fact
+            solver.VecSetValues(f, F, ADD_VALUES)                        # :880
+        timers["assembly_s"] = time.perf_counter() - t0
+    else:
+        raise ValueError(mode)
+    t0 = time.perf_counter()                                             # :898
+    its, reason, rnorm = solver.factoriseAndSolve()                      # :900
+    timers["solve_s"] = time.perf_counter() - t0                         # :902
+    if verbose:                                                          # solverpetsc.F:481-488
+        print("Divergence." if reason < 0 else f" Convergence in {its} iterations.")
+    u = solver.getSolution()                                             # VecScatterCreateToAll + VecGetArray :922-932
+    timers.update(solver.timings())
+    return _finish(kind, mesh, dm, solver, its, reason, rnorm, timers, u)
+
+
+def tetrapoissonparallelimpl1(mesh: H.Mesh | str, mode="batched", rtol=1e-5, maxits=10000, verbose=False) -> Result:
+    """PROGRAM TetraMeshPoissonEquation (tetrapoissonparallelimpl1.F) on one rank / one GPU."""
+    if isinstance(mesh, str):
+        mesh = H.read_mesh(mesh)
+    return _run(L.POISSON_TET, mesh, H.POISSON_ELEMDATA, H.TIMEDATA, mode, rtol, maxits, verbose)   # :822-824
+
+
+def tetraelasticityparallelimpl1(mesh: H.Mesh | str, mode="batched", rtol=1e-5, maxits=10000, verbose=False) -> Result:
+    """PROGRAM of tetraelasticityparallelimpl1.F (body force only; DESIGN.md 'deviations')."""
+    if isinstance(mesh, str):
+        mesh = H.read_mesh(mesh)
+    return _run(L.ELAST_TET, mesh, H.ELAST_ELEMDATA, H.TIMEDATA, mode, rtol, maxits, verbose)       # :894-902
+
+
+def triapoissonserialimpl1(mesh: H.Mesh | str, rtol=1e-5, maxits=10000, verbose=False) -> Result:
+    """PROGRAM of triapoissonserialimpl1.F: inline Ke = area*B*B^T (:573-594), Laplace."""
+    if isinstance(mesh, str):
+        mesh = H.read_mesh(mesh)
+    return _run(L.POISSON_TRIA_INLINE, mesh, None, H.TIMEDATA, "batched", rtol, maxits, verbose)

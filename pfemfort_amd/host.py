@@ -1,0 +1,168 @@
+"""Host-side bookkeeping of the PFEMFort drivers, through the C ABI (csrc/pfem_host.cpp).
+
+numpy wrappers of the integer/mesh logic the drivers run before the element loop:
+mesh files, the structured generator (genTetra.cpp), Dirichlet/DOF
+numbering and partition renumbering (tetrapoissonparallelimpl1.F:316-367, 393-734) and
+the per-element compat routines (MODULE ElementUtilitiesPoisson / ...Elasticity3D).
+Arrays are column-major like the Fortran: ``xyz (ndim, nNode)``, ``conn (npElem, nElem)``,
+``edof (nsize, nElem)``, 0-based, -1 = Dirichlet.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import gzip
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+# REAL(4) literals of the drivers, widened to double (the reference is built without
+# -fdefault-real-8): tetrapoissonparallelimpl1.F:822-823, tetraelasticityparallelimpl1.F:895-902
+def _f32(v):
+    return float(np.float32(v))
+
+
+POISSON_ELEMDATA = np.array([1.0, 1.0, 1.0])
+ELAST_ELEMDATA = np.array([_f32(240.565), _f32(0.3), 1.0, _f32(0.1), 0.0, 0.0])
+TIMEDATA = np.array([0.0, 1.0, 0.0])
+
+
+@dataclass
+class Mesh:
+    xyz: np.ndarray        # (ndim, nNode)
+    conn: np.ndarray       # (npElem, nElem) int32, 0-based, OLD numbering
+    bc_node: np.ndarray    # (nDBC,) int32 0-based
+    bc_dof: np.ndarray     # (nDBC,) int32 0-based
+    bc_val: np.ndarray     # (nDBC,)
+    box: tuple | None = None   # (nEx, nEy, nEz) for generated meshes
+
+    @property
+    def nNode(self):
+        return self.xyz.shape[1]
+
+    @property
+    def nElem(self):
+        return self.conn.shape[1]
+
+
+def read_mesh(prefix: str) -> Mesh:
+    """``<prefix>-nodes.dat[.gz]``, ``-elems``, ``-DirichBC``: whitespace ASCII, 1-based
+    (tetrapoissonparallelimpl1.F:216-355)."""
+    def load(kind, dtype=float):
+        for ext in (".dat.gz", ".dat"):
+            path = f"{prefix}-{kind}{ext}"
+            if os.path.exists(path):
+                with (gzip.open(path, "rt") if ext.endswith(".gz") else open(path, "rt")) as f:
+                    return np.loadtxt(f, dtype=dtype, ndmin=2)
+        raise FileNotFoundError(f"{prefix}-{kind}.dat[.gz]")
+    nodes, elems, bcs = load("nodes"), load("elems", np.int64), load("DirichBC")
+    return Mesh(np.ascontiguousarray(nodes[:, 1:].T), np.ascontiguousarray((elems[:, 1:] - 1).T.astype(np.int32)),
+                (bcs[:, 0] - 1).astype(np.int32), (bcs[:, 1] - 1).astype(np.int32), bcs[:, 2].copy())
+
+
+def gen_box_tets(x0, x1, nEx, y0, y1, nEy, z0, z1, nEz, bc_mode=0, ndof=1, kz=None, nodes=True) -> Mesh:
+    """genTetra.cpp: structured box, 6 tets per hex.  ``kz=(k0,k1)`` emits only the elements of
+    hex layers [k0,k1) (one rank's slab); nodes always cover the full grid."""
+    k0, k1 = (0, nEz) if kz is None else kz
+    nNode = (nEx + 1) * (nEy + 1) * (nEz + 1)
+    nElem = 6 * nEx * nEy * (k1 - k0)
+    xyz = np.empty((3, nNode)) if nodes else None
+    conn = np.empty((4, nElem), dtype=np.int32)
+    n = C.c_int64(0)
+    head = (x0, x1, nEx, y0, y1, nEy, z0, z1, nEz, k0, k1, bc_mode, ndof)
+    L.check(L.lib().pfem_gen_box_tets(*head, None, None, C.byref(n), None, None, None), "pfem_gen_box_tets")
+    bn = np.empty(n.value, np.int32); bd = np.empty(n.value, np.int32); bv = np.empty(n.value)
+    L.check(L.lib().pfem_gen_box_tets(*head, _p(xyz), _p(conn), C.byref(n), _p(bn), _p(bd), _p(bv)), "pfem_gen_box_tets")
+    return Mesh(xyz, conn, bn, bd, bv, box=(nEx, nEy, nEz))
+
+
+def partition_box_slabs(nEx, nEy, nEz, nParts):
+    """Deterministic stand-in for METIS_PartMeshNodal (:464) on generated boxes."""
+    epid = np.empty(6 * nEx * nEy * nEz, np.int32)
+    npid = np.empty((nEx + 1) * (nEy + 1) * (nEz + 1), np.int32)
+    L.check(L.lib().pfem_partition_box_slabs(nEx, nEy, nEz, nParts, _p(epid), _p(npid)), "pfem_partition_box_slabs")
+    return epid, npid
+
+
+@dataclass
+class DofMap:
+    node_map_get_old: np.ndarray
+    node_map_get_new: np.ndarray
+    NodeDofArrayNew: np.ndarray     # (nNode, ndof) 0-based ids, -1 = Dirichlet
+    solnApplied: np.ndarray         # (nNode*ndof,) by NEW node*ndof+d
+    node_start: np.ndarray
+    node_end: np.ndarray
+    row_start: np.ndarray
+    row_end: np.ndarray
+    size_global: int
+
+
+def dof_numbering(nNode, ndof, bc_node, bc_dof, bc_val, nParts=1, node_proc_id=None) -> DofMap:
+    old = np.empty(nNode, np.int32); new = np.empty(nNode, np.int32)
+    nda = np.empty((nNode, ndof), np.int32); sa = np.empty(nNode * ndof)
+    ns, ne, rs, re = (np.zeros(nParts, np.int64) for _ in range(4))
+    sg = C.c_int64(0)
+    npid = None if node_proc_id is None else _i32(node_proc_id)
+    L.check(L.lib().pfem_dof_numbering(nNode, ndof, len(bc_node), _p(_i32(bc_node)), _p(_i32(bc_dof)), _p(_f64(bc_val)),
+                                       nParts, _p(npid), _p(old), _p(new), _p(nda), _p(sa), _p(ns), _p(ne), _p(rs),
+                                       _p(re), C.byref(sg)), "pfem_dof_numbering")
+    return DofMap(old, new, nda, sa, ns, ne, rs, re, sg.value)
+
+
+def elem_dof_array(conn_new, NodeDofArrayNew):
+    conn_new = _i32(conn_new)
+    npE, nElem = conn_new.shape
+    ndof = NodeDofArrayNew.shape[1]
+    edof = np.empty((npE * ndof, nElem), np.int32)
+    L.check(L.lib().pfem_elem_dof_array(nElem, npE, ndof, _p(conn_new), _p(_i32(NodeDofArrayNew)), _p(edof)),
+            "pfem_elem_dof_array")
+    return edof
+
+
+def assy_for_soln(NodeDofArrayNew):
+    nNode, ndof = NodeDofArrayNew.shape
+    out = np.empty(int((NodeDofArrayNew >= 0).sum()), np.int32)
+    L.check(L.lib().pfem_assy_for_soln(nNode, ndof, _p(_i32(NodeDofArrayNew)), _p(out)), "pfem_assy_for_soln")
+    return out
+
+
+# ---- per-element compat routines (one element per call, like the Fortran) -----------
+def StiffnessResidualPoissonLinearTetra(xNode, yNode, zNode, elemData, timeData, valC, valDotC=None):
+    """elementutilitiespoisson.F:107; returns (Klocal[4,4], Flocal[4])."""
+    K = np.empty((4, 4), order="F"); F = np.empty(4)
+    L.check(L.lib().pfem_poisson_tet_ke(_p(_f64(xNode)), _p(_f64(yNode)), _p(_f64(zNode)), _p(_f64(elemData)),
+                                        _p(_f64(timeData)), _p(_f64(valC)), _p(K), _p(F)),
+            "StiffnessResidualPoissonLinearTetra")
+    return K, F
+
+
+def StiffnessResidualPoissonLinearTria(xNode, yNode, elemData, timeData, valC, valDotC=None):
+    """elementutilitiespoisson.F:23; returns (Klocal[3,3], Flocal[3])."""
+    K = np.empty((3, 3), order="F"); F = np.empty(3)
+    L.check(L.lib().pfem_poisson_tria_ke(_p(_f64(xNode)), _p(_f64(yNode)), _p(_f64(elemData)), _p(_f64(timeData)),
+                                         _p(_f64(valC)), _p(K), _p(F)), "StiffnessResidualPoissonLinearTria")
+    return K, F
+
+
+def StiffnessResidualElasticityLinearTetra(xNode, yNode, zNode, elemData, timeData, valC, valDotC=None):
+    """elementutilitieselasticity3D.F:248 (intended semantics); returns (Klocal[12,12], Flocal[12])."""
+    K = np.empty((12, 12), order="F"); F = np.empty(12)
+    L.check(L.lib().pfem_elast_tet_ke(_p(_f64(xNode)), _p(_f64(yNode)), _p(_f64(zNode)), _p(_f64(elemData)),
+                                      _p(_f64(timeData)), _p(_f64(valC)), _p(K), _p(F)),
+            "StiffnessResidualElasticityLinearTetra")
+    return K, F

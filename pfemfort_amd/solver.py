@@ -1,0 +1,230 @@
+"""``PetscSolver`` -- Python mirror of ``TYPE PetscSolver`` (MODULE Module_SolverPetsc,
+solverpetsc.F:72-105) over the C ABI.  Same procedure names, argument meaning and status
+machine as the reference; the linear algebra runs in hand-written HIP kernels on the GPU.
+There is no CPU fallback: constructing the device object without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import (ADD_VALUES, ASSEMBLY_OK, FACTORISE_OK, INIT_OK, INSERT_VALUES,  # noqa: F401
+                   PATTERN_OK, SOLVER_EMPTY)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class PetscSolver:
+    """Drop-in for ``solverpetsc`` in the drivers (``call solverpetsc%initialise(...)`` ...)."""
+
+    def __init__(self):
+        self._h = C.c_void_p(None)
+        self.nRow = self.nCol = 0
+        self.its = 0
+        self.reason = 0
+        self.norm = 0.0
+        self._keep = []          # ctypes callbacks / tensors that must outlive the handle
+
+    # ---- solverpetsc.F:116-214 -------------------------------------------------------
+    def initialise(self, size_local, size_global, diag_nnz=None, offdiag_nnz=None, row_start=0, device=-1):
+        if self._h:
+            self.free()
+        dn = None if diag_nnz is None else _i32(diag_nnz)
+        on = None if offdiag_nnz is None else _i32(offdiag_nnz)
+        h = C.c_void_p(None)
+        L.check(L.lib().pfem_solver_create(C.byref(h), size_local, size_global, row_start, _p(dn), _p(on), device),
+                "PetscSolver%initialise")
+        self._h = h
+        self.nRow = self.nCol = size_global
+        self.size_local, self.size_global, self.row_start = size_local, size_global, row_start
+        return self
+
+    @property
+    def currentStatus(self):
+        st = C.c_int(0)
+        L.check(L.lib().pfem_solver_status(self._h, C.byref(st)), "PetscSolver%currentStatus")
+        return st.value
+
+    def setTolerances(self, rtol=1e-5, abstol=1e-50, dtol=1e5, maxits=10000):
+        """KSPSetFromOptions stand-in (petsc_options.dat is not part of the reference tree)."""
+        L.check(L.lib().pfem_solver_set_tolerances(self._h, rtol, abstol, dtol, maxits), "PetscSolver%setTolerances")
+
+    def setStream(self, hip_stream):
+        L.check(L.lib().pfem_solver_set_stream(self._h, C.c_void_p(hip_stream)), "PetscSolver%setStream")
+
+    # ---- solverpetsc.F:222-246 -------------------------------------------------------
+    def setZero(self):
+        L.check(L.lib().pfem_solver_set_zero(self._h), "PetscSolver%setZero")
+
+    # ---- solverpetsc.F:254-278 -------------------------------------------------------
+    def free(self):
+        if self._h:
+            L.lib().pfem_solver_destroy(self._h)
+            self._h = C.c_void_p(None)
+        self._keep.clear()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    # ---- solverpetsc.F:286-320 -------------------------------------------------------
+    def printInfo(self):
+        L.check(L.lib().pfem_solver_print_info(self._h), "PetscSolver%printInfo")
+
+    # ---- the PETSc calls the drivers make on solverpetsc%mtx / %rhsVec ---------------
+    def MatSetValues(self, idxm, idxn, v, mode):
+        """``MatSetValues(mtx,m,idxm,n,idxn,v,mode)``; ``v`` is read row-major like PETSc does
+        (pass the Fortran-ordered Klocal's memory, i.e. ``np.asfortranarray(K).ravel(order='K')``)."""
+        idxm = _i32(idxm); idxn = _i32(idxn)
+        vv = None if v is None else _f64(v).ravel()
+        L.check(L.lib().pfem_mat_set_values(self._h, len(idxm), _p(idxm), len(idxn), _p(idxn), _p(vv), mode),
+                "MatSetValues")
+
+    def VecSetValues(self, idx, v, mode):
+        idx = _i32(idx)
+        L.check(L.lib().pfem_vec_set_values(self._h, len(idx), _p(idx), _p(_f64(v)), mode), "VecSetValues")
+
+    # ---- solverpetsc.F:328-401 -------------------------------------------------------
+    def assembleMatrixAndVector(self, R, Cc, Klocal, Flocal):
+        K = None if Klocal is None else np.asfortranarray(Klocal, dtype=np.float64)
+        F = None if Flocal is None else _f64(Flocal)
+        R = _i32(R); Cc = _i32(Cc)
+        L.check(L.lib().pfem_solver_assemble_matrix_and_vector(self._h, len(R), _p(R), _p(Cc), _p(K), _p(F)),
+                "PetscSolver%assembleMatrixAndVector")
+
+    def assembleMatrix(self, R, Cc, Klocal):
+        self.assembleMatrixAndVector(R, Cc, Klocal, None)
+
+    def assembleVector(self, R, Flocal):
+        self.assembleMatrixAndVector(R, R, None, Flocal)
+
+    # ---- solverpetsc.F:409-509 -------------------------------------------------------
+    def factorise(self):
+        L.check(L.lib().pfem_solver_factorise(self._h), "PetscSolver%factorise")
+
+    def _solve(self, fn, where):
+        its = C.c_int(0); reason = C.c_int(0); rn = C.c_double(0)
+        L.check(fn(self._h, C.byref(its), C.byref(reason), C.byref(rn)), where)
+        self.its, self.reason, self.norm = its.value, reason.value, rn.value
+        return self.its, self.reason, self.norm
+
+    def solve(self):
+        return self._solve(L.lib().pfem_solver_solve, "PetscSolver%solve")
+
+    def factoriseAndSolve(self):
+        return self._solve(L.lib().pfem_solver_factorise_and_solve, "PetscSolver%factoriseAndSolve")
+
+    def getSolution(self):
+        """VecGetArray(solnVec): the owned block of the solution."""
+        x = np.empty(self.size_local)
+        L.check(L.lib().pfem_solver_get_solution(self._h, _p(x)), "VecGetArray")
+        return x
+
+    def getHistory(self):
+        h = np.empty(self.its + 1)
+        n = C.c_int(0)
+        L.check(L.lib().pfem_solver_get_history(self._h, _p(h), len(h), C.byref(n)), "pfem_solver_get_history")
+        return h[:n.value]
+
+    # ---- batched device path (the element loop as one call) --------------------------
+    def uploadMesh(self, kind, conn, xyz, edof, solnApplied):
+        conn = _i32(conn); xyz = _f64(xyz); edof = _i32(edof); sa = _f64(solnApplied)
+        assert conn.shape[0] == L.NPELEM[kind] and xyz.shape[0] == L.NDIM[kind]
+        assert edof.shape == (L.NPELEM[kind] * L.NDOF[kind], conn.shape[1])
+        assert sa.size == xyz.shape[1] * L.NDOF[kind]
+        L.check(L.lib().pfem_mesh_upload(self._h, kind, conn.shape[1], _p(conn), xyz.shape[1], _p(xyz), _p(edof), _p(sa)),
+                "pfem_mesh_upload")
+        self.kind = kind
+        self.nElem = conn.shape[1]
+
+    def buildPattern(self):
+        L.check(L.lib().pfem_pattern_build(self._h), "pfem_pattern_build")
+
+    def assemble(self, elemData, timeData):
+        ed = None if elemData is None else _f64(elemData)
+        L.check(L.lib().pfem_assemble(self._h, _p(ed), _p(_f64(timeData))), "pfem_assemble")
+
+    def evalElems(self, elemData, timeData):
+        ns = L.NPELEM[self.kind] * L.NDOF[self.kind]
+        K = np.empty((self.nElem, ns, ns)); F = np.empty((self.nElem, ns))
+        ed = None if elemData is None else _f64(elemData)
+        L.check(L.lib().pfem_eval_elems(self._h, _p(ed), _p(_f64(timeData)), _p(K), _p(F)), "pfem_eval_elems")
+        return K.transpose(0, 2, 1).copy(), F     # column-major blocks -> K[e][i,j] = Klocal(i,j)
+
+    def matrixInfo(self):
+        a, b, c, d = (C.c_int64(0) for _ in range(4))
+        L.check(L.lib().pfem_matrix_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "pfem_matrix_info")
+        return {"n_owned": a.value, "n_local": b.value, "nnz": c.value, "stored": d.value}
+
+    def localToGlobal(self):
+        g = np.empty(self.matrixInfo()["n_local"], np.int64)
+        L.check(L.lib().pfem_get_local_to_global(self._h, _p(g)), "pfem_get_local_to_global")
+        return g
+
+    def getCSR(self, values=True):
+        info = self.matrixInfo()
+        rowptr = np.empty(info["n_local"] + 1, np.int64)
+        cols = np.empty(info["nnz"], np.int32)
+        vals = np.empty(info["nnz"]) if values else None
+        L.check(L.lib().pfem_get_csr(self._h, _p(rowptr), _p(cols), _p(vals)), "pfem_get_csr")
+        return rowptr, cols, vals
+
+    def getRHS(self):
+        r = np.empty(self.matrixInfo()["n_local"])
+        L.check(L.lib().pfem_get_rhs(self._h, _p(r)), "pfem_get_rhs")
+        return r
+
+    def spmv(self, x):
+        x = _f64(x)
+        y = np.empty_like(x)
+        L.check(L.lib().pfem_spmv(self._h, _p(x), _p(y)), "pfem_spmv")
+        return y
+
+    def benchSpmv(self, reps=20):
+        ms = C.c_double(0)
+        L.check(L.lib().pfem_bench_spmv(self._h, reps, C.byref(ms)), "pfem_bench_spmv")
+        return ms.value
+
+    def profileSpmv(self, enable=True):
+        L.check(L.lib().pfem_solver_profile_spmv(self._h, int(enable)), "pfem_solver_profile_spmv")
+
+    def timings(self):
+        t = L.Timings()
+        L.check(L.lib().pfem_get_timings(self._h, C.byref(t)), "pfem_get_timings")
+        return {k: getattr(t, k) for k, _ in t._fields_}
+
+    # ---- multi-GPU plumbing ----------------------------------------------------------
+    def ghosts(self):
+        n = C.c_int64(0)
+        L.check(L.lib().pfem_get_ghosts(self._h, C.byref(n), None), "pfem_get_ghosts")
+        g = np.empty(n.value, np.int64)
+        L.check(L.lib().pfem_get_ghosts(self._h, C.byref(n), _p(g)), "pfem_get_ghosts")
+        return g
+
+    def setComm(self, rank, nranks, allreduce_cb):
+        cb = L.ALLREDUCE_FN(allreduce_cb) if allreduce_cb is not None else L.ALLREDUCE_FN()
+        self._keep.append(cb)
+        L.check(L.lib().pfem_solver_set_comm(self._h, rank, nranks, cb, None), "pfem_solver_set_comm")
+
+    def setInterface(self, shared_gid, shared_slot, n_iface_global):
+        g = np.ascontiguousarray(shared_gid, dtype=np.int64); sl = _i32(shared_slot)
+        L.check(L.lib().pfem_solver_set_interface(self._h, len(g), _p(g), _p(sl), n_iface_global),
+                "pfem_solver_set_interface")
+
+    def setExchangeBuffer(self, device_ptr, capacity):
+        L.check(L.lib().pfem_solver_set_exchange_buffer(self._h, C.c_void_p(device_ptr), capacity),
+                "pfem_solver_set_exchange_buffer")

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """The native pieces must exist; build them if the tree is fresh (never falls back)."""
+    import __graft_entry__ as g
+    from pfemfort_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH) or not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        g.build()
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN

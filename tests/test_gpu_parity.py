@@ -1,0 +1,166 @@
+"""Parity of the HIP path against the oracle, through the C ABI, on a real MI355X.
+
+Bars (BASELINE.json north_star): integer maps and sparsity pattern bit-exact; per-element
+Ke/Fe bit-exact (the kernels evaluate in the reference's order without FMA contraction);
+assembled K/F within 1e-12 relative (atomic adds reorder the sums); solution within 1e-8 of
+the converged oracle solution at rtol 1e-10.
+"""
+import numpy as np
+import pytest
+
+import pfemfort_amd as pf
+from oracle import pfem_oracle as O
+from pfemfort_amd import host as H
+
+pytestmark = pytest.mark.gpu
+
+K_RTOL = 1e-12     # assembled matrix / rhs entries, relative to the largest entry
+U_ATOL = 1e-8      # solution vs oracle PCG at rtol 1e-10
+
+
+def _omesh(m):
+    return O.Mesh(m.xyz, m.conn, m.bc_node, m.bc_dof, m.bc_val)
+
+
+def _device_problem(kind, mesh, elemData):
+    from pfemfort_amd import drivers as D
+    dm, conn_new, xyz_new, edof = D._setup(kind, mesh)
+    s = pf.PetscSolver().initialise(dm.size_global, dm.size_global)
+    s.uploadMesh(kind, conn_new, xyz_new, edof, dm.solnApplied)
+    s.buildPattern()
+    s.assemble(elemData, H.TIMEDATA)
+    return s, dm
+
+
+@pytest.fixture(scope="module")
+def tet10(golden_dir):
+    return H.read_mesh(f"{golden_dir}/input/tet10")
+
+
+@pytest.fixture(scope="module")
+def tria20(golden_dir):
+    return H.read_mesh(f"{golden_dir}/input/tria20x20")
+
+
+@pytest.fixture(scope="module")
+def beam():
+    # small cousin of config 4: [-.5,.5]x[0,6]x[-.5,.5], clamp y=0, 3 dofs per node
+    return H.gen_box_tets(-0.5, 0.5, 3, 0.0, 6.0, 12, -0.5, 0.5, 3, bc_mode=1, ndof=3)
+
+
+@pytest.mark.parametrize("kind,ed", [(pf.POISSON_TET, H.POISSON_ELEMDATA),
+                                     (pf.POISSON_TET, np.array([1.3, 0.7, 2.1])),
+                                     (pf.ELAST_TET, H.ELAST_ELEMDATA)])
+def test_device_element_matrices_bit_exact(tet10, kind, ed):
+    s, _ = _device_problem(kind, tet10, ed)
+    K, F = s.evalElems(ed, H.TIMEDATA)
+    Ko, Fo = O.eval_elems(kind, tet10.xyz, tet10.conn, ed)
+    assert np.array_equal(K, Ko)
+    assert np.array_equal(F, Fo)
+
+
+def test_device_tria_elements_bit_exact(tria20):
+    for kind in (pf.POISSON_TRIA, pf.POISSON_TRIA_INLINE):
+        ed = np.array([1.0, 1.0])
+        s, _ = _device_problem(kind, tria20, ed)
+        K, F = s.evalElems(ed, H.TIMEDATA)
+        Ko, Fo = O.eval_elems(kind, tria20.xyz, tria20.conn, ed)
+        assert np.array_equal(K, Ko) and np.array_equal(F, Fo)
+
+
+@pytest.mark.parametrize("name", ["tet10", "tria20", "beam"])
+def test_assembly_matches_oracle(name, request):
+    mesh = request.getfixturevalue(name)
+    kind, ed = {"tet10": (pf.POISSON_TET, H.POISSON_ELEMDATA), "tria20": (pf.POISSON_TRIA_INLINE, np.array([1.0, 1.0, 0.0])),
+                "beam": (pf.ELAST_TET, H.ELAST_ELEMDATA)}[name]
+    s, dm = _device_problem(kind, mesh, ed)
+    prob = O.setup_problem(kind, _omesh(mesh), elemData=ed)
+    rowptr, cols, vals = s.getCSR()
+    assert dm.size_global == prob.dm.size_global
+    assert np.array_equal(rowptr, prob.rowptr)            # pattern: bit-exact
+    assert np.array_equal(cols, prob.cols)
+    scale = np.abs(prob.vals).max()
+    assert np.abs(vals - prob.vals).max() <= K_RTOL * scale
+    rhs = s.getRHS()
+    assert np.abs(rhs - prob.rhs).max() <= K_RTOL * max(np.abs(prob.rhs).max(), 1e-300)
+    if name == "tet10":
+        assert (dm.size_global, len(cols)) == (729, 9097)
+    if name == "tria20":
+        assert (dm.size_global, len(cols)) == (361, 2377)
+
+
+def test_spmv_matches_oracle(tet10):
+    s, dm = _device_problem(pf.POISSON_TET, tet10, H.POISSON_ELEMDATA)
+    rowptr, cols, vals = s.getCSR()
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(dm.size_global)
+    y = s.spmv(x)
+    yo = O.spmv(rowptr, cols, vals, x)
+    assert np.abs(y - yo).max() <= 1e-13 * np.abs(yo).max()
+
+
+@pytest.mark.parametrize("rtol", [1e-5, 1e-10])
+def test_poisson_tet10_solve(tet10, rtol):
+    res = pf.tetrapoissonparallelimpl1(tet10, rtol=rtol)
+    prob = O.setup_problem(O.POISSON_TET, _omesh(tet10))
+    x, its, reason, rn, hist = O.pcg_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=rtol, hist_len=200)
+    assert res.reason == reason == 2
+    assert abs(res.its - its) <= 1
+    h = res.solver.getHistory()
+    n = min(len(h), len(hist))
+    assert np.allclose(h[:n], hist[:n], rtol=1e-6)
+    xc, *_ = O.pcg_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-12)
+    tol = U_ATOL if rtol <= 1e-10 else 1e-3
+    assert np.abs(res.soln_free - xc).max() <= tol
+    if rtol <= 1e-10:
+        exact = (tet10.xyz ** 2).sum(0)                    # u = x^2+y^2+z^2, nodally exact
+        assert np.abs(res.solnVTK[:, 0] - exact).max() < 2e-7
+
+
+def test_compat_driver_equals_batched(tet10):
+    a = pf.tetrapoissonparallelimpl1(tet10, rtol=1e-10, mode="batched")
+    b = pf.tetrapoissonparallelimpl1(tet10, rtol=1e-10, mode="compat")
+    ra, ca, va = a.solver.getCSR()
+    rb, cb, vb = b.solver.getCSR()
+    assert np.array_equal(ra, rb) and np.array_equal(ca, cb)
+    prob = O.setup_problem(O.POISSON_TET, _omesh(tet10))
+    assert np.array_equal(vb, prob.vals)                   # host-staged serial sums: bit-exact
+    assert np.array_equal(b.solver.getRHS(), prob.rhs)
+    assert np.abs(va - vb).max() <= K_RTOL * np.abs(vb).max()
+    assert np.abs(a.soln_free - b.soln_free).max() <= U_ATOL
+
+
+def test_tria20x20_known_answer(tria20):
+    res = pf.triapoissonserialimpl1(tria20, rtol=1e-12)
+    assert res.reason > 0
+    assert abs(res.soln_free.sum() - 68.09843993245326) < 1e-8       # SURVEY 8c (direct solve)
+    assert np.allclose(res.soln_free[:3], [0.13364425, 0.26399773, 0.38785071], atol=1e-7)
+    x, y = tria20.xyz
+    exact = np.sin(np.pi * x) * (np.cosh(np.pi * y) - np.cosh(np.pi) / np.sinh(np.pi) * np.sinh(np.pi * y))
+    assert abs(np.abs(res.solnVTK[:, 0] - exact).max() - 7.11e-4) < 1e-5
+
+
+def test_elasticity_beam_solve(beam):
+    res = pf.tetraelasticityparallelimpl1(beam, rtol=1e-10)
+    prob = O.setup_problem(O.ELAST_TET, _omesh(beam))
+    xc, its, reason, *_ = O.pcg_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-10)
+    assert res.reason == reason == 2 and abs(res.its - its) <= 2
+    assert np.abs(res.soln_free - xc).max() <= U_ATOL * max(1.0, np.abs(xc).max())
+    assert res.solnVTK[:, 0].max() > 0.1                    # the beam bends in +x under (0.1,0,0)
+
+
+def test_negative_jacobian_is_reported(tet10):
+    bad = H.Mesh(tet10.xyz, tet10.conn.copy(), tet10.bc_node, tet10.bc_dof, tet10.bc_val)
+    bad.conn[[0, 1], 5] = bad.conn[[1, 0], 5]              # flip one tet
+    with pytest.raises(pf.PfemError) as ei:
+        pf.tetrapoissonparallelimpl1(bad)
+    assert ei.value.code == 3                               # PFEM_ERR_NEG_JAC (reference: STOP)
+
+
+def test_status_machine(tet10):
+    s = pf.PetscSolver().initialise(10, 10)
+    assert s.currentStatus == pf.solver.SOLVER_EMPTY
+    with pytest.raises(pf.PfemError):
+        s.factorise()                                       # "Assemble matrix first..." solverpetsc.F:415
+    with pytest.raises(pf.PfemError):
+        s.solve()
