@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- DOF/s (assembly + CG-to-tolerance) of the implicit-FEM hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over the resident mesh: setZero + element loop
+(Ke/Fe, Dirichlet lifting, scatter; the reference's timer tetrapoissonparallelimpl1.F:826->893)
++ factoriseAndSolve (Jacobi-PCG to the PETSc default rtol 1e-5; timer :898->902).
+Inputs (mesh, maps, pattern) are resident in HBM before the timed region, as in the reference
+where mesh read / numbering / pattern precede the timers.
+
+N = 1 : BASELINE.json configs[2]: synthetic [-1,1]^3, 200x200x200x6 P1 tets (genTetra logic).
+N > 1 : weak scaling, one process per GPU: the box grows along z, 200x200x(200 N) cells of the
+        same size over [-1,1]^2 x [-1,2N-1], rank r owns hex layers [200 r, 200 (r+1)); interface
+        rows are summed with one RCCL all-reduce per SpMV (torch.distributed "nccl").
+        (--cube runs BASELINE configs[4]'s 400^3 box for N = 8 instead.)
+
+Prints ONE JSON line on rank 0 (contract in the task description), with `roofline` for the CG
+SpMV kernel (HIP events around every SpMV launch of the timed solves) and `cpu_baseline` (the C
+oracle, single core, on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(n=100, rtol=1e-5):
+    """The oracle (C restatement of the reference path) on ONE host core, bounded sample:
+    BASELINE configs[1] (tet100: 100^3 x 6 tets), full assembly + Jacobi-PCG to the same rtol."""
+    import ctypes
+    import numpy as np
+    from oracle import pfem_oracle as O
+    try:
+        omp = ctypes.CDLL("libgomp.so.1")
+        omp.omp_set_num_threads(1)
+    except OSError:
+        pass
+    os.environ["OMP_NUM_THREADS"] = "1"
+    mesh = O.gen_box_tets(-1, 1, n, -1, 1, n, -1, 1, n)
+    dm = O.dof_numbering(mesh.nNode, 1, mesh.bc_node, mesh.bc_dof, mesh.bc_val)
+    edof = O.elem_dof_array(mesh.conn, dm.NodeDofArrayNew)
+    rowptr, cols = O.csr_pattern(edof, dm.size_global)          # pattern precedes the timers (:786-802)
+    t0 = time.perf_counter()
+    vals, rhs = O.assemble(O.POISSON_TET, mesh.xyz, mesh.conn, edof, dm.solnApplied, O.POISSON_ELEMDATA,
+                           dm.size_global, rowptr, cols)
+    t1 = time.perf_counter()
+    x, its, reason, rn, _ = O.pcg_jacobi(rowptr, cols, vals, rhs, rtol=rtol)
+    t2 = time.perf_counter()
+    nb = 12 * len(cols) + 20 * dm.size_global
+    return {"value": dm.size_global / (t2 - t0), "unit": "DOF/s", "cores": 1, "kind": "port",
+            "sample": f"{n}^3x6 tet Poisson (BASELINE configs[1]), N={dm.size_global}, full assembly "
+                      f"{t1 - t0:.2f}s + Jacobi-PCG rtol {rtol:g} {its} its {t2 - t1:.2f}s; "
+                      f"CG-iteration rate {nb * its / (t2 - t1) / 1e9:.1f} GB/s SpMV-equivalent",
+            "assembly_s": t1 - t0, "solve_s": t2 - t1, "its": its}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=200, help="cells per side of one rank's block")
+    ap.add_argument("--rtol", type=float, default=1e-5, help="PETSc default (the reference sets none)")
+    ap.add_argument("--cube", action="store_true", help="N>1: cube of (n*N^(1/3))^3 cells instead of the z-extended box")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl")
+    args = ap.parse_args()
+
+    import numpy as np
+    import pfemfort_amd as pf
+    from pfemfort_amd import host as H
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    dist = torch = None
+    device_index = local_rank if world > 1 else 0
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(device_index)
+        dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", device_index)
+                                if args.backend == "nccl" else None)
+
+    if pf.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: libpfem_amd has no CPU path")
+
+    # ---- mesh of this rank ------------------------------------------------------------
+    n = args.n
+    if world == 1:
+        nE = (n, n, n); zspan = (-1.0, 1.0)
+    elif args.cube:
+        side = round(n * world ** (1.0 / 3.0))
+        nE = (side, side, side); zspan = (-1.0, 1.0)
+    else:
+        nE = (n, n, n * world); zspan = (-1.0, -1.0 + 2.0 * world)
+    nEx, nEy, nEz = nE
+    kz = (nEz * rank // world, nEz * (rank + 1) // world)
+    t_setup = time.perf_counter()
+    mesh = H.gen_box_tets(-1.0, 1.0, nEx, -1.0, 1.0, nEy, zspan[0], zspan[1], nEz, kz=kz)
+    if world == 1:
+        dm = H.dof_numbering(mesh.nNode, 1, mesh.bc_node, mesh.bc_dof, mesh.bc_val)
+    else:
+        _, npid = H.partition_box_slabs(nEx, nEy, nEz, world)
+        dm = H.dof_numbering(mesh.nNode, 1, mesh.bc_node, mesh.bc_dof, mesh.bc_val, world, npid)
+    conn_new = dm.node_map_get_new[mesh.conn].astype(np.int32)
+    xyz_new = np.ascontiguousarray(mesh.xyz[:, dm.node_map_get_old])
+    edof = H.elem_dof_array(conn_new, dm.NodeDofArrayNew)
+    N = dm.size_global
+    row_start, row_end = int(dm.row_start[rank]), int(dm.row_end[rank])
+
+    solver = pf.PetscSolver().initialise(row_end - row_start, N, row_start=row_start, device=device_index)
+    solver.setTolerances(rtol=args.rtol)
+    solver.uploadMesh(pf.POISSON_TET, conn_new, xyz_new, edof, dm.solnApplied)
+    n_iface = 0
+    if world > 1:
+        from pfemfort_amd import distributed as PD
+        hook, n_iface = PD.attach(solver, dist, torch, torch.device("cuda", device_index))
+    solver.buildPattern()
+    info = solver.matrixInfo()
+    t_setup = time.perf_counter() - t_setup
+    solver.profileSpmv(True)
+
+    def step():
+        solver.assemble(H.POISSON_ELEMDATA, H.TIMEDATA)
+        return solver.factoriseAndSolve()
+
+    def sync():
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    spmv_ms = 0.0; spmv_n = 0; asm_ms = 0.0; sol_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        its, reason, rnorm = step()
+        tm = solver.timings()
+        spmv_ms += tm["spmv_ms_total"]; spmv_n += tm["spmv_launches"]
+        asm_ms += tm["assemble_ms"]; sol_ms += tm["solve_ms"]
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        if hook.error is not None:
+            raise hook.error
+
+    # sanity of the answer: u = x^2+y^2+z^2 is nodally exact on this mesh family
+    u = solver.getSolution()
+    owned_nodes_free = H.assy_for_soln(dm.NodeDofArrayNew)[row_start:row_end]
+    exact = (xyz_new[:, owned_nodes_free] ** 2).sum(0)
+    max_err = float(np.abs(u - exact).max()) if len(u) else 0.0
+
+    if rank == 0:
+        bytes_per_spmv = 12 * info["nnz"] + 20 * info["n_local"]       # FP64 vals, int32 cols
+        avg_spmv_ms = spmv_ms / max(spmv_n, 1)
+        achieved = bytes_per_spmv / (avg_spmv_ms * 1e-3) / 1e9 if spmv_n else 0.0
+        out = {
+            "metric": "DOF/s (assembly+CG-to-tol)", "value": N * args.steps / elapsed, "unit": "DOF/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"tetrapoissonparallelimpl1: [-1,1]^2x[{zspan[0]:g},{zspan[1]:g}] box, "
+                                   f"{nEx}x{nEy}x{nEz}x6 P1 tets, u=x^2+y^2+z^2 Dirichlet on all faces, f=-6",
+                       "elements": 6 * nEx * nEy * nEz, "nodes": int(mesh.nNode), "free_dofs": int(N),
+                       "solver": f"Jacobi-PCG, zero initial guess, rtol {args.rtol:g} on ||M^-1 r|| (PETSc KSPCG default norm)",
+                       "parallelism": "1 GPU" if world == 1 else f"{world} z-slabs, sub-assembled interface rows, "
+                                      f"RCCL all-reduce of {n_iface} interface dofs per SpMV"},
+            "iterations": its, "converged_reason": reason, "rnorm": rnorm, "max_nodal_error": max_err,
+            "assembly_ms_per_step": asm_ms / args.steps, "solve_ms_per_step": sol_ms / args.steps,
+            "setup_s_untimed": t_setup,
+            "roofline": {"bound": "hbm", "kernel": "pfem::k_spmv<true> (wave-sliced CSR SpMV + (p,Ap) partials), rank 0",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_per_spmv, "avg_launch_ms": avg_spmv_ms,
+                         "launches_timed": spmv_n, "nnz": info["nnz"], "rows": info["n_local"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(rtol=args.rtol)
+        print(json.dumps(out), flush=True)
+    solver.free()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

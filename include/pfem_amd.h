@@ -247,6 +247,10 @@ int pfem_solver_set_interface(pfem_solver *s, int64_t n_shared, const int64_t *s
 /* Exchange buffer to all-reduce in (device pointer, >= n_iface_global+4 doubles), e.g.
  * the storage of a torch tensor so the hook can hand the tensor to torch.distributed. */
 int pfem_solver_set_exchange_buffer(pfem_solver *s, void *device_buf, int64_t capacity);
+/* host-only helper (no GPU needed): ascending unique global dof ids in edof[0..count) that
+ * lie outside the owned block [row_start,row_start+n_owned); two-call (NULL -> count).  */
+int pfem_find_ghosts(int64_t count, const int32_t *edof, int64_t row_start, int64_t n_owned,
+                     int64_t *n_ghost, int64_t *ghost_gid);
 /* ghost dof ids (ascending) of the uploaded mesh: two-call (ghost_gid NULL -> count) */
 int pfem_get_ghosts(pfem_solver *s, int64_t *n_ghost, int64_t *ghost_gid);
 

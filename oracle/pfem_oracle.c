@@ -584,7 +584,7 @@ void orc_spmv(int64_t N, const int64_t *rowptr, const int32_t *cols, const doubl
               const double *x, double *y)
 {
     int64_t r;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (N > 200000)
     for (r = 0; r < N; ++r) {
         double s = 0.0;
         int64_t k;
@@ -597,7 +597,7 @@ static double dotp(int64_t N, const double *a, const double *b)
 {
     double s = 0.0;
     int64_t i;
-#pragma omp parallel for reduction(+ : s) schedule(static)
+#pragma omp parallel for reduction(+ : s) schedule(static) if (N > 200000)
     for (i = 0; i < N; ++i) s += a[i] * b[i];
     return s;
 }
@@ -621,7 +621,7 @@ int orc_pcg_jacobi(int64_t N, const int64_t *rowptr, const int32_t *cols,
         if (k >= 0) d = vals[k];
         dinv[i] = 1.0 / d;
     }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (N > 200000)
     for (i = 0; i < N; ++i) { x[i] = 0.0;  r[i] = b[i];  z[i] = r[i] * dinv[i];  p[i] = z[i]; }
     beta = dotp(N, r, z);
     rn0 = sqrt(dotp(N, z, z));
@@ -636,7 +636,7 @@ int orc_pcg_jacobi(int64_t N, const int64_t *rowptr, const int32_t *cols,
         pw = dotp(N, p, w);
         if (!(pw > 0.0)) { reason = -7; break; }
         alpha = beta / pw;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (N > 200000)
         for (i = 0; i < N; ++i) {
             x[i] += alpha * p[i];
             r[i] -= alpha * w[i];
@@ -650,7 +650,7 @@ int orc_pcg_jacobi(int64_t N, const int64_t *rowptr, const int32_t *cols,
         if (betan < 0.0) { reason = -8; break; }
         {
             const double bb = betan / beta;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (N > 200000)
             for (i = 0; i < N; ++i) p[i] = z[i] + bb * p[i];
         }
         beta = betan;

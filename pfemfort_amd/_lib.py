@@ -91,6 +91,7 @@ SIGNATURES = {
     "pfem_solver_set_interface": [_P, _L, _P, _P, _L],
     "pfem_solver_set_exchange_buffer": [_P, _P, _L],
     "pfem_get_ghosts": [_P, _P, _P],
+    "pfem_find_ghosts": [_L, _P, _L, _L, _P, _P],
 }
 _RESTYPES = {"pfem_strerror": C.c_char_p, "pfem_last_error_string": C.c_char_p}
 

@@ -378,15 +378,12 @@ extern "C" int pfem_mesh_upload(pfem_solver *s, int kind, int64_t nElem, const i
     const int64_t ndofs = static_cast<int64_t>(m.nsize) * nElem;
 
     // ghost dofs: global ids outside the owned row block (multi-rank only)
-    s->ghost_gid.clear();
-    const int64_t lo = s->row_start, hi = s->row_start + s->n_owned;
-    for (int64_t i = 0; i < ndofs; ++i) {
-        const int32_t g = edof[i];
-        if (g < -1 || g >= s->size_global) return PFEM_ERR_ARG;
-        if (g >= 0 && (g < lo || g >= hi)) s->ghost_gid.push_back(g);
-    }
-    std::sort(s->ghost_gid.begin(), s->ghost_gid.end());
-    s->ghost_gid.erase(std::unique(s->ghost_gid.begin(), s->ghost_gid.end()), s->ghost_gid.end());
+    for (int64_t i = 0; i < ndofs; ++i)
+        if (edof[i] < -1 || edof[i] >= s->size_global) return PFEM_ERR_ARG;
+    int64_t ng = 0;
+    PFEM_TRY(pfem_find_ghosts(ndofs, edof, s->row_start, s->n_owned, &ng, nullptr));
+    s->ghost_gid.assign(static_cast<size_t>(ng), 0);
+    if (ng) PFEM_TRY(pfem_find_ghosts(ndofs, edof, s->row_start, s->n_owned, &ng, s->ghost_gid.data()));
     s->n_ghost = static_cast<int64_t>(s->ghost_gid.size());
     s->n_loc = s->n_owned + s->n_ghost;
     if (s->n_loc > INT32_MAX) return PFEM_ERR_ARG;

@@ -286,3 +286,23 @@ extern "C" int pfem_assy_for_soln(int64_t nNode, int ndof, const int32_t *NodeDo
         if (NodeDofArrayNew[s] >= 0) assyForSoln[k++] = static_cast<int32_t>(s);
     return PFEM_OK;
 }
+
+// ---------------------------------------------------------------------------
+// 4. local numbering helper for the sub-assembled multi-rank layout
+// ---------------------------------------------------------------------------
+extern "C" int pfem_find_ghosts(int64_t count, const int32_t *edof, int64_t row_start, int64_t n_owned,
+                                int64_t *n_ghost, int64_t *ghost_gid)
+{
+    if (count < 0 || (count && !edof) || row_start < 0 || n_owned < 0 || !n_ghost) return PFEM_ERR_ARG;
+    std::vector<int64_t> g;
+    const int64_t lo = row_start, hi = row_start + n_owned;
+    for (int64_t i = 0; i < count; ++i) {
+        const int64_t d = edof[i];
+        if (d >= 0 && (d < lo || d >= hi)) g.push_back(d);
+    }
+    std::sort(g.begin(), g.end());
+    g.erase(std::unique(g.begin(), g.end()), g.end());
+    *n_ghost = static_cast<int64_t>(g.size());
+    if (ghost_gid) std::copy(g.begin(), g.end(), ghost_gid);
+    return PFEM_OK;
+}

@@ -166,3 +166,13 @@ def StiffnessResidualElasticityLinearTetra(xNode, yNode, zNode, elemData, timeDa
                                       _p(_f64(timeData)), _p(_f64(valC)), _p(K), _p(F)),
             "StiffnessResidualElasticityLinearTetra")
     return K, F
+
+
+def find_ghosts(edof, row_start, n_owned):
+    """Ascending unique global dof ids of ``edof`` outside the owned block (host-only)."""
+    e = _i32(edof).ravel()
+    n = C.c_int64(0)
+    L.check(L.lib().pfem_find_ghosts(e.size, _p(e), row_start, n_owned, C.byref(n), None), "pfem_find_ghosts")
+    g = np.empty(n.value, np.int64)
+    L.check(L.lib().pfem_find_ghosts(e.size, _p(e), row_start, n_owned, C.byref(n), _p(g)), "pfem_find_ghosts")
+    return g

@@ -1,0 +1,197 @@
+"""The N>1 path, world_size 2, 127.0.0.1 rendezvous.
+
+CPU (gloo): pins the product's host logic for the sub-assembled layout -- slab partition,
+reference renumbering, ghost detection, interface plan, the torch.distributed all-reduce hook --
+by running a numpy restatement of the device CG loop on each rank (local operators from the
+oracle) and comparing with the single-rank solution.
+
+GPU (gloo on CUDA tensors, both ranks on cuda:0): the same layout through the real C++/HIP path
+(pfem_solver_set_comm / _set_interface / run_pcg with the hook), against the 1-rank GPU solve.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_setup(rank, world, kind, mesh_args, H, PD, dist):
+    """Everything a rank does before the element loop (bench.py does the same)."""
+    mesh = H.gen_box_tets(*mesh_args["box"], bc_mode=mesh_args["bc_mode"], ndof=mesh_args["ndof"])
+    nEx, nEy, nEz = mesh.box
+    epid, npid = H.partition_box_slabs(nEx, nEy, nEz, world)
+    ndof = mesh_args["ndof"]
+    dm = H.dof_numbering(mesh.nNode, ndof, mesh.bc_node, mesh.bc_dof, mesh.bc_val, world, npid)
+    conn_new = dm.node_map_get_new[mesh.conn].astype(np.int32)
+    xyz_new = np.ascontiguousarray(mesh.xyz[:, dm.node_map_get_old])
+    mine = np.nonzero(epid == rank)[0]                       # elem_proc_id(ee)==this_mpi_proc (:829)
+    conn_loc = np.ascontiguousarray(conn_new[:, mine])
+    edof_loc = H.elem_dof_array(conn_loc, dm.NodeDofArrayNew)
+    rs, re = int(dm.row_start[rank]), int(dm.row_end[rank])
+    return mesh, dm, conn_loc, xyz_new, edof_loc, rs, re
+
+
+def _cpu_worker(rank, world, port, kind, mesh_args, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import pfem_oracle as O
+        from pfemfort_amd import distributed as PD
+        from pfemfort_amd import host as H
+        mesh, dm, conn_loc, xyz_new, edof_g, rs, re = _rank_setup(rank, world, kind, mesh_args, H, PD, dist)
+        n_owned = re - rs
+        ghosts = H.find_ghosts(edof_g, rs, n_owned)
+        lists = PD.gather_ghost_lists(ghosts, dist)
+        ranges = [None] * world
+        dist.all_gather_object(ranges, (rs, re))
+        gid, slot, n_iface = PD.interface_plan(lists, ranges, rank)
+        # local numbering exactly as the device does it (k_localize_dofs): owned first, ghosts after
+        n_loc = n_owned + len(ghosts)
+        e = edof_g.astype(np.int64)
+        loc = np.where((e >= rs) & (e < re), e - rs, n_owned + np.searchsorted(ghosts, e))
+        edof_l = np.where(e < 0, -1, loc).astype(np.int32)
+        lidx = np.where((gid >= rs) & (gid < re), gid - rs, n_owned + np.searchsorted(ghosts, gid))
+        # local sub-assembled operator and rhs from the oracle (this rank's elements only)
+        ed = O.ELAST_ELEMDATA if kind == O.ELAST_TET else O.POISSON_ELEMDATA
+        rowptr, cols = O.csr_pattern(edof_l, n_loc)
+        vals, rhs = O.assemble(kind, xyz_new, conn_loc, edof_l, dm.solnApplied, ed, n_loc, rowptr, cols)
+
+        xbuf = torch.zeros(n_iface + 4, dtype=torch.float64)
+        hook = PD.TorchAllReduce(dist, xbuf)
+        xb = xbuf.numpy()
+
+        def iface_sum(v, extra=()):
+            xb[:n_iface + len(extra)] = 0.0
+            xb[slot] = v[lidx]
+            for j, s in enumerate(extra):
+                xb[n_iface + j] = s
+            assert hook(None, hook.base, n_iface + len(extra), None) == 0
+            v[lidx] = xb[slot]
+            return [xb[n_iface + j] for j in range(len(extra))]
+
+        def sum2(a, b):
+            xb[n_iface + 2:n_iface + 4] = (a, b)
+            assert hook(None, hook.base + 8 * (n_iface + 2), 2, None) == 0
+            return xb[n_iface + 2], xb[n_iface + 3]
+
+        # run_pcg (csrc/pfem_device.hip) restated in numpy
+        diag = np.array([vals[rowptr[i]:rowptr[i + 1]][cols[rowptr[i]:rowptr[i + 1]] == i].sum() for i in range(n_loc)])
+        iface_sum(diag)
+        iface_sum(rhs)
+        dinv = 1.0 / diag
+        x = np.zeros(n_loc); r = rhs.copy(); p = r * dinv
+        own = slice(0, n_owned)
+        beta, zz = sum2(float(r[own] @ p[own]), float(p[own] @ p[own]))
+        rn0 = np.sqrt(zz); ttol = max(1e-10 * rn0, 1e-50)
+        its = 0
+        for it in range(5000):
+            w = O.spmv(rowptr, cols, vals, p)
+            (pw,) = iface_sum(w, extra=(float(p @ w),))           # (p,A_loc p) over ALL local rows
+            alpha = beta / pw
+            x += alpha * p; r -= alpha * w
+            z = r * dinv
+            rz, zz = sum2(float(r[own] @ z[own]), float(z[own] @ z[own]))
+            its = it + 1
+            if np.sqrt(zz) <= ttol:
+                break
+            p = z + (rz / beta) * p
+            beta = rz
+        assert hook.error is None
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=x[own], rs=rs, re=re, its=its, n_iface=n_iface,
+                 n_ghost=len(ghosts), calls=hook.calls)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind_name", ["poisson", "elast"])
+def test_gloo_world2_subassembled_cg_matches_serial(tmp_path, kind_name):
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    import torch.multiprocessing as mp
+    from oracle import pfem_oracle as O
+    kind = O.POISSON_TET if kind_name == "poisson" else O.ELAST_TET
+    mesh_args = ({"box": (-1, 1, 6, -1, 1, 5, -1, 1, 7), "bc_mode": 0, "ndof": 1} if kind_name == "poisson" else
+                 {"box": (-0.5, 0.5, 2, 0.0, 3.0, 6, -0.5, 0.5, 4), "bc_mode": 1, "ndof": 3})
+    mp.spawn(_cpu_worker, args=(2, _free_port(), kind, mesh_args, str(tmp_path)), nprocs=2, join=True)
+    # serial truth: oracle assembly + direct solve on the SAME (renumbered) global problem
+    from pfemfort_amd import host as H
+    mesh = H.gen_box_tets(*mesh_args["box"], bc_mode=mesh_args["bc_mode"], ndof=mesh_args["ndof"])
+    _, npid = H.partition_box_slabs(*mesh.box, 2)
+    prob = O.setup_problem(kind, O.Mesh(mesh.xyz, mesh.conn, mesh.bc_node, mesh.bc_dof, mesh.bc_val), nParts=2,
+                           node_proc_id=npid)
+    u = spl.spsolve(sp.csr_matrix((prob.vals, prob.cols, prob.rowptr)).tocsc(), prob.rhs)
+    got = np.empty_like(u)
+    tot = 0
+    for r in range(2):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        got[int(d["rs"]):int(d["re"])] = d["x"]
+        tot += int(d["re"]) - int(d["rs"])
+        assert int(d["n_iface"]) > 0 and int(d["calls"]) >= 2 * int(d["its"])
+    assert tot == len(u)
+    assert np.abs(got - u).max() <= 1e-8 * max(1.0, np.abs(u).max())
+
+
+def test_interface_plan_small_example():
+    from pfemfort_amd import distributed as PD
+    # rank0 owns [0,5), rank1 [5,9), rank2 [9,12); ghosts are what each touches but does not own
+    lists = [np.array([5, 6]), np.array([3, 4, 9]), np.array([6, 8])]
+    ranges = [(0, 5), (5, 9), (9, 12)]
+    iface = [3, 4, 5, 6, 8, 9]
+    for r, (exp_g) in enumerate([[3, 4, 5, 6], [3, 4, 5, 6, 8, 9], [6, 8, 9]]):
+        gid, slot, n = PD.interface_plan(lists, ranges, r)
+        assert n == 6 and gid.tolist() == exp_g and [iface[s] for s in slot] == exp_g
+
+
+# ---------------------------------------------------------------------------------------
+def _gpu_worker(rank, world, port, mesh_args, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pfemfort_amd as pf
+        from pfemfort_amd import distributed as PD
+        from pfemfort_amd import host as H
+        kind = pf.POISSON_TET if mesh_args["ndof"] == 1 else pf.ELAST_TET
+        mesh, dm, conn_loc, xyz_new, edof_g, rs, re = _rank_setup(rank, world, kind, mesh_args, H, PD, dist)
+        s = pf.PetscSolver().initialise(re - rs, dm.size_global, row_start=rs, device=0)
+        s.setTolerances(rtol=1e-10)
+        s.uploadMesh(kind, conn_loc, xyz_new, edof_g, dm.solnApplied)
+        hook, n_iface = PD.attach(s, dist, torch, torch.device("cuda", 0))
+        s.buildPattern()
+        s.assemble(H.ELAST_ELEMDATA if kind == pf.ELAST_TET else H.POISSON_ELEMDATA, H.TIMEDATA)
+        its, reason, rn = s.factoriseAndSolve()
+        assert hook.error is None, hook.error
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=s.getSolution(), rs=rs, re=re, its=its, reason=reason,
+                 n_iface=n_iface)
+        s.free()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind_name", ["poisson", "elast"])
+def test_gpu_two_ranks_on_one_device_match_single_rank(tmp_path, kind_name):
+    import torch.multiprocessing as mp
+    import pfemfort_amd as pf
+    from pfemfort_amd import host as H
+    mesh_args = ({"box": (-1, 1, 12, -1, 1, 10, -1, 1, 14), "bc_mode": 0, "ndof": 1} if kind_name == "poisson" else
+                 {"box": (-0.5, 0.5, 3, 0.0, 3.0, 8, -0.5, 0.5, 6), "bc_mode": 1, "ndof": 3})
+    mp.spawn(_gpu_worker, args=(2, _free_port(), mesh_args, str(tmp_path)), nprocs=2, join=True)
+    mesh = H.gen_box_tets(*mesh_args["box"], bc_mode=mesh_args["bc_mode"], ndof=mesh_args["ndof"])
+    drv = pf.tetrapoissonparallelimpl1 if kind_name == "poisson" else pf.tetraelasticityparallelimpl1
+    ref = drv(mesh, rtol=1e-10)                     # slab renumbering is the identity on these boxes
+    got = np.empty_like(ref.soln_free)
+    for r in range(2):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        got[int(d["rs"]):int(d["re"])] = d["x"]
+        assert int(d["reason"]) == 2 and abs(int(d["its"]) - ref.its) <= 2
+    assert np.abs(got - ref.soln_free).max() <= 1e-8 * max(1.0, np.abs(ref.soln_free).max())

@@ -1,0 +1,123 @@
+"""Host side of the product (C ABI functions that need no GPU) against the oracle:
+per-element compat routines bit-exact, integer bookkeeping bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+import pfemfort_amd as pf
+from oracle import pfem_oracle as O
+from pfemfort_amd import host as H
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "elements.npz"))
+
+
+@pytest.fixture(scope="module")
+def tet10(golden_dir):
+    return H.read_mesh(os.path.join(golden_dir, "input", "tet10"))
+
+
+def test_per_element_routines_bit_exact(gold, tet10):
+    z4, z12 = np.zeros(4), np.zeros(12)
+    for e in range(0, 6000, 61):
+        nd = tet10.conn[:, e]
+        K, F = H.StiffnessResidualPoissonLinearTetra(tet10.xyz[0, nd], tet10.xyz[1, nd], tet10.xyz[2, nd],
+                                                     H.POISSON_ELEMDATA, H.TIMEDATA, z4)
+        assert np.array_equal(K, gold["tet10_poisson_K"][e]) and np.array_equal(F, gold["tet10_poisson_F"][e])
+    xyz, conn = gold["rt_xyz"], gold["rt_conn"]
+    for e in range(300):
+        nd = conn[:, e]
+        K, F = H.StiffnessResidualElasticityLinearTetra(xyz[0, nd], xyz[1, nd], xyz[2, nd], gold["rt_elast_data"],
+                                                        H.TIMEDATA, z12)
+        assert np.array_equal(K, gold["rt_elast_K"][e]) and np.array_equal(F, gold["rt_elast_F"][e])
+        K, F = H.StiffnessResidualPoissonLinearTetra(xyz[0, nd], xyz[1, nd], xyz[2, nd], gold["rt_aniso"], H.TIMEDATA, z4)
+        assert np.array_equal(K, gold["rt_poisson_K"][e]) and np.array_equal(F, gold["rt_poisson_F"][e])
+    xy, c3 = gold["rtri_xy"], gold["rtri_conn"]
+    for e in range(300):
+        nd = c3[:, e]
+        K, F = H.StiffnessResidualPoissonLinearTria(xy[0, nd], xy[1, nd], gold["rtri_data"], H.TIMEDATA, np.zeros(3))
+        assert np.array_equal(K, gold["rtri_K"][e]) and np.array_equal(F, gold["rtri_F"][e])
+
+
+def test_per_element_valc_residual_matches_oracle(tet10):
+    rng = np.random.default_rng(5)
+    import ctypes as C
+    for e in range(0, 6000, 500):
+        nd = tet10.conn[:, e]
+        vc = rng.standard_normal(4)
+        K, F = H.StiffnessResidualPoissonLinearTetra(tet10.xyz[0, nd], tet10.xyz[1, nd], tet10.xyz[2, nd],
+                                                     H.POISSON_ELEMDATA, H.TIMEDATA, vc)
+        Ko = np.empty(16); Fo = np.empty(4)
+        p = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)   # noqa: E731
+        x, y, z = (np.ascontiguousarray(tet10.xyz[d, nd]) for d in range(3))
+        assert O.lib().orc_poisson_tet_ke(p(x), p(y), p(z), p(O.POISSON_ELEMDATA), p(O.TIMEDATA), p(vc), p(Ko), p(Fo)) == 0
+        assert np.array_equal(K.ravel(order="F"), Ko) and np.array_equal(F, Fo)
+
+
+def test_negative_jacobian_code(tet10):
+    nd = tet10.conn[[1, 0, 2, 3], 0]
+    with pytest.raises(pf.PfemError) as ei:
+        H.StiffnessResidualPoissonLinearTetra(tet10.xyz[0, nd], tet10.xyz[1, nd], tet10.xyz[2, nd],
+                                              H.POISSON_ELEMDATA, H.TIMEDATA, np.zeros(4))
+    assert ei.value.code == 3
+
+
+@pytest.mark.parametrize("args", [(-2, 2, 10, -1, 1, 10, -1, 1, 10), (-1, 1, 7, -1, 1, 5, 0, 3, 9)])
+def test_generator_equals_oracle(args):
+    a, b = H.gen_box_tets(*args), O.gen_box_tets(*args)
+    for f in ("xyz", "conn", "bc_node", "bc_dof", "bc_val"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    a, b = H.gen_box_tets(*args, bc_mode=1, ndof=3), O.gen_box_tets(*args, bc_mode=1, ndof=3)
+    for f in ("bc_node", "bc_dof", "bc_val"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+
+
+def test_generator_slab_is_a_slice_of_the_whole():
+    whole = H.gen_box_tets(-1, 1, 4, -1, 1, 5, -1, 3, 8)
+    part = H.gen_box_tets(-1, 1, 4, -1, 1, 5, -1, 3, 8, kz=(2, 5))
+    per = 6 * 4 * 5
+    assert np.array_equal(part.conn, whole.conn[:, 2 * per:5 * per])
+    assert np.array_equal(part.xyz, whole.xyz) and np.array_equal(part.bc_val, whole.bc_val)
+
+
+@pytest.mark.parametrize("ndof", [1, 3])
+def test_numbering_equals_oracle(tet10, ndof):
+    rng = np.random.default_rng(11)
+    bn = np.repeat(tet10.bc_node[::2], ndof).astype(np.int32)
+    bd = np.tile(np.arange(ndof, dtype=np.int32), len(bn) // ndof)
+    if ndof == 3:
+        keep = rng.random(len(bn)) < 0.8           # partially constrained nodes
+        bn, bd = bn[keep], bd[keep]
+    bv = rng.standard_normal(len(bn))
+    for nparts, npid in ((1, None), (4, rng.integers(0, 4, tet10.nNode).astype(np.int32)),
+                         (3, H.partition_box_slabs(10, 10, 10, 3)[1])):
+        a = H.dof_numbering(tet10.nNode, ndof, bn, bd, bv, nparts, npid)
+        b = O.dof_numbering(tet10.nNode, ndof, bn, bd, bv, nparts, npid)
+        for f in ("node_map_get_old", "node_map_get_new", "NodeDofArrayNew", "solnApplied", "node_start", "node_end",
+                  "row_start", "row_end"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), (nparts, f)
+        assert a.size_global == b.size_global
+        cn = a.node_map_get_new[tet10.conn].astype(np.int32)
+        assert np.array_equal(H.elem_dof_array(cn, a.NodeDofArrayNew), O.elem_dof_array(cn, b.NodeDofArrayNew))
+        assert np.array_equal(H.assy_for_soln(a.NodeDofArrayNew), O.assy_for_soln(b.NodeDofArrayNew))
+
+
+def test_slab_partition_properties():
+    epid, npid = H.partition_box_slabs(4, 3, 10, 4)
+    assert epid.min() == 0 and epid.max() == 3 and (np.diff(epid) >= 0).all()
+    assert np.bincount(epid).tolist() == [6 * 12 * c for c in (2, 3, 2, 3)]
+    m = H.gen_box_tets(0, 1, 4, 0, 1, 3, 0, 1, 10)
+    # a node belongs to the lowest part among the elements that touch it
+    low = np.full(m.nNode, 99)
+    for a in range(4):
+        np.minimum.at(low, m.conn[a], epid)
+    assert np.array_equal(low, npid)
+
+
+def test_find_ghosts():
+    edof = np.array([[0, 5, 9, -1], [3, 4, 12, 9]], np.int32)
+    assert H.find_ghosts(edof, 3, 4).tolist() == [0, 9, 12]
+    assert H.find_ghosts(edof, 0, 13).tolist() == []

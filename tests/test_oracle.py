@@ -1,0 +1,148 @@
+"""The oracle against the reference's own artefacts (CPU, no GPU):
+golden Ke/Fe from the flang-compiled reference routines, the shipped mesh files, and the
+known answers of SURVEY 8(c).  Bit-exact where the quantity is an integer or an element matrix."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spl
+
+from oracle import pfem_oracle as O
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "elements.npz"))
+
+
+@pytest.fixture(scope="module")
+def tet10(golden_dir):
+    return O.read_mesh(os.path.join(golden_dir, "input", "tet10"))
+
+
+@pytest.fixture(scope="module")
+def tria20(golden_dir):
+    return O.read_mesh(os.path.join(golden_dir, "input", "tria20x20"))
+
+
+def test_elements_bit_exact_vs_reference_golden(gold, tet10, tria20):
+    K, F = O.eval_elems(O.POISSON_TET, tet10.xyz, tet10.conn, O.POISSON_ELEMDATA)
+    assert np.array_equal(K, gold["tet10_poisson_K"]) and np.array_equal(F, gold["tet10_poisson_F"])
+    K, F = O.eval_elems(O.ELAST_TET, tet10.xyz, gold["tet10_elast_conn"], O.ELAST_ELEMDATA)
+    assert np.array_equal(K, gold["tet10_elast_K"]) and np.array_equal(F, gold["tet10_elast_F"])
+    K, F = O.eval_elems(O.POISSON_TET, gold["rt_xyz"], gold["rt_conn"], gold["rt_aniso"])
+    assert np.array_equal(K, gold["rt_poisson_K"]) and np.array_equal(F, gold["rt_poisson_F"])
+    K, F = O.eval_elems(O.ELAST_TET, gold["rt_xyz"], gold["rt_conn"], gold["rt_elast_data"])
+    assert np.array_equal(K, gold["rt_elast_K"]) and np.array_equal(F, gold["rt_elast_F"])
+    K, F = O.eval_elems(O.POISSON_TRIA, tria20.xyz, tria20.conn, np.array([1.0, 1.0]))
+    assert np.array_equal(K, gold["tria20_K"]) and np.array_equal(F, gold["tria20_F"])
+    K, F = O.eval_elems(O.POISSON_TRIA, gold["rtri_xy"], gold["rtri_conn"], gold["rtri_data"])
+    assert np.array_equal(K, gold["rtri_K"]) and np.array_equal(F, gold["rtri_F"])
+
+
+@pytest.mark.skipif(O.ref_lib() is None, reason="oracle/_ref not built (needs /root/reference + flang)")
+def test_elements_bit_exact_vs_live_reference(tet10):
+    for kind, ed in ((O.POISSON_TET, O.POISSON_ELEMDATA), (O.ELAST_TET, O.ELAST_ELEMDATA)):
+        K, F = O.eval_elems(kind, tet10.xyz, tet10.conn[:, :500], ed)
+        Kr, Fr = O.ref_eval_elems(kind, tet10.xyz, tet10.conn[:, :500], ed)
+        assert np.array_equal(K, Kr) and np.array_equal(F, Fr)
+
+
+def test_unit_tet_single_precision_literals():
+    # SURVEY finding 4 / probe E.2: K(2,2) on genTetra's first tet = 1.66666671633720398E-01*3
+    xyz = np.array([[0, 1, 1, 1.0], [0, 0, 1, 0.0], [0, 0, 0, 1.0]])
+    K, F = O.eval_elems(O.POISSON_TET, xyz, np.arange(4, dtype=np.int32).reshape(4, 1), O.POISSON_ELEMDATA)
+    assert K[0, 0, 0] == 0.16666667163372040 and K[0, 1, 1] == 0.5000000149011612
+    assert F[0, 0] == -0.25000000745058060
+    assert O.ELAST_ELEMDATA[0] == 240.56500244140625 and O.ELAST_ELEMDATA[1] == 0.30000001192092896
+
+
+def test_negative_jacobian_is_an_error(tet10):
+    conn = tet10.conn[:, :4].copy()
+    conn[[0, 1], 2] = conn[[1, 0], 2]
+    with pytest.raises(RuntimeError):
+        O.eval_elems(O.POISSON_TET, tet10.xyz, conn, O.POISSON_ELEMDATA)
+
+
+def test_generator_reproduces_shipped_tet10(tet10):
+    g = O.gen_box_tets(-2, 2, 10, -1, 1, 10, -1, 1, 10)
+    assert np.array_equal(g.xyz, tet10.xyz) and np.array_equal(g.conn, tet10.conn)
+    assert np.array_equal(g.bc_node, tet10.bc_node) and np.array_equal(g.bc_val, tet10.bc_val)
+
+
+def test_generator_reproduces_shipped_tet100_bcs(golden_dir):
+    bc = np.loadtxt(gzip.open(os.path.join(golden_dir, "input", "tet100-DirichBC.dat.gz"), "rt"))
+    g = O.gen_box_tets(-1, 1, 100, -1, 1, 100, -1, 1, 100)
+    assert len(bc) == 60002 and g.nNode == 1030301 and g.nElem == 6000000
+    assert np.array_equal(g.bc_node + 1, bc[:, 0].astype(np.int64))
+    assert np.array_equal(g.bc_val, bc[:, 2])
+    a, b, c, d = (g.xyz[:, g.conn[i, ::997]] for i in range(4))
+    jac = np.einsum("ij,ij->j", a - c, np.cross((b - c).T, (d - c).T).T)
+    assert (jac > 0).all()
+
+
+def test_tet10_sizes_and_known_answer(tet10):
+    p = O.setup_problem(O.POISSON_TET, tet10)
+    N = p.dm.size_global
+    assert (N, len(p.cols)) == (729, 9097)
+    A = sp.csr_matrix((p.vals, p.cols, p.rowptr), shape=(N, N))
+    assert abs(A - A.T).max() == 0.0
+    u = spl.spsolve(A.tocsc(), p.rhs)
+    exact = (tet10.xyz ** 2).sum(0)
+    assert np.abs(O.full_solution(p, u)[:, 0] - exact).max() < 2e-7  # probe E.5: 1.2e-7
+    x, its, reason, rn, hist = O.pcg_jacobi(p.rowptr, p.cols, p.vals, p.rhs, rtol=1e-10, hist_len=100)
+    assert reason == 2 and np.abs(x - u).max() < 1e-8
+    assert hist[0] > 0 and rn <= 1e-10 * hist[0]
+    assert np.array_equal(O.spmv(p.rowptr, p.cols, p.vals, x), A @ x) or np.allclose(O.spmv(p.rowptr, p.cols, p.vals, x), A @ x, rtol=1e-14)
+
+
+def test_tria20x20_known_answer(tria20):
+    p = O.setup_problem(O.POISSON_TRIA_INLINE, tria20, elemData=np.array([1.0, 1.0, 0.0]))
+    N = p.dm.size_global
+    assert (N, len(p.cols)) == (361, 2377)
+    A = sp.csr_matrix((p.vals, p.cols, p.rowptr), shape=(N, N))
+    u = spl.spsolve(A.tocsc(), p.rhs)
+    assert abs(u.sum() - 68.09843993245326) < 1e-10
+    assert np.allclose(u[:3], [0.13364425, 0.26399773, 0.38785071], atol=5e-9)
+    x, y = tria20.xyz
+    exact = np.sin(np.pi * x) * (np.cosh(np.pi * y) - np.cosh(np.pi) / np.sinh(np.pi) * np.sinh(np.pi * y))
+    assert abs(np.abs(O.full_solution(p, u)[:, 0] - exact).max() - 7.11e-4) < 1e-5   # probe E.6
+    # the module routine and the inline element agree to rounding
+    p2 = O.setup_problem(O.POISSON_TRIA, tria20, elemData=np.array([1.0, 1.0, 0.0]))
+    assert np.abs(p2.vals - p.vals).max() < 1e-12
+
+
+def test_partitioned_numbering_invariants(tet10):
+    rng = np.random.default_rng(3)
+    npid = rng.integers(0, 3, tet10.nNode).astype(np.int32)           # any partition, METIS-like input
+    dm = O.dof_numbering(tet10.nNode, 1, tet10.bc_node, tet10.bc_dof, tet10.bc_val, 3, npid)
+    assert np.array_equal(dm.node_map_get_new[dm.node_map_get_old], np.arange(tet10.nNode))
+    for p in range(3):                                                # ranks concatenated, ascending old id
+        seg = dm.node_map_get_old[dm.node_start[p]:dm.node_end[p]]
+        assert (npid[seg] == p).all() and (np.diff(seg) > 0).all()
+    free = dm.NodeDofArrayNew[dm.NodeDofArrayNew >= 0]
+    assert np.array_equal(free, np.arange(dm.size_global)) and dm.size_global == 729
+    assert dm.row_start[0] == 0 and dm.row_end[-1] == 729 and (dm.row_start[1:] == dm.row_end[:-1]).all()
+    # the partitioned problem is a symmetric permutation of the serial one
+    p1 = O.setup_problem(O.POISSON_TET, tet10)
+    p3 = O.setup_problem(O.POISSON_TET, tet10, nParts=3, node_proc_id=npid)
+    u1 = spl.spsolve(sp.csr_matrix((p1.vals, p1.cols, p1.rowptr)).tocsc(), p1.rhs)
+    u3 = spl.spsolve(sp.csr_matrix((p3.vals, p3.cols, p3.rowptr)).tocsc(), p3.rhs)
+    assert np.abs(O.full_solution(p1, u1) - O.full_solution(p3, u3)).max() < 1e-12
+
+
+def test_beam_config4_small_cousin():
+    m = O.gen_box_tets(-0.5, 0.5, 2, 0.0, 6.0, 12, -0.5, 0.5, 2, bc_mode=1, ndof=3)
+    assert len(m.bc_node) == 3 * 9 and (m.bc_val == 0).all()
+    p = O.setup_problem(O.ELAST_TET, m)
+    N = p.dm.size_global
+    A = sp.csr_matrix((p.vals, p.cols, p.rowptr), shape=(N, N))
+    assert abs(A - A.T).max() < 1e-10 * abs(A).max()
+    u = spl.spsolve(A.tocsc(), p.rhs)
+    full = O.full_solution(p, u)
+    tip = full[m.xyz[1] == 6.0]
+    # cantilever under body force (0.1,0,0): beam theory qL^4/8EI = 0.81; the coarse P1
+    # mesh locks, so only sign/order of magnitude is asserted here
+    assert 0.05 < tip[:, 0].mean() < 0.9
