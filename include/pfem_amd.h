@@ -143,7 +143,8 @@ int pfem_solver_create(pfem_solver **s, int64_t size_local, int64_t size_global,
                        int device);
 /* free  solverpetsc.F:254-278 */
 int pfem_solver_destroy(pfem_solver *s);
-/* launch everything on this hipStream_t (e.g. torch's current stream); NULL -> own stream */
+/* launch everything on the caller's hipStream_t (e.g. torch's current stream) instead of the
+ * solver's own non-blocking stream; a null handle means the legacy default stream */
 int pfem_solver_set_stream(pfem_solver *s, void *hip_stream);
 /* KSPSetFromOptions / petsc_options.dat stand-in (tetrapoissonparallelimpl1.F:168,
  * solverpetsc.F:198): PETSc defaults are rtol 1e-5, abstol 1e-50, dtol 1e5, maxits 1e4 */

@@ -5,6 +5,7 @@
 // Module_SolverPetsc (solverpetsc.F) and the element loops of the drivers
 // (tetrapoissonparallelimpl1.F:786-884, tetraelasticityparallelimpl1.F:906-965).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -319,12 +320,9 @@ extern "C" int pfem_solver_set_stream(pfem_solver *s, void *hip_stream)
     PFEM_TRY(use_device(s));
     PFEM_HIP(hipStreamSynchronize(s->stream));
     if (s->own_stream) { (void)hipStreamDestroy(s->stream); s->own_stream = false; }
-    if (hip_stream) {
-        s->stream = static_cast<hipStream_t>(hip_stream);
-    } else {
-        PFEM_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-        s->own_stream = true;
-    }
+    // adopt the caller's stream as is; a null handle IS a stream (the legacy default stream,
+    // which is what torch.cuda.current_stream() is unless the caller switched streams)
+    s->stream = static_cast<hipStream_t>(hip_stream);
     return PFEM_OK;
 }
 
@@ -911,10 +909,13 @@ int run_pcg(pfem_solver *s)
                 e0 = s->spmv_events[ev_used];
                 e1 = s->spmv_events[ev_used + 1];
                 ev_used += 2;
-                PFEM_HIP(hipEventRecord(e0, s->stream));
             }
-            hipLaunchKernelGGL(k_spmv<true>, dim3(gs), block, 0, s->stream, A, s->d_p.p, s->d_w.p, n, part_pw, ctl);
-            if (e1) PFEM_HIP(hipEventRecord(e1, s->stream));
+            if (e0)   // dispatch-precise begin/end timestamps of THIS kernel (what rocprofv3 reports)
+                hipExtLaunchKernelGGL(k_spmv<true>, dim3(gs), block, 0, s->stream, e0, e1, 0, A,
+                                      static_cast<const double *>(s->d_p.p), s->d_w.p, n, part_pw,
+                                      static_cast<const CgCtl *>(ctl));
+            else
+                hipLaunchKernelGGL(k_spmv<true>, dim3(gs), block, 0, s->stream, A, s->d_p.p, s->d_w.p, n, part_pw, ctl);
             const double *red_pw = nullptr;
             if (multi) {
                 PFEM_TRY(interface_sum(s, s->d_w.p, part_pw, nullptr, static_cast<int>(gs), 1, ctl));
