@@ -134,10 +134,8 @@ inline unsigned grid_for(int64_t n) { return static_cast<unsigned>(std::max<int6
 inline unsigned vec_grid(int64_t n) { return static_cast<unsigned>(std::min<int64_t>(kMaxGrid, std::max<int64_t>(1, (n + kBlock - 1) / kBlock))); }
 inline unsigned spmv_grid(int64_t n_slices)
 {
-    int64_t groups = (n_slices + 3) / 4;
-    int64_t g = std::min<int64_t>(kMaxGrid, std::max<int64_t>(1, groups));
-    if (g >= kXcds) g -= g % kXcds;
-    return static_cast<unsigned>(g);
+    // one block per group of four slices (k_spmv has no grid-stride loop)
+    return static_cast<unsigned>(std::max<int64_t>(1, (n_slices + 3) / 4));
 }
 
 }  // namespace
@@ -177,7 +175,8 @@ struct pfem_solver {
     bool rhs_summed = false;
 
     // CG state
-    DevBuf<double> d_part;     // 3 * kMaxGrid partial sums
+    DevBuf<double> d_part;     // 2 * kMaxGrid partial sums of the vector kernels + 2 reduced scalars
+    DevBuf<double> d_part_pw;  // one (p,Ap) partial per SpMV block
     DevBuf<CgCtl> d_ctl;
     DevBuf<double> d_hist;
     DevBuf<int> d_err;
@@ -845,7 +844,9 @@ int run_pcg(pfem_solver *s)
     const unsigned gv = vec_grid(n), gs = spmv_grid(s->n_slices);
     const dim3 block(kBlock);
     SellDev A = s->sell();
-    double *part_pw = s->d_part.p, *part_rz = s->d_part.p + kMaxGrid, *part_zz = s->d_part.p + 2 * kMaxGrid;
+    if (s->d_part_pw.n < gs) PFEM_TRY(s->d_part_pw.alloc(gs));
+    double *part_pw = s->d_part_pw.p, *part_rz = s->d_part.p, *part_zz = s->d_part.p + kMaxGrid;
+    double *scal_pw = s->d_part.p + 2 * kMaxGrid;      // (p,Ap) reduced by k_reduce_partials
     CgCtl *ctl = s->d_ctl.p;
     if (multi) PFEM_TRY(ensure_xbuf(s));
     if (s->hist_cap < s->maxits + 2) {
@@ -916,10 +917,13 @@ int run_pcg(pfem_solver *s)
                                       static_cast<const CgCtl *>(ctl));
             else
                 hipLaunchKernelGGL(k_spmv<true>, dim3(gs), block, 0, s->stream, A, s->d_p.p, s->d_w.p, n, part_pw, ctl);
-            const double *red_pw = nullptr;
+            const double *red_pw = scal_pw;
             if (multi) {
                 PFEM_TRY(interface_sum(s, s->d_w.p, part_pw, nullptr, static_cast<int>(gs), 1, ctl));
                 red_pw = s->xbuf + s->n_iface;
+            } else {
+                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s->stream, static_cast<const double *>(part_pw),
+                                   static_cast<const double *>(nullptr), static_cast<int>(gs), scal_pw, static_cast<const CgCtl *>(ctl));
             }
             hipLaunchKernelGGL(k_cg_update, dim3(gv), block, 0, s->stream, ctl, it, n, s->n_owned, part_pw, static_cast<int>(gs),
                                red_pw, s->d_p.p, s->d_w.p, s->d_dinv.p, s->d_x.p, s->d_r.p, part_rz, part_zz);
@@ -1136,3 +1140,7 @@ extern "C" int pfem_solver_get_history(pfem_solver *s, double *hist, int n, int 
     *n_written = std::max(avail, 0);
     return PFEM_OK;
 }
+
+#ifdef PFEM_LAB
+#include "pfem_lab.inc"
+#endif

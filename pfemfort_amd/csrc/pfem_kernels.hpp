@@ -391,15 +391,20 @@ __global__ void __launch_bounds__(kBlock) k_invert(double *d, int64_t n)
 }
 
 // ---------------------------------------------------------------------------
-// SpMV  y = A x  on the wave-sliced storage: one lane per row, one wave per slice.
+// SpMV  y = A x  on the wave-sliced storage: one lane per row, one wave per slice, one
+// block per group of four consecutive slices (no grid-stride).
 // The roofline kernel: per row it streams 12 B per stored entry (f64 value + int32
 // column), gathers x through L1/L2 (banded reuse) and writes 8 B.
 //
-// Work distribution is XCD-aware: the dispatcher places block b on XCD b % 8, so
-// block b works on the (b % 8)-th contiguous eighth of the slices; the x-gather
-// window of an XCD then stays inside its private 4 MiB L2.
-// With WITH_DOT the kernel also emits the per-block partial of x.y over rows
-// < n_dot (CG's (p, Ap)).
+// Measured choices (tools/spmv_lab.py, 200^3 Poisson, MI355X):
+//   * plain block->slice order beats an XCD-contiguous remap (5.6 vs 4.6 TB/s): the
+//     stream is read once, so spreading every XCD over the whole address range
+//     balances the HBM channels, while x is small enough to live in L2/MALL anyway;
+//   * one slice group per block beats a 2048-block grid-stride loop (+7 %);
+//   * matrix values/columns are touched exactly once -> nontemporal loads (+3 %),
+//     keeping L2 for the x gather.
+// With WITH_DOT the kernel also emits the per-block partial of x.y over rows < n_dot
+// (CG's (p, Ap)); k_reduce_partials turns the partials into one scalar, in fixed order.
 // ---------------------------------------------------------------------------
 struct CgCtl {            // device-resident control block of the CG iteration
     double beta[2];       // (r,z) ping-pong by iteration parity
@@ -417,23 +422,9 @@ __global__ void __launch_bounds__(kBlock) k_spmv(SellDev A, const double *__rest
     __shared__ double sm[4];
     if (WITH_DOT && ctl->flag != 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // XCD-aware slice-group assignment (group = 4 slices = one block iteration)
-    const int64_t groups = (A.n_slices + 3) >> 2;
-    int64_t g_lo, g_hi, g_step, g_first;
-    if (gridDim.x >= kXcds && (gridDim.x % kXcds) == 0) {
-        const int xcd = blockIdx.x % kXcds, bi = blockIdx.x / kXcds, nb = gridDim.x / kXcds;
-        g_lo = groups * xcd / kXcds;
-        g_hi = groups * (xcd + 1) / kXcds;
-        g_first = g_lo + bi;
-        g_step = nb;
-    } else {
-        g_lo = 0; g_hi = groups; g_first = blockIdx.x; g_step = gridDim.x;
-    }
-    (void)g_lo;
+    const int64_t s = (static_cast<int64_t>(blockIdx.x) << 2) + wave;
     double dot = 0.0;
-    for (int64_t g = g_first; g < g_hi; g += g_step) {
-        const int64_t s = (g << 2) + wave;
-        if (s >= A.n_slices) continue;
+    if (s < A.n_slices) {
         const int64_t off = A.slice_off[s];
         const int width = static_cast<int>((A.slice_off[s + 1] - off) >> 6);
         const int32_t *__restrict__ cp = A.cols + off + lane;
@@ -441,24 +432,53 @@ __global__ void __launch_bounds__(kBlock) k_spmv(SellDev A, const double *__rest
         double acc = 0.0;
         int k = 0;
         for (; k + 4 <= width; k += 4) {
-            const int c0 = cp[64 * k], c1 = cp[64 * (k + 1)], c2 = cp[64 * (k + 2)], c3 = cp[64 * (k + 3)];
-            const double v0 = vp[64 * k], v1 = vp[64 * (k + 1)], v2 = vp[64 * (k + 2)], v3 = vp[64 * (k + 3)];
-            const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
-            acc = __builtin_fma(v0, x0, acc);
-            acc = __builtin_fma(v1, x1, acc);
-            acc = __builtin_fma(v2, x2, acc);
-            acc = __builtin_fma(v3, x3, acc);
+            int c[4];
+            double v[4], xv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                c[j] = __builtin_nontemporal_load(cp + 64 * (k + j));
+                v[j] = __builtin_nontemporal_load(vp + 64 * (k + j));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[j] = x[c[j]];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_fma(v[j], xv[j], acc);
         }
-        for (; k < width; ++k) acc = __builtin_fma(vp[64 * k], x[cp[64 * k]], acc);
+        for (; k < width; ++k)
+            acc = __builtin_fma(__builtin_nontemporal_load(vp + 64 * k), x[__builtin_nontemporal_load(cp + 64 * k)], acc);
         const int64_t row = (s << 6) + lane;
         if (row < A.n_rows) {
             y[row] = acc;
-            if (WITH_DOT && row < n_dot) dot = __builtin_fma(x[row], acc, dot);
+            if (WITH_DOT && row < n_dot) dot = x[row] * acc;
         }
     }
     if (WITH_DOT) {
         const double t = block_sum(dot, sm);
         if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    }
+}
+
+// One block of 1024 threads: out[j] = sum of part_j[0..n) for up to two partial arrays, in a
+// fixed association order (bitwise reproducible run to run).
+__global__ void __launch_bounds__(1024) k_reduce_partials(const double *part0, const double *part1, int n, double *out,
+                                                           const CgCtl *ctl)
+{
+    __shared__ double sm[16];
+    if (ctl && ctl->flag != 0) return;
+    for (int j = 0; j < 2; ++j) {
+        const double *part = j ? part1 : part0;
+        if (!part) continue;
+        double a = 0.0;
+        for (int i = threadIdx.x; i < n; i += 1024) a += part[i];
+        a = wave_sum(a);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < 16; ++w) t += sm[w];
+            out[j] = t;
+        }
     }
 }
 
