@@ -198,6 +198,14 @@ int pfem_pattern_build(pfem_solver *s);
 /* setZero + element loop :817-884 on the device: Ke/Fe, Dirichlet lifting,
  * atomic scatter into the device matrix and rhs.                                */
 int pfem_assemble(pfem_solver *s, const double *elemData, const double *timeData);
+/* Numeric-assembly formulation used by pfem_assemble:
+ *   GATHER  (default) one thread per node walks its incident elements in ascending element
+ *           order and owns its matrix rows: no atomics, K and F bit-identical to the serial
+ *           reference loop, run-to-run deterministic;
+ *   SCATTER one thread per element, hardware f64 atomicAdd into the matrix (sum order varies). */
+#define PFEM_ASSEMBLY_GATHER 0
+#define PFEM_ASSEMBLY_SCATTER 1
+int pfem_solver_set_assembly_mode(pfem_solver *s, int mode);
 /* Per-element Ke/Fe of the uploaded mesh as computed by the DEVICE kernel (parity
  * inspection): K_out[e*nsize*nsize + i + nsize*j], F_out[e*nsize + i].           */
 int pfem_eval_elems(pfem_solver *s, const double *elemData, const double *timeData,

@@ -78,6 +78,7 @@ SIGNATURES = {
     "pfem_mesh_upload": [_P, _I, _L, _P, _L, _P, _P, _P],
     "pfem_pattern_build": [_P],
     "pfem_assemble": [_P, _P, _P],
+    "pfem_solver_set_assembly_mode": [_P, _I],
     "pfem_eval_elems": [_P, _P, _P, _P, _P],
     "pfem_matrix_info": [_P, _P, _P, _P, _P],
     "pfem_get_local_to_global": [_P, _P],

@@ -165,6 +165,11 @@ struct pfem_solver {
 
     // matrix
     bool have_pattern = false;
+    int assembly_mode = PFEM_ASSEMBLY_GATHER;
+    bool have_incidence = false;
+    int geom_err = 0;              // PFEM_ERR_NEG_JAC if any element is inverted (gather form)
+    DevBuf<int64_t> d_inc_ptr;     // [nNode+1] incidence list of every node ...
+    DevBuf<int32_t> d_inc_ea;      // ... entries 4*e + a, ascending element id
     int64_t nnz = 0, n_slices = 0, stored = 0;
     DevBuf<int64_t> d_rowptr, d_slice_off;
     DevBuf<int32_t> d_rowlen, d_cols;
@@ -525,6 +530,46 @@ int pattern_from_keys(pfem_solver *s, DevBuf<uint64_t> &keys, int64_t nkeys)
 
 }  // namespace
 
+namespace {
+
+// node -> (element, local node) incidence lists, ascending element id, for the gather assembly
+int build_incidence(pfem_solver *s)
+{
+    const MeshDev &m = s->mesh;
+    s->have_incidence = false;
+    const int64_t nk = static_cast<int64_t>(m.npe) * m.nElem;
+    if (nk == 0 || nk > INT_MAX || m.nElem >= (1LL << 29)) return PFEM_OK;   // scatter form remains available
+    DevBuf<uint64_t> keys, sorted;
+    DevBuf<char> temp;
+    PFEM_TRY(keys.alloc(static_cast<size_t>(nk)));
+    PFEM_TRY(sorted.alloc(static_cast<size_t>(nk)));
+    hipLaunchKernelGGL(k_emit_inc_keys, dim3(grid_for(m.nElem)), dim3(kBlock), 0, s->stream, m, keys.p);
+    PFEM_TRY(check_kernel("k_emit_inc_keys"));
+    int bits = 1;
+    while ((1LL << bits) < std::max<int64_t>(m.nNode, 2)) ++bits;
+    size_t tb = 0;
+    const int ni = static_cast<int>(nk);
+    PFEM_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, keys.p, sorted.p, ni, 0, 32 + bits, s->stream));
+    PFEM_TRY(temp.alloc(tb));
+    PFEM_HIP(hipcub::DeviceRadixSort::SortKeys(temp.p, tb, keys.p, sorted.p, ni, 0, 32 + bits, s->stream));
+    PFEM_TRY(s->d_inc_ptr.alloc(static_cast<size_t>(m.nNode) + 1));
+    PFEM_TRY(s->d_inc_ea.alloc(static_cast<size_t>(nk)));
+    hipLaunchKernelGGL(k_row_bounds, dim3(grid_for(std::max<int64_t>(nk, m.nNode + 1))), dim3(kBlock), 0, s->stream,
+                       sorted.p, nk, m.nNode, s->d_inc_ptr.p);
+    hipLaunchKernelGGL(k_low32, dim3(grid_for(nk)), dim3(kBlock), 0, s->stream, sorted.p, nk, s->d_inc_ea.p);
+    PFEM_TRY(check_kernel("incidence"));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    // orientation test of every element, once per mesh
+    PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
+    hipLaunchKernelGGL(k_check_jacobian, dim3(grid_for(m.nElem)), dim3(kBlock), 0, s->stream, m, s->d_err.p);
+    PFEM_TRY(check_kernel("k_check_jacobian"));
+    PFEM_TRY(fetch_err(s, &s->geom_err));
+    s->have_incidence = true;
+    return PFEM_OK;
+}
+
+}  // namespace
+
 extern "C" int pfem_pattern_build(pfem_solver *s)
 {
     if (!s) return PFEM_ERR_ARG;
@@ -540,8 +585,16 @@ extern "C" int pfem_pattern_build(pfem_solver *s)
         PFEM_TRY(check_kernel("k_emit_keys"));
     }
     PFEM_TRY(pattern_from_keys(s, keys, nkeys));
+    PFEM_TRY(build_incidence(s));
     PFEM_HIP(hipEventRecord(s->ev1, s->stream));
     PFEM_TRY(elapsed(s, &s->tm.pattern_ms));
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_set_assembly_mode(pfem_solver *s, int mode)
+{
+    if (!s || (mode != PFEM_ASSEMBLY_GATHER && mode != PFEM_ASSEMBLY_SCATTER)) return PFEM_ERR_ARG;
+    s->assembly_mode = mode;
     return PFEM_OK;
 }
 
@@ -601,7 +654,29 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
     PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
     PFEM_HIP(hipEventRecord(s->ev0, s->stream));
     PFEM_TRY(zero_values(s));                 // setZero, solverpetsc.F:222-246
-    if (m.nElem > 0) {
+    if (m.nElem > 0 && s->assembly_mode == PFEM_ASSEMBLY_GATHER && s->have_incidence) {
+        // gather form: one thread per node, no atomics, bit-reproducible
+        const dim3 grid(grid_for(m.nNode)), block(kBlock);
+        SellDev A = s->sell();
+        const int64_t *ip = s->d_inc_ptr.p;
+        const int32_t *ie = s->d_inc_ea.p;
+        switch (m.kind) {
+        case PFEM_POISSON_TET:
+            hipLaunchKernelGGL(k_gather_scalar<PFEM_POISSON_TET>, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ie, s->d_err.p);
+            break;
+        case PFEM_POISSON_TRIA:
+            hipLaunchKernelGGL(k_gather_scalar<PFEM_POISSON_TRIA>, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ie, s->d_err.p);
+            break;
+        case PFEM_POISSON_TRIA_INLINE:
+            hipLaunchKernelGGL(k_gather_scalar<PFEM_POISSON_TRIA_INLINE>, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ie, s->d_err.p);
+            break;
+        case PFEM_ELAST_TET:
+            hipLaunchKernelGGL(k_gather_elast, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ie, s->d_err.p);
+            break;
+        }
+        PFEM_TRY(check_kernel("k_gather"));
+    } else if (m.nElem > 0) {
+        // scatter form: one thread per element, hardware f64 atomics
         const dim3 grid(grid_for(m.nElem)), block(kBlock);
         SellDev A = s->sell();
         switch (m.kind) {
@@ -624,6 +699,7 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
     int err = 0;
     PFEM_TRY(fetch_err(s, &err));
     PFEM_TRY(elapsed(s, &s->tm.assemble_ms));
+    if (!err && s->assembly_mode == PFEM_ASSEMBLY_GATHER && s->have_incidence) err = s->geom_err;
     if (err) return err;
     s->host_values_dirty = false;
     s->status = PFEM_ASSEMBLY_OK;

@@ -220,11 +220,19 @@ PFEM_HD ElastMat elast_material(double E, double nu)
 }
 
 // 3x3 block K(3a+p,3b+q), p,q=0..2, into blk[p][q].
+// Value form: (ax,ay,az) = grad N_a, (bx,by,bz) = grad N_b.
+PFEM_HD void elast_block_v(double ax, double ay, double az, double bx, double by, double bz,
+                           const ElastMat &m, double dvol, double blk[3][3]);
+
 PFEM_HD void elast_block(const TetGeom &g, const ElastMat &m, double dvol, int a, int b,
                          double blk[3][3])
 {
-    const double ax = g.gx[a], ay = g.gy[a], az = g.gz[a];
-    const double bx = g.gx[b], by = g.gy[b], bz = g.gz[b];
+    elast_block_v(g.gx[a], g.gy[a], g.gz[a], g.gx[b], g.gy[b], g.gz[b], m, dvol, blk);
+}
+
+PFEM_HD void elast_block_v(double ax, double ay, double az, double bx, double by, double bz,
+                           const ElastMat &m, double dvol, double blk[3][3])
+{
     // DB columns of node b (rows 0..5); structural zeros omitted
     const double c0_0 = m.d11 * bx, c0_1 = m.d12 * bx, c0_2 = m.d12 * bx, c0_3 = m.gsh * by, c0_5 = m.gsh * bz;
     const double c1_0 = m.d12 * by, c1_1 = m.d11 * by, c1_2 = m.d12 * by, c1_3 = m.gsh * bx, c1_4 = m.gsh * bz;

@@ -322,6 +322,235 @@ __global__ void __launch_bounds__(kBlock) k_assemble_elast(MeshDev m, SellDev A,
         if (dof[i] >= 0) add_f64(&rhs[dof[i]], F[i]);
 }
 
+// ---------------------------------------------------------------------------
+// numeric assembly, gather form: one thread per NODE, no atomics
+// ---------------------------------------------------------------------------
+// The scatter form above pays one memory-side atomic per element-matrix entry
+// (960 M atomics / 15.9 GB of HBM writes at 200^3; profiles/r01).  Here each node walks
+// its incident elements in ASCENDING element order (inc_ea, built in the symbolic phase),
+// re-evaluates their Ke and adds its own rows with plain read-modify-writes: a matrix row
+// has exactly one writer.  Ke is evaluated ~4x redundantly (~70 GFLOP at 200^3, nothing on
+// this chip) in exchange for zero atomics and 1x value traffic.  Because every slot receives
+// its element contributions in the same order as the serial reference loop
+// (tetrapoissonparallelimpl1.F:828-884 on one rank), K and F are BIT-IDENTICAL to the
+// reference-equivalent serial assembly, and run-to-run deterministic.
+__device__ __forceinline__ int64_t find_slot_in(const SellDev &A, int64_t base, int len, int col)
+{
+    int lo = 0, hi = len - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const int c = A.cols[base + (static_cast<int64_t>(mid) << 6)];
+        if (c == col) return base + (static_cast<int64_t>(mid) << 6);
+        if (c < col) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+
+// inc_key = (node << 32) | (4*e + a) for every (element, local node)
+__global__ void __launch_bounds__(kBlock) k_emit_inc_keys(MeshDev m, uint64_t *keys)
+{
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (e >= m.nElem) return;
+    for (int a = 0; a < m.npe; ++a)
+        keys[a * m.nElem + e] = (static_cast<uint64_t>(static_cast<uint32_t>(m.conn[a * m.nElem + e])) << 32) |
+                                static_cast<uint32_t>(4 * e + a);
+}
+
+__global__ void __launch_bounds__(kBlock) k_low32(const uint64_t *keys, int64_t n, int32_t *out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n) out[i] = static_cast<int32_t>(keys[i] & 0xffffffffu);
+}
+
+// The gather form never evaluates an element whose nodes are all constrained, but the
+// reference STOPs on ANY element with a negative Jacobian (elementutilitiespoisson.F:157):
+// the sign test runs once per mesh in the symbolic phase (coordinates do not change).
+__global__ void __launch_bounds__(kBlock) k_check_jacobian(MeshDev m, int *err)
+{
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (e >= m.nElem) return;
+    double x[4], y[4], z[4];
+    for (int a = 0; a < m.npe; ++a) {
+        const int n = m.conn[a * m.nElem + e];
+        x[a] = m.xyz[n];
+        y[a] = m.xyz[m.nNode + n];
+        z[a] = m.ndim == 3 ? m.xyz[2 * m.nNode + n] : 0.0;
+    }
+    bool neg;
+    if (m.ndim == 3) {
+        TetGeom g;
+        tet_geometry(x, y, z, g);
+        neg = g.jac < 0.0;
+    } else if (m.kind == PFEM_POISSON_TRIA) {
+        // computeBasisFunctions2D: Jac = B11*B22 - B12*B21 with the accumulated differences
+        const double b11 = ((0.0 + x[0] * -1.0) + x[1]) + x[2] * 0.0, b21 = ((0.0 + x[0] * -1.0) + x[1] * 0.0) + x[2];
+        const double b12 = ((0.0 + y[0] * -1.0) + y[1]) + y[2] * 0.0, b22 = ((0.0 + y[0] * -1.0) + y[1] * 0.0) + y[2];
+        neg = (b11 * b22 - b12 * b21) < 0.0;
+    } else {
+        neg = false;   // the inline element of triapoissonserialimpl1 has no orientation test
+    }
+    if (neg) atomicMax(err, PFEM_ERR_NEG_JAC);
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(kBlock) k_gather_scalar(MeshDev m, SellDev A, double *rhs, ElemPrm prm,
+                                                           const int64_t *__restrict__ inc_ptr,
+                                                           const int32_t *__restrict__ inc_ea, int *err)
+{
+    constexpr int NPE = (KIND == PFEM_POISSON_TET) ? 4 : 3;
+    const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (n >= m.nNode) return;
+    const int64_t beg = inc_ptr[n], end = inc_ptr[n + 1];
+    if (beg == end) return;
+    const int ea0 = inc_ea[beg];
+    const int row = m.edof[static_cast<int64_t>(ea0 & 3) * m.nElem + (ea0 >> 2)];
+    if (row < 0) return;                       // Dirichlet node: no row
+    const int64_t base = A.slice_off[row >> 6] + (row & 63);
+    const int len = A.rowlen[row];
+    const double valC[4] = {0.0, 0.0, 0.0, 0.0};
+    double facc = 0.0;
+    for (int64_t t = beg; t < end; ++t) {
+        const int ea = inc_ea[t];
+        const int64_t e = ea >> 2;
+        const int a = ea & 3;
+        int nd[NPE], dof[NPE];
+        double x[NPE], y[NPE], z[NPE];
+#pragma unroll
+        for (int i = 0; i < NPE; ++i) {
+            nd[i] = m.conn[i * m.nElem + e];
+            dof[i] = m.edof[i * m.nElem + e];
+        }
+#pragma unroll
+        for (int i = 0; i < NPE; ++i) {
+            x[i] = m.xyz[nd[i]];
+            y[i] = m.xyz[m.nNode + nd[i]];
+            z[i] = (KIND == PFEM_POISSON_TET) ? m.xyz[2 * m.nNode + nd[i]] : 0.0;
+        }
+        double K[NPE * NPE], F[NPE];
+        bool ok;
+        if constexpr (KIND == PFEM_POISSON_TET)
+            ok = poisson_tet(x, y, z, prm.ed[0], prm.ed[1], prm.ed[2], prm.af, valC, K, F);
+        else if constexpr (KIND == PFEM_POISSON_TRIA)
+            ok = poisson_tria(x, y, prm.ed[0], prm.ed[1], prm.af, valC, K, F);
+        else
+            ok = poisson_tria_inline(x, y, K, F);
+        if (!ok) { atomicMax(err, PFEM_ERR_NEG_JAC); return; }
+        // this node's entries of the element: Klocal(a,:) for the lifting, Klocal(:,a) for the row
+        double Krow[NPE], Kcol[NPE], f = 0.0;
+#pragma unroll
+        for (int i = 0; i < NPE; ++i)
+            if (i == a) {
+                f = F[i];
+#pragma unroll
+                for (int j = 0; j < NPE; ++j) { Krow[j] = K[i + NPE * j]; Kcol[j] = K[j + NPE * i]; }
+            }
+#pragma unroll
+        for (int i = 0; i < NPE; ++i)          // Flocal(a) -= Klocal(a,i)*u_D(i)   (:859-870)
+            if (dof[i] < 0) f = f - Krow[i] * m.soln[nd[i]];
+        facc += f;                             // VecSetValues(ADD_VALUES) :880
+#pragma unroll
+        for (int j = 0; j < NPE; ++j) {        // entry (row, dof_j) += Klocal(j,a)   (:851, row-major read)
+            if (dof[j] < 0) continue;
+            const int64_t s = find_slot_in(A, base, len, dof[j]);
+            if (s < 0) { atomicMax(err, PFEM_ERR_PATTERN); continue; }
+            A.vals[s] += Kcol[j];
+        }
+    }
+    rhs[row] = facc;
+}
+
+__global__ void __launch_bounds__(kBlock) k_gather_elast(MeshDev m, SellDev A, double *rhs, ElemPrm prm,
+                                                          const int64_t *__restrict__ inc_ptr,
+                                                          const int32_t *__restrict__ inc_ea, int *err)
+{
+    const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (n >= m.nNode) return;
+    const int64_t beg = inc_ptr[n], end = inc_ptr[n + 1];
+    if (beg == end) return;
+    const int ea0 = inc_ea[beg];
+    int row[3];
+    int64_t base[3];
+    int len[3];
+    bool any = false;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        row[p] = m.edof[static_cast<int64_t>(3 * (ea0 & 3) + p) * m.nElem + (ea0 >> 2)];
+        base[p] = 0; len[p] = 0;
+        if (row[p] >= 0) {
+            any = true;
+            base[p] = A.slice_off[row[p] >> 6] + (row[p] & 63);
+            len[p] = A.rowlen[row[p]];
+        }
+    }
+    if (!any) return;
+    const ElastMat mat = elast_material(prm.ed[0], prm.ed[1]);
+    double facc[3] = {0.0, 0.0, 0.0};
+    for (int64_t t = beg; t < end; ++t) {
+        const int ea = inc_ea[t];
+        const int64_t e = ea >> 2;
+        const int a = ea & 3;
+        int nd[4], dof[12];
+        double x[4], y[4], z[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nd[i] = m.conn[i * m.nElem + e];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) dof[i] = m.edof[i * m.nElem + e];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x[i] = m.xyz[nd[i]];
+            y[i] = m.xyz[m.nNode + nd[i]];
+            z[i] = m.xyz[2 * m.nNode + nd[i]];
+        }
+        TetGeom g;
+        tet_geometry(x, y, z, g);
+        if (g.jac < 0.0) { atomicMax(err, PFEM_ERR_NEG_JAC); return; }
+        const double dvol = kGaussWtTet * g.jac;
+        double ax = 0.0, ay = 0.0, az = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i == a) { ax = g.gx[i]; ay = g.gy[i]; az = g.gz[i]; }
+        const double b4 = dvol * 0.25;
+        double f[3] = {0.0 + b4 * prm.ed[3], 0.0 + b4 * prm.ed[4], 0.0 + b4 * prm.ed[5]};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            double kab[3][3], kba[3][3];
+            elast_block_v(ax, ay, az, g.gx[b], g.gy[b], g.gz[b], mat, dvol, kab);   // Klocal(3a+p, 3b+q)
+            elast_block_v(g.gx[b], g.gy[b], g.gz[b], ax, ay, az, mat, dvol, kba);   // Klocal(3b+q, 3a+p) = kba[q][p]
+            int firstq = -1;
+#pragma unroll
+            for (int q = 2; q >= 0; --q)
+                if (dof[3 * b + q] >= 0) firstq = q;
+            // lifting, q ascending:  Flocal(3a+p) -= Klocal(3a+p,3b+q) * u_D(3b+q)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (dof[3 * b + q] < 0) {
+                    const double u = m.soln[3LL * nd[b] + q];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) f[p] = f[p] - kab[p][q] * u;
+                }
+            if (firstq < 0) continue;
+            // entry (row_p, dof(3b+q)) += Klocal(3b+q, 3a+p); node b's free dofs are consecutive columns
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                if (row[p] < 0) continue;
+                int64_t s = find_slot_in(A, base[p], len[p], dof[3 * b + firstq]);
+                if (s < 0) { atomicMax(err, PFEM_ERR_PATTERN); continue; }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    if (dof[3 * b + q] < 0) continue;
+                    A.vals[s] += kba[q][p];
+                    s += 64;
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) facc[p] += f[p];
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+        if (row[p] >= 0) rhs[row[p]] = facc[p];
+}
+
 // Parity inspection: Ke/Fe of every element exactly as the assembly kernels compute them.
 __global__ void __launch_bounds__(kBlock) k_eval_elems(MeshDev m, ElemPrm prm, double *Kout, double *Fout, int *err)
 {

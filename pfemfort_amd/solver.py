@@ -154,6 +154,11 @@ class PetscSolver:
     def buildPattern(self):
         L.check(L.lib().pfem_pattern_build(self._h), "pfem_pattern_build")
 
+    def setAssemblyMode(self, mode):
+        """"gather" (default: no atomics, bit-reproducible) or "scatter" (f64 atomics)."""
+        L.check(L.lib().pfem_solver_set_assembly_mode(self._h, {"gather": 0, "scatter": 1}[mode]),
+                "pfem_solver_set_assembly_mode")
+
     def assemble(self, elemData, timeData):
         ed = None if elemData is None else _f64(elemData)
         L.check(L.lib().pfem_assemble(self._h, _p(ed), _p(_f64(timeData))), "pfem_assemble")

@@ -68,21 +68,44 @@ def test_device_tria_elements_bit_exact(tria20):
         assert np.array_equal(K, Ko) and np.array_equal(F, Fo)
 
 
-@pytest.mark.parametrize("name", ["tet10", "tria20", "beam"])
-def test_assembly_matches_oracle(name, request):
-    mesh = request.getfixturevalue(name)
+@pytest.mark.parametrize("mode", ["gather", "scatter"])
+@pytest.mark.parametrize("name", ["tet10", "tria20", "tria20mod", "beam", "beam_partial"])
+def test_assembly_matches_oracle(name, mode, request):
+    mesh = request.getfixturevalue(name.split("_")[0].replace("mod", ""))
     kind, ed = {"tet10": (pf.POISSON_TET, H.POISSON_ELEMDATA), "tria20": (pf.POISSON_TRIA_INLINE, np.array([1.0, 1.0, 0.0])),
-                "beam": (pf.ELAST_TET, H.ELAST_ELEMDATA)}[name]
-    s, dm = _device_problem(kind, mesh, ed)
+                "tria20mod": (pf.POISSON_TRIA, np.array([1.5, 0.5, 0.0])),
+                "beam": (pf.ELAST_TET, H.ELAST_ELEMDATA), "beam_partial": (pf.ELAST_TET, H.ELAST_ELEMDATA)}[name]
+    if name == "beam_partial":     # partially constrained nodes + nonzero Dirichlet values (lifting path)
+        rng = np.random.default_rng(2)
+        keep = rng.random(len(mesh.bc_node)) < 0.6
+        extra = np.arange(40, 60, dtype=np.int32)
+        mesh = H.Mesh(mesh.xyz, mesh.conn, np.concatenate([mesh.bc_node[keep], extra]),
+                      np.concatenate([mesh.bc_dof[keep], extra % 3]).astype(np.int32),
+                      np.concatenate([rng.standard_normal(keep.sum()) * 0.01, rng.standard_normal(20) * 0.01]))
+    from pfemfort_amd import drivers as D
+    dm, conn_new, xyz_new, edof = D._setup(kind, mesh)
+    s = pf.PetscSolver().initialise(dm.size_global, dm.size_global)
+    s.uploadMesh(kind, conn_new, xyz_new, edof, dm.solnApplied)
+    s.buildPattern()
+    s.setAssemblyMode(mode)
+    s.assemble(ed, H.TIMEDATA)
     prob = O.setup_problem(kind, _omesh(mesh), elemData=ed)
     rowptr, cols, vals = s.getCSR()
     assert dm.size_global == prob.dm.size_global
     assert np.array_equal(rowptr, prob.rowptr)            # pattern: bit-exact
     assert np.array_equal(cols, prob.cols)
-    scale = np.abs(prob.vals).max()
-    assert np.abs(vals - prob.vals).max() <= K_RTOL * scale
     rhs = s.getRHS()
-    assert np.abs(rhs - prob.rhs).max() <= K_RTOL * max(np.abs(prob.rhs).max(), 1e-300)
+    if mode == "gather":
+        # one writer per row, element contributions added in ascending element order ==
+        # the serial reference loop: K and F are bit-identical to the oracle
+        assert np.array_equal(vals, prob.vals)
+        assert np.array_equal(rhs, prob.rhs)
+        s.assemble(ed, H.TIMEDATA)                        # and reproducible
+        assert np.array_equal(s.getCSR()[2], vals)
+    else:
+        scale = np.abs(prob.vals).max()
+        assert np.abs(vals - prob.vals).max() <= K_RTOL * scale
+        assert np.abs(rhs - prob.rhs).max() <= K_RTOL * max(np.abs(prob.rhs).max(), 1e-300)
     if name == "tet10":
         assert (dm.size_global, len(cols)) == (729, 9097)
     if name == "tria20":
