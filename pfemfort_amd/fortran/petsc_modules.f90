@@ -1,0 +1,37 @@
+! Build-owned stand-ins for the PETSc Fortran modules the drivers USE
+! (tetrapoissonparallelimpl1.F:36-39): constants, the MPI_Wtime interface, and the options that
+! PetscInitialize("petsc_options.dat") / KSPSetFromOptions would have read.
+module petscvec
+  implicit none
+  integer, parameter :: PETSC_COMM_WORLD = 0, PETSC_COMM_SELF = 1
+  integer, parameter :: MPI_COMM_WORLD = 0
+  integer, parameter :: MPI_INT = 1, MPI_INTEGER = 1, MPI_DOUBLE_PRECISION = 2, MPI_SUM = 1
+  integer, parameter :: INSERT_VALUES = 1, ADD_VALUES = 2            ! PFEM_INSERT_VALUES / PFEM_ADD_VALUES
+  integer, parameter :: SCATTER_FORWARD = 0, SCATTER_REVERSE = 1
+  logical, parameter :: PETSC_TRUE = .true., PETSC_FALSE = .false.
+  character(len=1), parameter :: PETSC_NULL_CHARACTER = ' '
+  ! KSP options (PETSc defaults; overridden by petsc_options.dat or PFEM_KSP_* environment variables)
+  double precision, save :: pfem_opt_rtol = 1.0d-5, pfem_opt_atol = 1.0d-50, pfem_opt_dtol = 1.0d5
+  integer, save :: pfem_opt_maxits = 10000
+  ! gathered solution of VecScatterCreateToAll / VecGetArray
+  double precision, allocatable, target, save :: pfem_seq_soln(:)
+  interface
+    double precision function MPI_Wtime()
+    end function
+    ! GNU extension the drivers rely on (tetrapoissonparallelimpl1.F:158); flang wants a type
+    integer function iargc()
+    end function
+  end interface
+end module petscvec
+
+module petscmat
+  use petscvec
+end module petscmat
+
+module petscksp
+  use petscvec
+end module petscksp
+
+module petscpc
+  use petscvec
+end module petscpc

@@ -1,0 +1,239 @@
+! External procedures with the names the drivers call directly (SURVEY 8b, tier 1b): PETSc
+! Mat/Vec entry points over the pfem_solver handle, single-rank MPI, METIS placeholders.
+! Implicit-interface externals on purpose: the drivers call them without explicit interfaces.
+
+subroutine PetscInitialize(file, ierr)
+  use petscvec
+  implicit none
+  character(len=*) :: file
+  integer :: ierr, io, n
+  character(len=256) :: line, key, val
+  logical :: ex
+  ierr = 0
+  inquire(file=trim(file), exist=ex)
+  if (ex) then
+    open(97, file=trim(file), status="old", action="read")
+    do
+      read(97, '(A)', iostat=io) line
+      if (io /= 0) exit
+      line = adjustl(line)
+      if (len_trim(line) == 0 .or. line(1:1) == '#') cycle
+      n = index(trim(line), ' ')
+      if (n == 0) cycle
+      key = line(1:n-1); val = adjustl(line(n+1:))
+      select case (trim(key))
+      case ("-ksp_rtol");   read(val, *, iostat=io) pfem_opt_rtol
+      case ("-ksp_atol");   read(val, *, iostat=io) pfem_opt_atol
+      case ("-ksp_divtol"); read(val, *, iostat=io) pfem_opt_dtol
+      case ("-ksp_max_it"); read(val, *, iostat=io) pfem_opt_maxits
+      end select
+    end do
+    close(97)
+  end if
+  call get_environment_variable("PFEM_KSP_RTOL", val, status=io)
+  if (io == 0 .and. len_trim(val) > 0) read(val, *, iostat=io) pfem_opt_rtol
+  call get_environment_variable("PFEM_KSP_MAX_IT", val, status=io)
+  if (io == 0 .and. len_trim(val) > 0) read(val, *, iostat=io) pfem_opt_maxits
+end subroutine PetscInitialize
+
+subroutine PetscFinalize(ierr)
+  implicit none
+  integer :: ierr
+  ierr = 0
+end subroutine PetscFinalize
+
+! PETSc passes the Fortran string to a C printf: the literal two characters "\n" become a newline
+subroutine PetscPrintf(comm, str, ierr)
+  implicit none
+  integer :: comm, ierr, i, n
+  character(len=*) :: str
+  ierr = 0
+  n = len_trim(str)
+  i = 1
+  do while (i <= n)
+    if (i < n .and. str(i:i) == achar(92) .and. str(i+1:i+1) == 'n') then
+      write(*, *)
+      i = i + 2
+    else
+      write(*, '(A)', advance='no') str(i:i)
+      i = i + 1
+    end if
+  end do
+  if (n == 0 .or. .not. (n >= 2 .and. str(max(n-1,1):n) == achar(92)//'n')) write(*, *)
+end subroutine PetscPrintf
+
+subroutine MatSetValues(mat, m, idxm, n, idxn, v, mode, ierr)
+  use pfem_amd_c
+  implicit none
+  integer(kind=8) :: mat
+  integer :: m, n, idxm(*), idxn(*), mode, ierr
+  double precision :: v(*)
+  ierr = pfem_mat_set_values(pfem_h2p(mat), m, idxm, n, idxn, v, mode)
+  if (ierr /= 0) call pfem_chkerr(ierr)
+end subroutine MatSetValues
+
+subroutine MatSetValue(mat, row, col, v, mode, ierr)
+  use pfem_amd_c
+  implicit none
+  integer(kind=8) :: mat
+  integer :: row, col, mode, ierr, r(1), c(1)
+  double precision :: v, vv(1)
+  r(1) = row; c(1) = col; vv(1) = v
+  ierr = pfem_mat_set_values(pfem_h2p(mat), 1, r, 1, c, vv, mode)
+  if (ierr /= 0) call pfem_chkerr(ierr)
+end subroutine MatSetValue
+
+subroutine VecSetValues(vec, n, idx, v, mode, ierr)
+  use pfem_amd_c
+  implicit none
+  integer(kind=8) :: vec
+  integer :: n, idx(*), mode, ierr
+  double precision :: v(*)
+  ierr = pfem_vec_set_values(pfem_h2p(vec), n, idx, v, mode)
+  if (ierr /= 0) call pfem_chkerr(ierr)
+end subroutine VecSetValues
+
+subroutine VecSetValue(vec, row, v, mode, ierr)
+  use pfem_amd_c
+  implicit none
+  integer(kind=8) :: vec
+  integer :: row, mode, ierr, r(1)
+  double precision :: v, vv(1)
+  r(1) = row; vv(1) = v
+  ierr = pfem_vec_set_values(pfem_h2p(vec), 1, r, vv, mode)
+  if (ierr /= 0) call pfem_chkerr(ierr)
+end subroutine VecSetValue
+
+! VecScatterCreateToAll + Begin/End: on one rank the gathered vector IS the solution vector
+subroutine VecScatterCreateToAll(vec, ctx, vec_seq, ierr)
+  implicit none
+  integer(kind=8) :: vec, ctx, vec_seq
+  integer :: ierr
+  ctx = vec; vec_seq = vec; ierr = 0
+end subroutine VecScatterCreateToAll
+
+subroutine VecScatterBegin(ctx, vin, vout, mode, dir, ierr)
+  implicit none
+  integer(kind=8) :: ctx, vin, vout
+  integer :: mode, dir, ierr
+  ierr = 0
+end subroutine VecScatterBegin
+
+subroutine VecScatterEnd(ctx, vin, vout, mode, dir, ierr)
+  implicit none
+  integer(kind=8) :: ctx, vin, vout
+  integer :: mode, dir, ierr
+  ierr = 0
+end subroutine VecScatterEnd
+
+subroutine VecScatterDestroy(ctx, ierr)
+  implicit none
+  integer(kind=8) :: ctx
+  integer :: ierr
+  ctx = 0; ierr = 0
+end subroutine VecScatterDestroy
+
+! Legacy VecGetArray(vec, xx_v, xx_i, ierr): the caller indexes xx_v(xx_i + k), k = 1..n
+! (tetrapoissonparallelimpl1.F:932-938), so xx_i is the distance in elements from xx_v(1) to
+! one-before the first entry of the fetched solution.
+subroutine VecGetArray(vec, xx_v, xx_i, ierr)
+  use pfem_amd_c
+  use petscvec, only: pfem_seq_soln
+  implicit none
+  integer(kind=8) :: vec, xx_i
+  double precision, target :: xx_v(*)
+  integer :: ierr
+  integer(c_int64_t) :: nown, nloc, nnz, nst
+  integer(kind=8) :: a0, a1
+  interface
+    integer(c_int) function pfem_matrix_info(s, a, b, c, d) bind(C, name="pfem_matrix_info")
+      import
+      type(c_ptr), value :: s
+      integer(c_int64_t) :: a, b, c, d
+    end function
+  end interface
+  ierr = pfem_matrix_info(pfem_h2p(vec), nown, nloc, nnz, nst)
+  if (ierr /= 0) call pfem_chkerr(ierr)
+  if (allocated(pfem_seq_soln)) deallocate(pfem_seq_soln)
+  allocate(pfem_seq_soln(max(nown, 1_c_int64_t)))
+  ierr = pfem_solver_get_solution(pfem_h2p(vec), pfem_seq_soln)
+  if (ierr /= 0) call pfem_chkerr(ierr)
+  a0 = transfer(c_loc(xx_v(1)), a0)
+  a1 = transfer(c_loc(pfem_seq_soln(1)), a1)
+  xx_i = (a1 - a0) / 8 - 0      ! xx_v(xx_i + 1) == pfem_seq_soln(1)
+end subroutine VecGetArray
+
+subroutine VecRestoreArray(vec, xx_v, xx_i, ierr)
+  implicit none
+  integer(kind=8) :: vec, xx_i
+  double precision :: xx_v(*)
+  integer :: ierr
+  ierr = 0
+end subroutine VecRestoreArray
+
+! ---- MPI on one rank -------------------------------------------------------------------------
+double precision function MPI_Wtime()
+  implicit none
+  integer(kind=8) :: c, r
+  call system_clock(c, r)
+  MPI_Wtime = dble(c) / dble(r)
+end function MPI_Wtime
+
+subroutine MPI_Comm_size(comm, n, ierr)
+  implicit none
+  integer :: comm, n, ierr
+  n = 1; ierr = 0
+end subroutine MPI_Comm_size
+
+subroutine MPI_Comm_rank(comm, r, ierr)
+  implicit none
+  integer :: comm, r, ierr
+  r = 0; ierr = 0
+end subroutine MPI_Comm_rank
+
+subroutine MPI_Barrier(comm, ierr)
+  implicit none
+  integer :: comm, ierr
+  ierr = 0
+end subroutine MPI_Barrier
+
+subroutine MPI_Bcast(buf, n, dtype, root, comm, ierr)
+  implicit none
+  integer :: buf(*), n, dtype, root, comm, ierr
+  ierr = 0
+end subroutine MPI_Bcast
+
+subroutine MPI_Allgather(sbuf, ns, stype, rbuf, nr, rtype, comm, ierr)
+  implicit none
+  integer :: sbuf(*), ns, stype, rbuf(*), nr, rtype, comm, ierr
+  rbuf(1:ns) = sbuf(1:ns); ierr = 0
+end subroutine MPI_Allgather
+
+subroutine MPI_Allgatherv(sbuf, ns, stype, rbuf, nrs, displs, rtype, comm, ierr)
+  implicit none
+  integer :: sbuf(*), ns, stype, rbuf(*), nrs(*), displs(*), rtype, comm, ierr
+  rbuf(displs(1)+1:displs(1)+ns) = sbuf(1:ns); ierr = 0
+end subroutine MPI_Allgatherv
+
+subroutine MPI_Allreduce(sbuf, rbuf, n, dtype, op, comm, ierr)
+  implicit none
+  integer :: sbuf(*), rbuf(*), n, dtype, op, comm, ierr
+  rbuf(1:n) = sbuf(1:n); ierr = 0
+end subroutine MPI_Allreduce
+
+! ---- METIS: only reached when n_mpi_procs > 1 (tetrapoissonparallelimpl1.F:423) ---------------
+subroutine METIS_SetDefaultOptions(options)
+  implicit none
+  integer :: options(*)
+  options(1) = 0
+end subroutine METIS_SetDefaultOptions
+
+subroutine METIS_PartMeshNodal(ne, nn, eptr, eind, vwgt, vsize, nparts, tpwgts, options, objval, epart, npart)
+  implicit none
+  integer :: ne, nn, eptr(*), eind(*), vwgt, vsize, nparts, options(*), objval, epart(*), npart(*)
+  double precision :: tpwgts
+  stop "METIS is not linked into the single-process Fortran shim (use the torch.distributed host for N>1)"
+end subroutine METIS_PartMeshNodal
+
+! (iargc/getarg, GNU extensions used by the drivers, come from the flang runtime; petscvec only
+!  declares iargc's type because the drivers are IMPLICIT NONE)

@@ -1,0 +1,140 @@
+! pfem_amd_c.f90 -- BIND(C) interfaces to libpfem_amd.so (include/pfem_amd.h).
+! Build-owned Fortran side of the drop-in boundary: the modules in this directory carry the
+! reference's own module / procedure / type names so that tetrapoissonparallelimpl1.F and
+! tetraelasticityparallelimpl1.F compile UNCHANGED against them (see INTEGRATION.md).
+module pfem_amd_c
+  use iso_c_binding
+  implicit none
+  interface
+    integer(c_int) function pfem_poisson_tria_ke(x, y, ed, td, vc, K, F) bind(C, name="pfem_poisson_tria_ke")
+      import
+      real(c_double) :: x(3), y(3), ed(*), td(*), vc(3), K(3,3), F(3)
+    end function
+    integer(c_int) function pfem_poisson_tet_ke(x, y, z, ed, td, vc, K, F) bind(C, name="pfem_poisson_tet_ke")
+      import
+      real(c_double) :: x(4), y(4), z(4), ed(*), td(*), vc(4), K(4,4), F(4)
+    end function
+    integer(c_int) function pfem_elast_tet_ke(x, y, z, ed, td, vc, K, F) bind(C, name="pfem_elast_tet_ke")
+      import
+      real(c_double) :: x(4), y(4), z(4), ed(*), td(*), vc(12), K(12,12), F(12)
+    end function
+    integer(c_int) function pfem_solver_create(s, size_local, size_global, row_start, diag_nnz, offdiag_nnz, device) &
+        bind(C, name="pfem_solver_create")
+      import
+      type(c_ptr) :: s
+      integer(c_int64_t), value :: size_local, size_global, row_start
+      integer(c_int) :: diag_nnz(*), offdiag_nnz(*)
+      integer(c_int), value :: device
+    end function
+    integer(c_int) function pfem_solver_destroy(s) bind(C, name="pfem_solver_destroy")
+      import
+      type(c_ptr), value :: s
+    end function
+    integer(c_int) function pfem_solver_set_tolerances(s, rtol, abstol, dtol, maxits) bind(C, name="pfem_solver_set_tolerances")
+      import
+      type(c_ptr), value :: s
+      real(c_double), value :: rtol, abstol, dtol
+      integer(c_int), value :: maxits
+    end function
+    integer(c_int) function pfem_solver_set_zero(s) bind(C, name="pfem_solver_set_zero")
+      import
+      type(c_ptr), value :: s
+    end function
+    integer(c_int) function pfem_solver_print_info(s) bind(C, name="pfem_solver_print_info")
+      import
+      type(c_ptr), value :: s
+    end function
+    integer(c_int) function pfem_mat_set_values(s, m, idxm, n, idxn, v, mode) bind(C, name="pfem_mat_set_values")
+      import
+      type(c_ptr), value :: s
+      integer(c_int), value :: m, n, mode
+      integer(c_int) :: idxm(*), idxn(*)
+      real(c_double) :: v(*)
+    end function
+    integer(c_int) function pfem_vec_set_values(s, n, idx, v, mode) bind(C, name="pfem_vec_set_values")
+      import
+      type(c_ptr), value :: s
+      integer(c_int), value :: n, mode
+      integer(c_int) :: idx(*)
+      real(c_double) :: v(*)
+    end function
+    integer(c_int) function pfem_solver_assemble_matrix_and_vector(s, n, rows, cols, K, F) &
+        bind(C, name="pfem_solver_assemble_matrix_and_vector")
+      import
+      type(c_ptr), value :: s
+      integer(c_int), value :: n
+      integer(c_int) :: rows(*), cols(*)
+      type(c_ptr), value :: K, F
+    end function
+    integer(c_int) function pfem_solver_factorise(s) bind(C, name="pfem_solver_factorise")
+      import
+      type(c_ptr), value :: s
+    end function
+    integer(c_int) function pfem_solver_solve(s, its, reason, rnorm) bind(C, name="pfem_solver_solve")
+      import
+      type(c_ptr), value :: s
+      integer(c_int) :: its, reason
+      real(c_double) :: rnorm
+    end function
+    integer(c_int) function pfem_solver_factorise_and_solve(s, its, reason, rnorm) bind(C, name="pfem_solver_factorise_and_solve")
+      import
+      type(c_ptr), value :: s
+      integer(c_int) :: its, reason
+      real(c_double) :: rnorm
+    end function
+    integer(c_int) function pfem_solver_status(s, st) bind(C, name="pfem_solver_status")
+      import
+      type(c_ptr), value :: s
+      integer(c_int) :: st
+    end function
+    integer(c_int) function pfem_solver_get_solution(s, x) bind(C, name="pfem_solver_get_solution")
+      import
+      type(c_ptr), value :: s
+      real(c_double) :: x(*)
+    end function
+    function pfem_last_error_string() bind(C, name="pfem_last_error_string") result(p)
+      import
+      type(c_ptr) :: p
+    end function
+    function pfem_strerror(code) bind(C, name="pfem_strerror") result(p)
+      import
+      integer(c_int), value :: code
+      type(c_ptr) :: p
+    end function
+  end interface
+contains
+  ! 8-byte PETSc-style handle <-> C pointer
+  function pfem_h2p(h) result(p)
+    integer(kind=8), intent(in) :: h
+    type(c_ptr) :: p
+    p = transfer(h, p)
+  end function
+  function pfem_p2h(p) result(h)
+    type(c_ptr), intent(in) :: p
+    integer(kind=8) :: h
+    h = transfer(p, h)
+  end function
+  subroutine pfem_print_cstr(p)
+    type(c_ptr), intent(in) :: p
+    character(kind=c_char), pointer :: s(:)
+    integer :: i
+    if (.not. c_associated(p)) return
+    call c_f_pointer(p, s, [4096])
+    do i = 1, 4096
+      if (s(i) == c_null_char) exit
+      write(*, '(A)', advance='no') s(i)
+    end do
+    write(*, *)
+  end subroutine
+end module pfem_amd_c
+
+! CHKERRQ(n) of the include files lands here (PETSc: MPI_Abort)
+subroutine pfem_chkerr(n)
+  use pfem_amd_c
+  implicit none
+  integer, intent(in) :: n
+  write(*, '(A,I0,A)', advance='no') " pfem_amd error ", n, ": "
+  call pfem_print_cstr(pfem_strerror(int(n, c_int)))
+  call pfem_print_cstr(pfem_last_error_string())
+  stop 1
+end subroutine pfem_chkerr

@@ -1,0 +1,158 @@
+! Build-owned replacement of MODULE Module_SolverPetsc (solverpetsc.F): TYPE PetscSolver with the
+! same public components and procedures; Mat/Vec/KSP components all alias the one pfem_solver
+! handle, because the drivers only hand them back to MatSetValues / VecSetValues / VecGetArray.
+module Module_SolverPetsc
+  use pfem_amd_c
+  use petscvec, only: pfem_opt_rtol, pfem_opt_atol, pfem_opt_dtol, pfem_opt_maxits
+  implicit none
+  integer, parameter :: SOLVER_EMPTY=1, PATTERN_OK=2, INIT_OK=3, ASSEMBLY_OK=4, FACTORISE_OK=5   ! solverpetsc.F:64-68
+
+  type PetscSolver
+    integer(kind=8) :: rhsVec = 0, solnVec = 0, solnPrev = 0, mtx = 0, ksp = 0, pc = 0
+    integer :: nRow = 0, nCol = 0, nnz = 0
+    double precision :: norm = 0.0d0
+    integer :: currentStatus = 0
+    integer :: its = 0, reason = 0
+  contains
+    procedure :: initialise
+    procedure :: setZero
+    procedure :: free
+    procedure :: printInfo
+    procedure :: assembleMatrix
+    procedure :: assembleVector
+    procedure :: assembleMatrixAndVector
+    procedure :: factorise
+    procedure :: solve
+    procedure :: factoriseAndSolve
+  end type PetscSolver
+
+contains
+
+  subroutine sync_status(this)
+    class(PetscSolver) :: this
+    integer(c_int) :: st
+    if (pfem_solver_status(pfem_h2p(this%mtx), st) == 0) this%currentStatus = st
+  end subroutine
+
+  ! solverpetsc.F:116-214
+  subroutine initialise(this, size_local, size_global, diag_nnz, offdiag_nnz)
+    class(PetscSolver) :: this
+    integer, intent(in) :: size_global, size_local
+    integer, dimension(:) :: diag_nnz, offdiag_nnz
+    type(c_ptr) :: h
+    integer :: ierr
+    this%nRow = size_global
+    this%nCol = size_global
+    ierr = pfem_solver_create(h, int(size_local, c_int64_t), int(size_global, c_int64_t), 0_c_int64_t, &
+                              diag_nnz, offdiag_nnz, -1_c_int)
+    if (ierr /= 0) call pfem_chkerr(ierr)
+    ierr = pfem_solver_set_tolerances(h, pfem_opt_rtol, pfem_opt_atol, pfem_opt_dtol, int(pfem_opt_maxits, c_int))
+    if (ierr /= 0) call pfem_chkerr(ierr)
+    this%mtx = pfem_p2h(h)
+    this%rhsVec = this%mtx
+    this%solnVec = this%mtx
+    this%ksp = this%mtx
+    this%pc = this%mtx
+    this%currentStatus = SOLVER_EMPTY
+  end subroutine initialise
+
+  ! solverpetsc.F:222-246
+  subroutine setZero(this)
+    class(PetscSolver) :: this
+    integer :: ierr
+    ierr = pfem_solver_set_zero(pfem_h2p(this%mtx))
+    if (ierr /= 0) call pfem_chkerr(ierr)
+    call sync_status(this)
+  end subroutine setZero
+
+  ! solverpetsc.F:254-278
+  subroutine free(this)
+    class(PetscSolver) :: this
+    integer :: ierr
+    if (this%mtx /= 0) ierr = pfem_solver_destroy(pfem_h2p(this%mtx))
+    this%mtx = 0; this%rhsVec = 0; this%solnVec = 0; this%ksp = 0; this%pc = 0
+  end subroutine free
+
+  ! solverpetsc.F:286-320
+  subroutine printInfo(this)
+    class(PetscSolver) :: this
+    integer :: ierr
+    ierr = pfem_solver_print_info(pfem_h2p(this%mtx))
+  end subroutine printInfo
+
+  ! solverpetsc.F:328-401
+  subroutine assembleMatrix(this, RINDICES, CINDICES, KLOCAL)
+    class(PetscSolver) :: this
+    integer, dimension(:) :: RINDICES, CINDICES
+    double precision, dimension(:,:), target :: KLOCAL
+    double precision, allocatable, target :: K(:,:)
+    integer :: ierr
+    K = KLOCAL
+    ierr = pfem_solver_assemble_matrix_and_vector(pfem_h2p(this%mtx), size(RINDICES), RINDICES, CINDICES, c_loc(K), c_null_ptr)
+    if (ierr /= 0) call pfem_chkerr(ierr)
+  end subroutine assembleMatrix
+
+  subroutine assembleVector(this, RINDICES, FLOCAL)
+    class(PetscSolver) :: this
+    integer, dimension(:) :: RINDICES
+    double precision, dimension(:), target :: FLOCAL
+    double precision, allocatable, target :: F(:)
+    integer :: ierr
+    F = FLOCAL
+    ierr = pfem_solver_assemble_matrix_and_vector(pfem_h2p(this%mtx), size(RINDICES), RINDICES, RINDICES, c_null_ptr, c_loc(F))
+    if (ierr /= 0) call pfem_chkerr(ierr)
+  end subroutine assembleVector
+
+  subroutine assembleMatrixAndVector(this, RINDICES, CINDICES, KLOCAL, FLOCAL)
+    class(PetscSolver) :: this
+    integer, dimension(:) :: RINDICES, CINDICES
+    double precision, dimension(:,:) :: KLOCAL
+    double precision, dimension(:) :: FLOCAL
+    double precision, allocatable, target :: K(:,:), F(:)
+    integer :: ierr
+    K = KLOCAL; F = FLOCAL
+    ierr = pfem_solver_assemble_matrix_and_vector(pfem_h2p(this%mtx), size(RINDICES), RINDICES, CINDICES, c_loc(K), c_loc(F))
+    if (ierr /= 0) call pfem_chkerr(ierr)
+  end subroutine assembleMatrixAndVector
+
+  ! solverpetsc.F:409-423
+  subroutine factorise(this)
+    class(PetscSolver) :: this
+    if (this%currentStatus /= ASSEMBLY_OK) then
+      write(*,*) "Assemble matrix first before solving it! "
+      stop " Aborting... in 'solverpetsc->factorise' "
+    end if
+    this%currentStatus = FACTORISE_OK          ! status check only, as in the reference
+  end subroutine factorise
+
+  ! solverpetsc.F:431-490
+  subroutine solve(this)
+    class(PetscSolver) :: this
+    integer(c_int) :: its, reason
+    real(c_double) :: rn
+    integer :: ierr
+    if (this%currentStatus /= FACTORISE_OK) then
+      write(*,*) "Factorise matrix first before solving it! "
+      stop " Aborting... in 'solverpetsc->solve' "
+    end if
+    write(*,*) " Solving the matrix system "
+    ! MatAssembly/VecAssembly (push host-staged values) + KSPSolve on the GPU
+    ierr = pfem_solver_factorise_and_solve(pfem_h2p(this%mtx), its, reason, rn)
+    if (ierr /= 0) call pfem_chkerr(ierr)
+    this%its = its; this%reason = reason; this%norm = rn
+    if (reason < 0) then
+      write(*,*) "Divergence."
+    else
+      write(*,*) "Convergence in", its, " iterations."
+    end if
+  end subroutine solve
+
+  ! solverpetsc.F:498-509
+  subroutine factoriseAndSolve(this)
+    class(PetscSolver) :: this
+    this%currentStatus = ASSEMBLY_OK
+    call this%factorise()
+    call this%solve()
+  end subroutine factoriseAndSolve
+
+end module Module_SolverPetsc

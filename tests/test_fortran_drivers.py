@@ -1,0 +1,96 @@
+"""The reference's own driver PROGRAMs (compiled in place by `make -C oracle drivers` against the
+build-owned Fortran modules + libpfem_amd.so) run end to end: mesh files in, temp.dat out.
+
+This is the "drop onto it unchanged" check of the boundary: the Fortran element loop calls
+StiffnessResidual* / MatSetValues / VecSetValues once per element exactly as written in
+tetrapoissonparallelimpl1.F:786-884, and solverpetsc%factoriseAndSolve runs the GPU solve.
+The executables are reference-derived build products (oracle/_ref, never committed)."""
+import gzip
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import pfemfort_amd as pf
+from oracle import pfem_oracle as O
+from pfemfort_amd import host as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def _exe(name):
+    path = os.path.join(REF, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not built (needs /root/reference + flang in the build container)")
+    return path
+
+
+def _write_mesh(mesh, prefix, ndof):
+    with open(prefix + "-nodes.dat", "w") as f:
+        for i in range(mesh.nNode):
+            f.write("%d\t%.8f\t%.8f\t%.8f\n" % (i + 1, *mesh.xyz[:, i]))
+    with open(prefix + "-elems.dat", "w") as f:
+        for e in range(mesh.nElem):
+            f.write("%d\t%d\t%d\t%d\t%d\n" % (e + 1, *(mesh.conn[:, e] + 1)))
+    with open(prefix + "-DirichBC.dat", "w") as f:
+        for n, d, v in zip(mesh.bc_node, mesh.bc_dof, mesh.bc_val):
+            f.write("%d\t%d\t%.8f\n" % (n + 1, d + 1, v))
+
+
+def _run(exe, prefix, cwd, rtol="1e-10"):
+    env = dict(os.environ, PFEM_KSP_RTOL=rtol)
+    return subprocess.run([exe, prefix + "-nodes.dat", prefix + "-elems.dat", prefix + "-DirichBC.dat"], cwd=cwd, env=env,
+                          capture_output=True, text=True, timeout=600)
+
+
+@pytest.mark.skipif(pf.device_count() > 0, reason="a GPU is present")
+def test_unchanged_driver_links_runs_bookkeeping_and_fails_loudly_without_gpu(tmp_path, golden_dir):
+    exe = _exe("tetrapoissonparallelimpl1")
+    for k in ("nodes", "elems", "DirichBC"):
+        with gzip.open(os.path.join(golden_dir, "input", f"tet10-{k}.dat.gz"), "rb") as src, \
+                open(tmp_path / f"tet10-{k}.dat", "wb") as dst:
+            shutil.copyfileobj(src, dst)
+    r = _run(exe, "tet10", tmp_path)
+    out = r.stdout + r.stderr
+    assert "Total DOF      =  729" in out               # the driver's own bookkeeping ran (:357-383)
+    assert "no HIP device" in out and r.returncode != 0  # solverpetsc%initialise refuses: no CPU path
+
+
+@pytest.mark.gpu
+def test_unchanged_poisson_driver_on_tet10(tmp_path, golden_dir):
+    exe = _exe("tetrapoissonparallelimpl1")
+    for k in ("nodes", "elems", "DirichBC"):
+        with gzip.open(os.path.join(golden_dir, "input", f"tet10-{k}.dat.gz"), "rb") as src, \
+                open(tmp_path / f"tet10-{k}.dat", "wb") as dst:
+            shutil.copyfileobj(src, dst)
+    r = _run(exe, "tet10", tmp_path)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Convergence in" in r.stdout and "Program is successful" in r.stdout
+    t = np.loadtxt(tmp_path / "temp.dat")                # ii, old node, value  (:935-942)
+    mesh = O.read_mesh(os.path.join(golden_dir, "input", "tet10"))
+    prob = O.setup_problem(O.POISSON_TET, mesh)
+    x, *_ = O.pcg_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-12)
+    assy = O.assy_for_soln(prob.dm.NodeDofArrayNew)
+    assert np.array_equal(t[:, 0].astype(int), np.arange(1, 730))
+    assert np.array_equal(t[:, 1].astype(int), prob.dm.node_map_get_old[assy] + 1)     # integer maps: bit-exact
+    assert np.abs(t[:, 2] - x).max() < 1e-8
+    exact = (mesh.xyz ** 2).sum(0)
+    assert np.abs(t[:, 2] - exact[t[:, 1].astype(int) - 1]).max() < 2e-7
+    assert os.path.exists(tmp_path / "Poisson-soln.vtk")  # the reference's own writervtk.F ran
+
+
+@pytest.mark.gpu
+def test_unchanged_elasticity_driver_on_small_beam(tmp_path):
+    exe = _exe("tetraelasticityparallelimpl1")
+    mesh = H.gen_box_tets(-0.5, 0.5, 3, 0.0, 6.0, 12, -0.5, 0.5, 3, bc_mode=1, ndof=3)
+    _write_mesh(mesh, str(tmp_path / "beam"), 3)
+    r = _run(exe, "beam", tmp_path)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Convergence in" in r.stdout
+    u = np.loadtxt(tmp_path / "temp.dat")                # one value per free dof (:1031-1046)
+    prob = O.setup_problem(O.ELAST_TET, O.Mesh(mesh.xyz, mesh.conn, mesh.bc_node, mesh.bc_dof, mesh.bc_val))
+    x, *_ = O.pcg_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-12)
+    assert len(u) == len(x) and np.abs(u - x).max() < 1e-8 * max(1.0, np.abs(x).max())
