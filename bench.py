@@ -10,10 +10,14 @@ Inputs (mesh, maps, pattern) are resident in HBM before the timed region, as in 
 where mesh read / numbering / pattern precede the timers.
 
 N = 1 : BASELINE.json configs[2]: synthetic [-1,1]^3, 200x200x200x6 P1 tets (genTetra logic).
-N > 1 : weak scaling, one process per GPU: the box grows along z, 200x200x(200 N) cells of the
-        same size over [-1,1]^2 x [-1,2N-1], rank r owns hex layers [200 r, 200 (r+1)); interface
-        rows are summed with one RCCL all-reduce per SpMV (torch.distributed "nccl").
-        (--cube runs BASELINE configs[4]'s 400^3 box for N = 8 instead.)
+N > 1 : weak scaling, one process per GPU, per-GPU element count fixed: the [-1,1]^3 cube with
+        round(200 N^(1/3)) cells per side (N = 8: BASELINE configs[4], 400x400x400x6), cut into N
+        z-slabs of hex layers; interface rows are summed with one RCCL all-reduce per SpMV
+        (torch.distributed "nccl").  --stack grows the box along z instead (200x200x200N cells of
+        the same size, 4x smaller interfaces).  Either way the Jacobi-PCG iteration count about
+        doubles from N=1 to N=8 (measured: tools/probe_iters.py), which caps DOF/s scaling at
+        ~0.5 N independently of the hardware; `iterations` is reported so per-iteration scaling
+        can be derived.
 
 Prints ONE JSON line on rank 0 (contract in the task description), with `roofline` for the CG
 SpMV kernel (HIP events around every SpMV launch of the timed solves) and `cpu_baseline` (the C
@@ -29,6 +33,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def pmc_traffic(nnz):
+    """HBM bytes per k_spmv<true> launch from the committed rocprofv3 PMC passes
+    (profiles/spmv_pmc_traffic.json, written by tools/gpu_round.sh on the SAME workload):
+    (2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "spmv_pmc_traffic.json")))
+        if d.get("nnz") == nnz:
+            return (2.0 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024.0
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def cpu_baseline(n=100, rtol=1e-5):
@@ -66,11 +83,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=200, help="cells per side of one rank's block")
+    ap.add_argument("--cells", dest="n", type=int, default=200, help="cells per side of one rank's block")
     ap.add_argument("--rtol", type=float, default=1e-5, help="PETSc default (the reference sets none)")
-    ap.add_argument("--cube", action="store_true", help="N>1: cube of (n*N^(1/3))^3 cells instead of the z-extended box")
+    ap.add_argument("--stack", action="store_true", help="N>1: z-extended box n x n x (n N) instead of the cube of n N^(1/3) cells per side")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--same-device", action="store_true",
+                    help="development: put every rank on cuda:0 (with --backend gloo) to exercise the N>1 path on a 1-GPU box")
     args = ap.parse_args()
 
     import numpy as np
@@ -86,7 +105,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
 
     dist = torch = None
-    device_index = local_rank if world > 1 else 0
+    device_index = local_rank if (world > 1 and not args.same_device) else 0
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -101,7 +120,7 @@ def main():
     n = args.n
     if world == 1:
         nE = (n, n, n); zspan = (-1.0, 1.0)
-    elif args.cube:
+    elif not args.stack:
         side = round(n * world ** (1.0 / 3.0))
         nE = (side, side, side); zspan = (-1.0, 1.0)
     else:
@@ -113,7 +132,7 @@ def main():
     if world == 1:
         dm = H.dof_numbering(mesh.nNode, 1, mesh.bc_node, mesh.bc_dof, mesh.bc_val)
     else:
-        _, npid = H.partition_box_slabs(nEx, nEy, nEz, world)
+        _, npid = H.partition_box_slabs(nEx, nEy, nEz, world, elements=False)
         dm = H.dof_numbering(mesh.nNode, 1, mesh.bc_node, mesh.bc_dof, mesh.bc_val, world, npid)
     conn_new = dm.node_map_get_new[mesh.conn].astype(np.int32)
     xyz_new = np.ascontiguousarray(mesh.xyz[:, dm.node_map_get_old])
@@ -170,7 +189,12 @@ def main():
 
     if rank == 0:
         bytes_per_spmv = 12 * info["nnz"] + 20 * info["n_local"]       # FP64 vals, int32 cols
-        avg_spmv_ms = spmv_ms / max(spmv_n, 1)
+        # event pair = marker-end -> kernel-end; net of the pair's own offset measured on an empty
+        # kernel at solve start (pfem_timings.event_overhead_ms) this is the dispatch duration that
+        # rocprofv3 --kernel-trace reports (profiles/)
+        ev_off = tm["event_overhead_ms"]
+        raw_spmv_ms = spmv_ms / max(spmv_n, 1)
+        avg_spmv_ms = max(raw_spmv_ms - ev_off, 1e-9)
         achieved = bytes_per_spmv / (avg_spmv_ms * 1e-3) / 1e9 if spmv_n else 0.0
         out = {
             "metric": "DOF/s (assembly+CG-to-tol)", "value": N * args.steps / elapsed, "unit": "DOF/s",
@@ -188,8 +212,9 @@ def main():
             "setup_s_untimed": t_setup,
             "roofline": {"bound": "hbm", "kernel": "pfem::k_spmv<true> (wave-sliced CSR SpMV + (p,Ap) partials), rank 0",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(info["nnz"]) if world == 1 else None,
                          "algorithmic_bytes_per_launch": bytes_per_spmv, "avg_launch_ms": avg_spmv_ms,
+                         "event_pair_ms_raw": raw_spmv_ms, "event_pair_offset_ms": ev_off,
                          "launches_timed": spmv_n, "nnz": info["nnz"], "rows": info["n_local"]},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -233,6 +233,9 @@ typedef struct pfem_timings {
     double spmv_ms_total;   /* sum of the SpMV launches inside the last solve      */
     int64_t spmv_launches;  /* number of SpMV launches inside the last solve       */
     double upload_ms;       /* pfem_mesh_upload (PCIe, host wall clock)            */
+    double event_overhead_ms; /* what a start/stop event pair reports for an EMPTY kernel (marker-to-
+                               * dispatch gap of the measurement itself, calibrated at solve start);
+                               * kernel time per SpMV = spmv_ms_total/spmv_launches - event_overhead_ms */
 } pfem_timings;
 int pfem_get_timings(pfem_solver *s, pfem_timings *t);
 /* record an event pair around every SpMV launch of the next solves (bench.py) */

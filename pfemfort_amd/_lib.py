@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpfem_amd.so")
+LIB_PATH = os.environ.get("PFEM_AMD_LIB") or os.path.join(_HERE, "libpfem_amd.so")   # override: development A/B builds
 
 # error codes (include/pfem_amd.h)
 OK, ERR_ARG, ERR_STATE, ERR_NEG_JAC, ERR_HIP, ERR_NOGPU, ERR_NOMEM, ERR_DIVERGED, ERR_PATTERN, ERR_COMM = range(10)
@@ -37,7 +37,8 @@ class PfemError(RuntimeError):
 
 class Timings(C.Structure):
     _fields_ = [("pattern_ms", C.c_double), ("assemble_ms", C.c_double), ("solve_ms", C.c_double),
-                ("spmv_ms_total", C.c_double), ("spmv_launches", C.c_int64), ("upload_ms", C.c_double)]
+                ("spmv_ms_total", C.c_double), ("spmv_launches", C.c_int64), ("upload_ms", C.c_double),
+                ("event_overhead_ms", C.c_double)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)

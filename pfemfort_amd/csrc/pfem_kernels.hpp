@@ -776,7 +776,9 @@ __global__ void __launch_bounds__(kBlock) k_cg_update(CgCtl *ctl, int it, int64_
     double rz = 0.0, zz = 0.0;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
          i += static_cast<int64_t>(gridDim.x) * kBlock) {
-        x[i] = __builtin_fma(alpha, p[i], x[i]);
+        // x is touched once per iteration (reuse distance = a whole iteration of traffic):
+        // stream it past the caches (measured: k_cg_update -4 %, following k_spmv -1.6 %)
+        __builtin_nontemporal_store(__builtin_fma(alpha, p[i], __builtin_nontemporal_load(x + i)), x + i);
         const double ri = __builtin_fma(-alpha, w[i], r[i]);
         r[i] = ri;
         const double zi = ri * dinv[i];

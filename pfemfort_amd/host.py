@@ -91,9 +91,10 @@ def gen_box_tets(x0, x1, nEx, y0, y1, nEy, z0, z1, nEz, bc_mode=0, ndof=1, kz=No
     return Mesh(xyz, conn, bn, bd, bv, box=(nEx, nEy, nEz))
 
 
-def partition_box_slabs(nEx, nEy, nEz, nParts):
-    """Deterministic stand-in for METIS_PartMeshNodal (:464) on generated boxes."""
-    epid = np.empty(6 * nEx * nEy * nEz, np.int32)
+def partition_box_slabs(nEx, nEy, nEz, nParts, elements=True):
+    """Deterministic stand-in for METIS_PartMeshNodal (:464) on generated boxes.
+    ``elements=False`` skips the (large) elem_proc_id array and returns None for it."""
+    epid = np.empty(6 * nEx * nEy * nEz, np.int32) if elements else None
     npid = np.empty((nEx + 1) * (nEy + 1) * (nEz + 1), np.int32)
     L.check(L.lib().pfem_partition_box_slabs(nEx, nEy, nEz, nParts, _p(epid), _p(npid)), "pfem_partition_box_slabs")
     return epid, npid

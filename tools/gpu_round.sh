@@ -15,4 +15,14 @@ timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_spmv|k_cg_|k_as
 python tools/summarize_prof.py pmc /tmp/prof_fetch FETCH_SIZE > $OUT/rocprof_pmc_fetch_$TAG.txt 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "k_spmv|k_cg_|k_assemble" -f csv -d /tmp/prof_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/prof_write_$TAG.log 2>&1
 python tools/summarize_prof.py pmc /tmp/prof_write WRITE_SIZE > $OUT/rocprof_pmc_write_$TAG.txt 2>&1
+python3 - <<PY > $OUT/spmv_pmc_traffic.json
+import re, json
+def val(path):
+    for line in open(path):
+        if "k_spmv<true>" in line:
+            return float(line.split()[-1])
+nnz = json.load(open("$OUT/bench_$TAG.json"))["roofline"]["nnz"]
+print(json.dumps({"kernel": "pfem::k_spmv<true>", "nnz": nnz, "FETCH_SIZE_KB": val("$OUT/rocprof_pmc_fetch_$TAG.txt"),
+                  "WRITE_SIZE_KB": val("$OUT/rocprof_pmc_write_$TAG.txt"), "source": "rocprofv3 --pmc, separate passes, tools/gpu_round.sh $TAG"}))
+PY
 tail -5 $OUT/pytest_gpu_$TAG.log; cat $OUT/bench_$TAG.json; head -12 $OUT/rocprof_kernel_stats_$TAG.txt; cat $OUT/rocprof_pmc_fetch_$TAG.txt $OUT/rocprof_pmc_write_$TAG.txt
