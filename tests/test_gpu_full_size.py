@@ -1,0 +1,86 @@
+"""BASELINE.json's full-size configurations on the GPU, checked through size-independent
+properties (the oracle would need minutes at these sizes): closed-form problem sizes,
+the nodally-exact solution u = x^2+y^2+z^2, symmetry of the assembled operator through two SpMVs,
+gather == scatter assembly, run-to-run reproducibility, and the beam's published tip deflection.
+"""
+import numpy as np
+import pytest
+
+import pfemfort_amd as pf
+from pfemfort_amd import drivers as D
+from pfemfort_amd import host as H
+
+pytestmark = pytest.mark.gpu
+
+
+def closed_form_sizes(a, b, c, ndof):
+    """free-node grid a x b x c with the 7 edge directions of the 6-tet split."""
+    pairs = a * b * c + 2 * ((a - 1) * b * c + a * (b - 1) * c + a * b * (c - 1) + (a - 1) * (b - 1) * c +
+                             (a - 1) * b * (c - 1) + a * (b - 1) * (c - 1) + (a - 1) * (b - 1) * (c - 1))
+    return a * b * c * ndof, pairs * ndof * ndof
+
+
+def _solver(kind, mesh, rtol):
+    dm, conn, xyz, edof = D._setup(kind, mesh)
+    s = pf.PetscSolver().initialise(dm.size_global, dm.size_global)
+    s.setTolerances(rtol=rtol, maxits=100000)
+    s.uploadMesh(kind, conn, xyz, edof, dm.solnApplied)
+    s.buildPattern()
+    return s, dm, xyz
+
+
+@pytest.mark.parametrize("n,N,nnz", [(100, 970299, 14320447), (200, 7880599, 117260947)])   # configs[1], configs[2]
+def test_poisson_cube_full_size(n, N, nnz):
+    mesh = H.gen_box_tets(-1, 1, n, -1, 1, n, -1, 1, n)
+    assert mesh.nNode == (n + 1) ** 3 and mesh.nElem == 6 * n ** 3 and len(mesh.bc_node) == (n + 1) ** 3 - (n - 1) ** 3
+    s, dm, xyz = _solver(pf.POISSON_TET, mesh, 1e-10)
+    info = s.matrixInfo()
+    assert (dm.size_global, info["nnz"]) == (N, nnz) == closed_form_sizes(n - 1, n - 1, n - 1, 1)
+    assert info["stored"] <= 1.01 * nnz                     # wave-slice padding below 1 %
+
+    s.setAssemblyMode("scatter"); s.assemble(H.POISSON_ELEMDATA, H.TIMEDATA)
+    _, _, v_sc = s.getCSR()
+    s.setAssemblyMode("gather"); s.assemble(H.POISSON_ELEMDATA, H.TIMEDATA)
+    rowptr, cols, v_g = s.getCSR()
+    assert np.abs(v_sc - v_g).max() <= 1e-12 * np.abs(v_g).max()
+    s.assemble(H.POISSON_ELEMDATA, H.TIMEDATA)
+    assert np.array_equal(s.getCSR()[2], v_g)               # gather assembly is bit-reproducible
+    # interior row of the uniform grid (x 1/h): 15 entries, diag 6.667/h', row sum 0
+    r = N // 2
+    row = v_g[rowptr[r]:rowptr[r + 1]]
+    assert len(row) == 15 and abs(row.sum()) < 1e-12 * abs(row).max()
+
+    rng = np.random.default_rng(n)                          # symmetry: x.(A y) == y.(A x)
+    x, y = rng.standard_normal(N), rng.standard_normal(N)
+    assert abs(x @ s.spmv(y) - y @ s.spmv(x)) <= 1e-10 * np.sqrt(N) * abs(v_g).max()
+
+    its, reason, rn = s.factoriseAndSolve()
+    assert reason == 2
+    h0 = s.getHistory()
+    assert rn <= 1e-10 * h0[0] and len(h0) == its + 1
+    u = s.getSolution()
+    exact = (xyz[:, H.assy_for_soln(dm.NodeDofArrayNew)] ** 2).sum(0)
+    assert np.abs(u - exact).max() < 2e-7                   # limited by the %.8f BC round trip (1.1e-7)
+    assert -1e-6 < u.min() and u.max() <= 3.0               # docs image colour bar: 0 ... 3.00
+    its2, _, _ = s.factoriseAndSolve()
+    assert its2 == its and np.array_equal(s.getSolution(), u)   # the solve is bit-reproducible too
+
+
+def test_elasticity_beam_config4():
+    mesh = H.gen_box_tets(-0.5, 0.5, 50, 0.0, 6.0, 300, -0.5, 0.5, 50, bc_mode=1, ndof=3)
+    assert (mesh.nNode, mesh.nElem, len(mesh.bc_node)) == (782901, 4500000, 7803)
+    s, dm, xyz = _solver(pf.ELAST_TET, mesh, 1e-5)
+    info = s.matrixInfo()
+    assert (dm.size_global, info["nnz"]) == (2340900, 102964482) == closed_form_sizes(51, 300, 51, 3)
+    s.assemble(H.ELAST_ELEMDATA, H.TIMEDATA)
+    N = dm.size_global
+    rng = np.random.default_rng(4)
+    x, y = rng.standard_normal(N), rng.standard_normal(N)
+    Ax, Ay = s.spmv(x), s.spmv(y)
+    assert abs(x @ Ay - y @ Ax) <= 1e-9 * np.sqrt(N) * np.abs(Ax).max() * np.abs(y).max()
+    its, reason, rn = s.factoriseAndSolve()
+    assert reason == 2
+    full = dm.solnApplied.copy()
+    full[H.assy_for_soln(dm.NodeDofArrayNew)] = s.getSolution()
+    disp = np.linalg.norm(full.reshape(-1, 3), axis=1)
+    assert abs(disp.max() - 0.82) < 0.01                    # docs/beam3Dtet5030050-nproc80-soln.jpg: 0.82
