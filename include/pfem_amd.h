@@ -206,6 +206,14 @@ int pfem_assemble(pfem_solver *s, const double *elemData, const double *timeData
 #define PFEM_ASSEMBLY_GATHER 0
 #define PFEM_ASSEMBLY_SCATTER 1
 int pfem_solver_set_assembly_mode(pfem_solver *s, int mode);
+/* Column-index encoding streamed by the SpMV: AUTO uses 16-bit gaps between the ascending
+ * columns of a row (4 + 2 B per entry instead of 4 B) whenever every gap of the pattern fits,
+ * INT32 forces plain int32 columns.  Same products in the same order: bit-identical results. */
+#define PFEM_SPMV_AUTO 0
+#define PFEM_SPMV_INT32 1
+int pfem_solver_set_spmv_format(pfem_solver *s, int format);
+/* 16 if the SpMV currently streams 16-bit column gaps, 32 for int32 columns */
+int pfem_solver_get_spmv_format(pfem_solver *s, int *bits_per_column);
 /* Per-element Ke/Fe of the uploaded mesh as computed by the DEVICE kernel (parity
  * inspection): K_out[e*nsize*nsize + i + nsize*j], F_out[e*nsize + i].           */
 int pfem_eval_elems(pfem_solver *s, const double *elemData, const double *timeData,

@@ -80,6 +80,8 @@ SIGNATURES = {
     "pfem_pattern_build": [_P],
     "pfem_assemble": [_P, _P, _P],
     "pfem_solver_set_assembly_mode": [_P, _I],
+    "pfem_solver_set_spmv_format": [_P, _I],
+    "pfem_solver_get_spmv_format": [_P, _P],
     "pfem_eval_elems": [_P, _P, _P, _P, _P],
     "pfem_matrix_info": [_P, _P, _P, _P, _P],
     "pfem_get_local_to_global": [_P, _P],

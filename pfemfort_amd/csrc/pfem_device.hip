@@ -174,6 +174,12 @@ struct pfem_solver {
     DevBuf<int64_t> d_rowptr, d_slice_off;
     DevBuf<int32_t> d_rowlen, d_cols;
     DevBuf<double> d_vals;
+    // SpMV-only 16-bit column-gap representation (k_spmv16), when every gap fits
+    bool cols16 = false;
+    int spmv_format = PFEM_SPMV_AUTO;
+    DevBuf<int32_t> d_col0;
+    DevBuf<uint32_t> d_dwords;
+    DevBuf<int64_t> d_slice_doff;
 
     // vectors
     DevBuf<double> d_rhs, d_x, d_r, d_p, d_w, d_dinv;
@@ -455,6 +461,8 @@ int alloc_vectors(pfem_solver *s)
     return PFEM_OK;
 }
 
+int build_cols16(pfem_solver *s);
+
 // keys: device array of `nkeys` (row<<32|col) keys, kNoKey = ignore.  Consumed.
 int pattern_from_keys(pfem_solver *s, DevBuf<uint64_t> &keys, int64_t nkeys)
 {
@@ -522,6 +530,7 @@ int pattern_from_keys(pfem_solver *s, DevBuf<uint64_t> &keys, int64_t nkeys)
     PFEM_TRY(alloc_vectors(s));
     PFEM_HIP(hipStreamSynchronize(s->stream));
     keys.release();
+    PFEM_TRY(build_cols16(s));
     s->have_pattern = true;
     s->rhs_summed = false;
     s->status = PFEM_PATTERN_OK;
@@ -768,6 +777,80 @@ extern "C" int pfem_get_rhs(pfem_solver *s, double *rhs_local)
 // ---------------------------------------------------------------------------
 // SpMV entry points
 // ---------------------------------------------------------------------------
+namespace {
+
+// 16-bit column-gap representation next to the int32 columns (SpMV only)
+int build_cols16(pfem_solver *s)
+{
+    s->cols16 = false;
+    if (s->n_slices == 0) return PFEM_OK;
+    DevBuf<int64_t> words;
+    DevBuf<char> temp;
+    PFEM_TRY(words.alloc(static_cast<size_t>(s->n_slices) + 1));
+    PFEM_TRY(s->d_slice_doff.alloc(static_cast<size_t>(s->n_slices) + 1));
+    hipLaunchKernelGGL(k_cols16_sizes, dim3(grid_for(s->n_slices + 1)), dim3(kBlock), 0, s->stream, s->d_slice_off.p,
+                       s->n_slices, words.p);
+    PFEM_TRY(check_kernel("k_cols16_sizes"));
+    size_t tb = 0;
+    const int nsl = static_cast<int>(s->n_slices + 1);
+    PFEM_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, words.p, s->d_slice_doff.p, nsl, s->stream));
+    PFEM_TRY(temp.alloc(tb));
+    PFEM_HIP(hipcub::DeviceScan::ExclusiveSum(temp.p, tb, words.p, s->d_slice_doff.p, nsl, s->stream));
+    int64_t total = 0;
+    PFEM_HIP(hipMemcpyAsync(&total, s->d_slice_doff.p + s->n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    PFEM_TRY(s->d_col0.alloc(static_cast<size_t>(s->n_slices) * 64));
+    PFEM_TRY(s->d_dwords.alloc(static_cast<size_t>(std::max<int64_t>(total, 1))));
+    PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
+    hipLaunchKernelGGL(k_cols16_fill, dim3(grid_for(s->n_slices * 64)), dim3(kBlock), 0, s->stream, s->sell(), s->d_slice_doff.p,
+                       s->d_col0.p, s->d_dwords.p, s->d_err.p);
+    PFEM_TRY(check_kernel("k_cols16_fill"));
+    int overflow = 0;
+    PFEM_TRY(fetch_err(s, &overflow));
+    PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
+    if (overflow) {     // some gap needs more than 16 bits: keep the int32 kernel
+        s->d_col0.release();
+        s->d_dwords.release();
+        s->d_slice_doff.release();
+        return PFEM_OK;
+    }
+    s->cols16 = true;
+    return PFEM_OK;
+}
+
+// the CG / standalone SpMV launch: 16-bit gaps when available and not disabled, else int32
+template <bool WITH_DOT>
+void launch_spmv(pfem_solver *s, const double *x, double *y, int64_t n_dot, double *partial, const CgCtl *ctl,
+                 hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
+{
+    const dim3 grid(spmv_grid(s->n_slices)), block(kBlock);
+    SellDev A = s->sell();
+    if (s->cols16 && s->spmv_format != PFEM_SPMV_INT32) {
+        Sell16Dev C{s->d_col0.p, s->d_dwords.p, s->d_slice_doff.p};
+        if (e0) hipExtLaunchKernelGGL(k_spmv16<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, A, C, x, y, n_dot, partial, ctl);
+        else hipLaunchKernelGGL(k_spmv16<WITH_DOT>, grid, block, 0, s->stream, A, C, x, y, n_dot, partial, ctl);
+    } else {
+        if (e0) hipExtLaunchKernelGGL(k_spmv<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, A, x, y, n_dot, partial, ctl);
+        else hipLaunchKernelGGL(k_spmv<WITH_DOT>, grid, block, 0, s->stream, A, x, y, n_dot, partial, ctl);
+    }
+}
+
+}  // namespace
+
+extern "C" int pfem_solver_get_spmv_format(pfem_solver *s, int *bits_per_column)
+{
+    if (!s || !bits_per_column) return PFEM_ERR_ARG;
+    *bits_per_column = (s->cols16 && s->spmv_format != PFEM_SPMV_INT32) ? 16 : 32;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_set_spmv_format(pfem_solver *s, int format)
+{
+    if (!s || (format != PFEM_SPMV_AUTO && format != PFEM_SPMV_INT32)) return PFEM_ERR_ARG;
+    s->spmv_format = format;
+    return PFEM_OK;
+}
+
 extern "C" int pfem_spmv(pfem_solver *s, const double *x, double *y)
 {
     if (!s || !x || !y) return PFEM_ERR_ARG;
@@ -775,8 +858,7 @@ extern "C" int pfem_spmv(pfem_solver *s, const double *x, double *y)
     PFEM_TRY(use_device(s));
     const size_t nb = sizeof(double) * static_cast<size_t>(s->n_loc);
     PFEM_HIP(hipMemcpyAsync(s->d_p.p, x, nb, hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(k_spmv<false>, dim3(spmv_grid(s->n_slices)), dim3(kBlock), 0, s->stream, s->sell(), s->d_p.p, s->d_w.p,
-                       static_cast<int64_t>(0), static_cast<double *>(nullptr), static_cast<const CgCtl *>(nullptr));
+    launch_spmv<false>(s, s->d_p.p, s->d_w.p, 0, nullptr, nullptr);
     PFEM_TRY(check_kernel("k_spmv"));
     PFEM_HIP(hipMemcpyAsync(y, s->d_w.p, nb, hipMemcpyDeviceToHost, s->stream));
     PFEM_HIP(hipStreamSynchronize(s->stream));
@@ -788,14 +870,10 @@ extern "C" int pfem_bench_spmv(pfem_solver *s, int reps, double *ms_per_launch)
     if (!s || reps < 1 || !ms_per_launch) return PFEM_ERR_ARG;
     if (!s->have_pattern) return PFEM_ERR_STATE;
     PFEM_TRY(use_device(s));
-    const dim3 grid(spmv_grid(s->n_slices)), block(kBlock);
     // warm-up launch, then `reps` timed ones with x = rhs (any resident vector)
-    hipLaunchKernelGGL(k_spmv<false>, grid, block, 0, s->stream, s->sell(), s->d_rhs.p, s->d_w.p, static_cast<int64_t>(0),
-                       static_cast<double *>(nullptr), static_cast<const CgCtl *>(nullptr));
+    launch_spmv<false>(s, s->d_rhs.p, s->d_w.p, 0, nullptr, nullptr);
     PFEM_HIP(hipEventRecord(s->ev0, s->stream));
-    for (int i = 0; i < reps; ++i)
-        hipLaunchKernelGGL(k_spmv<false>, grid, block, 0, s->stream, s->sell(), s->d_rhs.p, s->d_w.p, static_cast<int64_t>(0),
-                           static_cast<double *>(nullptr), static_cast<const CgCtl *>(nullptr));
+    for (int i = 0; i < reps; ++i) launch_spmv<false>(s, s->d_rhs.p, s->d_w.p, 0, nullptr, nullptr);
     PFEM_HIP(hipEventRecord(s->ev1, s->stream));
     PFEM_TRY(check_kernel("k_spmv"));
     double ms = 0;
@@ -1011,12 +1089,8 @@ int run_pcg(pfem_solver *s)
                 e1 = s->spmv_events[ev_used + 1];
                 ev_used += 2;
             }
-            if (e0)   // dispatch-precise begin/end timestamps of THIS kernel (what rocprofv3 reports)
-                hipExtLaunchKernelGGL(k_spmv<true>, dim3(gs), block, 0, s->stream, e0, e1, 0, A,
-                                      static_cast<const double *>(s->d_p.p), s->d_w.p, n, part_pw,
-                                      static_cast<const CgCtl *>(ctl));
-            else
-                hipLaunchKernelGGL(k_spmv<true>, dim3(gs), block, 0, s->stream, A, s->d_p.p, s->d_w.p, n, part_pw, ctl);
+            // with events: marker-end -> kernel-end of THIS launch (see event_overhead_ms)
+            launch_spmv<true>(s, s->d_p.p, s->d_w.p, n, part_pw, ctl, e0, e1);
             const double *red_pw = scal_pw;
             if (multi) {
                 PFEM_TRY(interface_sum(s, s->d_w.p, part_pw, nullptr, static_cast<int>(gs), 1, ctl));

@@ -687,6 +687,125 @@ __global__ void __launch_bounds__(kBlock) k_spmv(SellDev A, const double *__rest
     }
 }
 
+// ---------------------------------------------------------------------------
+// SpMV with 16-bit column deltas.  Columns are ascending inside a row, so a row is stored as
+// its first column (int32, col0[row]) plus unsigned 16-bit gaps to the next column, two gaps per
+// 32-bit word, in the same wave-sliced order as the values: word j of lane l of slice s sits
+// at slice_doff[s] + 64*j + l and holds gap(2j+1) | gap(2j+2) << 16.  Padding entries carry gap
+// 0 (and value 0).  A Poisson row of 15 entries costs 4 + 28 = 32 B of index data instead of
+// 60 B: the SpMV streams 152 instead of 180 B per row.  Used when every gap fits 16 bits
+// (structured cfg 3: max gap 39 202; checked when the pattern is built), otherwise the int32
+// kernel above runs.  Same products, same summation order -> bit-identical y.
+// ---------------------------------------------------------------------------
+struct Sell16Dev {
+    const int32_t *col0;        // [64 * n_slices]
+    const uint32_t *dwords;     // packed gaps
+    const int64_t *slice_doff;  // [n_slices+1], in words
+};
+
+// words per slice = 64 * ceil((width-1)/2); one thread per slice
+__global__ void __launch_bounds__(kBlock) k_cols16_sizes(const int64_t *slice_off, int64_t n_slices, int64_t *slice_words)
+{
+    const int64_t s = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (s > n_slices) return;
+    if (s == n_slices) { slice_words[s] = 0; return; }
+    const int width = static_cast<int>((slice_off[s + 1] - slice_off[s]) >> 6);
+    slice_words[s] = 64LL * (width > 1 ? (width / 2) : 0);     // ceil((width-1)/2) == width/2
+}
+
+// one thread per row: first column + packed gaps; *overflow is set if a gap needs > 16 bits
+__global__ void __launch_bounds__(kBlock) k_cols16_fill(SellDev A, const int64_t *slice_doff, int32_t *col0,
+                                                         uint32_t *dwords, int *overflow)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t s = r >> 6;
+    if (s >= A.n_slices) return;
+    const int lane = static_cast<int>(r & 63);
+    const int64_t off = A.slice_off[s];
+    const int width = static_cast<int>((A.slice_off[s + 1] - off) >> 6);
+    const int len = r < A.n_rows ? A.rowlen[r] : 0;
+    const int32_t *cp = A.cols + off + lane;
+    int prev = len > 0 ? cp[0] : 0;
+    col0[r] = prev;
+    uint32_t *wp = dwords + slice_doff[s] + lane;
+    bool bad = false;
+    for (int j = 0; 2 * j + 1 < width; ++j) {
+        uint32_t w = 0;
+        for (int h = 0; h < 2; ++h) {
+            const int k = 2 * j + 1 + h;
+            uint32_t gap = 0;
+            if (k < len) {
+                const int c = cp[64 * k];
+                const int64_t g = static_cast<int64_t>(c) - prev;
+                if (g < 0 || g > 65535) bad = true;
+                gap = static_cast<uint32_t>(g) & 0xffffu;
+                prev = c;
+            }
+            w |= gap << (16 * h);
+        }
+        wp[64LL * j] = w;
+    }
+    if (bad) atomicMax(overflow, 1);
+}
+
+template <bool WITH_DOT>
+__global__ void __launch_bounds__(kBlock) k_spmv16(SellDev A, Sell16Dev C, const double *__restrict__ x,
+                                                    double *__restrict__ y, int64_t n_dot, double *partial,
+                                                    const CgCtl *ctl)
+{
+    __shared__ double sm[4];
+    if (WITH_DOT && ctl->flag != 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t s = (static_cast<int64_t>(blockIdx.x) << 2) + wave;
+    double dot = 0.0;
+    if (s < A.n_slices) {
+        const int64_t off = A.slice_off[s];
+        const int width = static_cast<int>((A.slice_off[s + 1] - off) >> 6);
+        const double *__restrict__ vp = A.vals + off + lane;
+        const uint32_t *__restrict__ wp = C.dwords + C.slice_doff[s] + lane;
+        int c = __builtin_nontemporal_load(C.col0 + (s << 6) + lane);
+        double acc = 0.0;
+        if (width > 0) acc = __builtin_nontemporal_load(vp) * x[c];
+        const int nw = width / 2;          // full words: entries 1 .. 2*nw
+        int j = 0;
+        for (; 2 * j + 4 < width; j += 2) {   // two words = four entries (all inside the slice) per trip
+            const uint32_t w0 = __builtin_nontemporal_load(wp + 64 * j);
+            const uint32_t w1 = __builtin_nontemporal_load(wp + 64 * (j + 1));
+            const double v0 = __builtin_nontemporal_load(vp + 64 * (2 * j + 1));
+            const double v1 = __builtin_nontemporal_load(vp + 64 * (2 * j + 2));
+            const double v2 = __builtin_nontemporal_load(vp + 64 * (2 * j + 3));
+            const double v3 = __builtin_nontemporal_load(vp + 64 * (2 * j + 4));
+            const int c0 = c + static_cast<int>(w0 & 0xffffu);
+            const int c1 = c0 + static_cast<int>(w0 >> 16);
+            const int c2 = c1 + static_cast<int>(w1 & 0xffffu);
+            const int c3 = c2 + static_cast<int>(w1 >> 16);
+            const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+            acc = __builtin_fma(v0, x0, acc);
+            acc = __builtin_fma(v1, x1, acc);
+            acc = __builtin_fma(v2, x2, acc);
+            acc = __builtin_fma(v3, x3, acc);
+            c = c3;
+        }
+        for (; j < nw; ++j) {
+            const uint32_t w0 = __builtin_nontemporal_load(wp + 64 * j);
+            const int c0 = c + static_cast<int>(w0 & 0xffffu);
+            const int c1 = c0 + static_cast<int>(w0 >> 16);
+            acc = __builtin_fma(__builtin_nontemporal_load(vp + 64 * (2 * j + 1)), x[c0], acc);
+            if (2 * j + 2 < width) acc = __builtin_fma(__builtin_nontemporal_load(vp + 64 * (2 * j + 2)), x[c1], acc);
+            c = c1;
+        }
+        const int64_t row = (s << 6) + lane;
+        if (row < A.n_rows) {
+            y[row] = acc;
+            if (WITH_DOT && row < n_dot) dot = x[row] * acc;
+        }
+    }
+    if (WITH_DOT) {
+        const double t = block_sum(dot, sm);
+        if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    }
+}
+
 // One block of 1024 threads: out[j] = sum of part_j[0..n) for up to two partial arrays, in a
 // fixed association order (bitwise reproducible run to run).
 __global__ void __launch_bounds__(1024) k_reduce_partials(const double *part0, const double *part1, int n, double *out,

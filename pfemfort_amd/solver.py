@@ -159,6 +159,15 @@ class PetscSolver:
         L.check(L.lib().pfem_solver_set_assembly_mode(self._h, {"gather": 0, "scatter": 1}[mode]),
                 "pfem_solver_set_assembly_mode")
 
+    def setSpmvFormat(self, fmt):
+        """"auto" (16-bit column gaps when they fit) or "int32"."""
+        L.check(L.lib().pfem_solver_set_spmv_format(self._h, {"auto": 0, "int32": 1}[fmt]), "pfem_solver_set_spmv_format")
+
+    def spmvColumnBits(self):
+        b = C.c_int(0)
+        L.check(L.lib().pfem_solver_get_spmv_format(self._h, C.byref(b)), "pfem_solver_get_spmv_format")
+        return b.value
+
     def assemble(self, elemData, timeData):
         ed = None if elemData is None else _f64(elemData)
         L.check(L.lib().pfem_assemble(self._h, _p(ed), _p(_f64(timeData))), "pfem_assemble")

@@ -54,6 +54,11 @@ def test_poisson_cube_full_size(n, N, nnz):
     x, y = rng.standard_normal(N), rng.standard_normal(N)
     assert abs(x @ s.spmv(y) - y @ s.spmv(x)) <= 1e-10 * np.sqrt(N) * abs(v_g).max()
 
+    ya = s.spmv(x)                                          # 16-bit column gaps (max gap 39 202 at 200^3) ...
+    s.setSpmvFormat("int32")
+    assert np.array_equal(ya, s.spmv(x))                    # ... give the same bits as int32 columns
+    s.setSpmvFormat("auto")
+
     its, reason, rn = s.factoriseAndSolve()
     assert reason == 2
     h0 = s.getHistory()

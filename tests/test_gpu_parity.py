@@ -122,6 +122,22 @@ def test_spmv_matches_oracle(tet10):
     assert np.abs(y - yo).max() <= 1e-13 * np.abs(yo).max()
 
 
+@pytest.mark.parametrize("name", ["tet10", "beam", "tria20"])
+def test_spmv_column_formats_bit_identical(name, request):
+    """16-bit column gaps (auto) vs int32 columns: same products, same order, same bits."""
+    mesh = request.getfixturevalue(name)
+    kind, ed = {"tet10": (pf.POISSON_TET, H.POISSON_ELEMDATA), "beam": (pf.ELAST_TET, H.ELAST_ELEMDATA),
+                "tria20": (pf.POISSON_TRIA, np.array([1.0, 1.0]))}[name]
+    s, dm = _device_problem(kind, mesh, ed)
+    x = np.random.default_rng(1).standard_normal(dm.size_global)
+    y_auto = s.spmv(x)
+    s.setSpmvFormat("int32")
+    y_32 = s.spmv(x)
+    assert np.array_equal(y_auto, y_32)
+    rowptr, cols, vals = s.getCSR()
+    assert np.abs(y_32 - O.spmv(rowptr, cols, vals, x)).max() <= 1e-13 * np.abs(y_32).max()
+
+
 @pytest.mark.parametrize("rtol", [1e-5, 1e-10])
 def test_poisson_tet10_solve(tet10, rtol):
     res = pf.tetrapoissonparallelimpl1(tet10, rtol=rtol)

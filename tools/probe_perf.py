@@ -13,7 +13,7 @@ t = time.time(); dm, conn, xyz, edof = D._setup(pf.POISSON_TET, mesh); print(f"b
 s = pf.PetscSolver().initialise(dm.size_global, dm.size_global)
 s.setTolerances(rtol=rtol)
 t = time.time(); s.uploadMesh(pf.POISSON_TET, conn, xyz, edof, dm.solnApplied); print(f"upload {time.time()-t:.2f}s")
-t = time.time(); s.buildPattern(); print(f"pattern {time.time()-t:.2f}s", s.matrixInfo())
+t = time.time(); s.buildPattern(); print(f"pattern {time.time()-t:.2f}s", s.matrixInfo(), "column bits", s.spmvColumnBits())
 for rep in range(3):
     s.assemble(H.POISSON_ELEMDATA, H.TIMEDATA)
     s.profileSpmv(True)
