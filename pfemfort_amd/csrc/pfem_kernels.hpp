@@ -748,6 +748,31 @@ __global__ void __launch_bounds__(kBlock) k_cols16_fill(SellDev A, const int64_t
     if (bad) atomicMax(overflow, 1);
 }
 
+// W words = 2W consecutive entries (all inside the slice: caller guarantees 2*(j+W) < width)
+template <int W>
+__device__ __forceinline__ void spmv16_trip(const double *__restrict__ vp, const uint32_t *__restrict__ wp,
+                                            const double *__restrict__ x, int &j, int &c, double &acc)
+{
+    uint32_t w[W];
+    double v[2 * W], xv[2 * W];
+#pragma unroll
+    for (int t = 0; t < W; ++t) w[t] = __builtin_nontemporal_load(wp + 64 * (j + t));
+#pragma unroll
+    for (int t = 0; t < 2 * W; ++t) v[t] = __builtin_nontemporal_load(vp + 64 * (2 * j + 1 + t));
+    int cc = c;
+#pragma unroll
+    for (int t = 0; t < W; ++t) {
+        cc += static_cast<int>(w[t] & 0xffffu);
+        xv[2 * t] = x[cc];
+        cc += static_cast<int>(w[t] >> 16);
+        xv[2 * t + 1] = x[cc];
+    }
+#pragma unroll
+    for (int t = 0; t < 2 * W; ++t) acc = __builtin_fma(v[t], xv[t], acc);
+    c = cc;
+    j += W;
+}
+
 template <bool WITH_DOT>
 __global__ void __launch_bounds__(kBlock) k_spmv16(SellDev A, Sell16Dev C, const double *__restrict__ x,
                                                     double *__restrict__ y, int64_t n_dot, double *partial,
@@ -766,26 +791,13 @@ __global__ void __launch_bounds__(kBlock) k_spmv16(SellDev A, Sell16Dev C, const
         int c = __builtin_nontemporal_load(C.col0 + (s << 6) + lane);
         double acc = 0.0;
         if (width > 0) acc = __builtin_nontemporal_load(vp) * x[c];
-        const int nw = width / 2;          // full words: entries 1 .. 2*nw
+        const int nw = width / 2;          // words: entries 1 .. 2*nw (the last one may be a pad)
         int j = 0;
-        for (; 2 * j + 4 < width; j += 2) {   // two words = four entries (all inside the slice) per trip
-            const uint32_t w0 = __builtin_nontemporal_load(wp + 64 * j);
-            const uint32_t w1 = __builtin_nontemporal_load(wp + 64 * (j + 1));
-            const double v0 = __builtin_nontemporal_load(vp + 64 * (2 * j + 1));
-            const double v1 = __builtin_nontemporal_load(vp + 64 * (2 * j + 2));
-            const double v2 = __builtin_nontemporal_load(vp + 64 * (2 * j + 3));
-            const double v3 = __builtin_nontemporal_load(vp + 64 * (2 * j + 4));
-            const int c0 = c + static_cast<int>(w0 & 0xffffu);
-            const int c1 = c0 + static_cast<int>(w0 >> 16);
-            const int c2 = c1 + static_cast<int>(w1 & 0xffffu);
-            const int c3 = c2 + static_cast<int>(w1 >> 16);
-            const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
-            acc = __builtin_fma(v0, x0, acc);
-            acc = __builtin_fma(v1, x1, acc);
-            acc = __builtin_fma(v2, x2, acc);
-            acc = __builtin_fma(v3, x3, acc);
-            c = c3;
-        }
+        // cascade of trip sizes: all streaming loads of a trip are issued before the first use, so
+        // a wave keeps up to 8 words + 16 values (+16 gathers) in flight
+        while (2 * (j + 8) < width) spmv16_trip<8>(vp, wp, x, j, c, acc);
+        if (2 * (j + 4) < width) spmv16_trip<4>(vp, wp, x, j, c, acc);
+        if (2 * (j + 2) < width) spmv16_trip<2>(vp, wp, x, j, c, acc);
         for (; j < nw; ++j) {
             const uint32_t w0 = __builtin_nontemporal_load(wp + 64 * j);
             const int c0 = c + static_cast<int>(w0 & 0xffffu);
