@@ -49,33 +49,45 @@ def pmc_traffic(nnz):
 
 
 def cpu_baseline(n=100, rtol=1e-5):
-    """The oracle (C restatement of the reference path) on ONE host core, bounded sample:
-    BASELINE configs[1] (tet100: 100^3 x 6 tets), full assembly + Jacobi-PCG to the same rtol."""
-    import ctypes
+    """The oracle (C restatement of the reference path) on the host cores, bounded sample:
+    BASELINE configs[1] (tet100: 100^3 x 6 tets), full assembly + Jacobi-PCG to the same rtol.
+    Threads: OpenMP over the element loop (atomic ADD_VALUES) and over SpMV / dots / axpys -- the
+    shared-memory stand-in for the reference's `mpirun -np P`; the 1-core figure rides in `sample`."""
     import numpy as np
     from oracle import pfem_oracle as O
-    try:
-        omp = ctypes.CDLL("libgomp.so.1")
-        omp.omp_set_num_threads(1)
-    except OSError:
-        pass
-    os.environ["OMP_NUM_THREADS"] = "1"
     mesh = O.gen_box_tets(-1, 1, n, -1, 1, n, -1, 1, n)
     dm = O.dof_numbering(mesh.nNode, 1, mesh.bc_node, mesh.bc_dof, mesh.bc_val)
     edof = O.elem_dof_array(mesh.conn, dm.NodeDofArrayNew)
     rowptr, cols = O.csr_pattern(edof, dm.size_global)          # pattern precedes the timers (:786-802)
-    t0 = time.perf_counter()
-    vals, rhs = O.assemble(O.POISSON_TET, mesh.xyz, mesh.conn, edof, dm.solnApplied, O.POISSON_ELEMDATA,
-                           dm.size_global, rowptr, cols)
-    t1 = time.perf_counter()
-    x, its, reason, rn, _ = O.pcg_jacobi(rowptr, cols, vals, rhs, rtol=rtol)
-    t2 = time.perf_counter()
     nb = 12 * len(cols) + 20 * dm.size_global
-    return {"value": dm.size_global / (t2 - t0), "unit": "DOF/s", "cores": 1, "kind": "port",
-            "sample": f"{n}^3x6 tet Poisson (BASELINE configs[1]), N={dm.size_global}, full assembly "
-                      f"{t1 - t0:.2f}s + Jacobi-PCG rtol {rtol:g} {its} its {t2 - t1:.2f}s; "
-                      f"CG-iteration rate {nb * its / (t2 - t1) / 1e9:.1f} GB/s SpMV-equivalent",
-            "assembly_s": t1 - t0, "solve_s": t2 - t1, "its": its}
+
+    def run(threads):
+        O.set_threads(threads)
+        t0 = time.perf_counter()
+        if threads == 1:
+            vals, rhs = O.assemble(O.POISSON_TET, mesh.xyz, mesh.conn, edof, dm.solnApplied, O.POISSON_ELEMDATA,
+                                   dm.size_global, rowptr, cols)
+        else:
+            vals, rhs = O.assemble_mt(O.POISSON_TET, mesh.xyz, mesh.conn, edof, dm.solnApplied, O.POISSON_ELEMDATA,
+                                      dm.size_global, rowptr, cols)
+        t1 = time.perf_counter()
+        x, its, reason, rn, _ = O.pcg_jacobi(rowptr, cols, vals, rhs, rtol=rtol)
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1, its
+
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    a1, s1, its1 = run(1)
+    if cores > 1:
+        run(cores)                                               # first touch / thread pool warm-up
+        am, sm, itsm = run(cores)
+    else:
+        am, sm, itsm = a1, s1, its1
+    return {"value": dm.size_global / (am + sm), "unit": "DOF/s", "cores": cores, "kind": "port",
+            "sample": f"{n}^3x6 tet Poisson (BASELINE configs[1]), N={dm.size_global}: {cores} OpenMP threads: assembly "
+                      f"{am:.2f}s + Jacobi-PCG rtol {rtol:g} {itsm} its {sm:.2f}s "
+                      f"({nb * itsm / sm / 1e9:.0f} GB/s SpMV-equivalent); 1 thread: assembly {a1:.2f}s + {its1} its "
+                      f"{s1:.2f}s = {dm.size_global / (a1 + s1):.3g} DOF/s",
+            "assembly_s": am, "solve_s": sm, "its": itsm, "single_core_value": dm.size_global / (a1 + s1)}
 
 
 def main():

@@ -574,6 +574,55 @@ int orc_assemble(int kind, int64_t nElem, const int32_t *conn, int64_t nNode,
     return ORC_OK;
 }
 
+/* Threaded variant for the CPU-baseline leg of bench.py ONLY (never for parity): the same element
+ * loop split over OpenMP threads, every ADD_VALUES an atomic update.  This is what the reference's
+ * "mpirun -np P" buys on a shared-memory node, minus the stash exchange; the sum order (hence the
+ * last bits) depends on the thread interleaving, so tests always use orc_assemble. */
+int orc_assemble_mt(int kind, int64_t nElem, const int32_t *conn, int64_t nNode,
+                    const double *xyz, const int32_t *edof, const double *solnApplied,
+                    const double *elemData, const double *timeData,
+                    int64_t N, const int64_t *rowptr, const int32_t *cols,
+                    double *vals, double *rhs)
+{
+    const int np = kind_npelem(kind), ndof = kind_ndof(kind), nsize = np * ndof;
+    int err = ORC_OK;
+    int64_t e;
+    (void)N;
+#pragma omp parallel for schedule(static)
+    for (e = 0; e < nElem; ++e) {
+        double K[144], F[12];
+        int32_t idx[12];
+        int ii, jj;
+        int rc = eval_elem(kind, e, nElem, conn, nNode, xyz, elemData, timeData, K, F);
+        if (rc) { err = rc; continue; }
+        for (ii = 0; ii < nsize; ++ii) idx[ii] = edof[(int64_t)ii * nElem + e];
+        for (ii = 0; ii < nsize; ++ii) {
+            if (idx[ii] < 0) continue;
+            for (jj = 0; jj < nsize; ++jj) {
+                int64_t p;
+                if (idx[jj] < 0) continue;
+                p = csr_find(rowptr, cols, idx[ii], idx[jj]);
+                if (p < 0) { err = ORC_ERR_PATTERN; continue; }
+#pragma omp atomic
+                vals[p] += K[jj + nsize * ii];
+            }
+        }
+        for (ii = 0; ii < nsize; ++ii)
+            if (idx[ii] == -1) {
+                const int64_t n = conn[(int64_t)(ii / ndof) * nElem + e];
+                const double fact = solnApplied[n * ndof + ii % ndof];
+                for (jj = 0; jj < nsize; ++jj)
+                    if (idx[jj] != -1) F[jj] = F[jj] - K[jj + nsize * ii] * fact;
+            }
+        for (ii = 0; ii < nsize; ++ii)
+            if (idx[ii] >= 0) {
+#pragma omp atomic
+                rhs[idx[ii]] += F[ii];
+            }
+    }
+    return err;
+}
+
 /* ------------------------------------------------------------------------ */
 /* Linear algebra: CSR SpMV and Jacobi-PCG (PETSc KSPCG   */
 /* semantics are third-party knowledge: PETSc 3.6-era, left-preconditioned,  */

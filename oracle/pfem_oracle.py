@@ -256,6 +256,26 @@ def assemble(kind, xyz_new, conn_new, edof, solnApplied, elemData, N, rowptr, co
     return vals, rhs
 
 
+def assemble_mt(kind, xyz_new, conn_new, edof, solnApplied, elemData, N, rowptr, cols, timeData=TIMEDATA):
+    """OpenMP + atomics variant, for bench.py's cpu_baseline timing only (sum order not fixed)."""
+    xyz_new = _f64(xyz_new); conn_new = _i32(conn_new); edof = _i32(edof)
+    vals = np.zeros(len(cols)); rhs = np.zeros(N)
+    ed = _f64(np.resize(elemData, 6) if len(elemData) < 6 else elemData)
+    rc = lib().orc_assemble_mt(C.c_int(kind), C.c_int64(conn_new.shape[1]), _p(conn_new), C.c_int64(xyz_new.shape[1]),
+                               _p(xyz_new), _p(edof), _p(_f64(solnApplied)), _p(ed), _p(_f64(timeData)),
+                               C.c_int64(N), _p(rowptr), _p(cols), _p(vals), _p(rhs))
+    if rc:
+        raise RuntimeError(f"oracle assembly failed rc={rc}")
+    return vals, rhs
+
+
+def set_threads(n):
+    """OpenMP thread count of liboracle.so (its own libgomp instance)."""
+    import ctypes.util
+    g = C.CDLL(ctypes.util.find_library("gomp") or "libgomp.so.1")
+    g.omp_set_num_threads(int(n))
+
+
 def spmv(rowptr, cols, vals, x):
     N = len(rowptr) - 1
     y = np.empty(N)

@@ -1091,15 +1091,19 @@ int run_pcg(pfem_solver *s)
             }
             // with events: marker-end -> kernel-end of THIS launch (see event_overhead_ms)
             launch_spmv<true>(s, s->d_p.p, s->d_w.p, n, part_pw, ctl, e0, e1);
-            const double *red_pw = scal_pw;
+            const double *red_pw = nullptr, *pw_parts = part_pw;
+            int pw_n = static_cast<int>(gs);
             if (multi) {
                 PFEM_TRY(interface_sum(s, s->d_w.p, part_pw, nullptr, static_cast<int>(gs), 1, ctl));
                 red_pw = s->xbuf + s->n_iface;
-            } else {
-                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s->stream, static_cast<const double *>(part_pw),
-                                   static_cast<const double *>(nullptr), static_cast<int>(gs), scal_pw, static_cast<const CgCtl *>(ctl));
+            } else if (gs > kMaxGrid) {
+                // too many SpMV blocks for every consumer block to re-sum: fold to kFoldBlocks first
+                hipLaunchKernelGGL(k_fold_partials, dim3(kFoldBlocks), block, 0, s->stream, static_cast<const double *>(part_pw),
+                                   static_cast<int>(gs), scal_pw, static_cast<const CgCtl *>(ctl));
+                pw_parts = scal_pw;
+                pw_n = kFoldBlocks;
             }
-            hipLaunchKernelGGL(k_cg_update, dim3(gv), block, 0, s->stream, ctl, it, n, s->n_owned, part_pw, static_cast<int>(gs),
+            hipLaunchKernelGGL(k_cg_update, dim3(gv), block, 0, s->stream, ctl, it, n, s->n_owned, pw_parts, pw_n,
                                red_pw, s->d_p.p, s->d_w.p, s->d_dinv.p, s->d_x.p, s->d_r.p, part_rz, part_zz);
             if (multi) PFEM_TRY(scalar_sum2(s, part_rz, part_zz, static_cast<int>(gv), ctl));
             hipLaunchKernelGGL(k_cg_direction, dim3(gv), block, 0, s->stream, ctl, it, n, part_rz, part_zz, static_cast<int>(gv),

@@ -842,6 +842,23 @@ __global__ void __launch_bounds__(1024) k_reduce_partials(const double *part0, c
     }
 }
 
+// First stage of a two-stage fold of MANY partials (one per SpMV block): block b of kFoldBlocks
+// sums the b-th contiguous chunk into out[b]; the consumer kernel re-sums those kFoldBlocks values
+// (sum_partials).  Fixed chunking and order -> bitwise reproducible; ~2x quicker than one block.
+constexpr int kFoldBlocks = 32;
+__global__ void __launch_bounds__(kBlock) k_fold_partials(const double *__restrict__ part, int n, double *out,
+                                                           const CgCtl *ctl)
+{
+    __shared__ double sm[4];
+    if (ctl && ctl->flag != 0) return;
+    const int chunk = (n + kFoldBlocks - 1) / kFoldBlocks;
+    const int lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
+    double a = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += kBlock) a += part[i];
+    const double t = block_sum(a, sm);
+    if (threadIdx.x == 0) out[blockIdx.x] = t;
+}
+
 // ---------------------------------------------------------------------------
 // Jacobi-PCG vector kernels (PETSc KSPCG semantics)
 // ---------------------------------------------------------------------------

@@ -18,11 +18,10 @@ def run(var, grid, block, reps=30):
     ms = C.c_double(0); chk = C.c_double(0)
     rc = lab(s._h, var, grid, block, reps, C.byref(ms), C.byref(chk))
     return rc, ms.value, chk.value
-names = {0: "product", 3: "noXCD", 9: "noXCD+nt", 10: "2rows noXCD", 11: "2rows noXCD nt"}
+names = {0: "int32 product", 13: "16-bit product", 12: "16-bit 2rows/lane", 11: "int32 2rows nt"}
 ns = info["n_local"] // 64 + 1
-for var in (0, 3, 9, 10, 11):
-    for grid, block in ((2048, 256), (4096, 256), (8192, 256), (16384, 256), (ns // 4 + 1, 256), (ns // 2 + 1, 128), (ns + 1, 64), (ns // 8 + 1, 512), (ns // 16 + 1, 1024), (ns // 8 + 1, 256), (ns // 16 + 1, 256)):
-        if var == 0 and (grid, block) != (2048, 256): continue
-        if var >= 10: grid = (grid + 1) // 2
-        rc, ms, chk = run(var, grid, block)
-        print(f"var {var:2d} {names[var]:15s} grid {grid:6d} block {block:5d} rc {rc} {ms*1e3:8.1f} us  {byts/ms/1e6:7.0f} GB/s  chk {chk:.6e}", flush=True)
+for rep in range(3):
+    for var in (0, 13, 12, 11):
+        grid = (ns // 8 + 1) if var == 11 else 1
+        rc, ms, chk = run(var, grid, 256, reps=50)
+        print(f"var {var:2d} {names[var]:20s} rc {rc} {ms*1e3:8.1f} us  {byts/ms/1e6:7.0f} GB/s  chk {chk:.6e}", flush=True)
