@@ -156,7 +156,7 @@ struct pfem_solver {
     // mesh
     MeshDev mesh{};
     bool have_mesh = false;
-    DevBuf<int32_t> d_conn, d_edof;
+    DevBuf<int32_t> d_conn, d_edof, d_elemrec;
     DevBuf<double> d_xyz, d_soln;
 
     // local numbering
@@ -170,7 +170,9 @@ struct pfem_solver {
     int geom_err = 0;              // PFEM_ERR_NEG_JAC if any element is inverted (gather form)
     DevBuf<int64_t> d_inc_ptr;     // [nNode+1] incidence list of every node ...
     DevBuf<int32_t> d_inc_ea;      // ... entries 4*e + a, ascending element id
+    DevBuf<uint32_t> d_inc_slots;  // ... and the matrix entry index of each element node inside the node's rows
     int64_t nnz = 0, n_slices = 0, stored = 0;
+    int max_row_len = 0;
     DevBuf<int64_t> d_rowptr, d_slice_off;
     DevBuf<int32_t> d_rowlen, d_cols;
     DevBuf<double> d_vals;
@@ -419,6 +421,14 @@ extern "C" int pfem_mesh_upload(pfem_solver *s, int kind, int64_t nElem, const i
     m.edof = s->d_edof.p;
     m.xyz = s->d_xyz.p;
     m.soln = s->d_soln.p;
+    // AoS element records for the gather assembly
+    PFEM_TRY(s->d_elemrec.alloc(static_cast<size_t>(std::max<int64_t>(nElem, 1)) * (m.ndof == 1 ? 8 : 16)));
+    m.elemrec = s->d_elemrec.p;
+    if (nElem > 0) {
+        hipLaunchKernelGGL(k_build_elemrec, dim3(grid_for(nElem)), dim3(kBlock), 0, s->stream, m, s->d_elemrec.p);
+        PFEM_TRY(check_kernel("k_build_elemrec"));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+    }
     s->have_mesh = true;
     s->have_pattern = false;
     s->tm.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -521,6 +531,13 @@ int pattern_from_keys(pfem_solver *s, DevBuf<uint64_t> &keys, int64_t nkeys)
     PFEM_HIP(hipMemcpyAsync(&stored, s->d_slice_off.p + s->n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, s->stream));
     PFEM_HIP(hipStreamSynchronize(s->stream));
     s->stored = stored;
+    {   // widest row (= widest slice) of the pattern
+        std::vector<int64_t> h_off(static_cast<size_t>(s->n_slices) + 1);
+        PFEM_HIP(hipMemcpy(h_off.data(), s->d_slice_off.p, sizeof(int64_t) * h_off.size(), hipMemcpyDeviceToHost));
+        int64_t w = 0;
+        for (int64_t i = 0; i < s->n_slices; ++i) w = std::max(w, (h_off[i + 1] - h_off[i]) >> 6);
+        s->max_row_len = static_cast<int>(w);
+    }
     PFEM_TRY(s->d_cols.alloc(static_cast<size_t>(stored)));
     PFEM_TRY(s->d_vals.alloc(static_cast<size_t>(stored)));
     hipLaunchKernelGGL(k_fill_sell, dim3(grid_for(s->n_slices * 64)), dim3(kBlock), 0, s->stream, keys.p, s->d_rowptr.p, n,
@@ -568,6 +585,22 @@ int build_incidence(pfem_solver *s)
     hipLaunchKernelGGL(k_low32, dim3(grid_for(nk)), dim3(kBlock), 0, s->stream, sorted.p, nk, s->d_inc_ea.p);
     PFEM_TRY(check_kernel("incidence"));
     PFEM_HIP(hipStreamSynchronize(s->stream));
+    // slot map: entry index of every (node row, element node) pair, so the numeric kernels never search
+    PFEM_TRY(s->d_inc_slots.alloc(static_cast<size_t>(nk)));
+    PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
+    hipLaunchKernelGGL(k_build_inc_slots, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m, s->sell(),
+                       static_cast<const int64_t *>(s->d_inc_ptr.p), static_cast<const int32_t *>(s->d_inc_ea.p),
+                       s->d_inc_slots.p, s->d_err.p);
+    PFEM_TRY(check_kernel("k_build_inc_slots"));
+    int slot_err = 0;
+    PFEM_TRY(fetch_err(s, &slot_err));
+    if (slot_err == 2) return PFEM_ERR_PATTERN;
+    if (slot_err == 1) {          // a row with more than 255 entries: keep the scatter form
+        s->d_inc_slots.release();
+        s->d_inc_ptr.release();
+        s->d_inc_ea.release();
+        return PFEM_OK;
+    }
     // orientation test of every element, once per mesh
     PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
     hipLaunchKernelGGL(k_check_jacobian, dim3(grid_for(m.nElem)), dim3(kBlock), 0, s->stream, m, s->d_err.p);
@@ -669,20 +702,22 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
         SellDev A = s->sell();
         const int64_t *ip = s->d_inc_ptr.p;
         const int32_t *ie = s->d_inc_ea.p;
+        const uint32_t *is = s->d_inc_slots.p;
+        // rows of the 1-dof kinds are accumulated in LDS when maxlen*256 doubles fit 64 KiB
+        const size_t lds = static_cast<size_t>(s->max_row_len) * kBlock * sizeof(double);
+        const bool use_lds = m.kind != PFEM_ELAST_TET && s->max_row_len > 0 && lds <= 65536;
+#define PFEM_GATHER(KIND)                                                                                             \
+    if (use_lds) hipLaunchKernelGGL((k_gather_scalar<KIND, true>), grid, block, lds, s->stream, m, A, s->d_rhs.p, prm, ip, ie, is, s->d_err.p); \
+    else hipLaunchKernelGGL((k_gather_scalar<KIND, false>), grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ie, is, s->d_err.p)
         switch (m.kind) {
-        case PFEM_POISSON_TET:
-            hipLaunchKernelGGL(k_gather_scalar<PFEM_POISSON_TET>, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ie, s->d_err.p);
-            break;
-        case PFEM_POISSON_TRIA:
-            hipLaunchKernelGGL(k_gather_scalar<PFEM_POISSON_TRIA>, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ie, s->d_err.p);
-            break;
-        case PFEM_POISSON_TRIA_INLINE:
-            hipLaunchKernelGGL(k_gather_scalar<PFEM_POISSON_TRIA_INLINE>, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ie, s->d_err.p);
-            break;
+        case PFEM_POISSON_TET: PFEM_GATHER(PFEM_POISSON_TET); break;
+        case PFEM_POISSON_TRIA: PFEM_GATHER(PFEM_POISSON_TRIA); break;
+        case PFEM_POISSON_TRIA_INLINE: PFEM_GATHER(PFEM_POISSON_TRIA_INLINE); break;
         case PFEM_ELAST_TET:
-            hipLaunchKernelGGL(k_gather_elast, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ie, s->d_err.p);
+            hipLaunchKernelGGL(k_gather_elast, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ie, is, s->d_err.p);
             break;
         }
+#undef PFEM_GATHER
         PFEM_TRY(check_kernel("k_gather"));
     } else if (m.nElem > 0) {
         // scatter form: one thread per element, hardware f64 atomics
