@@ -130,6 +130,21 @@ int pfem_assy_for_soln(int64_t nNode, int ndof, const int32_t *NodeDofArrayNew,
 int pfem_partition_box_slabs(int nEx, int nEy, int nEz, int nParts,
                              int32_t *elem_proc_id, int32_t *node_proc_id);
 
+/* Mesh ingest, the step before the path: the three/four `.dat` files are whitespace-
+ * separated ASCII tables, one record per line (tetrapoissonparallelimpl1.F:216-355).  `shape` counts
+ * the non-empty records and the tokens of the first one; `parse` fills out[c*rows + r] (column-major,
+ * like the Fortran arrays), OpenMP over records.  Extra tokens on a line are ignored, as a
+ * list-directed READ does.                                                                     */
+int pfem_text_table_shape(const char *buf, int64_t len, int64_t *rows, int *cols);
+int pfem_text_table_parse(const char *buf, int64_t len, int64_t rows, int cols, double *out);
+
+/* Output step after the path: legacy ASCII VTK exactly as MODULE WriterVTK writes it
+ * (writervtk.F:33-201: F12.6 reals, I10 ids, CELL_TYPES 5/10, `procid` cell scalars, scalar or vector
+ * `solution` point data).  conn is 0-based SoA, soln is [node*ndof+d] by node id.                  */
+int pfem_write_vtk(const char *path, int ndim, int64_t nElem, int64_t nNode, int npElem, int ndof,
+                   const double *coords, const int32_t *conn, const int32_t *elem_procid,
+                   const double *soln);
+
 /* ========================================================================= */
 /* 3. the solver object == TYPE PetscSolver (solverpetsc.F:72-105)            */
 /* ========================================================================= */

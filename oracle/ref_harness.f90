@@ -93,3 +93,23 @@ subroutine ref_poisson_tria_batch(n, x, y, ed, td, K, F) bind(C, name="ref_poiss
     call StiffnessResidualPoissonLinearTria(xx, yy, edd, tdd, vcc, vdd, K(:,:,e), F(:,e))
   end do
 end subroutine ref_poisson_tria_batch
+
+! The reference's own VTK writer (writervtk.F), for the golden output file of the "output step".
+subroutine ref_write_vtk(ndim, nElem, nNode, npElem, ndof, coords, conn1, procid, soln, fname, flen) bind(C, name="ref_write_vtk")
+  use iso_c_binding
+  use WriterVTK, only: writeoutputvtk
+  implicit none
+  integer(c_int), value :: ndim, nElem, nNode, npElem, ndof, flen
+  real(c_double), intent(in) :: coords(nNode, ndim), soln(nNode*ndof)
+  integer(c_int), intent(in) :: conn1(nElem, npElem), procid(nElem)
+  character(kind=c_char), intent(in) :: fname(flen)
+  character(len=flen) :: fn
+  double precision, allocatable :: cc(:,:), ss(:)
+  integer, allocatable :: ee(:,:), pp(:)
+  integer :: i
+  do i = 1, flen
+    fn(i:i) = fname(i)
+  end do
+  cc = coords; ss = soln; ee = conn1; pp = procid
+  call writeoutputvtk(ndim, nElem, nNode, npElem, ndof, cc, ee, pp, ss, fn)
+end subroutine ref_write_vtk

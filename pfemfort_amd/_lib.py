@@ -61,6 +61,9 @@ SIGNATURES = {
     "pfem_elem_dof_array": [_L, _I, _I, _P, _P, _P],
     "pfem_assy_for_soln": [_L, _I, _P, _P],
     "pfem_partition_box_slabs": [_I, _I, _I, _I, _P, _P],
+    "pfem_text_table_shape": [C.c_char_p, _L, _P, _P],
+    "pfem_text_table_parse": [C.c_char_p, _L, _L, _I, _P],
+    "pfem_write_vtk": [C.c_char_p, _I, _L, _L, _I, _I, _P, _P, _P, _P],
     "pfem_solver_create": [_P, _L, _L, _L, _P, _P, _I],
     "pfem_solver_destroy": [_P],
     "pfem_solver_set_stream": [_P, _P],

@@ -306,3 +306,127 @@ extern "C" int pfem_find_ghosts(int64_t count, const int32_t *edof, int64_t row_
     if (ghost_gid) std::copy(g.begin(), g.end(), ghost_gid);
     return PFEM_OK;
 }
+
+// ---------------------------------------------------------------------------
+// 5. output step (after the path): legacy ASCII VTK, byte-compatible with writervtk.F:33-201
+// ---------------------------------------------------------------------------
+extern "C" int pfem_write_vtk(const char *path, int ndim, int64_t nElem, int64_t nNode, int npElem, int ndof,
+                              const double *coords /*SoA [d*nNode+n]*/, const int32_t *conn /*SoA, 0-based*/,
+                              const int32_t *elem_procid, const double *soln /*[n*ndof+d]*/)
+{
+    if (!path || (ndim != 2 && ndim != 3) || nElem < 0 || nNode < 0 || npElem < 3 || ndof < 1 || !coords || !conn ||
+        !elem_procid || !soln)
+        return PFEM_ERR_ARG;
+    int cell_type;                                               // writervtk.F:85-140
+    if (ndim == 2) cell_type = npElem == 3 ? 5 : (npElem == 6 ? 22 : 9);
+    else cell_type = npElem == 4 ? 10 : (npElem == 6 ? 13 : 12);
+    const int ncol = ndim == 2 ? (npElem == 3 ? 3 : (npElem == 6 ? 6 : 4)) : (npElem == 4 ? 4 : (npElem == 6 ? 4 : 0));
+    if (ncol == 0 || ncol > npElem) return PFEM_ERR_ARG;
+    std::FILE *f = std::fopen(path, "w");
+    if (!f) return PFEM_ERR_ARG;
+    std::vector<char> buf(1 << 22);
+    std::setvbuf(f, buf.data(), _IOFBF, buf.size());
+    std::fputs("# vtk DataFile Version 4.0\n", f);               // '(A)'
+    std::fputs("PoissonTwoD example\n", f);
+    std::fputs(" ASCII\n", f);                                   // list-directed write(1,*): leading blank
+    std::fputs("DATASET UNSTRUCTURED_GRID\n", f);
+    std::fprintf(f, "POINTS %10lld float\n", static_cast<long long>(nNode));     // '(A,I10,A)'
+    for (int64_t n = 0; n < nNode; ++n)                          // '(F12.6,F12.6,F12.6)'
+        std::fprintf(f, "%12.6f%12.6f%12.6f\n", coords[n], coords[nNode + n], ndim == 3 ? coords[2 * nNode + n] : 0.0);
+    std::fprintf(f, "CELLS %10lld%10lld\n", static_cast<long long>(nElem), static_cast<long long>(nElem * (npElem + 1)));
+    for (int64_t e = 0; e < nElem; ++e) {                        // 0-based ids, npElem first
+        std::fprintf(f, "%10d", npElem);
+        for (int a = 0; a < ncol; ++a) std::fprintf(f, "%10d", conn[a * nElem + e]);
+        std::fputc('\n', f);
+    }
+    std::fprintf(f, "CELL_TYPES%10lld\n", static_cast<long long>(nElem));
+    for (int64_t e = 0; e < nElem; ++e) std::fprintf(f, "%3d\n", cell_type);
+    std::fprintf(f, "CELL_DATA%10lld\n", static_cast<long long>(nElem));
+    std::fputs("SCALARS procid int 1\nLOOKUP_TABLE default\n", f);
+    for (int64_t e = 0; e < nElem; ++e) std::fprintf(f, "%3d\n", elem_procid[e]);
+    std::fprintf(f, "POINT_DATA%10lld\n", static_cast<long long>(nNode));
+    if (ndof == 1) {
+        std::fputs("SCALARS solution float 1\nLOOKUP_TABLE default\n", f);
+        for (int64_t n = 0; n < nNode; ++n) std::fprintf(f, "%12.6f\n", soln[n]);
+    } else {
+        std::fputs("VECTORS solution float\n", f);
+        for (int64_t n = 0; n < nNode; ++n)
+            std::fprintf(f, "%12.6f%12.6f%12.6f\n", soln[n * ndof], soln[n * ndof + 1], ndof == 2 ? 0.0 : soln[n * ndof + 2]);
+    }
+    const bool ok = std::fflush(f) == 0 && !std::ferror(f);
+    std::fclose(f);
+    return ok ? PFEM_OK : PFEM_ERR_ARG;
+}
+
+// ---------------------------------------------------------------------------
+// 6. mesh ingest (the step before the path): whitespace-separated ASCII tables, one record per
+//    line, as the drivers read them with list-directed READs (tetrapoissonparallelimpl1.F:216-355)
+// ---------------------------------------------------------------------------
+namespace {
+inline bool is_blank(char c) { return c == ' ' || c == '\t' || c == '\r' || c == ','; }
+}
+
+extern "C" int pfem_text_table_shape(const char *buf, int64_t len, int64_t *rows, int *cols)
+{
+    if (!buf || len < 0 || !rows || !cols) return PFEM_ERR_ARG;
+    int64_t r = 0;
+    int c0 = 0;
+    int64_t i = 0;
+    while (i < len) {
+        int tokens = 0;
+        while (i < len && buf[i] != '\n') {
+            while (i < len && is_blank(buf[i])) ++i;
+            if (i < len && buf[i] != '\n') {
+                ++tokens;
+                while (i < len && buf[i] != '\n' && !is_blank(buf[i])) ++i;
+            }
+        }
+        if (i < len) ++i;   // newline
+        if (tokens > 0) {
+            if (r == 0) c0 = tokens;
+            else if (tokens < c0) return PFEM_ERR_ARG;      // short record
+            ++r;
+        }
+    }
+    *rows = r;
+    *cols = c0;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_text_table_parse(const char *buf, int64_t len, int64_t rows, int cols, double *out)
+{
+    if (!buf || len < 0 || rows < 0 || cols < 1 || !out) return PFEM_ERR_ARG;
+    // line starts of the non-empty records, then parse them in parallel
+    std::vector<int64_t> start;
+    start.reserve(static_cast<size_t>(rows));
+    int64_t i = 0;
+    while (i < len) {
+        int64_t j = i;
+        bool any = false;
+        while (j < len && buf[j] != '\n') { any = any || !is_blank(buf[j]); ++j; }
+        if (any) start.push_back(i);
+        i = j + 1;
+    }
+    if (static_cast<int64_t>(start.size()) != rows) return PFEM_ERR_ARG;
+    int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+    for (int64_t r = 0; r < rows; ++r) {
+        const char *p = buf + start[r];
+        const char *end = buf + len;
+        for (int c = 0; c < cols; ++c) {
+            while (p < end && is_blank(*p)) ++p;
+            if (p >= end || *p == '\n') { bad |= 1; break; }
+            // tokens are short: copy to a bounded, NUL-terminated scratch for strtod
+            char tok[64];
+            int n = 0;
+            while (p < end && *p != '\n' && !is_blank(*p) && n < 63) tok[n++] = *p++;
+            tok[n] = 0;
+            for (int k = 0; k < n; ++k) if (tok[k] == 'D' || tok[k] == 'd') tok[k] = 'e';   // Fortran exponent
+            char *q = nullptr;
+            const double v = std::strtod(tok, &q);
+            if (q == tok) { bad |= 1; break; }
+            out[static_cast<int64_t>(c) * rows + r] = v;
+        }
+    }
+    return bad ? PFEM_ERR_ARG : PFEM_OK;
+}

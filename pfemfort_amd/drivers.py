@@ -47,6 +47,25 @@ class Result:
             ind = self.dm.node_map_get_old[assy // ndof] * ndof + assy % ndof + 1
         return np.arange(1, len(assy) + 1), ind, self.soln_free
 
+    def write_outputs(self, directory=".", elem_procid=None):
+        """The output step of the drivers: ``temp.dat`` (:935-942 / elasticity :1031-1046) and the
+        legacy VTK file through the writervtk.F-compatible writer (:944-966)."""
+        import os
+        ndof = self.dm.NodeDofArrayNew.shape[1]
+        ii, ind, val = self.temp_dat()
+        with open(os.path.join(directory, "temp.dat"), "w") as f:
+            if ndof == 1:
+                for a, b, c in zip(ii, ind, val):
+                    f.write(f" {a:11d} {b:11d}   {c:.16E}\n")
+            else:
+                for c in val:
+                    f.write(f"   {c:.16E}\n")
+        name = "Poisson-soln.vtk" if ndof == 1 else "Elasticity-soln.vtk"
+        pid = np.zeros(self.mesh.nElem, np.int32) if elem_procid is None else elem_procid
+        H.writeoutputvtk(self.mesh.xyz.shape[0], self.mesh.xyz, self.mesh.conn, pid, self.solnVTK, os.path.join(directory, name),
+                         ndof=ndof)
+        return os.path.join(directory, name)
+
 
 def _setup(kind, mesh: H.Mesh, nParts=1, node_proc_id=None):
     ndof = L.NDOF[kind]

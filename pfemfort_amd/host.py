@@ -60,17 +60,29 @@ class Mesh:
         return self.conn.shape[1]
 
 
+def read_table(path: str) -> np.ndarray:
+    """One mesh file -> (rows, cols) float64, parsed by the library's multithreaded ASCII reader."""
+    with (gzip.open(path, "rb") if str(path).endswith(".gz") else open(path, "rb")) as f:
+        buf = f.read()
+    rows = C.c_int64(0); cols = C.c_int(0)
+    L.check(L.lib().pfem_text_table_shape(buf, len(buf), C.byref(rows), C.byref(cols)), f"pfem_text_table_shape({path})")
+    out = np.empty((cols.value, rows.value))
+    if rows.value == 0:
+        return out.T
+    L.check(L.lib().pfem_text_table_parse(buf, len(buf), rows.value, cols.value, _p(out)), f"pfem_text_table_parse({path})")
+    return out.T
+
+
 def read_mesh(prefix: str) -> Mesh:
     """``<prefix>-nodes.dat[.gz]``, ``-elems``, ``-DirichBC``: whitespace ASCII, 1-based
     (tetrapoissonparallelimpl1.F:216-355)."""
-    def load(kind, dtype=float):
+    def load(kind):
         for ext in (".dat.gz", ".dat"):
             path = f"{prefix}-{kind}{ext}"
             if os.path.exists(path):
-                with (gzip.open(path, "rt") if ext.endswith(".gz") else open(path, "rt")) as f:
-                    return np.loadtxt(f, dtype=dtype, ndmin=2)
+                return read_table(path)
         raise FileNotFoundError(f"{prefix}-{kind}.dat[.gz]")
-    nodes, elems, bcs = load("nodes"), load("elems", np.int64), load("DirichBC")
+    nodes, elems, bcs = load("nodes"), load("elems"), load("DirichBC")
     return Mesh(np.ascontiguousarray(nodes[:, 1:].T), np.ascontiguousarray((elems[:, 1:] - 1).T.astype(np.int32)),
                 (bcs[:, 0] - 1).astype(np.int32), (bcs[:, 1] - 1).astype(np.int32), bcs[:, 2].copy())
 
@@ -177,3 +189,15 @@ def find_ghosts(edof, row_start, n_owned):
     g = np.empty(n.value, np.int64)
     L.check(L.lib().pfem_find_ghosts(e.size, _p(e), row_start, n_owned, C.byref(n), _p(g)), "pfem_find_ghosts")
     return g
+
+
+def writeoutputvtk(ndim, coords, elemNodeConn, elem_procid, soln, fileName, ndof=None):
+    """MODULE WriterVTK: writeoutputvtk (writervtk.F:33).  ``coords (ndim,nNode)``, ``elemNodeConn
+    (npElem,nElem)`` 0-based, ``soln (nNode, ndof)`` or flat by node id."""
+    coords = _f64(coords); conn = _i32(elemNodeConn); pid = _i32(elem_procid)
+    soln = _f64(soln)
+    nNode, nElem = coords.shape[1], conn.shape[1]
+    if ndof is None:
+        ndof = soln.size // nNode
+    L.check(L.lib().pfem_write_vtk(str(fileName).encode(), ndim, nElem, nNode, conn.shape[0], ndof, _p(coords), _p(conn),
+                                   _p(pid), _p(soln.ravel())), "writeoutputvtk")

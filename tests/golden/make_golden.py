@@ -62,6 +62,28 @@ def main():
     xy, c3 = random_trias(300, 7)
     K, F = O.ref_eval_elems(O.POISSON_TRIA, xy, c3, np.array([2.5, 0.4]))
     out.update(rtri_xy=xy, rtri_conn=c3, rtri_data=np.array([2.5, 0.4]), rtri_K=K, rtri_F=F)
+    # output step: the reference's own writervtk.F on fixed inputs -> golden VTK text (gzip)
+    import ctypes as C
+    import gzip
+    import tempfile
+    rng = np.random.default_rng(0)
+    pid = (np.arange(tet10.nElem) * 7 // tet10.nElem).astype(np.int32)
+    sol = (tet10.xyz ** 2).sum(0) - 1.7 + rng.standard_normal(tet10.nNode) * 1e-3
+    sol[5:10] = [-1e-9, 0.0, -0.0, 12345.6789, 0.0000005]
+    vec = rng.standard_normal((tet10.nNode, 3))
+    out.update(vtk_procid=pid, vtk_scalar=sol, vtk_vector=vec)
+    L = O.ref_lib()
+    for name, field, ndof in (("tet10_scalar", sol, 1), ("tet10_vector", vec.ravel(), 3)):
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "o.vtk").encode()
+            coords = np.asfortranarray(tet10.xyz.T)
+            c1 = np.asfortranarray((tet10.conn.T + 1).astype(np.int32))
+            L.ref_write_vtk(C.c_int(3), C.c_int(tet10.nElem), C.c_int(tet10.nNode), C.c_int(4), C.c_int(ndof),
+                            coords.ctypes.data_as(C.c_void_p), c1.ctypes.data_as(C.c_void_p),
+                            pid.ctypes.data_as(C.c_void_p), np.ascontiguousarray(field).ctypes.data_as(C.c_void_p),
+                            path, C.c_int(len(path)))
+            with open(path, "rb") as f, gzip.GzipFile(os.path.join(g, f"vtk_{name}.vtk.gz"), "wb", mtime=0) as z:
+                z.write(f.read())
     np.savez_compressed(os.path.join(g, "elements.npz"), **out)
     print("wrote", os.path.join(g, "elements.npz"), {k: v.shape for k, v in out.items()})
 

@@ -121,3 +121,39 @@ def test_find_ghosts():
     edof = np.array([[0, 5, 9, -1], [3, 4, 12, 9]], np.int32)
     assert H.find_ghosts(edof, 3, 4).tolist() == [0, 9, 12]
     assert H.find_ghosts(edof, 0, 13).tolist() == []
+
+
+def test_vtk_writer_byte_identical_to_reference_writer(gold, tet10, golden_dir, tmp_path):
+    """Output step: same bytes as the reference's writervtk.F (golden files written by it)."""
+    import gzip
+    for name, field, ndof in (("tet10_scalar", gold["vtk_scalar"], 1), ("tet10_vector", gold["vtk_vector"], 3)):
+        out = tmp_path / f"{name}.vtk"
+        H.writeoutputvtk(3, tet10.xyz, tet10.conn, gold["vtk_procid"], field, out, ndof=ndof)
+        with gzip.open(os.path.join(golden_dir, f"vtk_{name}.vtk.gz"), "rb") as z:
+            assert out.read_bytes() == z.read()
+
+
+def test_ascii_mesh_reader_equals_numpy(golden_dir):
+    """Ingest step: the library's ASCII table reader against numpy.loadtxt on the shipped files."""
+    import gzip
+    for name in ("tet10-nodes", "tet10-elems", "tet10-DirichBC", "tria20x20-nodes", "tria20x20-elems", "tet100-DirichBC"):
+        path = os.path.join(golden_dir, "input", name + ".dat.gz")
+        with gzip.open(path, "rt") as f:
+            ref = np.loadtxt(f, ndmin=2)
+        got = H.read_table(path)
+        assert got.shape == ref.shape and np.array_equal(got, ref), name
+    m = H.read_mesh(os.path.join(golden_dir, "input", "tet10"))
+    o = O.read_mesh(os.path.join(golden_dir, "input", "tet10"))
+    assert np.array_equal(m.xyz, o.xyz) and np.array_equal(m.conn, o.conn) and np.array_equal(m.bc_val, o.bc_val)
+
+
+def test_ascii_reader_edge_cases(tmp_path):
+    p = tmp_path / "t.dat"
+    p.write_text("  1   0.5\t-2.0D+01 \r\n\n 2 1e-3 7  trailing\n3,4,5\n")
+    t = H.read_table(str(p))
+    assert t.shape == (3, 3) and np.array_equal(t, [[1, 0.5, -20.0], [2, 1e-3, 7], [3, 4, 5]])
+    p.write_text("1 2 3\n4 5\n")
+    with pytest.raises(pf.PfemError):
+        H.read_table(str(p))
+    p.write_text("")
+    assert H.read_table(str(p)).shape == (0, 0)
