@@ -48,6 +48,7 @@ extern "C" {
 #define PFEM_POISSON_TET 2         /* StiffnessResidualPoissonLinearTetra elementutilitiespoisson.F:107  */
 #define PFEM_ELAST_TET 3           /* StiffnessResidualElasticityLinearTetra elementutilitieselasticity3D.F:248 */
 #define PFEM_POISSON_TRIA_INLINE 4 /* inline area*B*B^T of triapoissonserialimpl1.F:573-594             */
+#define PFEM_ELAST_TRIA 5          /* StiffnessResidualElasticityLinearTria elementutilitieselasticity2D.F:23 (next row 8f.1) */
 
 /* ---- solver status (solverpetsc.F:64-68) -------------------------------- */
 #define PFEM_SOLVER_EMPTY 1
@@ -94,6 +95,11 @@ int pfem_poisson_tet_ke(const double xNode[4], const double yNode[4], const doub
 int pfem_elast_tet_ke(const double xNode[4], const double yNode[4], const double zNode[4],
                       const double *elemData /*E,nu,thick,bx,by,bz*/, const double *timeData,
                       const double valC[12], double K[144], double F[12]);
+
+/* elementutilitieselasticity2D.F:23-153: plane stress, D(3,3) = b1(1-nu) as in the reference */
+int pfem_elast_tria_ke(const double xNode[3], const double yNode[3],
+                       const double *elemData /*E,nu,thick,bx,by*/, const double *timeData,
+                       const double valC[6], double K[36], double F[6]);
 
 /* ========================================================================= */
 /* 2. driver bookkeeping, host, integer-exact (tetrapoissonparallelimpl1.F)   */
@@ -229,6 +235,11 @@ int pfem_solver_set_assembly_mode(pfem_solver *s, int mode);
 int pfem_solver_set_spmv_format(pfem_solver *s, int format);
 /* 16 if the SpMV currently streams 16-bit column gaps, 32 for int32 columns */
 int pfem_solver_get_spmv_format(pfem_solver *s, int *bits_per_column);
+/* Specified nodal forces after the element loop (VecSetValue(rhsVec,row,fact,ADD_VALUES),
+ * tetraelasticityparallelimpl1.F:971-982) for the batched path: GLOBAL free-dof ids (i.e.
+ * NodeDofArrayNew(n,d)-1; the reference's own row formula ignores constrained dofs);
+ * ids this rank does not own and negative ids are skipped.                                      */
+int pfem_rhs_add_values(pfem_solver *s, int64_t n, const int64_t *global_dof, const double *values);
 /* Per-element Ke/Fe of the uploaded mesh as computed by the DEVICE kernel (parity
  * inspection): K_out[e*nsize*nsize + i + nsize*j], F_out[e*nsize + i].           */
 int pfem_eval_elems(pfem_solver *s, const double *elemData, const double *timeData,

@@ -44,6 +44,7 @@
 #define ORC_POISSON_TET 2
 #define ORC_ELAST_TET 3
 #define ORC_POISSON_TRIA_INLINE 4
+#define ORC_ELAST_TRIA 5
 
 /* ------------------------------------------------------------------------ */
 /* Element routines                                                          */
@@ -303,9 +304,59 @@ int orc_elast_tet_ke(const double *xN, const double *yN, const double *zN,
     return ORC_OK;
 }
 
+/* elementutilitieselasticity2D.F:23-153 StiffnessResidualElasticityLinearTria: plane stress
+ * with the reference's D(3,3) = b1*(1-nu), one Gauss point (1/3,1/3) as REAL(4)
+ * literals, weight 0.5, dvol = gwts*(Jac*thick).  elemData = (E, nu, thick, bx, by). K col-major 6x6. */
+int orc_elast_tria_ke(const double *xN, const double *yN, const double *elemData,
+                      const double *timeData, double *K, double *F)
+{
+    const double E = elemData[0], nu = elemData[1], thick = elemData[2];
+    const double bforce[2] = {elemData[3], elemData[4]};
+    const double xi[2] = {(double)(1.0f / 3.0f), (double)(1.0f / 3.0f)};   /* :73 */
+    const double gwts = 0.5;
+    double D[3][3], Bm[3][6], DB[3][6], N[3], dNdx[3], dNdy[3], Jac, dvol, b1, b4, s;
+    int i, j, k, ii, TI;
+    (void)timeData;
+    b1 = E / (1.0 - nu * nu);                           /* :60 */
+    D[0][0] = b1;       D[0][1] = b1 * nu;  D[0][2] = 0.0;   /* :63-65 */
+    D[1][0] = b1 * nu;  D[1][1] = b1;       D[1][2] = 0.0;
+    D[2][0] = 0.0;      D[2][1] = 0.0;      D[2][2] = b1 * (1.0 - nu);
+    for (i = 0; i < 36; ++i) K[i] = 0.0;
+    for (i = 0; i < 6; ++i) F[i] = 0.0;
+    basis_tria(xi, xN, yN, N, dNdx, dNdy, &Jac);        /* :84 */
+    if (Jac < 0.0) return ORC_ERR_NEG_JAC;              /* :88 */
+    dvol = gwts * (Jac * thick);                        /* :92 */
+    memset(Bm, 0, sizeof Bm);                           /* :124-131 */
+    for (ii = 0; ii < 3; ++ii) {
+        TI = ii * 2;
+        Bm[0][TI] = dNdx[ii];  Bm[0][TI + 1] = 0.0;
+        Bm[1][TI] = 0.0;       Bm[1][TI + 1] = dNdy[ii];
+        Bm[2][TI] = dNdy[ii];  Bm[2][TI + 1] = dNdx[ii];
+    }
+    for (i = 0; i < 3; ++i)                             /* :134 Bmat = MATMUL(Dmat, Bmat) */
+        for (j = 0; j < 6; ++j) {
+            s = 0.0;
+            for (k = 0; k < 3; ++k) s = s + D[i][k] * Bm[k][j];
+            DB[i][j] = s;
+        }
+    for (i = 0; i < 6; ++i)                             /* :136-137 */
+        for (j = 0; j < 6; ++j) {
+            s = 0.0;
+            for (k = 0; k < 3; ++k) s = s + Bm[k][i] * DB[k][j];
+            K[i + 6 * j] = dvol * s;
+        }
+    for (ii = 0; ii < 3; ++ii) {                        /* :140-148 */
+        TI = ii * 2;
+        b4 = dvol * N[ii];
+        F[TI] = F[TI] + b4 * bforce[0];
+        F[TI + 1] = F[TI + 1] + b4 * bforce[1];
+    }
+    return ORC_OK;
+}
+
 /* Geometry of each element kind. */
 static int kind_npelem(int kind) { return (kind == ORC_POISSON_TET || kind == ORC_ELAST_TET) ? 4 : 3; }
-static int kind_ndof(int kind) { return kind == ORC_ELAST_TET ? 3 : 1; }
+static int kind_ndof(int kind) { return kind == ORC_ELAST_TET ? 3 : (kind == ORC_ELAST_TRIA ? 2 : 1); }
 static int kind_ndim(int kind) { return (kind == ORC_POISSON_TET || kind == ORC_ELAST_TET) ? 3 : 2; }
 
 /* Evaluate one element of a mesh: gathers coordinates like the driver does
@@ -329,6 +380,7 @@ static int eval_elem(int kind, int64_t e, int64_t nElem, const int32_t *conn,
     case ORC_POISSON_TRIA_INLINE: return orc_poisson_tria_inline_ke(xN, yN, K, F);
     case ORC_POISSON_TET: return orc_poisson_tet_ke(xN, yN, zN, elemData, timeData, valC, K, F);
     case ORC_ELAST_TET: return orc_elast_tet_ke(xN, yN, zN, elemData, timeData, K, F);
+    case ORC_ELAST_TRIA: return orc_elast_tria_ke(xN, yN, elemData, timeData, K, F);
     }
     return ORC_ERR_ARG;
 }

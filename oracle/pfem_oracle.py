@@ -23,16 +23,19 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-POISSON_TRIA, POISSON_TET, ELAST_TET, POISSON_TRIA_INLINE = 1, 2, 3, 4
-NPELEM = {POISSON_TRIA: 3, POISSON_TET: 4, ELAST_TET: 4, POISSON_TRIA_INLINE: 3}
-NDOF = {POISSON_TRIA: 1, POISSON_TET: 1, ELAST_TET: 3, POISSON_TRIA_INLINE: 1}
-NDIM = {POISSON_TRIA: 2, POISSON_TET: 3, ELAST_TET: 3, POISSON_TRIA_INLINE: 2}
+POISSON_TRIA, POISSON_TET, ELAST_TET, POISSON_TRIA_INLINE, ELAST_TRIA = 1, 2, 3, 4, 5
+NPELEM = {POISSON_TRIA: 3, POISSON_TET: 4, ELAST_TET: 4, POISSON_TRIA_INLINE: 3, ELAST_TRIA: 3}
+NDOF = {POISSON_TRIA: 1, POISSON_TET: 1, ELAST_TET: 3, POISSON_TRIA_INLINE: 1, ELAST_TRIA: 2}
+NDIM = {POISSON_TRIA: 2, POISSON_TET: 3, ELAST_TET: 3, POISSON_TRIA_INLINE: 2, ELAST_TRIA: 2}
 
 # REAL(4) literals of the drivers widened to double
 F32 = lambda v: float(np.float32(v))  # noqa: E731
 POISSON_ELEMDATA = np.array([1.0, 1.0, 1.0])                     # tetrapoissonparallelimpl1.F:822
 ELAST_ELEMDATA = np.array([F32(240.565), F32(0.3), 1.0, F32(0.1), 0.0, 0.0])  # tetraelasticity...F:895-899
 TIMEDATA = np.array([0.0, 1.0, 0.0])                             # :823
+# triaelasticityparallelimpl1.F:907 sets only E, nu (thick, bforce are left uninitialised there:
+# SURVEY 8f.1); intended values: unit thickness, no body force
+ELAST2D_ELEMDATA = np.array([F32(240.565), F32(0.3), 1.0, 0.0, 0.0, 0.0])
 
 
 def build(ref: bool = True) -> None:
@@ -174,6 +177,8 @@ def ref_eval_elems(kind, xyz, conn, elemData, timeData=TIMEDATA):
         L.ref_elast_tet_batch(C.c_int64(nElem), _p(g[0]), _p(g[1]), _p(g[2]), _p(ed), _p(td), _p(K), _p(F))
     elif kind == POISSON_TRIA:
         L.ref_poisson_tria_batch(C.c_int64(nElem), _p(g[0]), _p(g[1]), _p(ed), _p(td), _p(K), _p(F))
+    elif kind == ELAST_TRIA:
+        L.ref_elast_tria_batch(C.c_int64(nElem), _p(g[0]), _p(g[1]), _p(ed), _p(td), _p(K), _p(F))
     else:
         raise ValueError(kind)
     return K.transpose(0, 2, 1).copy(), F
@@ -316,7 +321,7 @@ class Problem:
 def setup_problem(kind, mesh: Mesh, elemData=None, nParts=1, node_proc_id=None) -> Problem:
     """tetrapoissonparallelimpl1.F:316-884 on one process (all elements assembled)."""
     if elemData is None:
-        elemData = ELAST_ELEMDATA if kind == ELAST_TET else POISSON_ELEMDATA
+        elemData = {ELAST_TET: ELAST_ELEMDATA, ELAST_TRIA: ELAST2D_ELEMDATA}.get(kind, POISSON_ELEMDATA)
     ndof = NDOF[kind]
     dm = dof_numbering(mesh.nNode, ndof, mesh.bc_node, mesh.bc_dof, mesh.bc_val, nParts, node_proc_id)
     conn_new = dm.node_map_get_new[mesh.conn].astype(np.int32)

@@ -113,3 +113,19 @@ subroutine ref_write_vtk(ndim, nElem, nNode, npElem, ndof, coords, conn1, procid
   cc = coords; ss = soln; ee = conn1; pp = procid
   call writeoutputvtk(ndim, nElem, nNode, npElem, ndof, cc, ee, pp, ss, fn)
 end subroutine ref_write_vtk
+
+subroutine ref_elast_tria_batch(n, x, y, ed, td, K, F) bind(C, name="ref_elast_tria_batch")
+  use iso_c_binding
+  use ElementUtilitiesElasticity2D, only: StiffnessResidualElasticityLinearTria
+  implicit none
+  integer(c_int64_t), value :: n
+  real(c_double), intent(in)  :: x(3,n), y(3,n), ed(5), td(3)
+  real(c_double), intent(out) :: K(6,6,n), F(6,n)
+  double precision :: xx(3), yy(3), edd(5), tdd(3), vcc(6), vdd(6)
+  integer(c_int64_t) :: e
+  edd = ed; tdd = td; vcc = 0.0d0; vdd = 0.0d0
+  do e = 1, n
+    xx = x(:,e); yy = y(:,e)
+    call StiffnessResidualElasticityLinearTria(xx, yy, edd, tdd, vcc, vdd, K(:,:,e), F(:,e))
+  end do
+end subroutine ref_elast_tria_batch

@@ -16,14 +16,14 @@ LIB_PATH = os.environ.get("PFEM_AMD_LIB") or os.path.join(_HERE, "libpfem_amd.so
 # error codes (include/pfem_amd.h)
 OK, ERR_ARG, ERR_STATE, ERR_NEG_JAC, ERR_HIP, ERR_NOGPU, ERR_NOMEM, ERR_DIVERGED, ERR_PATTERN, ERR_COMM = range(10)
 # element kinds
-POISSON_TRIA, POISSON_TET, ELAST_TET, POISSON_TRIA_INLINE = 1, 2, 3, 4
+POISSON_TRIA, POISSON_TET, ELAST_TET, POISSON_TRIA_INLINE, ELAST_TRIA = 1, 2, 3, 4, 5
 # solver status (solverpetsc.F:64-68)
 SOLVER_EMPTY, PATTERN_OK, INIT_OK, ASSEMBLY_OK, FACTORISE_OK = 1, 2, 3, 4, 5
 INSERT_VALUES, ADD_VALUES = 1, 2
 
-NPELEM = {POISSON_TRIA: 3, POISSON_TET: 4, ELAST_TET: 4, POISSON_TRIA_INLINE: 3}
-NDOF = {POISSON_TRIA: 1, POISSON_TET: 1, ELAST_TET: 3, POISSON_TRIA_INLINE: 1}
-NDIM = {POISSON_TRIA: 2, POISSON_TET: 3, ELAST_TET: 3, POISSON_TRIA_INLINE: 2}
+NPELEM = {POISSON_TRIA: 3, POISSON_TET: 4, ELAST_TET: 4, POISSON_TRIA_INLINE: 3, ELAST_TRIA: 3}
+NDOF = {POISSON_TRIA: 1, POISSON_TET: 1, ELAST_TET: 3, POISSON_TRIA_INLINE: 1, ELAST_TRIA: 2}
+NDIM = {POISSON_TRIA: 2, POISSON_TET: 3, ELAST_TET: 3, POISSON_TRIA_INLINE: 2, ELAST_TRIA: 2}
 
 
 class PfemError(RuntimeError):
@@ -56,6 +56,7 @@ SIGNATURES = {
     "pfem_poisson_tria_ke": [_P] * 7,
     "pfem_poisson_tet_ke": [_P] * 8,
     "pfem_elast_tet_ke": [_P] * 8,
+    "pfem_elast_tria_ke": [_P] * 7,
     "pfem_gen_box_tets": [_D, _D, _I, _D, _D, _I, _D, _D, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "pfem_dof_numbering": [_L, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "pfem_elem_dof_array": [_L, _I, _I, _P, _P, _P],
@@ -86,6 +87,7 @@ SIGNATURES = {
     "pfem_solver_set_spmv_format": [_P, _I],
     "pfem_solver_get_spmv_format": [_P, _P],
     "pfem_eval_elems": [_P, _P, _P, _P, _P],
+    "pfem_rhs_add_values": [_P, _L, _P, _P],
     "pfem_matrix_info": [_P, _P, _P, _P, _P],
     "pfem_get_local_to_global": [_P, _P],
     "pfem_get_csr": [_P, _P, _P, _P],

@@ -669,7 +669,7 @@ namespace {
 ElemPrm make_prm(const double *elemData, const double *timeData, int kind)
 {
     ElemPrm p{};
-    const int ned = kind == PFEM_ELAST_TET ? 6 : (kind == PFEM_POISSON_TET ? 3 : 2);
+    const int ned = kind == PFEM_ELAST_TET ? 6 : (kind == PFEM_ELAST_TRIA ? 5 : (kind == PFEM_POISSON_TET ? 3 : 2));
     for (int i = 0; i < ned; ++i) p.ed[i] = elemData ? elemData[i] : 0.0;
     p.af = timeData ? timeData[1] : 1.0;
     return p;
@@ -705,7 +705,7 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
         const uint32_t *is = s->d_inc_slots.p;
         // rows of the 1-dof kinds are accumulated in LDS when maxlen*256 doubles fit 64 KiB
         const size_t lds = static_cast<size_t>(s->max_row_len) * kBlock * sizeof(double);
-        const bool use_lds = m.kind != PFEM_ELAST_TET && s->max_row_len > 0 && lds <= 65536;
+        const bool use_lds = m.ndof == 1 && s->max_row_len > 0 && lds <= 65536;
 #define PFEM_GATHER(KIND)                                                                                             \
     if (use_lds) hipLaunchKernelGGL((k_gather_scalar<KIND, true>), grid, block, lds, s->stream, m, A, s->d_rhs.p, prm, ip, ie, is, s->d_err.p); \
     else hipLaunchKernelGGL((k_gather_scalar<KIND, false>), grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ie, is, s->d_err.p)
@@ -715,6 +715,9 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
         case PFEM_POISSON_TRIA_INLINE: PFEM_GATHER(PFEM_POISSON_TRIA_INLINE); break;
         case PFEM_ELAST_TET:
             hipLaunchKernelGGL(k_gather_elast, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ie, is, s->d_err.p);
+            break;
+        case PFEM_ELAST_TRIA:
+            hipLaunchKernelGGL(k_gather_elast2d, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ie, is, s->d_err.p);
             break;
         }
 #undef PFEM_GATHER
@@ -736,6 +739,9 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
         case PFEM_ELAST_TET:
             hipLaunchKernelGGL(k_assemble_elast, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, s->d_err.p);
             break;
+        case PFEM_ELAST_TRIA:
+            hipLaunchKernelGGL(k_assemble_elast2d, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, s->d_err.p);
+            break;
         }
         PFEM_TRY(check_kernel("k_assemble"));
     }
@@ -747,6 +753,37 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
     if (err) return err;
     s->host_values_dirty = false;
     s->status = PFEM_ASSEMBLY_OK;
+    return PFEM_OK;
+}
+
+// Specified nodal forces: VecSetValue(rhsVec, row, fact, ADD_VALUES) after the element loop
+// (tetraelasticityparallelimpl1.F:971-982).  Global dof ids; entries this rank does not own are
+// skipped, like the reference's row_start/row_end test; negative ids ignored.
+extern "C" int pfem_rhs_add_values(pfem_solver *s, int64_t n, const int64_t *gdof, const double *v)
+{
+    if (!s || n < 0 || (n && (!gdof || !v))) return PFEM_ERR_ARG;
+    if (!s->have_pattern) return PFEM_ERR_STATE;
+    PFEM_TRY(use_device(s));
+    std::vector<int32_t> idx;
+    std::vector<double> val;
+    for (int64_t i = 0; i < n; ++i) {
+        if (gdof[i] < 0) continue;
+        if (gdof[i] >= s->size_global) return PFEM_ERR_ARG;
+        if (gdof[i] < s->row_start || gdof[i] >= s->row_start + s->n_owned) continue;
+        idx.push_back(static_cast<int32_t>(gdof[i] - s->row_start));
+        val.push_back(v[i]);
+    }
+    if (idx.empty()) return PFEM_OK;
+    DevBuf<int32_t> di;
+    DevBuf<double> dv;
+    PFEM_TRY(di.alloc(idx.size()));
+    PFEM_TRY(dv.alloc(val.size()));
+    PFEM_HIP(hipMemcpyAsync(di.p, idx.data(), sizeof(int32_t) * idx.size(), hipMemcpyHostToDevice, s->stream));
+    PFEM_HIP(hipMemcpyAsync(dv.p, val.data(), sizeof(double) * val.size(), hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_add_values, dim3(grid_for(static_cast<int64_t>(idx.size()))), dim3(kBlock), 0, s->stream, s->d_rhs.p,
+                       static_cast<const int32_t *>(di.p), static_cast<const double *>(dv.p), static_cast<int64_t>(idx.size()));
+    PFEM_TRY(check_kernel("k_add_values"));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
     return PFEM_OK;
 }
 

@@ -187,6 +187,102 @@ PFEM_HD bool poisson_tria_inline(const double x[3], const double y[3], double K[
 }
 
 // ---------------------------------------------------------------------------
+// Plane-stress elasticity on a P1 triangle [elementutilitieselasticity2D.F:23-153], the 2-D sibling
+// (SURVEY 8f.1).  D = b1*[[1,nu,0],[nu,1,0],[0,0,(1-nu)]] with b1 = E/(1-nu^2) -- the reference's
+// D(3,3) = b1*(1-nu), i.e. 2G with engineering shear, is reproduced as is.
+// B (3x6) has columns (gx,0,gy) / (0,gy,gx); with the structural zeros dropped the reference's two
+// MATMULs collapse, in the same summation order, to two products per entry:
+//   K(2a+0,2b+0) = dvol*(ax*(D11 bx) + ay*(D33 by))   K(2a+0,2b+1) = dvol*(ax*(D12 by) + ay*(D33 bx))
+//   K(2a+1,2b+0) = dvol*(ay*(D21 bx) + ax*(D33 by))   K(2a+1,2b+1) = dvol*(ay*(D22 by) + ax*(D33 bx))
+// ---------------------------------------------------------------------------
+struct TriaGeom {
+    double gx[3], gy[3], jac;
+};
+
+PFEM_HD void tria_geometry(const double x[3], const double y[3], TriaGeom &g)
+{
+    const double u1[3] = {-1.0, 1.0, 0.0};
+    const double u2[3] = {-1.0, 0.0, 1.0};
+    double b11 = 0.0, b21 = 0.0, b12 = 0.0, b22 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {                            // elementutilitiesbasisfuncs.F:207-215
+        b11 = b11 + (x[a] * u1[a]);
+        b21 = b21 + (x[a] * u2[a]);
+        b12 = b12 + (y[a] * u1[a]);
+        b22 = b22 + (y[a] * u2[a]);
+    }
+    g.jac = b11 * b22 - b12 * b21;
+    const double di = 1.0 / g.jac;
+    const double i11 = b22 * di, i12 = -b12 * di, i21 = -b21 * di, i22 = b11 * di;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        g.gx[a] = u1[a] * i11 + u2[a] * i12;
+        g.gy[a] = u1[a] * i21 + u2[a] * i22;
+    }
+}
+
+struct Elast2dMat {
+    double d11, d12, d33;
+};
+
+PFEM_HD Elast2dMat elast2d_material(double E, double nu)
+{
+    const double b1 = E / (1.0 - nu * nu);                   // [:60]
+    Elast2dMat m;
+    m.d11 = b1;
+    m.d12 = b1 * nu;
+    m.d33 = b1 * (1.0 - nu);
+    return m;
+}
+
+// 2x2 block K(2a+p, 2b+q) from grad N_a = (ax,ay), grad N_b = (bx,by)
+PFEM_HD void elast2d_block_v(double ax, double ay, double bx, double by, const Elast2dMat &m, double dvol,
+                             double blk[2][2])
+{
+    blk[0][0] = dvol * (ax * (m.d11 * bx) + ay * (m.d33 * by));
+    blk[0][1] = dvol * (ax * (m.d12 * by) + ay * (m.d33 * bx));
+    blk[1][0] = dvol * (ay * (m.d12 * bx) + ax * (m.d33 * by));
+    blk[1][1] = dvol * (ay * (m.d11 * by) + ax * (m.d33 * bx));
+}
+
+// shape functions at the Gauss point (1/3,1/3) given as REAL(4) literals [:73]: N = (xi3, xi1, xi2)
+PFEM_HD void tria_shape_gp(double N[3])
+{
+    const double xi1 = kGaussPtTria, xi2 = kGaussPtTria;
+    N[0] = 1.0 - xi1 - xi2;
+    N[1] = xi1;
+    N[2] = xi2;
+}
+
+// Full 6x6 (column-major) + load vector; elemData = (E, nu, thick, bx, by)
+PFEM_HD bool elast_tria(const double x[3], const double y[3], double E, double nu, double thick,
+                        const double bforce[2], double K[36], double F[6])
+{
+    TriaGeom g;
+    tria_geometry(x, y, g);
+    if (g.jac < 0.0) return false;                           // [:88]
+    const double dvol = 0.5 * (g.jac * thick);               // [:92]
+    const Elast2dMat m = elast2d_material(E, nu);
+    double blk[2][2], N[3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            elast2d_block_v(g.gx[a], g.gy[a], g.gx[b], g.gy[b], m, dvol, blk);
+            K[(2 * a) + 6 * (2 * b)] = blk[0][0];
+            K[(2 * a) + 6 * (2 * b + 1)] = blk[0][1];
+            K[(2 * a + 1) + 6 * (2 * b)] = blk[1][0];
+            K[(2 * a + 1) + 6 * (2 * b + 1)] = blk[1][1];
+        }
+    tria_shape_gp(N);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {                            // [:140-148]
+        const double b4 = dvol * N[a];
+        F[2 * a] = 0.0 + b4 * bforce[0];
+        F[2 * a + 1] = 0.0 + b4 * bforce[1];
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------
 // Linear elasticity on a P1 tet [elementutilitieselasticity3D.F:248-393], intended
 // semantics (one Gauss point, Ke = dvol * B^T (D B); DESIGN.md "deviations").
 //

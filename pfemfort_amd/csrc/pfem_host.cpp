@@ -46,6 +46,15 @@ extern "C" int pfem_elast_tet_ke(const double xNode[4], const double yNode[4],
                                                                             : PFEM_ERR_NEG_JAC;
 }
 
+extern "C" int pfem_elast_tria_ke(const double xNode[3], const double yNode[3], const double *elemData,
+                                  const double *timeData, const double valC[6], double K[36], double F[6])
+{
+    (void)timeData; (void)valC;  // strain/stress from valC never reach Ke/Fe (elementutilitieselasticity2D.F:96-117)
+    if (!xNode || !yNode || !elemData || !K || !F) return PFEM_ERR_ARG;
+    const double bf[2] = {elemData[3], elemData[4]};
+    return elast_tria(xNode, yNode, elemData[0], elemData[1], elemData[2], bf, K, F) ? PFEM_OK : PFEM_ERR_NEG_JAC;
+}
+
 // ---------------------------------------------------------------------------
 // 2. structured box mesh (genTetra.cpp)
 // ---------------------------------------------------------------------------

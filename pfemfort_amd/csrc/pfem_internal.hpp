@@ -12,9 +12,9 @@ namespace pfem {
 
 // per-kind geometry of the element families on the hot path
 inline int kind_npelem(int kind) { return (kind == PFEM_POISSON_TET || kind == PFEM_ELAST_TET) ? 4 : 3; }
-inline int kind_ndof(int kind) { return kind == PFEM_ELAST_TET ? 3 : 1; }
+inline int kind_ndof(int kind) { return kind == PFEM_ELAST_TET ? 3 : (kind == PFEM_ELAST_TRIA ? 2 : 1); }
 inline int kind_ndim(int kind) { return (kind == PFEM_POISSON_TET || kind == PFEM_ELAST_TET) ? 3 : 2; }
-inline bool kind_valid(int kind) { return kind >= PFEM_POISSON_TRIA && kind <= PFEM_POISSON_TRIA_INLINE; }
+inline bool kind_valid(int kind) { return kind >= PFEM_POISSON_TRIA && kind <= PFEM_ELAST_TRIA; }
 
 void set_last_error(const std::string &msg);
 

@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(kBlock) k_check_jacobian(MeshDev m, int *err)
         TetGeom g;
         tet_geometry(x, y, z, g);
         neg = g.jac < 0.0;
-    } else if (m.kind == PFEM_POISSON_TRIA) {
+    } else if (m.kind == PFEM_POISSON_TRIA || m.kind == PFEM_ELAST_TRIA) {
         // computeBasisFunctions2D: Jac = B11*B22 - B12*B21 with the accumulated differences
         const double b11 = ((0.0 + x[0] * -1.0) + x[1]) + x[2] * 0.0, b21 = ((0.0 + x[0] * -1.0) + x[1] * 0.0) + x[2];
         const double b12 = ((0.0 + y[0] * -1.0) + y[1]) + y[2] * 0.0, b22 = ((0.0 + y[0] * -1.0) + y[1] * 0.0) + y[2];
@@ -626,6 +626,155 @@ __global__ void __launch_bounds__(kBlock) k_gather_elast(MeshDev m, SellDev A, d
         if (row[p] >= 0) rhs[row[p]] = facc[p];
 }
 
+// ---------------------------------------------------------------------------
+// plane-stress elasticity on P1 triangles (2 dofs per node, next row 8f.1): same two
+// formulations as the tetrahedron kernels, 2x2 node blocks from elast2d_block_v
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_assemble_elast2d(MeshDev m, SellDev A, double *rhs, ElemPrm prm, int *err)
+{
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (e >= m.nElem) return;
+    int nd[3], dof[6];
+    double x[3], y[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) nd[a] = m.conn[a * m.nElem + e];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dof[i] = m.edof[i * m.nElem + e];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { x[a] = m.xyz[nd[a]]; y[a] = m.xyz[m.nNode + nd[a]]; }
+    TriaGeom g;
+    tria_geometry(x, y, g);
+    if (g.jac < 0.0) { atomicMax(err, PFEM_ERR_NEG_JAC); return; }
+    const double dvol = 0.5 * (g.jac * prm.ed[2]);
+    const Elast2dMat mat = elast2d_material(prm.ed[0], prm.ed[1]);
+    double N[3], F[6], fact[6];
+    tria_shape_gp(N);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double b4 = dvol * N[a];
+        F[2 * a] = 0.0 + b4 * prm.ed[3];
+        F[2 * a + 1] = 0.0 + b4 * prm.ed[4];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) fact[i] = dof[i] < 0 ? m.soln[2LL * nd[i / 2] + i % 2] : 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            double blk[2][2];
+            elast2d_block_v(g.gx[a], g.gy[a], g.gx[b], g.gy[b], mat, dvol, blk);   // Klocal(2a+p, 2b+q)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (dof[2 * b + q] < 0) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        if (dof[2 * a + p] >= 0) F[2 * a + p] = F[2 * a + p] - blk[p][q] * fact[2 * b + q];
+                }
+            // MatSetValues row-major read: entry (row = dof(2b+q), col = dof(2a+p)) += Klocal(2a+p,2b+q)
+            const int firstp = dof[2 * a] >= 0 ? 0 : (dof[2 * a + 1] >= 0 ? 1 : -1);
+            if (firstp < 0) continue;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int row = dof[2 * b + q];
+                if (row < 0) continue;
+                int64_t s = find_slot(A, row, dof[2 * a + firstp]);
+                if (s < 0) { atomicMax(err, PFEM_ERR_PATTERN); continue; }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    if (dof[2 * a + p] < 0) continue;
+                    add_f64(&A.vals[s], blk[p][q]);
+                    s += 64;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        if (dof[i] >= 0) add_f64(&rhs[dof[i]], F[i]);
+}
+
+__global__ void __launch_bounds__(kBlock) k_gather_elast2d(MeshDev m, SellDev A, double *rhs, ElemPrm prm,
+                                                            const int64_t *__restrict__ inc_ptr,
+                                                            const int32_t *__restrict__ inc_ea,
+                                                            const uint32_t *__restrict__ inc_slots, int *err)
+{
+    const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (n >= m.nNode) return;
+    const int64_t beg = inc_ptr[n], end = inc_ptr[n + 1];
+    if (beg == end) return;
+    const int ea0 = inc_ea[beg];
+    int row[2];
+    int64_t base[2];
+    bool any = false;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        row[p] = m.edof[static_cast<int64_t>(2 * (ea0 & 3) + p) * m.nElem + (ea0 >> 2)];
+        base[p] = 0;
+        if (row[p] >= 0) { any = true; base[p] = A.slice_off[row[p] >> 6] + (row[p] & 63); }
+    }
+    if (!any) return;
+    const Elast2dMat mat = elast2d_material(prm.ed[0], prm.ed[1]);
+    double N[3];
+    tria_shape_gp(N);
+    double facc[2] = {0.0, 0.0};
+    for (int64_t t = beg; t < end; ++t) {
+        const int ea = inc_ea[t];
+        const uint32_t slots = inc_slots[t];
+        const int64_t e = ea >> 2;
+        const int a = ea & 3;
+        int nd[3], dof[6];
+        double x[3], y[3];
+        {
+            const int4 *rp = reinterpret_cast<const int4 *>(m.elemrec + e * 16);
+            const int4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+            nd[0] = r0.x; nd[1] = r0.y; nd[2] = r0.z;
+            dof[0] = r1.x; dof[1] = r1.y; dof[2] = r1.z; dof[3] = r1.w; dof[4] = r2.x; dof[5] = r2.y;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { x[i] = m.xyz[nd[i]]; y[i] = m.xyz[m.nNode + nd[i]]; }
+        TriaGeom g;
+        tria_geometry(x, y, g);
+        if (g.jac < 0.0) { atomicMax(err, PFEM_ERR_NEG_JAC); return; }
+        const double dvol = 0.5 * (g.jac * prm.ed[2]);
+        double ax = 0.0, ay = 0.0, na = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i == a) { ax = g.gx[i]; ay = g.gy[i]; na = N[i]; }
+        const double b4 = dvol * na;
+        double f[2] = {0.0 + b4 * prm.ed[3], 0.0 + b4 * prm.ed[4]};
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            double kab[2][2], kba[2][2];
+            elast2d_block_v(ax, ay, g.gx[b], g.gy[b], mat, dvol, kab);   // Klocal(2a+p, 2b+q)
+            elast2d_block_v(g.gx[b], g.gy[b], ax, ay, mat, dvol, kba);   // Klocal(2b+q, 2a+p) = kba[q][p]
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (dof[2 * b + q] < 0) {
+                    const double u = m.soln[2LL * nd[b] + q];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) f[p] = f[p] - kab[p][q] * u;
+                }
+            if (dof[2 * b] < 0 && dof[2 * b + 1] < 0) continue;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                if (row[p] < 0) continue;
+                int64_t s = base[p] + (static_cast<int64_t>((slots >> (8 * b)) & 0xffu) << 6);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (dof[2 * b + q] < 0) continue;
+                    A.vals[s] += kba[q][p];
+                    s += 64;
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) facc[p] += f[p];
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+        if (row[p] >= 0) rhs[row[p]] = facc[p];
+}
+
 // Parity inspection: Ke/Fe of every element exactly as the assembly kernels compute them.
 __global__ void __launch_bounds__(kBlock) k_eval_elems(MeshDev m, ElemPrm prm, double *Kout, double *Fout, int *err)
 {
@@ -648,6 +797,11 @@ __global__ void __launch_bounds__(kBlock) k_eval_elems(MeshDev m, ElemPrm prm, d
     case PFEM_ELAST_TET: {
         const double bf[3] = {prm.ed[3], prm.ed[4], prm.ed[5]};
         ok = elast_tet(x, y, z, prm.ed[0], prm.ed[1], bf, K, F);
+        break;
+    }
+    case PFEM_ELAST_TRIA: {
+        const double bf[2] = {prm.ed[3], prm.ed[4]};
+        ok = elast_tria(x, y, prm.ed[0], prm.ed[1], prm.ed[2], bf, K, F);
         break;
     }
     }
@@ -686,6 +840,13 @@ __global__ void __launch_bounds__(kBlock) k_extract_diag(SellDev A, double *diag
     if (r >= A.n_rows) return;
     const int64_t s = find_slot(A, static_cast<int>(r), static_cast<int>(r));
     diag[r] = s >= 0 ? A.vals[s] : 0.0;
+}
+
+// rhs[idx[i]] += v[i]  (nodal forces; indices are distinct dofs)
+__global__ void __launch_bounds__(kBlock) k_add_values(double *rhs, const int32_t *idx, const double *v, int64_t n)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n) add_f64(&rhs[idx[i]], v[i]);
 }
 
 __global__ void __launch_bounds__(kBlock) k_invert(double *d, int64_t n)

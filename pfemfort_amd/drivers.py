@@ -120,6 +120,8 @@ def _run(kind, mesh, elemData, timeData, mode, rtol, maxits, verbose):
                 K, F = H.StiffnessResidualElasticityLinearTetra(xN, yN, xyz_new[2, nd], elemData, timeData, valC)
             elif kind == L.POISSON_TRIA:
                 K, F = H.StiffnessResidualPoissonLinearTria(xN, yN, elemData, timeData, valC)
+            elif kind == L.ELAST_TRIA:
+                K, F = H.StiffnessResidualElasticityLinearTria(xN, yN, elemData, timeData, valC)
             else:
                 raise ValueError("compat mode needs a module element routine")
             f = edof[:, e]
@@ -134,6 +136,13 @@ def _run(kind, mesh, elemData, timeData, mode, rtol, maxits, verbose):
         timers["assembly_s"] = time.perf_counter() - t0
     else:
         raise ValueError(mode)
+    if mesh.force_node is not None and ndof > 1:                         # nodal forces :971-982, with the intended
+        gdof = dm.NodeDofArrayNew[dm.node_map_get_new[mesh.force_node], mesh.force_dof]   # row = NodeDofArrayNew(n,d)-1
+        if mode == "batched":
+            solver.addNodalForces(gdof, mesh.force_val)
+        else:
+            for g, v in zip(gdof, mesh.force_val):
+                solver.VecSetValues([g], [v], ADD_VALUES)
     t0 = time.perf_counter()                                             # :898
     its, reason, rnorm = solver.factoriseAndSolve()                      # :900
     timers["solve_s"] = time.perf_counter() - t0                         # :902
@@ -163,3 +172,20 @@ def triapoissonserialimpl1(mesh: H.Mesh | str, rtol=1e-5, maxits=10000, verbose=
     if isinstance(mesh, str):
         mesh = H.read_mesh(mesh)
     return _run(L.POISSON_TRIA_INLINE, mesh, None, H.TIMEDATA, "batched", rtol, maxits, verbose)
+
+
+def triapoissonparallelimpl1(mesh: H.Mesh | str, mode="batched", rtol=1e-5, maxits=10000, verbose=False) -> Result:
+    """PROGRAM of triapoissonparallelimpl1.F on one rank: the module routine
+    StiffnessResidualPoissonLinearTria (:862), kx = ky = 1, no source (next row 8f.1)."""
+    if isinstance(mesh, str):
+        mesh = H.read_mesh(mesh)
+    return _run(L.POISSON_TRIA, mesh, np.array([1.0, 1.0]), H.TIMEDATA, mode, rtol, maxits, verbose)
+
+
+def triaelasticityparallelimpl1(mesh: H.Mesh | str, mode="batched", rtol=1e-5, maxits=10000, verbose=False) -> Result:
+    """PROGRAM of triaelasticityparallelimpl1.F on one rank with its intended semantics (the committed
+    driver USEs a module that does not exist and reads thick/bforce uninitialised: SURVEY A.3#7, 8f.1):
+    plane stress, E = 240.565, nu = 0.3 (REAL(4) literals), unit thickness, nodal forces from ForceBC."""
+    if isinstance(mesh, str):
+        mesh = H.read_mesh(mesh)
+    return _run(L.ELAST_TRIA, mesh, H.ELAST2D_ELEMDATA, H.TIMEDATA, mode, rtol, maxits, verbose)

@@ -36,3 +36,19 @@ contains
     end if
   end subroutine
 end module ElementUtilitiesElasticity3D
+
+! 2-D sibling (SURVEY 8f.1): MODULE ElementUtilitiesElasticity2D, the one routine on the implicit path
+module ElementUtilitiesElasticity2D
+  use pfem_amd_c
+  implicit none
+contains
+  subroutine StiffnessResidualElasticityLinearTria(xNode, yNode, elemData, timeData, valC, valDotC, Klocal, Flocal)
+    double precision, dimension(3) :: xNode, yNode
+    double precision, dimension(:) :: elemData, timeData, valC, valDotC
+    double precision, dimension(6,6) :: Klocal
+    double precision, dimension(6) :: Flocal
+    if (pfem_elast_tria_ke(xNode, yNode, elemData, timeData, valC, Klocal, Flocal) /= 0) then
+      stop " Negative Jacobian for the Tria element in Elasticity"
+    end if
+  end subroutine
+end module ElementUtilitiesElasticity2D

@@ -18,6 +18,10 @@ module pfem_amd_c
       import
       real(c_double) :: x(4), y(4), z(4), ed(*), td(*), vc(12), K(12,12), F(12)
     end function
+    integer(c_int) function pfem_elast_tria_ke(x, y, ed, td, vc, K, F) bind(C, name="pfem_elast_tria_ke")
+      import
+      real(c_double) :: x(3), y(3), ed(*), td(*), vc(6), K(6,6), F(6)
+    end function
     integer(c_int) function pfem_solver_create(s, size_local, size_global, row_start, diag_nnz, offdiag_nnz, device) &
         bind(C, name="pfem_solver_create")
       import

@@ -40,6 +40,9 @@ def _f32(v):
 POISSON_ELEMDATA = np.array([1.0, 1.0, 1.0])
 ELAST_ELEMDATA = np.array([_f32(240.565), _f32(0.3), 1.0, _f32(0.1), 0.0, 0.0])
 TIMEDATA = np.array([0.0, 1.0, 0.0])
+# triaelasticityparallelimpl1.F:907 sets only E and nu; thick / bforce are read uninitialised there
+# (SURVEY 8f.1): the intended unit thickness and zero body force are used
+ELAST2D_ELEMDATA = np.array([_f32(240.565), _f32(0.3), 1.0, 0.0, 0.0])
 
 
 @dataclass
@@ -50,6 +53,9 @@ class Mesh:
     bc_dof: np.ndarray     # (nDBC,) int32 0-based
     bc_val: np.ndarray     # (nDBC,)
     box: tuple | None = None   # (nEx, nEy, nEz) for generated meshes
+    force_node: np.ndarray | None = None   # ForceBC file: node (0-based), dof (0-based), value
+    force_dof: np.ndarray | None = None
+    force_val: np.ndarray | None = None
 
     @property
     def nNode(self):
@@ -83,8 +89,14 @@ def read_mesh(prefix: str) -> Mesh:
                 return read_table(path)
         raise FileNotFoundError(f"{prefix}-{kind}.dat[.gz]")
     nodes, elems, bcs = load("nodes"), load("elems"), load("DirichBC")
-    return Mesh(np.ascontiguousarray(nodes[:, 1:].T), np.ascontiguousarray((elems[:, 1:] - 1).T.astype(np.int32)),
-                (bcs[:, 0] - 1).astype(np.int32), (bcs[:, 1] - 1).astype(np.int32), bcs[:, 2].copy())
+    m = Mesh(np.ascontiguousarray(nodes[:, 1:].T), np.ascontiguousarray((elems[:, 1:] - 1).T.astype(np.int32)),
+             (bcs[:, 0] - 1).astype(np.int32), (bcs[:, 1] - 1).astype(np.int32), bcs[:, 2].copy())
+    try:                                    # optional 4th file (tetraelasticityparallelimpl1.F:207-214)
+        fb = load("ForceBC")
+        m.force_node, m.force_dof, m.force_val = (fb[:, 0] - 1).astype(np.int32), (fb[:, 1] - 1).astype(np.int32), fb[:, 2].copy()
+    except FileNotFoundError:
+        pass
+    return m
 
 
 def gen_box_tets(x0, x1, nEx, y0, y1, nEy, z0, z1, nEz, bc_mode=0, ndof=1, kz=None, nodes=True) -> Mesh:
@@ -178,6 +190,14 @@ def StiffnessResidualElasticityLinearTetra(xNode, yNode, zNode, elemData, timeDa
     L.check(L.lib().pfem_elast_tet_ke(_p(_f64(xNode)), _p(_f64(yNode)), _p(_f64(zNode)), _p(_f64(elemData)),
                                       _p(_f64(timeData)), _p(_f64(valC)), _p(K), _p(F)),
             "StiffnessResidualElasticityLinearTetra")
+    return K, F
+
+
+def StiffnessResidualElasticityLinearTria(xNode, yNode, elemData, timeData, valC, valDotC=None):
+    """elementutilitieselasticity2D.F:23; returns (Klocal[6,6], Flocal[6])."""
+    K = np.empty((6, 6), order="F"); F = np.empty(6)
+    L.check(L.lib().pfem_elast_tria_ke(_p(_f64(xNode)), _p(_f64(yNode)), _p(_f64(elemData)), _p(_f64(timeData)),
+                                       _p(_f64(valC)), _p(K), _p(F)), "StiffnessResidualElasticityLinearTria")
     return K, F
 
 

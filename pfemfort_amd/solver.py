@@ -172,6 +172,11 @@ class PetscSolver:
         ed = None if elemData is None else _f64(elemData)
         L.check(L.lib().pfem_assemble(self._h, _p(ed), _p(_f64(timeData))), "pfem_assemble")
 
+    def addNodalForces(self, global_dof, values):
+        """VecSetValue(rhsVec, row, fact, ADD_VALUES) loop of the elasticity drivers (:971-982)."""
+        g = np.ascontiguousarray(global_dof, dtype=np.int64); v = _f64(values)
+        L.check(L.lib().pfem_rhs_add_values(self._h, len(g), _p(g), _p(v)), "pfem_rhs_add_values")
+
     def evalElems(self, elemData, timeData):
         ns = L.NPELEM[self.kind] * L.NDOF[self.kind]
         K = np.empty((self.nElem, ns, ns)); F = np.empty((self.nElem, ns))

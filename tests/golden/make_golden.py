@@ -62,6 +62,10 @@ def main():
     xy, c3 = random_trias(300, 7)
     K, F = O.ref_eval_elems(O.POISSON_TRIA, xy, c3, np.array([2.5, 0.4]))
     out.update(rtri_xy=xy, rtri_conn=c3, rtri_data=np.array([2.5, 0.4]), rtri_K=K, rtri_F=F)
+    cook = O.read_mesh(os.path.join(g, "input", "cookmembranetria32"))
+    e2d = np.array([O.F32(240.565), O.F32(0.3), 0.7, 0.3, -1.1])
+    K, F = O.ref_eval_elems(O.ELAST_TRIA, cook.xyz, cook.conn, e2d)
+    out.update(cook_elast_data=e2d, cook_elast_K=K, cook_elast_F=F)
     # output step: the reference's own writervtk.F on fixed inputs -> golden VTK text (gzip)
     import ctypes as C
     import gzip

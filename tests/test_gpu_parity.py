@@ -203,3 +203,81 @@ def test_status_machine(tet10):
         s.factorise()                                       # "Assemble matrix first..." solverpetsc.F:415
     with pytest.raises(pf.PfemError):
         s.solve()
+
+
+def test_assemble_matrix_and_vector_methods(tet10):
+    """PetscSolver%assembleMatrixAndVector / assembleMatrix / assembleVector (solverpetsc.F:328-401):
+    per-entry MatSetValue(R(ii), C(jj), K(ii,jj)) -- K is NOT transposed on this route."""
+    from pfemfort_amd import drivers as D
+    dm, conn, xyz, edof = D._setup(pf.POISSON_TET, tet10)
+    N = dm.size_global
+    s = pf.PetscSolver().initialise(N, N)
+    z16 = np.zeros(16)
+    for e in range(tet10.nElem):
+        s.MatSetValues(edof[:, e], edof[:, e], z16, pf.solver.INSERT_VALUES)
+    s.setZero()
+    rng = np.random.default_rng(3)
+    A = np.zeros((N, N)); b = np.zeros(N)
+    for e in range(0, tet10.nElem, 7):                       # any values: this checks the plumbing
+        K = rng.standard_normal((4, 4)); F = rng.standard_normal(4)
+        f = edof[:, e]
+        if e % 14 == 0:
+            s.assembleMatrixAndVector(f, f, K, F)
+        else:
+            s.assembleMatrix(f, f, K)
+            s.assembleVector(f, F)
+        ok = f >= 0
+        A[np.ix_(f[ok], f[ok])] += K[np.ix_(ok, ok)]
+        b[f[ok]] += F[ok]
+    s.setTolerances(maxits=0)
+    s.factoriseAndSolve()                                    # pushes the staged values to the device
+    rowptr, cols, vals = s.getCSR()
+    dense = np.zeros((N, N))
+    for r in range(N):
+        dense[r, cols[rowptr[r]:rowptr[r + 1]]] = vals[rowptr[r]:rowptr[r + 1]]
+    assert np.allclose(dense, A, rtol=0, atol=1e-14) and np.allclose(s.getRHS(), b, rtol=0, atol=1e-14)
+
+
+@pytest.fixture(scope="module")
+def cook(golden_dir):
+    return H.read_mesh(f"{golden_dir}/input/cookmembranetria32")
+
+
+@pytest.mark.parametrize("mode", ["gather", "scatter"])
+def test_elast_tria_cook_membrane(cook, mode):
+    """2-D sibling behind the same boundary: plane-stress triangles, nodal forces."""
+    from pfemfort_amd import drivers as D
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    ed = np.array([H.ELAST2D_ELEMDATA[0], H.ELAST2D_ELEMDATA[1], 0.7, 0.3, -1.1])
+    dm, conn_new, xyz_new, edof = D._setup(pf.ELAST_TRIA, cook)
+    s = pf.PetscSolver().initialise(dm.size_global, dm.size_global)
+    s.uploadMesh(pf.ELAST_TRIA, conn_new, xyz_new, edof, dm.solnApplied)
+    s.buildPattern()
+    s.setAssemblyMode(mode)
+    K, F = s.evalElems(ed, H.TIMEDATA)
+    Ko, Fo = O.eval_elems(O.ELAST_TRIA, cook.xyz, cook.conn, ed)
+    assert np.array_equal(K, Ko) and np.array_equal(F, Fo)          # device element matrices: bit-exact
+    s.assemble(ed, H.TIMEDATA)
+    prob = O.setup_problem(O.ELAST_TRIA, _omesh(cook), elemData=ed)
+    rowptr, cols, vals = s.getCSR()
+    assert np.array_equal(rowptr, prob.rowptr) and np.array_equal(cols, prob.cols)
+    if mode == "gather":
+        assert np.array_equal(vals, prob.vals) and np.array_equal(s.getRHS(), prob.rhs)
+    else:
+        assert np.abs(vals - prob.vals).max() <= K_RTOL * np.abs(prob.vals).max()
+    # the driver with its intended semantics: unit thickness, no body force, ForceBC nodal loads
+    res = pf.triaelasticityparallelimpl1(cook, rtol=1e-12, maxits=100000)
+    prob = O.setup_problem(O.ELAST_TRIA, _omesh(cook))
+    rhs = prob.rhs.copy()
+    rhs[prob.dm.NodeDofArrayNew[cook.force_node, cook.force_dof]] += cook.force_val
+    u = spl.spsolve(sp.csr_matrix((prob.vals, prob.cols, prob.rowptr)).tocsc(), rhs)
+    assert res.reason == 2 and np.abs(res.soln_free - u).max() <= 1e-8 * np.abs(u).max()
+    tip = res.solnVTK[np.argmax(cook.xyz[0] + cook.xyz[1])]          # corner (48, 60)
+    assert tip[1] > 0.0                                               # the membrane is sheared upwards
+
+
+def test_tria_poisson_parallel_driver(tria20):
+    a = pf.triapoissonparallelimpl1(tria20, rtol=1e-12)
+    b = pf.triapoissonserialimpl1(tria20, rtol=1e-12)                 # inline element: same problem to rounding
+    assert np.abs(a.soln_free - b.soln_free).max() < 1e-10

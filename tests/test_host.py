@@ -157,3 +157,13 @@ def test_ascii_reader_edge_cases(tmp_path):
         H.read_table(str(p))
     p.write_text("")
     assert H.read_table(str(p)).shape == (0, 0)
+
+
+def test_elast_tria_host_routine_bit_exact(gold, golden_dir):
+    cook = H.read_mesh(os.path.join(golden_dir, "input", "cookmembranetria32"))
+    assert cook.force_val.sum() == 100.0 and len(cook.force_node) == 33        # shipped ForceBC file
+    for e in range(0, 2048, 11):
+        nd = cook.conn[:, e]
+        K, F = H.StiffnessResidualElasticityLinearTria(cook.xyz[0, nd], cook.xyz[1, nd], gold["cook_elast_data"],
+                                                       H.TIMEDATA, np.zeros(6))
+        assert np.array_equal(K, gold["cook_elast_K"][e]) and np.array_equal(F, gold["cook_elast_F"][e])

@@ -42,6 +42,15 @@ def test_elements_bit_exact_vs_reference_golden(gold, tet10, tria20):
     assert np.array_equal(K, gold["rtri_K"]) and np.array_equal(F, gold["rtri_F"])
 
 
+def test_elast_tria_bit_exact_vs_reference_golden(gold, golden_dir):
+    """2-D sibling: plane-stress P1 triangle on the shipped Cook's-membrane mesh."""
+    cook = O.read_mesh(os.path.join(golden_dir, "input", "cookmembranetria32"))
+    assert (cook.nNode, cook.nElem, len(cook.bc_node)) == (1089, 2048, 66)
+    K, F = O.eval_elems(O.ELAST_TRIA, cook.xyz, cook.conn, gold["cook_elast_data"])
+    assert np.array_equal(K, gold["cook_elast_K"]) and np.array_equal(F, gold["cook_elast_F"])
+    assert np.abs(K - K.transpose(0, 2, 1)).max() < 1e-12 * np.abs(K).max()
+
+
 @pytest.mark.skipif(O.ref_lib() is None, reason="oracle/_ref not built (needs /root/reference + flang)")
 def test_elements_bit_exact_vs_live_reference(tet10):
     for kind, ed in ((O.POISSON_TET, O.POISSON_ELEMDATA), (O.ELAST_TET, O.ELAST_ELEMDATA)):
