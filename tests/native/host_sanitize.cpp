@@ -1,0 +1,87 @@
+// Host side of the C ABI under AddressSanitizer + UBSan (CPU build only: GPU sanitizers are not
+// available on this pool).  Exercises every host entry point of pfem_host.cpp on small inputs,
+// including ragged / empty / out-of-contract ones.  Built and run by tests/test_sanitize.py.
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/pfem_amd.h"
+
+int main(int argc, char **argv)
+{
+    const std::string tmp = argc > 1 ? argv[1] : "/tmp";
+    // --- structured mesh, slabs, numbering -----------------------------------------------
+    const int nEx = 5, nEy = 4, nEz = 7, ndof = 3;
+    const int64_t nNode = (nEx + 1) * (nEy + 1) * (nEz + 1), nElem = 6LL * nEx * nEy * nEz;
+    int64_t nDBC = 0;
+    assert(pfem_gen_box_tets(-1, 1, nEx, 0, 2, nEy, -1, 3, nEz, 0, nEz, 1, ndof, nullptr, nullptr, &nDBC, nullptr, nullptr, nullptr) == 0);
+    std::vector<double> xyz(3 * nNode), bv(nDBC);
+    std::vector<int32_t> conn(4 * nElem), bn(nDBC), bd(nDBC);
+    assert(pfem_gen_box_tets(-1, 1, nEx, 0, 2, nEy, -1, 3, nEz, 0, nEz, 1, ndof, xyz.data(), conn.data(), &nDBC, bn.data(), bd.data(), bv.data()) == 0);
+    std::vector<int32_t> slab(4 * 6 * nEx * nEy * 2);
+    int64_t n2 = 0;
+    assert(pfem_gen_box_tets(-1, 1, nEx, 0, 2, nEy, -1, 3, nEz, 2, 4, 0, 1, nullptr, slab.data(), &n2, nullptr, nullptr, nullptr) == 0);
+    assert(pfem_gen_box_tets(-1, 1, 0, 0, 2, nEy, -1, 3, nEz, 0, nEz, 0, 1, nullptr, nullptr, &n2, nullptr, nullptr, nullptr) == PFEM_ERR_ARG);
+    for (int parts : {1, 2, 3, 7}) {
+        std::vector<int32_t> epid(nElem), npid(nNode), old_(nNode), new_(nNode), nda(nNode * ndof), edof(12 * nElem), assy(nNode * ndof);
+        std::vector<double> sa(nNode * ndof);
+        std::vector<int64_t> ns(parts), ne(parts), rs(parts), re(parts);
+        int64_t N = 0;
+        assert(pfem_partition_box_slabs(nEx, nEy, nEz, parts, epid.data(), npid.data()) == 0);
+        assert(pfem_dof_numbering(nNode, ndof, nDBC, bn.data(), bd.data(), bv.data(), parts, npid.data(), old_.data(), new_.data(),
+                                  nda.data(), sa.data(), ns.data(), ne.data(), rs.data(), re.data(), &N) == 0);
+        assert(re[parts - 1] == N && rs[0] == 0);
+        std::vector<int32_t> cn(4 * nElem);
+        for (size_t i = 0; i < cn.size(); ++i) cn[i] = new_[conn[i]];
+        assert(pfem_elem_dof_array(nElem, 4, ndof, cn.data(), nda.data(), edof.data()) == 0);
+        assert(pfem_assy_for_soln(nNode, ndof, nda.data(), assy.data()) == 0);
+        int64_t ng = 0;
+        assert(pfem_find_ghosts(12 * nElem, edof.data(), rs[0], re[0] - rs[0], &ng, nullptr) == 0);
+        std::vector<int64_t> gh(ng + 1);
+        assert(pfem_find_ghosts(12 * nElem, edof.data(), rs[0], re[0] - rs[0], &ng, gh.data()) == 0);
+        assert((parts == 1) == (ng == 0));
+    }
+    assert(pfem_partition_box_slabs(nEx, nEy, nEz, nEz + 1, nullptr, nullptr) == PFEM_ERR_ARG);
+    {   // out-of-range Dirichlet record is rejected, not written
+        int32_t badn = static_cast<int32_t>(nNode), badd = 0; double v = 1;
+        std::vector<int32_t> o(nNode), w(nNode), nda(nNode); std::vector<double> sa(nNode); int64_t a, b, c, d, N;
+        assert(pfem_dof_numbering(nNode, 1, 1, &badn, &badd, &v, 1, nullptr, o.data(), w.data(), nda.data(), sa.data(), &a, &b, &c, &d, &N) == PFEM_ERR_ARG);
+    }
+    // --- per-element routines ---------------------------------------------------------------
+    std::mt19937 rng(7);
+    std::normal_distribution<double> nd(0, 1);
+    for (int rep = 0; rep < 200; ++rep) {
+        double x[4], y[4], z[4], K[144], F[12], vc[12] = {0}, ed[6] = {240.5, 0.3, 1.0, 0.1, 0.2, 0.3}, td[3] = {0, 1, 0};
+        for (int i = 0; i < 4; ++i) { x[i] = nd(rng); y[i] = nd(rng); z[i] = nd(rng); }
+        int a = pfem_poisson_tet_ke(x, y, z, ed, td, vc, K, F), b = pfem_elast_tet_ke(x, y, z, ed, td, vc, K, F);
+        assert((a == 0 || a == PFEM_ERR_NEG_JAC) && a == b);
+        int c = pfem_poisson_tria_ke(x, y, ed, td, vc, K, F), d = pfem_elast_tria_ke(x, y, ed, td, vc, K, F);
+        assert((c == 0 || c == PFEM_ERR_NEG_JAC) && c == d);
+    }
+    assert(pfem_poisson_tet_ke(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == PFEM_ERR_ARG);
+    // --- ASCII ingest: ragged / empty / unterminated / huge tokens ------------------------------
+    for (const char *txt : {"", "\n\n", "1 2 3", "1 2 3\n4 5 6\n", " 1\t2  3 \r\n4 5 6 7 8\n", "1 2 3\n4 5\n", "x y z\n",
+                            "1 2 9999999999999999999999999999999999999999999999999999999999999999999999999999\n"}) {
+        int64_t rows = -1; int cols = -1;
+        int rc = pfem_text_table_shape(txt, static_cast<int64_t>(std::strlen(txt)), &rows, &cols);
+        if (rc == 0 && rows > 0) {
+            std::vector<double> out(rows * cols);
+            (void)pfem_text_table_parse(txt, static_cast<int64_t>(std::strlen(txt)), rows, cols, out.data());
+        }
+    }
+    // --- VTK writer ------------------------------------------------------------------------------
+    {
+        std::vector<int32_t> pid(nElem, 1);
+        std::vector<double> sol(nNode * 3, -0.0);
+        const std::string p = tmp + "/san.vtk";
+        assert(pfem_write_vtk(p.c_str(), 3, nElem, nNode, 4, 3, xyz.data(), conn.data(), pid.data(), sol.data()) == 0);
+        assert(pfem_write_vtk("/nonexistent-dir/x.vtk", 3, nElem, nNode, 4, 1, xyz.data(), conn.data(), pid.data(), sol.data()) == PFEM_ERR_ARG);
+        std::remove(p.c_str());
+    }
+    std::puts("host_sanitize: ok");
+    return 0;
+}

@@ -281,3 +281,51 @@ def test_tria_poisson_parallel_driver(tria20):
     a = pf.triapoissonparallelimpl1(tria20, rtol=1e-12)
     b = pf.triapoissonserialimpl1(tria20, rtol=1e-12)                 # inline element: same problem to rounding
     assert np.abs(a.soln_free - b.soln_free).max() < 1e-10
+
+
+def test_edge_cases_of_the_solver_boundary(tet10):
+    """Empty / degenerate / out-of-contract inputs behave like PETSc's documented semantics."""
+    # (1) zero right-hand side: converged at iteration 0 on the absolute tolerance (KSP_CONVERGED_ATOL)
+    s = pf.PetscSolver().initialise(3, 3)
+    idx = np.arange(3, dtype=np.int32)
+    s.MatSetValues(idx, idx, np.zeros(9), pf.solver.INSERT_VALUES)
+    s.setZero()
+    s.MatSetValues(idx, idx, np.array([2.0, -1, 0, -1, 2, -1, 0, -1, 2]), pf.solver.ADD_VALUES)
+    assert s.factoriseAndSolve()[:2] == (0, 3) and np.array_equal(s.getSolution(), np.zeros(3))
+    # (2) negative indices are ignored in rows, columns and the rhs; ragged m != n blocks are fine
+    s.setZero()
+    s.MatSetValues([0, -1, 2], [1, -1], np.array([5.0, 9, 9, 9, 7, 9]), pf.solver.ADD_VALUES)
+    s.MatSetValues(idx, idx, np.diag([4.0, 4, 4]).ravel(), pf.solver.ADD_VALUES)
+    s.VecSetValues([-1, 1, 2], [100.0, 4.0, 8.0], pf.solver.ADD_VALUES)
+    s.setTolerances(rtol=1e-14)
+    its, reason, _ = s.factoriseAndSolve()
+    A = np.array([[4.0, 5, 0], [0, 4, 0], [0, 7, 4]])
+    assert reason in (2, -7, -8) or its >= 0          # a non-symmetric toy matrix: only the plumbing is asserted
+    rowptr, cols, vals = s.getCSR()
+    dense = np.zeros((3, 3))
+    for r in range(3):
+        dense[r, cols[rowptr[r]:rowptr[r + 1]]] = vals[rowptr[r]:rowptr[r + 1]]
+    assert np.array_equal(dense, A) and np.array_equal(s.getRHS(), [0.0, 4.0, 8.0])
+    # (3) ADD_VALUES outside the inserted pattern is an error (MAT_NEW_NONZERO_LOCATIONS stays off after setZero)
+    t = pf.PetscSolver().initialise(3, 3)
+    t.MatSetValues([0], [0], np.zeros(1), pf.solver.INSERT_VALUES)
+    t.setZero()
+    with pytest.raises(pf.PfemError) as ei:
+        t.MatSetValues([0], [2], np.ones(1), pf.solver.ADD_VALUES)
+    assert ei.value.code == 8
+    # (4) iteration limit: KSP_DIVERGED_ITS, solution is the last iterate
+    r = pf.tetrapoissonparallelimpl1(tet10, rtol=1e-14, maxits=5)
+    assert (r.its, r.reason) == (5, -3)
+    # (5) a single free dof (everything else Dirichlet)
+    free = 665                                                        # an interior node of tet10
+    keep = np.ones(tet10.nNode, bool); keep[free] = False
+    exact = (tet10.xyz ** 2).sum(0)
+    m1 = H.Mesh(tet10.xyz, tet10.conn, np.nonzero(keep)[0].astype(np.int32), np.zeros(keep.sum(), np.int32), exact[keep])
+    r1 = pf.tetrapoissonparallelimpl1(m1, rtol=1e-12)
+    assert r1.dm.size_global == 1 and r1.reason > 0 and abs(r1.soln_free[0] - exact[free]) < 1e-10
+    # (6) mesh with zero elements on this rank is legal (an idle rank): pattern of 0 entries
+    z = pf.PetscSolver().initialise(0, 0)
+    z.uploadMesh(pf.POISSON_TET, np.empty((4, 0), np.int32), tet10.xyz, np.empty((4, 0), np.int32), np.zeros(tet10.nNode))
+    z.buildPattern()
+    z.assemble(H.POISSON_ELEMDATA, H.TIMEDATA)
+    assert z.matrixInfo()["nnz"] == 0 and z.factoriseAndSolve()[1] == 3
