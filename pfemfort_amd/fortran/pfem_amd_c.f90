@@ -96,6 +96,15 @@ module pfem_amd_c
       type(c_ptr), value :: s
       real(c_double) :: x(*)
     end function
+    integer(c_int) function pfem_write_vtk(path, ndim, nElem, nNode, npElem, ndof, coords, conn, procid, soln) &
+        bind(C, name="pfem_write_vtk")
+      import
+      character(kind=c_char) :: path(*)
+      integer(c_int), value :: ndim, npElem, ndof
+      integer(c_int64_t), value :: nElem, nNode
+      real(c_double) :: coords(*), soln(*)
+      integer(c_int) :: conn(*), procid(*)
+    end function
     function pfem_last_error_string() bind(C, name="pfem_last_error_string") result(p)
       import
       type(c_ptr) :: p
