@@ -168,8 +168,9 @@ struct pfem_solver {
     int assembly_mode = PFEM_ASSEMBLY_GATHER;
     bool have_incidence = false;
     int geom_err = 0;              // PFEM_ERR_NEG_JAC if any element is inverted (gather form)
-    DevBuf<int64_t> d_inc_ptr;     // [nNode+1] incidence list of every node ...
-    DevBuf<int32_t> d_inc_ea;      // ... entries 4*e + a, ascending element id
+    DevBuf<int64_t> d_inc_ptr;     // [nNode/64+1] offsets of the wave-sliced incidence lists (64 nodes per chunk) ...
+    DevBuf<int32_t> d_inc_cnt;     // ... list length of every node ...
+    DevBuf<int32_t> d_inc_ea;      // ... entries 4*e + a, ascending element id, entry j of node n at ptr[n/64]+64j+n%64
     DevBuf<uint32_t> d_inc_slots;  // ... and the matrix entry index of each element node inside the node's rows
     int64_t nnz = 0, n_slices = 0, stored = 0;
     int max_row_len = 0;
@@ -578,19 +579,43 @@ int build_incidence(pfem_solver *s)
     PFEM_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, keys.p, sorted.p, ni, 0, 32 + bits, s->stream));
     PFEM_TRY(temp.alloc(tb));
     PFEM_HIP(hipcub::DeviceRadixSort::SortKeys(temp.p, tb, keys.p, sorted.p, ni, 0, 32 + bits, s->stream));
-    PFEM_TRY(s->d_inc_ptr.alloc(static_cast<size_t>(m.nNode) + 1));
-    PFEM_TRY(s->d_inc_ea.alloc(static_cast<size_t>(nk)));
+    DevBuf<int64_t> node_ptr;     // node-contiguous bounds of the sorted keys
+    PFEM_TRY(node_ptr.alloc(static_cast<size_t>(m.nNode) + 1));
     hipLaunchKernelGGL(k_row_bounds, dim3(grid_for(std::max<int64_t>(nk, m.nNode + 1))), dim3(kBlock), 0, s->stream,
-                       sorted.p, nk, m.nNode, s->d_inc_ptr.p);
-    hipLaunchKernelGGL(k_low32, dim3(grid_for(nk)), dim3(kBlock), 0, s->stream, sorted.p, nk, s->d_inc_ea.p);
+                       sorted.p, nk, m.nNode, node_ptr.p);
+    // wave-sliced lists: chunk c = nodes 64c..64c+63, entry j of lane l at inc_ptr[c] + 64 j + l, padded with -1
+    const int64_t n_chunks = (m.nNode + 63) / 64;
+    const int64_t n_pad = n_chunks * 64;
+    DevBuf<int64_t> chunk_entries;
+    PFEM_TRY(chunk_entries.alloc(static_cast<size_t>(n_chunks) + 1));
+    PFEM_TRY(s->d_inc_ptr.alloc(static_cast<size_t>(n_chunks) + 1));
+    PFEM_TRY(s->d_inc_cnt.alloc(static_cast<size_t>(n_pad)));
+    hipLaunchKernelGGL(k_inc_chunk_sizes, dim3(grid_for(n_pad)), dim3(kBlock), 0, s->stream, node_ptr.p, m.nNode, n_chunks,
+                       s->d_inc_cnt.p, chunk_entries.p);
+    PFEM_TRY(check_kernel("k_inc_chunk_sizes"));
+    {
+        size_t sb = 0;
+        const int nc1 = static_cast<int>(n_chunks + 1);
+        PFEM_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, chunk_entries.p, s->d_inc_ptr.p, nc1, s->stream));
+        DevBuf<char> stemp;
+        PFEM_TRY(stemp.alloc(sb));
+        PFEM_HIP(hipcub::DeviceScan::ExclusiveSum(stemp.p, sb, chunk_entries.p, s->d_inc_ptr.p, nc1, s->stream));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+    }
+    int64_t inc_total = 0;
+    PFEM_HIP(hipMemcpyAsync(&inc_total, s->d_inc_ptr.p + n_chunks, sizeof(int64_t), hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    PFEM_TRY(s->d_inc_ea.alloc(static_cast<size_t>(std::max<int64_t>(inc_total, 1))));
+    hipLaunchKernelGGL(k_inc_fill, dim3(grid_for(n_pad)), dim3(kBlock), 0, s->stream, sorted.p, node_ptr.p, m.nNode, n_chunks,
+                       static_cast<const int64_t *>(s->d_inc_ptr.p), s->d_inc_ea.p);
     PFEM_TRY(check_kernel("incidence"));
     PFEM_HIP(hipStreamSynchronize(s->stream));
     // slot map: entry index of every (node row, element node) pair, so the numeric kernels never search
-    PFEM_TRY(s->d_inc_slots.alloc(static_cast<size_t>(nk)));
+    PFEM_TRY(s->d_inc_slots.alloc(static_cast<size_t>(std::max<int64_t>(inc_total, 1))));
     PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
     hipLaunchKernelGGL(k_build_inc_slots, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m, s->sell(),
-                       static_cast<const int64_t *>(s->d_inc_ptr.p), static_cast<const int32_t *>(s->d_inc_ea.p),
-                       s->d_inc_slots.p, s->d_err.p);
+                       static_cast<const int64_t *>(s->d_inc_ptr.p), static_cast<const int32_t *>(s->d_inc_cnt.p),
+                       static_cast<const int32_t *>(s->d_inc_ea.p), s->d_inc_slots.p, s->d_err.p);
     PFEM_TRY(check_kernel("k_build_inc_slots"));
     int slot_err = 0;
     PFEM_TRY(fetch_err(s, &slot_err));
@@ -598,6 +623,7 @@ int build_incidence(pfem_solver *s)
     if (slot_err == 1) {          // a row with more than 255 entries: keep the scatter form
         s->d_inc_slots.release();
         s->d_inc_ptr.release();
+        s->d_inc_cnt.release();
         s->d_inc_ea.release();
         return PFEM_OK;
     }
@@ -701,23 +727,24 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
         const dim3 grid(grid_for(m.nNode)), block(kBlock);
         SellDev A = s->sell();
         const int64_t *ip = s->d_inc_ptr.p;
+        const int32_t *ic = s->d_inc_cnt.p;
         const int32_t *ie = s->d_inc_ea.p;
         const uint32_t *is = s->d_inc_slots.p;
         // rows of the 1-dof kinds are accumulated in LDS when maxlen*256 doubles fit 64 KiB
         const size_t lds = static_cast<size_t>(s->max_row_len) * kBlock * sizeof(double);
         const bool use_lds = m.ndof == 1 && s->max_row_len > 0 && lds <= 65536;
 #define PFEM_GATHER(KIND)                                                                                             \
-    if (use_lds) hipLaunchKernelGGL((k_gather_scalar<KIND, true>), grid, block, lds, s->stream, m, A, s->d_rhs.p, prm, ip, ie, is, s->d_err.p); \
-    else hipLaunchKernelGGL((k_gather_scalar<KIND, false>), grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ie, is, s->d_err.p)
+    if (use_lds) hipLaunchKernelGGL((k_gather_scalar<KIND, true>), grid, block, lds, s->stream, m, A, s->d_rhs.p, prm, ip, ic, ie, is, s->d_err.p); \
+    else hipLaunchKernelGGL((k_gather_scalar<KIND, false>), grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ic, ie, is, s->d_err.p)
         switch (m.kind) {
         case PFEM_POISSON_TET: PFEM_GATHER(PFEM_POISSON_TET); break;
         case PFEM_POISSON_TRIA: PFEM_GATHER(PFEM_POISSON_TRIA); break;
         case PFEM_POISSON_TRIA_INLINE: PFEM_GATHER(PFEM_POISSON_TRIA_INLINE); break;
         case PFEM_ELAST_TET:
-            hipLaunchKernelGGL(k_gather_elast, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ie, is, s->d_err.p);
+            hipLaunchKernelGGL(k_gather_elast, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ic, ie, is, s->d_err.p);
             break;
         case PFEM_ELAST_TRIA:
-            hipLaunchKernelGGL(k_gather_elast2d, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ie, is, s->d_err.p);
+            hipLaunchKernelGGL(k_gather_elast2d, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ic, ie, is, s->d_err.p);
             break;
         }
 #undef PFEM_GATHER

@@ -370,10 +370,36 @@ __global__ void __launch_bounds__(kBlock) k_emit_inc_keys(MeshDev m, uint64_t *k
                                 static_cast<uint32_t>(4 * e + a);
 }
 
-__global__ void __launch_bounds__(kBlock) k_low32(const uint64_t *keys, int64_t n, int32_t *out)
+// per-node incidence count and per-chunk (64 nodes = one wave) padded size in entries
+__global__ void __launch_bounds__(kBlock) k_inc_chunk_sizes(const int64_t *node_ptr, int64_t nNode, int64_t n_chunks,
+                                                             int32_t *cnt, int64_t *chunk_entries)
 {
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (i < n) out[i] = static_cast<int32_t>(keys[i] & 0xffffffffu);
+    const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    int c = 0;
+    if (n < nNode) {
+        c = static_cast<int>(node_ptr[n + 1] - node_ptr[n]);
+        cnt[n] = c;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c = max(c, __shfl_xor(c, o, 64));
+    const int64_t ch = n >> 6;
+    if ((threadIdx.x & 63) == 0 && ch < n_chunks) chunk_entries[ch] = 64LL * c;
+    if (n == 0) chunk_entries[n_chunks] = 0;
+}
+
+// node-contiguous sorted keys -> wave-sliced (4e+a) lists, -1 padded
+__global__ void __launch_bounds__(kBlock) k_inc_fill(const uint64_t *keys, const int64_t *node_ptr, int64_t nNode,
+                                                      int64_t n_chunks, const int64_t *chunk_off, int32_t *ea)
+{
+    const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t ch = n >> 6;
+    if (ch >= n_chunks) return;
+    const int64_t off = chunk_off[ch] + (n & 63);
+    const int width = static_cast<int>((chunk_off[ch + 1] - chunk_off[ch]) >> 6);
+    int64_t p0 = 0;
+    int c = 0;
+    if (n < nNode) { p0 = node_ptr[n]; c = static_cast<int>(node_ptr[n + 1] - p0); }
+    for (int j = 0; j < width; ++j) ea[off + 64LL * j] = j < c ? static_cast<int32_t>(keys[p0 + j] & 0xffffffffu) : -1;
 }
 
 // Slot map of the gather form, built once per pattern: for incidence t = (node n, element e) the
@@ -382,23 +408,27 @@ __global__ void __launch_bounds__(kBlock) k_low32(const uint64_t *keys, int64_t 
 // set and a node's free dofs are consecutive columns, so one byte per element node serves all
 // (row, column) pairs; the numeric kernels then never search.
 __global__ void __launch_bounds__(kBlock) k_build_inc_slots(MeshDev m, SellDev A, const int64_t *__restrict__ inc_ptr,
+                                                             const int32_t *__restrict__ inc_cnt,
                                                              const int32_t *__restrict__ inc_ea, uint32_t *inc_slots, int *err)
 {
     const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (n >= m.nNode) return;
-    const int64_t beg = inc_ptr[n], end = inc_ptr[n + 1];
-    if (beg == end) return;
+    // incidence lists are wave-sliced like the matrix: entry j of node n sits at
+    // inc_ptr[n >> 6] + 64*j + (n & 63), so a wave reads one contiguous 256-B run per step
+    const int cnt = inc_cnt[n];
+    if (cnt == 0) return;
+    const int64_t beg = inc_ptr[n >> 6] + (n & 63), end = beg + 64LL * cnt;
     const int ea0 = inc_ea[beg];
     int row = -1;
     for (int p = m.ndof - 1; p >= 0; --p) {
         const int r = m.edof[static_cast<int64_t>(m.ndof * (ea0 & 3) + p) * m.nElem + (ea0 >> 2)];
         if (r >= 0) row = r;
     }
-    if (row < 0) { for (int64_t t = beg; t < end; ++t) inc_slots[t] = 0xffffffffu; return; }
+    if (row < 0) { for (int64_t t = beg; t < end; t += 64) inc_slots[t] = 0xffffffffu; return; }
     const int64_t base = A.slice_off[row >> 6] + (row & 63);
     const int len = A.rowlen[row];
     if (len > 255) { atomicMax(err, 1); return; }           // byte-sized entry index
-    for (int64_t t = beg; t < end; ++t) {
+    for (int64_t t = beg; t < end; t += 64) {
         const int64_t e = inc_ea[t] >> 2;
         uint32_t w = 0;
         for (int b = 0; b < 4; ++b) {
@@ -456,6 +486,7 @@ __global__ void __launch_bounds__(kBlock) k_check_jacobian(MeshDev m, int *err)
 template <int KIND, bool LDSACC>
 __global__ void __launch_bounds__(kBlock) k_gather_scalar(MeshDev m, SellDev A, double *rhs, ElemPrm prm,
                                                            const int64_t *__restrict__ inc_ptr,
+                                                           const int32_t *__restrict__ inc_cnt,
                                                            const int32_t *__restrict__ inc_ea,
                                                            const uint32_t *__restrict__ inc_slots, int *err)
 {
@@ -463,8 +494,11 @@ __global__ void __launch_bounds__(kBlock) k_gather_scalar(MeshDev m, SellDev A, 
     constexpr int NPE = (KIND == PFEM_POISSON_TET) ? 4 : 3;
     const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (n >= m.nNode) return;
-    const int64_t beg = inc_ptr[n], end = inc_ptr[n + 1];
-    if (beg == end) return;
+    // incidence lists are wave-sliced like the matrix: entry j of node n sits at
+    // inc_ptr[n >> 6] + 64*j + (n & 63), so a wave reads one contiguous 256-B run per step
+    const int cnt = inc_cnt[n];
+    if (cnt == 0) return;
+    const int64_t beg = inc_ptr[n >> 6] + (n & 63), end = beg + 64LL * cnt;
     const int ea0 = inc_ea[beg];
     const int row = m.edof[static_cast<int64_t>(ea0 & 3) * m.nElem + (ea0 >> 2)];
     if (row < 0) return;                       // Dirichlet node: no row
@@ -475,7 +509,7 @@ __global__ void __launch_bounds__(kBlock) k_gather_scalar(MeshDev m, SellDev A, 
     double *acc = lds_acc + threadIdx.x;
     if (LDSACC)
         for (int k = 0; k < len; ++k) acc[k * kBlock] = 0.0;
-    for (int64_t t = beg; t < end; ++t) {
+    for (int64_t t = beg; t < end; t += 64) {
         const int ea = inc_ea[t];
         const uint32_t slots = inc_slots[t];
         const int64_t e = ea >> 2;
@@ -531,13 +565,17 @@ __global__ void __launch_bounds__(kBlock) k_gather_scalar(MeshDev m, SellDev A, 
 
 __global__ void __launch_bounds__(kBlock) k_gather_elast(MeshDev m, SellDev A, double *rhs, ElemPrm prm,
                                                           const int64_t *__restrict__ inc_ptr,
+                                                          const int32_t *__restrict__ inc_cnt,
                                                           const int32_t *__restrict__ inc_ea,
                                                           const uint32_t *__restrict__ inc_slots, int *err)
 {
     const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (n >= m.nNode) return;
-    const int64_t beg = inc_ptr[n], end = inc_ptr[n + 1];
-    if (beg == end) return;
+    // incidence lists are wave-sliced like the matrix: entry j of node n sits at
+    // inc_ptr[n >> 6] + 64*j + (n & 63), so a wave reads one contiguous 256-B run per step
+    const int cnt = inc_cnt[n];
+    if (cnt == 0) return;
+    const int64_t beg = inc_ptr[n >> 6] + (n & 63), end = beg + 64LL * cnt;
     const int ea0 = inc_ea[beg];
     int row[3];
     int64_t base[3];
@@ -556,7 +594,7 @@ __global__ void __launch_bounds__(kBlock) k_gather_elast(MeshDev m, SellDev A, d
     if (!any) return;
     const ElastMat mat = elast_material(prm.ed[0], prm.ed[1]);
     double facc[3] = {0.0, 0.0, 0.0};
-    for (int64_t t = beg; t < end; ++t) {
+    for (int64_t t = beg; t < end; t += 64) {
         const int ea = inc_ea[t];
         const uint32_t slots = inc_slots[t];
         const int64_t e = ea >> 2;
@@ -695,13 +733,17 @@ __global__ void __launch_bounds__(kBlock) k_assemble_elast2d(MeshDev m, SellDev 
 
 __global__ void __launch_bounds__(kBlock) k_gather_elast2d(MeshDev m, SellDev A, double *rhs, ElemPrm prm,
                                                             const int64_t *__restrict__ inc_ptr,
+                                                            const int32_t *__restrict__ inc_cnt,
                                                             const int32_t *__restrict__ inc_ea,
                                                             const uint32_t *__restrict__ inc_slots, int *err)
 {
     const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (n >= m.nNode) return;
-    const int64_t beg = inc_ptr[n], end = inc_ptr[n + 1];
-    if (beg == end) return;
+    // incidence lists are wave-sliced like the matrix: entry j of node n sits at
+    // inc_ptr[n >> 6] + 64*j + (n & 63), so a wave reads one contiguous 256-B run per step
+    const int cnt = inc_cnt[n];
+    if (cnt == 0) return;
+    const int64_t beg = inc_ptr[n >> 6] + (n & 63), end = beg + 64LL * cnt;
     const int ea0 = inc_ea[beg];
     int row[2];
     int64_t base[2];
@@ -717,7 +759,7 @@ __global__ void __launch_bounds__(kBlock) k_gather_elast2d(MeshDev m, SellDev A,
     double N[3];
     tria_shape_gp(N);
     double facc[2] = {0.0, 0.0};
-    for (int64_t t = beg; t < end; ++t) {
+    for (int64_t t = beg; t < end; t += 64) {
         const int ea = inc_ea[t];
         const uint32_t slots = inc_slots[t];
         const int64_t e = ea >> 2;
