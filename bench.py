@@ -158,8 +158,7 @@ def main():
     else:
         _, npid = H.partition_box_slabs(nEx, nEy, nEz, world, elements=False)
         dm = H.dof_numbering(mesh.nNode, ndof, mesh.bc_node, mesh.bc_dof, mesh.bc_val, world, npid)
-    conn_new = dm.node_map_get_new[mesh.conn].astype(np.int32)
-    xyz_new = np.ascontiguousarray(mesh.xyz[:, dm.node_map_get_old])
+    conn_new, xyz_new = H.renumber_mesh(mesh, dm)                         # :659-664, :832-838
     edof = H.elem_dof_array(conn_new, dm.NodeDofArrayNew)
     N = dm.size_global
     row_start, row_end = int(dm.row_start[rank]), int(dm.row_end[rank])

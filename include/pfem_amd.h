@@ -122,6 +122,12 @@ int pfem_dof_numbering(int64_t nNode, int ndof, int64_t nDBC, const int32_t *dbc
                        int32_t *node_map_get_new, int32_t *NodeDofArrayNew,
                        double *solnApplied, int64_t *node_start, int64_t *node_end,
                        int64_t *row_start, int64_t *row_end, int64_t *size_global);
+/* The renumbering gathers of the driver: elemNodeConn(e,a) = node_map_get_new(elemNodeConn(e,a)) (:659-664)
+ * and the coordinate gather through node_map_get_old (:832-838).  conn arrays are SoA [npElem][nElem],
+ * xyz arrays SoA [ndim][nNode]; all ids 0-based.  Threaded (the outputs are first touched in parallel). */
+int pfem_renumber_mesh(int64_t nNode, int ndim, int64_t nElem, int npElem, const int32_t *conn_old,
+                       const double *xyz_old, const int32_t *node_map_get_new,
+                       const int32_t *node_map_get_old, int32_t *conn_new, double *xyz_new);
 /* :698-713 */
 int pfem_elem_dof_array(int64_t nElem, int npElem, int ndof, const int32_t *conn_new,
                         const int32_t *NodeDofArrayNew, int32_t *edof);

@@ -59,6 +59,7 @@ SIGNATURES = {
     "pfem_elast_tria_ke": [_P] * 7,
     "pfem_gen_box_tets": [_D, _D, _I, _D, _D, _I, _D, _D, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "pfem_dof_numbering": [_L, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "pfem_renumber_mesh": [_L, _I, _L, _I, _P, _P, _P, _P, _P, _P],
     "pfem_elem_dof_array": [_L, _I, _I, _P, _P, _P],
     "pfem_assy_for_soln": [_L, _I, _P, _P],
     "pfem_partition_box_slabs": [_I, _I, _I, _I, _P, _P],

@@ -272,6 +272,32 @@ extern "C" int pfem_dof_numbering(int64_t nNode, int ndof, int64_t nDBC, const i
     return PFEM_OK;
 }
 
+extern "C" int pfem_renumber_mesh(int64_t nNode, int ndim, int64_t nElem, int npElem, const int32_t *conn_old,
+                                  const double *xyz_old, const int32_t *node_map_get_new,
+                                  const int32_t *node_map_get_old, int32_t *conn_new, double *xyz_new)
+{
+    if (nNode < 0 || nElem < 0 || ndim < 1 || npElem < 1 || !node_map_get_new || !node_map_get_old) return PFEM_ERR_ARG;
+    if ((nElem > 0 && (!conn_old || !conn_new)) || (nNode > 0 && (!xyz_old || !xyz_new))) return PFEM_ERR_ARG;
+    int bad = 0;
+    const int64_t nc = static_cast<int64_t>(npElem) * nElem;
+#pragma omp parallel for schedule(static) reduction(| : bad) if (nc > 100000)
+    for (int64_t i = 0; i < nc; ++i) {
+        const int32_t n = conn_old[i];
+        if (n < 0 || n >= nNode) { bad = 1; conn_new[i] = -1; } else conn_new[i] = node_map_get_new[n];
+    }
+    for (int d = 0; d < ndim; ++d) {
+        const double *src = xyz_old + static_cast<int64_t>(d) * nNode;
+        double *dst = xyz_new + static_cast<int64_t>(d) * nNode;
+#pragma omp parallel for schedule(static) reduction(| : bad) if (nNode > 100000)
+        for (int64_t i = 0; i < nNode; ++i) {
+            const int32_t o = node_map_get_old[i];
+            if (o < 0 || o >= nNode) { bad = 1; dst[i] = 0.0; } else dst[i] = src[o];
+        }
+    }
+    if (bad) return PFEM_ERR_ARG;              // a node id out of range
+    return PFEM_OK;
+}
+
 extern "C" int pfem_elem_dof_array(int64_t nElem, int npElem, int ndof, const int32_t *conn_new,
                                    const int32_t *NodeDofArrayNew, int32_t *edof)
 {

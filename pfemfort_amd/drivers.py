@@ -71,8 +71,7 @@ def _setup(kind, mesh: H.Mesh, nParts=1, node_proc_id=None):
     ndof = L.NDOF[kind]
     # NodeTypeOld / solnApplied / NodeDofArray*, node maps  (:316-367, :393-679)
     dm = H.dof_numbering(mesh.nNode, ndof, mesh.bc_node, mesh.bc_dof, mesh.bc_val, nParts, node_proc_id)
-    conn_new = dm.node_map_get_new[mesh.conn].astype(np.int32)           # :659-664
-    xyz_new = np.ascontiguousarray(mesh.xyz[:, dm.node_map_get_old])     # coords(node_map_get_old(.)) :832-838
+    conn_new, xyz_new = H.renumber_mesh(mesh, dm)                         # :659-664, :832-838
     edof = H.elem_dof_array(conn_new, dm.NodeDofArrayNew)                # :698-713
     return dm, conn_new, xyz_new, edof
 

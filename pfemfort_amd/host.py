@@ -149,6 +149,18 @@ def dof_numbering(nNode, ndof, bc_node, bc_dof, bc_val, nParts=1, node_proc_id=N
     return DofMap(old, new, nda, sa, ns, ne, rs, re, sg.value)
 
 
+def renumber_mesh(mesh, dm: DofMap):
+    """Connectivity and coordinates in the NEW node numbering: ``elemNodeConn = node_map_get_new(.)``
+    (tetrapoissonparallelimpl1.F:659-664) and ``coords(node_map_get_old(.))`` (:832-838)."""
+    conn = _i32(mesh.conn); xyz = _f64(mesh.xyz)
+    conn_new = np.empty(conn.shape, np.int32)
+    xyz_new = np.empty(xyz.shape, np.float64)
+    L.check(L.lib().pfem_renumber_mesh(xyz.shape[1], xyz.shape[0], conn.shape[1], conn.shape[0], _p(conn), _p(xyz),
+                                       _p(_i32(dm.node_map_get_new)), _p(_i32(dm.node_map_get_old)), _p(conn_new),
+                                       _p(xyz_new)), "pfem_renumber_mesh")
+    return conn_new, xyz_new
+
+
 def elem_dof_array(conn_new, NodeDofArrayNew):
     conn_new = _i32(conn_new)
     npE, nElem = conn_new.shape

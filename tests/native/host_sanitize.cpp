@@ -36,7 +36,10 @@ int main(int argc, char **argv)
                                   nda.data(), sa.data(), ns.data(), ne.data(), rs.data(), re.data(), &N) == 0);
         assert(re[parts - 1] == N && rs[0] == 0);
         std::vector<int32_t> cn(4 * nElem);
-        for (size_t i = 0; i < cn.size(); ++i) cn[i] = new_[conn[i]];
+        std::vector<double> xn(3 * nNode);
+        assert(pfem_renumber_mesh(nNode, 3, nElem, 4, conn.data(), xyz.data(), new_.data(), old_.data(), cn.data(), xn.data()) == 0);
+        for (size_t i = 0; i < cn.size(); ++i) assert(cn[i] == new_[conn[i]]);
+        for (int64_t i = 0; i < nNode; ++i) assert(xn[i] == xyz[old_[i]]);
         assert(pfem_elem_dof_array(nElem, 4, ndof, cn.data(), nda.data(), edof.data()) == 0);
         assert(pfem_assy_for_soln(nNode, ndof, nda.data(), assy.data()) == 0);
         int64_t ng = 0;

@@ -45,8 +45,7 @@ def _rank_setup(rank, world, kind, mesh_args, H, PD, dist):
     epid, npid = _partition(mesh, world, mesh_args.get("partition", "slabs"), H)
     ndof = mesh_args["ndof"]
     dm = H.dof_numbering(mesh.nNode, ndof, mesh.bc_node, mesh.bc_dof, mesh.bc_val, world, npid)
-    conn_new = dm.node_map_get_new[mesh.conn].astype(np.int32)
-    xyz_new = np.ascontiguousarray(mesh.xyz[:, dm.node_map_get_old])
+    conn_new, xyz_new = H.renumber_mesh(mesh, dm)                         # :659-664, :832-838
     mine = np.nonzero(epid == rank)[0]                       # elem_proc_id(ee)==this_mpi_proc (:829)
     conn_loc = np.ascontiguousarray(conn_new[:, mine])
     edof_loc = H.elem_dof_array(conn_loc, dm.NodeDofArrayNew)

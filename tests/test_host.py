@@ -101,6 +101,8 @@ def test_numbering_equals_oracle(tet10, ndof):
             assert np.array_equal(getattr(a, f), getattr(b, f)), (nparts, f)
         assert a.size_global == b.size_global
         cn = a.node_map_get_new[tet10.conn].astype(np.int32)
+        cn2, xn2 = H.renumber_mesh(tet10, a)            # the C gathers vs. plain numpy indexing
+        assert np.array_equal(cn2, cn) and np.array_equal(xn2, tet10.xyz[:, a.node_map_get_old])
         assert np.array_equal(H.elem_dof_array(cn, a.NodeDofArrayNew), O.elem_dof_array(cn, b.NodeDofArrayNew))
         assert np.array_equal(H.assy_for_soln(a.NodeDofArrayNew), O.assy_for_soln(b.NodeDofArrayNew))
 
