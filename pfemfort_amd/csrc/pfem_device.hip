@@ -171,6 +171,8 @@ struct pfem_solver {
     DevBuf<int64_t> d_inc_ptr;     // [nNode/64+1] offsets of the wave-sliced incidence lists (64 nodes per chunk) ...
     DevBuf<int32_t> d_inc_cnt;     // ... list length of every node ...
     DevBuf<int32_t> d_inc_ea;      // ... entries 4*e + a, ascending element id, entry j of node n at ptr[n/64]+64j+n%64
+    DevBuf<int4> d_inc_rec;        // 1-dof kinds: packed {other nodes, slots} record per incidence (replaces ea + slots)
+    DevBuf<int32_t> d_node_row;    // 1-dof kinds: row of every node, -1 = no row
     DevBuf<uint32_t> d_inc_slots;  // ... and the matrix entry index of each element node inside the node's rows
     int64_t nnz = 0, n_slices = 0, stored = 0;
     int max_row_len = 0;
@@ -422,10 +424,12 @@ extern "C" int pfem_mesh_upload(pfem_solver *s, int kind, int64_t nElem, const i
     m.edof = s->d_edof.p;
     m.xyz = s->d_xyz.p;
     m.soln = s->d_soln.p;
-    // AoS element records for the gather assembly
-    PFEM_TRY(s->d_elemrec.alloc(static_cast<size_t>(std::max<int64_t>(nElem, 1)) * (m.ndof == 1 ? 8 : 16)));
+    // AoS element records for the gather assembly of the elasticity kinds (the 1-dof kinds read packed
+    // per-incidence records instead, built with the pattern)
+    s->d_elemrec.release();
+    if (m.ndof > 1) PFEM_TRY(s->d_elemrec.alloc(static_cast<size_t>(std::max<int64_t>(nElem, 1)) * 16));
     m.elemrec = s->d_elemrec.p;
-    if (nElem > 0) {
+    if (nElem > 0 && m.ndof > 1) {
         hipLaunchKernelGGL(k_build_elemrec, dim3(grid_for(nElem)), dim3(kBlock), 0, s->stream, m, s->d_elemrec.p);
         PFEM_TRY(check_kernel("k_build_elemrec"));
         PFEM_HIP(hipStreamSynchronize(s->stream));
@@ -627,6 +631,20 @@ int build_incidence(pfem_solver *s)
         s->d_inc_ea.release();
         return PFEM_OK;
     }
+    s->d_inc_rec.release();
+    s->d_node_row.release();
+    if (m.ndof == 1) {            // packed per-incidence records; the lists they came from are dropped
+        PFEM_TRY(s->d_inc_rec.alloc(static_cast<size_t>(std::max<int64_t>(inc_total, 1))));
+        PFEM_TRY(s->d_node_row.alloc(static_cast<size_t>(std::max<int64_t>(m.nNode, 1))));
+        hipLaunchKernelGGL(k_build_inc_rec, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m,
+                           static_cast<const int64_t *>(s->d_inc_ptr.p), static_cast<const int32_t *>(s->d_inc_cnt.p),
+                           static_cast<const int32_t *>(s->d_inc_ea.p), static_cast<const uint32_t *>(s->d_inc_slots.p),
+                           s->d_inc_rec.p, s->d_node_row.p);
+        PFEM_TRY(check_kernel("k_build_inc_rec"));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+        s->d_inc_ea.release();
+        s->d_inc_slots.release();
+    }
     // orientation test of every element, once per mesh
     PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
     hipLaunchKernelGGL(k_check_jacobian, dim3(grid_for(m.nElem)), dim3(kBlock), 0, s->stream, m, s->d_err.p);
@@ -730,12 +748,14 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
         const int32_t *ic = s->d_inc_cnt.p;
         const int32_t *ie = s->d_inc_ea.p;
         const uint32_t *is = s->d_inc_slots.p;
+        const int4 *irec = s->d_inc_rec.p;
+        const int32_t *nrow = s->d_node_row.p;
         // rows of the 1-dof kinds are accumulated in LDS when maxlen*256 doubles fit 64 KiB
         const size_t lds = static_cast<size_t>(s->max_row_len) * kBlock * sizeof(double);
         const bool use_lds = m.ndof == 1 && s->max_row_len > 0 && lds <= 65536;
 #define PFEM_GATHER(KIND)                                                                                             \
-    if (use_lds) hipLaunchKernelGGL((k_gather_scalar<KIND, true>), grid, block, lds, s->stream, m, A, s->d_rhs.p, prm, ip, ic, ie, is, s->d_err.p); \
-    else hipLaunchKernelGGL((k_gather_scalar<KIND, false>), grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ic, ie, is, s->d_err.p)
+    if (use_lds) hipLaunchKernelGGL((k_gather_scalar<KIND, true>), grid, block, lds, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, nrow, s->d_err.p); \
+    else hipLaunchKernelGGL((k_gather_scalar<KIND, false>), grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, nrow, s->d_err.p)
         switch (m.kind) {
         case PFEM_POISSON_TET: PFEM_GATHER(PFEM_POISSON_TET); break;
         case PFEM_POISSON_TRIA: PFEM_GATHER(PFEM_POISSON_TRIA); break;

@@ -30,9 +30,9 @@ struct MeshDev {
     const int32_t *edof;
     const double *xyz;
     const double *soln;
-    // AoS copy for the gather assembly: per element [conn0..3 | edof0..nsize-1], 8 ints (1-dof kinds)
-    // or 16 ints (elasticity) -- one 32/64-B contiguous read per visit instead of 8/16 scattered
-    // 4-B reads from as many arrays (PMC: the SoA form missed L2 on 94 % of its sectors)
+    // AoS copy for the gather assembly of the elasticity kinds: per element [conn0..3 | edof0..11],
+    // 16 ints -- one 64-B contiguous read per visit instead of 16 scattered 4-B reads from as many
+    // arrays (PMC: the SoA form missed L2 on 94 % of its sectors).  Null for the 1-dof kinds.
     const int32_t *elemrec;
 };
 
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(kBlock) k_build_elemrec(MeshDev m, int32_t *re
 {
     const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (e >= m.nElem) return;
-    const int w = m.ndof == 1 ? 8 : 16;
+    const int w = 16;
     int32_t *r = rec + e * w;
     for (int a = 0; a < 4; ++a) r[a] = a < m.npe ? m.conn[a * m.nElem + e] : 0;
     for (int i = 0; i < w - 4; ++i) r[4 + i] = i < m.nsize ? m.edof[i * m.nElem + e] : -1;
@@ -450,6 +450,38 @@ __global__ void __launch_bounds__(kBlock) k_build_inc_slots(MeshDev m, SellDev A
     }
 }
 
+// Packed incidence record of the 1-dof kinds: {o0, o1, o2, slots}, the element's OTHER nodes in
+// local order (the node itself is implied by the list it sits in; its local position a rides in
+// the sign bits of o0 / o1) and the slot bytes.  With it the numeric kernel streams 16 B per
+// visit, coalesced, and reads neither connectivity nor dof arrays: a byte 0xff says "constrained".
+__global__ void __launch_bounds__(kBlock) k_build_inc_rec(MeshDev m, const int64_t *__restrict__ inc_ptr,
+                                                           const int32_t *__restrict__ inc_cnt,
+                                                           const int32_t *__restrict__ inc_ea,
+                                                           const uint32_t *__restrict__ inc_slots, int4 *inc_rec,
+                                                           int32_t *node_row)
+{
+    const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (n >= m.nNode) return;
+    const int cnt = inc_cnt[n];
+    if (cnt == 0) { node_row[n] = -1; return; }
+    const int64_t beg = inc_ptr[n >> 6] + (n & 63), end = beg + 64LL * cnt;
+    const int ea0 = inc_ea[beg];
+    node_row[n] = m.edof[static_cast<int64_t>(ea0 & 3) * m.nElem + (ea0 >> 2)];
+    for (int64_t t = beg; t < end; t += 64) {
+        const int ea = inc_ea[t];
+        const int64_t e = ea >> 2;
+        const uint32_t a = static_cast<uint32_t>(ea & 3);
+        uint32_t o[3] = {0u, 0u, 0u};
+        int q = 0;
+        for (int b = 0; b < m.npe; ++b)
+            if (b != static_cast<int>(a)) o[q++] = static_cast<uint32_t>(m.conn[b * m.nElem + e]);
+        o[0] |= (a & 1u) << 31;
+        o[1] |= (a >> 1) << 31;
+        inc_rec[t] = make_int4(static_cast<int>(o[0]), static_cast<int>(o[1]), static_cast<int>(o[2]),
+                               static_cast<int>(inc_slots[t]));
+    }
+}
+
 // The gather form never evaluates an element whose nodes are all constrained, but the
 // reference STOPs on ANY element with a negative Jacobian (elementutilitiespoisson.F:157):
 // the sign test runs once per mesh in the symbolic phase (coordinates do not change).
@@ -487,21 +519,19 @@ template <int KIND, bool LDSACC>
 __global__ void __launch_bounds__(kBlock) k_gather_scalar(MeshDev m, SellDev A, double *rhs, ElemPrm prm,
                                                            const int64_t *__restrict__ inc_ptr,
                                                            const int32_t *__restrict__ inc_cnt,
-                                                           const int32_t *__restrict__ inc_ea,
-                                                           const uint32_t *__restrict__ inc_slots, int *err)
+                                                           const int4 *__restrict__ inc_rec,
+                                                           const int32_t *__restrict__ node_row, int *err)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];
     constexpr int NPE = (KIND == PFEM_POISSON_TET) ? 4 : 3;
     const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (n >= m.nNode) return;
     // incidence lists are wave-sliced like the matrix: entry j of node n sits at
-    // inc_ptr[n >> 6] + 64*j + (n & 63), so a wave reads one contiguous 256-B run per step
+    // inc_ptr[n >> 6] + 64*j + (n & 63), so a wave reads one contiguous 1-KiB run per step
+    const int row = node_row[n];
+    if (row < 0) return;                       // Dirichlet node (or a node of no element): no row
     const int cnt = inc_cnt[n];
-    if (cnt == 0) return;
     const int64_t beg = inc_ptr[n >> 6] + (n & 63), end = beg + 64LL * cnt;
-    const int ea0 = inc_ea[beg];
-    const int row = m.edof[static_cast<int64_t>(ea0 & 3) * m.nElem + (ea0 >> 2)];
-    if (row < 0) return;                       // Dirichlet node: no row
     const int64_t base = A.slice_off[row >> 6] + (row & 63);
     const int len = A.rowlen[row];
     const double valC[4] = {0.0, 0.0, 0.0, 0.0};
@@ -510,18 +540,19 @@ __global__ void __launch_bounds__(kBlock) k_gather_scalar(MeshDev m, SellDev A, 
     if (LDSACC)
         for (int k = 0; k < len; ++k) acc[k * kBlock] = 0.0;
     for (int64_t t = beg; t < end; t += 64) {
-        const int ea = inc_ea[t];
-        const uint32_t slots = inc_slots[t];
-        const int64_t e = ea >> 2;
-        const int a = ea & 3;
-        int nd[4], dof[4];
-        double x[NPE], y[NPE], z[NPE];
-        {
-            const int4 rc = *reinterpret_cast<const int4 *>(m.elemrec + e * 8);
-            const int4 rd = *reinterpret_cast<const int4 *>(m.elemrec + e * 8 + 4);
-            nd[0] = rc.x; nd[1] = rc.y; nd[2] = rc.z; nd[3] = rc.w;
-            dof[0] = rd.x; dof[1] = rd.y; dof[2] = rd.z; dof[3] = rd.w;
+        const int4 rc = inc_rec[t];
+        const uint32_t slots = static_cast<uint32_t>(rc.w);
+        const int a = static_cast<int>((static_cast<uint32_t>(rc.x) >> 31) | ((static_cast<uint32_t>(rc.y) >> 31) << 1));
+        const int o[3] = {rc.x & 0x7fffffff, rc.y & 0x7fffffff, rc.z};
+        int nd[NPE];
+        bool fixed[NPE];
+#pragma unroll
+        for (int i = 0; i < NPE; ++i) {
+            const int q = i < a ? i : (i > 0 ? i - 1 : 0);
+            nd[i] = (i == a) ? static_cast<int>(n) : o[q];
+            fixed[i] = ((slots >> (8 * i)) & 0xffu) == 0xffu;
         }
+        double x[NPE], y[NPE], z[NPE];
 #pragma unroll
         for (int i = 0; i < NPE; ++i) {
             x[i] = m.xyz[nd[i]];
@@ -548,11 +579,11 @@ __global__ void __launch_bounds__(kBlock) k_gather_scalar(MeshDev m, SellDev A, 
             }
 #pragma unroll
         for (int i = 0; i < NPE; ++i)          // Flocal(a) -= Klocal(a,i)*u_D(i)   (:859-870)
-            if (dof[i] < 0) f = f - Krow[i] * m.soln[nd[i]];
+            if (fixed[i]) f = f - Krow[i] * m.soln[nd[i]];
         facc += f;                             // VecSetValues(ADD_VALUES) :880
 #pragma unroll
         for (int j = 0; j < NPE; ++j) {        // entry (row, dof_j) += Klocal(j,a)   (:851, row-major read)
-            if (dof[j] < 0) continue;
+            if (fixed[j]) continue;
             const uint32_t k = (slots >> (8 * j)) & 0xffu;
             if (LDSACC) acc[k * kBlock] += Kcol[j];
             else A.vals[base + (static_cast<int64_t>(k) << 6)] += Kcol[j];
