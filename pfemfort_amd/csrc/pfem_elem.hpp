@@ -120,6 +120,48 @@ PFEM_HD bool poisson_tet(const double x[4], const double y[4], const double z[4]
     return true;
 }
 
+// The part of poisson_tet() one NODE of the element needs (gather assembly): column a and, when
+// `need_row`, row a of Klocal plus Flocal(a) -- the same expressions in the same order, entry by
+// entry, so the bits equal those of the full routine (a is a run-time index: selects, no branches).
+PFEM_HD bool poisson_tet_node(const double x[4], const double y[4], const double z[4], double kx,
+                              double ky, double kz, double af, const double valC[4], int a, bool need_row,
+                              double Kcol[4], double Krow[4], double &Fa)
+{
+    TetGeom g;
+    tet_geometry(x, y, z, g);
+    if (g.jac < 0.0) return false;
+    const double dvol = kGaussWtTet * g.jac;
+    const double N[4] = {0.25, 0.25, 1.0 - 0.25 - 0.25 - 0.25, 0.25};
+    double du0 = 0.0, du1 = 0.0, du2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        du0 = du0 + valC[i] * g.gx[i];
+        du1 = du1 + valC[i] * g.gy[i];
+        du2 = du2 + valC[i] * g.gz[i];
+    }
+    double gxa = g.gx[0], gya = g.gy[0], gza = g.gz[0], Na = N[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i == a) { gxa = g.gx[i]; gya = g.gy[i]; gza = g.gz[i]; Na = N[i]; }
+    const double force = -6.0;
+    const double b1a = gxa * dvol, b2a = gya * dvol, b3a = gza * dvol, b4a = Na * dvol;
+    double f = 0.0 + b4a * force;
+    f = f - b1a * du0 - b2a * du1 - b3a * du2;
+    Fa = f;
+    const double cx = kx * gxa, cy = ky * gya, cz = kz * gza;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {          // Klocal(j,a): b's of row j, gradient of column a
+        const double b1 = g.gx[j] * dvol, b2 = g.gy[j] * dvol, b3 = g.gz[j] * dvol;
+        Kcol[j] = 0.0 + af * (b1 * cx + b2 * cy + b3 * cz);
+    }
+    if (need_row) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)        // Klocal(a,j)
+            Krow[j] = 0.0 + af * (b1a * (kx * g.gx[j]) + b2a * (ky * g.gy[j]) + b3a * (kz * g.gz[j]));
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------------------
 // P1 triangle [elementutilitiesbasisfuncs.F:16-52,165-234]: N=(xi3,xi1,xi2),
 // parametric gradients (-1,-1),(1,0),(0,1); mapping rows n2-n1, n3-n1.

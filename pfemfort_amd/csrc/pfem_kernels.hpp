@@ -559,24 +559,31 @@ __global__ void __launch_bounds__(kBlock) k_gather_scalar(MeshDev m, SellDev A, 
             y[i] = m.xyz[m.nNode + nd[i]];
             z[i] = (KIND == PFEM_POISSON_TET) ? m.xyz[2 * m.nNode + nd[i]] : 0.0;
         }
-        double K[NPE * NPE], F[NPE];
-        bool ok;
-        if constexpr (KIND == PFEM_POISSON_TET)
-            ok = poisson_tet(x, y, z, prm.ed[0], prm.ed[1], prm.ed[2], prm.af, valC, K, F);
-        else if constexpr (KIND == PFEM_POISSON_TRIA)
-            ok = poisson_tria(x, y, prm.ed[0], prm.ed[1], prm.af, valC, K, F);
-        else
-            ok = poisson_tria_inline(x, y, K, F);
-        if (!ok) { atomicMax(err, PFEM_ERR_NEG_JAC); return; }
         // this node's entries of the element: Klocal(a,:) for the lifting, Klocal(:,a) for the row
         double Krow[NPE], Kcol[NPE], f = 0.0;
+        bool ok;
+        if constexpr (KIND == PFEM_POISSON_TET) {
+            bool any_fixed = false;
 #pragma unroll
-        for (int i = 0; i < NPE; ++i)
-            if (i == a) {
-                f = F[i];
+            for (int i = 0; i < NPE; ++i) any_fixed |= fixed[i];
 #pragma unroll
-                for (int j = 0; j < NPE; ++j) { Krow[j] = K[i + NPE * j]; Kcol[j] = K[j + NPE * i]; }
-            }
+            for (int i = 0; i < NPE; ++i) Krow[i] = 0.0;
+            ok = poisson_tet_node(x, y, z, prm.ed[0], prm.ed[1], prm.ed[2], prm.af, valC, a, any_fixed, Kcol, Krow, f);
+        } else {
+            double K[NPE * NPE], F[NPE];
+            if constexpr (KIND == PFEM_POISSON_TRIA)
+                ok = poisson_tria(x, y, prm.ed[0], prm.ed[1], prm.af, valC, K, F);
+            else
+                ok = poisson_tria_inline(x, y, K, F);
+#pragma unroll
+            for (int i = 0; i < NPE; ++i)
+                if (i == a) {
+                    f = F[i];
+#pragma unroll
+                    for (int j = 0; j < NPE; ++j) { Krow[j] = K[i + NPE * j]; Kcol[j] = K[j + NPE * i]; }
+                }
+        }
+        if (!ok) { atomicMax(err, PFEM_ERR_NEG_JAC); return; }
 #pragma unroll
         for (int i = 0; i < NPE; ++i)          // Flocal(a) -= Klocal(a,i)*u_D(i)   (:859-870)
             if (fixed[i]) f = f - Krow[i] * m.soln[nd[i]];

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/pfem_amd.h"
+#include "../../pfemfort_amd/csrc/pfem_elem.hpp"
 
 int main(int argc, char **argv)
 {
@@ -62,6 +63,20 @@ int main(int argc, char **argv)
         for (int i = 0; i < 4; ++i) { x[i] = nd(rng); y[i] = nd(rng); z[i] = nd(rng); }
         int a = pfem_poisson_tet_ke(x, y, z, ed, td, vc, K, F), b = pfem_elast_tet_ke(x, y, z, ed, td, vc, K, F);
         assert((a == 0 || a == PFEM_ERR_NEG_JAC) && a == b);
+        {   // the per-node slice used by the gather assembly reproduces the full routine bit for bit
+            double vr[4] = {nd(rng), nd(rng), nd(rng), nd(rng)}, Kp[16], Fp[4];
+            const bool ok = pfem::poisson_tet(x, y, z, 1.5, 0.5, 2.0, 0.75, vr, Kp, Fp);
+            for (int an = 0; an < 4; ++an) {
+                double kc[4], kr[4], fa = 0.0;
+                assert(pfem::poisson_tet_node(x, y, z, 1.5, 0.5, 2.0, 0.75, vr, an, true, kc, kr, fa) == ok);
+                if (!ok) continue;
+                assert(std::memcmp(&fa, &Fp[an], 8) == 0);
+                for (int j = 0; j < 4; ++j) {
+                    assert(std::memcmp(&kc[j], &Kp[j + 4 * an], 8) == 0);
+                    assert(std::memcmp(&kr[j], &Kp[an + 4 * j], 8) == 0);
+                }
+            }
+        }
         int c = pfem_poisson_tria_ke(x, y, ed, td, vc, K, F), d = pfem_elast_tria_ke(x, y, ed, td, vc, K, F);
         assert((c == 0 || c == PFEM_ERR_NEG_JAC) && c == d);
     }
