@@ -171,8 +171,10 @@ struct pfem_solver {
     DevBuf<int64_t> d_inc_ptr;     // [nNode/64+1] offsets of the wave-sliced incidence lists (64 nodes per chunk) ...
     DevBuf<int32_t> d_inc_cnt;     // ... list length of every node ...
     DevBuf<int32_t> d_inc_ea;      // ... entries 4*e + a, ascending element id, entry j of node n at ptr[n/64]+64j+n%64
-    DevBuf<int4> d_inc_rec;        // 1-dof kinds: packed {other nodes, slots} record per incidence (replaces ea + slots)
-    DevBuf<int32_t> d_node_row;    // 1-dof kinds: row of every node, -1 = no row
+    DevBuf<int4> d_inc_rec;        // packed {other nodes, slots} record per incidence (replaces ea + slots + elemrec)
+    DevBuf<uint16_t> d_inc_flags;  // ... with the constrained-dof bits of the element (kinds with ndof > 1)
+    DevBuf<int32_t> d_node_row;    // [nNode*ndof] matrix row of every node dof, -1 = no row
+    int elast_rows_threads = 0;    // block size of k_gather_elast_rows, 0 = not applicable
     DevBuf<uint32_t> d_inc_slots;  // ... and the matrix entry index of each element node inside the node's rows
     int64_t nnz = 0, n_slices = 0, stored = 0;
     int max_row_len = 0;
@@ -424,16 +426,8 @@ extern "C" int pfem_mesh_upload(pfem_solver *s, int kind, int64_t nElem, const i
     m.edof = s->d_edof.p;
     m.xyz = s->d_xyz.p;
     m.soln = s->d_soln.p;
-    // AoS element records for the gather assembly of the elasticity kinds (the 1-dof kinds read packed
-    // per-incidence records instead, built with the pattern)
-    s->d_elemrec.release();
-    if (m.ndof > 1) PFEM_TRY(s->d_elemrec.alloc(static_cast<size_t>(std::max<int64_t>(nElem, 1)) * 16));
-    m.elemrec = s->d_elemrec.p;
-    if (nElem > 0 && m.ndof > 1) {
-        hipLaunchKernelGGL(k_build_elemrec, dim3(grid_for(nElem)), dim3(kBlock), 0, s->stream, m, s->d_elemrec.p);
-        PFEM_TRY(check_kernel("k_build_elemrec"));
-        PFEM_HIP(hipStreamSynchronize(s->stream));
-    }
+    s->d_elemrec.release();       // built with the incidence lists when the fallback gather kernels need it
+    m.elemrec = nullptr;
     s->have_mesh = true;
     s->have_pattern = false;
     s->tm.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -632,18 +626,42 @@ int build_incidence(pfem_solver *s)
         return PFEM_OK;
     }
     s->d_inc_rec.release();
+    s->d_inc_flags.release();
     s->d_node_row.release();
-    if (m.ndof == 1) {            // packed per-incidence records; the lists they came from are dropped
+    s->d_elemrec.release();
+    s->mesh.elemrec = nullptr;
+    // packed per-incidence records: the 1-dof kinds always, 3-D elasticity when a row fits the LDS
+    // accumulator of k_gather_elast_rows with at least one wave per block
+    s->elast_rows_threads = 0;
+    if (m.kind == PFEM_ELAST_TET && s->max_row_len > 0)
+        for (int T = kBlock; T >= 64; T >>= 1)
+            if (static_cast<size_t>(s->max_row_len) * T * sizeof(double) <= 65536) { s->elast_rows_threads = T; break; }
+    if (m.kind == PFEM_ELAST_TET && s->elast_rows_threads == 0) {   // rows too long for LDS: scatter form
+        s->d_inc_slots.release();
+        s->d_inc_ptr.release();
+        s->d_inc_cnt.release();
+        s->d_inc_ea.release();
+        return PFEM_OK;
+    }
+    if (m.ndof == 1 || s->elast_rows_threads > 0) {
         PFEM_TRY(s->d_inc_rec.alloc(static_cast<size_t>(std::max<int64_t>(inc_total, 1))));
-        PFEM_TRY(s->d_node_row.alloc(static_cast<size_t>(std::max<int64_t>(m.nNode, 1))));
+        if (m.ndof > 1) PFEM_TRY(s->d_inc_flags.alloc(static_cast<size_t>(std::max<int64_t>(inc_total, 1))));
+        PFEM_TRY(s->d_node_row.alloc(static_cast<size_t>(std::max<int64_t>(m.nNode * m.ndof, 1))));
         hipLaunchKernelGGL(k_build_inc_rec, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m,
                            static_cast<const int64_t *>(s->d_inc_ptr.p), static_cast<const int32_t *>(s->d_inc_cnt.p),
                            static_cast<const int32_t *>(s->d_inc_ea.p), static_cast<const uint32_t *>(s->d_inc_slots.p),
-                           s->d_inc_rec.p, s->d_node_row.p);
+                           s->d_inc_rec.p, m.ndof > 1 ? s->d_inc_flags.p : nullptr, s->d_node_row.p);
         PFEM_TRY(check_kernel("k_build_inc_rec"));
         PFEM_HIP(hipStreamSynchronize(s->stream));
-        s->d_inc_ea.release();
+        s->d_inc_ea.release();          // the lists the records came from are dropped
         s->d_inc_slots.release();
+    } else {
+        // the 2-D elasticity kernel reads AoS element records
+        PFEM_TRY(s->d_elemrec.alloc(static_cast<size_t>(std::max<int64_t>(m.nElem, 1)) * 16));
+        s->mesh.elemrec = s->d_elemrec.p;
+        hipLaunchKernelGGL(k_build_elemrec, dim3(grid_for(m.nElem)), dim3(kBlock), 0, s->stream, s->mesh, s->d_elemrec.p);
+        PFEM_TRY(check_kernel("k_build_elemrec"));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
     }
     // orientation test of every element, once per mesh
     PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
@@ -719,9 +737,13 @@ ElemPrm make_prm(const double *elemData, const double *timeData, int kind)
     return p;
 }
 
-int zero_values(pfem_solver *s)
+// `rows_overwritten`: the caller's kernel stores every entry of every row (gather form with LDS rows), so
+// only the right-hand side needs clearing; the pad entries are zero since the pattern was built and no
+// kernel ever writes them
+int zero_values(pfem_solver *s, bool rows_overwritten = false)
 {
-    PFEM_HIP(hipMemsetAsync(s->d_vals.p, 0, sizeof(double) * static_cast<size_t>(std::max<int64_t>(s->stored, 1)), s->stream));
+    if (!rows_overwritten)
+        PFEM_HIP(hipMemsetAsync(s->d_vals.p, 0, sizeof(double) * static_cast<size_t>(std::max<int64_t>(s->stored, 1)), s->stream));
     PFEM_HIP(hipMemsetAsync(s->d_rhs.p, 0, sizeof(double) * static_cast<size_t>(std::max<int64_t>(s->n_loc, 1)), s->stream));
     s->rhs_summed = false;
     return PFEM_OK;
@@ -739,8 +761,13 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
     const ElemPrm prm = make_prm(elemData, timeData, m.kind);
     PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
     PFEM_HIP(hipEventRecord(s->ev0, s->stream));
-    PFEM_TRY(zero_values(s));                 // setZero, solverpetsc.F:222-246
-    if (m.nElem > 0 && s->assembly_mode == PFEM_ASSEMBLY_GATHER && s->have_incidence) {
+    const bool gather = m.nElem > 0 && s->assembly_mode == PFEM_ASSEMBLY_GATHER && s->have_incidence;
+    // rows of the 1-dof kinds are accumulated in LDS when maxlen*256 doubles fit 64 KiB
+    const size_t lds = static_cast<size_t>(s->max_row_len) * kBlock * sizeof(double);
+    const bool use_lds = m.ndof == 1 && s->max_row_len > 0 && lds <= 65536;
+    const bool elast_rows = m.kind == PFEM_ELAST_TET && s->elast_rows_threads > 0;
+    PFEM_TRY(zero_values(s, gather && (use_lds || elast_rows)));   // setZero, solverpetsc.F:222-246
+    if (gather) {
         // gather form: one thread per node, no atomics, bit-reproducible
         const dim3 grid(grid_for(m.nNode)), block(kBlock);
         SellDev A = s->sell();
@@ -750,9 +777,6 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
         const uint32_t *is = s->d_inc_slots.p;
         const int4 *irec = s->d_inc_rec.p;
         const int32_t *nrow = s->d_node_row.p;
-        // rows of the 1-dof kinds are accumulated in LDS when maxlen*256 doubles fit 64 KiB
-        const size_t lds = static_cast<size_t>(s->max_row_len) * kBlock * sizeof(double);
-        const bool use_lds = m.ndof == 1 && s->max_row_len > 0 && lds <= 65536;
 #define PFEM_GATHER(KIND)                                                                                             \
     if (use_lds) hipLaunchKernelGGL((k_gather_scalar<KIND, true>), grid, block, lds, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, nrow, s->d_err.p); \
     else hipLaunchKernelGGL((k_gather_scalar<KIND, false>), grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, nrow, s->d_err.p)
@@ -761,7 +785,13 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
         case PFEM_POISSON_TRIA: PFEM_GATHER(PFEM_POISSON_TRIA); break;
         case PFEM_POISSON_TRIA_INLINE: PFEM_GATHER(PFEM_POISSON_TRIA_INLINE); break;
         case PFEM_ELAST_TET:
-            hipLaunchKernelGGL(k_gather_elast, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ic, ie, is, s->d_err.p);
+            {
+                const int T = s->elast_rows_threads;
+                const int64_t nthr = 3 * m.nNode;
+                hipLaunchKernelGGL(k_gather_elast_rows, dim3(static_cast<unsigned>((nthr + T - 1) / T)), dim3(T),
+                                   static_cast<size_t>(s->max_row_len) * T * sizeof(double), s->stream, m, A, s->d_rhs.p, prm,
+                                   ip, ic, irec, static_cast<const uint16_t *>(s->d_inc_flags.p), nrow, s->d_err.p);
+            }
             break;
         case PFEM_ELAST_TRIA:
             hipLaunchKernelGGL(k_gather_elast2d, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ic, ie, is, s->d_err.p);

@@ -450,23 +450,29 @@ __global__ void __launch_bounds__(kBlock) k_build_inc_slots(MeshDev m, SellDev A
     }
 }
 
-// Packed incidence record of the 1-dof kinds: {o0, o1, o2, slots}, the element's OTHER nodes in
-// local order (the node itself is implied by the list it sits in; its local position a rides in
-// the sign bits of o0 / o1) and the slot bytes.  With it the numeric kernel streams 16 B per
-// visit, coalesced, and reads neither connectivity nor dof arrays: a byte 0xff says "constrained".
+// Packed incidence record: {o0, o1, o2, slots}, the element's OTHER nodes in local order (the
+// node itself is implied by the list it sits in; its local position a rides in the sign bits of
+// o0 / o1) and the slot bytes.  With it the numeric kernels stream 16 B per visit, coalesced, and
+// read neither connectivity nor dof arrays.  1-dof kinds: a slot byte 0xff says "constrained";
+// kinds with more dofs per node also get inc_flags (bit ndof*b+q set: dof q of local node b is
+// constrained).  node_row[ndof*n+p] is the matrix row of dof p of node n, -1 if it has none.
 __global__ void __launch_bounds__(kBlock) k_build_inc_rec(MeshDev m, const int64_t *__restrict__ inc_ptr,
                                                            const int32_t *__restrict__ inc_cnt,
                                                            const int32_t *__restrict__ inc_ea,
                                                            const uint32_t *__restrict__ inc_slots, int4 *inc_rec,
-                                                           int32_t *node_row)
+                                                           uint16_t *inc_flags, int32_t *node_row)
 {
     const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (n >= m.nNode) return;
     const int cnt = inc_cnt[n];
-    if (cnt == 0) { node_row[n] = -1; return; }
+    if (cnt == 0) {
+        for (int p = 0; p < m.ndof; ++p) node_row[n * m.ndof + p] = -1;
+        return;
+    }
     const int64_t beg = inc_ptr[n >> 6] + (n & 63), end = beg + 64LL * cnt;
     const int ea0 = inc_ea[beg];
-    node_row[n] = m.edof[static_cast<int64_t>(ea0 & 3) * m.nElem + (ea0 >> 2)];
+    for (int p = 0; p < m.ndof; ++p)
+        node_row[n * m.ndof + p] = m.edof[static_cast<int64_t>(m.ndof * (ea0 & 3) + p) * m.nElem + (ea0 >> 2)];
     for (int64_t t = beg; t < end; t += 64) {
         const int ea = inc_ea[t];
         const int64_t e = ea >> 2;
@@ -479,6 +485,12 @@ __global__ void __launch_bounds__(kBlock) k_build_inc_rec(MeshDev m, const int64
         o[1] |= (a >> 1) << 31;
         inc_rec[t] = make_int4(static_cast<int>(o[0]), static_cast<int>(o[1]), static_cast<int>(o[2]),
                                static_cast<int>(inc_slots[t]));
+        if (inc_flags) {
+            uint32_t fl = 0;
+            for (int i = 0; i < m.nsize; ++i)
+                if (m.edof[static_cast<int64_t>(i) * m.nElem + e] < 0) fl |= 1u << i;
+            inc_flags[t] = static_cast<uint16_t>(fl);
+        }
     }
 }
 
@@ -601,54 +613,47 @@ __global__ void __launch_bounds__(kBlock) k_gather_scalar(MeshDev m, SellDev A, 
     rhs[row] = facc;
 }
 
-__global__ void __launch_bounds__(kBlock) k_gather_elast(MeshDev m, SellDev A, double *rhs, ElemPrm prm,
-                                                          const int64_t *__restrict__ inc_ptr,
-                                                          const int32_t *__restrict__ inc_cnt,
-                                                          const int32_t *__restrict__ inc_ea,
-                                                          const uint32_t *__restrict__ inc_slots, int *err)
+// Elasticity gather, one thread per (node, dof) ROW: the row is accumulated in LDS (entry k of
+// thread t at acc[k*T + t]: conflict free; T = blockDim.x chosen so maxlen*T doubles fit) and
+// stored once, coalesced -- no read-modify-write of the matrix in global memory (what bounded
+// the thread-per-node form: 5.0 ms on the 50x300x50 beam).  The three threads of a node walk the same packed incidence list and
+// recompute the element geometry; same additions in the same (ascending element) order.
+__global__ void __launch_bounds__(kBlock) k_gather_elast_rows(MeshDev m, SellDev A, double *rhs, ElemPrm prm,
+                                                               const int64_t *__restrict__ inc_ptr,
+                                                               const int32_t *__restrict__ inc_cnt,
+                                                               const int4 *__restrict__ inc_rec,
+                                                               const uint16_t *__restrict__ inc_flags,
+                                                               const int32_t *__restrict__ node_row, int *err)
 {
-    const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (n >= m.nNode) return;
-    // incidence lists are wave-sliced like the matrix: entry j of node n sits at
-    // inc_ptr[n >> 6] + 64*j + (n & 63), so a wave reads one contiguous 256-B run per step
+    extern __shared__ __attribute__((aligned(16))) double lds_acc[];
+    const int T = blockDim.x;
+    const int64_t tid = static_cast<int64_t>(blockIdx.x) * T + threadIdx.x;
+    if (tid >= 3 * m.nNode) return;
+    const int64_t n = tid / 3;
+    const int p = static_cast<int>(tid - 3 * n);
+    const int row = node_row[tid];
+    if (row < 0) return;
     const int cnt = inc_cnt[n];
-    if (cnt == 0) return;
     const int64_t beg = inc_ptr[n >> 6] + (n & 63), end = beg + 64LL * cnt;
-    const int ea0 = inc_ea[beg];
-    int row[3];
-    int64_t base[3];
-    int len[3];
-    bool any = false;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        row[p] = m.edof[static_cast<int64_t>(3 * (ea0 & 3) + p) * m.nElem + (ea0 >> 2)];
-        base[p] = 0; len[p] = 0;
-        if (row[p] >= 0) {
-            any = true;
-            base[p] = A.slice_off[row[p] >> 6] + (row[p] & 63);
-            len[p] = A.rowlen[row[p]];
-        }
-    }
-    if (!any) return;
+    const int64_t base = A.slice_off[row >> 6] + (row & 63);
+    const int len = A.rowlen[row];
+    double *acc = lds_acc + threadIdx.x;
+    for (int k = 0; k < len; ++k) acc[k * T] = 0.0;
     const ElastMat mat = elast_material(prm.ed[0], prm.ed[1]);
-    double facc[3] = {0.0, 0.0, 0.0};
+    const double bf = p == 0 ? prm.ed[3] : (p == 1 ? prm.ed[4] : prm.ed[5]);
+    double facc = 0.0;
     for (int64_t t = beg; t < end; t += 64) {
-        const int ea = inc_ea[t];
-        const uint32_t slots = inc_slots[t];
-        const int64_t e = ea >> 2;
-        const int a = ea & 3;
-        int nd[4], dof[12];
+        const int4 rc = inc_rec[t];
+        const uint32_t flags = inc_flags[t];
+        const uint32_t slots = static_cast<uint32_t>(rc.w);
+        const int a = static_cast<int>((static_cast<uint32_t>(rc.x) >> 31) | ((static_cast<uint32_t>(rc.y) >> 31) << 1));
+        const int o[3] = {rc.x & 0x7fffffff, rc.y & 0x7fffffff, rc.z};
+        int nd[4];
         double x[4], y[4], z[4];
-        {
-            const int4 *rp = reinterpret_cast<const int4 *>(m.elemrec + e * 16);
-            const int4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
-            nd[0] = r0.x; nd[1] = r0.y; nd[2] = r0.z; nd[3] = r0.w;
-            dof[0] = r1.x; dof[1] = r1.y; dof[2] = r1.z; dof[3] = r1.w;
-            dof[4] = r2.x; dof[5] = r2.y; dof[6] = r2.z; dof[7] = r2.w;
-            dof[8] = r3.x; dof[9] = r3.y; dof[10] = r3.z; dof[11] = r3.w;
-        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            const int q = i < a ? i : (i > 0 ? i - 1 : 0);
+            nd[i] = (i == a) ? static_cast<int>(n) : o[q];
             x[i] = m.xyz[nd[i]];
             y[i] = m.xyz[m.nNode + nd[i]];
             z[i] = m.xyz[2 * m.nNode + nd[i]];
@@ -657,49 +662,41 @@ __global__ void __launch_bounds__(kBlock) k_gather_elast(MeshDev m, SellDev A, d
         tet_geometry(x, y, z, g);
         if (g.jac < 0.0) { atomicMax(err, PFEM_ERR_NEG_JAC); return; }
         const double dvol = kGaussWtTet * g.jac;
-        double ax = 0.0, ay = 0.0, az = 0.0;
+        double ax = g.gx[0], ay = g.gy[0], az = g.gz[0];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 1; i < 4; ++i)
             if (i == a) { ax = g.gx[i]; ay = g.gy[i]; az = g.gz[i]; }
         const double b4 = dvol * 0.25;
-        double f[3] = {0.0 + b4 * prm.ed[3], 0.0 + b4 * prm.ed[4], 0.0 + b4 * prm.ed[5]};
+        double f = 0.0 + b4 * bf;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            double kab[3][3], kba[3][3];
-            elast_block_v(ax, ay, az, g.gx[b], g.gy[b], g.gz[b], mat, dvol, kab);   // Klocal(3a+p, 3b+q)
+            const uint32_t fb = (flags >> (3 * b)) & 7u;
+            if (fb != 0) {                 // lifting, q ascending:  Flocal(3a+p) -= Klocal(3a+p,3b+q) * u_D(3b+q)
+                double kab[3][3];
+                elast_block_v(ax, ay, az, g.gx[b], g.gy[b], g.gz[b], mat, dvol, kab);
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (fb & (1u << q)) {
+                        const double kpq = p == 0 ? kab[0][q] : (p == 1 ? kab[1][q] : kab[2][q]);
+                        f = f - kpq * m.soln[3LL * nd[b] + q];
+                    }
+                if (fb == 7u) continue;
+            }
+            double kba[3][3];
             elast_block_v(g.gx[b], g.gy[b], g.gz[b], ax, ay, az, mat, dvol, kba);   // Klocal(3b+q, 3a+p) = kba[q][p]
-            int firstq = -1;
+            // entry (row, dof(3b+q)) += Klocal(3b+q, 3a+p); node b's free dofs are consecutive columns
+            int k = static_cast<int>((slots >> (8 * b)) & 0xffu);
 #pragma unroll
-            for (int q = 2; q >= 0; --q)
-                if (dof[3 * b + q] >= 0) firstq = q;
-            // lifting, q ascending:  Flocal(3a+p) -= Klocal(3a+p,3b+q) * u_D(3b+q)
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-                if (dof[3 * b + q] < 0) {
-                    const double u = m.soln[3LL * nd[b] + q];
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) f[p] = f[p] - kab[p][q] * u;
-                }
-            if (firstq < 0) continue;
-            // entry (row_p, dof(3b+q)) += Klocal(3b+q, 3a+p); node b's free dofs are consecutive columns
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                if (row[p] < 0) continue;
-                int64_t s = base[p] + (static_cast<int64_t>((slots >> (8 * b)) & 0xffu) << 6);
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    if (dof[3 * b + q] < 0) continue;
-                    A.vals[s] += kba[q][p];
-                    s += 64;
-                }
+            for (int q = 0; q < 3; ++q) {
+                if (fb & (1u << q)) continue;
+                acc[k * T] += p == 0 ? kba[q][0] : (p == 1 ? kba[q][1] : kba[q][2]);
+                ++k;
             }
         }
-#pragma unroll
-        for (int p = 0; p < 3; ++p) facc[p] += f[p];
+        facc += f;
     }
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-        if (row[p] >= 0) rhs[row[p]] = facc[p];
+    for (int k = 0; k < len; ++k) A.vals[base + (static_cast<int64_t>(k) << 6)] = acc[k * T];
+    rhs[row] = facc;
 }
 
 // ---------------------------------------------------------------------------
