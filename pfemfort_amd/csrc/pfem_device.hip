@@ -437,7 +437,7 @@ extern "C" int pfem_mesh_upload(pfem_solver *s, int kind, int64_t nElem, const i
 extern "C" int pfem_get_ghosts(pfem_solver *s, int64_t *n_ghost, int64_t *ghost_gid)
 {
     if (!s || !n_ghost) return PFEM_ERR_ARG;
-    if (!s->have_mesh) return PFEM_ERR_STATE;
+    if (!s->have_mesh && !s->have_pattern) return PFEM_ERR_STATE;   // batched: after the upload; compat: after setZero
     *n_ghost = s->n_ghost;
     if (ghost_gid) std::copy(s->ghost_gid.begin(), s->ghost_gid.end(), ghost_gid);
     return PFEM_OK;
@@ -1057,7 +1057,7 @@ extern "C" int pfem_solver_set_interface(pfem_solver *s, int64_t n_shared, const
 {
     if (!s || n_shared < 0 || n_iface_global < n_shared || (n_shared && (!shared_gid || !shared_slot)))
         return PFEM_ERR_ARG;
-    if (!s->have_mesh) return PFEM_ERR_STATE;   // local numbering must exist
+    if (!s->have_mesh && !s->have_pattern) return PFEM_ERR_STATE;   // local numbering must exist
     PFEM_TRY(use_device(s));
     std::vector<int32_t> lidx(static_cast<size_t>(n_shared));
     const int64_t lo = s->row_start, hi = s->row_start + s->n_owned;
@@ -1281,13 +1281,30 @@ int run_pcg(pfem_solver *s)
 // ---------------------------------------------------------------------------
 // compat path: MatSetValues / VecSetValues staged on the host
 // ---------------------------------------------------------------------------
+// With more than one rank the staged matrix is the rank's SUB-ASSEMBLED local matrix, exactly as in the
+// batched path: rows/columns outside the owned block become ghost rows (owned rows first, then ghosts
+// ascending by global id) and carry this rank's partial sums; nothing is shipped at MatAssemblyEnd, the
+// solve sums interface entries instead.
+namespace {
+
+// global dof id -> local id, -1 if the rank does not know the dof
+inline int64_t compat_local(const pfem_solver *s, int64_t g)
+{
+    if (g >= s->row_start && g < s->row_start + s->n_owned) return g - s->row_start;
+    auto it = std::lower_bound(s->ghost_gid.begin(), s->ghost_gid.end(), g);
+    if (it == s->ghost_gid.end() || *it != g) return -1;
+    return s->n_owned + (it - s->ghost_gid.begin());
+}
+
+}  // namespace
+
 extern "C" int pfem_mat_set_values(pfem_solver *s, int m, const int *idxm, int n, const int *idxn,
                                    const double *v, int mode)
 {
     if (!s || m < 0 || n < 0 || (m && !idxm) || (n && !idxn) || (mode != PFEM_INSERT_VALUES && mode != PFEM_ADD_VALUES))
         return PFEM_ERR_ARG;
-    if (s->nranks > 1 || s->have_mesh) {
-        set_last_error("the MatSetValues compat path is single-rank and exclusive with pfem_mesh_upload/pfem_assemble");
+    if (s->have_mesh) {
+        set_last_error("the MatSetValues compat path is exclusive with pfem_mesh_upload/pfem_assemble");
         return PFEM_ERR_STATE;
     }
     if (s->status == PFEM_SOLVER_EMPTY) {
@@ -1307,13 +1324,16 @@ extern "C" int pfem_mat_set_values(pfem_solver *s, int m, const int *idxm, int n
     if (s->h_rowptr.empty()) return PFEM_ERR_STATE;
     for (int i = 0; i < m; ++i) {
         if (idxm[i] < 0) continue;
-        const int64_t r = idxm[i];
-        if (r >= s->size_global) return PFEM_ERR_ARG;
+        if (idxm[i] >= s->size_global) return PFEM_ERR_ARG;
+        const int64_t r = compat_local(s, idxm[i]);
+        if (r < 0) return PFEM_ERR_PATTERN;
         const int32_t *cb = s->h_cols.data() + s->h_rowptr[r], *ce = s->h_cols.data() + s->h_rowptr[r + 1];
         for (int j = 0; j < n; ++j) {
             if (idxn[j] < 0) continue;
-            const int32_t *p = std::lower_bound(cb, ce, idxn[j]);
-            if (p == ce || *p != idxn[j]) return PFEM_ERR_PATTERN;
+            const int64_t cl = idxn[j] < s->size_global ? compat_local(s, idxn[j]) : -1;
+            if (cl < 0) return PFEM_ERR_PATTERN;
+            const int32_t *p = std::lower_bound(cb, ce, static_cast<int32_t>(cl));
+            if (p == ce || *p != cl) return PFEM_ERR_PATTERN;
             double &dst = s->h_vals[static_cast<size_t>(p - s->h_cols.data())];
             const double val = v[static_cast<size_t>(i) * n + j];      // PETSc reads v row-major
             if (mode == PFEM_ADD_VALUES) dst += val; else dst = val;
@@ -1327,11 +1347,18 @@ extern "C" int pfem_vec_set_values(pfem_solver *s, int n, const int *idx, const 
 {
     if (!s || n < 0 || (n && (!idx || !v)) || (mode != PFEM_INSERT_VALUES && mode != PFEM_ADD_VALUES)) return PFEM_ERR_ARG;
     if (s->have_mesh) { set_last_error("VecSetValues compat path is not available once a mesh is uploaded (batched mode)"); return PFEM_ERR_STATE; }
-    if (s->h_rhs.empty() && s->size_global > 0) s->h_rhs.assign(static_cast<size_t>(s->size_global), 0.0);
+    if (!s->have_pattern && s->n_owned < s->size_global) {
+        set_last_error("VecSetValues before the pattern is final: the local numbering of a multi-rank solver is not known yet");
+        return PFEM_ERR_STATE;
+    }
+    const int64_t nl = s->have_pattern ? s->n_loc : s->n_owned;
+    if (s->h_rhs.empty() && nl > 0) s->h_rhs.assign(static_cast<size_t>(nl), 0.0);
     for (int i = 0; i < n; ++i) {
         if (idx[i] < 0) continue;                       // VEC_IGNORE_NEGATIVE_INDICES
         if (idx[i] >= s->size_global) return PFEM_ERR_ARG;
-        if (mode == PFEM_ADD_VALUES) s->h_rhs[idx[i]] += v[i]; else s->h_rhs[idx[i]] = v[i];
+        const int64_t l = compat_local(s, idx[i]);
+        if (l < 0) return PFEM_ERR_PATTERN;             // a dof no MatSetValues of this rank touched
+        if (mode == PFEM_ADD_VALUES) s->h_rhs[l] += v[i]; else s->h_rhs[l] = v[i];
     }
     s->host_values_dirty = true;
     return PFEM_OK;
@@ -1361,9 +1388,25 @@ extern "C" int pfem_solver_set_zero(pfem_solver *s)
         if (compat) {
             if (s->h_keys.empty() && s->size_global > 0) return PFEM_ERR_STATE;
             // MatAssembly of the INSERT_VALUES pass: finalise the recorded pattern on the device
-            s->n_loc = s->n_owned;
-            DevBuf<uint64_t> keys;
             const int64_t nk = static_cast<int64_t>(s->h_keys.size());
+            s->ghost_gid.clear();
+            if (s->n_owned < s->size_global) {          // multi-rank: ids outside the owned block become ghosts
+                const int64_t lo = s->row_start, hi = s->row_start + s->n_owned;
+                for (const uint64_t k : s->h_keys) {
+                    const int64_t r = static_cast<int64_t>(k >> 32), c = static_cast<int64_t>(k & 0xffffffffu);
+                    if (r < lo || r >= hi) s->ghost_gid.push_back(r);
+                    if (c < lo || c >= hi) s->ghost_gid.push_back(c);
+                }
+                std::sort(s->ghost_gid.begin(), s->ghost_gid.end());
+                s->ghost_gid.erase(std::unique(s->ghost_gid.begin(), s->ghost_gid.end()), s->ghost_gid.end());
+                for (uint64_t &k : s->h_keys)
+                    k = (static_cast<uint64_t>(compat_local(s, static_cast<int64_t>(k >> 32))) << 32) |
+                        static_cast<uint64_t>(compat_local(s, static_cast<int64_t>(k & 0xffffffffu)));
+            }
+            s->n_ghost = static_cast<int64_t>(s->ghost_gid.size());
+            s->n_loc = s->n_owned + s->n_ghost;
+            if (s->n_loc > INT32_MAX) return PFEM_ERR_ARG;
+            DevBuf<uint64_t> keys;
             PFEM_TRY(keys.alloc(static_cast<size_t>(std::max<int64_t>(nk, 1))));
             if (nk) PFEM_HIP(hipMemcpy(keys.p, s->h_keys.data(), sizeof(uint64_t) * nk, hipMemcpyHostToDevice));
             std::vector<uint64_t>().swap(s->h_keys);
@@ -1380,7 +1423,7 @@ extern "C" int pfem_solver_set_zero(pfem_solver *s)
             PFEM_TRY(pfem_get_csr(s, s->h_rowptr.data(), s->h_cols.data(), nullptr));
         }
         s->h_vals.assign(static_cast<size_t>(s->nnz), 0.0);
-        s->h_rhs.assign(static_cast<size_t>(s->size_global), 0.0);
+        s->h_rhs.assign(static_cast<size_t>(s->n_loc), 0.0);
     }
     PFEM_TRY(zero_values(s));
     PFEM_HIP(hipStreamSynchronize(s->stream));

@@ -182,10 +182,31 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
         mesh, dm, conn_loc, xyz_new, edof_g, rs, re = _rank_setup(rank, world, kind, mesh_args, H, PD, dist)
         s = pf.PetscSolver().initialise(re - rs, dm.size_global, row_start=rs, device=0)
         s.setTolerances(rtol=1e-10)
-        s.uploadMesh(kind, conn_loc, xyz_new, edof_g, dm.solnApplied)
-        hook, n_iface = PD.attach(s, dist, torch, torch.device("cuda", 0))
-        s.buildPattern()
-        s.assemble(H.ELAST_ELEMDATA if kind == pf.ELAST_TET else H.POISSON_ELEMDATA, H.TIMEDATA)
+        ed = H.ELAST_ELEMDATA if kind == pf.ELAST_TET else H.POISSON_ELEMDATA
+        if mesh_args.get("mode", "batched") == "batched":
+            s.uploadMesh(kind, conn_loc, xyz_new, edof_g, dm.solnApplied)
+            hook, n_iface = PD.attach(s, dist, torch, torch.device("cuda", 0))
+            s.buildPattern()
+            s.assemble(ed, H.TIMEDATA)
+        else:
+            # the Fortran driver's own loops (tetrapoissonparallelimpl1.F:786-884) with GLOBAL indices: pattern by
+            # INSERT_VALUES, setZero, then per-element routine + lifting + ADD_VALUES for this rank's elements
+            from pfemfort_amd.solver import ADD_VALUES, INSERT_VALUES
+            ndof, nsize = mesh_args["ndof"], edof_g.shape[0]
+            for e in range(conn_loc.shape[1]):
+                s.MatSetValues(edof_g[:, e], edof_g[:, e], np.zeros(nsize * nsize), INSERT_VALUES)
+            s.setZero()
+            hook, n_iface = PD.attach(s, dist, torch, torch.device("cuda", 0))
+            fn = H.StiffnessResidualElasticityLinearTetra if kind == pf.ELAST_TET else H.StiffnessResidualPoissonLinearTetra
+            for e in range(conn_loc.shape[1]):
+                nd = conn_loc[:, e]
+                K, F = fn(xyz_new[0, nd], xyz_new[1, nd], xyz_new[2, nd], ed, H.TIMEDATA, np.zeros(nsize))
+                f = edof_g[:, e]
+                s.MatSetValues(f, f, K.ravel(order="F"), ADD_VALUES)
+                for ii in np.nonzero(f == -1)[0]:
+                    fact = dm.solnApplied[nd[ii // ndof] * ndof + ii % ndof]
+                    F = F - np.where(f != -1, K[:, ii] * fact, 0.0)
+                s.VecSetValues(f, F, ADD_VALUES)
         its, reason, rn = s.factoriseAndSolve()
         assert hook.error is None, hook.error
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=s.getSolution(), rs=rs, re=re, its=its, reason=reason,
@@ -196,15 +217,19 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind_name,world,partition", [("poisson", 2, "slabs"), ("elast", 2, "slabs"),
-                                                       ("poisson", 3, "sectors"), ("elast", 3, "sectors")])
-def test_gpu_ranks_on_one_device_match_single_rank(tmp_path, kind_name, world, partition):
+@pytest.mark.parametrize("kind_name,world,partition,mode", [("poisson", 2, "slabs", "batched"), ("elast", 2, "slabs", "batched"),
+                                                            ("poisson", 3, "sectors", "batched"), ("elast", 3, "sectors", "batched"),
+                                                            ("poisson", 2, "slabs", "compat"), ("elast", 3, "sectors", "compat")])
+def test_gpu_ranks_on_one_device_match_single_rank(tmp_path, kind_name, world, partition, mode):
     import torch.multiprocessing as mp
     import pfemfort_amd as pf
     from pfemfort_amd import host as H
     mesh_args = ({"box": (-1, 1, 12, -1, 1, 10, -1, 1, 14), "bc_mode": 0, "ndof": 1} if kind_name == "poisson" else
                  {"box": (-0.5, 0.5, 3, 0.0, 3.0, 8, -0.5, 0.5, 6), "bc_mode": 1, "ndof": 3})
     mesh_args["partition"] = partition
+    mesh_args["mode"] = mode
+    if mode == "compat" and kind_name == "poisson":
+        mesh_args["box"] = (-1, 1, 6, -1, 1, 5, -1, 1, 7)
     mp.spawn(_gpu_worker, args=(world, _free_port(), mesh_args, str(tmp_path)), nprocs=world, join=True)
     mesh = H.gen_box_tets(*mesh_args["box"], bc_mode=mesh_args["bc_mode"], ndof=mesh_args["ndof"])
     ndof = mesh_args["ndof"]
