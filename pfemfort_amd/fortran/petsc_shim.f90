@@ -1,5 +1,7 @@
 ! External procedures with the names the drivers call directly (SURVEY 8b, tier 1b): PETSc
-! Mat/Vec entry points over the pfem_solver handle, single-rank MPI, METIS placeholders.
+! Mat/Vec entry points over the pfem_solver handle, a single-rank MPI (default flavour; with
+! -DPFEM_WITH_MPI the real MPI library provides MPI_* and the drivers run under mpiexec), and a
+! deterministic stand-in for METIS_PartMeshNodal.
 ! Implicit-interface externals on purpose: the drivers call them without explicit interfaces.
 
 subroutine PetscInitialize(file, ierr)
@@ -9,6 +11,11 @@ subroutine PetscInitialize(file, ierr)
   integer :: ierr, io, n
   character(len=256) :: line, key, val
   logical :: ex
+#ifdef PFEM_WITH_MPI
+  logical :: up
+  call MPI_Initialized(up, ierr)
+  if (.not. up) call MPI_Init(ierr)
+#endif
   ierr = 0
   inquire(file=trim(file), exist=ex)
   if (ex) then
@@ -40,6 +47,9 @@ subroutine PetscFinalize(ierr)
   implicit none
   integer :: ierr
   ierr = 0
+#ifdef PFEM_WITH_MPI
+  call MPI_Finalize(ierr)
+#endif
 end subroutine PetscFinalize
 
 ! PETSc passes the Fortran string to a C printf: the literal two characters "\n" become a newline
@@ -47,6 +57,12 @@ subroutine PetscPrintf(comm, str, ierr)
   implicit none
   integer :: comm, ierr, i, n
   character(len=*) :: str
+#ifdef PFEM_WITH_MPI
+  integer :: me
+  call MPI_Comm_rank(comm, me, ierr)
+  ierr = 0
+  if (me /= 0) return                 ! PetscPrintf prints on the first rank of the communicator only
+#endif
   ierr = 0
   n = len_trim(str)
   i = 1
@@ -138,13 +154,20 @@ end subroutine VecScatterDestroy
 ! one-before the first entry of the fetched solution.
 subroutine VecGetArray(vec, xx_v, xx_i, ierr)
   use pfem_amd_c
+#ifdef PFEM_WITH_MPI
+  use petscvec, only: pfem_seq_soln, PETSC_COMM_WORLD, MPI_INTEGER, MPI_SUM
+#else
   use petscvec, only: pfem_seq_soln
+#endif
   implicit none
   integer(kind=8) :: vec, xx_i
   double precision, target :: xx_v(*)
   integer :: ierr
   integer(c_int64_t) :: nown, nloc, nnz, nst
   integer(kind=8) :: a0, a1
+#ifdef PFEM_WITH_MPI
+  integer :: nmine, ntot, ierr2
+#endif
   interface
     integer(c_int) function pfem_matrix_info(s, a, b, c, d) bind(C, name="pfem_matrix_info")
       import
@@ -155,8 +178,16 @@ subroutine VecGetArray(vec, xx_v, xx_i, ierr)
   ierr = pfem_matrix_info(pfem_h2p(vec), nown, nloc, nnz, nst)
   if (ierr /= 0) call pfem_chkerr(ierr)
   if (allocated(pfem_seq_soln)) deallocate(pfem_seq_soln)
+#ifdef PFEM_WITH_MPI
+  ! vec_SEQ of VecScatterCreateToAll: every rank gets all size_global entries, rank blocks in order
+  nmine = int(nown)
+  call MPI_Allreduce(nmine, ntot, 1, MPI_INTEGER, MPI_SUM, PETSC_COMM_WORLD, ierr2)
+  allocate(pfem_seq_soln(max(ntot, 1)))
+  ierr = pfem_mpi_gather_solution(pfem_h2p(vec), PETSC_COMM_WORLD, nown, pfem_seq_soln)
+#else
   allocate(pfem_seq_soln(max(nown, 1_c_int64_t)))
   ierr = pfem_solver_get_solution(pfem_h2p(vec), pfem_seq_soln)
+#endif
   if (ierr /= 0) call pfem_chkerr(ierr)
   a0 = transfer(c_loc(xx_v(1)), a0)
   a1 = transfer(c_loc(pfem_seq_soln(1)), a1)
@@ -172,6 +203,7 @@ subroutine VecRestoreArray(vec, xx_v, xx_i, ierr)
 end subroutine VecRestoreArray
 
 ! ---- MPI on one rank -------------------------------------------------------------------------
+#ifndef PFEM_WITH_MPI
 double precision function MPI_Wtime()
   implicit none
   integer(kind=8) :: c, r
@@ -221,7 +253,14 @@ subroutine MPI_Allreduce(sbuf, rbuf, n, dtype, op, comm, ierr)
   rbuf(1:n) = sbuf(1:n); ierr = 0
 end subroutine MPI_Allreduce
 
-! ---- METIS: only reached when n_mpi_procs > 1 (tetrapoissonparallelimpl1.F:423) ---------------
+#endif
+
+! ---- METIS: only reached when n_mpi_procs > 1 (tetrapoissonparallelimpl1.F:423-467) ----------------
+! METIS 5 is a third-party library that is neither part of the reference tree nor installed here.
+! Stand-in with the same interface and the same kind of result (0-based part of every element and
+! node): nodes are cut into nparts contiguous index blocks of equal size -- z-slabs for the
+! structured generator's numbering -- and an element goes to the lowest part among its nodes.
+! Any valid partition works downstream: the drivers renumber from (epart, npart) alone.
 subroutine METIS_SetDefaultOptions(options)
   implicit none
   integer :: options(*)
@@ -232,7 +271,19 @@ subroutine METIS_PartMeshNodal(ne, nn, eptr, eind, vwgt, vsize, nparts, tpwgts, 
   implicit none
   integer :: ne, nn, eptr(*), eind(*), vwgt, vsize, nparts, options(*), objval, epart(*), npart(*)
   double precision :: tpwgts
-  stop "METIS is not linked into the single-process Fortran shim (use the torch.distributed host for N>1)"
+  integer :: e, k, p
+  integer(kind=8) :: i
+  do i = 1, nn
+    npart(i) = int(((i - 1) * int(nparts, 8)) / int(nn, 8))
+  end do
+  do e = 1, ne
+    p = nparts
+    do k = eptr(e) + 1, eptr(e + 1)          ! eptr / eind are 0-based (C numbering)
+      p = min(p, npart(eind(k) + 1))
+    end do
+    epart(e) = p
+  end do
+  objval = 0
 end subroutine METIS_PartMeshNodal
 
 ! (iargc/getarg, GNU extensions used by the drivers, come from the flang runtime; petscvec only

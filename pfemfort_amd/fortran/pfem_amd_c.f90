@@ -114,6 +114,25 @@ module pfem_amd_c
       integer(c_int), value :: code
       type(c_ptr) :: p
     end function
+    ! pfem_mpi.cpp (MPI flavour of the shim only)
+    integer(c_int) function pfem_mpi_attach(s, fcomm, row_start, size_local) bind(C, name="pfem_mpi_attach")
+      import
+      type(c_ptr), value :: s
+      integer(c_int), value :: fcomm
+      integer(c_int64_t), value :: row_start, size_local
+    end function
+    integer(c_int) function pfem_mpi_gather_solution(s, fcomm, size_local, out) bind(C, name="pfem_mpi_gather_solution")
+      import
+      type(c_ptr), value :: s
+      integer(c_int), value :: fcomm
+      integer(c_int64_t), value :: size_local
+      real(c_double) :: out(*)
+    end function
+    integer(c_int) function pfem_mpi_pick_device(fcomm, device) bind(C, name="pfem_mpi_pick_device")
+      import
+      integer(c_int), value :: fcomm
+      integer(c_int) :: device
+    end function
   end interface
 contains
   ! 8-byte PETSc-style handle <-> C pointer

@@ -3,7 +3,11 @@
 ! handle, because the drivers only hand them back to MatSetValues / VecSetValues / VecGetArray.
 module Module_SolverPetsc
   use pfem_amd_c
+#ifdef PFEM_WITH_MPI
+  use petscvec, only: pfem_opt_rtol, pfem_opt_atol, pfem_opt_dtol, pfem_opt_maxits, PETSC_COMM_WORLD, MPI_INTEGER, MPI_SUM
+#else
   use petscvec, only: pfem_opt_rtol, pfem_opt_atol, pfem_opt_dtol, pfem_opt_maxits
+#endif
   implicit none
   integer, parameter :: SOLVER_EMPTY=1, PATTERN_OK=2, INIT_OK=3, ASSEMBLY_OK=4, FACTORISE_OK=5   ! solverpetsc.F:64-68
 
@@ -13,6 +17,9 @@ module Module_SolverPetsc
     double precision :: norm = 0.0d0
     integer :: currentStatus = 0
     integer :: its = 0, reason = 0
+    ! not in the reference type: the rank's row block, and whether the communicator is wired (MPI flavour)
+    integer(c_int64_t) :: row_start = 0, size_local = 0
+    logical :: attached = .false.
   contains
     procedure :: initialise
     procedure :: setZero
@@ -40,11 +47,25 @@ contains
     integer, intent(in) :: size_global, size_local
     integer, dimension(:) :: diag_nnz, offdiag_nnz
     type(c_ptr) :: h
-    integer :: ierr
+    integer :: ierr, rs, me
+    integer(c_int) :: dev
     this%nRow = size_global
     this%nCol = size_global
-    ierr = pfem_solver_create(h, int(size_local, c_int64_t), int(size_global, c_int64_t), 0_c_int64_t, &
-                              diag_nnz, offdiag_nnz, -1_c_int)
+    rs = 0
+    dev = -1
+#ifdef PFEM_WITH_MPI
+    ! PETSc's ownership ranges: rows of rank r start after the size_local of the lower ranks
+    call MPI_Comm_rank(PETSC_COMM_WORLD, me, ierr)
+    call MPI_Exscan(size_local, rs, 1, MPI_INTEGER, MPI_SUM, PETSC_COMM_WORLD, ierr)
+    if (me == 0) rs = 0
+    ierr = pfem_mpi_pick_device(PETSC_COMM_WORLD, dev)
+    if (ierr /= 0) call pfem_chkerr(ierr)
+#endif
+    this%row_start = rs
+    this%size_local = size_local
+    this%attached = .false.
+    ierr = pfem_solver_create(h, int(size_local, c_int64_t), int(size_global, c_int64_t), int(rs, c_int64_t), &
+                              diag_nnz, offdiag_nnz, dev)
     if (ierr /= 0) call pfem_chkerr(ierr)
     ierr = pfem_solver_set_tolerances(h, pfem_opt_rtol, pfem_opt_atol, pfem_opt_dtol, int(pfem_opt_maxits, c_int))
     if (ierr /= 0) call pfem_chkerr(ierr)
@@ -62,6 +83,15 @@ contains
     integer :: ierr
     ierr = pfem_solver_set_zero(pfem_h2p(this%mtx))
     if (ierr /= 0) call pfem_chkerr(ierr)
+#ifdef PFEM_WITH_MPI
+    ! the first setZero finalises the pattern (MatAssembly of the INSERT_VALUES pass), and with it the
+    ! local numbering: exchange the ghost lists and install the interface plan + all-reduce hook
+    if (.not. this%attached) then
+      ierr = pfem_mpi_attach(pfem_h2p(this%mtx), PETSC_COMM_WORLD, this%row_start, this%size_local)
+      if (ierr /= 0) call pfem_chkerr(ierr)
+      this%attached = .true.
+    end if
+#endif
     call sync_status(this)
   end subroutine setZero
 

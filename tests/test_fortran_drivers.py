@@ -94,3 +94,60 @@ def test_unchanged_elasticity_driver_on_small_beam(tmp_path):
     prob = O.setup_problem(O.ELAST_TET, O.Mesh(mesh.xyz, mesh.conn, mesh.bc_node, mesh.bc_dof, mesh.bc_val))
     x, *_ = O.pcg_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-12)
     assert len(u) == len(x) and np.abs(u - x).max() < 1e-8 * max(1.0, np.abs(x).max())
+
+
+# ---------------------------------------------------------------------------------------
+# The same PROGRAMs under mpiexec: the reference's parallel path (METIS call, MPI renumbering,
+# per-rank element loop with global indices, VecScatterCreateToAll) on the MPI flavour of the shim.
+def _mpiexec():
+    for cand in ("/opt/conda/bin/mpiexec", shutil.which("mpiexec")):
+        if cand and os.path.exists(cand):
+            return cand
+    pytest.skip("mpiexec not available")
+
+
+def _run_mpi(exe, nranks, prefix, cwd, rtol="1e-10"):
+    env = dict(os.environ, PFEM_KSP_RTOL=rtol)
+    return subprocess.run([_mpiexec(), "-n", str(nranks), exe, prefix + "-nodes.dat", prefix + "-elems.dat",
+                           prefix + "-DirichBC.dat"], cwd=cwd, env=env, capture_output=True, text=True, timeout=900)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_unchanged_poisson_driver_under_mpiexec(tmp_path, golden_dir, nranks):
+    exe = _exe("tetrapoissonparallelimpl1_mpi")
+    for k in ("nodes", "elems", "DirichBC"):
+        with gzip.open(os.path.join(golden_dir, "input", f"tet10-{k}.dat.gz"), "rb") as src, \
+                open(tmp_path / f"tet10-{k}.dat", "wb") as dst:
+            shutil.copyfileobj(src, dst)
+    r = _run_mpi(exe, nranks, "tet10", tmp_path)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "Convergence in" in r.stdout and "Program is successful" in r.stdout
+    t = np.loadtxt(tmp_path / "temp.dat")                # written by rank 0: ii, old node, value
+    mesh = O.read_mesh(os.path.join(golden_dir, "input", "tet10"))
+    # the stand-in partitioner: contiguous node-index blocks (petsc_shim.f90: METIS_PartMeshNodal)
+    npid = ((np.arange(mesh.nNode, dtype=np.int64) * nranks) // mesh.nNode).astype(np.int32)
+    prob = O.setup_problem(O.POISSON_TET, mesh, nParts=nranks, node_proc_id=npid)
+    assy = O.assy_for_soln(prob.dm.NodeDofArrayNew)
+    assert np.array_equal(t[:, 0].astype(int), np.arange(1, 730))
+    assert np.array_equal(t[:, 1].astype(int), prob.dm.node_map_get_old[assy] + 1)     # the driver's MPI renumbering
+    x, *_ = O.pcg_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-12)
+    assert np.abs(t[:, 2] - x).max() < 1e-8
+    exact = (mesh.xyz ** 2).sum(0)
+    assert np.abs(t[:, 2] - exact[t[:, 1].astype(int) - 1]).max() < 2e-7
+
+
+@pytest.mark.gpu
+def test_unchanged_elasticity_driver_under_mpiexec(tmp_path):
+    exe = _exe("tetraelasticityparallelimpl1_mpi")
+    mesh = H.gen_box_tets(-0.5, 0.5, 3, 0.0, 6.0, 12, -0.5, 0.5, 3, bc_mode=1, ndof=3)
+    _write_mesh(mesh, str(tmp_path / "beam"), 3)
+    r = _run_mpi(exe, 2, "beam", tmp_path)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "Convergence in" in r.stdout
+    u = np.loadtxt(tmp_path / "temp.dat")
+    npid = ((np.arange(mesh.nNode, dtype=np.int64) * 2) // mesh.nNode).astype(np.int32)
+    prob = O.setup_problem(O.ELAST_TET, O.Mesh(mesh.xyz, mesh.conn, mesh.bc_node, mesh.bc_dof, mesh.bc_val), nParts=2,
+                           node_proc_id=npid)
+    x, *_ = O.pcg_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-12)
+    assert len(u) == len(x) and np.abs(u - x).max() < 1e-8 * max(1.0, np.abs(x).max())
