@@ -47,16 +47,20 @@ def _run(exe, prefix, cwd, rtol="1e-10"):
 
 
 @pytest.mark.skipif(pf.device_count() > 0, reason="a GPU is present")
-def test_unchanged_driver_links_runs_bookkeeping_and_fails_loudly_without_gpu(tmp_path, golden_dir):
-    exe = _exe("tetrapoissonparallelimpl1")
+@pytest.mark.parametrize("nranks", [1, 2])
+def test_unchanged_driver_links_runs_bookkeeping_and_fails_loudly_without_gpu(tmp_path, golden_dir, nranks):
+    exe = _exe("tetrapoissonparallelimpl1" if nranks == 1 else "tetrapoissonparallelimpl1_mpi")
     for k in ("nodes", "elems", "DirichBC"):
         with gzip.open(os.path.join(golden_dir, "input", f"tet10-{k}.dat.gz"), "rb") as src, \
                 open(tmp_path / f"tet10-{k}.dat", "wb") as dst:
             shutil.copyfileobj(src, dst)
-    r = _run(exe, "tet10", tmp_path)
+    r = _run(exe, "tet10", tmp_path) if nranks == 1 else _run_mpi(exe, nranks, "tet10", tmp_path)
     out = r.stdout + r.stderr
     assert "Total DOF      =  729" in out               # the driver's own bookkeeping ran (:357-383)
-    assert "no HIP device" in out and r.returncode != 0  # solverpetsc%initialise refuses: no CPU path
+    if nranks > 1:                                      # ... and its METIS call + MPI renumbering (:423-679)
+        assert "After Metis" in out and "size_local" in out
+    assert "no HIP device" in out                       # solverpetsc%initialise refuses: no CPU path
+    assert nranks > 1 or r.returncode != 0              # (hydra does not forward a Fortran STOP code)
 
 
 @pytest.mark.gpu
