@@ -77,7 +77,14 @@ def test_elasticity_beam_config4():
     s, dm, xyz = _solver(pf.ELAST_TET, mesh, 1e-5)
     info = s.matrixInfo()
     assert (dm.size_global, info["nnz"]) == (2340900, 102964482) == closed_form_sizes(51, 300, 51, 3)
+    s.setAssemblyMode("scatter"); s.assemble(H.ELAST_ELEMDATA, H.TIMEDATA)
+    v_sc, f_sc = s.getCSR()[2], s.getRHS()
+    s.setAssemblyMode("gather"); s.assemble(H.ELAST_ELEMDATA, H.TIMEDATA)      # row-per-thread LDS form
+    v_g, f_g = s.getCSR()[2], s.getRHS()
+    assert np.abs(v_sc - v_g).max() <= 1e-12 * np.abs(v_g).max() and np.abs(f_sc - f_g).max() <= 1e-12 * np.abs(f_g).max()
     s.assemble(H.ELAST_ELEMDATA, H.TIMEDATA)
+    assert np.array_equal(s.getCSR()[2], v_g) and np.array_equal(s.getRHS(), f_g)   # bit-reproducible
+    del v_sc, v_g
     N = dm.size_global
     rng = np.random.default_rng(4)
     x, y = rng.standard_normal(N), rng.standard_normal(N)
