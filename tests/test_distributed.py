@@ -246,3 +246,51 @@ def test_gpu_ranks_on_one_device_match_single_rank(tmp_path, kind_name, world, p
         got[dm.node_map_get_old[assy[rows] // ndof], assy[rows] % ndof] = d["x"]
         assert int(d["reason"]) == 2 and abs(int(d["its"]) - ref.its) <= 3
     assert np.abs(got - ref.solnVTK).max() <= 1e-8 * max(1.0, np.abs(ref.solnVTK).max())
+
+
+def _nccl_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        import pfemfort_amd as pf
+        from pfemfort_amd import distributed as PD
+        from pfemfort_amd import host as H
+        mesh = H.gen_box_tets(-1, 1, 6, -1, 1, 5, -1, 1, 7)
+        dm = H.dof_numbering(mesh.nNode, 1, mesh.bc_node, mesh.bc_dof, mesh.bc_val)
+        conn, xyz = H.renumber_mesh(mesh, dm)
+        edof = H.elem_dof_array(conn, dm.NodeDofArrayNew)
+        s = pf.PetscSolver().initialise(dm.size_global, dm.size_global, device=0)
+        s.setTolerances(rtol=1e-10)
+        s.uploadMesh(pf.POISSON_TET, conn, xyz, edof, dm.solnApplied)
+        hook, n_iface = PD.attach(s, dist, torch, torch.device("cuda", 0))      # all_gather_object over RCCL
+        s.buildPattern()
+        s.assemble(H.POISSON_ELEMDATA, H.TIMEDATA)
+        its, reason, _ = s.factoriseAndSolve()
+        # the hook itself, as the library calls it: in-place SUM on a slice of the exchange tensor
+        hook.xbuf[:] = torch.arange(hook.xbuf.numel(), dtype=torch.float64, device="cuda")
+        assert hook(None, hook.base + 8, 3, None) == 0 and hook.error is None
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, "nccl.npz"), its=its, reason=reason, n_iface=n_iface, x=s.getSolution(),
+                 xbuf=hook.xbuf.cpu().numpy())
+        s.free()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_backend_binds_to_the_hook_world_size_1(tmp_path):
+    """Only one GPU per box here, and RCCL refuses two ranks on one device: this pins what CAN be pinned of the
+    backend bench.py uses for N>1 -- process-group creation on the device, the object all-gather of attach(), and an
+    in-place float64 all_reduce on a slice of the exchange tensor issued through the hook -- with world_size 1."""
+    import torch.multiprocessing as mp
+    import pfemfort_amd as pf
+    from pfemfort_amd import host as H
+    mp.spawn(_nccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    d = np.load(tmp_path / "nccl.npz")
+    ref = pf.tetrapoissonparallelimpl1(H.gen_box_tets(-1, 1, 6, -1, 1, 5, -1, 1, 7), rtol=1e-10)
+    assert int(d["reason"]) == 2 and int(d["its"]) == ref.its and int(d["n_iface"]) == 0
+    assert np.array_equal(d["x"], ref.soln_free)
+    assert np.array_equal(d["xbuf"], np.arange(len(d["xbuf"]), dtype=np.float64))   # SUM over one rank: unchanged
