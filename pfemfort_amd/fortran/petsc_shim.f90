@@ -261,6 +261,8 @@ end subroutine MPI_Allreduce
 ! node): nodes are cut into nparts contiguous index blocks of equal size -- z-slabs for the
 ! structured generator's numbering -- and an element goes to the lowest part among its nodes.
 ! Any valid partition works downstream: the drivers renumber from (epart, npart) alone.
+! A partition computed offline by the real METIS is taken instead when PFEM_METIS_PREFIX is set:
+! mpmetis writes <prefix>.epart.<nparts> and <prefix>.npart.<nparts>, one 0-based part per line.
 subroutine METIS_SetDefaultOptions(options)
   implicit none
   integer :: options(*)
@@ -271,8 +273,28 @@ subroutine METIS_PartMeshNodal(ne, nn, eptr, eind, vwgt, vsize, nparts, tpwgts, 
   implicit none
   integer :: ne, nn, eptr(*), eind(*), vwgt, vsize, nparts, options(*), objval, epart(*), npart(*)
   double precision :: tpwgts
-  integer :: e, k, p
+  integer :: e, k, p, io
   integer(kind=8) :: i
+  character(len=1024) :: prefix
+  character(len=16) :: sfx
+  call get_environment_variable("PFEM_METIS_PREFIX", prefix, status=io)
+  if (io == 0 .and. len_trim(prefix) > 0) then
+    write(sfx, '(I0)') nparts
+    open(98, file=trim(prefix)//'.epart.'//trim(sfx), status='old', action='read', iostat=io)
+    if (io /= 0) stop "PFEM_METIS_PREFIX is set but <prefix>.epart.<nparts> cannot be opened"
+    read(98, *, iostat=io) (epart(e), e = 1, ne)
+    if (io /= 0) stop "short or malformed .epart file"
+    close(98)
+    open(98, file=trim(prefix)//'.npart.'//trim(sfx), status='old', action='read', iostat=io)
+    if (io /= 0) stop "PFEM_METIS_PREFIX is set but <prefix>.npart.<nparts> cannot be opened"
+    read(98, *, iostat=io) (npart(i), i = 1, nn)
+    if (io /= 0) stop "short or malformed .npart file"
+    close(98)
+    if (minval(epart(1:ne)) < 0 .or. maxval(epart(1:ne)) >= nparts .or. &
+        minval(npart(1:nn)) < 0 .or. maxval(npart(1:nn)) >= nparts) stop "part id out of range in the METIS files"
+    objval = 0
+    return
+  end if
   do i = 1, nn
     npart(i) = int(((i - 1) * int(nparts, 8)) / int(nn, 8))
   end do

@@ -124,6 +124,22 @@ def partition_box_slabs(nEx, nEy, nEz, nParts, elements=True):
     return epid, npid
 
 
+def read_metis_partition(prefix: str, nParts: int):
+    """(elem_proc_id, node_proc_id) from the files METIS' ``mpmetis <mesh> nParts`` writes
+    (``<prefix>.epart.<nParts>`` / ``<prefix>.npart.<nParts>``, one 0-based part per line): the
+    file hook for ``METIS_PartMeshNodal`` (tetrapoissonparallelimpl1.F:464), which is not installed here."""
+    out = []
+    for kind in ("epart", "npart"):
+        t = read_table(f"{prefix}.{kind}.{nParts}")
+        if t.ndim != 2 or t.shape[1] != 1:
+            raise ValueError(f"{prefix}.{kind}.{nParts}: expected one part id per line")
+        ids = t[:, 0].astype(np.int32)
+        if len(ids) and (ids.min() < 0 or ids.max() >= nParts or np.any(ids != t[:, 0])):
+            raise ValueError(f"{prefix}.{kind}.{nParts}: part id out of range")
+        out.append(ids)
+    return out[0], out[1]
+
+
 @dataclass
 class DofMap:
     node_map_get_old: np.ndarray

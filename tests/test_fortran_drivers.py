@@ -155,3 +155,36 @@ def test_unchanged_elasticity_driver_under_mpiexec(tmp_path):
                            node_proc_id=npid)
     x, *_ = O.pcg_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-12)
     assert len(u) == len(x) and np.abs(u - x).max() < 1e-8 * max(1.0, np.abs(x).max())
+
+
+@pytest.mark.gpu
+def test_mpi_driver_takes_a_metis_partition_from_files(tmp_path, golden_dir):
+    """PFEM_METIS_PREFIX: epart/npart files in mpmetis' format replace the stand-in partitioner; an irregular
+    3-part partition (angular sectors; interface nodes given to a pseudo-random adjacent part)."""
+    exe = _exe("tetrapoissonparallelimpl1_mpi")
+    for k in ("nodes", "elems", "DirichBC"):
+        with gzip.open(os.path.join(golden_dir, "input", f"tet10-{k}.dat.gz"), "rb") as src, \
+                open(tmp_path / f"tet10-{k}.dat", "wb") as dst:
+            shutil.copyfileobj(src, dst)
+    mesh = O.read_mesh(os.path.join(golden_dir, "input", "tet10"))
+    world = 3
+    cen = mesh.xyz[:, mesh.conn].mean(axis=1)
+    epid = np.minimum(((np.arctan2(cen[1] + 0.013, cen[0] + 0.007) + np.pi) / (2 * np.pi) * world).astype(np.int32), world - 1)
+    touch = np.zeros((world, mesh.nNode), bool)
+    for a in range(4):
+        touch[epid, mesh.conn[a]] = True
+    npid = (np.random.default_rng(5).random((world, mesh.nNode)) * touch).argmax(axis=0).astype(np.int32)
+    np.savetxt(tmp_path / "tet10.epart.3", epid, fmt="%d")
+    np.savetxt(tmp_path / "tet10.npart.3", npid, fmt="%d")
+    e2, n2 = H.read_metis_partition(str(tmp_path / "tet10"), 3)       # the Python side of the same hook
+    assert np.array_equal(e2, epid) and np.array_equal(n2, npid)
+    env = dict(os.environ, PFEM_KSP_RTOL="1e-10", PFEM_METIS_PREFIX="tet10")
+    r = subprocess.run([_mpiexec(), "-n", "3", exe, "tet10-nodes.dat", "tet10-elems.dat", "tet10-DirichBC.dat"], cwd=tmp_path,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "Program is successful" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    t = np.loadtxt(tmp_path / "temp.dat")
+    prob = O.setup_problem(O.POISSON_TET, mesh, nParts=world, node_proc_id=npid)
+    assy = O.assy_for_soln(prob.dm.NodeDofArrayNew)
+    assert np.array_equal(t[:, 1].astype(int), prob.dm.node_map_get_old[assy] + 1)
+    x, *_ = O.pcg_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-12)
+    assert np.abs(t[:, 2] - x).max() < 1e-8

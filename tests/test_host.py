@@ -169,3 +169,13 @@ def test_elast_tria_host_routine_bit_exact(gold, golden_dir):
         K, F = H.StiffnessResidualElasticityLinearTria(cook.xyz[0, nd], cook.xyz[1, nd], gold["cook_elast_data"],
                                                        H.TIMEDATA, np.zeros(6))
         assert np.array_equal(K, gold["cook_elast_K"][e]) and np.array_equal(F, gold["cook_elast_F"][e])
+
+
+def test_read_metis_partition_files(tmp_path):
+    ep = np.array([0, 2, 1, 1, 0], np.int32); npart = np.array([1, 1, 0, 2], np.int32)
+    np.savetxt(tmp_path / "m.epart.3", ep, fmt="%d"); np.savetxt(tmp_path / "m.npart.3", npart, fmt="%d")
+    e, n = H.read_metis_partition(str(tmp_path / "m"), 3)
+    assert np.array_equal(e, ep) and np.array_equal(n, npart) and e.dtype == np.int32
+    np.savetxt(tmp_path / "m.npart.2", npart, fmt="%d"); np.savetxt(tmp_path / "m.epart.2", ep, fmt="%d")
+    with pytest.raises(ValueError):
+        H.read_metis_partition(str(tmp_path / "m"), 2)          # part id 2 with nParts = 2
