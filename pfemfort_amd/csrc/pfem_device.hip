@@ -156,7 +156,7 @@ struct pfem_solver {
     // mesh
     MeshDev mesh{};
     bool have_mesh = false;
-    DevBuf<int32_t> d_conn, d_edof, d_elemrec;
+    DevBuf<int32_t> d_conn, d_edof;
     DevBuf<double> d_xyz, d_soln;
 
     // local numbering
@@ -426,8 +426,6 @@ extern "C" int pfem_mesh_upload(pfem_solver *s, int kind, int64_t nElem, const i
     m.edof = s->d_edof.p;
     m.xyz = s->d_xyz.p;
     m.soln = s->d_soln.p;
-    s->d_elemrec.release();       // built with the incidence lists when the fallback gather kernels need it
-    m.elemrec = nullptr;
     s->have_mesh = true;
     s->have_pattern = false;
     s->tm.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -628,41 +626,31 @@ int build_incidence(pfem_solver *s)
     s->d_inc_rec.release();
     s->d_inc_flags.release();
     s->d_node_row.release();
-    s->d_elemrec.release();
-    s->mesh.elemrec = nullptr;
-    // packed per-incidence records: the 1-dof kinds always, 3-D elasticity when a row fits the LDS
-    // accumulator of k_gather_elast_rows with at least one wave per block
+    // The numeric kernels read packed per-incidence records.  The elasticity kinds accumulate one matrix row
+    // per thread in LDS: the block size is the largest of 256/128/64 for which max_row_len*T doubles fit
+    // 64 KiB; rows longer than that keep the scatter form.
     s->elast_rows_threads = 0;
-    if (m.kind == PFEM_ELAST_TET && s->max_row_len > 0)
+    if (m.ndof > 1 && s->max_row_len > 0)
         for (int T = kBlock; T >= 64; T >>= 1)
             if (static_cast<size_t>(s->max_row_len) * T * sizeof(double) <= 65536) { s->elast_rows_threads = T; break; }
-    if (m.kind == PFEM_ELAST_TET && s->elast_rows_threads == 0) {   // rows too long for LDS: scatter form
+    if (m.ndof > 1 && s->elast_rows_threads == 0) {
         s->d_inc_slots.release();
         s->d_inc_ptr.release();
         s->d_inc_cnt.release();
         s->d_inc_ea.release();
         return PFEM_OK;
     }
-    if (m.ndof == 1 || s->elast_rows_threads > 0) {
-        PFEM_TRY(s->d_inc_rec.alloc(static_cast<size_t>(std::max<int64_t>(inc_total, 1))));
-        if (m.ndof > 1) PFEM_TRY(s->d_inc_flags.alloc(static_cast<size_t>(std::max<int64_t>(inc_total, 1))));
-        PFEM_TRY(s->d_node_row.alloc(static_cast<size_t>(std::max<int64_t>(m.nNode * m.ndof, 1))));
-        hipLaunchKernelGGL(k_build_inc_rec, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m,
-                           static_cast<const int64_t *>(s->d_inc_ptr.p), static_cast<const int32_t *>(s->d_inc_cnt.p),
-                           static_cast<const int32_t *>(s->d_inc_ea.p), static_cast<const uint32_t *>(s->d_inc_slots.p),
-                           s->d_inc_rec.p, m.ndof > 1 ? s->d_inc_flags.p : nullptr, s->d_node_row.p);
-        PFEM_TRY(check_kernel("k_build_inc_rec"));
-        PFEM_HIP(hipStreamSynchronize(s->stream));
-        s->d_inc_ea.release();          // the lists the records came from are dropped
-        s->d_inc_slots.release();
-    } else {
-        // the 2-D elasticity kernel reads AoS element records
-        PFEM_TRY(s->d_elemrec.alloc(static_cast<size_t>(std::max<int64_t>(m.nElem, 1)) * 16));
-        s->mesh.elemrec = s->d_elemrec.p;
-        hipLaunchKernelGGL(k_build_elemrec, dim3(grid_for(m.nElem)), dim3(kBlock), 0, s->stream, s->mesh, s->d_elemrec.p);
-        PFEM_TRY(check_kernel("k_build_elemrec"));
-        PFEM_HIP(hipStreamSynchronize(s->stream));
-    }
+    PFEM_TRY(s->d_inc_rec.alloc(static_cast<size_t>(std::max<int64_t>(inc_total, 1))));
+    if (m.ndof > 1) PFEM_TRY(s->d_inc_flags.alloc(static_cast<size_t>(std::max<int64_t>(inc_total, 1))));
+    PFEM_TRY(s->d_node_row.alloc(static_cast<size_t>(std::max<int64_t>(m.nNode * m.ndof, 1))));
+    hipLaunchKernelGGL(k_build_inc_rec, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m,
+                       static_cast<const int64_t *>(s->d_inc_ptr.p), static_cast<const int32_t *>(s->d_inc_cnt.p),
+                       static_cast<const int32_t *>(s->d_inc_ea.p), static_cast<const uint32_t *>(s->d_inc_slots.p),
+                       s->d_inc_rec.p, m.ndof > 1 ? s->d_inc_flags.p : nullptr, s->d_node_row.p);
+    PFEM_TRY(check_kernel("k_build_inc_rec"));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    s->d_inc_ea.release();          // the lists the records came from are dropped
+    s->d_inc_slots.release();
     // orientation test of every element, once per mesh
     PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
     hipLaunchKernelGGL(k_check_jacobian, dim3(grid_for(m.nElem)), dim3(kBlock), 0, s->stream, m, s->d_err.p);
@@ -765,7 +753,7 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
     // rows of the 1-dof kinds are accumulated in LDS when maxlen*256 doubles fit 64 KiB
     const size_t lds = static_cast<size_t>(s->max_row_len) * kBlock * sizeof(double);
     const bool use_lds = m.ndof == 1 && s->max_row_len > 0 && lds <= 65536;
-    const bool elast_rows = m.kind == PFEM_ELAST_TET && s->elast_rows_threads > 0;
+    const bool elast_rows = m.ndof > 1 && s->elast_rows_threads > 0;
     PFEM_TRY(zero_values(s, gather && (use_lds || elast_rows)));   // setZero, solverpetsc.F:222-246
     if (gather) {
         // gather form: one thread per node, no atomics, bit-reproducible
@@ -773,28 +761,25 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
         SellDev A = s->sell();
         const int64_t *ip = s->d_inc_ptr.p;
         const int32_t *ic = s->d_inc_cnt.p;
-        const int32_t *ie = s->d_inc_ea.p;
-        const uint32_t *is = s->d_inc_slots.p;
         const int4 *irec = s->d_inc_rec.p;
+        const uint16_t *ifl = s->d_inc_flags.p;
         const int32_t *nrow = s->d_node_row.p;
 #define PFEM_GATHER(KIND)                                                                                             \
     if (use_lds) hipLaunchKernelGGL((k_gather_scalar<KIND, true>), grid, block, lds, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, nrow, s->d_err.p); \
     else hipLaunchKernelGGL((k_gather_scalar<KIND, false>), grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, nrow, s->d_err.p)
+        const int T = s->elast_rows_threads;
+        const int64_t nthr = static_cast<int64_t>(m.ndof) * m.nNode;
+        const dim3 rgrid(static_cast<unsigned>(T > 0 ? (nthr + T - 1) / T : 1)), rblock(T > 0 ? T : 1);
+        const size_t rlds = static_cast<size_t>(s->max_row_len) * (T > 0 ? T : 1) * sizeof(double);
         switch (m.kind) {
         case PFEM_POISSON_TET: PFEM_GATHER(PFEM_POISSON_TET); break;
         case PFEM_POISSON_TRIA: PFEM_GATHER(PFEM_POISSON_TRIA); break;
         case PFEM_POISSON_TRIA_INLINE: PFEM_GATHER(PFEM_POISSON_TRIA_INLINE); break;
         case PFEM_ELAST_TET:
-            {
-                const int T = s->elast_rows_threads;
-                const int64_t nthr = 3 * m.nNode;
-                hipLaunchKernelGGL(k_gather_elast_rows, dim3(static_cast<unsigned>((nthr + T - 1) / T)), dim3(T),
-                                   static_cast<size_t>(s->max_row_len) * T * sizeof(double), s->stream, m, A, s->d_rhs.p, prm,
-                                   ip, ic, irec, static_cast<const uint16_t *>(s->d_inc_flags.p), nrow, s->d_err.p);
-            }
+            hipLaunchKernelGGL(k_gather_elast_rows, rgrid, rblock, rlds, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, ifl, nrow, s->d_err.p);
             break;
         case PFEM_ELAST_TRIA:
-            hipLaunchKernelGGL(k_gather_elast2d, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ic, ie, is, s->d_err.p);
+            hipLaunchKernelGGL(k_gather_elast2d_rows, rgrid, rblock, rlds, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, ifl, nrow, s->d_err.p);
             break;
         }
 #undef PFEM_GATHER

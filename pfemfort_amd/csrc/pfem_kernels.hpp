@@ -30,10 +30,6 @@ struct MeshDev {
     const int32_t *edof;
     const double *xyz;
     const double *soln;
-    // AoS copy for the gather assembly of the elasticity kinds: per element [conn0..3 | edof0..11],
-    // 16 ints -- one 64-B contiguous read per visit instead of 16 scattered 4-B reads from as many
-    // arrays (PMC: the SoA form missed L2 on 94 % of its sectors).  Null for the 1-dof kinds.
-    const int32_t *elemrec;
 };
 
 struct SellDev {
@@ -167,16 +163,6 @@ __global__ void __launch_bounds__(kBlock) k_localize_dofs(int32_t *edof, int64_t
     int64_t lo = 0, hi = n_ghost;
     while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ghost_gid[mid] < g) lo = mid + 1; else hi = mid; }
     edof[i] = static_cast<int32_t>(n_owned + lo);
-}
-
-__global__ void __launch_bounds__(kBlock) k_build_elemrec(MeshDev m, int32_t *rec)
-{
-    const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (e >= m.nElem) return;
-    const int w = 16;
-    int32_t *r = rec + e * w;
-    for (int a = 0; a < 4; ++a) r[a] = a < m.npe ? m.conn[a * m.nElem + e] : 0;
-    for (int i = 0; i < w - 4; ++i) r[4 + i] = i < m.nsize ? m.edof[i * m.nElem + e] : -1;
 }
 
 // ---------------------------------------------------------------------------
@@ -766,90 +752,81 @@ __global__ void __launch_bounds__(kBlock) k_assemble_elast2d(MeshDev m, SellDev 
         if (dof[i] >= 0) add_f64(&rhs[dof[i]], F[i]);
 }
 
-__global__ void __launch_bounds__(kBlock) k_gather_elast2d(MeshDev m, SellDev A, double *rhs, ElemPrm prm,
-                                                            const int64_t *__restrict__ inc_ptr,
-                                                            const int32_t *__restrict__ inc_cnt,
-                                                            const int32_t *__restrict__ inc_ea,
-                                                            const uint32_t *__restrict__ inc_slots, int *err)
+// Plane-stress sibling of k_gather_elast_rows: one thread per (node, dof) row, 2x2 node blocks.
+__global__ void __launch_bounds__(kBlock) k_gather_elast2d_rows(MeshDev m, SellDev A, double *rhs, ElemPrm prm,
+                                                                 const int64_t *__restrict__ inc_ptr,
+                                                                 const int32_t *__restrict__ inc_cnt,
+                                                                 const int4 *__restrict__ inc_rec,
+                                                                 const uint16_t *__restrict__ inc_flags,
+                                                                 const int32_t *__restrict__ node_row, int *err)
 {
-    const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (n >= m.nNode) return;
-    // incidence lists are wave-sliced like the matrix: entry j of node n sits at
-    // inc_ptr[n >> 6] + 64*j + (n & 63), so a wave reads one contiguous 256-B run per step
+    extern __shared__ __attribute__((aligned(16))) double lds_acc[];
+    const int T = blockDim.x;
+    const int64_t tid = static_cast<int64_t>(blockIdx.x) * T + threadIdx.x;
+    if (tid >= 2 * m.nNode) return;
+    const int64_t n = tid >> 1;
+    const int p = static_cast<int>(tid & 1);
+    const int row = node_row[tid];
+    if (row < 0) return;
     const int cnt = inc_cnt[n];
-    if (cnt == 0) return;
     const int64_t beg = inc_ptr[n >> 6] + (n & 63), end = beg + 64LL * cnt;
-    const int ea0 = inc_ea[beg];
-    int row[2];
-    int64_t base[2];
-    bool any = false;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        row[p] = m.edof[static_cast<int64_t>(2 * (ea0 & 3) + p) * m.nElem + (ea0 >> 2)];
-        base[p] = 0;
-        if (row[p] >= 0) { any = true; base[p] = A.slice_off[row[p] >> 6] + (row[p] & 63); }
-    }
-    if (!any) return;
+    const int64_t base = A.slice_off[row >> 6] + (row & 63);
+    const int len = A.rowlen[row];
+    double *acc = lds_acc + threadIdx.x;
+    for (int k = 0; k < len; ++k) acc[k * T] = 0.0;
     const Elast2dMat mat = elast2d_material(prm.ed[0], prm.ed[1]);
     double N[3];
     tria_shape_gp(N);
-    double facc[2] = {0.0, 0.0};
+    const double bf = p == 0 ? prm.ed[3] : prm.ed[4];
+    double facc = 0.0;
     for (int64_t t = beg; t < end; t += 64) {
-        const int ea = inc_ea[t];
-        const uint32_t slots = inc_slots[t];
-        const int64_t e = ea >> 2;
-        const int a = ea & 3;
-        int nd[3], dof[6];
+        const int4 rc = inc_rec[t];
+        const uint32_t flags = inc_flags[t];
+        const uint32_t slots = static_cast<uint32_t>(rc.w);
+        const int a = static_cast<int>((static_cast<uint32_t>(rc.x) >> 31) | ((static_cast<uint32_t>(rc.y) >> 31) << 1));
+        const int o0 = rc.x & 0x7fffffff, o1 = rc.y & 0x7fffffff, me = static_cast<int>(n);
+        const int nd[3] = {a == 0 ? me : o0, a == 0 ? o0 : (a == 1 ? me : o1), a == 2 ? me : o1};
         double x[3], y[3];
-        {
-            const int4 *rp = reinterpret_cast<const int4 *>(m.elemrec + e * 16);
-            const int4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-            nd[0] = r0.x; nd[1] = r0.y; nd[2] = r0.z;
-            dof[0] = r1.x; dof[1] = r1.y; dof[2] = r1.z; dof[3] = r1.w; dof[4] = r2.x; dof[5] = r2.y;
-        }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { x[i] = m.xyz[nd[i]]; y[i] = m.xyz[m.nNode + nd[i]]; }
+        for (int i = 0; i < 3; ++i) {
+            x[i] = m.xyz[nd[i]];
+            y[i] = m.xyz[m.nNode + nd[i]];
+        }
         TriaGeom g;
         tria_geometry(x, y, g);
         if (g.jac < 0.0) { atomicMax(err, PFEM_ERR_NEG_JAC); return; }
         const double dvol = 0.5 * (g.jac * prm.ed[2]);
-        double ax = 0.0, ay = 0.0, na = 0.0;
+        double ax = g.gx[0], ay = g.gy[0], na = N[0];
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 1; i < 3; ++i)
             if (i == a) { ax = g.gx[i]; ay = g.gy[i]; na = N[i]; }
         const double b4 = dvol * na;
-        double f[2] = {0.0 + b4 * prm.ed[3], 0.0 + b4 * prm.ed[4]};
+        double f = 0.0 + b4 * bf;
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
-            double kab[2][2], kba[2][2];
-            elast2d_block_v(ax, ay, g.gx[b], g.gy[b], mat, dvol, kab);   // Klocal(2a+p, 2b+q)
+            const uint32_t fb = (flags >> (2 * b)) & 3u;
+            if (fb != 0) {                 // lifting, q ascending:  Flocal(2a+p) -= Klocal(2a+p,2b+q) * u_D(2b+q)
+                double kab[2][2];
+                elast2d_block_v(ax, ay, g.gx[b], g.gy[b], mat, dvol, kab);
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    if (fb & (1u << q)) f = f - (p == 0 ? kab[0][q] : kab[1][q]) * m.soln[2LL * nd[b] + q];
+                if (fb == 3u) continue;
+            }
+            double kba[2][2];
             elast2d_block_v(g.gx[b], g.gy[b], ax, ay, mat, dvol, kba);   // Klocal(2b+q, 2a+p) = kba[q][p]
+            int k = static_cast<int>((slots >> (8 * b)) & 0xffu);
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-                if (dof[2 * b + q] < 0) {
-                    const double u = m.soln[2LL * nd[b] + q];
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) f[p] = f[p] - kab[p][q] * u;
-                }
-            if (dof[2 * b] < 0 && dof[2 * b + 1] < 0) continue;
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                if (row[p] < 0) continue;
-                int64_t s = base[p] + (static_cast<int64_t>((slots >> (8 * b)) & 0xffu) << 6);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    if (dof[2 * b + q] < 0) continue;
-                    A.vals[s] += kba[q][p];
-                    s += 64;
-                }
+            for (int q = 0; q < 2; ++q) {
+                if (fb & (1u << q)) continue;
+                acc[k * T] += p == 0 ? kba[q][0] : kba[q][1];
+                ++k;
             }
         }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) facc[p] += f[p];
+        facc += f;
     }
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-        if (row[p] >= 0) rhs[row[p]] = facc[p];
+    for (int k = 0; k < len; ++k) A.vals[base + (static_cast<int64_t>(k) << 6)] = acc[k * T];
+    rhs[row] = facc;
 }
 
 // Parity inspection: Ke/Fe of every element exactly as the assembly kernels compute them.
