@@ -174,7 +174,7 @@ struct pfem_solver {
     DevBuf<int4> d_inc_rec;        // packed {other nodes, slots} record per incidence (replaces ea + slots + elemrec)
     DevBuf<uint16_t> d_inc_flags;  // ... with the constrained-dof bits of the element (kinds with ndof > 1)
     DevBuf<int32_t> d_node_row;    // [nNode*ndof] matrix row of every node dof, -1 = no row
-    int elast_rows_threads = 0;    // block size of k_gather_elast_rows, 0 = not applicable
+    int rows_threads = 0;    // block size of the LDS-row gather kernels (256/128/64), 0 = rows too long
     DevBuf<uint32_t> d_inc_slots;  // ... and the matrix entry index of each element node inside the node's rows
     int64_t nnz = 0, n_slices = 0, stored = 0;
     int max_row_len = 0;
@@ -629,11 +629,11 @@ int build_incidence(pfem_solver *s)
     // The numeric kernels read packed per-incidence records.  The elasticity kinds accumulate one matrix row
     // per thread in LDS: the block size is the largest of 256/128/64 for which max_row_len*T doubles fit
     // 64 KiB; rows longer than that keep the scatter form.
-    s->elast_rows_threads = 0;
-    if (m.ndof > 1 && s->max_row_len > 0)
+    s->rows_threads = 0;
+    if (s->max_row_len > 0)
         for (int T = kBlock; T >= 64; T >>= 1)
-            if (static_cast<size_t>(s->max_row_len) * T * sizeof(double) <= 65536) { s->elast_rows_threads = T; break; }
-    if (m.ndof > 1 && s->elast_rows_threads == 0) {
+            if (static_cast<size_t>(s->max_row_len) * T * sizeof(double) <= 65536) { s->rows_threads = T; break; }
+    if (m.ndof > 1 && s->rows_threads == 0) {
         s->d_inc_slots.release();
         s->d_inc_ptr.release();
         s->d_inc_cnt.release();
@@ -750,10 +750,10 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
     PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
     PFEM_HIP(hipEventRecord(s->ev0, s->stream));
     const bool gather = m.nElem > 0 && s->assembly_mode == PFEM_ASSEMBLY_GATHER && s->have_incidence;
-    // rows of the 1-dof kinds are accumulated in LDS when maxlen*256 doubles fit 64 KiB
-    const size_t lds = static_cast<size_t>(s->max_row_len) * kBlock * sizeof(double);
-    const bool use_lds = m.ndof == 1 && s->max_row_len > 0 && lds <= 65536;
-    const bool elast_rows = m.ndof > 1 && s->elast_rows_threads > 0;
+    // rows are accumulated in LDS by blocks of T = 256/128/64 threads such that maxlen*T doubles fit 64 KiB
+    // (elasticity: otherwise scatter; 1-dof kinds: otherwise read-modify-write in global memory)
+    const bool use_lds = m.ndof == 1 && s->rows_threads > 0;
+    const bool elast_rows = m.ndof > 1 && s->rows_threads > 0;
     PFEM_TRY(zero_values(s, gather && (use_lds || elast_rows)));   // setZero, solverpetsc.F:222-246
     if (gather) {
         // gather form: one thread per node, no atomics, bit-reproducible
@@ -764,13 +764,13 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
         const int4 *irec = s->d_inc_rec.p;
         const uint16_t *ifl = s->d_inc_flags.p;
         const int32_t *nrow = s->d_node_row.p;
-#define PFEM_GATHER(KIND)                                                                                             \
-    if (use_lds) hipLaunchKernelGGL((k_gather_scalar<KIND, true>), grid, block, lds, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, nrow, s->d_err.p); \
-    else hipLaunchKernelGGL((k_gather_scalar<KIND, false>), grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, nrow, s->d_err.p)
-        const int T = s->elast_rows_threads;
+        const int T = s->rows_threads > 0 ? s->rows_threads : kBlock;
         const int64_t nthr = static_cast<int64_t>(m.ndof) * m.nNode;
-        const dim3 rgrid(static_cast<unsigned>(T > 0 ? (nthr + T - 1) / T : 1)), rblock(T > 0 ? T : 1);
-        const size_t rlds = static_cast<size_t>(s->max_row_len) * (T > 0 ? T : 1) * sizeof(double);
+        const dim3 rgrid(static_cast<unsigned>((nthr + T - 1) / T)), rblock(T);
+        const size_t rlds = static_cast<size_t>(s->max_row_len) * T * sizeof(double);
+#define PFEM_GATHER(KIND)                                                                                             \
+    if (use_lds) hipLaunchKernelGGL((k_gather_scalar<KIND, true>), rgrid, rblock, rlds, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, nrow, s->d_err.p); \
+    else hipLaunchKernelGGL((k_gather_scalar<KIND, false>), grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, nrow, s->d_err.p)
         switch (m.kind) {
         case PFEM_POISSON_TET: PFEM_GATHER(PFEM_POISSON_TET); break;
         case PFEM_POISSON_TRIA: PFEM_GATHER(PFEM_POISSON_TRIA); break;

@@ -510,9 +510,9 @@ __global__ void __launch_bounds__(kBlock) k_check_jacobian(MeshDev m, int *err)
     if (neg) atomicMax(err, PFEM_ERR_NEG_JAC);
 }
 
-// LDSACC: the node's row is accumulated in LDS (entry k of thread t at acc[k*256 + t]: conflict
-// free) and written out once, coalesced, instead of ~6 global read-modify-writes per entry; the
-// caller provides maxlen*256*8 bytes of dynamic LDS.  Same additions in the same order.
+// LDSACC: the node's row is accumulated in LDS (entry k of thread t at acc[k*T + t], T = block
+// size: conflict free) and written out once, coalesced, instead of ~6 global read-modify-writes
+// per entry; the caller provides maxlen*T*8 bytes of dynamic LDS.  Same additions in the same order.
 template <int KIND, bool LDSACC>
 __global__ void __launch_bounds__(kBlock) k_gather_scalar(MeshDev m, SellDev A, double *rhs, ElemPrm prm,
                                                            const int64_t *__restrict__ inc_ptr,
@@ -522,7 +522,8 @@ __global__ void __launch_bounds__(kBlock) k_gather_scalar(MeshDev m, SellDev A, 
 {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];
     constexpr int NPE = (KIND == PFEM_POISSON_TET) ? 4 : 3;
-    const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const int T = blockDim.x;                  // 256, or 128 / 64 when long rows need the LDS space
+    const int64_t n = static_cast<int64_t>(blockIdx.x) * T + threadIdx.x;
     if (n >= m.nNode) return;
     // incidence lists are wave-sliced like the matrix: entry j of node n sits at
     // inc_ptr[n >> 6] + 64*j + (n & 63), so a wave reads one contiguous 1-KiB run per step
@@ -536,7 +537,7 @@ __global__ void __launch_bounds__(kBlock) k_gather_scalar(MeshDev m, SellDev A, 
     double facc = 0.0;
     double *acc = lds_acc + threadIdx.x;
     if (LDSACC)
-        for (int k = 0; k < len; ++k) acc[k * kBlock] = 0.0;
+        for (int k = 0; k < len; ++k) acc[k * T] = 0.0;
     for (int64_t t = beg; t < end; t += 64) {
         const int4 rc = inc_rec[t];
         const uint32_t slots = static_cast<uint32_t>(rc.w);
@@ -590,12 +591,12 @@ __global__ void __launch_bounds__(kBlock) k_gather_scalar(MeshDev m, SellDev A, 
         for (int j = 0; j < NPE; ++j) {        // entry (row, dof_j) += Klocal(j,a)   (:851, row-major read)
             if (fixed[j]) continue;
             const uint32_t k = (slots >> (8 * j)) & 0xffu;
-            if (LDSACC) acc[k * kBlock] += Kcol[j];
+            if (LDSACC) acc[k * T] += Kcol[j];
             else A.vals[base + (static_cast<int64_t>(k) << 6)] += Kcol[j];
         }
     }
     if (LDSACC)
-        for (int k = 0; k < len; ++k) A.vals[base + (static_cast<int64_t>(k) << 6)] = acc[k * kBlock];
+        for (int k = 0; k < len; ++k) A.vals[base + (static_cast<int64_t>(k) << 6)] = acc[k * T];
     rhs[row] = facc;
 }
 

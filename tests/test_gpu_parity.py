@@ -112,6 +112,58 @@ def test_assembly_matches_oracle(name, mode, request):
         assert (dm.size_global, len(cols)) == (361, 2377)
 
 
+def _hub_mesh(npts, ndof):
+    """A hub node joined to every triangle of a triangulated sphere: the hub's matrix rows have
+    ndof*(npts+1) entries -- the long-row cases of the gather kernels (LDS blocks of 128 / 64 threads,
+    read-modify-write fallback, > 255 entries: scatter)."""
+    from scipy.spatial import ConvexHull
+    rng = np.random.default_rng(npts)
+    pts = rng.standard_normal((npts, 3))
+    pts /= np.linalg.norm(pts, axis=1)[:, None]
+    tri = ConvexHull(pts).simplices
+    xyz = np.round(np.vstack([pts, [[0.03, -0.02, 0.01]]]).T.copy(), 8)
+    conn = np.vstack([tri.T, np.full(len(tri), npts)]).astype(np.int32)
+    # orient every tet positively: Jac = det[(n1-n3); (n2-n3); (n4-n3)] (elementutilitiesbasisfuncs.F:493-514),
+    # and the reference STOPs on a negative one
+    a, b, c, d = (xyz[:, conn[i]] for i in range(4))
+    bad = np.einsum("ij,ij->j", np.cross((a - c).T, (b - c).T).T, d - c) < 0
+    conn[:2, bad] = conn[:2, bad][::-1]
+    bn = np.repeat(np.arange(0, npts, 7, dtype=np.int32), ndof)            # every 7th surface node clamped ...
+    bd = np.tile(np.arange(ndof, dtype=np.int32), len(bn) // ndof)
+    if ndof == 3:                                                           # ... some only partially, beyond three
+        keep = np.ones(len(bn), bool); keep[10::5] = False                  # fully fixed nodes (no rigid-body mode)
+        bn, bd = bn[keep], bd[keep]
+        first = np.repeat(np.array([1, 2, 3], np.int32), 3)
+        bn = np.concatenate([first, bn]); bd = np.concatenate([np.tile(np.arange(3, dtype=np.int32), 3), bd])
+    bv = 0.01 * np.random.default_rng(1).standard_normal(len(bn))
+    return H.Mesh(np.ascontiguousarray(xyz), np.ascontiguousarray(conn), bn, bd.astype(np.int32), bv)
+
+
+@pytest.mark.parametrize("npts,kind_name", [(24, "poisson"), (40, "poisson"), (100, "poisson"), (140, "poisson"), (200, "poisson"), (300, "poisson"),
+                                            (12, "elast"), (20, "elast"), (35, "elast"), (60, "elast"), (100, "elast")])
+def test_gather_assembly_long_rows(npts, kind_name):
+    from pfemfort_amd import drivers as D
+    kind, ed, ndof = (pf.POISSON_TET, H.POISSON_ELEMDATA, 1) if kind_name == "poisson" else (pf.ELAST_TET, H.ELAST_ELEMDATA, 3)
+    mesh = _hub_mesh(npts, ndof)
+    dm, conn_new, xyz_new, edof = D._setup(kind, mesh)
+    s = pf.PetscSolver().initialise(dm.size_global, dm.size_global)
+    s.uploadMesh(kind, conn_new, xyz_new, edof, dm.solnApplied)
+    s.buildPattern()
+    s.assemble(ed, H.TIMEDATA)                            # default mode: gather wherever it applies
+    prob = O.setup_problem(kind, _omesh(mesh), elemData=ed)
+    rowptr, cols, vals = s.getCSR()
+    assert np.array_equal(rowptr, prob.rowptr) and np.array_equal(cols, prob.cols)
+    maxlen = int(np.diff(rowptr).max())
+    assert maxlen >= ndof * (npts + 1 - len(np.unique(mesh.bc_node)))       # the hub row really is that long
+    if maxlen <= 255 and (ndof == 1 or maxlen <= 128):
+        assert np.array_equal(vals, prob.vals) and np.array_equal(s.getRHS(), prob.rhs)     # gather: bit-exact
+    else:                                                 # scatter fallback: atomics reorder the sums
+        assert np.abs(vals - prob.vals).max() <= K_RTOL * np.abs(prob.vals).max()
+        assert np.abs(s.getRHS() - prob.rhs).max() <= K_RTOL * max(np.abs(prob.rhs).max(), 1e-300)
+    its, reason, _ = s.factoriseAndSolve()
+    assert reason > 0
+
+
 def test_spmv_matches_oracle(tet10):
     s, dm = _device_problem(pf.POISSON_TET, tet10, H.POISSON_ELEMDATA)
     rowptr, cols, vals = s.getCSR()
