@@ -233,14 +233,20 @@ int pfem_assemble(pfem_solver *s, const double *elemData, const double *timeData
 #define PFEM_ASSEMBLY_GATHER 0
 #define PFEM_ASSEMBLY_SCATTER 1
 int pfem_solver_set_assembly_mode(pfem_solver *s, int mode);
-/* Column-index encoding streamed by the SpMV: AUTO uses 16-bit gaps between the ascending
- * columns of a row (4 + 2 B per entry instead of 4 B) whenever every gap of the pattern fits,
- * INT32 forces plain int32 columns.  Same products in the same order: bit-identical results. */
+/* Matrix encoding streamed by the SpMV.  AUTO uses 16-bit gaps between the ascending columns of a
+ * row (4 + 2 B per entry instead of 4 B) whenever every gap of the pattern fits, and on top of that
+ * serves consecutive rows with identical column sets (the dof rows of a node) from one lane with a
+ * shared column stream when the pattern has, on average, at least 2.75 such rows per group of 3;
+ * GAPS16 forces the plain row form with 16-bit gaps, INT32 plain int32 columns.  Every row sums
+ * the same products in the same order: y is bit-identical in all three. */
 #define PFEM_SPMV_AUTO 0
 #define PFEM_SPMV_INT32 1
+#define PFEM_SPMV_GAPS16 2
 int pfem_solver_set_spmv_format(pfem_solver *s, int format);
 /* 16 if the SpMV currently streams 16-bit column gaps, 32 for int32 columns */
 int pfem_solver_get_spmv_format(pfem_solver *s, int *bits_per_column);
+/* rows served by one lane of the current SpMV: 3 in the row-grouped form, else 1 */
+int pfem_solver_get_spmv_row_group(pfem_solver *s, int *rows_per_lane);
 /* Specified nodal forces after the element loop (VecSetValue(rhsVec,row,fact,ADD_VALUES),
  * tetraelasticityparallelimpl1.F:971-982) for the batched path: GLOBAL free-dof ids (i.e.
  * NodeDofArrayNew(n,d)-1; the reference's own row formula ignores constrained dofs);

@@ -187,6 +187,28 @@ struct pfem_solver {
     DevBuf<int32_t> d_col0;
     DevBuf<uint32_t> d_dwords;
     DevBuf<int64_t> d_slice_doff;
+    // SpMV-only row-grouped representation (k_spmvg): rows with identical column sets share one lane
+    bool grouped = false;
+    bool group_vals_stale = true;
+    int64_t n_groups = 0, n_gslices = 0, g_stored = 0;
+    DevBuf<int32_t> d_group_row0, d_gcol0;
+    DevBuf<int64_t> d_gslice_off, d_gslice_doff;
+    DevBuf<uint32_t> d_gdwords;
+    DevBuf<double> d_gvals;
+    bool use_grouped() const { return grouped && spmv_format == PFEM_SPMV_AUTO; }
+    SellGDev sellg() const
+    {
+        SellGDev G;
+        G.n_groups = n_groups;
+        G.n_gslices = n_gslices;
+        G.group_row0 = d_group_row0.p;
+        G.gslice_off = d_gslice_off.p;
+        G.vals = d_gvals.p;
+        G.col0 = d_gcol0.p;
+        G.dwords = d_gdwords.p;
+        G.gslice_doff = d_gslice_doff.p;
+        return G;
+    }
 
     // vectors
     DevBuf<double> d_rhs, d_x, d_r, d_p, d_w, d_dinv;
@@ -469,6 +491,7 @@ int alloc_vectors(pfem_solver *s)
 }
 
 int build_cols16(pfem_solver *s);
+int build_groups(pfem_solver *s);
 
 // keys: device array of `nkeys` (row<<32|col) keys, kNoKey = ignore.  Consumed.
 int pattern_from_keys(pfem_solver *s, DevBuf<uint64_t> &keys, int64_t nkeys)
@@ -545,6 +568,7 @@ int pattern_from_keys(pfem_solver *s, DevBuf<uint64_t> &keys, int64_t nkeys)
     PFEM_HIP(hipStreamSynchronize(s->stream));
     keys.release();
     PFEM_TRY(build_cols16(s));
+    PFEM_TRY(build_groups(s));
     s->have_pattern = true;
     s->rhs_summed = false;
     s->status = PFEM_PATTERN_OK;
@@ -952,14 +976,114 @@ int build_cols16(pfem_solver *s)
     return PFEM_OK;
 }
 
-// the CG / standalone SpMV launch: 16-bit gaps when available and not disabled, else int32
+// Row groups for k_spmvg: consecutive rows with identical column sets, at most kGroupRows per group.  Kept only
+// when it pays (groups nearly full on average, i.e. three dofs per node) and 16-bit gaps apply.
+int build_groups(pfem_solver *s)
+{
+    s->grouped = false;
+    s->group_vals_stale = true;
+    const int64_t n = s->n_loc;
+    if (!s->cols16 || n < 2 || n > INT_MAX) return PFEM_OK;
+    DevBuf<int32_t> run_start;
+    DevBuf<char> flag, temp;
+    DevBuf<int> d_num;
+    PFEM_TRY(run_start.alloc(static_cast<size_t>(n)));
+    PFEM_TRY(flag.alloc(static_cast<size_t>(n)));
+    PFEM_TRY(d_num.alloc(1));
+    hipLaunchKernelGGL(k_group_breaks, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->sell(), run_start.p);
+    PFEM_TRY(check_kernel("k_group_breaks"));
+    size_t tb = 0;
+    const int ni = static_cast<int>(n);
+    PFEM_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, tb, run_start.p, run_start.p, hipcub::Max(), ni, s->stream));
+    PFEM_TRY(temp.alloc(tb));
+    PFEM_HIP(hipcub::DeviceScan::InclusiveScan(temp.p, tb, run_start.p, run_start.p, hipcub::Max(), ni, s->stream));
+    hipLaunchKernelGGL(k_group_flags, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, static_cast<const int32_t *>(run_start.p), n,
+                       flag.p);
+    PFEM_TRY(check_kernel("k_group_flags"));
+    PFEM_TRY(s->d_group_row0.alloc(static_cast<size_t>(n) + 1));
+    hipcub::CountingInputIterator<int32_t> iota(0);
+    size_t tb2 = 0;
+    PFEM_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb2, iota, flag.p, s->d_group_row0.p, d_num.p, ni, s->stream));
+    if (tb2 > temp.n) { PFEM_HIP(hipStreamSynchronize(s->stream)); PFEM_TRY(temp.alloc(tb2)); }
+    PFEM_HIP(hipcub::DeviceSelect::Flagged(temp.p, tb2, iota, flag.p, s->d_group_row0.p, d_num.p, ni, s->stream));
+    int ng = 0;
+    PFEM_HIP(hipMemcpyAsync(&ng, d_num.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    // a lane streams kGroupRows value planes whatever the size of its group: with a rows per group on average the
+    // grouped form moves (8*kGroupRows + 2)/a bytes per entry against 10 in the row form -> worth it from a = 2.75
+    if (ng <= 0 || 11LL * ng > 4LL * n) {
+        s->d_group_row0.release();
+        return PFEM_OK;
+    }
+    const int32_t sentinel = static_cast<int32_t>(n);
+    PFEM_HIP(hipMemcpyAsync(s->d_group_row0.p + ng, &sentinel, sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+    s->n_groups = ng;
+    s->n_gslices = (s->n_groups + 63) / 64;
+    DevBuf<int64_t> entries, words;
+    PFEM_TRY(entries.alloc(static_cast<size_t>(s->n_gslices) + 1));
+    PFEM_TRY(words.alloc(static_cast<size_t>(s->n_gslices) + 1));
+    PFEM_TRY(s->d_gslice_off.alloc(static_cast<size_t>(s->n_gslices) + 1));
+    PFEM_TRY(s->d_gslice_doff.alloc(static_cast<size_t>(s->n_gslices) + 1));
+    hipLaunchKernelGGL(k_gslice_sizes, dim3(grid_for(s->n_gslices * 64)), dim3(kBlock), 0, s->stream,
+                       static_cast<const int32_t *>(s->d_group_row0.p), static_cast<const int32_t *>(s->d_rowlen.p), s->n_groups,
+                       s->n_gslices, entries.p);
+    PFEM_TRY(check_kernel("k_gslice_sizes"));
+    const int nsl = static_cast<int>(s->n_gslices + 1);
+    size_t tb3 = 0;
+    PFEM_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, entries.p, s->d_gslice_off.p, nsl, s->stream));
+    if (tb3 > temp.n) { PFEM_HIP(hipStreamSynchronize(s->stream)); PFEM_TRY(temp.alloc(tb3)); }
+    PFEM_HIP(hipcub::DeviceScan::ExclusiveSum(temp.p, tb3, entries.p, s->d_gslice_off.p, nsl, s->stream));
+    hipLaunchKernelGGL(k_cols16_sizes, dim3(grid_for(s->n_gslices + 1)), dim3(kBlock), 0, s->stream,
+                       static_cast<const int64_t *>(s->d_gslice_off.p), s->n_gslices, words.p);
+    PFEM_TRY(check_kernel("k_cols16_sizes"));
+    PFEM_HIP(hipcub::DeviceScan::ExclusiveSum(temp.p, tb3, words.p, s->d_gslice_doff.p, nsl, s->stream));
+    int64_t tot_e = 0, tot_w = 0;
+    PFEM_HIP(hipMemcpyAsync(&tot_e, s->d_gslice_off.p + s->n_gslices, sizeof(int64_t), hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipMemcpyAsync(&tot_w, s->d_gslice_doff.p + s->n_gslices, sizeof(int64_t), hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    s->g_stored = tot_e;
+    PFEM_TRY(s->d_gcol0.alloc(static_cast<size_t>(s->n_gslices) * 64));
+    PFEM_TRY(s->d_gdwords.alloc(static_cast<size_t>(std::max<int64_t>(tot_w, 1))));
+    PFEM_TRY(s->d_gvals.alloc(static_cast<size_t>(std::max<int64_t>(tot_e, 1)) * kGroupRows));
+    hipLaunchKernelGGL(k_group_cols_fill, dim3(grid_for(s->n_gslices * 64)), dim3(kBlock), 0, s->stream, s->sell(),
+                       static_cast<const int32_t *>(s->d_group_row0.p), s->n_groups, s->n_gslices,
+                       static_cast<const int64_t *>(s->d_gslice_off.p), static_cast<const int64_t *>(s->d_gslice_doff.p),
+                       s->d_gcol0.p, s->d_gdwords.p);
+    PFEM_TRY(check_kernel("k_group_cols_fill"));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    s->grouped = true;
+    return PFEM_OK;
+}
+
+// grouped copy of the current matrix values (the row form is what assembly writes)
+int refresh_group_vals(pfem_solver *s)
+{
+    if (!s->use_grouped() || !s->group_vals_stale) return PFEM_OK;
+    hipLaunchKernelGGL(k_group_vals, dim3(grid_for(s->n_gslices * 64)), dim3(kBlock), 0, s->stream, s->sell(), s->sellg(),
+                       s->d_gvals.p);
+    PFEM_TRY(check_kernel("k_group_vals"));
+    s->group_vals_stale = false;
+    return PFEM_OK;
+}
+
+inline unsigned spmv_blocks(const pfem_solver *s)
+{
+    return s->use_grouped() ? spmv_grid(s->n_gslices) : spmv_grid(s->n_slices);
+}
+
+// the CG / standalone SpMV launch: row-grouped form when the pattern has it, else 16-bit gaps when available
+// and not disabled, else int32
 template <bool WITH_DOT>
 void launch_spmv(pfem_solver *s, const double *x, double *y, int64_t n_dot, double *partial, const CgCtl *ctl,
                  hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
-    const dim3 grid(spmv_grid(s->n_slices)), block(kBlock);
+    const dim3 grid(spmv_blocks(s)), block(kBlock);
     SellDev A = s->sell();
-    if (s->cols16 && s->spmv_format != PFEM_SPMV_INT32) {
+    if (s->use_grouped()) {
+        SellGDev G = s->sellg();
+        if (e0) hipExtLaunchKernelGGL(k_spmvg<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, G, s->n_loc, x, y, n_dot, partial, ctl);
+        else hipLaunchKernelGGL(k_spmvg<WITH_DOT>, grid, block, 0, s->stream, G, s->n_loc, x, y, n_dot, partial, ctl);
+    } else if (s->cols16 && s->spmv_format != PFEM_SPMV_INT32) {
         Sell16Dev C{s->d_col0.p, s->d_dwords.p, s->d_slice_doff.p};
         if (e0) hipExtLaunchKernelGGL(k_spmv16<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, A, C, x, y, n_dot, partial, ctl);
         else hipLaunchKernelGGL(k_spmv16<WITH_DOT>, grid, block, 0, s->stream, A, C, x, y, n_dot, partial, ctl);
@@ -978,9 +1102,16 @@ extern "C" int pfem_solver_get_spmv_format(pfem_solver *s, int *bits_per_column)
     return PFEM_OK;
 }
 
+extern "C" int pfem_solver_get_spmv_row_group(pfem_solver *s, int *rows_per_lane)
+{
+    if (!s || !rows_per_lane) return PFEM_ERR_ARG;
+    *rows_per_lane = s->use_grouped() ? kGroupRows : 1;
+    return PFEM_OK;
+}
+
 extern "C" int pfem_solver_set_spmv_format(pfem_solver *s, int format)
 {
-    if (!s || (format != PFEM_SPMV_AUTO && format != PFEM_SPMV_INT32)) return PFEM_ERR_ARG;
+    if (!s || (format != PFEM_SPMV_AUTO && format != PFEM_SPMV_INT32 && format != PFEM_SPMV_GAPS16)) return PFEM_ERR_ARG;
     s->spmv_format = format;
     return PFEM_OK;
 }
@@ -992,6 +1123,8 @@ extern "C" int pfem_spmv(pfem_solver *s, const double *x, double *y)
     PFEM_TRY(use_device(s));
     const size_t nb = sizeof(double) * static_cast<size_t>(s->n_loc);
     PFEM_HIP(hipMemcpyAsync(s->d_p.p, x, nb, hipMemcpyHostToDevice, s->stream));
+    s->group_vals_stale = true;
+    PFEM_TRY(refresh_group_vals(s));
     launch_spmv<false>(s, s->d_p.p, s->d_w.p, 0, nullptr, nullptr);
     PFEM_TRY(check_kernel("k_spmv"));
     PFEM_HIP(hipMemcpyAsync(y, s->d_w.p, nb, hipMemcpyDeviceToHost, s->stream));
@@ -1004,6 +1137,8 @@ extern "C" int pfem_bench_spmv(pfem_solver *s, int reps, double *ms_per_launch)
     if (!s || reps < 1 || !ms_per_launch) return PFEM_ERR_ARG;
     if (!s->have_pattern) return PFEM_ERR_STATE;
     PFEM_TRY(use_device(s));
+    s->group_vals_stale = true;
+    PFEM_TRY(refresh_group_vals(s));
     // warm-up launch, then `reps` timed ones with x = rhs (any resident vector)
     launch_spmv<false>(s, s->d_rhs.p, s->d_w.p, 0, nullptr, nullptr);
     PFEM_HIP(hipEventRecord(s->ev0, s->stream));
@@ -1129,7 +1264,9 @@ int run_pcg(pfem_solver *s)
 {
     const int64_t n = s->n_loc;
     const bool multi = s->nranks > 1;
-    const unsigned gv = vec_grid(n), gs = spmv_grid(s->n_slices);
+    s->group_vals_stale = true;            // the row form may have been re-assembled since the last solve
+    PFEM_TRY(refresh_group_vals(s));
+    const unsigned gv = vec_grid(n), gs = spmv_blocks(s);
     const dim3 block(kBlock);
     SellDev A = s->sell();
     if (s->d_part_pw.n < gs) PFEM_TRY(s->d_part_pw.alloc(gs));

@@ -1109,6 +1109,208 @@ __global__ void __launch_bounds__(kBlock) k_spmv16(SellDev A, Sell16Dev C, const
     }
 }
 
+// ---------------------------------------------------------------------------
+// Row-grouped SpMV (problems with several dofs per node).  Consecutive rows with IDENTICAL column
+// sets -- the dof rows of one node -- form a group of up to kGroupRows rows served by ONE lane: the
+// column stream (first column + 16-bit gaps, as above) and the x gather are shared by the rows of
+// the group, so an entry costs 8 B + 2/3 B instead of 8 + 2 B and a third of the gather
+// instructions.  Groups are found from the pattern alone (k_group_breaks), no mesh needed; the
+// values are a regrouped copy of the matrix made at the start of a solve (k_group_vals).  Every
+// row still accumulates its products in ascending column order: y is bit-identical to k_spmv16.
+// ---------------------------------------------------------------------------
+constexpr int kGroupRows = 3;
+
+struct SellGDev {
+    int64_t n_groups, n_gslices;
+    const int32_t *group_row0;   // [n_groups+1] first row of every group (sentinel: n_rows)
+    const int64_t *gslice_off;   // [n_gslices+1] entries per plane, 64 * width of the slice of 64 groups
+    const double *vals;          // entry k of row p of lane l: vals[kGroupRows*off + (kGroupRows*k + p)*64 + l]
+    const int32_t *col0;         // [64 * n_gslices]
+    const uint32_t *dwords;      // packed gaps of the group's column list
+    const int64_t *gslice_doff;  // [n_gslices+1] in words
+};
+
+// run_start[r] = r if row r cannot share a group with row r-1 (different length or columns), else 0;
+// an inclusive max-scan then gives every row the first row of its run
+__global__ void __launch_bounds__(kBlock) k_group_breaks(SellDev A, int32_t *run_start)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (r >= A.n_rows) return;
+    bool brk = r == 0;
+    if (!brk) {
+        const int len = A.rowlen[r];
+        brk = len != A.rowlen[r - 1] || len == 0;
+        const int64_t b1 = A.slice_off[r >> 6] + (r & 63), b0 = A.slice_off[(r - 1) >> 6] + ((r - 1) & 63);
+        for (int k = 0; k < len && !brk; ++k) brk = A.cols[b1 + 64LL * k] != A.cols[b0 + 64LL * k];
+    }
+    run_start[r] = brk ? static_cast<int32_t>(r) : 0;
+}
+
+__global__ void __launch_bounds__(kBlock) k_group_flags(const int32_t *run_start, int64_t n, char *flag)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (r < n) flag[r] = ((r - run_start[r]) % kGroupRows) == 0;
+}
+
+// width of every slice of 64 groups (the longest row among them), as 64*width entries per plane
+__global__ void __launch_bounds__(kBlock) k_gslice_sizes(const int32_t *group_row0, const int32_t *rowlen, int64_t n_groups,
+                                                          int64_t n_gslices, int64_t *entries)
+{
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    int c = g < n_groups ? rowlen[group_row0[g]] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c = max(c, __shfl_xor(c, o, 64));
+    const int64_t gs = g >> 6;
+    if ((threadIdx.x & 63) == 0 && gs < n_gslices) entries[gs] = 64LL * c;
+    if (g == 0) entries[n_gslices] = 0;
+}
+
+// first column + packed 16-bit gaps of every group's column list (that of its first row)
+__global__ void __launch_bounds__(kBlock) k_group_cols_fill(SellDev A, const int32_t *group_row0, int64_t n_groups,
+                                                             int64_t n_gslices, const int64_t *gslice_off,
+                                                             const int64_t *gslice_doff, int32_t *col0, uint32_t *dwords)
+{
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t gs = g >> 6;
+    if (gs >= n_gslices) return;
+    const int lane = static_cast<int>(g & 63);
+    const int width = static_cast<int>((gslice_off[gs + 1] - gslice_off[gs]) >> 6);
+    int len = 0;
+    const int32_t *cp = A.cols;
+    if (g < n_groups) {
+        const int64_t r = group_row0[g];
+        len = A.rowlen[r];
+        cp = A.cols + A.slice_off[r >> 6] + (r & 63);
+    }
+    int prev = len > 0 ? cp[0] : 0;
+    col0[g] = prev;
+    uint32_t *wp = dwords + gslice_doff[gs] + lane;
+    for (int j = 0; 2 * j + 1 < width; ++j) {
+        uint32_t w = 0;
+        for (int h = 0; h < 2; ++h) {
+            const int k = 2 * j + 1 + h;
+            if (k < len) {
+                const int c = cp[64LL * k];
+                w |= (static_cast<uint32_t>(c - prev) & 0xffffu) << (16 * h);   // fits: checked on the row form
+                prev = c;
+            }
+        }
+        wp[64LL * j] = w;
+    }
+}
+
+// matrix values, row form -> grouped form (zero padded); once per solve
+__global__ void __launch_bounds__(kBlock) k_group_vals(SellDev A, SellGDev G, double *out)
+{
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t gs = g >> 6;
+    if (gs >= G.n_gslices) return;
+    const int lane = static_cast<int>(g & 63);
+    const int64_t off = G.gslice_off[gs];
+    const int width = static_cast<int>((G.gslice_off[gs + 1] - off) >> 6);
+    double *op = out + kGroupRows * off + lane;
+    int64_t r0 = 0;
+    int sz = 0, len = 0;
+    if (g < G.n_groups) { r0 = G.group_row0[g]; sz = G.group_row0[g + 1] - static_cast<int>(r0); len = A.rowlen[r0]; }
+#pragma unroll
+    for (int p = 0; p < kGroupRows; ++p) {
+        const int64_t r = r0 + p;
+        const double *vp = A.vals + A.slice_off[(p < sz ? r : r0) >> 6] + ((p < sz ? r : r0) & 63);
+        for (int k = 0; k < width; ++k)
+            op[(static_cast<int64_t>(kGroupRows) * k + p) * 64] = (p < sz && k < len) ? vp[64LL * k] : 0.0;
+    }
+}
+
+// W words = 2W consecutive entries of kGroupRows rows (caller guarantees 2*(j+W) < width)
+template <int W>
+__device__ __forceinline__ void spmvg_trip(const double *__restrict__ vp, const uint32_t *__restrict__ wp,
+                                           const double *__restrict__ x, int &j, int &c, double (&acc)[kGroupRows])
+{
+    uint32_t w[W];
+    double v[2 * W][kGroupRows], xv[2 * W];
+#pragma unroll
+    for (int t = 0; t < W; ++t) w[t] = __builtin_nontemporal_load(wp + 64 * (j + t));
+#pragma unroll
+    for (int t = 0; t < 2 * W; ++t)
+#pragma unroll
+        for (int p = 0; p < kGroupRows; ++p)
+            v[t][p] = __builtin_nontemporal_load(vp + 64 * (kGroupRows * (2 * j + 1 + t) + p));
+#pragma unroll
+    for (int t = 0; t < W; ++t) {
+        const int c0 = c + static_cast<int>(w[t] & 0xffffu);
+        const int c1 = c0 + static_cast<int>(w[t] >> 16);
+        xv[2 * t] = x[c0];
+        xv[2 * t + 1] = x[c1];
+        c = c1;
+    }
+#pragma unroll
+    for (int t = 0; t < 2 * W; ++t)
+#pragma unroll
+        for (int p = 0; p < kGroupRows; ++p) acc[p] = __builtin_fma(v[t][p], xv[t], acc[p]);
+    j += W;
+}
+
+template <bool WITH_DOT>
+__global__ void __launch_bounds__(kBlock) k_spmvg(SellGDev G, int64_t n_rows, const double *__restrict__ x,
+                                                   double *__restrict__ y, int64_t n_dot, double *partial, const CgCtl *ctl)
+{
+    __shared__ double sm[4];
+    if (WITH_DOT && ctl->flag != 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t gs = (static_cast<int64_t>(blockIdx.x) << 2) + wave;
+    double dot = 0.0;
+    if (gs < G.n_gslices) {
+        const int64_t off = G.gslice_off[gs];
+        const int width = static_cast<int>((G.gslice_off[gs + 1] - off) >> 6);
+        const double *__restrict__ vp = G.vals + kGroupRows * off + lane;
+        const uint32_t *__restrict__ wp = G.dwords + G.gslice_doff[gs] + lane;
+        int c = __builtin_nontemporal_load(G.col0 + (gs << 6) + lane);
+        double acc[kGroupRows];
+#pragma unroll
+        for (int p = 0; p < kGroupRows; ++p) acc[p] = 0.0;
+        if (width > 0) {
+            const double x0 = x[c];
+#pragma unroll
+            for (int p = 0; p < kGroupRows; ++p) acc[p] = __builtin_nontemporal_load(vp + 64 * p) * x0;
+        }
+        const int nw = width / 2;
+        int j = 0;
+        while (2 * (j + 4) < width) spmvg_trip<4>(vp, wp, x, j, c, acc);
+        if (2 * (j + 2) < width) spmvg_trip<2>(vp, wp, x, j, c, acc);
+        for (; j < nw; ++j) {
+            const uint32_t w0 = __builtin_nontemporal_load(wp + 64 * j);
+            const int c0 = c + static_cast<int>(w0 & 0xffffu);
+            const int c1 = c0 + static_cast<int>(w0 >> 16);
+            const double x0 = x[c0];
+#pragma unroll
+            for (int p = 0; p < kGroupRows; ++p)
+                acc[p] = __builtin_fma(__builtin_nontemporal_load(vp + 64 * (kGroupRows * (2 * j + 1) + p)), x0, acc[p]);
+            if (2 * j + 2 < width) {
+                const double x1 = x[c1];
+#pragma unroll
+                for (int p = 0; p < kGroupRows; ++p)
+                    acc[p] = __builtin_fma(__builtin_nontemporal_load(vp + 64 * (kGroupRows * (2 * j + 2) + p)), x1, acc[p]);
+            }
+            c = c1;
+        }
+        const int64_t g = (gs << 6) + lane;
+        if (g < G.n_groups) {
+            const int64_t r0 = G.group_row0[g];
+            const int sz = G.group_row0[g + 1] - static_cast<int>(r0);
+#pragma unroll
+            for (int p = 0; p < kGroupRows; ++p)
+                if (p < sz) {
+                    y[r0 + p] = acc[p];
+                    if (WITH_DOT && r0 + p < n_dot) dot = __builtin_fma(x[r0 + p], acc[p], dot);
+                }
+        }
+    }
+    if (WITH_DOT) {
+        const double t = block_sum(dot, sm);
+        if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    }
+}
+
 // One block of 1024 threads: out[j] = sum of part_j[0..n) for up to two partial arrays, in a
 // fixed association order (bitwise reproducible run to run).
 __global__ void __launch_bounds__(1024) k_reduce_partials(const double *part0, const double *part1, int n, double *out,

@@ -160,12 +160,19 @@ class PetscSolver:
                 "pfem_solver_set_assembly_mode")
 
     def setSpmvFormat(self, fmt):
-        """"auto" (16-bit column gaps when they fit) or "int32"."""
-        L.check(L.lib().pfem_solver_set_spmv_format(self._h, {"auto": 0, "int32": 1}[fmt]), "pfem_solver_set_spmv_format")
+        """"auto" (16-bit column gaps when they fit, row-grouped when the pattern has multi-dof nodes),
+        "gaps16" (16-bit gaps, one row per lane) or "int32"."""
+        L.check(L.lib().pfem_solver_set_spmv_format(self._h, {"auto": 0, "int32": 1, "gaps16": 2}[fmt]), "pfem_solver_set_spmv_format")
 
     def spmvColumnBits(self):
         b = C.c_int(0)
         L.check(L.lib().pfem_solver_get_spmv_format(self._h, C.byref(b)), "pfem_solver_get_spmv_format")
+        return b.value
+
+    def spmvRowGroup(self):
+        """Rows served by one lane of the current SpMV (3: row-grouped form)."""
+        b = C.c_int(0)
+        L.check(L.lib().pfem_solver_get_spmv_row_group(self._h, C.byref(b)), "pfem_solver_get_spmv_row_group")
         return b.value
 
     def assemble(self, elemData, timeData):

@@ -174,15 +174,25 @@ def test_spmv_matches_oracle(tet10):
     assert np.abs(y - yo).max() <= 1e-13 * np.abs(yo).max()
 
 
-@pytest.mark.parametrize("name", ["tet10", "beam", "tria20"])
+@pytest.mark.parametrize("name", ["tet10", "beam", "beam_partial", "tria20", "cook"])
 def test_spmv_column_formats_bit_identical(name, request):
-    """16-bit column gaps (auto) vs int32 columns: same products, same order, same bits."""
-    mesh = request.getfixturevalue(name)
+    """Row-grouped / 16-bit column gaps / int32 columns: same products, same order, same bits."""
+    mesh = request.getfixturevalue(name.split("_")[0])
     kind, ed = {"tet10": (pf.POISSON_TET, H.POISSON_ELEMDATA), "beam": (pf.ELAST_TET, H.ELAST_ELEMDATA),
+                "beam_partial": (pf.ELAST_TET, H.ELAST_ELEMDATA), "cook": (pf.ELAST_TRIA, H.ELAST2D_ELEMDATA),
                 "tria20": (pf.POISSON_TRIA, np.array([1.0, 1.0]))}[name]
+    if name == "beam_partial":     # nodes with one or two free dofs: groups of 1, 2 and 3 rows
+        rng = np.random.default_rng(2)
+        keep = rng.random(len(mesh.bc_node)) < 0.6
+        extra = np.arange(40, 70, dtype=np.int32)
+        mesh = H.Mesh(mesh.xyz, mesh.conn, np.concatenate([mesh.bc_node[keep], extra]),
+                      np.concatenate([mesh.bc_dof[keep], extra % 3]).astype(np.int32), np.zeros(keep.sum() + 30))
     s, dm = _device_problem(kind, mesh, ed)
     x = np.random.default_rng(1).standard_normal(dm.size_global)
     y_auto = s.spmv(x)
+    assert s.spmvRowGroup() == (3 if name.startswith("beam") else 1)       # 2-dof nodes: groups of 2 (< 2 rows/lane saved) -> row form
+    s.setSpmvFormat("gaps16")
+    assert s.spmvRowGroup() == 1 and np.array_equal(y_auto, s.spmv(x))
     s.setSpmvFormat("int32")
     y_32 = s.spmv(x)
     assert np.array_equal(y_auto, y_32)

@@ -11,7 +11,7 @@ t = time.time(); mesh = H.gen_box_tets(-0.5, 0.5, nx, 0.0, 6.0, ny, -0.5, 0.5, n
 dm, conn, xyz, edof = D._setup(pf.ELAST_TET, mesh); print(f"setup {time.time()-t:.2f}s nodes {mesh.nNode} elems {mesh.nElem} N {dm.size_global}")
 s = pf.PetscSolver().initialise(dm.size_global, dm.size_global); s.setTolerances(rtol=rtol, maxits=100000)
 s.uploadMesh(pf.ELAST_TET, conn, xyz, edof, dm.solnApplied)
-t = time.time(); s.buildPattern(); print(f"pattern {time.time()-t:.2f}s", s.matrixInfo(), "column bits", s.spmvColumnBits())
+t = time.time(); s.buildPattern(); print(f"pattern {time.time()-t:.2f}s", s.matrixInfo(), "column bits", s.spmvColumnBits(), "rows per lane", s.spmvRowGroup())
 for mode in ("gather", "scatter"):
     s.setAssemblyMode(mode); s.assemble(H.ELAST_ELEMDATA, H.TIMEDATA); print(mode, "assemble ms", s.timings()["assemble_ms"])
 s.setAssemblyMode("gather"); s.assemble(H.ELAST_ELEMDATA, H.TIMEDATA)
