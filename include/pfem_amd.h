@@ -247,6 +247,15 @@ int pfem_solver_set_spmv_format(pfem_solver *s, int format);
 int pfem_solver_get_spmv_format(pfem_solver *s, int *bits_per_column);
 /* rows served by one lane of the current SpMV: 3 in the row-grouped form, else 1 */
 int pfem_solver_get_spmv_row_group(pfem_solver *s, int *rows_per_lane);
+/* Preconditioner of the CG (PCSetType, solverpetsc.F:206).  JACOBI (default) is the diagonal scaling
+ * BASELINE's north_star names.  NODE_BLOCK_JACOBI (PETSc: -pc_type pbjacobi) inverts the
+ * diagonal block of every row group of the SpMV (the 1..3 dof rows of a node); it takes effect when the
+ * pattern has such groups (3-dof problems) and the solver runs on one rank, otherwise JACOBI stays in
+ * effect -- pfem_solver_get_preconditioner reports which one the next solve uses. */
+#define PFEM_PC_JACOBI 0
+#define PFEM_PC_NODE_BLOCK_JACOBI 1
+int pfem_solver_set_preconditioner(pfem_solver *s, int pc);
+int pfem_solver_get_preconditioner(pfem_solver *s, int *pc_in_effect);
 /* Specified nodal forces after the element loop (VecSetValue(rhsVec,row,fact,ADD_VALUES),
  * tetraelasticityparallelimpl1.F:971-982) for the batched path: GLOBAL free-dof ids (i.e.
  * NodeDofArrayNew(n,d)-1; the reference's own row formula ignores constrained dofs);

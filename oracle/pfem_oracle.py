@@ -300,6 +300,62 @@ def pcg_jacobi(rowptr, cols, vals, b, rtol=1e-5, abstol=1e-50, dtol=1e5, maxits=
     return x, its.value, reason.value, rn.value, hist[:min(hist_len, its.value + 1)]
 
 
+def row_groups(rowptr, cols, max_rows=3):
+    """First rows of the row groups a node-block preconditioner works on: consecutive rows with identical
+    column sets (the dof rows of a node), at most ``max_rows`` per group; last entry = number of rows."""
+    N = len(rowptr) - 1
+    starts = []
+    run0 = 0
+    for r in range(N):
+        brk = r == 0 or (rowptr[r + 1] - rowptr[r]) != (rowptr[r] - rowptr[r - 1]) or rowptr[r + 1] == rowptr[r] or \
+            not np.array_equal(cols[rowptr[r]:rowptr[r + 1]], cols[rowptr[r - 1]:rowptr[r]])
+        if brk:
+            run0 = r
+        if (r - run0) % max_rows == 0:
+            starts.append(r)
+    return np.array(starts + [N], np.int64)
+
+
+def pcg_block_jacobi(rowptr, cols, vals, b, groups, rtol=1e-5, abstol=1e-50, dtol=1e5, maxits=10000):
+    """PETSc's CG with -pc_type pbjacobi restated in numpy (test sizes only): M = the diagonal blocks of A
+    over ``groups``; same preconditioned-norm convergence test as pcg_jacobi (KSPConvergedDefault)."""
+    import scipy.sparse as sp
+    N = len(rowptr) - 1
+    A = sp.csr_matrix((vals, cols, rowptr), shape=(N, N))
+    inv = []
+    for g in range(len(groups) - 1):
+        i0, i1 = int(groups[g]), int(groups[g + 1])
+        inv.append(np.linalg.inv(A[i0:i1, i0:i1].toarray()))
+
+    def apply(r):
+        z = np.empty_like(r)
+        for g, Bi in enumerate(inv):
+            i0, i1 = int(groups[g]), int(groups[g + 1])
+            z[i0:i1] = Bi @ r[i0:i1]
+        return z
+
+    x = np.zeros(N); r = np.asarray(b, float).copy(); z = apply(r); pv = z.copy()
+    beta = float(r @ z); rn0 = float(np.sqrt(z @ z)); ttol = max(rtol * rn0, abstol)
+    if rn0 <= abstol:
+        return x, 0, 3, rn0
+    for it in range(1, maxits + 1):
+        w = A @ pv
+        pw = float(pv @ w)
+        if not pw > 0.0:
+            return x, it - 1, -7, rn0
+        alpha = beta / pw
+        x += alpha * pv; r -= alpha * w
+        z = apply(r)
+        bnew = float(r @ z); rn = float(np.sqrt(z @ z))
+        if rn <= ttol:
+            return x, it, 2, rn
+        if rn >= dtol * rn0:
+            return x, it, -4, rn
+        pv = z + (bnew / beta) * pv
+        beta = bnew
+    return x, maxits, -3, rn
+
+
 # ----------------------------------------------------------------------------
 # the whole path, as the driver runs it on one or several ranks
 # ----------------------------------------------------------------------------

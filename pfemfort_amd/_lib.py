@@ -88,6 +88,8 @@ SIGNATURES = {
     "pfem_solver_set_spmv_format": [_P, _I],
     "pfem_solver_get_spmv_format": [_P, _P],
     "pfem_solver_get_spmv_row_group": [_P, _P],
+    "pfem_solver_set_preconditioner": [_P, _I],
+    "pfem_solver_get_preconditioner": [_P, _P],
     "pfem_eval_elems": [_P, _P, _P, _P, _P],
     "pfem_rhs_add_values": [_P, _L, _P, _P],
     "pfem_matrix_info": [_P, _P, _P, _P, _P],

@@ -212,6 +212,11 @@ struct pfem_solver {
 
     // vectors
     DevBuf<double> d_rhs, d_x, d_r, d_p, d_w, d_dinv;
+    int pc = PFEM_PC_JACOBI;
+    DevBuf<double> d_binv[3];      // node-block Jacobi: row (i - r0) of the inverse diagonal block, columns 0..2
+    DevBuf<double> d_r2;           // ... second residual buffer (ping-pong) and per-row (first row | size << 30)
+    DevBuf<uint32_t> d_row_grp;
+    bool block_pc() const { return pc == PFEM_PC_NODE_BLOCK_JACOBI && grouped && nranks == 1 && n_loc < (1LL << 30); }
     bool rhs_summed = false;
 
     // CG state
@@ -1102,6 +1107,20 @@ extern "C" int pfem_solver_get_spmv_format(pfem_solver *s, int *bits_per_column)
     return PFEM_OK;
 }
 
+extern "C" int pfem_solver_set_preconditioner(pfem_solver *s, int pc)
+{
+    if (!s || (pc != PFEM_PC_JACOBI && pc != PFEM_PC_NODE_BLOCK_JACOBI)) return PFEM_ERR_ARG;
+    s->pc = pc;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_get_preconditioner(pfem_solver *s, int *pc_in_effect)
+{
+    if (!s || !pc_in_effect) return PFEM_ERR_ARG;
+    *pc_in_effect = s->block_pc() ? PFEM_PC_NODE_BLOCK_JACOBI : PFEM_PC_JACOBI;
+    return PFEM_OK;
+}
+
 extern "C" int pfem_solver_get_spmv_row_group(pfem_solver *s, int *rows_per_lane)
 {
     if (!s || !rows_per_lane) return PFEM_ERR_ARG;
@@ -1280,6 +1299,24 @@ int run_pcg(pfem_solver *s)
     }
     PFEM_HIP(hipMemsetAsync(ctl, 0, sizeof(CgCtl), s->stream));
 
+    const bool bpc = s->block_pc();
+    const int32_t *grow0 = s->d_group_row0.p;
+    if (bpc) {
+        // node-block Jacobi: inverse of the diagonal block of every row group (single rank)
+        for (auto &b : s->d_binv)
+            if (b.n < static_cast<size_t>(n)) PFEM_TRY(b.alloc(static_cast<size_t>(n)));
+        hipLaunchKernelGGL(k_extract_blocks, dim3(grid_for(s->n_groups)), block, 0, s->stream, A, grow0, s->n_groups,
+                           s->d_binv[0].p, s->d_binv[1].p, s->d_binv[2].p);
+        hipLaunchKernelGGL(k_invert_blocks, dim3(grid_for(s->n_groups)), block, 0, s->stream, grow0, s->n_groups, s->d_binv[0].p,
+                           s->d_binv[1].p, s->d_binv[2].p);
+        PFEM_TRY(check_kernel("k_invert_blocks"));
+        if (s->d_r2.n < static_cast<size_t>(n)) PFEM_TRY(s->d_r2.alloc(static_cast<size_t>(n)));
+        if (s->d_row_grp.n < static_cast<size_t>(n)) PFEM_TRY(s->d_row_grp.alloc(static_cast<size_t>(n)));
+        hipLaunchKernelGGL(k_fill_row_groups, dim3(grid_for(s->n_groups)), block, 0, s->stream, grow0, s->n_groups, s->d_row_grp.p);
+        hipLaunchKernelGGL(k_cg_init_b, dim3(gv), block, 0, s->stream, n, static_cast<const uint32_t *>(s->d_row_grp.p), s->n_owned,
+                           s->d_rhs.p, s->d_binv[0].p, s->d_binv[1].p, s->d_binv[2].p, s->d_x.p, s->d_r.p, s->d_p.p, part_rz, part_zz);
+        PFEM_TRY(check_kernel("k_cg_init_b"));
+    } else {
     // Jacobi: dinv = 1 / diag(A); interface diagonals and rhs are summed over the ranks
     if (n > 0) {
         hipLaunchKernelGGL(k_extract_diag, dim3(grid_for(n)), block, 0, s->stream, A, s->d_dinv.p);
@@ -1300,12 +1337,14 @@ int run_pcg(pfem_solver *s)
     hipLaunchKernelGGL(k_cg_init, dim3(gv), block, 0, s->stream, n, s->n_owned, s->d_rhs.p, s->d_dinv.p, s->d_x.p, s->d_r.p,
                        s->d_p.p, part_rz, part_zz);
     PFEM_TRY(check_kernel("k_cg_init"));
+    }
+    const unsigned gvec = gv;                  // blocks (= partials) of the vector kernels
     const double *red2 = nullptr;
     if (multi) {
-        PFEM_TRY(scalar_sum2(s, part_rz, part_zz, static_cast<int>(gv), nullptr));
+        PFEM_TRY(scalar_sum2(s, part_rz, part_zz, static_cast<int>(gvec), nullptr));
         red2 = s->xbuf + s->n_iface + 2;
     }
-    hipLaunchKernelGGL(k_cg_start, dim3(1), block, 0, s->stream, ctl, part_rz, part_zz, static_cast<int>(gv), red2, s->rtol,
+    hipLaunchKernelGGL(k_cg_start, dim3(1), block, 0, s->stream, ctl, part_rz, part_zz, static_cast<int>(gvec), red2, s->rtol,
                        s->abstol, s->dtol, s->d_hist.p);
     PFEM_TRY(check_kernel("k_cg_start"));
 
@@ -1373,6 +1412,19 @@ int run_pcg(pfem_solver *s)
                                    static_cast<int>(gs), scal_pw, static_cast<const CgCtl *>(ctl));
                 pw_parts = scal_pw;
                 pw_n = kFoldBlocks;
+            }
+            if (bpc) {
+                // residual ping-pong: iteration `it` reads r_a, writes r_b
+                const double *r_a = (it & 1) ? s->d_r2.p : s->d_r.p;
+                double *r_b = (it & 1) ? s->d_r.p : s->d_r2.p;
+                const uint32_t *rgp = s->d_row_grp.p;
+                hipLaunchKernelGGL(k_cg_update_b, dim3(gv), block, 0, s->stream, ctl, it, n, rgp, s->n_owned, pw_parts, pw_n, red_pw,
+                                   s->d_p.p, s->d_w.p, s->d_binv[0].p, s->d_binv[1].p, s->d_binv[2].p, s->d_x.p, r_a, r_b, part_rz,
+                                   part_zz);
+                hipLaunchKernelGGL(k_cg_direction_b, dim3(gv), block, 0, s->stream, ctl, it, n, rgp, part_rz, part_zz,
+                                   static_cast<int>(gv), red2, static_cast<const double *>(r_b), s->d_binv[0].p, s->d_binv[1].p,
+                                   s->d_binv[2].p, s->d_p.p, s->d_hist.p, s->hist_cap, s->maxits);
+                continue;
             }
             hipLaunchKernelGGL(k_cg_update, dim3(gv), block, 0, s->stream, ctl, it, n, s->n_owned, pw_parts, pw_n,
                                red_pw, s->d_p.p, s->d_w.p, s->d_dinv.p, s->d_x.p, s->d_r.p, part_rz, part_zz);

@@ -1472,6 +1472,181 @@ __global__ void __launch_bounds__(kBlock) k_cg_direction(CgCtl *ctl, int it, int
 }
 
 // ---------------------------------------------------------------------------
+// Node-block Jacobi (PETSc: -pc_type pbjacobi): M = the diagonal blocks of A over the
+// row groups of k_spmvg (the dof rows of a node, 1..3 rows).  binv_q[i] holds row (i - r0) of the
+// inverse block, column q; z_i = sum_q binv_q[i] * r[r0 + q].  One thread per GROUP in the vector
+// kernels, so a block's residual is read and written by one thread.
+// ---------------------------------------------------------------------------
+// b_q[i] = A(i, r0 + q) for the rows of every group (0 outside the block)
+__global__ void __launch_bounds__(kBlock) k_extract_blocks(SellDev A, const int32_t *group_row0, int64_t n_groups, double *b0,
+                                                            double *b1, double *b2)
+{
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (g >= n_groups) return;
+    const int r0 = group_row0[g], sz = group_row0[g + 1] - r0;
+    double *b[kGroupRows] = {b0, b1, b2};
+    for (int p = 0; p < sz; ++p)
+        for (int q = 0; q < kGroupRows; ++q) {
+            double v = 0.0;
+            if (q < sz) {
+                const int64_t sl = find_slot(A, r0 + p, r0 + q);
+                if (sl >= 0) v = A.vals[sl];
+            }
+            b[q][r0 + p] = v;
+        }
+}
+
+// in place: block -> inverse block (adjugate / determinant, fixed operation order)
+__global__ void __launch_bounds__(kBlock) k_invert_blocks(const int32_t *group_row0, int64_t n_groups, double *b0, double *b1,
+                                                           double *b2)
+{
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (g >= n_groups) return;
+    const int r0 = group_row0[g], sz = group_row0[g + 1] - r0;
+    if (sz == 1) {
+        b0[r0] = 1.0 / b0[r0];
+    } else if (sz == 2) {
+        const double a = b0[r0], b = b1[r0], c = b0[r0 + 1], d = b1[r0 + 1];
+        const double di = 1.0 / (a * d - b * c);
+        b0[r0] = d * di; b1[r0] = -b * di;
+        b0[r0 + 1] = -c * di; b1[r0 + 1] = a * di;
+    } else if (sz == 3) {
+        const double a00 = b0[r0], a01 = b1[r0], a02 = b2[r0];
+        const double a10 = b0[r0 + 1], a11 = b1[r0 + 1], a12 = b2[r0 + 1];
+        const double a20 = b0[r0 + 2], a21 = b1[r0 + 2], a22 = b2[r0 + 2];
+        const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+        const double di = 1.0 / (a00 * c00 + a01 * c01 + a02 * c02);
+        b0[r0] = c00 * di; b1[r0] = (a02 * a21 - a01 * a22) * di; b2[r0] = (a01 * a12 - a02 * a11) * di;
+        b0[r0 + 1] = c01 * di; b1[r0 + 1] = (a00 * a22 - a02 * a20) * di; b2[r0 + 1] = (a02 * a10 - a00 * a12) * di;
+        b0[r0 + 2] = c02 * di; b1[r0 + 2] = (a01 * a20 - a00 * a21) * di; b2[r0 + 2] = (a00 * a11 - a01 * a10) * di;
+    }
+}
+
+// row_grp[i] = first row of i's group | (group size << 30): lets the vector kernels run one thread per ROW
+// (coalesced streams) and still see the whole block
+__global__ void __launch_bounds__(kBlock) k_fill_row_groups(const int32_t *group_row0, int64_t n_groups, uint32_t *row_grp)
+{
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (g >= n_groups) return;
+    const int r0 = group_row0[g], sz = group_row0[g + 1] - r0;
+    for (int q = 0; q < sz; ++q) row_grp[r0 + q] = static_cast<uint32_t>(r0) | (static_cast<uint32_t>(sz) << 30);
+}
+
+// z_i = sum_q binv_q[i] * rr[q], q ascending
+__device__ __forceinline__ double block_row_apply(double bi0, double bi1, double bi2, int sz, const double (&rr)[kGroupRows])
+{
+    double t = bi0 * rr[0];
+    if (sz > 1) t = __builtin_fma(bi1, rr[1], t);
+    if (sz > 2) t = __builtin_fma(bi2, rr[2], t);
+    return t;
+}
+
+__global__ void __launch_bounds__(kBlock) k_cg_init_b(int64_t n, const uint32_t *__restrict__ row_grp, int64_t n_owned,
+                                                       const double *__restrict__ b, const double *__restrict__ b0,
+                                                       const double *__restrict__ b1, const double *__restrict__ b2,
+                                                       double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
+                                                       double *part_rz, double *part_zz)
+{
+    __shared__ double sm[4];
+    double rz = 0.0, zz = 0.0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const uint32_t rg = row_grp[i];
+        const int r0 = static_cast<int>(rg & 0x3fffffffu), sz = static_cast<int>(rg >> 30);
+        double rr[kGroupRows] = {0.0, 0.0, 0.0};
+        for (int q = 0; q < sz; ++q) rr[q] = b[r0 + q];
+        const double ri = b[i], zi = block_row_apply(b0[i], b1[i], b2[i], sz, rr);
+        x[i] = 0.0;
+        r[i] = ri;
+        p[i] = zi;
+        if (i < n_owned) { rz = __builtin_fma(ri, zi, rz); zz = __builtin_fma(zi, zi, zz); }
+    }
+    const double a = block_sum(rz, sm), c = block_sum(zz, sm);
+    if (threadIdx.x == 0) { part_rz[blockIdx.x] = a; part_zz[blockIdx.x] = c; }
+}
+
+// the residual is ping-ponged (r_old -> r_new): a thread recomputes the new residual of its block mates
+// from r_old instead of waiting for them
+__global__ void __launch_bounds__(kBlock) k_cg_update_b(CgCtl *ctl, int it, int64_t n, const uint32_t *__restrict__ row_grp,
+                                                         int64_t n_owned, const double *part_pw, int nparts,
+                                                         const double *reduced_pw, const double *__restrict__ p,
+                                                         const double *__restrict__ w, const double *__restrict__ b0,
+                                                         const double *__restrict__ b1, const double *__restrict__ b2,
+                                                         double *__restrict__ x, const double *__restrict__ r_old,
+                                                         double *__restrict__ r_new, double *part_rz, double *part_zz)
+{
+    __shared__ double sm[4];
+    if (ctl->flag != 0) return;
+    const double pw = reduced_pw ? *reduced_pw : sum_partials(part_pw, nparts, sm);
+    if (!(pw > 0.0)) {                      // KSP_DIVERGED_INDEFINITE_MAT
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->its = it; }
+        part_rz[blockIdx.x] = 0.0; part_zz[blockIdx.x] = -1.0;
+        return;
+    }
+    const double alpha = ctl->beta[it & 1] / pw;
+    double rz = 0.0, zz = 0.0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const uint32_t rg = row_grp[i];
+        const int r0 = static_cast<int>(rg & 0x3fffffffu), sz = static_cast<int>(rg >> 30);
+        double rr[kGroupRows] = {0.0, 0.0, 0.0};
+        for (int q = 0; q < sz; ++q) rr[q] = __builtin_fma(-alpha, w[r0 + q], r_old[r0 + q]);
+        const double ri = __builtin_fma(-alpha, w[i], r_old[i]);
+        x[i] = __builtin_fma(alpha, p[i], x[i]);
+        r_new[i] = ri;
+        const double zi = block_row_apply(b0[i], b1[i], b2[i], sz, rr);
+        if (i < n_owned) { rz = __builtin_fma(ri, zi, rz); zz = __builtin_fma(zi, zi, zz); }
+    }
+    const double a = block_sum(rz, sm), c = block_sum(zz, sm);
+    if (threadIdx.x == 0) { part_rz[blockIdx.x] = a; part_zz[blockIdx.x] = c; }
+}
+
+__global__ void __launch_bounds__(kBlock) k_cg_direction_b(CgCtl *ctl, int it, int64_t n, const uint32_t *__restrict__ row_grp,
+                                                            const double *part_rz, const double *part_zz, int nparts,
+                                                            const double *reduced, const double *__restrict__ r,
+                                                            const double *__restrict__ b0, const double *__restrict__ b1,
+                                                            const double *__restrict__ b2, double *__restrict__ p, double *hist,
+                                                            int hist_cap, int maxits)
+{
+    __shared__ double sm[4];
+    if (ctl->flag != 0) return;
+    double rz, zz;
+    if (reduced) { rz = reduced[0]; zz = reduced[1]; }
+    else { rz = sum_partials(part_rz, nparts, sm); zz = sum_partials(part_zz, nparts, sm); }
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    if (zz < 0.0) {
+        if (lead) { ctl->flag = -7; ctl->its = it + 1; }
+        return;
+    }
+    const double rn = sqrt(zz);
+    const double beta_old = ctl->beta[it & 1];
+    int flag = 0;
+    if (rn <= ctl->ttol) flag = 2;
+    else if (rn >= ctl->dtol * ctl->rn0) flag = -4;
+    else if (rz < 0.0) flag = -8;
+    else if (it + 1 >= maxits) flag = -3;
+    if (lead) {
+        ctl->beta[(it + 1) & 1] = rz;
+        ctl->rn = rn;
+        ctl->its = it + 1;
+        if (it + 1 < hist_cap) hist[it + 1] = rn;
+    }
+    if (flag != 0) {
+        if (lead) ctl->flag = flag;
+        return;
+    }
+    const double bb = rz / beta_old;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const uint32_t rg = row_grp[i];
+        const int r0 = static_cast<int>(rg & 0x3fffffffu), sz = static_cast<int>(rg >> 30);
+        double rr[kGroupRows] = {0.0, 0.0, 0.0};
+        for (int q = 0; q < sz; ++q) rr[q] = r[r0 + q];
+        p[i] = __builtin_fma(bb, p[i], block_row_apply(b0[i], b1[i], b2[i], sz, rr));
+    }
+}
+
+// ---------------------------------------------------------------------------
 // interface exchange (multi-GPU, sub-assembled rows)
 // ---------------------------------------------------------------------------
 // buf[slot] = v[lidx]; the extra block reduces `n_extra` partial arrays into buf[n_iface+j]

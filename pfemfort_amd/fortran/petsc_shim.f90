@@ -33,6 +33,7 @@ subroutine PetscInitialize(file, ierr)
       case ("-ksp_atol");   read(val, *, iostat=io) pfem_opt_atol
       case ("-ksp_divtol"); read(val, *, iostat=io) pfem_opt_dtol
       case ("-ksp_max_it"); read(val, *, iostat=io) pfem_opt_maxits
+      case ("-pc_type");    if (trim(val) == "pbjacobi") pfem_opt_pc = 1
       end select
     end do
     close(97)
@@ -41,6 +42,8 @@ subroutine PetscInitialize(file, ierr)
   if (io == 0 .and. len_trim(val) > 0) read(val, *, iostat=io) pfem_opt_rtol
   call get_environment_variable("PFEM_KSP_MAX_IT", val, status=io)
   if (io == 0 .and. len_trim(val) > 0) read(val, *, iostat=io) pfem_opt_maxits
+  call get_environment_variable("PFEM_PC_TYPE", val, status=io)
+  if (io == 0 .and. trim(val) == "pbjacobi") pfem_opt_pc = 1
 end subroutine PetscInitialize
 
 subroutine PetscFinalize(ierr)

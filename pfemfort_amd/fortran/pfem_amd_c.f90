@@ -40,6 +40,11 @@ module pfem_amd_c
       real(c_double), value :: rtol, abstol, dtol
       integer(c_int), value :: maxits
     end function
+    integer(c_int) function pfem_solver_set_preconditioner(s, pc) bind(C, name="pfem_solver_set_preconditioner")
+      import
+      type(c_ptr), value :: s
+      integer(c_int), value :: pc
+    end function
     integer(c_int) function pfem_solver_set_zero(s) bind(C, name="pfem_solver_set_zero")
       import
       type(c_ptr), value :: s

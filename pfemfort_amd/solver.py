@@ -169,6 +169,16 @@ class PetscSolver:
         L.check(L.lib().pfem_solver_get_spmv_format(self._h, C.byref(b)), "pfem_solver_get_spmv_format")
         return b.value
 
+    def setPreconditioner(self, pc):
+        """"jacobi" (default; PCJACOBI) or "pbjacobi" (node-block Jacobi, PETSc's -pc_type pbjacobi)."""
+        L.check(L.lib().pfem_solver_set_preconditioner(self._h, {"jacobi": 0, "pbjacobi": 1}[pc]), "pfem_solver_set_preconditioner")
+
+    def preconditioner(self):
+        """The preconditioner the next solve uses ("pbjacobi" needs 3-dof row groups and one rank)."""
+        b = C.c_int(0)
+        L.check(L.lib().pfem_solver_get_preconditioner(self._h, C.byref(b)), "pfem_solver_get_preconditioner")
+        return ("jacobi", "pbjacobi")[b.value]
+
     def spmvRowGroup(self):
         """Rows served by one lane of the current SpMV (3: row-grouped form)."""
         b = C.c_int(0)

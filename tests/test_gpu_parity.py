@@ -250,6 +250,41 @@ def test_elasticity_beam_solve(beam):
     assert res.solnVTK[:, 0].max() > 0.1                    # the beam bends in +x under (0.1,0,0)
 
 
+@pytest.mark.parametrize("partial", [False, True])
+def test_node_block_jacobi_matches_oracle(beam, partial):
+    """-pc_type pbjacobi.  Same blocks as the oracle's rule (rows with identical column sets),
+    same convergence test; fewer iterations than point Jacobi, same solution."""
+    mesh = beam
+    if partial:       # nodes with one or two free dofs -> blocks of 1, 2 and 3 rows
+        rng = np.random.default_rng(2)
+        keep = rng.random(len(mesh.bc_node)) < 0.8
+        extra = np.arange(40, 70, dtype=np.int32)
+        mesh = H.Mesh(mesh.xyz, mesh.conn, np.concatenate([mesh.bc_node[keep], extra]),
+                      np.concatenate([mesh.bc_dof[keep], extra % 3]).astype(np.int32), np.zeros(keep.sum() + 30))
+    s, dm = _device_problem(pf.ELAST_TET, mesh, H.ELAST_ELEMDATA)
+    prob = O.setup_problem(O.ELAST_TET, _omesh(mesh))
+    s.setTolerances(rtol=1e-10, maxits=20000)
+    its_j, reason_j, _ = s.factoriseAndSolve()
+    u_j = s.getSolution()
+    assert s.preconditioner() == "jacobi"
+    s.setPreconditioner("pbjacobi")
+    assert s.preconditioner() == "pbjacobi"
+    its_b, reason_b, rn_b = s.factoriseAndSolve()
+    u_b = s.getSolution()
+    groups = O.row_groups(prob.rowptr, prob.cols)
+    x, its_o, reason_o, rn_o = O.pcg_block_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs, groups, rtol=1e-10, maxits=20000)
+    assert reason_j == reason_b == reason_o == 2
+    assert abs(its_b - its_o) <= 2 and its_b < its_j
+    assert np.abs(u_b - x).max() <= U_ATOL * max(1.0, np.abs(x).max())
+    assert np.abs(u_b - u_j).max() <= U_ATOL * max(1.0, np.abs(x).max())
+    if partial:
+        assert np.diff(groups).min() < 3 and np.diff(groups).max() == 3
+    # Poisson has no multi-row groups: the request falls back to point Jacobi, and says so
+    sp, _ = _device_problem(pf.POISSON_TET, H.gen_box_tets(-1, 1, 4, -1, 1, 4, -1, 1, 4), H.POISSON_ELEMDATA)
+    sp.setPreconditioner("pbjacobi")
+    assert sp.preconditioner() == "jacobi"
+
+
 def test_negative_jacobian_is_reported(tet10):
     bad = H.Mesh(tet10.xyz, tet10.conn.copy(), tet10.bc_node, tet10.bc_dof, tet10.bc_val)
     bad.conn[[0, 1], 5] = bad.conn[[1, 0], 5]              # flip one tet

@@ -22,3 +22,7 @@ print(f"solve {tm['solve_ms']:.1f} ms its {its} reason {reason} rn {rn:.3e} spmv
 u = s.getSolution(); full = dm.solnApplied.copy(); full[H.assy_for_soln(dm.NodeDofArrayNew)] = u
 disp = np.linalg.norm(full.reshape(-1, 3), axis=1)
 print("max displacement magnitude", disp.max(), " (docs image: 0.82; beam theory 0.81)")
+s.setPreconditioner("pbjacobi"); print("pc in effect:", s.preconditioner())
+its, reason, rn = s.factoriseAndSolve(); tm = s.timings()
+print(f"pbjacobi: solve {tm['solve_ms']:.1f} ms its {its} reason {reason} rn {rn:.3e}")
+u2 = s.getSolution(); print("max |u_pbjacobi - u_jacobi| =", np.abs(u2 - u).max())
