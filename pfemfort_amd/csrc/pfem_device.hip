@@ -196,6 +196,26 @@ struct pfem_solver {
     DevBuf<uint32_t> d_gdwords;
     DevBuf<double> d_gvals;
     bool use_grouped() const { return grouped && spmv_format == PFEM_SPMV_AUTO; }
+    // SpMV-only relative row groups (k_spmvr): 4 consecutive rows, one relative column stream
+    bool relgrouped = false;
+    int64_t n_rgroups = 0, n_rslices = 0, r_stored = 0;
+    DevBuf<int32_t> d_rcol0;
+    DevBuf<int64_t> d_rslice_off, d_rslice_doff;
+    DevBuf<uint32_t> d_rdwords;
+    DevBuf<double> d_rvals;
+    bool use_rel() const { return relgrouped && !use_grouped() && spmv_format == PFEM_SPMV_AUTO; }
+    SellRDev sellr() const
+    {
+        SellRDev G;
+        G.n_groups = n_rgroups;
+        G.n_gslices = n_rslices;
+        G.gslice_off = d_rslice_off.p;
+        G.vals = d_rvals.p;
+        G.col0 = d_rcol0.p;
+        G.dwords = d_rdwords.p;
+        G.gslice_doff = d_rslice_doff.p;
+        return G;
+    }
     SellGDev sellg() const
     {
         SellGDev G;
@@ -211,7 +231,11 @@ struct pfem_solver {
     }
 
     // vectors
-    DevBuf<double> d_rhs, d_x, d_r, d_p, d_w, d_dinv;
+    DevBuf<double> d_rhs, d_x, d_r, d_w, d_dinv;
+    struct GuardedVec {            // the SpMV input vector: kVecGuard zeros before and after (k_spmvr reads a few
+        DevBuf<double> store;      // places outside [0,n) for explicit zero entries)
+        double *p = nullptr;
+    } d_p;
     int pc = PFEM_PC_JACOBI;
     DevBuf<double> d_binv[3];      // node-block Jacobi: row (i - r0) of the inverse diagonal block, columns 0..2
     DevBuf<double> d_r2;           // ... second residual buffer (ping-pong) and per-row (first row | size << 30)
@@ -487,7 +511,9 @@ int alloc_vectors(pfem_solver *s)
     PFEM_TRY(s->d_rhs.alloc(n));
     PFEM_TRY(s->d_x.alloc(n));
     PFEM_TRY(s->d_r.alloc(n));
-    PFEM_TRY(s->d_p.alloc(n));
+    PFEM_TRY(s->d_p.store.alloc(n + 2 * kVecGuard));
+    PFEM_HIP(hipMemsetAsync(s->d_p.store.p, 0, (n + 2 * kVecGuard) * sizeof(double), s->stream));
+    s->d_p.p = s->d_p.store.p + kVecGuard;
     PFEM_TRY(s->d_w.alloc(n));
     PFEM_TRY(s->d_dinv.alloc(n));
     PFEM_HIP(hipMemsetAsync(s->d_rhs.p, 0, n * sizeof(double), s->stream));
@@ -497,6 +523,7 @@ int alloc_vectors(pfem_solver *s)
 
 int build_cols16(pfem_solver *s);
 int build_groups(pfem_solver *s);
+int build_rel_groups(pfem_solver *s);
 
 // keys: device array of `nkeys` (row<<32|col) keys, kNoKey = ignore.  Consumed.
 int pattern_from_keys(pfem_solver *s, DevBuf<uint64_t> &keys, int64_t nkeys)
@@ -574,6 +601,7 @@ int pattern_from_keys(pfem_solver *s, DevBuf<uint64_t> &keys, int64_t nkeys)
     keys.release();
     PFEM_TRY(build_cols16(s));
     PFEM_TRY(build_groups(s));
+    PFEM_TRY(build_rel_groups(s));
     s->have_pattern = true;
     s->rhs_summed = false;
     s->status = PFEM_PATTERN_OK;
@@ -1060,9 +1088,73 @@ int build_groups(pfem_solver *s)
     return PFEM_OK;
 }
 
+// Relative row groups for k_spmvr (see pfem_kernels.hpp): fixed groups of kRelRows consecutive rows, union of the
+// relative column sets.  Kept only when the union form is smaller than the row form.
+int build_rel_groups(pfem_solver *s)
+{
+    s->relgrouped = false;
+    const int64_t n = s->n_loc;
+    if (!s->cols16 || s->grouped || n < kRelRows || n > INT_MAX - kRelRows) return PFEM_OK;
+    s->n_rgroups = (n + kRelRows - 1) / kRelRows;
+    s->n_rslices = (s->n_rgroups + 63) / 64;
+    DevBuf<int64_t> entries, words;
+    DevBuf<char> temp;
+    PFEM_TRY(entries.alloc(static_cast<size_t>(s->n_rslices) + 1));
+    PFEM_TRY(words.alloc(static_cast<size_t>(s->n_rslices) + 1));
+    PFEM_TRY(s->d_rslice_off.alloc(static_cast<size_t>(s->n_rslices) + 1));
+    PFEM_TRY(s->d_rslice_doff.alloc(static_cast<size_t>(s->n_rslices) + 1));
+    PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
+    hipLaunchKernelGGL(k_rel_sizes, dim3(grid_for(s->n_rslices * 64)), dim3(kBlock), 0, s->stream, s->sell(), s->n_rgroups,
+                       s->n_rslices, entries.p, s->d_err.p);
+    PFEM_TRY(check_kernel("k_rel_sizes"));
+    int overflow = 0;
+    PFEM_TRY(fetch_err(s, &overflow));
+    PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
+    const int nsl = static_cast<int>(s->n_rslices + 1);
+    size_t tb = 0;
+    PFEM_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, entries.p, s->d_rslice_off.p, nsl, s->stream));
+    PFEM_TRY(temp.alloc(tb));
+    PFEM_HIP(hipcub::DeviceScan::ExclusiveSum(temp.p, tb, entries.p, s->d_rslice_off.p, nsl, s->stream));
+    int64_t tot_e = 0;
+    PFEM_HIP(hipMemcpyAsync(&tot_e, s->d_rslice_off.p + s->n_rslices, sizeof(int64_t), hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    // bytes streamed per SpMV: (8*kRelRows + 2) per union entry against (8 + 2) per stored entry of the row form
+    const double rel_bytes = static_cast<double>(tot_e) * (8.0 * kRelRows + 2.0), row_bytes = static_cast<double>(s->stored) * 10.0;
+    if (overflow || rel_bytes > 0.95 * row_bytes) {
+        s->d_rslice_off.release();
+        s->d_rslice_doff.release();
+        return PFEM_OK;
+    }
+    hipLaunchKernelGGL(k_cols16_sizes, dim3(grid_for(s->n_rslices + 1)), dim3(kBlock), 0, s->stream,
+                       static_cast<const int64_t *>(s->d_rslice_off.p), s->n_rslices, words.p);
+    PFEM_TRY(check_kernel("k_cols16_sizes"));
+    PFEM_HIP(hipcub::DeviceScan::ExclusiveSum(temp.p, tb, words.p, s->d_rslice_doff.p, nsl, s->stream));
+    int64_t tot_w = 0;
+    PFEM_HIP(hipMemcpyAsync(&tot_w, s->d_rslice_doff.p + s->n_rslices, sizeof(int64_t), hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    s->r_stored = tot_e;
+    PFEM_TRY(s->d_rcol0.alloc(static_cast<size_t>(s->n_rslices) * 64));
+    PFEM_TRY(s->d_rdwords.alloc(static_cast<size_t>(std::max<int64_t>(tot_w, 1))));
+    PFEM_TRY(s->d_rvals.alloc(static_cast<size_t>(std::max<int64_t>(tot_e, 1)) * kRelRows));
+    hipLaunchKernelGGL(k_rel_cols_fill, dim3(grid_for(s->n_rslices * 64)), dim3(kBlock), 0, s->stream, s->sell(), s->n_rgroups,
+                       s->n_rslices, static_cast<const int64_t *>(s->d_rslice_off.p),
+                       static_cast<const int64_t *>(s->d_rslice_doff.p), s->d_rcol0.p, s->d_rdwords.p);
+    PFEM_TRY(check_kernel("k_rel_cols_fill"));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    s->relgrouped = true;
+    return PFEM_OK;
+}
+
 // grouped copy of the current matrix values (the row form is what assembly writes)
 int refresh_group_vals(pfem_solver *s)
 {
+    if (s->use_rel() && s->group_vals_stale) {
+        hipLaunchKernelGGL(k_rel_vals, dim3(grid_for(s->n_rslices * 64)), dim3(kBlock), 0, s->stream, s->sell(), s->sellr(),
+                           s->d_rvals.p);
+        PFEM_TRY(check_kernel("k_rel_vals"));
+        s->group_vals_stale = false;
+        return PFEM_OK;
+    }
     if (!s->use_grouped() || !s->group_vals_stale) return PFEM_OK;
     hipLaunchKernelGGL(k_group_vals, dim3(grid_for(s->n_gslices * 64)), dim3(kBlock), 0, s->stream, s->sell(), s->sellg(),
                        s->d_gvals.p);
@@ -1073,7 +1165,7 @@ int refresh_group_vals(pfem_solver *s)
 
 inline unsigned spmv_blocks(const pfem_solver *s)
 {
-    return s->use_grouped() ? spmv_grid(s->n_gslices) : spmv_grid(s->n_slices);
+    return s->use_grouped() ? spmv_grid(s->n_gslices) : (s->use_rel() ? spmv_grid(s->n_rslices) : spmv_grid(s->n_slices));
 }
 
 // the CG / standalone SpMV launch: row-grouped form when the pattern has it, else 16-bit gaps when available
@@ -1088,6 +1180,10 @@ void launch_spmv(pfem_solver *s, const double *x, double *y, int64_t n_dot, doub
         SellGDev G = s->sellg();
         if (e0) hipExtLaunchKernelGGL(k_spmvg<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, G, s->n_loc, x, y, n_dot, partial, ctl);
         else hipLaunchKernelGGL(k_spmvg<WITH_DOT>, grid, block, 0, s->stream, G, s->n_loc, x, y, n_dot, partial, ctl);
+    } else if (s->use_rel()) {
+        SellRDev G = s->sellr();
+        if (e0) hipExtLaunchKernelGGL(k_spmvr<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, G, s->n_loc, x, y, n_dot, partial, ctl);
+        else hipLaunchKernelGGL(k_spmvr<WITH_DOT>, grid, block, 0, s->stream, G, s->n_loc, x, y, n_dot, partial, ctl);
     } else if (s->cols16 && s->spmv_format != PFEM_SPMV_INT32) {
         Sell16Dev C{s->d_col0.p, s->d_dwords.p, s->d_slice_doff.p};
         if (e0) hipExtLaunchKernelGGL(k_spmv16<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, A, C, x, y, n_dot, partial, ctl);
@@ -1124,7 +1220,7 @@ extern "C" int pfem_solver_get_preconditioner(pfem_solver *s, int *pc_in_effect)
 extern "C" int pfem_solver_get_spmv_row_group(pfem_solver *s, int *rows_per_lane)
 {
     if (!s || !rows_per_lane) return PFEM_ERR_ARG;
-    *rows_per_lane = s->use_grouped() ? kGroupRows : 1;
+    *rows_per_lane = s->use_grouped() ? kGroupRows : (s->use_rel() ? kRelRows : 1);
     return PFEM_OK;
 }
 
@@ -1158,10 +1254,11 @@ extern "C" int pfem_bench_spmv(pfem_solver *s, int reps, double *ms_per_launch)
     PFEM_TRY(use_device(s));
     s->group_vals_stale = true;
     PFEM_TRY(refresh_group_vals(s));
-    // warm-up launch, then `reps` timed ones with x = rhs (any resident vector)
-    launch_spmv<false>(s, s->d_rhs.p, s->d_w.p, 0, nullptr, nullptr);
+    // warm-up launch, then `reps` timed ones with x = rhs (copied into the guarded SpMV input vector)
+    PFEM_HIP(hipMemcpyAsync(s->d_p.p, s->d_rhs.p, sizeof(double) * static_cast<size_t>(s->n_loc), hipMemcpyDeviceToDevice, s->stream));
+    launch_spmv<false>(s, s->d_p.p, s->d_w.p, 0, nullptr, nullptr);
     PFEM_HIP(hipEventRecord(s->ev0, s->stream));
-    for (int i = 0; i < reps; ++i) launch_spmv<false>(s, s->d_rhs.p, s->d_w.p, 0, nullptr, nullptr);
+    for (int i = 0; i < reps; ++i) launch_spmv<false>(s, s->d_p.p, s->d_w.p, 0, nullptr, nullptr);
     PFEM_HIP(hipEventRecord(s->ev1, s->stream));
     PFEM_TRY(check_kernel("k_spmv"));
     double ms = 0;

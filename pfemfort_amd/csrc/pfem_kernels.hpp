@@ -1472,6 +1472,234 @@ __global__ void __launch_bounds__(kBlock) k_cg_direction(CgCtl *ctl, int it, int
 }
 
 // ---------------------------------------------------------------------------
+// Relative row groups (scalar problems on regularly numbered meshes).  kRelRows CONSECUTIVE rows
+// r0..r0+3 are served by one lane with ONE column stream: the union of their column sets taken
+// RELATIVE to the row (col - row), i.e. entry k of row r0+p multiplies x[c_k + p].  Where adjacent
+// rows see the same stencil (x-lines of a structured mesh) the union is as long as one row, so an
+// entry costs 8 + 2/4 B instead of 8 + 2 B, and the four x values of an entry are one contiguous
+// 32-B read.  A row that lacks an offset of the union carries an explicit zero there (the product
+// is +-0 and leaves the sum unchanged); x is read up to kRelRows-1 places outside [0,n) for such
+// zeros, hence the guard band of the SpMV input vector.  Built from the pattern alone and kept only
+// when it is smaller than the row form (unstructured numbering: unions grow, the row form stays).
+// ---------------------------------------------------------------------------
+constexpr int kRelRows = 4;
+constexpr int kVecGuard = 8;       // zeros kept before and after the SpMV input vector
+
+struct SellRDev {
+    int64_t n_groups, n_gslices;
+    const int64_t *gslice_off;   // [n_gslices+1] entries per plane, 64 * width
+    const double *vals;          // entry k of row p of lane l: vals[kRelRows*off + (kRelRows*k + p)*64 + l]
+    const int32_t *col0;         // [64 * n_gslices] c_0 = r0 + (smallest relative offset); may be < 0
+    const uint32_t *dwords;      // packed 16-bit gaps between the ascending relative offsets
+    const int64_t *gslice_doff;
+};
+
+// Walks the union of the relative column lists of rows r0 .. r0+nr-1 in ascending order and calls
+// f(k, offset).  Returns the union size.
+template <class F>
+__device__ __forceinline__ int rel_union_walk(const SellDev &A, int64_t r0, int nr, F &&f)
+{
+    int head[kRelRows], len[kRelRows];
+    const int32_t *cp[kRelRows];
+#pragma unroll
+    for (int p = 0; p < kRelRows; ++p) {
+        head[p] = 0;
+        len[p] = p < nr ? A.rowlen[r0 + p] : 0;
+        cp[p] = A.cols + A.slice_off[(r0 + (p < nr ? p : 0)) >> 6] + ((r0 + (p < nr ? p : 0)) & 63);
+    }
+    int k = 0;
+    for (;;) {
+        int64_t best = INT64_MAX;
+#pragma unroll
+        for (int p = 0; p < kRelRows; ++p)
+            if (head[p] < len[p]) {
+                const int64_t o = static_cast<int64_t>(cp[p][64LL * head[p]]) - (r0 + p);
+                best = o < best ? o : best;
+            }
+        if (best == INT64_MAX) break;
+        f(k, best);
+        ++k;
+#pragma unroll
+        for (int p = 0; p < kRelRows; ++p)
+            if (head[p] < len[p] && static_cast<int64_t>(cp[p][64LL * head[p]]) - (r0 + p) == best) ++head[p];
+    }
+    return k;
+}
+
+// union size of every group (as 64*width per slice of 64 groups) and the 16-bit test of its gaps
+__global__ void __launch_bounds__(kBlock) k_rel_sizes(SellDev A, int64_t n_groups, int64_t n_gslices, int64_t *entries,
+                                                       int *overflow)
+{
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    int u = 0;
+    if (g < n_groups) {
+        const int64_t r0 = g * kRelRows;
+        const int nr = static_cast<int>(min(static_cast<int64_t>(kRelRows), A.n_rows - r0));
+        int64_t prev = 0;
+        bool bad = false;
+        u = rel_union_walk(A, r0, nr, [&](int k, int64_t o) {
+            if (k > 0 && o - prev > 65535) bad = true;
+            if (k == 0 && (r0 + o < INT32_MIN || r0 + o > INT32_MAX)) bad = true;
+            prev = o;
+        });
+        if (bad) atomicMax(overflow, 1);
+    }
+    int c = u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c = max(c, __shfl_xor(c, o, 64));
+    const int64_t gs = g >> 6;
+    if ((threadIdx.x & 63) == 0 && gs < n_gslices) entries[gs] = 64LL * c;
+    if (g == 0) entries[n_gslices] = 0;
+}
+
+__global__ void __launch_bounds__(kBlock) k_rel_cols_fill(SellDev A, int64_t n_groups, int64_t n_gslices,
+                                                           const int64_t *gslice_off, const int64_t *gslice_doff, int32_t *col0,
+                                                           uint32_t *dwords)
+{
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t gs = g >> 6;
+    if (gs >= n_gslices) return;
+    const int lane = static_cast<int>(g & 63);
+    const int width = static_cast<int>((gslice_off[gs + 1] - gslice_off[gs]) >> 6);
+    uint32_t *wp = dwords + gslice_doff[gs] + lane;
+    for (int j = 0; 2 * j + 1 < width; ++j) wp[64LL * j] = 0u;        // pads: gap 0
+    const int64_t r0 = g * kRelRows;
+    col0[g] = static_cast<int32_t>(g < n_groups ? r0 : 0);          // empty group: any valid address
+    if (g >= n_groups) return;
+    const int nr = static_cast<int>(min(static_cast<int64_t>(kRelRows), A.n_rows - r0));
+    int64_t prev = 0;
+    rel_union_walk(A, r0, nr, [&](int k, int64_t o) {
+        if (k == 0) col0[g] = static_cast<int32_t>(r0 + o);
+        else {
+            const int j = (k - 1) >> 1, h = (k - 1) & 1;
+            wp[64LL * j] |= (static_cast<uint32_t>(o - prev) & 0xffffu) << (16 * h);
+        }
+        prev = o;
+    });
+}
+
+// matrix values, row form -> relative-group form (explicit zeros where a row lacks an offset); once per solve
+__global__ void __launch_bounds__(kBlock) k_rel_vals(SellDev A, SellRDev G, double *out)
+{
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t gs = g >> 6;
+    if (gs >= G.n_gslices) return;
+    const int lane = static_cast<int>(g & 63);
+    const int64_t off = G.gslice_off[gs];
+    const int width = static_cast<int>((G.gslice_off[gs + 1] - off) >> 6);
+    double *op = out + kRelRows * off + lane;
+    const uint32_t *wp = G.dwords + G.gslice_doff[gs] + lane;
+    const int64_t r0 = g * kRelRows;
+    const int nr = g < G.n_groups ? static_cast<int>(min(static_cast<int64_t>(kRelRows), A.n_rows - r0)) : 0;
+#pragma unroll
+    for (int p = 0; p < kRelRows; ++p) {
+        const int64_t r = r0 + (p < nr ? p : 0);
+        const int len = p < nr ? A.rowlen[r] : 0;
+        const int64_t base = p < nr ? A.slice_off[r >> 6] + (r & 63) : 0;
+        int64_t c = G.col0[g];       // column of entry k for row r0; row r0+p: c + p
+        int j = 0;
+        for (int k = 0; k < width; ++k) {
+            if (k > 0) {
+                const uint32_t w = wp[64LL * ((k - 1) >> 1)];
+                c += ((k - 1) & 1) ? (w >> 16) : (w & 0xffffu);
+            }
+            double v = 0.0;
+            while (j < len && A.cols[base + 64LL * j] < c + p) ++j;
+            if (j < len && A.cols[base + 64LL * j] == c + p) { v = A.vals[base + 64LL * j]; ++j; }   // ++j: pads repeat c
+            op[(static_cast<int64_t>(kRelRows) * k + p) * 64] = v;
+        }
+    }
+}
+
+typedef double pfem_double2u __attribute__((ext_vector_type(2), aligned(8)));
+
+// x[c .. c+3]: two 16-B loads (8-B aligned)
+__device__ __forceinline__ void load_x4(const double *__restrict__ x, int c, double (&xv)[kRelRows])
+{
+    const pfem_double2u a = *reinterpret_cast<const pfem_double2u *>(x + c);
+    const pfem_double2u b = *reinterpret_cast<const pfem_double2u *>(x + c + 2);
+    xv[0] = a.x; xv[1] = a.y; xv[2] = b.x; xv[3] = b.y;
+}
+
+template <bool WITH_DOT>
+__global__ void __launch_bounds__(kBlock) k_spmvr(SellRDev G, int64_t n_rows, const double *__restrict__ x,
+                                                   double *__restrict__ y, int64_t n_dot, double *partial, const CgCtl *ctl)
+{
+    __shared__ double sm[4];
+    if (WITH_DOT && ctl->flag != 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t gs = (static_cast<int64_t>(blockIdx.x) << 2) + wave;
+    double dot = 0.0;
+    if (gs < G.n_gslices) {
+        const int64_t off = G.gslice_off[gs];
+        const int width = static_cast<int>((G.gslice_off[gs + 1] - off) >> 6);
+        const double *__restrict__ vp = G.vals + kRelRows * off + lane;
+        const uint32_t *__restrict__ wp = G.dwords + G.gslice_doff[gs] + lane;
+        int c = __builtin_nontemporal_load(G.col0 + (gs << 6) + lane);
+        double acc[kRelRows] = {0.0, 0.0, 0.0, 0.0};
+        if (width > 0) {
+            double xv[kRelRows];
+            load_x4(x, c, xv);
+#pragma unroll
+            for (int p = 0; p < kRelRows; ++p) acc[p] = __builtin_nontemporal_load(vp + 64 * p) * xv[p];
+        }
+        const int nw = width / 2;
+        int j = 0;
+        // two words = four entries per trip: 16 value loads + 4 x quads in flight.  The gap words are fetched one
+        // trip ahead so that the x addresses never wait on them, and the scheduling barrier keeps the compiler
+        // from re-using x registers (it would serialise the quads behind vmcnt(0) waits)
+        uint32_t w0 = 0, w1 = 0;
+        if (2 * (j + 2) < width) { w0 = __builtin_nontemporal_load(wp + 64 * j); w1 = __builtin_nontemporal_load(wp + 64 * (j + 1)); }
+        while (2 * (j + 2) < width) {
+            const int c0 = c + static_cast<int>(w0 & 0xffffu), c1 = c0 + static_cast<int>(w0 >> 16);
+            const int c2 = c1 + static_cast<int>(w1 & 0xffffu), c3 = c2 + static_cast<int>(w1 >> 16);
+            double v[4][kRelRows], xv[4][kRelRows];
+            load_x4(x, c0, xv[0]); load_x4(x, c1, xv[1]); load_x4(x, c2, xv[2]); load_x4(x, c3, xv[3]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int p = 0; p < kRelRows; ++p) v[t][p] = __builtin_nontemporal_load(vp + 64 * (kRelRows * (2 * j + 1 + t) + p));
+            c = c3;
+            j += 2;
+            if (2 * (j + 2) < width) { w0 = __builtin_nontemporal_load(wp + 64 * j); w1 = __builtin_nontemporal_load(wp + 64 * (j + 1)); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int p = 0; p < kRelRows; ++p) acc[p] = __builtin_fma(v[t][p], xv[t][p], acc[p]);
+        }
+        for (; j < nw; ++j) {
+            const uint32_t w0 = __builtin_nontemporal_load(wp + 64 * j);
+            const int c0 = c + static_cast<int>(w0 & 0xffffu);
+            const int c1 = c0 + static_cast<int>(w0 >> 16);
+            double xv[kRelRows];
+            load_x4(x, c0, xv);
+#pragma unroll
+            for (int p = 0; p < kRelRows; ++p)
+                acc[p] = __builtin_fma(__builtin_nontemporal_load(vp + 64 * (kRelRows * (2 * j + 1) + p)), xv[p], acc[p]);
+            if (2 * j + 2 < width) {
+                load_x4(x, c1, xv);
+#pragma unroll
+                for (int p = 0; p < kRelRows; ++p)
+                    acc[p] = __builtin_fma(__builtin_nontemporal_load(vp + 64 * (kRelRows * (2 * j + 2) + p)), xv[p], acc[p]);
+            }
+            c = c1;
+        }
+        const int64_t r0 = ((gs << 6) + lane) * kRelRows;
+#pragma unroll
+        for (int p = 0; p < kRelRows; ++p)
+            if (r0 + p < n_rows) {
+                y[r0 + p] = acc[p];
+                if (WITH_DOT && r0 + p < n_dot) dot = __builtin_fma(x[r0 + p], acc[p], dot);
+            }
+    }
+    if (WITH_DOT) {
+        const double t = block_sum(dot, sm);
+        if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Node-block Jacobi (PETSc: -pc_type pbjacobi): M = the diagonal blocks of A over the
 // row groups of k_spmvg (the dof rows of a node, 1..3 rows).  binv_q[i] holds row (i - r0) of the
 // inverse block, column q; z_i = sum_q binv_q[i] * r[r0 + q].  One thread per GROUP in the vector

@@ -190,7 +190,9 @@ def test_spmv_column_formats_bit_identical(name, request):
     s, dm = _device_problem(kind, mesh, ed)
     x = np.random.default_rng(1).standard_normal(dm.size_global)
     y_auto = s.spmv(x)
-    assert s.spmvRowGroup() == (3 if name.startswith("beam") else 1)       # 2-dof nodes: groups of 2 (< 2 rows/lane saved) -> row form
+    # beam: the 3 dof rows of a node share a lane; structured scalar meshes: 4 consecutive rows share a relative
+    # column stream; Cook's membrane (2 dofs per node, unstructured) stays in the row form
+    assert s.spmvRowGroup() == {"beam": 3, "beam_partial": 3, "tet10": 4, "tria20": 1, "cook": 1}[name]
     s.setSpmvFormat("gaps16")
     assert s.spmvRowGroup() == 1 and np.array_equal(y_auto, s.spmv(x))
     s.setSpmvFormat("int32")
