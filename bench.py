@@ -241,11 +241,14 @@ def main():
             "assembly_ms_per_step": asm_ms / args.steps, "solve_ms_per_step": sol_ms / args.steps,
             "setup_s_untimed": t_setup,
             "roofline": {"bound": "hbm",
-                         "kernel": ("pfem::k_spmvg<true> (row-grouped wave-sliced CSR SpMV + (p,Ap) partials: the 3 dof rows of a node "
-                                    "share one lane, 16-bit column gaps), rank 0" if solver.spmvRowGroup() > 1 else
-                                    ("pfem::k_spmv16<true>" if solver.spmvColumnBits() == 16 else "pfem::k_spmv<true>") +
-                                    " (wave-sliced CSR SpMV + (p,Ap) partials; %d-bit column %s), rank 0"
-                                    % (solver.spmvColumnBits(), "gaps" if solver.spmvColumnBits() == 16 else "indices")),
+                         "kernel": {3: "pfem::k_spmvg<true> (row-grouped wave-sliced CSR SpMV + (p,Ap) partials: the 3 dof rows of a "
+                                       "node share one lane, 16-bit column gaps), rank 0",
+                                    4: "pfem::k_spmvr<true> (wave-sliced CSR SpMV + (p,Ap) partials; 4 consecutive rows per lane share "
+                                       "one relative column stream of 16-bit gaps, x read as 32-B quads), rank 0"}.get(
+                             solver.spmvRowGroup(),
+                             ("pfem::k_spmv16<true>" if solver.spmvColumnBits() == 16 else "pfem::k_spmv<true>") +
+                             " (wave-sliced CSR SpMV + (p,Ap) partials; %d-bit column %s), rank 0"
+                             % (solver.spmvColumnBits(), "gaps" if solver.spmvColumnBits() == 16 else "indices")),
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(info["nnz"]) if world == 1 else None,
                          "algorithmic_bytes_per_launch": bytes_per_spmv, "avg_launch_ms": avg_spmv_ms,
