@@ -22,7 +22,7 @@ def val(path):
         if "k_spmv" in line and "<true>" in line:
             return float(line.split()[-1])
 nnz = json.load(open("$OUT/bench_$TAG.json"))["roofline"]["nnz"]
-print(json.dumps({"kernel": "pfem::k_spmv16<true> / k_spmv<true> (whichever the solver selected)", "nnz": nnz, "FETCH_SIZE_KB": val("$OUT/rocprof_pmc_fetch_$TAG.txt"),
+print(json.dumps({"kernel": "the CG SpMV the solver selected (pfem::k_spmvr<true> / k_spmvg<true> / k_spmv16<true> / k_spmv<true>)", "nnz": nnz, "FETCH_SIZE_KB": val("$OUT/rocprof_pmc_fetch_$TAG.txt"),
                   "WRITE_SIZE_KB": val("$OUT/rocprof_pmc_write_$TAG.txt"), "source": "rocprofv3 --pmc, separate passes, tools/gpu_round.sh $TAG"}))
 PY
 tail -5 $OUT/pytest_gpu_$TAG.log; cat $OUT/bench_$TAG.json; head -12 $OUT/rocprof_kernel_stats_$TAG.txt; cat $OUT/rocprof_pmc_fetch_$TAG.txt $OUT/rocprof_pmc_write_$TAG.txt
