@@ -1422,9 +1422,9 @@ __global__ void __launch_bounds__(kBlock) k_cg_update(CgCtl *ctl, int it, int64_
         // x is touched once per iteration (reuse distance = a whole iteration of traffic):
         // stream it past the caches (measured: k_cg_update -4 %, following k_spmv -1.6 %)
         __builtin_nontemporal_store(__builtin_fma(alpha, p[i], __builtin_nontemporal_load(x + i)), x + i);
-        const double ri = __builtin_fma(-alpha, w[i], r[i]);
+        const double ri = __builtin_fma(-alpha, __builtin_nontemporal_load(w + i), r[i]);
         r[i] = ri;
-        const double zi = ri * dinv[i];
+        const double zi = ri * __builtin_nontemporal_load(dinv + i);
         if (i < n_owned) { rz = __builtin_fma(ri, zi, rz); zz = __builtin_fma(zi, zi, zz); }
     }
     const double a = block_sum(rz, sm), c = block_sum(zz, sm);
@@ -1470,7 +1470,7 @@ __global__ void __launch_bounds__(kBlock) k_cg_direction(CgCtl *ctl, int it, int
     const double bb = rz / beta_old;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
          i += static_cast<int64_t>(gridDim.x) * kBlock)
-        p[i] = __builtin_fma(bb, p[i], r[i] * dinv[i]);
+        p[i] = __builtin_fma(bb, p[i], __builtin_nontemporal_load(r + i) * __builtin_nontemporal_load(dinv + i));
 }
 
 // ---------------------------------------------------------------------------
