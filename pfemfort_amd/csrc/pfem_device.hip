@@ -1149,7 +1149,7 @@ int build_rel_groups(pfem_solver *s)
 int refresh_group_vals(pfem_solver *s)
 {
     if (s->use_rel() && s->group_vals_stale) {
-        hipLaunchKernelGGL(k_rel_vals, dim3(grid_for(s->n_rslices * 64)), dim3(kBlock), 0, s->stream, s->sell(), s->sellr(),
+        hipLaunchKernelGGL(k_rel_vals, dim3(static_cast<unsigned>(s->n_rslices)), dim3(kBlock), 0, s->stream, s->sell(), s->sellr(),
                            s->d_rvals.p);
         PFEM_TRY(check_kernel("k_rel_vals"));
         s->group_vals_stale = false;

@@ -1580,36 +1580,35 @@ __global__ void __launch_bounds__(kBlock) k_rel_cols_fill(SellDev A, int64_t n_g
     });
 }
 
-// matrix values, row form -> relative-group form (explicit zeros where a row lacks an offset); once per solve
+// matrix values, row form -> relative-group form (explicit zeros where a row lacks an offset); once per solve.
+// One 256-thread block per slice of 64 groups; wave p converts row r0+p of every group, so its stores are 512-B
+// runs and the four waves of the block share the row-form lines they read.
 __global__ void __launch_bounds__(kBlock) k_rel_vals(SellDev A, SellRDev G, double *out)
 {
-    const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    const int64_t gs = g >> 6;
+    static_assert(kBlock == 64 * kRelRows, "one wave per row of the group");
+    const int64_t gs = blockIdx.x;
     if (gs >= G.n_gslices) return;
-    const int lane = static_cast<int>(g & 63);
+    const int lane = threadIdx.x & 63, p = threadIdx.x >> 6;
+    const int64_t g = (gs << 6) + lane;
     const int64_t off = G.gslice_off[gs];
     const int width = static_cast<int>((G.gslice_off[gs + 1] - off) >> 6);
-    double *op = out + kRelRows * off + lane;
+    double *op = out + kRelRows * off + lane + 64 * p;
     const uint32_t *wp = G.dwords + G.gslice_doff[gs] + lane;
-    const int64_t r0 = g * kRelRows;
-    const int nr = g < G.n_groups ? static_cast<int>(min(static_cast<int64_t>(kRelRows), A.n_rows - r0)) : 0;
-#pragma unroll
-    for (int p = 0; p < kRelRows; ++p) {
-        const int64_t r = r0 + (p < nr ? p : 0);
-        const int len = p < nr ? A.rowlen[r] : 0;
-        const int64_t base = p < nr ? A.slice_off[r >> 6] + (r & 63) : 0;
-        int64_t c = G.col0[g];       // column of entry k for row r0; row r0+p: c + p
-        int j = 0;
-        for (int k = 0; k < width; ++k) {
-            if (k > 0) {
-                const uint32_t w = wp[64LL * ((k - 1) >> 1)];
-                c += ((k - 1) & 1) ? (w >> 16) : (w & 0xffffu);
-            }
-            double v = 0.0;
-            while (j < len && A.cols[base + 64LL * j] < c + p) ++j;
-            if (j < len && A.cols[base + 64LL * j] == c + p) { v = A.vals[base + 64LL * j]; ++j; }   // ++j: pads repeat c
-            op[(static_cast<int64_t>(kRelRows) * k + p) * 64] = v;
+    const int64_t r = g * kRelRows + p;
+    const bool live = g < G.n_groups && r < A.n_rows;
+    const int len = live ? A.rowlen[r] : 0;
+    const int64_t base = live ? A.slice_off[r >> 6] + (r & 63) : 0;
+    int64_t c = G.col0[g] + p;          // column of entry k in THIS row
+    int j = 0;
+    for (int k = 0; k < width; ++k) {
+        if (k > 0) {
+            const uint32_t w = wp[64LL * ((k - 1) >> 1)];
+            c += ((k - 1) & 1) ? (w >> 16) : (w & 0xffffu);
         }
+        double v = 0.0;
+        while (j < len && A.cols[base + 64LL * j] < c) ++j;
+        if (j < len && A.cols[base + 64LL * j] == c) { v = A.vals[base + 64LL * j]; ++j; }   // ++j: pads repeat c
+        op[static_cast<int64_t>(kRelRows) * k * 64] = v;
     }
 }
 
