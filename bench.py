@@ -93,8 +93,8 @@ def cpu_baseline(n=100, rtol=1e-5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cells", dest="n", type=int, default=200, help="cells per side of one rank's block")
     ap.add_argument("--rtol", type=float, default=1e-5, help="PETSc default (the reference sets none)")
     ap.add_argument("--workload", choices=["poisson", "beam"], default="poisson",
@@ -173,7 +173,7 @@ def main():
     solver.buildPattern()
     info = solver.matrixInfo()
     t_setup = time.perf_counter() - t_setup
-    solver.profileSpmv(True)
+    solver.profileSpmv(8)        # event pair around every 8th SpMV launch of the timed solves (each pair costs ~2 us)
 
     def step():
         solver.assemble(elem_data, H.TIMEDATA)

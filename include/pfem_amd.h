@@ -294,7 +294,7 @@ typedef struct pfem_timings {
 } pfem_timings;
 int pfem_get_timings(pfem_solver *s, pfem_timings *t);
 /* record an event pair around every SpMV launch of the next solves (bench.py) */
-int pfem_solver_profile_spmv(pfem_solver *s, int enable);
+int pfem_solver_profile_spmv(pfem_solver *s, int enable);   /* 0 off, 1 every launch, k > 1 every k-th launch */
 
 /* ========================================================================= */
 /* 5. multi-GPU: one process per GPU, sub-assembled interface rows            */

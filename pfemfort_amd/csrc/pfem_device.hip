@@ -276,6 +276,7 @@ struct pfem_solver {
     pfem_timings tm{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool profile_spmv = false;
+    int profile_every = 1;         // event pair around every profile_every-th SpMV launch of a solve
     std::vector<hipEvent_t> spmv_events;
 
     SellDev sell() const
@@ -412,6 +413,7 @@ extern "C" int pfem_solver_profile_spmv(pfem_solver *s, int enable)
 {
     if (!s) return PFEM_ERR_ARG;
     s->profile_spmv = enable != 0;
+    s->profile_every = enable > 1 ? enable : 1;
     return PFEM_OK;
 }
 
@@ -1484,7 +1486,7 @@ int run_pcg(pfem_solver *s)
         for (; it < it_end; ++it) {
             // w = A p, partial (p, A_loc p) over ALL local rows (sub-assembled identity)
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (s->profile_spmv && ev_used + 2 <= 8192) {
+            if (s->profile_spmv && it % s->profile_every == 0 && ev_used + 2 <= 8192) {
                 if (s->spmv_events.size() < ev_used + 2) {
                     hipEvent_t a, b;
                     PFEM_HIP(hipEventCreate(&a));
@@ -1537,7 +1539,8 @@ int run_pcg(pfem_solver *s)
     s->tm.spmv_ms_total = 0.0;
     s->tm.spmv_launches = 0;
     // only launches that did work count (the tail of the last chunk exits at the flag test)
-    const size_t live = std::min(ev_used / 2, static_cast<size_t>(h.its));
+    // (the k-th pair belongs to iteration k * profile_every)
+    const size_t live = std::min(ev_used / 2, (static_cast<size_t>(h.its) + s->profile_every - 1) / s->profile_every);
     for (size_t k = 0; k < live; ++k) {
         float f = 0.f;
         PFEM_HIP(hipEventElapsedTime(&f, s->spmv_events[2 * k], s->spmv_events[2 * k + 1]));
