@@ -250,8 +250,10 @@ int pfem_solver_get_spmv_row_group(pfem_solver *s, int *rows_per_lane);
 /* Preconditioner of the CG (PCSetType, solverpetsc.F:206).  JACOBI (default) is the diagonal scaling
  * BASELINE's north_star names.  NODE_BLOCK_JACOBI (PETSc: -pc_type pbjacobi) inverts the
  * diagonal block of every row group of the SpMV (the 1..3 dof rows of a node); it takes effect when the
- * pattern has such groups (3-dof problems) and the solver runs on one rank, otherwise JACOBI stays in
- * effect -- pfem_solver_get_preconditioner reports which one the next solve uses. */
+ * pattern has such groups (3-dof problems) and, on several ranks, when all ranks hold the same groups for
+ * the dofs they share (voted at the start of a solve; blocks of shared nodes are summed over the ranks),
+ * otherwise JACOBI stays in effect -- pfem_solver_get_preconditioner reports which one the last solve
+ * used / the next one will try. */
 #define PFEM_PC_JACOBI 0
 #define PFEM_PC_NODE_BLOCK_JACOBI 1
 int pfem_solver_set_preconditioner(pfem_solver *s, int pc);

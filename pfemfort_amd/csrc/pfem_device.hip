@@ -240,7 +240,8 @@ struct pfem_solver {
     DevBuf<double> d_binv[3];      // node-block Jacobi: row (i - r0) of the inverse diagonal block, columns 0..2
     DevBuf<double> d_r2;           // ... second residual buffer (ping-pong) and per-row (first row | size << 30)
     DevBuf<uint32_t> d_row_grp;
-    bool block_pc() const { return pc == PFEM_PC_NODE_BLOCK_JACOBI && grouped && nranks == 1 && n_loc < (1LL << 30); }
+    bool block_pc_ok = true;       // multi-rank: the ranks agreed that their row groups coincide on shared dofs
+    bool block_pc() const { return pc == PFEM_PC_NODE_BLOCK_JACOBI && grouped && n_loc < (1LL << 30) && (nranks == 1 || block_pc_ok); }
     bool rhs_summed = false;
 
     // CG state
@@ -1355,7 +1356,7 @@ int interface_sum(pfem_solver *s, double *v, const double *part0, const double *
                        s->n_iface, part0, part1, nparts, n_extra, ctl);
     PFEM_TRY(check_kernel("k_pack"));
     PFEM_TRY(call_hook(s, buf, s->n_iface + n_extra));
-    if (s->n_shared > 0) {
+    if (v && s->n_shared > 0) {
         hipLaunchKernelGGL(k_unpack, dim3(grid_for(s->n_shared)), dim3(kBlock), 0, s->stream, v, s->d_shared_lidx.p,
                            s->d_shared_slot.p, s->n_shared, buf, ctl);
         PFEM_TRY(check_kernel("k_unpack"));
@@ -1398,20 +1399,60 @@ int run_pcg(pfem_solver *s)
     }
     PFEM_HIP(hipMemsetAsync(ctl, 0, sizeof(CgCtl), s->stream));
 
-    const bool bpc = s->block_pc();
     const int32_t *grow0 = s->d_group_row0.p;
-    if (bpc) {
-        // node-block Jacobi: inverse of the diagonal block of every row group (single rank)
+    s->block_pc_ok = true;
+    if (s->block_pc()) {
         for (auto &b : s->d_binv)
             if (b.n < static_cast<size_t>(n)) PFEM_TRY(b.alloc(static_cast<size_t>(n)));
+        if (s->d_row_grp.n < static_cast<size_t>(n)) PFEM_TRY(s->d_row_grp.alloc(static_cast<size_t>(n)));
+        hipLaunchKernelGGL(k_fill_row_groups, dim3(grid_for(s->n_groups)), block, 0, s->stream, grow0, s->n_groups, s->d_row_grp.p);
+        PFEM_TRY(check_kernel("k_fill_row_groups"));
+    }
+    if (multi && s->pc == PFEM_PC_NODE_BLOCK_JACOBI) {
+        // Every rank must take the same branch.  The groups come from each rank's own local pattern: use them only
+        // if all ranks hold the same group (position, size) for every dof they share; a rank without groups votes no.
+        double *bad = part_rz;              // scratch: [0] = this rank's verdict, summed over the ranks
+        PFEM_HIP(hipMemsetAsync(bad, 0, 2 * sizeof(double), s->stream));
+        PFEM_HIP(hipMemsetAsync(part_zz, 0, sizeof(double), s->stream));
+        if (s->block_pc()) {
+            const uint32_t *rgp = s->d_row_grp.p;
+            hipLaunchKernelGGL(k_group_sig, dim3(grid_for(n)), block, 0, s->stream, rgp, n, s->d_binv[0].p, s->d_binv[1].p);
+            PFEM_TRY(interface_sum(s, s->d_binv[0].p, nullptr, nullptr, 0, 0, nullptr));
+            PFEM_TRY(interface_sum(s, s->d_binv[1].p, nullptr, nullptr, 0, 0, nullptr));
+            hipLaunchKernelGGL(k_group_sig_check, dim3(grid_for(n)), block, 0, s->stream, rgp, n,
+                               static_cast<const double *>(s->d_binv[0].p), static_cast<const double *>(s->d_binv[1].p), bad);
+            PFEM_TRY(check_kernel("k_group_sig_check"));
+        } else {
+            // no groups here: still take part in the two interface sums of the others, then vote no
+            PFEM_TRY(interface_sum(s, nullptr, nullptr, nullptr, 0, 0, nullptr));
+            PFEM_TRY(interface_sum(s, nullptr, nullptr, nullptr, 0, 0, nullptr));
+            const double one = 1.0;
+            PFEM_HIP(hipMemcpyAsync(bad, &one, sizeof(double), hipMemcpyHostToDevice, s->stream));
+        }
+        PFEM_TRY(scalar_sum2(s, bad, part_zz, 1, nullptr));
+        double verdict[2] = {0.0, 0.0};
+        PFEM_HIP(hipMemcpyAsync(verdict, s->xbuf + s->n_iface + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+        s->block_pc_ok = verdict[0] == 0.0;
+    }
+    const bool bpc = s->block_pc();
+    if (bpc) {
+        // node-block Jacobi: inverse of the diagonal block of every row group; blocks of shared nodes and the rhs
+        // are summed over the ranks first
         hipLaunchKernelGGL(k_extract_blocks, dim3(grid_for(s->n_groups)), block, 0, s->stream, A, grow0, s->n_groups,
                            s->d_binv[0].p, s->d_binv[1].p, s->d_binv[2].p);
+        PFEM_TRY(check_kernel("k_extract_blocks"));
+        if (multi) {
+            for (auto &b : s->d_binv) PFEM_TRY(interface_sum(s, b.p, nullptr, nullptr, 0, 0, nullptr));
+            if (!s->rhs_summed) {
+                PFEM_TRY(interface_sum(s, s->d_rhs.p, nullptr, nullptr, 0, 0, nullptr));
+                s->rhs_summed = true;
+            }
+        }
         hipLaunchKernelGGL(k_invert_blocks, dim3(grid_for(s->n_groups)), block, 0, s->stream, grow0, s->n_groups, s->d_binv[0].p,
                            s->d_binv[1].p, s->d_binv[2].p);
         PFEM_TRY(check_kernel("k_invert_blocks"));
         if (s->d_r2.n < static_cast<size_t>(n)) PFEM_TRY(s->d_r2.alloc(static_cast<size_t>(n)));
-        if (s->d_row_grp.n < static_cast<size_t>(n)) PFEM_TRY(s->d_row_grp.alloc(static_cast<size_t>(n)));
-        hipLaunchKernelGGL(k_fill_row_groups, dim3(grid_for(s->n_groups)), block, 0, s->stream, grow0, s->n_groups, s->d_row_grp.p);
         hipLaunchKernelGGL(k_cg_init_b, dim3(gv), block, 0, s->stream, n, static_cast<const uint32_t *>(s->d_row_grp.p), s->n_owned,
                            s->d_rhs.p, s->d_binv[0].p, s->d_binv[1].p, s->d_binv[2].p, s->d_x.p, s->d_r.p, s->d_p.p, part_rz, part_zz);
         PFEM_TRY(check_kernel("k_cg_init_b"));
@@ -1520,6 +1561,7 @@ int run_pcg(pfem_solver *s)
                 hipLaunchKernelGGL(k_cg_update_b, dim3(gv), block, 0, s->stream, ctl, it, n, rgp, s->n_owned, pw_parts, pw_n, red_pw,
                                    s->d_p.p, s->d_w.p, s->d_binv[0].p, s->d_binv[1].p, s->d_binv[2].p, s->d_x.p, r_a, r_b, part_rz,
                                    part_zz);
+                if (multi) PFEM_TRY(scalar_sum2(s, part_rz, part_zz, static_cast<int>(gv), ctl));
                 hipLaunchKernelGGL(k_cg_direction_b, dim3(gv), block, 0, s->stream, ctl, it, n, rgp, part_rz, part_zz,
                                    static_cast<int>(gv), red2, static_cast<const double *>(r_b), s->d_binv[0].p, s->d_binv[1].p,
                                    s->d_binv[2].p, s->d_p.p, s->d_hist.p, s->hist_cap, s->maxits);

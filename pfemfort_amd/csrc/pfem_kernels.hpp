@@ -1761,6 +1761,29 @@ __global__ void __launch_bounds__(kBlock) k_fill_row_groups(const int32_t *group
     for (int q = 0; q < sz; ++q) row_grp[r0 + q] = static_cast<uint32_t>(r0) | (static_cast<uint32_t>(sz) << 30);
 }
 
+// Multi-rank consistency of the row groups: sig_i = 1 + (i - r0) + 4 * size must be the same on every rank
+// that holds dof i.  After interface sums S1 = sum sig, S2 = sum sig^2 (small integers: exact), all ranks
+// agree on dof i iff S2 = sig_i * S1 on every one of them.
+__global__ void __launch_bounds__(kBlock) k_group_sig(const uint32_t *row_grp, int64_t n, double *s1, double *s2)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t rg = row_grp[i];
+    const double sig = 1.0 + static_cast<double>(i - static_cast<int64_t>(rg & 0x3fffffffu)) + 4.0 * static_cast<double>(rg >> 30);
+    s1[i] = sig;
+    s2[i] = sig * sig;
+}
+
+__global__ void __launch_bounds__(kBlock) k_group_sig_check(const uint32_t *row_grp, int64_t n, const double *s1, const double *s2,
+                                                             double *bad)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t rg = row_grp[i];
+    const double sig = 1.0 + static_cast<double>(i - static_cast<int64_t>(rg & 0x3fffffffu)) + 4.0 * static_cast<double>(rg >> 30);
+    if (s2[i] != sig * s1[i]) bad[0] = 1.0;     // benign race: every writer stores the same value
+}
+
 // z_i = sum_q binv_q[i] * rr[q], q ascending
 __device__ __forceinline__ double block_row_apply(double bi0, double bi1, double bi2, int sz, const double (&rr)[kGroupRows])
 {
