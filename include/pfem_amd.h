@@ -237,11 +237,15 @@ int pfem_solver_set_assembly_mode(pfem_solver *s, int mode);
  * row (4 + 2 B per entry instead of 4 B) whenever every gap of the pattern fits, and on top of that
  * serves consecutive rows with identical column sets (the dof rows of a node) from one lane with a
  * shared column stream when the pattern has, on average, at least 2.75 such rows per group of 3;
- * GAPS16 forces the plain row form with 16-bit gaps, INT32 plain int32 columns.  Every row sums
- * the same products in the same order: y is bit-identical in all three. */
+ * or (scalar problems) serves 4 consecutive rows from one lane with the union of their columns
+ * relative to the row -- both only when the system is large enough to keep the chip full with
+ * 3-4x fewer waves (>= 327 680 groups); GROUPED takes the group forms at any size, GAPS16 forces
+ * the plain row form with 16-bit gaps, INT32 plain int32 columns.  Every row sums the same
+ * products in the same order: y is bit-identical in all of them. */
 #define PFEM_SPMV_AUTO 0
 #define PFEM_SPMV_INT32 1
 #define PFEM_SPMV_GAPS16 2
+#define PFEM_SPMV_GROUPED 3   /* the row-group forms whenever the pattern has them, however small the system */
 int pfem_solver_set_spmv_format(pfem_solver *s, int format);
 /* 16 if the SpMV currently streams 16-bit column gaps, 32 for int32 columns */
 int pfem_solver_get_spmv_format(pfem_solver *s, int *bits_per_column);

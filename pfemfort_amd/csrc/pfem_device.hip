@@ -195,7 +195,13 @@ struct pfem_solver {
     DevBuf<int64_t> d_gslice_off, d_gslice_doff;
     DevBuf<uint32_t> d_gdwords;
     DevBuf<double> d_gvals;
-    bool use_grouped() const { return grouped && spmv_format == PFEM_SPMV_AUTO; }
+    // the grouped forms put 3-4 rows on a lane, i.e. 3-4x fewer waves: AUTO takes them only when the slices still
+    // fill the chip several times over (measured: 50^3 Poisson 10.3 vs 8.5 us per SpMV, 100^3 equal, 200^3 -15 %)
+    static constexpr int64_t kMinGroupsAuto = 327680;      // 5120 wave slots x 64 lanes
+    bool use_grouped() const
+    {
+        return grouped && (spmv_format == PFEM_SPMV_GROUPED || (spmv_format == PFEM_SPMV_AUTO && n_groups >= kMinGroupsAuto));
+    }
     // SpMV-only relative row groups (k_spmvr): 4 consecutive rows, one relative column stream
     bool relgrouped = false;
     int64_t n_rgroups = 0, n_rslices = 0, r_stored = 0;
@@ -203,7 +209,11 @@ struct pfem_solver {
     DevBuf<int64_t> d_rslice_off, d_rslice_doff;
     DevBuf<uint32_t> d_rdwords;
     DevBuf<double> d_rvals;
-    bool use_rel() const { return relgrouped && !use_grouped() && spmv_format == PFEM_SPMV_AUTO; }
+    bool use_rel() const
+    {
+        return relgrouped && !use_grouped() &&
+               (spmv_format == PFEM_SPMV_GROUPED || (spmv_format == PFEM_SPMV_AUTO && n_rgroups >= kMinGroupsAuto));
+    }
     SellRDev sellr() const
     {
         SellRDev G;
@@ -276,6 +286,11 @@ struct pfem_solver {
     // timing
     pfem_timings tm{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // hipGraph replay of the CG iteration (single rank, point Jacobi): units of kGraphIters iterations;
+    // [0] = full iterations, [1] = the first SpMV left out (it is launched with its event pair on the stream)
+    hipGraphExec_t cg_graph[2] = {nullptr, nullptr};
+    std::vector<uint64_t> cg_graph_key;
+    bool cg_graph_off = false;
     bool profile_spmv = false;
     int profile_every = 1;         // event pair around every profile_every-th SpMV launch of a solve
     std::vector<hipEvent_t> spmv_events;
@@ -379,6 +394,8 @@ extern "C" int pfem_solver_destroy(pfem_solver *s)
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     if (s->h_err) (void)hipHostFree(s->h_err);
+    for (auto &g : s->cg_graph)
+        if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return PFEM_OK;
@@ -393,6 +410,8 @@ extern "C" int pfem_solver_set_stream(pfem_solver *s, void *hip_stream)
     // adopt the caller's stream as is; a null handle IS a stream (the legacy default stream,
     // which is what torch.cuda.current_stream() is unless the caller switched streams)
     s->stream = static_cast<hipStream_t>(hip_stream);
+    s->cg_graph_key.clear();
+    s->cg_graph_off = false;
     return PFEM_OK;
 }
 
@@ -536,6 +555,7 @@ int pattern_from_keys(pfem_solver *s, DevBuf<uint64_t> &keys, int64_t nkeys)
         return PFEM_ERR_ARG;
     }
     const int64_t n = s->n_loc;
+    s->cg_graph_key.clear();               // every array a captured CG iteration points at is about to be replaced
     int bits = 1;
     while ((1LL << bits) < std::max<int64_t>(n, 2)) ++bits;
     const int end_bit = std::min(64, 32 + bits);
@@ -1229,7 +1249,7 @@ extern "C" int pfem_solver_get_spmv_row_group(pfem_solver *s, int *rows_per_lane
 
 extern "C" int pfem_solver_set_spmv_format(pfem_solver *s, int format)
 {
-    if (!s || (format != PFEM_SPMV_AUTO && format != PFEM_SPMV_INT32 && format != PFEM_SPMV_GAPS16)) return PFEM_ERR_ARG;
+    if (!s || format < PFEM_SPMV_AUTO || format > PFEM_SPMV_GROUPED) return PFEM_ERR_ARG;
     s->spmv_format = format;
     return PFEM_OK;
 }
@@ -1488,6 +1508,69 @@ int run_pcg(pfem_solver *s)
                        s->abstol, s->dtol, s->d_hist.p);
     PFEM_TRY(check_kernel("k_cg_start"));
 
+    // ---- hipGraph replay (single rank, point Jacobi, capturable stream) --------------------------------
+    // A dependent kernel costs ~3.4 us launched on a stream and ~1.75 us inside a graph (tools/lab/graph_gap.hip).
+    // Measured per iteration, graph vs stream: 30^3 (27 k rows) 19.3 vs 26.6 us, 100^3 60.0 vs 59.3, 200^3 345 vs
+    // 340: replay pays while the kernels are latency-bound, so it is used below kGraphMaxRows rows only.
+    // The iteration index travels in the control block for replayed launches (it_arg = -1).
+    constexpr int kGraphIters = 8;
+    constexpr int64_t kGraphMaxRows = 1 << 18;
+    bool use_graph = false;
+    {
+        static const int graph_env = [] { const char *e = std::getenv("PFEM_CG_GRAPH"); return e ? std::atoi(e) : 1; }();
+        const bool sampled_ok = !s->profile_spmv || s->profile_every % kGraphIters == 0;
+        if (graph_env && !s->cg_graph_off && !multi && !bpc && n > 0 && (n <= kGraphMaxRows || graph_env > 1) &&
+            s->stream != nullptr && sampled_ok) {
+            const int fmt = s->use_grouped() ? 3 : (s->use_rel() ? 4 : ((s->cols16 && s->spmv_format != PFEM_SPMV_INT32) ? 2 : 1));
+            const std::vector<uint64_t> key = {
+                reinterpret_cast<uint64_t>(s->d_p.p), reinterpret_cast<uint64_t>(s->d_w.p), reinterpret_cast<uint64_t>(s->d_r.p),
+                reinterpret_cast<uint64_t>(s->d_x.p), reinterpret_cast<uint64_t>(s->d_dinv.p), reinterpret_cast<uint64_t>(s->d_part.p),
+                reinterpret_cast<uint64_t>(s->d_part_pw.p), reinterpret_cast<uint64_t>(ctl), reinterpret_cast<uint64_t>(s->d_hist.p),
+                reinterpret_cast<uint64_t>(s->d_vals.p), reinterpret_cast<uint64_t>(s->d_cols.p), reinterpret_cast<uint64_t>(s->d_rvals.p),
+                reinterpret_cast<uint64_t>(s->d_gvals.p), reinterpret_cast<uint64_t>(s->d_dwords.p), reinterpret_cast<uint64_t>(s->stream),
+                static_cast<uint64_t>(s->hist_cap), static_cast<uint64_t>(s->maxits), static_cast<uint64_t>(n),
+                static_cast<uint64_t>(s->n_owned), static_cast<uint64_t>(gs), static_cast<uint64_t>(gv), static_cast<uint64_t>(fmt)};
+            if (key != s->cg_graph_key || !s->cg_graph[0] || !s->cg_graph[1]) {
+                for (auto &g : s->cg_graph)
+                    if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+                s->cg_graph_key.clear();
+                bool ok = true;
+                for (int variant = 0; variant < 2 && ok; ++variant) {
+                    hipGraph_t graph = nullptr;
+                    if (hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { ok = false; break; }
+                    for (int k = 0; k < kGraphIters; ++k) {
+                        if (!(variant == 1 && k == 0)) launch_spmv<true>(s, s->d_p.p, s->d_w.p, n, part_pw, ctl);
+                        const double *pw_parts = part_pw;
+                        int pw_n = static_cast<int>(gs);
+                        if (gs > kMaxGrid) {
+                            hipLaunchKernelGGL(k_fold_partials, dim3(kFoldBlocks), block, 0, s->stream, static_cast<const double *>(part_pw),
+                                               static_cast<int>(gs), scal_pw, static_cast<const CgCtl *>(ctl));
+                            pw_parts = scal_pw;
+                            pw_n = kFoldBlocks;
+                        }
+                        hipLaunchKernelGGL(k_cg_update, dim3(gv), block, 0, s->stream, ctl, -1, n, s->n_owned, pw_parts, pw_n,
+                                           static_cast<const double *>(nullptr), s->d_p.p, s->d_w.p, s->d_dinv.p, s->d_x.p, s->d_r.p,
+                                           part_rz, part_zz);
+                        hipLaunchKernelGGL(k_cg_direction, dim3(gv), block, 0, s->stream, ctl, -1, n, part_rz, part_zz,
+                                           static_cast<int>(gv), static_cast<const double *>(nullptr), s->d_r.p, s->d_dinv.p, s->d_p.p,
+                                           s->d_hist.p, s->hist_cap, s->maxits);
+                    }
+                    if (hipStreamEndCapture(s->stream, &graph) != hipSuccess || !graph) { ok = false; break; }
+                    if (hipGraphInstantiate(&s->cg_graph[variant], graph, nullptr, nullptr, 0) != hipSuccess) ok = false;
+                    (void)hipGraphDestroy(graph);
+                }
+                if (ok) {
+                    s->cg_graph_key = key;
+                } else {        // not capturable here (e.g. a legacy default stream): stream launches from now on
+                    (void)hipGetLastError();
+                    for (auto &g : s->cg_graph)
+                        if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+                    s->cg_graph_off = true;
+                }
+            }
+            use_graph = !s->cg_graph_off && s->cg_graph[0] && s->cg_graph[1];
+        }
+    }
     static const int chunk_env = [] { const char *e = std::getenv("PFEM_CG_CHUNK"); return e ? std::atoi(e) : 0; }();
     const int chunk = chunk_env > 0 ? chunk_env : 32;
     size_t ev_used = 0;
@@ -1527,7 +1610,8 @@ int run_pcg(pfem_solver *s)
         for (; it < it_end; ++it) {
             // w = A p, partial (p, A_loc p) over ALL local rows (sub-assembled identity)
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (s->profile_spmv && it % s->profile_every == 0 && ev_used + 2 <= 8192) {
+            const bool sample = s->profile_spmv && it % s->profile_every == 0 && ev_used + 2 <= 8192;
+            if (sample) {
                 if (s->spmv_events.size() < ev_used + 2) {
                     hipEvent_t a, b;
                     PFEM_HIP(hipEventCreate(&a));
@@ -1538,6 +1622,13 @@ int run_pcg(pfem_solver *s)
                 e0 = s->spmv_events[ev_used];
                 e1 = s->spmv_events[ev_used + 1];
                 ev_used += 2;
+            }
+            if (use_graph && it + kGraphIters <= it_end) {
+                // kGraphIters iterations from one graph launch; a sampled SpMV stays outside with its event pair
+                if (sample) launch_spmv<true>(s, s->d_p.p, s->d_w.p, n, part_pw, ctl, e0, e1);
+                PFEM_HIP(hipGraphLaunch(s->cg_graph[sample ? 1 : 0], s->stream));
+                it += kGraphIters - 1;
+                continue;
             }
             // with events: marker-end -> kernel-end of THIS launch (see event_overhead_ms)
             launch_spmv<true>(s, s->d_p.p, s->d_w.p, n, part_pw, ctl, e0, e1);

@@ -932,7 +932,8 @@ struct CgCtl {            // device-resident control block of the CG iteration
     double rn;            // last preconditioned residual norm
     double dtol;
     int flag;             // 0 = running, else KSPConvergedReason
-    int its;              // iterations completed
+    int its;              // iterations completed (written by k_cg_direction, read by k_cg_update of the next iteration)
+    int its_dir;          // iteration index handed from k_cg_update to k_cg_direction (graph launches carry no `it`)
 };
 
 template <bool WITH_DOT>
@@ -1401,7 +1402,8 @@ __global__ void __launch_bounds__(kBlock) k_cg_start(CgCtl *ctl, const double *p
 }
 
 // alpha = beta/(p,w); x += alpha p; r -= alpha w; partials of (r,z), (z,z), z = r*dinv
-__global__ void __launch_bounds__(kBlock) k_cg_update(CgCtl *ctl, int it, int64_t n, int64_t n_owned,
+// `it_arg` < 0 (launches replayed from a hipGraph): the iteration index is taken from the control block.
+__global__ void __launch_bounds__(kBlock) k_cg_update(CgCtl *ctl, int it_arg, int64_t n, int64_t n_owned,
                                                        const double *part_pw, int nparts, const double *reduced_pw,
                                                        const double *__restrict__ p, const double *__restrict__ w,
                                                        const double *__restrict__ dinv, double *__restrict__ x,
@@ -1409,6 +1411,8 @@ __global__ void __launch_bounds__(kBlock) k_cg_update(CgCtl *ctl, int it, int64_
 {
     __shared__ double sm[4];
     if (ctl->flag != 0) return;
+    const int it = it_arg >= 0 ? it_arg : ctl->its;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->its_dir = it;      // nobody in this launch reads it
     const double pw = reduced_pw ? *reduced_pw : sum_partials(part_pw, nparts, sm);
     if (!(pw > 0.0)) {                      // KSP_DIVERGED_INDEFINITE_MAT
         if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->its = it; }
@@ -1432,13 +1436,14 @@ __global__ void __launch_bounds__(kBlock) k_cg_update(CgCtl *ctl, int it, int64_
 }
 
 // finish (r,z), ||z||; convergence test; p = z + (beta_new/beta) p
-__global__ void __launch_bounds__(kBlock) k_cg_direction(CgCtl *ctl, int it, int64_t n, const double *part_rz,
+__global__ void __launch_bounds__(kBlock) k_cg_direction(CgCtl *ctl, int it_arg, int64_t n, const double *part_rz,
                                                           const double *part_zz, int nparts, const double *reduced,
                                                           const double *__restrict__ r, const double *__restrict__ dinv,
                                                           double *__restrict__ p, double *hist, int hist_cap, int maxits)
 {
     __shared__ double sm[4];
     if (ctl->flag != 0) return;
+    const int it = it_arg >= 0 ? it_arg : ctl->its_dir;              // ctl->its is written by this launch: not read here
     double rz, zz;
     if (reduced) { rz = reduced[0]; zz = reduced[1]; }
     else { rz = sum_partials(part_rz, nparts, sm); zz = sum_partials(part_zz, nparts, sm); }

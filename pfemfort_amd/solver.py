@@ -160,9 +160,9 @@ class PetscSolver:
                 "pfem_solver_set_assembly_mode")
 
     def setSpmvFormat(self, fmt):
-        """"auto" (16-bit column gaps when they fit, row-grouped when the pattern has multi-dof nodes),
-        "gaps16" (16-bit gaps, one row per lane) or "int32"."""
-        L.check(L.lib().pfem_solver_set_spmv_format(self._h, {"auto": 0, "int32": 1, "gaps16": 2}[fmt]), "pfem_solver_set_spmv_format")
+        """"auto" (16-bit column gaps when they fit; row groups when the pattern has them and the system is large),
+        "grouped" (row groups at any size), "gaps16" (16-bit gaps, one row per lane) or "int32"."""
+        L.check(L.lib().pfem_solver_set_spmv_format(self._h, {"auto": 0, "int32": 1, "gaps16": 2, "grouped": 3}[fmt]), "pfem_solver_set_spmv_format")
 
     def spmvColumnBits(self):
         b = C.c_int(0)

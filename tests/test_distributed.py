@@ -184,6 +184,7 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
         s.setTolerances(rtol=1e-10)
         if mesh_args.get("pc"):
             s.setPreconditioner(mesh_args["pc"])
+        s.setSpmvFormat(mesh_args.get("spmv", "auto"))
         ed = H.ELAST_ELEMDATA if kind == pf.ELAST_TET else H.POISSON_ELEMDATA
         if mesh_args.get("mode", "batched") == "batched":
             s.uploadMesh(kind, conn_loc, xyz_new, edof_g, dm.solnApplied)
@@ -232,6 +233,8 @@ def test_gpu_ranks_on_one_device_match_single_rank(tmp_path, kind_name, world, p
                  {"box": (-0.5, 0.5, 3, 0.0, 3.0, 8, -0.5, 0.5, 6), "bc_mode": 1, "ndof": 3})
     mesh_args["partition"] = partition
     mesh_args["mode"] = mode
+    if world == 3 or mode != "batched":   # the row-group SpMV forms ("auto" keeps systems this small in the row form)
+        mesh_args["spmv"] = "grouped"
     if mode == "pbjacobi":            # node-block Jacobi on several ranks (blocks of shared nodes summed, groups voted)
         mesh_args["mode"], mesh_args["pc"] = "batched", "pbjacobi"
     if mode == "compat" and kind_name == "poisson":

@@ -189,6 +189,8 @@ def test_spmv_column_formats_bit_identical(name, request):
                       np.concatenate([mesh.bc_dof[keep], extra % 3]).astype(np.int32), np.zeros(keep.sum() + 30))
     s, dm = _device_problem(kind, mesh, ed)
     x = np.random.default_rng(1).standard_normal(dm.size_global)
+    assert s.spmvRowGroup() == 1               # "auto" keeps small systems in the row form
+    s.setSpmvFormat("grouped")
     y_auto = s.spmv(x)
     # beam: the 3 dof rows of a node share a lane; structured scalar meshes: 4 consecutive rows share a relative
     # column stream; Cook's membrane (2 dofs per node, unstructured) stays in the row form
