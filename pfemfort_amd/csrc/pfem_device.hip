@@ -248,7 +248,7 @@ struct pfem_solver {
     } d_p;
     int pc = PFEM_PC_JACOBI;
     DevBuf<double> d_binv[3];      // node-block Jacobi: row (i - r0) of the inverse diagonal block, columns 0..2
-    DevBuf<double> d_r2;           // ... second residual buffer (ping-pong) and per-row (first row | size << 30)
+    DevBuf<double> d_r2, d_z;      // ... second residual buffer (ping-pong), z = Binv r, per-row (first row | size << 30)
     DevBuf<uint32_t> d_row_grp;
     bool block_pc_ok = true;       // multi-rank: the ranks agreed that their row groups coincide on shared dofs
     bool block_pc() const { return pc == PFEM_PC_NODE_BLOCK_JACOBI && grouped && n_loc < (1LL << 30) && (nranks == 1 || block_pc_ok); }
@@ -1473,6 +1473,7 @@ int run_pcg(pfem_solver *s)
                            s->d_binv[1].p, s->d_binv[2].p);
         PFEM_TRY(check_kernel("k_invert_blocks"));
         if (s->d_r2.n < static_cast<size_t>(n)) PFEM_TRY(s->d_r2.alloc(static_cast<size_t>(n)));
+        if (s->d_z.n < static_cast<size_t>(n)) PFEM_TRY(s->d_z.alloc(static_cast<size_t>(n)));
         hipLaunchKernelGGL(k_cg_init_b, dim3(gv), block, 0, s->stream, n, static_cast<const uint32_t *>(s->d_row_grp.p), s->n_owned,
                            s->d_rhs.p, s->d_binv[0].p, s->d_binv[1].p, s->d_binv[2].p, s->d_x.p, s->d_r.p, s->d_p.p, part_rz, part_zz);
         PFEM_TRY(check_kernel("k_cg_init_b"));
@@ -1650,12 +1651,12 @@ int run_pcg(pfem_solver *s)
                 double *r_b = (it & 1) ? s->d_r.p : s->d_r2.p;
                 const uint32_t *rgp = s->d_row_grp.p;
                 hipLaunchKernelGGL(k_cg_update_b, dim3(gv), block, 0, s->stream, ctl, it, n, rgp, s->n_owned, pw_parts, pw_n, red_pw,
-                                   s->d_p.p, s->d_w.p, s->d_binv[0].p, s->d_binv[1].p, s->d_binv[2].p, s->d_x.p, r_a, r_b, part_rz,
-                                   part_zz);
+                                   s->d_p.p, s->d_w.p, s->d_binv[0].p, s->d_binv[1].p, s->d_binv[2].p, s->d_x.p, r_a, r_b, s->d_z.p,
+                                   part_rz, part_zz);
                 if (multi) PFEM_TRY(scalar_sum2(s, part_rz, part_zz, static_cast<int>(gv), ctl));
-                hipLaunchKernelGGL(k_cg_direction_b, dim3(gv), block, 0, s->stream, ctl, it, n, rgp, part_rz, part_zz,
-                                   static_cast<int>(gv), red2, static_cast<const double *>(r_b), s->d_binv[0].p, s->d_binv[1].p,
-                                   s->d_binv[2].p, s->d_p.p, s->d_hist.p, s->hist_cap, s->maxits);
+                hipLaunchKernelGGL(k_cg_direction_b, dim3(gv), block, 0, s->stream, ctl, it, n, part_rz, part_zz,
+                                   static_cast<int>(gv), red2, static_cast<const double *>(s->d_z.p), s->d_p.p, s->d_hist.p,
+                                   s->hist_cap, s->maxits);
                 continue;
             }
             hipLaunchKernelGGL(k_cg_update, dim3(gv), block, 0, s->stream, ctl, it, n, s->n_owned, pw_parts, pw_n,

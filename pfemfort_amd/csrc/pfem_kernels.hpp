@@ -1426,9 +1426,9 @@ __global__ void __launch_bounds__(kBlock) k_cg_update(CgCtl *ctl, int it_arg, in
         // x is touched once per iteration (reuse distance = a whole iteration of traffic):
         // stream it past the caches (measured: k_cg_update -4 %, following k_spmv -1.6 %)
         __builtin_nontemporal_store(__builtin_fma(alpha, p[i], __builtin_nontemporal_load(x + i)), x + i);
-        const double ri = __builtin_fma(-alpha, __builtin_nontemporal_load(w + i), r[i]);
+        const double ri = __builtin_fma(-alpha, w[i], r[i]);
         r[i] = ri;
-        const double zi = ri * __builtin_nontemporal_load(dinv + i);
+        const double zi = ri * dinv[i];
         if (i < n_owned) { rz = __builtin_fma(ri, zi, rz); zz = __builtin_fma(zi, zi, zz); }
     }
     const double a = block_sum(rz, sm), c = block_sum(zz, sm);
@@ -1475,7 +1475,7 @@ __global__ void __launch_bounds__(kBlock) k_cg_direction(CgCtl *ctl, int it_arg,
     const double bb = rz / beta_old;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
          i += static_cast<int64_t>(gridDim.x) * kBlock)
-        p[i] = __builtin_fma(bb, p[i], __builtin_nontemporal_load(r + i) * __builtin_nontemporal_load(dinv + i));
+        p[i] = __builtin_fma(bb, p[i], r[i] * dinv[i]);
 }
 
 // ---------------------------------------------------------------------------
@@ -1830,7 +1830,8 @@ __global__ void __launch_bounds__(kBlock) k_cg_update_b(CgCtl *ctl, int it, int6
                                                          const double *__restrict__ w, const double *__restrict__ b0,
                                                          const double *__restrict__ b1, const double *__restrict__ b2,
                                                          double *__restrict__ x, const double *__restrict__ r_old,
-                                                         double *__restrict__ r_new, double *part_rz, double *part_zz)
+                                                         double *__restrict__ r_new, double *__restrict__ z_out, double *part_rz,
+                                                         double *part_zz)
 {
     __shared__ double sm[4];
     if (ctl->flag != 0) return;
@@ -1852,17 +1853,16 @@ __global__ void __launch_bounds__(kBlock) k_cg_update_b(CgCtl *ctl, int it, int6
         x[i] = __builtin_fma(alpha, p[i], x[i]);
         r_new[i] = ri;
         const double zi = block_row_apply(b0[i], b1[i], b2[i], sz, rr);
+        z_out[i] = zi;                          // stored: re-applying the block in k_cg_direction_b would cost 36 B/row
         if (i < n_owned) { rz = __builtin_fma(ri, zi, rz); zz = __builtin_fma(zi, zi, zz); }
     }
     const double a = block_sum(rz, sm), c = block_sum(zz, sm);
     if (threadIdx.x == 0) { part_rz[blockIdx.x] = a; part_zz[blockIdx.x] = c; }
 }
 
-__global__ void __launch_bounds__(kBlock) k_cg_direction_b(CgCtl *ctl, int it, int64_t n, const uint32_t *__restrict__ row_grp,
-                                                            const double *part_rz, const double *part_zz, int nparts,
-                                                            const double *reduced, const double *__restrict__ r,
-                                                            const double *__restrict__ b0, const double *__restrict__ b1,
-                                                            const double *__restrict__ b2, double *__restrict__ p, double *hist,
+__global__ void __launch_bounds__(kBlock) k_cg_direction_b(CgCtl *ctl, int it, int64_t n, const double *part_rz,
+                                                            const double *part_zz, int nparts, const double *reduced,
+                                                            const double *__restrict__ z, double *__restrict__ p, double *hist,
                                                             int hist_cap, int maxits)
 {
     __shared__ double sm[4];
@@ -1894,13 +1894,8 @@ __global__ void __launch_bounds__(kBlock) k_cg_direction_b(CgCtl *ctl, int it, i
     }
     const double bb = rz / beta_old;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
-         i += static_cast<int64_t>(gridDim.x) * kBlock) {
-        const uint32_t rg = row_grp[i];
-        const int r0 = static_cast<int>(rg & 0x3fffffffu), sz = static_cast<int>(rg >> 30);
-        double rr[kGroupRows] = {0.0, 0.0, 0.0};
-        for (int q = 0; q < sz; ++q) rr[q] = r[r0 + q];
-        p[i] = __builtin_fma(bb, p[i], block_row_apply(b0[i], b1[i], b2[i], sz, rr));
-    }
+         i += static_cast<int64_t>(gridDim.x) * kBlock)
+        p[i] = __builtin_fma(bb, p[i], z[i]);
 }
 
 // ---------------------------------------------------------------------------
