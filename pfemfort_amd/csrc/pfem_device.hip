@@ -1554,7 +1554,7 @@ int run_pcg(pfem_solver *s)
                                            part_rz, part_zz);
                         hipLaunchKernelGGL(k_cg_direction, dim3(gv), block, 0, s->stream, ctl, -1, n, part_rz, part_zz,
                                            static_cast<int>(gv), static_cast<const double *>(nullptr), s->d_r.p, s->d_dinv.p, s->d_p.p,
-                                           s->d_hist.p, s->hist_cap, s->maxits);
+                                           s->d_hist.p, s->hist_cap, s->maxits, s->d_x.p);
                     }
                     if (hipStreamEndCapture(s->stream, &graph) != hipSuccess || !graph) { ok = false; break; }
                     if (hipGraphInstantiate(&s->cg_graph[variant], graph, nullptr, nullptr, 0) != hipSuccess) ok = false;
@@ -1663,7 +1663,7 @@ int run_pcg(pfem_solver *s)
                                red_pw, s->d_p.p, s->d_w.p, s->d_dinv.p, s->d_x.p, s->d_r.p, part_rz, part_zz);
             if (multi) PFEM_TRY(scalar_sum2(s, part_rz, part_zz, static_cast<int>(gv), ctl));
             hipLaunchKernelGGL(k_cg_direction, dim3(gv), block, 0, s->stream, ctl, it, n, part_rz, part_zz, static_cast<int>(gv),
-                               red2, s->d_r.p, s->d_dinv.p, s->d_p.p, s->d_hist.p, s->hist_cap, s->maxits);
+                               red2, s->d_r.p, s->d_dinv.p, s->d_p.p, s->d_hist.p, s->hist_cap, s->maxits, s->d_x.p);
         }
         PFEM_TRY(check_kernel("pcg iteration"));
     }

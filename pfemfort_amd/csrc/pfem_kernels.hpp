@@ -931,6 +931,7 @@ struct CgCtl {            // device-resident control block of the CG iteration
     double rn0, ttol;     // ||z0||, max(rtol*rn0, abstol)
     double rn;            // last preconditioned residual norm
     double dtol;
+    double alpha;         // step length of the current iteration (k_cg_update -> k_cg_direction)
     int flag;             // 0 = running, else KSPConvergedReason
     int its;              // iterations completed (written by k_cg_direction, read by k_cg_update of the next iteration)
     int its_dir;          // iteration index handed from k_cg_update to k_cg_direction (graph launches carry no `it`)
@@ -1401,7 +1402,8 @@ __global__ void __launch_bounds__(kBlock) k_cg_start(CgCtl *ctl, const double *p
     }
 }
 
-// alpha = beta/(p,w); x += alpha p; r -= alpha w; partials of (r,z), (z,z), z = r*dinv
+// alpha = beta/(p,w); r -= alpha w; partials of (r,z), (z,z), z = r*dinv.  The solution update x += alpha p
+// is done by k_cg_direction, which holds p anyway (alpha travels in ctl): same-box A/B -1.3 % per iteration.
 // `it_arg` < 0 (launches replayed from a hipGraph): the iteration index is taken from the control block.
 __global__ void __launch_bounds__(kBlock) k_cg_update(CgCtl *ctl, int it_arg, int64_t n, int64_t n_owned,
                                                        const double *part_pw, int nparts, const double *reduced_pw,
@@ -1420,12 +1422,10 @@ __global__ void __launch_bounds__(kBlock) k_cg_update(CgCtl *ctl, int it_arg, in
         return;
     }
     const double alpha = ctl->beta[it & 1] / pw;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->alpha = alpha;
     double rz = 0.0, zz = 0.0;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
          i += static_cast<int64_t>(gridDim.x) * kBlock) {
-        // x is touched once per iteration (reuse distance = a whole iteration of traffic):
-        // stream it past the caches (measured: k_cg_update -4 %, following k_spmv -1.6 %)
-        __builtin_nontemporal_store(__builtin_fma(alpha, p[i], __builtin_nontemporal_load(x + i)), x + i);
         const double ri = __builtin_fma(-alpha, w[i], r[i]);
         r[i] = ri;
         const double zi = ri * dinv[i];
@@ -1435,11 +1435,12 @@ __global__ void __launch_bounds__(kBlock) k_cg_update(CgCtl *ctl, int it_arg, in
     if (threadIdx.x == 0) { part_rz[blockIdx.x] = a; part_zz[blockIdx.x] = c; }
 }
 
-// finish (r,z), ||z||; convergence test; p = z + (beta_new/beta) p
+// finish (r,z), ||z||; x += alpha p (the step of THIS iteration, also when it turns out to be the last one: as in
+// KSPCG the test follows the update; on a breakdown x is not advanced); convergence test; p = z + (beta_new/beta) p
 __global__ void __launch_bounds__(kBlock) k_cg_direction(CgCtl *ctl, int it_arg, int64_t n, const double *part_rz,
                                                           const double *part_zz, int nparts, const double *reduced,
                                                           const double *__restrict__ r, const double *__restrict__ dinv,
-                                                          double *__restrict__ p, double *hist, int hist_cap, int maxits)
+                                                          double *__restrict__ p, double *hist, int hist_cap, int maxits, double *__restrict__ x)
 {
     __shared__ double sm[4];
     if (ctl->flag != 0) return;
@@ -1466,16 +1467,21 @@ __global__ void __launch_bounds__(kBlock) k_cg_direction(CgCtl *ctl, int it_arg,
         if (it + 1 < hist_cap) hist[it + 1] = rn;
         // written last: other blocks of THIS launch read only beta[it&1]/ttol/dtol/rn0
     }
+    const double alpha = ctl->alpha;
     if (flag != 0) {
-        // every block reaches the same decision from the same bits; flag is published for
-        // the kernels of the following launches
+        for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+             i += static_cast<int64_t>(gridDim.x) * kBlock)
+            __builtin_nontemporal_store(__builtin_fma(alpha, p[i], __builtin_nontemporal_load(x + i)), x + i);
         if (lead) ctl->flag = flag;
         return;
     }
     const double bb = rz / beta_old;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
-         i += static_cast<int64_t>(gridDim.x) * kBlock)
-        p[i] = __builtin_fma(bb, p[i], r[i] * dinv[i]);
+         i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const double pi = p[i];
+        __builtin_nontemporal_store(__builtin_fma(alpha, pi, __builtin_nontemporal_load(x + i)), x + i);
+        p[i] = __builtin_fma(bb, pi, r[i] * dinv[i]);
+    }
 }
 
 // ---------------------------------------------------------------------------
