@@ -239,6 +239,7 @@ def main():
                                       f"RCCL all-reduce of {n_iface} interface dofs per SpMV"},
             "iterations": its, "converged_reason": reason, "rnorm": rnorm, check_name: check,
             "assembly_ms_per_step": asm_ms / args.steps, "solve_ms_per_step": sol_ms / args.steps,
+            "ms_per_iteration": sol_ms / args.steps / max(its, 1),     # weak scaling: iterations grow with the problem
             "setup_s_untimed": t_setup,
             "roofline": {"bound": "hbm",
                          "kernel": {3: "pfem::k_spmvg<true> (row-grouped wave-sliced CSR SpMV + (p,Ap) partials: the 3 dof rows of a "
