@@ -170,6 +170,8 @@ def test_interface_plan_small_example():
 
 # ---------------------------------------------------------------------------------------
 def _gpu_worker(rank, world, port, mesh_args, out_dir):
+    import faulthandler
+    faulthandler.dump_traceback_later(90, exit=True)      # a stuck rank reports where, instead of hanging the suite
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
