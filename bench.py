@@ -188,13 +188,14 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    spmv_ms = 0.0; spmv_n = 0; asm_ms = 0.0; sol_ms = 0.0
+    spmv_ms = 0.0; spmv_n = 0; asm_ms = 0.0; sol_ms = 0.0; if_ms = 0.0; sc_ms = 0.0; comm_n = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         its, reason, rnorm = step()
         tm = solver.timings()
         spmv_ms += tm["spmv_ms_total"]; spmv_n += tm["spmv_launches"]
         asm_ms += tm["assemble_ms"]; sol_ms += tm["solve_ms"]
+        if_ms += tm["iface_ms_total"]; sc_ms += tm["scalar_ms_total"]; comm_n += tm["comm_samples"]
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -241,6 +242,9 @@ def main():
             "assembly_ms_per_step": asm_ms / args.steps, "solve_ms_per_step": sol_ms / args.steps,
             "ms_per_iteration": sol_ms / args.steps / max(its, 1),     # weak scaling: iterations grow with the problem
             "setup_s_untimed": t_setup,
+            # N > 1, rank 0, sampled with the SpMV: stream time of the two exchanges of an iteration (for the next round)
+            "comm": ({"interface_exchange_ms": if_ms / comm_n, "scalar_allreduce_ms": sc_ms / comm_n, "samples": comm_n,
+                      "interface_dofs": n_iface} if comm_n else None),
             "roofline": {"bound": "hbm",
                          "kernel": {3: "pfem::k_spmvg<true> (row-grouped wave-sliced CSR SpMV + (p,Ap) partials: the 3 dof rows of a "
                                        "node share one lane, 16-bit column gaps), rank 0",

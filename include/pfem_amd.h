@@ -297,6 +297,9 @@ typedef struct pfem_timings {
     double event_overhead_ms; /* what a start/stop event pair reports for an EMPTY kernel (marker-to-
                                * dispatch gap of the measurement itself, calibrated at solve start);
                                * kernel time per SpMV = spmv_ms_total/spmv_launches - event_overhead_ms */
+    double iface_ms_total;  /* multi-rank, sampled with the SpMV: pack + interface all-reduce + unpack ...   */
+    double scalar_ms_total; /* ... and the 2-scalar all-reduce, stream time (the collective blocks the stream) */
+    int64_t comm_samples;   /* number of iterations both were sampled in                                      */
 } pfem_timings;
 int pfem_get_timings(pfem_solver *s, pfem_timings *t);
 /* record an event pair around every SpMV launch of the next solves (bench.py) */

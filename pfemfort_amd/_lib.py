@@ -38,7 +38,8 @@ class PfemError(RuntimeError):
 class Timings(C.Structure):
     _fields_ = [("pattern_ms", C.c_double), ("assemble_ms", C.c_double), ("solve_ms", C.c_double),
                 ("spmv_ms_total", C.c_double), ("spmv_launches", C.c_int64), ("upload_ms", C.c_double),
-                ("event_overhead_ms", C.c_double)]
+                ("event_overhead_ms", C.c_double), ("iface_ms_total", C.c_double), ("scalar_ms_total", C.c_double),
+                ("comm_samples", C.c_int64)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)

@@ -294,6 +294,7 @@ struct pfem_solver {
     bool profile_spmv = false;
     int profile_every = 1;         // event pair around every profile_every-th SpMV launch of a solve
     std::vector<hipEvent_t> spmv_events;
+    std::vector<hipEvent_t> comm_events;   // 4 per sampled iteration: interface exchange begin/end, scalar exchange begin/end
 
     SellDev sell() const
     {
@@ -390,6 +391,7 @@ extern "C" int pfem_solver_destroy(pfem_solver *s)
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (hipEvent_t e : s->spmv_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : s->comm_events) (void)hipEventDestroy(e);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
@@ -1574,7 +1576,7 @@ int run_pcg(pfem_solver *s)
     }
     static const int chunk_env = [] { const char *e = std::getenv("PFEM_CG_CHUNK"); return e ? std::atoi(e) : 0; }();
     const int chunk = chunk_env > 0 ? chunk_env : 32;
-    size_t ev_used = 0;
+    size_t ev_used = 0, comm_used = 0;
     int it = 0;
     CgCtl h{};
     if (s->profile_spmv && s->tm.event_overhead_ms == 0.0) {
@@ -1635,8 +1637,20 @@ int run_pcg(pfem_solver *s)
             launch_spmv<true>(s, s->d_p.p, s->d_w.p, n, part_pw, ctl, e0, e1);
             const double *red_pw = nullptr, *pw_parts = part_pw;
             int pw_n = static_cast<int>(gs);
+            hipEvent_t *cev = nullptr;
+            if (multi && sample && comm_used + 4 <= 4096) {
+                while (s->comm_events.size() < comm_used + 4) {
+                    hipEvent_t e;
+                    PFEM_HIP(hipEventCreate(&e));
+                    s->comm_events.push_back(e);
+                }
+                cev = &s->comm_events[comm_used];
+                comm_used += 4;
+            }
             if (multi) {
+                if (cev) PFEM_HIP(hipEventRecord(cev[0], s->stream));
                 PFEM_TRY(interface_sum(s, s->d_w.p, part_pw, nullptr, static_cast<int>(gs), 1, ctl));
+                if (cev) PFEM_HIP(hipEventRecord(cev[1], s->stream));
                 red_pw = s->xbuf + s->n_iface;
             } else if (gs > kMaxGrid) {
                 // too many SpMV blocks for every consumer block to re-sum: fold to kFoldBlocks first
@@ -1653,7 +1667,11 @@ int run_pcg(pfem_solver *s)
                 hipLaunchKernelGGL(k_cg_update_b, dim3(gv), block, 0, s->stream, ctl, it, n, rgp, s->n_owned, pw_parts, pw_n, red_pw,
                                    s->d_p.p, s->d_w.p, s->d_binv[0].p, s->d_binv[1].p, s->d_binv[2].p, s->d_x.p, r_a, r_b, s->d_z.p,
                                    part_rz, part_zz);
-                if (multi) PFEM_TRY(scalar_sum2(s, part_rz, part_zz, static_cast<int>(gv), ctl));
+                if (multi) {
+                    if (cev) PFEM_HIP(hipEventRecord(cev[2], s->stream));
+                    PFEM_TRY(scalar_sum2(s, part_rz, part_zz, static_cast<int>(gv), ctl));
+                    if (cev) PFEM_HIP(hipEventRecord(cev[3], s->stream));
+                }
                 hipLaunchKernelGGL(k_cg_direction_b, dim3(gv), block, 0, s->stream, ctl, it, n, part_rz, part_zz,
                                    static_cast<int>(gv), red2, static_cast<const double *>(s->d_z.p), s->d_p.p, s->d_hist.p,
                                    s->hist_cap, s->maxits);
@@ -1661,7 +1679,11 @@ int run_pcg(pfem_solver *s)
             }
             hipLaunchKernelGGL(k_cg_update, dim3(gv), block, 0, s->stream, ctl, it, n, s->n_owned, pw_parts, pw_n,
                                red_pw, s->d_p.p, s->d_w.p, s->d_dinv.p, s->d_x.p, s->d_r.p, part_rz, part_zz);
-            if (multi) PFEM_TRY(scalar_sum2(s, part_rz, part_zz, static_cast<int>(gv), ctl));
+            if (multi) {
+                if (cev) PFEM_HIP(hipEventRecord(cev[2], s->stream));
+                PFEM_TRY(scalar_sum2(s, part_rz, part_zz, static_cast<int>(gv), ctl));
+                if (cev) PFEM_HIP(hipEventRecord(cev[3], s->stream));
+            }
             hipLaunchKernelGGL(k_cg_direction, dim3(gv), block, 0, s->stream, ctl, it, n, part_rz, part_zz, static_cast<int>(gv),
                                red2, s->d_r.p, s->d_dinv.p, s->d_p.p, s->d_hist.p, s->hist_cap, s->maxits, s->d_x.p);
         }
@@ -1680,6 +1702,16 @@ int run_pcg(pfem_solver *s)
         PFEM_HIP(hipEventElapsedTime(&f, s->spmv_events[2 * k], s->spmv_events[2 * k + 1]));
         s->tm.spmv_ms_total += f;
         ++s->tm.spmv_launches;
+    }
+    s->tm.iface_ms_total = s->tm.scalar_ms_total = 0.0;
+    s->tm.comm_samples = 0;
+    for (size_t k = 0; k < std::min(comm_used / 4, live); ++k) {     // same sampled iterations as the SpMV pairs
+        float a = 0.f, b = 0.f;
+        PFEM_HIP(hipEventElapsedTime(&a, s->comm_events[4 * k], s->comm_events[4 * k + 1]));
+        PFEM_HIP(hipEventElapsedTime(&b, s->comm_events[4 * k + 2], s->comm_events[4 * k + 3]));
+        s->tm.iface_ms_total += a;
+        s->tm.scalar_ms_total += b;
+        ++s->tm.comm_samples;
     }
     return PFEM_OK;
 }
