@@ -198,7 +198,7 @@ int pfem_solver_assemble_matrix_and_vector(pfem_solver *s, int n, const int *row
 /* factorise solverpetsc.F:409-423 (status check only, as in the reference) */
 int pfem_solver_factorise(pfem_solver *s);
 /* solve solverpetsc.F:431-490: final assembly, zero initial guess, Jacobi-PCG on the GPU.
- * reason follows KSPConvergedReason (2 rtol, 3 atol, -3 its, -4 dtol, -7/-8 indefinite).
+ * reason follows KSPConvergedReason (2 rtol, 3 atol, -3 its, -4 dtol, -10 indefinite matrix, -8 indefinite PC).
  * Returns PFEM_OK also when reason < 0 ("Divergence." is printed by the caller).   */
 int pfem_solver_solve(pfem_solver *s, int *its, int *reason, double *rnorm);
 /* factoriseAndSolve solverpetsc.F:498-509 */

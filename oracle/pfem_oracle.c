@@ -704,7 +704,7 @@ static double dotp(int64_t N, const double *a, const double *b)
 }
 
 /* reason: 2 = converged rtol, 3 = converged atol, -3 = max its, -4 = dtol,
- * -8 = indefinite PC, -7 = indefinite matrix (PETSc KSPConvergedReason values). */
+ * -8 = indefinite PC, -10 = indefinite matrix (PETSc KSPConvergedReason values). */
 int orc_pcg_jacobi(int64_t N, const int64_t *rowptr, const int32_t *cols,
                    const double *vals, const double *b, double *x, double rtol,
                    double abstol, double dtol, int maxits, int *its_out,
@@ -735,7 +735,7 @@ int orc_pcg_jacobi(int64_t N, const int64_t *rowptr, const int32_t *cols,
         ++its;
         orc_spmv(N, rowptr, cols, vals, p, w);
         pw = dotp(N, p, w);
-        if (!(pw > 0.0)) { reason = -7; break; }
+        if (!(pw > 0.0)) { reason = -10; break; }
         alpha = beta / pw;
 #pragma omp parallel for schedule(static) if (N > 200000)
         for (i = 0; i < N; ++i) {

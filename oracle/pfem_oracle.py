@@ -342,7 +342,7 @@ def pcg_block_jacobi(rowptr, cols, vals, b, groups, rtol=1e-5, abstol=1e-50, dto
         w = A @ pv
         pw = float(pv @ w)
         if not pw > 0.0:
-            return x, it - 1, -7, rn0
+            return x, it - 1, -10, rn0
         alpha = beta / pw
         x += alpha * pv; r -= alpha * w
         z = apply(r)

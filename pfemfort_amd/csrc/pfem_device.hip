@@ -1520,7 +1520,7 @@ int run_pcg(pfem_solver *s)
     constexpr int64_t kGraphMaxRows = 1 << 18;
     bool use_graph = false;
     {
-        static const int graph_env = [] { const char *e = std::getenv("PFEM_CG_GRAPH"); return e ? std::atoi(e) : 1; }();
+        const int graph_env = [] { const char *e = std::getenv("PFEM_CG_GRAPH"); return e ? std::atoi(e) : 1; }();   // read per solve
         const bool sampled_ok = !s->profile_spmv || s->profile_every % kGraphIters == 0;
         if (graph_env && !s->cg_graph_off && !multi && !bpc && n > 0 && (n <= kGraphMaxRows || graph_env > 1) &&
             s->stream != nullptr && sampled_ok) {
@@ -1574,7 +1574,11 @@ int run_pcg(pfem_solver *s)
             use_graph = !s->cg_graph_off && s->cg_graph[0] && s->cg_graph[1];
         }
     }
-    static const int chunk_env = [] { const char *e = std::getenv("PFEM_CG_CHUNK"); return e ? std::atoi(e) : 0; }();
+    const int chunk_env = [] { const char *e = std::getenv("PFEM_CG_CHUNK"); return e ? std::atoi(e) : 0; }();
+    // test knob: dynamic LDS bytes added to the direction launches, so that only one or two of their blocks fit a CU
+    // and most blocks START after the lead block has published its verdict (tests/test_gpu_parity.py: late blocks)
+    const size_t dir_lds = [] { const char *e = std::getenv("PFEM_DEBUG_DIRECTION_LDS"); return e ? static_cast<size_t>(std::atol(e)) : 0; }();
+    if (dir_lds) use_graph = false;
     const int chunk = chunk_env > 0 ? chunk_env : 32;
     size_t ev_used = 0, comm_used = 0;
     int it = 0;
@@ -1672,7 +1676,7 @@ int run_pcg(pfem_solver *s)
                     PFEM_TRY(scalar_sum2(s, part_rz, part_zz, static_cast<int>(gv), ctl));
                     if (cev) PFEM_HIP(hipEventRecord(cev[3], s->stream));
                 }
-                hipLaunchKernelGGL(k_cg_direction_b, dim3(gv), block, 0, s->stream, ctl, it, n, part_rz, part_zz,
+                hipLaunchKernelGGL(k_cg_direction_b, dim3(gv), block, dir_lds, s->stream, ctl, it, n, part_rz, part_zz,
                                    static_cast<int>(gv), red2, static_cast<const double *>(s->d_z.p), s->d_p.p, s->d_hist.p,
                                    s->hist_cap, s->maxits);
                 continue;
@@ -1684,7 +1688,7 @@ int run_pcg(pfem_solver *s)
                 PFEM_TRY(scalar_sum2(s, part_rz, part_zz, static_cast<int>(gv), ctl));
                 if (cev) PFEM_HIP(hipEventRecord(cev[3], s->stream));
             }
-            hipLaunchKernelGGL(k_cg_direction, dim3(gv), block, 0, s->stream, ctl, it, n, part_rz, part_zz, static_cast<int>(gv),
+            hipLaunchKernelGGL(k_cg_direction, dim3(gv), block, dir_lds, s->stream, ctl, it, n, part_rz, part_zz, static_cast<int>(gv),
                                red2, s->d_r.p, s->d_dinv.p, s->d_p.p, s->d_hist.p, s->hist_cap, s->maxits, s->d_x.p);
         }
         PFEM_TRY(check_kernel("pcg iteration"));
@@ -1907,6 +1911,7 @@ extern "C" int pfem_solver_solve(pfem_solver *s, int *its, int *reason, double *
         if (!s->h_rhs.empty()) {
             PFEM_HIP(hipMemcpyAsync(s->d_rhs.p, s->h_rhs.data(), sizeof(double) * s->n_loc, hipMemcpyHostToDevice, s->stream));
             PFEM_HIP(hipStreamSynchronize(s->stream));
+            s->rhs_summed = false;          // the staged rhs is this rank's sub-assembled one: interface rows are summed again
         }
         s->host_values_dirty = false;
     }

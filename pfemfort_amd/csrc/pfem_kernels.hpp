@@ -932,10 +932,29 @@ struct CgCtl {            // device-resident control block of the CG iteration
     double rn;            // last preconditioned residual norm
     double dtol;
     double alpha;         // step length of the current iteration (k_cg_update -> k_cg_direction)
-    int flag;             // 0 = running, else KSPConvergedReason
-    int its;              // iterations completed (written by k_cg_direction, read by k_cg_update of the next iteration)
-    int its_dir;          // iteration index handed from k_cg_update to k_cg_direction (graph launches carry no `it`)
+    int flag;             // 0 = running, else KSPConvergedReason   } one aligned 8-byte word, published with a single
+    int its;              // iterations completed                     } store by the direction kernel (ctl_publish)
+    int its_dir;          // iteration index handed from k_cg_update to k_cg_direction (graph launches carry no `it`);
+                          // -2 once the update kernel has seen the solve finished
+    int pad_;
 };
+static_assert(offsetof(CgCtl, flag) % 8 == 0 && offsetof(CgCtl, its) == offsetof(CgCtl, flag) + 4, "flag/its share a word");
+
+// The direction kernel is the only one that writes `flag` in a launch whose other blocks still read it.  A block
+// that starts after the lead thread has published the verdict of THIS iteration must not take it for "finished
+// before this launch" (it would skip its share of the final x += alpha p): {flag, its} travel in one word and a
+// block leaves early only when the verdict belongs to an earlier iteration.
+__device__ inline void ctl_publish(CgCtl *ctl, int flag, int its)
+{
+    const unsigned long long w = static_cast<unsigned long long>(static_cast<unsigned>(flag)) |
+                                 (static_cast<unsigned long long>(static_cast<unsigned>(its)) << 32);
+    __atomic_store_n(reinterpret_cast<unsigned long long *>(&ctl->flag), w, __ATOMIC_RELAXED);
+}
+__device__ inline bool ctl_finished_before(const CgCtl *ctl, int it)
+{
+    const unsigned long long w = __atomic_load_n(reinterpret_cast<const unsigned long long *>(&ctl->flag), __ATOMIC_RELAXED);
+    return static_cast<int>(w & 0xffffffffu) != 0 && static_cast<int>(w >> 32) != it + 1;
+}
 
 template <bool WITH_DOT>
 __global__ void __launch_bounds__(kBlock) k_spmv(SellDev A, const double *__restrict__ x, double *__restrict__ y,
@@ -1412,7 +1431,10 @@ __global__ void __launch_bounds__(kBlock) k_cg_update(CgCtl *ctl, int it_arg, in
                                                        double *__restrict__ r, double *part_rz, double *part_zz)
 {
     __shared__ double sm[4];
-    if (ctl->flag != 0) return;
+    if (ctl->flag != 0) {                   // finished in an earlier iteration (this kernel never writes flag)
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctl->its_dir = -2;
+        return;
+    }
     const int it = it_arg >= 0 ? it_arg : ctl->its;
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->its_dir = it;      // nobody in this launch reads it
     const double pw = reduced_pw ? *reduced_pw : sum_partials(part_pw, nparts, sm);
@@ -1443,14 +1465,14 @@ __global__ void __launch_bounds__(kBlock) k_cg_direction(CgCtl *ctl, int it_arg,
                                                           double *__restrict__ p, double *hist, int hist_cap, int maxits, double *__restrict__ x)
 {
     __shared__ double sm[4];
-    if (ctl->flag != 0) return;
     const int it = it_arg >= 0 ? it_arg : ctl->its_dir;              // ctl->its is written by this launch: not read here
+    if (ctl_finished_before(ctl, it)) return;
     double rz, zz;
     if (reduced) { rz = reduced[0]; zz = reduced[1]; }
     else { rz = sum_partials(part_rz, nparts, sm); zz = sum_partials(part_zz, nparts, sm); }
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
-    if (zz < 0.0) {                          // breakdown flagged by k_cg_update
-        if (lead) { ctl->flag = -7; ctl->its = it + 1; }
+    if (zz < 0.0) {                          // breakdown flagged by k_cg_update: KSP_DIVERGED_INDEFINITE_MAT
+        if (lead) ctl_publish(ctl, -10, it + 1);
         return;
     }
     const double rn = sqrt(zz);
@@ -1461,18 +1483,17 @@ __global__ void __launch_bounds__(kBlock) k_cg_direction(CgCtl *ctl, int it_arg,
     else if (rz < 0.0) flag = -8;            // KSP_DIVERGED_INDEFINITE_PC
     else if (it + 1 >= maxits) flag = -3;
     if (lead) {
+        // other blocks of THIS launch read only beta[it&1]/ttol/dtol/rn0/alpha and test the verdict word against `it`
         ctl->beta[(it + 1) & 1] = rz;
         ctl->rn = rn;
-        ctl->its = it + 1;
         if (it + 1 < hist_cap) hist[it + 1] = rn;
-        // written last: other blocks of THIS launch read only beta[it&1]/ttol/dtol/rn0
+        ctl_publish(ctl, flag, it + 1);
     }
     const double alpha = ctl->alpha;
     if (flag != 0) {
         for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
              i += static_cast<int64_t>(gridDim.x) * kBlock)
             __builtin_nontemporal_store(__builtin_fma(alpha, p[i], __builtin_nontemporal_load(x + i)), x + i);
-        if (lead) ctl->flag = flag;
         return;
     }
     const double bb = rz / beta_old;
@@ -1872,13 +1893,13 @@ __global__ void __launch_bounds__(kBlock) k_cg_direction_b(CgCtl *ctl, int it, i
                                                             int hist_cap, int maxits)
 {
     __shared__ double sm[4];
-    if (ctl->flag != 0) return;
+    if (ctl_finished_before(ctl, it)) return;
     double rz, zz;
     if (reduced) { rz = reduced[0]; zz = reduced[1]; }
     else { rz = sum_partials(part_rz, nparts, sm); zz = sum_partials(part_zz, nparts, sm); }
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
     if (zz < 0.0) {
-        if (lead) { ctl->flag = -7; ctl->its = it + 1; }
+        if (lead) ctl_publish(ctl, -10, it + 1);
         return;
     }
     const double rn = sqrt(zz);
@@ -1891,13 +1912,10 @@ __global__ void __launch_bounds__(kBlock) k_cg_direction_b(CgCtl *ctl, int it, i
     if (lead) {
         ctl->beta[(it + 1) & 1] = rz;
         ctl->rn = rn;
-        ctl->its = it + 1;
         if (it + 1 < hist_cap) hist[it + 1] = rn;
+        ctl_publish(ctl, flag, it + 1);
     }
-    if (flag != 0) {
-        if (lead) ctl->flag = flag;
-        return;
-    }
+    if (flag != 0) return;
     const double bb = rz / beta_old;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
          i += static_cast<int64_t>(gridDim.x) * kBlock)

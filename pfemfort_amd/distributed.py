@@ -62,9 +62,45 @@ class TorchAllReduce:
             return 1
 
 
-def attach(solver, dist, torch, device):
+class HostStagedAllReduce:
+    """The all-reduce hook for process groups that work on HOST memory (gloo): stream-sync, device -> host,
+    reduce to rank 0 + broadcast (every rank receives the same bits, whatever the group's all-reduce
+    algorithm), host -> device.  What pfemfort_amd/fortran/pfem_mpi.cpp does with MPI; used where several
+    ranks share one GPU (RCCL refuses two ranks on a device)."""
+
+    def __init__(self, dist, torch, xbuf, stream):
+        self.dist, self.torch = dist, torch
+        self.xbuf = xbuf
+        self.base = xbuf.data_ptr()
+        self.stream = stream                     # torch.cuda.Stream the solver was given
+        self.calls = 0
+        self.error = None
+        self.log = None                          # optional list of (call#, count) for call-sequence checks
+
+    def __call__(self, ctx, buf, count, stream):
+        try:
+            off = (int(buf) - self.base) // 8
+            view = self.xbuf[off:off + int(count)]
+            with self.torch.cuda.stream(self.stream):
+                self.stream.synchronize()
+                host = view.cpu()
+                self.dist.reduce(host, 0)
+                self.dist.broadcast(host, 0)
+                view.copy_(host)
+                self.stream.synchronize()
+            self.calls += 1
+            if self.log is not None:
+                self.log.append((self.calls, int(count)))
+            return 0
+        except Exception as e:   # never let an exception cross the C boundary
+            self.error = e
+            return 1
+
+
+def attach(solver, dist, torch, device, staged=False):
     """Wire a solver that already holds its mesh to the process group: exchanges the ghost
-    lists, installs the interface plan, the exchange buffer and the all-reduce hook."""
+    lists, installs the interface plan, the exchange buffer and the all-reduce hook.
+    ``staged``: the group reduces host memory (gloo) -- the hook stages the exchange buffer through the host."""
     rank, world = dist.get_rank(), dist.get_world_size()
     ghosts = solver.ghosts()
     lists = gather_ghost_lists(ghosts, dist)
@@ -72,9 +108,15 @@ def attach(solver, dist, torch, device):
     dist.all_gather_object(ranges, (solver.row_start, solver.row_start + solver.size_local))
     gid, slot, n_iface = interface_plan(lists, ranges, rank)
     xbuf = torch.zeros(n_iface + 4, dtype=torch.float64, device=device)
-    hook = TorchAllReduce(dist, xbuf)
-    if device.type == "cuda":
-        solver.setStream(torch.cuda.current_stream(device).cuda_stream)
+    if staged:
+        stream = torch.cuda.Stream(device)
+        hook = HostStagedAllReduce(dist, torch, xbuf, stream)
+        solver.setStream(stream.cuda_stream)
+        solver._keep.append(stream)
+    else:
+        hook = TorchAllReduce(dist, xbuf)
+        if device.type == "cuda":
+            solver.setStream(torch.cuda.current_stream(device).cuda_stream)
     solver.setExchangeBuffer(xbuf.data_ptr(), n_iface + 4)
     solver.setInterface(gid, slot, n_iface)
     solver.setComm(rank, world, hook)

@@ -5,8 +5,9 @@ reference renumbering, ghost detection, interface plan, the torch.distributed al
 by running a numpy restatement of the device CG loop on each rank (local operators from the
 oracle) and comparing with the single-rank solution.
 
-GPU (gloo on CUDA tensors, both ranks on cuda:0): the same layout through the real C++/HIP path
-(pfem_solver_set_comm / _set_interface / run_pcg with the hook), against the 1-rank GPU solve.
+GPU (2-3 ranks on cuda:0, exchange staged through the host and reduced by gloo on CPU tensors, as the MPI
+flavour does): the same layout through the real C++/HIP path (pfem_solver_set_comm / _set_interface / run_pcg
+with the hook), against the oracle's direct solve and iteration count.
 """
 import os
 import socket
@@ -171,7 +172,7 @@ def test_interface_plan_small_example():
 # ---------------------------------------------------------------------------------------
 def _gpu_worker(rank, world, port, mesh_args, out_dir):
     import faulthandler
-    faulthandler.dump_traceback_later(90, exit=True)      # a stuck rank reports where, instead of hanging the suite
+    faulthandler.dump_traceback_later(240, exit=True)     # a stuck rank reports where, instead of hanging the suite
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -190,7 +191,7 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
         ed = H.ELAST_ELEMDATA if kind == pf.ELAST_TET else H.POISSON_ELEMDATA
         if mesh_args.get("mode", "batched") == "batched":
             s.uploadMesh(kind, conn_loc, xyz_new, edof_g, dm.solnApplied)
-            hook, n_iface = PD.attach(s, dist, torch, torch.device("cuda", 0))
+            hook, n_iface = PD.attach(s, dist, torch, torch.device("cuda", 0), staged=True)
             s.buildPattern()
             s.assemble(ed, H.TIMEDATA)
         else:
@@ -201,7 +202,7 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
             for e in range(conn_loc.shape[1]):
                 s.MatSetValues(edof_g[:, e], edof_g[:, e], np.zeros(nsize * nsize), INSERT_VALUES)
             s.setZero()
-            hook, n_iface = PD.attach(s, dist, torch, torch.device("cuda", 0))
+            hook, n_iface = PD.attach(s, dist, torch, torch.device("cuda", 0), staged=True)
             fn = H.StiffnessResidualElasticityLinearTetra if kind == pf.ELAST_TET else H.StiffnessResidualPoissonLinearTetra
             for e in range(conn_loc.shape[1]):
                 nd = conn_loc[:, e]
@@ -212,10 +213,11 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                     fact = dm.solnApplied[nd[ii // ndof] * ndof + ii % ndof]
                     F = F - np.where(f != -1, K[:, ii] * fact, 0.0)
                 s.VecSetValues(f, F, ADD_VALUES)
+        hook.log = []
         its, reason, rn = s.factoriseAndSolve()
         assert hook.error is None, hook.error
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=s.getSolution(), rs=rs, re=re, its=its, reason=reason,
-                 n_iface=n_iface, pc=s.preconditioner())
+                 n_iface=n_iface, pc=s.preconditioner(), calls=hook.calls, log=np.array([c for _, c in hook.log]))
         s.free()
     finally:
         dist.destroy_process_group()
@@ -227,9 +229,14 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                                                             ("poisson", 2, "slabs", "compat"), ("elast", 3, "sectors", "compat"),
                                                             ("elast", 2, "slabs", "pbjacobi"), ("elast", 3, "sectors", "pbjacobi"),
                                                             ("poisson", 2, "slabs", "pbjacobi")])
-def test_gpu_ranks_on_one_device_match_single_rank(tmp_path, kind_name, world, partition, mode):
+def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partition, mode):
+    """2-3 ranks share cuda:0 (host-staged gloo exchange): the product's multi-rank device loop against the ORACLE --
+    a direct solve of the oracle-assembled global system in the partition's new numbering, and the oracle's
+    Jacobi-PCG iteration count."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
     import torch.multiprocessing as mp
-    import pfemfort_amd as pf
+    from oracle import pfem_oracle as O
     from pfemfort_amd import host as H
     mesh_args = ({"box": (-1, 1, 12, -1, 1, 10, -1, 1, 14), "bc_mode": 0, "ndof": 1} if kind_name == "poisson" else
                  {"box": (-0.5, 0.5, 3, 0.0, 3.0, 8, -0.5, 0.5, 6), "bc_mode": 1, "ndof": 3})
@@ -243,28 +250,31 @@ def test_gpu_ranks_on_one_device_match_single_rank(tmp_path, kind_name, world, p
         mesh_args["box"] = (-1, 1, 6, -1, 1, 5, -1, 1, 7)
     mp.spawn(_gpu_worker, args=(world, _free_port(), mesh_args, str(tmp_path)), nprocs=world, join=True)
     mesh = H.gen_box_tets(*mesh_args["box"], bc_mode=mesh_args["bc_mode"], ndof=mesh_args["ndof"])
-    ndof = mesh_args["ndof"]
-    drv = pf.tetrapoissonparallelimpl1 if kind_name == "poisson" else pf.tetraelasticityparallelimpl1
-    ref = drv(mesh, rtol=1e-10)                     # one rank, OLD numbering (point Jacobi)
+    kind = O.POISSON_TET if kind_name == "poisson" else O.ELAST_TET
+    _, npid = _partition(mesh, world, partition, H)
+    prob = O.setup_problem(kind, O.Mesh(mesh.xyz, mesh.conn, mesh.bc_node, mesh.bc_dof, mesh.bc_val), nParts=world,
+                           node_proc_id=npid)
+    u = spl.spsolve(sp.csr_matrix((prob.vals, prob.cols, prob.rowptr)).tocsc(), prob.rhs)
+    _, its_oracle, reason_oracle, *_ = O.pcg_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-10)
+    assert reason_oracle == 2
     its_tol = 3
     if mode == "pbjacobi":
         want = "pbjacobi" if kind_name == "elast" else "jacobi"      # Poisson has no multi-row groups: all ranks fall back
         assert all(str(np.load(tmp_path / f"rank{r}.npz")["pc"]) == want for r in range(world))
         if kind_name == "elast":
             d0 = np.load(tmp_path / "rank0.npz")
-            assert int(d0["its"]) < ref.its                          # fewer iterations than point Jacobi ...
+            assert int(d0["its"]) < its_oracle                       # fewer iterations than point Jacobi ...
             its_tol = 10 ** 9                                        # ... so the count is not compared below
-    # the ranks worked in the partition's NEW numbering: map their rows back to (old node, dof)
-    _, npid = _partition(mesh, world, partition, H)
-    dm = H.dof_numbering(mesh.nNode, ndof, mesh.bc_node, mesh.bc_dof, mesh.bc_val, world, npid)
-    assy = H.assy_for_soln(dm.NodeDofArrayNew)
-    got = ref.solnVTK.copy()
+    got = np.full_like(u, np.nan)
     for r in range(world):
         d = np.load(tmp_path / f"rank{r}.npz")
-        rows = np.arange(int(d["rs"]), int(d["re"]))
-        got[dm.node_map_get_old[assy[rows] // ndof], assy[rows] % ndof] = d["x"]
-        assert int(d["reason"]) == 2 and abs(int(d["its"]) - ref.its) <= its_tol
-    assert np.abs(got - ref.solnVTK).max() <= 1e-8 * max(1.0, np.abs(ref.solnVTK).max())
+        assert (int(d["rs"]), int(d["re"])) == (int(prob.dm.row_start[r]), int(prob.dm.row_end[r]))
+        got[int(d["rs"]):int(d["re"])] = d["x"]
+        assert int(d["reason"]) == 2 and abs(int(d["its"]) - its_oracle) <= its_tol
+        assert int(d["calls"]) >= 2 * int(d["its"])
+        # every rank issued the same sequence of exchanges (count per call)
+        assert np.array_equal(d["log"], np.load(tmp_path / "rank0.npz")["log"])
+    assert np.abs(got - u).max() <= 1e-8 * max(1.0, np.abs(u).max())
 
 
 def _nccl_worker(rank, world, port, out_dir):
