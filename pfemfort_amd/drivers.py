@@ -152,6 +152,54 @@ def _run(kind, mesh, elemData, timeData, mode, rtol, maxits, verbose):
     return _finish(kind, mesh, dm, solver, its, reason, rnorm, timers, u)
 
 
+def run_parallel(kind, mesh: H.Mesh, elem_proc_id, node_proc_id, dist, torch, elemData=None, timeData=None, rtol=1e-5,
+                 maxits=10000, staged=False, device=None, pc=None, spmv=None) -> Result:
+    """The parallel branch of the driver PROGRAMs (tetrapoissonparallelimpl1.F:423-679 renumbering from
+    (elem_proc_id, node_proc_id), :779 row blocks, :828-884 element loop over ``elem_proc_id == this_mpi_proc``,
+    :898-902 solve, :922-932 VecScatterCreateToAll) on an initialised ``torch.distributed`` group, one rank per
+    GPU.  ``staged``: ranks share a device and the group reduces host memory (gloo) -- tests only.
+    Every rank returns the gathered Result (``soln_free`` is the whole solution, like vec_SEQ)."""
+    from . import distributed as PD
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ndof = L.NDOF[kind]
+    if elemData is None:
+        elemData = {L.ELAST_TET: H.ELAST_ELEMDATA, L.ELAST_TRIA: H.ELAST2D_ELEMDATA}.get(kind, H.POISSON_ELEMDATA)
+    timeData = H.TIMEDATA if timeData is None else timeData
+    dm = H.dof_numbering(mesh.nNode, ndof, mesh.bc_node, mesh.bc_dof, mesh.bc_val, world, node_proc_id)
+    conn_new, xyz_new = H.renumber_mesh(mesh, dm)                         # :659-664, :832-838
+    mine = np.nonzero(np.asarray(elem_proc_id) == rank)[0]                # :829
+    conn_loc = np.ascontiguousarray(conn_new[:, mine])
+    edof = H.elem_dof_array(conn_loc, dm.NodeDofArrayNew)                # :698-713 for the rank's elements
+    rs, re = int(dm.row_start[rank]), int(dm.row_end[rank])
+    if device is None:
+        device = torch.device("cuda", 0 if staged else rank % max(1, torch.cuda.device_count()))
+    solver = PetscSolver().initialise(re - rs, dm.size_global, row_start=rs, device=device.index)   # :779
+    solver.setTolerances(rtol=rtol, maxits=maxits)
+    if pc:
+        solver.setPreconditioner(pc)
+    if spmv:
+        solver.setSpmvFormat(spmv)
+    timers = {}
+    solver.uploadMesh(kind, conn_loc, xyz_new, edof, dm.solnApplied)
+    hook, _ = PD.attach(solver, dist, torch, device, staged=staged)
+    solver.buildPattern()                                                # :786-802
+    t0 = time.perf_counter()
+    solver.assemble(elemData, timeData)                                  # :817-884
+    timers["assembly_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    its, reason, rnorm = solver.factoriseAndSolve()                      # :898-902
+    timers["solve_s"] = time.perf_counter() - t0
+    if getattr(hook, "error", None) is not None:
+        raise hook.error
+    parts = [None] * world                                               # VecScatterCreateToAll (:922-932)
+    dist.all_gather_object(parts, (rs, solver.getSolution()))
+    u = np.empty(dm.size_global)
+    for r0, x in parts:
+        u[r0:r0 + len(x)] = x
+    timers.update(solver.timings())
+    return _finish(kind, mesh, dm, solver, its, reason, rnorm, timers, u)
+
+
 def tetrapoissonparallelimpl1(mesh: H.Mesh | str, mode="batched", rtol=1e-5, maxits=10000, verbose=False) -> Result:
     """PROGRAM TetraMeshPoissonEquation (tetrapoissonparallelimpl1.F) on one rank / one GPU."""
     if isinstance(mesh, str):
