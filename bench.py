@@ -166,10 +166,13 @@ def main():
     solver = pf.PetscSolver().initialise(row_end - row_start, N, row_start=row_start, device=device_index)
     solver.setTolerances(rtol=args.rtol, maxits=100000 if beam else 10000)
     solver.uploadMesh(kind, conn_new, xyz_new, edof, dm.solnApplied)
-    n_iface = 0
+    hooks = None
     if world > 1:
         from pfemfort_amd import distributed as PD
-        hook, n_iface = PD.attach(solver, dist, torch, torch.device("cuda", device_index))
+        hooks = PD.attach(solver, dist, torch, staged=(args.backend == "gloo"))   # RCCL inside the library unless gloo
+        bad = solver.commSelftest(4096)
+        if bad:
+            raise SystemExit(f"rank {rank}: communication self-test failed ({bad} wrong entries)")
     solver.buildPattern()
     info = solver.matrixInfo()
     t_setup = time.perf_counter() - t_setup
@@ -188,22 +191,22 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    spmv_ms = 0.0; spmv_n = 0; asm_ms = 0.0; sol_ms = 0.0; if_ms = 0.0; sc_ms = 0.0; comm_n = 0
+    spmv_ms = 0.0; spmv_n = 0; asm_ms = 0.0; sol_ms = 0.0; if_ms = 0.0; sc_ms = 0.0; ex_ms = 0.0; comm_n = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         its, reason, rnorm = step()
         tm = solver.timings()
         spmv_ms += tm["spmv_ms_total"]; spmv_n += tm["spmv_launches"]
         asm_ms += tm["assemble_ms"]; sol_ms += tm["solve_ms"]
-        if_ms += tm["iface_ms_total"]; sc_ms += tm["scalar_ms_total"]; comm_n += tm["comm_samples"]
+        if_ms += tm["iface_ms_total"]; sc_ms += tm["scalar_ms_total"]; ex_ms += tm["exposed_ms_total"]; comm_n += tm["comm_samples"]
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        if hook.error is not None:
-            raise hook.error
+        if hooks is not None and hooks.error is not None:
+            raise hooks.error
 
     # sanity of the answer: u = x^2+y^2+z^2 is nodally exact on this mesh family
     u = solver.getSolution()
@@ -215,6 +218,7 @@ def main():
         exact = (xyz_new[:, owned_free] ** 2).sum(0)
         check_name, check = "max_nodal_error", float(np.abs(u - exact).max()) if len(u) else 0.0
 
+    cinfo = solver.commInfo()
     if rank == 0:
         bytes_per_spmv = 12 * info["nnz"] + 20 * info["n_local"]       # FP64 vals, int32 cols
         # event pair = marker-end -> kernel-end; net of the pair's own offset measured on an empty
@@ -237,14 +241,19 @@ def main():
                        "elements": 6 * nEx * nEy * nEz, "nodes": int(mesh.nNode), "free_dofs": int(N),
                        "solver": f"Jacobi-PCG, zero initial guess, rtol {args.rtol:g} on ||M^-1 r|| (PETSc KSPCG default norm)",
                        "parallelism": "1 GPU" if world == 1 else f"{world} z-slabs, sub-assembled interface rows, "
-                                      f"RCCL all-reduce of {n_iface} interface dofs per SpMV"},
+                                      f"neighbour exchange of {cinfo['doubles_per_exchange']} doubles with {cinfo['n_peers']} "
+                                      f"neighbour(s) per SpMV (overlapped with the interior slices) + 2 scalar all-reduces, "
+                                      + ("gloo host hooks" if args.backend == "gloo" else "RCCL bound in C++")},
             "iterations": its, "converged_reason": reason, "rnorm": rnorm, check_name: check,
             "assembly_ms_per_step": asm_ms / args.steps, "solve_ms_per_step": sol_ms / args.steps,
             "ms_per_iteration": sol_ms / args.steps / max(its, 1),     # weak scaling: iterations grow with the problem
             "setup_s_untimed": t_setup,
             # N > 1, rank 0, sampled with the SpMV: stream time of the two exchanges of an iteration (for the next round)
-            "comm": ({"interface_exchange_ms": if_ms / comm_n, "scalar_allreduce_ms": sc_ms / comm_n, "samples": comm_n,
-                      "interface_dofs": n_iface} if comm_n else None),
+            "comm": ({"interface_exchange_ms": if_ms / comm_n, "scalar_allreduce_ms": sc_ms / comm_n,
+                      "exposed_wait_ms": ex_ms / comm_n, "samples": comm_n, "neighbours": cinfo["n_peers"],
+                      "bytes_per_exchange": 8 * cinfo["doubles_per_exchange"],
+                      "bytes_per_neighbour": 8 * cinfo["doubles_per_exchange"] // max(cinfo["n_peers"], 1),
+                      "boundary_slices": cinfo["boundary_slices"], "slices": cinfo["total_slices"]} if comm_n else None),
             "roofline": {"bound": "hbm",
                          "kernel": {3: "pfem::k_spmvg<true> (row-grouped wave-sliced CSR SpMV + (p,Ap) partials: the 3 dof rows of a "
                                        "node share one lane, 16-bit column gaps), rank 0",

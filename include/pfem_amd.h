@@ -297,9 +297,11 @@ typedef struct pfem_timings {
     double event_overhead_ms; /* what a start/stop event pair reports for an EMPTY kernel (marker-to-
                                * dispatch gap of the measurement itself, calibrated at solve start);
                                * kernel time per SpMV = spmv_ms_total/spmv_launches - event_overhead_ms */
-    double iface_ms_total;  /* multi-rank, sampled with the SpMV: pack + interface all-reduce + unpack ...   */
-    double scalar_ms_total; /* ... and the 2-scalar all-reduce, stream time (the collective blocks the stream) */
-    int64_t comm_samples;   /* number of iterations both were sampled in                                      */
+    double iface_ms_total;  /* multi-rank, sampled with the SpMV: pack + neighbour exchange, time on the comm stream ... */
+    double scalar_ms_total; /* ... and the two scalar all-reduces of the iteration, time on the comm stream           */
+    int64_t comm_samples;   /* number of iterations both were sampled in                                             */
+    double exposed_ms_total;/* of those: time the compute stream spent WAITING for the comm stream (not hidden by the
+                             * interior SpMV), per sampled iteration                                                 */
 } pfem_timings;
 int pfem_get_timings(pfem_solver *s, pfem_timings *t);
 /* record an event pair around every SpMV launch of the next solves (bench.py) */
@@ -310,19 +312,52 @@ int pfem_solver_profile_spmv(pfem_solver *s, int enable);   /* 0 off, 1 every la
 /*    (replaces MatAssembly stash + VecScatter + VecDot MPI_Allreduce inside   */
 /*    KSPSolve, solverpetsc.F:447-476)                                        */
 /* ========================================================================= */
-/* In-place SUM all-reduce of `count` doubles at DEVICE pointer `buf`, enqueued on
- * `hip_stream`; returns 0 on success.  The Python host binds torch.distributed
- * (backend "nccl" == RCCL over xGMI); a Fortran/MPI host can bind MPI_Allreduce.  */
-typedef int (*pfem_allreduce_fn)(void *ctx, void *buf, int64_t count, void *hip_stream);
-int pfem_solver_set_comm(pfem_solver *s, int rank, int nranks, pfem_allreduce_fn fn, void *ctx);
-/* Interface plan: the n_shared GLOBAL dof ids (ascending) this rank touches that are
- * also touched by another rank, and the slot of each in the packed global interface
- * vector of n_iface_global entries (identical numbering on every rank).           */
-int pfem_solver_set_interface(pfem_solver *s, int64_t n_shared, const int64_t *shared_gid,
-                              const int32_t *shared_slot, int64_t n_iface_global);
-/* Exchange buffer to all-reduce in (device pointer, >= n_iface_global+4 doubles), e.g.
- * the storage of a torch tensor so the hook can hand the tensor to torch.distributed. */
-int pfem_solver_set_exchange_buffer(pfem_solver *s, void *device_buf, int64_t capacity);
+/* Every rank assembles only its own elements (elem_proc_id == rank, tetrapoissonparallelimpl1.F:829) into a local
+ * matrix over owned + ghost rows; rows of dofs that another rank also touches hold partial sums.  Per CG iteration:
+ *   1. w = A_loc p on the slices that hold shared rows, then  pack -> NEIGHBOUR exchange  on a second stream while
+ *      the interior slices run; every rank adds the partials of a shared dof in ascending rank order (same bits on
+ *      all ranks, so the replicated ghost entries of the vectors never drift);
+ *   2. two scalar all-reduces: (p, A p) and [(r,z), (z,z)].
+ * Who shares which dofs with whom is the NEIGHBOUR PLAN (pure integer host logic):                                */
+
+/* Neighbour plan of `rank`: dof g is shared with rank q when both have it in their local numbering (owned block or
+ * ghost list).  Inputs: every rank's owned block [row_start[r], row_end[r]) and ghost list (ascending global ids,
+ * concatenated; ghost_off[r]..ghost_off[r+1]).  Two-call: with peers == NULL only *n_peers and *n_total are set.
+ * Outputs: peers[] ascending, peer_off[n_peers+1], shared_gid[] = for each peer the ascending global ids shared with
+ * it (both sides of a pair compute the same list).  Host only, no GPU needed.                                      */
+int pfem_neighbour_plan(int nranks, int rank, const int64_t *row_start, const int64_t *row_end,
+                        const int64_t *ghost_off, const int64_t *ghost_gid, int *n_peers, int64_t *n_total,
+                        int *peers, int64_t *peer_off, int64_t *shared_gid);
+/* install the plan (after pfem_mesh_upload, or after the first setZero of the compat path: the local numbering
+ * must exist).  n_peers == 0 is legal (a rank that shares nothing still takes part in the scalar all-reduces).   */
+int pfem_solver_set_neighbours(pfem_solver *s, int n_peers, const int *peers, const int64_t *peer_off,
+                               const int64_t *shared_gid);
+/* Communication backend 1 -- RCCL over xGMI, bound inside the library (librccl is loaded at run time; nothing else
+ * needs it): rank 0 creates the unique id (128 bytes), the host program broadcasts it by whatever means it has
+ * (torch.distributed store, MPI_Bcast, a file) and every rank calls pfem_solver_set_comm_rccl.  The exchange is one
+ * grouped ncclSend/ncclRecv per neighbour, the reductions ncclAllReduce, all on the solver's communication stream. */
+#define PFEM_RCCL_ID_BYTES 128
+int pfem_rccl_unique_id(void *id_out);
+int pfem_solver_set_comm_rccl(pfem_solver *s, int rank, int nranks, const void *id);
+/* Communication backend 2 -- host hooks, for hosts whose transport works on HOST memory (MPI: the reference's own
+ * transport, pfemfort_amd/fortran/pfem_mpi.cpp; gloo in the tests where several ranks share one GPU).  The library
+ * stages the packed buffers through pinned host memory and calls:
+ *   allreduce(ctx, buf, count)         in-place SUM of `count` doubles; EVERY rank must receive the same bits
+ *   exchange(ctx, n_peers, peers, off, send, recv)   send[off[k]..off[k+1]) goes to peers[k], the same range of
+ *                                      recv is filled with what peers[k] sent (symmetric counts)
+ * Return 0 on success.                                                                                             */
+typedef int (*pfem_host_allreduce_fn)(void *ctx, double *buf, int64_t count);
+typedef int (*pfem_host_exchange_fn)(void *ctx, int n_peers, const int *peers, const int64_t *off,
+                                     const double *send, double *recv);
+int pfem_solver_set_comm_host(pfem_solver *s, int rank, int nranks, pfem_host_allreduce_fn allreduce,
+                              pfem_host_exchange_fn exchange, void *ctx);
+/* Transport self-test (collective, no mesh needed): stamped buffers of `count` doubles to every other rank (to itself
+ * when there is one rank) through the backend's exchange, then an all-reduce of a known vector; *bad = wrong entries. */
+int pfem_solver_comm_selftest(pfem_solver *s, int64_t count, int64_t *bad);
+/* what the last solve exchanged per iteration: number of neighbours, doubles sent to all of them together, and
+ * how many of the SpMV's slices hold shared rows (they run first) out of how many                                  */
+int pfem_solver_comm_info(pfem_solver *s, int *n_peers, int64_t *doubles_per_exchange, int64_t *boundary_slices,
+                          int64_t *total_slices);
 /* host-only helper (no GPU needed): ascending unique global dof ids in edof[0..count) that
  * lie outside the owned block [row_start,row_start+n_owned); two-call (NULL -> count).  */
 int pfem_find_ghosts(int64_t count, const int32_t *edof, int64_t row_start, int64_t n_owned,

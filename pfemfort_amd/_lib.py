@@ -39,10 +39,14 @@ class Timings(C.Structure):
     _fields_ = [("pattern_ms", C.c_double), ("assemble_ms", C.c_double), ("solve_ms", C.c_double),
                 ("spmv_ms_total", C.c_double), ("spmv_launches", C.c_int64), ("upload_ms", C.c_double),
                 ("event_overhead_ms", C.c_double), ("iface_ms_total", C.c_double), ("scalar_ms_total", C.c_double),
-                ("comm_samples", C.c_int64)]
+                ("comm_samples", C.c_int64), ("exposed_ms_total", C.c_double)]
 
 
-ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+# host hooks of the communication backend (include/pfem_amd.h, section 5)
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
+HOST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64),
+                               C.POINTER(C.c_double), C.POINTER(C.c_double))
+RCCL_ID_BYTES = 128
 
 _P = C.c_void_p
 _I, _L, _D = C.c_int, C.c_int64, C.c_double
@@ -101,9 +105,13 @@ SIGNATURES = {
     "pfem_bench_spmv": [_P, _I, _P],
     "pfem_get_timings": [_P, _P],
     "pfem_solver_profile_spmv": [_P, _I],
-    "pfem_solver_set_comm": [_P, _I, _I, ALLREDUCE_FN, _P],
-    "pfem_solver_set_interface": [_P, _L, _P, _P, _L],
-    "pfem_solver_set_exchange_buffer": [_P, _P, _L],
+    "pfem_neighbour_plan": [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "pfem_solver_set_neighbours": [_P, _I, _P, _P, _P],
+    "pfem_rccl_unique_id": [_P],
+    "pfem_solver_set_comm_rccl": [_P, _I, _I, _P],
+    "pfem_solver_set_comm_host": [_P, _I, _I, HOST_ALLREDUCE_FN, HOST_EXCHANGE_FN, _P],
+    "pfem_solver_comm_info": [_P, _P, _P, _P, _P],
+    "pfem_solver_comm_selftest": [_P, _L, _P],
     "pfem_get_ghosts": [_P, _P, _P],
     "pfem_find_ghosts": [_L, _P, _L, _L, _P, _P],
 }

@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <hipcub/hipcub.hpp>
+#include <rccl/rccl.h>      // types and prototypes only: librccl is loaded with dlopen when a solver asks for it
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -61,7 +63,7 @@ extern "C" const char *pfem_strerror(int code)
     case PFEM_ERR_NOMEM: return "out of memory";
     case PFEM_ERR_DIVERGED: return "Divergence.";
     case PFEM_ERR_PATTERN: return "ADD_VALUES outside the inserted nonzero pattern";
-    case PFEM_ERR_COMM: return "all-reduce hook failed";
+    case PFEM_ERR_COMM: return "communication backend failed";
     }
     return "unknown error";
 }
@@ -139,6 +141,20 @@ inline unsigned spmv_grid(int64_t n_slices)
 }
 
 }  // namespace
+
+// ---------------------------------------------------------------------------
+// communication backend of a multi-rank solver (implementations further down)
+// ---------------------------------------------------------------------------
+// One interface, two backends.  Every call is made in the same order on all ranks and refers to the solver's
+// communication stream: the RCCL backend enqueues on it, the host backend synchronises with it.
+struct CommBackend {
+    virtual ~CommBackend() {}
+    virtual const char *name() const = 0;
+    // in-place SUM of n doubles at device pointer d; all ranks receive identical bits
+    virtual int allreduce(double *d, int64_t n, hipStream_t st) = 0;
+    // d_send[off[k]..off[k+1]) -> peers[k]; the same range of d_recv <- peers[k]
+    virtual int exchange(int np, const int *peers, const int64_t *off, const double *d_send, double *d_recv, hipStream_t st) = 0;
+};
 
 // ---------------------------------------------------------------------------
 // the solver object
@@ -273,15 +289,22 @@ struct pfem_solver {
     std::vector<double> h_vals, h_rhs;
     bool host_values_dirty = false;
 
-    // comm
+    // comm: backend (RCCL or host hooks), neighbour plan, exchange buffers
     int rank = 0, nranks = 1;
-    pfem_allreduce_fn allreduce = nullptr;
-    void *comm_ctx = nullptr;
-    int64_t n_shared = 0, n_iface = 0;
-    DevBuf<int32_t> d_shared_lidx, d_shared_slot;
-    double *xbuf = nullptr;       // exchange buffer (device), capacity >= n_iface + 4
-    int64_t xbuf_cap = 0;
-    DevBuf<double> d_xbuf_own;
+    struct CommBackend *comm = nullptr;          // owned
+    hipStream_t comm_stream = nullptr;           // every exchange / all-reduce is enqueued here, in one order on all ranks
+    std::vector<hipEvent_t> xev;                 // cross-stream events (no timing), used round-robin
+    size_t xev_next = 0;
+    bool have_plan = false;
+    std::vector<int> peers;
+    std::vector<int64_t> peer_off;               // [n_peers+1] offsets into the send / receive buffers
+    int64_t n_send = 0, n_sh = 0;                // doubles per exchange; distinct shared dofs of this rank
+    DevBuf<int32_t> d_send_lidx, d_sh_lidx, d_sh_ptr, d_sh_src;
+    DevBuf<double> d_send, d_recv, d_sbuf;       // d_sbuf: [ (p,Ap) | pad | (r,z) | (z,z) ]
+    // slices of the SpMV form in use that hold shared rows (run first) / the others (run under the exchange)
+    DevBuf<int32_t> d_slices_b, d_slices_i;
+    int64_t n_slices_b = 0, n_slices_i = 0;
+    int slices_fmt = -1;
 
     // timing
     pfem_timings tm{};
@@ -294,7 +317,7 @@ struct pfem_solver {
     bool profile_spmv = false;
     int profile_every = 1;         // event pair around every profile_every-th SpMV launch of a solve
     std::vector<hipEvent_t> spmv_events;
-    std::vector<hipEvent_t> comm_events;   // 4 per sampled iteration: interface exchange begin/end, scalar exchange begin/end
+    std::vector<hipEvent_t> comm_events;   // 8 per sampled iteration (timing events on the comm / compute streams)
 
     SellDev sell() const
     {
@@ -392,6 +415,11 @@ extern "C" int pfem_solver_destroy(pfem_solver *s)
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (hipEvent_t e : s->spmv_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : s->comm_events) (void)hipEventDestroy(e);
+    if (s->comm_stream) (void)hipStreamSynchronize(s->comm_stream);
+    delete s->comm;            // before the streams go: an RCCL communicator is destroyed here
+    s->comm = nullptr;
+    for (hipEvent_t e : s->xev) (void)hipEventDestroy(e);
+    if (s->comm_stream) (void)hipStreamDestroy(s->comm_stream);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
@@ -1194,28 +1222,29 @@ inline unsigned spmv_blocks(const pfem_solver *s)
 }
 
 // the CG / standalone SpMV launch: row-grouped form when the pattern has it, else 16-bit gaps when available
-// and not disabled, else int32
+// and not disabled, else int32.  `sel`: all slices (default) or a list of them (multi-GPU boundary / interior pass;
+// `partial` then points at this pass's share of the (p,Ap) partials).
 template <bool WITH_DOT>
 void launch_spmv(pfem_solver *s, const double *x, double *y, int64_t n_dot, double *partial, const CgCtl *ctl,
-                 hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
+                 hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, SliceSel sel = SliceSel{nullptr, 0})
 {
-    const dim3 grid(spmv_blocks(s)), block(kBlock);
+    const dim3 grid(sel.list ? spmv_grid(sel.count) : spmv_blocks(s)), block(kBlock);
     SellDev A = s->sell();
     if (s->use_grouped()) {
         SellGDev G = s->sellg();
-        if (e0) hipExtLaunchKernelGGL(k_spmvg<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, G, s->n_loc, x, y, n_dot, partial, ctl);
-        else hipLaunchKernelGGL(k_spmvg<WITH_DOT>, grid, block, 0, s->stream, G, s->n_loc, x, y, n_dot, partial, ctl);
+        if (e0) hipExtLaunchKernelGGL(k_spmvg<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
+        else hipLaunchKernelGGL(k_spmvg<WITH_DOT>, grid, block, 0, s->stream, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
     } else if (s->use_rel()) {
         SellRDev G = s->sellr();
-        if (e0) hipExtLaunchKernelGGL(k_spmvr<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, G, s->n_loc, x, y, n_dot, partial, ctl);
-        else hipLaunchKernelGGL(k_spmvr<WITH_DOT>, grid, block, 0, s->stream, G, s->n_loc, x, y, n_dot, partial, ctl);
+        if (e0) hipExtLaunchKernelGGL(k_spmvr<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
+        else hipLaunchKernelGGL(k_spmvr<WITH_DOT>, grid, block, 0, s->stream, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
     } else if (s->cols16 && s->spmv_format != PFEM_SPMV_INT32) {
         Sell16Dev C{s->d_col0.p, s->d_dwords.p, s->d_slice_doff.p};
-        if (e0) hipExtLaunchKernelGGL(k_spmv16<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, A, C, x, y, n_dot, partial, ctl);
-        else hipLaunchKernelGGL(k_spmv16<WITH_DOT>, grid, block, 0, s->stream, A, C, x, y, n_dot, partial, ctl);
+        if (e0) hipExtLaunchKernelGGL(k_spmv16<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, A, C, x, y, n_dot, partial, ctl, sel);
+        else hipLaunchKernelGGL(k_spmv16<WITH_DOT>, grid, block, 0, s->stream, A, C, x, y, n_dot, partial, ctl, sel);
     } else {
-        if (e0) hipExtLaunchKernelGGL(k_spmv<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, A, x, y, n_dot, partial, ctl);
-        else hipLaunchKernelGGL(k_spmv<WITH_DOT>, grid, block, 0, s->stream, A, x, y, n_dot, partial, ctl);
+        if (e0) hipExtLaunchKernelGGL(k_spmv<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, A, x, y, n_dot, partial, ctl, sel);
+        else hipLaunchKernelGGL(k_spmv<WITH_DOT>, grid, block, 0, s->stream, A, x, y, n_dot, partial, ctl, sel);
     }
 }
 
@@ -1293,109 +1322,421 @@ extern "C" int pfem_bench_spmv(pfem_solver *s, int reps, double *ms_per_launch)
 }
 
 // ---------------------------------------------------------------------------
-// multi-GPU plumbing
+// multi-GPU plumbing: communication backends, neighbour plan, exchange
 // ---------------------------------------------------------------------------
-extern "C" int pfem_solver_set_comm(pfem_solver *s, int rank, int nranks, pfem_allreduce_fn fn, void *ctx)
+namespace {
+
+// ---- RCCL, loaded at run time ------------------------------------------------------------------------------
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+// The copy of librccl already mapped into the process is taken if there is one (a torch host has its own; two RCCL
+// instances in one process would each claim the device's IPC resources), else the ROCm installation's.
+RcclApi *rccl_api()
 {
-    if (!s || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !fn)) return PFEM_ERR_ARG;
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.handle ? &api : nullptr;
+    tried = true;
+    void *h = nullptr;
+    if (const char *e = std::getenv("PFEM_RCCL_LIB")) h = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+        set_last_error(std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "?"));
+        return nullptr;
+    }
+    bool ok = true;
+    auto sym = [&](const char *n) { void *p = dlsym(h, n); if (!p) { ok = false; set_last_error(std::string("librccl lacks ") + n); } return p; };
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+    api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+    api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+    api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) return nullptr;
+    api.handle = h;
+    return &api;
+}
+
+struct RcclBackend final : CommBackend {
+    RcclApi *api;
+    ncclComm_t comm = nullptr;
+    explicit RcclBackend(RcclApi *a) : api(a) {}
+    ~RcclBackend() override { if (comm) (void)api->CommDestroy(comm); }
+    const char *name() const override { return "rccl"; }
+    int fail(const char *what, ncclResult_t r)
+    {
+        set_last_error(std::string(what) + ": " + api->GetErrorString(r));
+        return PFEM_ERR_COMM;
+    }
+    int allreduce(double *d, int64_t n, hipStream_t st) override
+    {
+        const ncclResult_t r = api->AllReduce(d, d, static_cast<size_t>(n), ncclDouble, ncclSum, comm, st);
+        return r == ncclSuccess ? PFEM_OK : fail("ncclAllReduce", r);
+    }
+    int exchange(int np, const int *peers, const int64_t *off, const double *d_send, double *d_recv, hipStream_t st) override
+    {
+        if (np == 0) return PFEM_OK;
+        ncclResult_t r = api->GroupStart();
+        if (r != ncclSuccess) return fail("ncclGroupStart", r);
+        for (int k = 0; k < np; ++k) {     // one send and one receive per neighbour, all in one group: no ordering deadlock
+            const size_t cnt = static_cast<size_t>(off[k + 1] - off[k]);
+            r = api->Send(d_send + off[k], cnt, ncclDouble, peers[k], comm, st);
+            if (r != ncclSuccess) { (void)api->GroupEnd(); return fail("ncclSend", r); }
+            r = api->Recv(d_recv + off[k], cnt, ncclDouble, peers[k], comm, st);
+            if (r != ncclSuccess) { (void)api->GroupEnd(); return fail("ncclRecv", r); }
+        }
+        r = api->GroupEnd();
+        return r == ncclSuccess ? PFEM_OK : fail("ncclGroupEnd", r);
+    }
+};
+
+// ---- host hooks (MPI, gloo): staged through pinned memory ---------------------------------------------------
+struct HostBackend final : CommBackend {
+    pfem_host_allreduce_fn ar;
+    pfem_host_exchange_fn ex;
+    void *ctx;
+    double *h_send = nullptr, *h_recv = nullptr;
+    size_t cap = 0;
+    HostBackend(pfem_host_allreduce_fn a, pfem_host_exchange_fn e, void *c) : ar(a), ex(e), ctx(c) {}
+    ~HostBackend() override
+    {
+        if (h_send) (void)hipHostFree(h_send);
+        if (h_recv) (void)hipHostFree(h_recv);
+    }
+    const char *name() const override { return "host"; }
+    int reserve(size_t n)
+    {
+        if (n <= cap) return PFEM_OK;
+        if (h_send) (void)hipHostFree(h_send);
+        if (h_recv) (void)hipHostFree(h_recv);
+        h_send = h_recv = nullptr;
+        cap = 0;
+        const size_t want = std::max<size_t>(n, 64);
+        if (hipHostMalloc(reinterpret_cast<void **>(&h_send), want * sizeof(double)) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void **>(&h_recv), want * sizeof(double)) != hipSuccess)
+            return PFEM_ERR_NOMEM;
+        cap = want;
+        return PFEM_OK;
+    }
+    int allreduce(double *d, int64_t n, hipStream_t st) override
+    {
+        PFEM_TRY(reserve(static_cast<size_t>(n)));
+        PFEM_HIP(hipMemcpyAsync(h_send, d, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+        PFEM_HIP(hipStreamSynchronize(st));
+        if (ar(ctx, h_send, n) != 0) { set_last_error("host all-reduce hook returned nonzero"); return PFEM_ERR_COMM; }
+        PFEM_HIP(hipMemcpyAsync(d, h_send, sizeof(double) * n, hipMemcpyHostToDevice, st));
+        PFEM_HIP(hipStreamSynchronize(st));
+        return PFEM_OK;
+    }
+    int exchange(int np, const int *peers, const int64_t *off, const double *d_send, double *d_recv, hipStream_t st) override
+    {
+        if (np == 0) return PFEM_OK;
+        const int64_t n = off[np];
+        PFEM_TRY(reserve(static_cast<size_t>(n)));
+        PFEM_HIP(hipMemcpyAsync(h_send, d_send, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+        PFEM_HIP(hipStreamSynchronize(st));
+        if (ex(ctx, np, peers, off, h_send, h_recv) != 0) { set_last_error("host exchange hook returned nonzero"); return PFEM_ERR_COMM; }
+        PFEM_HIP(hipMemcpyAsync(d_recv, h_recv, sizeof(double) * n, hipMemcpyHostToDevice, st));
+        PFEM_HIP(hipStreamSynchronize(st));
+        return PFEM_OK;
+    }
+};
+
+int ensure_comm_stream(pfem_solver *s)
+{
+    if (!s->comm_stream) PFEM_HIP(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
+    while (s->xev.size() < 32) {
+        hipEvent_t e;
+        PFEM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        s->xev.push_back(e);
+    }
+    if (!s->d_sbuf.p) {
+        PFEM_TRY(s->d_sbuf.alloc(4));
+        PFEM_HIP(hipMemsetAsync(s->d_sbuf.p, 0, 4 * sizeof(double), s->stream));
+    }
+    return PFEM_OK;
+}
+
+int install_backend(pfem_solver *s, int rank, int nranks, CommBackend *b)
+{
+    delete s->comm;
+    s->comm = b;
     s->rank = rank;
     s->nranks = nranks;
-    s->allreduce = fn;
-    s->comm_ctx = ctx;
+    return ensure_comm_stream(s);
+}
+
+// `to` continues only after everything queued on `from` so far
+int stream_follows(pfem_solver *s, hipStream_t to, hipStream_t from)
+{
+    hipEvent_t e = s->xev[s->xev_next++ % s->xev.size()];
+    PFEM_HIP(hipEventRecord(e, from));
+    PFEM_HIP(hipStreamWaitEvent(to, e, 0));
     return PFEM_OK;
 }
 
-extern "C" int pfem_solver_set_exchange_buffer(pfem_solver *s, void *device_buf, int64_t capacity)
+}  // namespace
+
+extern "C" int pfem_rccl_unique_id(void *id_out)
 {
-    if (!s || (device_buf && capacity < 4)) return PFEM_ERR_ARG;
-    s->xbuf = static_cast<double *>(device_buf);
-    s->xbuf_cap = device_buf ? capacity : 0;
+    static_assert(sizeof(ncclUniqueId) == PFEM_RCCL_ID_BYTES, "ncclUniqueId size");
+    if (!id_out) return PFEM_ERR_ARG;
+    RcclApi *api = rccl_api();
+    if (!api) return PFEM_ERR_COMM;
+    ncclUniqueId id;
+    const ncclResult_t r = api->GetUniqueId(&id);
+    if (r != ncclSuccess) { set_last_error(std::string("ncclGetUniqueId: ") + api->GetErrorString(r)); return PFEM_ERR_COMM; }
+    std::memcpy(id_out, &id, sizeof id);
     return PFEM_OK;
 }
 
-extern "C" int pfem_solver_set_interface(pfem_solver *s, int64_t n_shared, const int64_t *shared_gid,
-                                         const int32_t *shared_slot, int64_t n_iface_global)
+extern "C" int pfem_solver_set_comm_rccl(pfem_solver *s, int rank, int nranks, const void *id_bytes)
 {
-    if (!s || n_shared < 0 || n_iface_global < n_shared || (n_shared && (!shared_gid || !shared_slot)))
-        return PFEM_ERR_ARG;
+    if (!s || nranks < 1 || rank < 0 || rank >= nranks || !id_bytes) return PFEM_ERR_ARG;
+    PFEM_TRY(use_device(s));
+    RcclApi *api = rccl_api();
+    if (!api) return PFEM_ERR_COMM;
+    ncclUniqueId id;
+    std::memcpy(&id, id_bytes, sizeof id);
+    RcclBackend *b = new (std::nothrow) RcclBackend(api);
+    if (!b) return PFEM_ERR_NOMEM;
+    const ncclResult_t r = api->CommInitRank(&b->comm, nranks, id, rank);
+    if (r != ncclSuccess) {
+        const int rc = b->fail("ncclCommInitRank", r);
+        b->comm = nullptr;
+        delete b;
+        return rc;
+    }
+    return install_backend(s, rank, nranks, b);
+}
+
+extern "C" int pfem_solver_set_comm_host(pfem_solver *s, int rank, int nranks, pfem_host_allreduce_fn allreduce,
+                                         pfem_host_exchange_fn exchange, void *ctx)
+{
+    if (!s || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && (!allreduce || !exchange))) return PFEM_ERR_ARG;
+    PFEM_TRY(use_device(s));
+    HostBackend *b = new (std::nothrow) HostBackend(allreduce, exchange, ctx);
+    if (!b) return PFEM_ERR_NOMEM;
+    return install_backend(s, rank, nranks, b);
+}
+
+// The plan in local terms: send list (one segment per neighbour) and, per distinct shared dof, the receive-buffer
+// positions of the other ranks' partials in ascending rank order with this rank's own partial (-1) in its place.
+extern "C" int pfem_solver_set_neighbours(pfem_solver *s, int n_peers, const int *peers, const int64_t *peer_off,
+                                          const int64_t *shared_gid)
+{
+    if (!s || n_peers < 0 || (n_peers && (!peers || !peer_off || !shared_gid))) return PFEM_ERR_ARG;
     if (!s->have_mesh && !s->have_pattern) return PFEM_ERR_STATE;   // local numbering must exist
     PFEM_TRY(use_device(s));
-    std::vector<int32_t> lidx(static_cast<size_t>(n_shared));
+    const int64_t total = n_peers ? peer_off[n_peers] : 0;
+    if (total > INT32_MAX) return PFEM_ERR_ARG;
     const int64_t lo = s->row_start, hi = s->row_start + s->n_owned;
-    for (int64_t i = 0; i < n_shared; ++i) {
-        const int64_t g = shared_gid[i];
-        if (shared_slot[i] < 0 || shared_slot[i] >= n_iface_global) return PFEM_ERR_ARG;
-        if (g >= lo && g < hi) { lidx[i] = static_cast<int32_t>(g - lo); continue; }
-        auto it = std::lower_bound(s->ghost_gid.begin(), s->ghost_gid.end(), g);
-        if (it == s->ghost_gid.end() || *it != g) return PFEM_ERR_ARG;   // not a dof of this rank
-        lidx[i] = static_cast<int32_t>(s->n_owned + (it - s->ghost_gid.begin()));
+    std::vector<int32_t> send_lidx(static_cast<size_t>(total));
+    for (int k = 0; k < n_peers; ++k) {
+        if (peers[k] < 0 || peers[k] == s->rank || (k && peers[k] <= peers[k - 1]) || peer_off[k] > peer_off[k + 1]) return PFEM_ERR_ARG;
+        for (int64_t i = peer_off[k]; i < peer_off[k + 1]; ++i) {
+            const int64_t g = shared_gid[i];
+            if (i > peer_off[k] && shared_gid[i - 1] >= g) return PFEM_ERR_ARG;
+            if (g >= lo && g < hi) { send_lidx[i] = static_cast<int32_t>(g - lo); continue; }
+            auto it = std::lower_bound(s->ghost_gid.begin(), s->ghost_gid.end(), g);
+            if (it == s->ghost_gid.end() || *it != g) { set_last_error("neighbour plan names a dof this rank does not hold"); return PFEM_ERR_ARG; }
+            send_lidx[i] = static_cast<int32_t>(s->n_owned + (it - s->ghost_gid.begin()));
+        }
     }
-    PFEM_TRY(s->d_shared_lidx.alloc(static_cast<size_t>(n_shared)));
-    PFEM_TRY(s->d_shared_slot.alloc(static_cast<size_t>(n_shared)));
-    if (n_shared) {
-        PFEM_HIP(hipMemcpy(s->d_shared_lidx.p, lidx.data(), sizeof(int32_t) * n_shared, hipMemcpyHostToDevice));
-        PFEM_HIP(hipMemcpy(s->d_shared_slot.p, shared_slot, sizeof(int32_t) * n_shared, hipMemcpyHostToDevice));
+    // distinct shared dofs, each with its contributions ordered by rank
+    std::vector<std::pair<int32_t, std::pair<int, int32_t>>> contrib;      // (lidx, (rank, position in recv or -1))
+    contrib.reserve(static_cast<size_t>(total) * 2);
+    for (int k = 0; k < n_peers; ++k)
+        for (int64_t i = peer_off[k]; i < peer_off[k + 1]; ++i) contrib.push_back({send_lidx[i], {peers[k], static_cast<int32_t>(i)}});
+    std::sort(contrib.begin(), contrib.end());
+    std::vector<int32_t> sh_lidx, sh_ptr{0}, sh_src;
+    for (size_t a = 0; a < contrib.size();) {
+        size_t b = a;
+        while (b < contrib.size() && contrib[b].first == contrib[a].first) ++b;
+        sh_lidx.push_back(contrib[a].first);
+        bool own_done = false;
+        for (size_t c = a; c < b; ++c) {
+            if (!own_done && contrib[c].second.first > s->rank) { sh_src.push_back(-1); own_done = true; }
+            sh_src.push_back(contrib[c].second.second);
+        }
+        if (!own_done) sh_src.push_back(-1);
+        sh_ptr.push_back(static_cast<int32_t>(sh_src.size()));
+        a = b;
     }
-    s->n_shared = n_shared;
-    s->n_iface = n_iface_global;
+    s->peers.assign(peers, peers + n_peers);
+    s->peer_off.assign(1, 0);
+    if (n_peers) s->peer_off.assign(peer_off, peer_off + n_peers + 1);
+    s->n_send = total;
+    s->n_sh = static_cast<int64_t>(sh_lidx.size());
+    PFEM_TRY(s->d_send_lidx.alloc(send_lidx.size()));
+    PFEM_TRY(s->d_sh_lidx.alloc(sh_lidx.size()));
+    PFEM_TRY(s->d_sh_ptr.alloc(sh_ptr.size()));
+    PFEM_TRY(s->d_sh_src.alloc(sh_src.size()));
+    PFEM_TRY(s->d_send.alloc(static_cast<size_t>(total)));
+    PFEM_TRY(s->d_recv.alloc(static_cast<size_t>(total)));
+    if (total) PFEM_HIP(hipMemcpy(s->d_send_lidx.p, send_lidx.data(), sizeof(int32_t) * send_lidx.size(), hipMemcpyHostToDevice));
+    if (!sh_lidx.empty()) PFEM_HIP(hipMemcpy(s->d_sh_lidx.p, sh_lidx.data(), sizeof(int32_t) * sh_lidx.size(), hipMemcpyHostToDevice));
+    PFEM_HIP(hipMemcpy(s->d_sh_ptr.p, sh_ptr.data(), sizeof(int32_t) * sh_ptr.size(), hipMemcpyHostToDevice));
+    if (!sh_src.empty()) PFEM_HIP(hipMemcpy(s->d_sh_src.p, sh_src.data(), sizeof(int32_t) * sh_src.size(), hipMemcpyHostToDevice));
+    s->have_plan = true;
+    s->slices_fmt = -1;
+    return PFEM_OK;
+}
+
+// Transport self-test, independent of any mesh: every rank sends `count` stamped doubles to every other rank (with
+// one rank: to itself) through the backend's exchange and checks what arrives, then all-reduces a known vector.
+// Collective: all ranks call it.  *bad = number of wrong entries seen by this rank.
+extern "C" int pfem_solver_comm_selftest(pfem_solver *s, int64_t count, int64_t *bad)
+{
+    if (!s || count < 1 || !bad) return PFEM_ERR_ARG;
+    if (!s->comm) return PFEM_ERR_STATE;
+    PFEM_TRY(use_device(s));
+    PFEM_TRY(ensure_comm_stream(s));
+    std::vector<int> peers;
+    for (int q = 0; q < s->nranks; ++q)
+        if (q != s->rank || s->nranks == 1) peers.push_back(q);
+    const int np = static_cast<int>(peers.size());
+    std::vector<int64_t> off(static_cast<size_t>(np) + 1, 0);
+    for (int k = 0; k < np; ++k) off[k + 1] = off[k] + count;
+    const size_t tot = static_cast<size_t>(off[np]);
+    std::vector<double> h_send(tot), h_recv(tot, -1.0);
+    auto stamp = [&](int from, int to, int64_t i) { return 1.0e6 * from + 1.0e3 * to + static_cast<double>(i % 997); };
+    for (int k = 0; k < np; ++k)
+        for (int64_t i = 0; i < count; ++i) h_send[static_cast<size_t>(off[k] + i)] = stamp(s->rank, peers[k], i);
+    DevBuf<double> d_send, d_recv, d_red;
+    PFEM_TRY(d_send.alloc(tot));
+    PFEM_TRY(d_recv.alloc(tot));
+    PFEM_TRY(d_red.alloc(4));
+    PFEM_HIP(hipMemcpyAsync(d_send.p, h_send.data(), sizeof(double) * tot, hipMemcpyHostToDevice, s->stream));
+    PFEM_HIP(hipMemsetAsync(d_recv.p, 0xff, sizeof(double) * tot, s->stream));
+    const double red_in[4] = {1.0, static_cast<double>(s->rank + 1), 0.5 * (s->rank + 1), -2.0};
+    PFEM_HIP(hipMemcpyAsync(d_red.p, red_in, sizeof red_in, hipMemcpyHostToDevice, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    PFEM_TRY(stream_follows(s, s->comm_stream, s->stream));
+    PFEM_TRY(s->comm->exchange(np, peers.data(), off.data(), d_send.p, d_recv.p, s->comm_stream));
+    PFEM_TRY(s->comm->allreduce(d_red.p, 4, s->comm_stream));
+    PFEM_TRY(stream_follows(s, s->stream, s->comm_stream));
+    double red_out[4];
+    PFEM_HIP(hipMemcpyAsync(h_recv.data(), d_recv.p, sizeof(double) * tot, hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipMemcpyAsync(red_out, d_red.p, sizeof red_out, hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    int64_t nbad = 0;
+    for (int k = 0; k < np; ++k)
+        for (int64_t i = 0; i < count; ++i)
+            if (h_recv[static_cast<size_t>(off[k] + i)] != stamp(peers[k], s->rank, i)) ++nbad;
+    const double n = s->nranks, tri = 0.5 * n * (n + 1.0);
+    const double want[4] = {n, tri, 0.5 * tri, -2.0 * n};
+    for (int j = 0; j < 4; ++j)
+        if (red_out[j] != want[j]) ++nbad;
+    *bad = nbad;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_comm_info(pfem_solver *s, int *n_peers, int64_t *doubles_per_exchange, int64_t *boundary_slices,
+                                     int64_t *total_slices)
+{
+    if (!s) return PFEM_ERR_ARG;
+    if (n_peers) *n_peers = static_cast<int>(s->peers.size());
+    if (doubles_per_exchange) *doubles_per_exchange = s->n_send;
+    if (boundary_slices) *boundary_slices = s->slices_fmt >= 0 ? s->n_slices_b : 0;
+    if (total_slices) *total_slices = s->slices_fmt >= 0 ? s->n_slices_b + s->n_slices_i : 0;
     return PFEM_OK;
 }
 
 namespace {
 
-int ensure_xbuf(pfem_solver *s)
+// v[shared] <- sum over the ranks that hold the dof (ascending rank order), outside the iteration: the compute
+// stream packs, the communication stream exchanges, the compute stream unpacks
+int exchange_sum(pfem_solver *s, double *v)
 {
-    const int64_t need = s->n_iface + 4;
-    if (s->xbuf && s->xbuf_cap >= need) return PFEM_OK;
-    if (s->xbuf && !s->d_xbuf_own.p) {
-        set_last_error("exchange buffer too small for the interface plan");
-        return PFEM_ERR_ARG;
+    if (s->n_send > 0) {
+        hipLaunchKernelGGL(k_pack_send, dim3(grid_for(s->n_send)), dim3(kBlock), 0, s->stream, static_cast<const double *>(v),
+                           static_cast<const int32_t *>(s->d_send_lidx.p), s->n_send, s->d_send.p, static_cast<const CgCtl *>(nullptr));
+        PFEM_TRY(check_kernel("k_pack_send"));
     }
-    PFEM_TRY(s->d_xbuf_own.alloc(static_cast<size_t>(need)));
-    s->xbuf = s->d_xbuf_own.p;
-    s->xbuf_cap = need;
-    return PFEM_OK;
-}
-
-int call_hook(pfem_solver *s, double *buf, int64_t count)
-{
-    if (s->allreduce(s->comm_ctx, buf, count, s->stream) != 0) {
-        set_last_error("all-reduce hook returned nonzero");
-        return PFEM_ERR_COMM;
-    }
-    return PFEM_OK;
-}
-
-// v[shared] <- sum over ranks of v[shared]; optionally carries n_extra scalars reduced
-// from partial arrays in buf[n_iface + j]
-int interface_sum(pfem_solver *s, double *v, const double *part0, const double *part1, int nparts, int n_extra,
-                  const CgCtl *ctl)
-{
-    double *buf = s->xbuf;
-    PFEM_HIP(hipMemsetAsync(buf, 0, sizeof(double) * static_cast<size_t>(s->n_iface + n_extra), s->stream));
-    const unsigned gb = grid_for(s->n_shared) + 1;
-    hipLaunchKernelGGL(k_pack, dim3(gb), dim3(kBlock), 0, s->stream, v, s->d_shared_lidx.p, s->d_shared_slot.p, s->n_shared, buf,
-                       s->n_iface, part0, part1, nparts, n_extra, ctl);
-    PFEM_TRY(check_kernel("k_pack"));
-    PFEM_TRY(call_hook(s, buf, s->n_iface + n_extra));
-    if (v && s->n_shared > 0) {
-        hipLaunchKernelGGL(k_unpack, dim3(grid_for(s->n_shared)), dim3(kBlock), 0, s->stream, v, s->d_shared_lidx.p,
-                           s->d_shared_slot.p, s->n_shared, buf, ctl);
-        PFEM_TRY(check_kernel("k_unpack"));
+    PFEM_TRY(stream_follows(s, s->comm_stream, s->stream));
+    PFEM_TRY(s->comm->exchange(static_cast<int>(s->peers.size()), s->peers.data(), s->peer_off.data(), s->d_send.p, s->d_recv.p,
+                               s->comm_stream));
+    PFEM_TRY(stream_follows(s, s->stream, s->comm_stream));
+    if (s->n_sh > 0) {
+        hipLaunchKernelGGL(k_unpack_sum, dim3(grid_for(s->n_sh)), dim3(kBlock), 0, s->stream, v,
+                           static_cast<const int32_t *>(s->d_sh_lidx.p), static_cast<const int32_t *>(s->d_sh_ptr.p),
+                           static_cast<const int32_t *>(s->d_sh_src.p), s->n_sh, static_cast<const double *>(s->d_recv.p),
+                           static_cast<const CgCtl *>(nullptr));
+        PFEM_TRY(check_kernel("k_unpack_sum"));
     }
     return PFEM_OK;
 }
 
-// two scalars reduced from partial arrays -> all-reduce -> buf2[0..1]
-int scalar_sum2(pfem_solver *s, const double *part0, const double *part1, int nparts, const CgCtl *ctl)
+// sbuf[at..at+n) <- sum over the ranks, result visible to the compute stream
+int scalar_allreduce(pfem_solver *s, int at, int n)
 {
-    double *buf2 = s->xbuf + s->n_iface + 2;
-    PFEM_HIP(hipMemsetAsync(buf2, 0, 2 * sizeof(double), s->stream));
-    hipLaunchKernelGGL(k_pack, dim3(1), dim3(kBlock), 0, s->stream, static_cast<const double *>(nullptr),
-                       static_cast<const int32_t *>(nullptr), static_cast<const int32_t *>(nullptr), static_cast<int64_t>(0),
-                       buf2, static_cast<int64_t>(0), part0, part1, nparts, 2, ctl);
-    PFEM_TRY(check_kernel("k_pack(scalars)"));
-    return call_hook(s, buf2, 2);
+    PFEM_TRY(stream_follows(s, s->comm_stream, s->stream));
+    PFEM_TRY(s->comm->allreduce(s->d_sbuf.p + at, n, s->comm_stream));
+    return stream_follows(s, s->stream, s->comm_stream);
+}
+
+// which SpMV form the next launch uses (key of the slice lists and of the captured graph)
+inline int spmv_form(const pfem_solver *s)
+{
+    return s->use_grouped() ? 3 : (s->use_rel() ? 4 : ((s->cols16 && s->spmv_format != PFEM_SPMV_INT32) ? 2 : 1));
+}
+
+// boundary / interior slice lists of the SpMV form in use
+int build_slice_lists(pfem_solver *s)
+{
+    const int fmt = spmv_form(s);
+    if (s->slices_fmt == fmt) return PFEM_OK;
+    const int64_t ns = fmt == 3 ? s->n_gslices : (fmt == 4 ? s->n_rslices : s->n_slices);
+    std::vector<char> flag(static_cast<size_t>(std::max<int64_t>(ns, 1)), 0);
+    if (s->n_sh > 0 && ns > 0) {
+        DevBuf<char> d_flag;
+        DevBuf<int32_t> d_row_group;
+        PFEM_TRY(d_flag.alloc(static_cast<size_t>(ns)));
+        PFEM_HIP(hipMemsetAsync(d_flag.p, 0, static_cast<size_t>(ns), s->stream));
+        const int32_t *rg = nullptr;
+        int shift = 6;                                  // 64 rows per slice
+        if (fmt == 4) shift = 8;                        // 64 groups of kRelRows = 4 consecutive rows
+        if (fmt == 3) {                                 // 64 groups of up to 3 rows: look the group up
+            PFEM_TRY(d_row_group.alloc(static_cast<size_t>(s->n_loc)));
+            hipLaunchKernelGGL(k_row_group_index, dim3(grid_for(s->n_groups)), dim3(kBlock), 0, s->stream,
+                               static_cast<const int32_t *>(s->d_group_row0.p), s->n_groups, d_row_group.p);
+            PFEM_TRY(check_kernel("k_row_group_index"));
+            rg = d_row_group.p;
+        }
+        hipLaunchKernelGGL(k_mark_boundary_slices, dim3(grid_for(s->n_sh)), dim3(kBlock), 0, s->stream,
+                           static_cast<const int32_t *>(s->d_sh_lidx.p), s->n_sh, shift, rg, d_flag.p);
+        PFEM_TRY(check_kernel("k_mark_boundary_slices"));
+        PFEM_HIP(hipMemcpyAsync(flag.data(), d_flag.p, static_cast<size_t>(ns), hipMemcpyDeviceToHost, s->stream));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+    }
+    std::vector<int32_t> lb, li;
+    for (int64_t i = 0; i < ns; ++i) (flag[i] ? lb : li).push_back(static_cast<int32_t>(i));
+    s->n_slices_b = static_cast<int64_t>(lb.size());
+    s->n_slices_i = static_cast<int64_t>(li.size());
+    PFEM_TRY(s->d_slices_b.alloc(lb.size()));
+    PFEM_TRY(s->d_slices_i.alloc(li.size()));
+    if (!lb.empty()) PFEM_HIP(hipMemcpy(s->d_slices_b.p, lb.data(), sizeof(int32_t) * lb.size(), hipMemcpyHostToDevice));
+    if (!li.empty()) PFEM_HIP(hipMemcpy(s->d_slices_i.p, li.data(), sizeof(int32_t) * li.size(), hipMemcpyHostToDevice));
+    s->slices_fmt = fmt;
+    return PFEM_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -1404,17 +1745,33 @@ int scalar_sum2(pfem_solver *s, const double *part0, const double *part1, int np
 int run_pcg(pfem_solver *s)
 {
     const int64_t n = s->n_loc;
-    const bool multi = s->nranks > 1;
+    // test knob PFEM_FORCE_MULTI: a single rank with a backend and an (empty) plan takes the multi-rank loop too
+    const bool multi = s->nranks > 1 || (s->comm && s->have_plan && std::getenv("PFEM_FORCE_MULTI"));
     s->group_vals_stale = true;            // the row form may have been re-assembled since the last solve
     PFEM_TRY(refresh_group_vals(s));
     const unsigned gv = vec_grid(n), gs = spmv_blocks(s);
     const dim3 block(kBlock);
     SellDev A = s->sell();
-    if (s->d_part_pw.n < gs) PFEM_TRY(s->d_part_pw.alloc(gs));
+    if (s->d_part_pw.n < gs + 2) PFEM_TRY(s->d_part_pw.alloc(gs + 2));     // + 2: the boundary / interior passes round up separately
     double *part_pw = s->d_part_pw.p, *part_rz = s->d_part.p, *part_zz = s->d_part.p + kMaxGrid;
     double *scal_pw = s->d_part.p + 2 * kMaxGrid;      // (p,Ap) reduced by k_reduce_partials
     CgCtl *ctl = s->d_ctl.p;
-    if (multi) PFEM_TRY(ensure_xbuf(s));
+    if (multi) {
+        if (!s->comm || !s->have_plan) {
+            set_last_error("a solver of a multi-rank run needs a communication backend (pfem_solver_set_comm_rccl / _host) "
+                           "and the neighbour plan (pfem_solver_set_neighbours) before the solve");
+            return PFEM_ERR_STATE;
+        }
+        PFEM_TRY(ensure_comm_stream(s));
+        PFEM_TRY(build_slice_lists(s));
+    }
+    double *sbuf = s->d_sbuf.p;                        // multi: [ (p,Ap) | - | (r,z) | (z,z) ] summed over the ranks
+    // two partial arrays -> sbuf[at], sbuf[at+1] (one block, fixed order), then the all-reduce over the ranks
+    auto reduce_scalars = [&](const double *p0, const double *p1, int np, int at, int cnt, const CgCtl *c) -> int {
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s->stream, p0, p1, np, sbuf + at, c);
+        PFEM_TRY(check_kernel("k_reduce_partials"));
+        return scalar_allreduce(s, at, cnt);
+    };
     if (s->hist_cap < s->maxits + 2) {
         PFEM_TRY(s->d_hist.alloc(static_cast<size_t>(s->maxits) + 2));
         s->hist_cap = s->maxits + 2;
@@ -1439,21 +1796,22 @@ int run_pcg(pfem_solver *s)
         if (s->block_pc()) {
             const uint32_t *rgp = s->d_row_grp.p;
             hipLaunchKernelGGL(k_group_sig, dim3(grid_for(n)), block, 0, s->stream, rgp, n, s->d_binv[0].p, s->d_binv[1].p);
-            PFEM_TRY(interface_sum(s, s->d_binv[0].p, nullptr, nullptr, 0, 0, nullptr));
-            PFEM_TRY(interface_sum(s, s->d_binv[1].p, nullptr, nullptr, 0, 0, nullptr));
+            PFEM_TRY(exchange_sum(s, s->d_binv[0].p));
+            PFEM_TRY(exchange_sum(s, s->d_binv[1].p));
             hipLaunchKernelGGL(k_group_sig_check, dim3(grid_for(n)), block, 0, s->stream, rgp, n,
                                static_cast<const double *>(s->d_binv[0].p), static_cast<const double *>(s->d_binv[1].p), bad);
             PFEM_TRY(check_kernel("k_group_sig_check"));
         } else {
-            // no groups here: still take part in the two interface sums of the others, then vote no
-            PFEM_TRY(interface_sum(s, nullptr, nullptr, nullptr, 0, 0, nullptr));
-            PFEM_TRY(interface_sum(s, nullptr, nullptr, nullptr, 0, 0, nullptr));
+            // no groups here: still take part in the two exchanges of the others (zeros), then vote no
+            PFEM_HIP(hipMemsetAsync(s->d_w.p, 0, sizeof(double) * static_cast<size_t>(std::max<int64_t>(n, 1)), s->stream));
+            PFEM_TRY(exchange_sum(s, s->d_w.p));
+            PFEM_TRY(exchange_sum(s, s->d_w.p));
             const double one = 1.0;
             PFEM_HIP(hipMemcpyAsync(bad, &one, sizeof(double), hipMemcpyHostToDevice, s->stream));
         }
-        PFEM_TRY(scalar_sum2(s, bad, part_zz, 1, nullptr));
+        PFEM_TRY(reduce_scalars(bad, part_zz, 1, 2, 2, nullptr));
         double verdict[2] = {0.0, 0.0};
-        PFEM_HIP(hipMemcpyAsync(verdict, s->xbuf + s->n_iface + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        PFEM_HIP(hipMemcpyAsync(verdict, sbuf + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
         PFEM_HIP(hipStreamSynchronize(s->stream));
         s->block_pc_ok = verdict[0] == 0.0;
     }
@@ -1465,9 +1823,9 @@ int run_pcg(pfem_solver *s)
                            s->d_binv[0].p, s->d_binv[1].p, s->d_binv[2].p);
         PFEM_TRY(check_kernel("k_extract_blocks"));
         if (multi) {
-            for (auto &b : s->d_binv) PFEM_TRY(interface_sum(s, b.p, nullptr, nullptr, 0, 0, nullptr));
+            for (auto &b : s->d_binv) PFEM_TRY(exchange_sum(s, b.p));
             if (!s->rhs_summed) {
-                PFEM_TRY(interface_sum(s, s->d_rhs.p, nullptr, nullptr, 0, 0, nullptr));
+                PFEM_TRY(exchange_sum(s, s->d_rhs.p));
                 s->rhs_summed = true;
             }
         }
@@ -1486,9 +1844,9 @@ int run_pcg(pfem_solver *s)
         PFEM_TRY(check_kernel("k_extract_diag"));
     }
     if (multi) {
-        PFEM_TRY(interface_sum(s, s->d_dinv.p, nullptr, nullptr, 0, 0, nullptr));
+        PFEM_TRY(exchange_sum(s, s->d_dinv.p));
         if (!s->rhs_summed) {
-            PFEM_TRY(interface_sum(s, s->d_rhs.p, nullptr, nullptr, 0, 0, nullptr));
+            PFEM_TRY(exchange_sum(s, s->d_rhs.p));
             s->rhs_summed = true;
         }
     }
@@ -1504,8 +1862,8 @@ int run_pcg(pfem_solver *s)
     const unsigned gvec = gv;                  // blocks (= partials) of the vector kernels
     const double *red2 = nullptr;
     if (multi) {
-        PFEM_TRY(scalar_sum2(s, part_rz, part_zz, static_cast<int>(gvec), nullptr));
-        red2 = s->xbuf + s->n_iface + 2;
+        PFEM_TRY(reduce_scalars(part_rz, part_zz, static_cast<int>(gvec), 2, 2, nullptr));
+        red2 = sbuf + 2;
     }
     hipLaunchKernelGGL(k_cg_start, dim3(1), block, 0, s->stream, ctl, part_rz, part_zz, static_cast<int>(gvec), red2, s->rtol,
                        s->abstol, s->dtol, s->d_hist.p);
@@ -1524,7 +1882,7 @@ int run_pcg(pfem_solver *s)
         const bool sampled_ok = !s->profile_spmv || s->profile_every % kGraphIters == 0;
         if (graph_env && !s->cg_graph_off && !multi && !bpc && n > 0 && (n <= kGraphMaxRows || graph_env > 1) &&
             s->stream != nullptr && sampled_ok) {
-            const int fmt = s->use_grouped() ? 3 : (s->use_rel() ? 4 : ((s->cols16 && s->spmv_format != PFEM_SPMV_INT32) ? 2 : 1));
+            const int fmt = spmv_form(s);
             const std::vector<uint64_t> key = {
                 reinterpret_cast<uint64_t>(s->d_p.p), reinterpret_cast<uint64_t>(s->d_w.p), reinterpret_cast<uint64_t>(s->d_r.p),
                 reinterpret_cast<uint64_t>(s->d_x.p), reinterpret_cast<uint64_t>(s->d_dinv.p), reinterpret_cast<uint64_t>(s->d_part.p),
@@ -1616,19 +1974,19 @@ int run_pcg(pfem_solver *s)
         const int it_end = std::min(it + chunk, s->maxits);
         for (; it < it_end; ++it) {
             // w = A p, partial (p, A_loc p) over ALL local rows (sub-assembled identity)
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            const bool sample = s->profile_spmv && it % s->profile_every == 0 && ev_used + 2 <= 8192;
+            hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+            const size_t ev_per = multi ? 4 : 2;      // multi: one pair for the boundary pass, one for the interior pass
+            const bool sample = s->profile_spmv && it % s->profile_every == 0 && ev_used + ev_per <= 8192;
             if (sample) {
-                if (s->spmv_events.size() < ev_used + 2) {
-                    hipEvent_t a, b;
+                while (s->spmv_events.size() < ev_used + ev_per) {
+                    hipEvent_t a;
                     PFEM_HIP(hipEventCreate(&a));
-                    PFEM_HIP(hipEventCreate(&b));
                     s->spmv_events.push_back(a);
-                    s->spmv_events.push_back(b);
                 }
                 e0 = s->spmv_events[ev_used];
                 e1 = s->spmv_events[ev_used + 1];
-                ev_used += 2;
+                if (multi) { e2 = s->spmv_events[ev_used + 2]; e3 = s->spmv_events[ev_used + 3]; }
+                ev_used += ev_per;
             }
             if (use_graph && it + kGraphIters <= it_end) {
                 // kGraphIters iterations from one graph launch; a sampled SpMV stays outside with its event pair
@@ -1637,32 +1995,73 @@ int run_pcg(pfem_solver *s)
                 it += kGraphIters - 1;
                 continue;
             }
-            // with events: marker-end -> kernel-end of THIS launch (see event_overhead_ms)
-            launch_spmv<true>(s, s->d_p.p, s->d_w.p, n, part_pw, ctl, e0, e1);
             const double *red_pw = nullptr, *pw_parts = part_pw;
             int pw_n = static_cast<int>(gs);
             hipEvent_t *cev = nullptr;
-            if (multi && sample && comm_used + 4 <= 4096) {
-                while (s->comm_events.size() < comm_used + 4) {
+            if (multi && sample && comm_used + 8 <= 8192) {
+                while (s->comm_events.size() < comm_used + 8) {
                     hipEvent_t e;
                     PFEM_HIP(hipEventCreate(&e));
                     s->comm_events.push_back(e);
                 }
                 cev = &s->comm_events[comm_used];
-                comm_used += 4;
+                comm_used += 8;
             }
             if (multi) {
-                if (cev) PFEM_HIP(hipEventRecord(cev[0], s->stream));
-                PFEM_TRY(interface_sum(s, s->d_w.p, part_pw, nullptr, static_cast<int>(gs), 1, ctl));
-                if (cev) PFEM_HIP(hipEventRecord(cev[1], s->stream));
-                red_pw = s->xbuf + s->n_iface;
-            } else if (gs > kMaxGrid) {
-                // too many SpMV blocks for every consumer block to re-sum: fold to kFoldBlocks first
-                hipLaunchKernelGGL(k_fold_partials, dim3(kFoldBlocks), block, 0, s->stream, static_cast<const double *>(part_pw),
-                                   static_cast<int>(gs), scal_pw, static_cast<const CgCtl *>(ctl));
-                pw_parts = scal_pw;
-                pw_n = kFoldBlocks;
+                // (1) the slices that hold shared rows, then pack; (2) the neighbour exchange on the communication stream
+                // while (3) the interior slices run; (4) (p,Ap) of this rank -> all-reduce behind the exchange;
+                // (5) the compute stream waits for both and adds the neighbours' partials in rank order
+                const unsigned nb_blocks = s->n_slices_b > 0 ? spmv_grid(s->n_slices_b) : 0;
+                const unsigned ni_blocks = s->n_slices_i > 0 ? spmv_grid(s->n_slices_i) : 0;
+                if (s->n_slices_b > 0)
+                    launch_spmv<true>(s, s->d_p.p, s->d_w.p, n, part_pw, ctl, e0, e1, SliceSel{s->d_slices_b.p, s->n_slices_b});
+                if (s->n_send > 0)
+                    hipLaunchKernelGGL(k_pack_send, dim3(grid_for(s->n_send)), block, 0, s->stream, static_cast<const double *>(s->d_w.p),
+                                       static_cast<const int32_t *>(s->d_send_lidx.p), s->n_send, s->d_send.p, static_cast<const CgCtl *>(ctl));
+                PFEM_TRY(stream_follows(s, s->comm_stream, s->stream));
+                if (cev) PFEM_HIP(hipEventRecord(cev[0], s->comm_stream));
+                PFEM_TRY(s->comm->exchange(static_cast<int>(s->peers.size()), s->peers.data(), s->peer_off.data(), s->d_send.p,
+                                           s->d_recv.p, s->comm_stream));
+                if (cev) PFEM_HIP(hipEventRecord(cev[1], s->comm_stream));
+                if (s->n_slices_i > 0)
+                    launch_spmv<true>(s, s->d_p.p, s->d_w.p, n, part_pw + nb_blocks, ctl, e2, e3, SliceSel{s->d_slices_i.p, s->n_slices_i});
+                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s->stream, static_cast<const double *>(part_pw),
+                                   static_cast<const double *>(nullptr), static_cast<int>(nb_blocks + ni_blocks), sbuf,
+                                   static_cast<const CgCtl *>(ctl));
+                PFEM_TRY(stream_follows(s, s->comm_stream, s->stream));
+                if (cev) PFEM_HIP(hipEventRecord(cev[2], s->comm_stream));
+                PFEM_TRY(s->comm->allreduce(sbuf, 1, s->comm_stream));
+                if (cev) PFEM_HIP(hipEventRecord(cev[3], s->comm_stream));
+                if (cev) PFEM_HIP(hipEventRecord(cev[6], s->stream));
+                PFEM_TRY(stream_follows(s, s->stream, s->comm_stream));
+                if (cev) PFEM_HIP(hipEventRecord(cev[7], s->stream));
+                if (s->n_sh > 0)
+                    hipLaunchKernelGGL(k_unpack_sum, dim3(grid_for(s->n_sh)), block, 0, s->stream, s->d_w.p,
+                                       static_cast<const int32_t *>(s->d_sh_lidx.p), static_cast<const int32_t *>(s->d_sh_ptr.p),
+                                       static_cast<const int32_t *>(s->d_sh_src.p), s->n_sh, static_cast<const double *>(s->d_recv.p),
+                                       static_cast<const CgCtl *>(ctl));
+                red_pw = sbuf;
+            } else {
+                // with events: marker-end -> kernel-end of THIS launch (see event_overhead_ms)
+                launch_spmv<true>(s, s->d_p.p, s->d_w.p, n, part_pw, ctl, e0, e1);
+                if (gs > kMaxGrid) {
+                    // too many SpMV blocks for every consumer block to re-sum: fold to kFoldBlocks first
+                    hipLaunchKernelGGL(k_fold_partials, dim3(kFoldBlocks), block, 0, s->stream, static_cast<const double *>(part_pw),
+                                       static_cast<int>(gs), scal_pw, static_cast<const CgCtl *>(ctl));
+                    pw_parts = scal_pw;
+                    pw_n = kFoldBlocks;
+                }
             }
+            // (r,z), (z,z) of the owned rows -> one all-reduce of two doubles between the update and the direction kernel
+            auto scalars23 = [&]() -> int {
+                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s->stream, static_cast<const double *>(part_rz),
+                                   static_cast<const double *>(part_zz), static_cast<int>(gv), sbuf + 2, static_cast<const CgCtl *>(ctl));
+                PFEM_TRY(stream_follows(s, s->comm_stream, s->stream));
+                if (cev) PFEM_HIP(hipEventRecord(cev[4], s->comm_stream));
+                PFEM_TRY(s->comm->allreduce(sbuf + 2, 2, s->comm_stream));
+                if (cev) PFEM_HIP(hipEventRecord(cev[5], s->comm_stream));
+                return stream_follows(s, s->stream, s->comm_stream);
+            };
             if (bpc) {
                 // residual ping-pong: iteration `it` reads r_a, writes r_b
                 const double *r_a = (it & 1) ? s->d_r2.p : s->d_r.p;
@@ -1671,11 +2070,7 @@ int run_pcg(pfem_solver *s)
                 hipLaunchKernelGGL(k_cg_update_b, dim3(gv), block, 0, s->stream, ctl, it, n, rgp, s->n_owned, pw_parts, pw_n, red_pw,
                                    s->d_p.p, s->d_w.p, s->d_binv[0].p, s->d_binv[1].p, s->d_binv[2].p, s->d_x.p, r_a, r_b, s->d_z.p,
                                    part_rz, part_zz);
-                if (multi) {
-                    if (cev) PFEM_HIP(hipEventRecord(cev[2], s->stream));
-                    PFEM_TRY(scalar_sum2(s, part_rz, part_zz, static_cast<int>(gv), ctl));
-                    if (cev) PFEM_HIP(hipEventRecord(cev[3], s->stream));
-                }
+                if (multi) PFEM_TRY(scalars23());
                 hipLaunchKernelGGL(k_cg_direction_b, dim3(gv), block, dir_lds, s->stream, ctl, it, n, part_rz, part_zz,
                                    static_cast<int>(gv), red2, static_cast<const double *>(s->d_z.p), s->d_p.p, s->d_hist.p,
                                    s->hist_cap, s->maxits);
@@ -1683,11 +2078,7 @@ int run_pcg(pfem_solver *s)
             }
             hipLaunchKernelGGL(k_cg_update, dim3(gv), block, 0, s->stream, ctl, it, n, s->n_owned, pw_parts, pw_n,
                                red_pw, s->d_p.p, s->d_w.p, s->d_dinv.p, s->d_x.p, s->d_r.p, part_rz, part_zz);
-            if (multi) {
-                if (cev) PFEM_HIP(hipEventRecord(cev[2], s->stream));
-                PFEM_TRY(scalar_sum2(s, part_rz, part_zz, static_cast<int>(gv), ctl));
-                if (cev) PFEM_HIP(hipEventRecord(cev[3], s->stream));
-            }
+            if (multi) PFEM_TRY(scalars23());
             hipLaunchKernelGGL(k_cg_direction, dim3(gv), block, dir_lds, s->stream, ctl, it, n, part_rz, part_zz, static_cast<int>(gv),
                                red2, s->d_r.p, s->d_dinv.p, s->d_p.p, s->d_hist.p, s->hist_cap, s->maxits, s->d_x.p);
         }
@@ -1700,21 +2091,29 @@ int run_pcg(pfem_solver *s)
     s->tm.spmv_launches = 0;
     // only launches that did work count (the tail of the last chunk exits at the flag test)
     // (the k-th pair belongs to iteration k * profile_every)
-    const size_t live = std::min(ev_used / 2, (static_cast<size_t>(h.its) + s->profile_every - 1) / s->profile_every);
+    const size_t ev_per = multi ? 4 : 2;
+    const size_t live = std::min(ev_used / ev_per, (static_cast<size_t>(h.its) + s->profile_every - 1) / s->profile_every);
     for (size_t k = 0; k < live; ++k) {
-        float f = 0.f;
-        PFEM_HIP(hipEventElapsedTime(&f, s->spmv_events[2 * k], s->spmv_events[2 * k + 1]));
-        s->tm.spmv_ms_total += f;
+        for (size_t q = 0; q < ev_per; q += 2) {
+            if (multi && ((q == 0 && s->n_slices_b == 0) || (q == 2 && s->n_slices_i == 0))) continue;   // pass not launched
+            float f = 0.f;
+            PFEM_HIP(hipEventElapsedTime(&f, s->spmv_events[ev_per * k + q], s->spmv_events[ev_per * k + q + 1]));
+            s->tm.spmv_ms_total += f;
+        }
         ++s->tm.spmv_launches;
     }
-    s->tm.iface_ms_total = s->tm.scalar_ms_total = 0.0;
+    s->tm.iface_ms_total = s->tm.scalar_ms_total = s->tm.exposed_ms_total = 0.0;
     s->tm.comm_samples = 0;
-    for (size_t k = 0; k < std::min(comm_used / 4, live); ++k) {     // same sampled iterations as the SpMV pairs
-        float a = 0.f, b = 0.f;
-        PFEM_HIP(hipEventElapsedTime(&a, s->comm_events[4 * k], s->comm_events[4 * k + 1]));
-        PFEM_HIP(hipEventElapsedTime(&b, s->comm_events[4 * k + 2], s->comm_events[4 * k + 3]));
-        s->tm.iface_ms_total += a;
-        s->tm.scalar_ms_total += b;
+    for (size_t k = 0; k < std::min(comm_used / 8, live); ++k) {     // same sampled iterations as the SpMV pairs
+        hipEvent_t *c = &s->comm_events[8 * k];
+        float x = 0.f, a1 = 0.f, a2 = 0.f, w = 0.f;
+        PFEM_HIP(hipEventElapsedTime(&x, c[0], c[1]));
+        PFEM_HIP(hipEventElapsedTime(&a1, c[2], c[3]));
+        PFEM_HIP(hipEventElapsedTime(&a2, c[4], c[5]));
+        PFEM_HIP(hipEventElapsedTime(&w, c[6], c[7]));
+        s->tm.iface_ms_total += x;
+        s->tm.scalar_ms_total += a1 + a2;
+        s->tm.exposed_ms_total += w + a2;          // the second all-reduce sits between two dependent kernels: fully exposed
         ++s->tm.comm_samples;
     }
     return PFEM_OK;

@@ -342,6 +342,53 @@ extern "C" int pfem_find_ghosts(int64_t count, const int32_t *edof, int64_t row_
     return PFEM_OK;
 }
 
+// Neighbour plan (include/pfem_amd.h, section 5).  local(r) = owned block of r + ghost list of r; rank q is a peer of
+// `rank` when local(rank) and local(q) intersect, and the shared list is that intersection, ascending:
+//   { g in ghost(q)    : g owned by rank or g in ghost(rank) }  +  { g in ghost(rank) : g owned by q }
+// (the owned blocks are disjoint, so these are all the cases).  Both sides of a pair arrive at the same list.
+// Replaces the VecScatter setup PETSc derives from the matrix's off-diagonal columns (solverpetsc.F:447-450).
+extern "C" int pfem_neighbour_plan(int nranks, int rank, const int64_t *row_start, const int64_t *row_end,
+                                   const int64_t *ghost_off, const int64_t *ghost_gid, int *n_peers, int64_t *n_total,
+                                   int *peers, int64_t *peer_off, int64_t *shared_gid)
+{
+    if (nranks < 1 || rank < 0 || rank >= nranks || !row_start || !row_end || !ghost_off || !n_peers || !n_total ||
+        (ghost_off[nranks] > 0 && !ghost_gid))
+        return PFEM_ERR_ARG;
+    for (int r = 0; r < nranks; ++r) {
+        if (row_start[r] > row_end[r] || ghost_off[r] > ghost_off[r + 1]) return PFEM_ERR_ARG;
+        for (int64_t k = ghost_off[r] + 1; k < ghost_off[r + 1]; ++k)
+            if (ghost_gid[k - 1] >= ghost_gid[k]) return PFEM_ERR_ARG;           // ascending, unique
+    }
+    const int64_t *mine = ghost_gid + ghost_off[rank], *mine_end = ghost_gid + ghost_off[rank + 1];
+    const int64_t lo = row_start[rank], hi = row_end[rank];
+    int np = 0;
+    int64_t total = 0;
+    if (peer_off) peer_off[0] = 0;
+    std::vector<int64_t> sh;
+    for (int q = 0; q < nranks; ++q) {
+        if (q == rank) continue;
+        sh.clear();
+        for (int64_t k = ghost_off[q]; k < ghost_off[q + 1]; ++k) {
+            const int64_t g = ghost_gid[k];
+            if ((g >= lo && g < hi) || std::binary_search(mine, mine_end, g)) sh.push_back(g);
+        }
+        for (const int64_t *g = mine; g != mine_end; ++g)
+            if (*g >= row_start[q] && *g < row_end[q]) sh.push_back(*g);
+        if (sh.empty()) continue;
+        std::sort(sh.begin(), sh.end());        // the two parts are disjoint (a ghost of q is not owned by q)
+        if (peers) {
+            peers[np] = q;
+            std::copy(sh.begin(), sh.end(), shared_gid + total);
+            peer_off[np + 1] = total + static_cast<int64_t>(sh.size());
+        }
+        total += static_cast<int64_t>(sh.size());
+        ++np;
+    }
+    *n_peers = np;
+    *n_total = total;
+    return PFEM_OK;
+}
+
 // ---------------------------------------------------------------------------
 // 5. output step (after the path): legacy ASCII VTK, byte-compatible with writervtk.F:33-201
 // ---------------------------------------------------------------------------

@@ -926,6 +926,18 @@ __global__ void __launch_bounds__(kBlock) k_invert(double *d, int64_t n)
 // With WITH_DOT the kernel also emits the per-block partial of x.y over rows < n_dot
 // (CG's (p, Ap)); k_reduce_partials turns the partials into one scalar, in fixed order.
 // ---------------------------------------------------------------------------
+// Which slices a SpMV launch works on: all of them in order (list == nullptr), or the `count` slices named in
+// `list` (multi-GPU: the slices that hold shared rows run first, the interior ones under the neighbour exchange).
+struct SliceSel {
+    const int32_t *list;
+    int64_t count;
+};
+__device__ inline int64_t pick_slice(const SliceSel &sel, int64_t idx, int64_t n_all)
+{
+    if (!sel.list) return idx;
+    return idx < sel.count ? static_cast<int64_t>(sel.list[idx]) : n_all;
+}
+
 struct CgCtl {            // device-resident control block of the CG iteration
     double beta[2];       // (r,z) ping-pong by iteration parity
     double rn0, ttol;     // ||z0||, max(rtol*rn0, abstol)
@@ -958,12 +970,12 @@ __device__ inline bool ctl_finished_before(const CgCtl *ctl, int it)
 
 template <bool WITH_DOT>
 __global__ void __launch_bounds__(kBlock) k_spmv(SellDev A, const double *__restrict__ x, double *__restrict__ y,
-                                                  int64_t n_dot, double *partial, const CgCtl *ctl)
+                                                  int64_t n_dot, double *partial, const CgCtl *ctl, SliceSel sel)
 {
     __shared__ double sm[4];
     if (WITH_DOT && ctl->flag != 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t s = (static_cast<int64_t>(blockIdx.x) << 2) + wave;
+    const int64_t s = pick_slice(sel, (static_cast<int64_t>(blockIdx.x) << 2) + wave, A.n_slices);
     double dot = 0.0;
     if (s < A.n_slices) {
         const int64_t off = A.slice_off[s];
@@ -1089,12 +1101,12 @@ __device__ __forceinline__ void spmv16_trip(const double *__restrict__ vp, const
 template <bool WITH_DOT>
 __global__ void __launch_bounds__(kBlock) k_spmv16(SellDev A, Sell16Dev C, const double *__restrict__ x,
                                                     double *__restrict__ y, int64_t n_dot, double *partial,
-                                                    const CgCtl *ctl)
+                                                    const CgCtl *ctl, SliceSel sel)
 {
     __shared__ double sm[4];
     if (WITH_DOT && ctl->flag != 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t s = (static_cast<int64_t>(blockIdx.x) << 2) + wave;
+    const int64_t s = pick_slice(sel, (static_cast<int64_t>(blockIdx.x) << 2) + wave, A.n_slices);
     double dot = 0.0;
     if (s < A.n_slices) {
         const int64_t off = A.slice_off[s];
@@ -1275,12 +1287,13 @@ __device__ __forceinline__ void spmvg_trip(const double *__restrict__ vp, const 
 
 template <bool WITH_DOT>
 __global__ void __launch_bounds__(kBlock) k_spmvg(SellGDev G, int64_t n_rows, const double *__restrict__ x,
-                                                   double *__restrict__ y, int64_t n_dot, double *partial, const CgCtl *ctl)
+                                                   double *__restrict__ y, int64_t n_dot, double *partial, const CgCtl *ctl,
+                                                   SliceSel sel)
 {
     __shared__ double sm[4];
     if (WITH_DOT && ctl->flag != 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t gs = (static_cast<int64_t>(blockIdx.x) << 2) + wave;
+    const int64_t gs = pick_slice(sel, (static_cast<int64_t>(blockIdx.x) << 2) + wave, G.n_gslices);
     double dot = 0.0;
     if (gs < G.n_gslices) {
         const int64_t off = G.gslice_off[gs];
@@ -1656,12 +1669,13 @@ __device__ __forceinline__ void load_x4(const double *__restrict__ x, int c, dou
 
 template <bool WITH_DOT>
 __global__ void __launch_bounds__(kBlock) k_spmvr(SellRDev G, int64_t n_rows, const double *__restrict__ x,
-                                                   double *__restrict__ y, int64_t n_dot, double *partial, const CgCtl *ctl)
+                                                   double *__restrict__ y, int64_t n_dot, double *partial, const CgCtl *ctl,
+                                                   SliceSel sel)
 {
     __shared__ double sm[4];
     if (WITH_DOT && ctl->flag != 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t gs = (static_cast<int64_t>(blockIdx.x) << 2) + wave;
+    const int64_t gs = pick_slice(sel, (static_cast<int64_t>(blockIdx.x) << 2) + wave, G.n_gslices);
     double dot = 0.0;
     if (gs < G.n_gslices) {
         const int64_t off = G.gslice_off[gs];
@@ -1923,32 +1937,57 @@ __global__ void __launch_bounds__(kBlock) k_cg_direction_b(CgCtl *ctl, int it, i
 }
 
 // ---------------------------------------------------------------------------
-// interface exchange (multi-GPU, sub-assembled rows)
+// neighbour exchange (multi-GPU, sub-assembled rows)
 // ---------------------------------------------------------------------------
-// buf[slot] = v[lidx]; the extra block reduces `n_extra` partial arrays into buf[n_iface+j]
-__global__ void __launch_bounds__(kBlock) k_pack(const double *__restrict__ v, const int32_t *__restrict__ lidx,
-                                                  const int32_t *__restrict__ slot, int64_t n_shared, double *buf,
-                                                  int64_t n_iface, const double *part0, const double *part1, int nparts,
-                                                  int n_extra, const CgCtl *ctl)
+// send[i] = v[send_lidx[i]]: the partials of the shared dofs, one segment per neighbour (ascending rank)
+__global__ void __launch_bounds__(kBlock) k_pack_send(const double *__restrict__ v, const int32_t *__restrict__ send_lidx,
+                                                       int64_t n_send, double *__restrict__ send, const CgCtl *ctl)
 {
-    __shared__ double sm[4];
     if (ctl && ctl->flag != 0) return;
-    if (blockIdx.x == gridDim.x - 1) {
-        if (n_extra > 0) { const double a = sum_partials(part0, nparts, sm); if (threadIdx.x == 0) buf[n_iface] = a; }
-        if (n_extra > 1) { const double a = sum_partials(part1, nparts, sm); if (threadIdx.x == 0) buf[n_iface + 1] = a; }
-        return;
-    }
     const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (v && i < n_shared) buf[slot[i]] = v[lidx[i]];
+    if (i < n_send) send[i] = v[send_lidx[i]];
 }
 
-__global__ void __launch_bounds__(kBlock) k_unpack(double *__restrict__ v, const int32_t *__restrict__ lidx,
-                                                    const int32_t *__restrict__ slot, int64_t n_shared, const double *buf,
-                                                    const CgCtl *ctl)
+// v[dof] = sum of the partials of all ranks that hold the dof, ADDED IN ASCENDING RANK ORDER on every rank (floating
+// point addition is not associative: a fixed order gives every rank the same bits, so the replicated ghost entries
+// stay identical).  Contributions of shared dof j: src[ptr[j]..ptr[j+1]), a position in the receive buffer, or -1
+// for this rank's own partial.
+__global__ void __launch_bounds__(kBlock) k_unpack_sum(double *__restrict__ v, const int32_t *__restrict__ sh_lidx,
+                                                        const int32_t *__restrict__ sh_ptr, const int32_t *__restrict__ sh_src,
+                                                        int64_t n_sh, const double *__restrict__ recv, const CgCtl *ctl)
 {
     if (ctl && ctl->flag != 0) return;
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (i < n_shared) v[lidx[i]] = buf[slot[i]];
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (j >= n_sh) return;
+    const int32_t l = sh_lidx[j];
+    const double own = v[l];
+    double acc = 0.0;
+    for (int32_t k = sh_ptr[j]; k < sh_ptr[j + 1]; ++k) {
+        const int32_t q = sh_src[k];
+        acc += q < 0 ? own : recv[q];
+    }
+    v[l] = acc;
+}
+
+// slice_flag[slice of row] = 1 for every shared row (rows_per_slice = 64 rows, or 256 for the relative row groups;
+// row_grp != nullptr: the row-grouped form, slice = group / 64 with the group looked up per row)
+__global__ void __launch_bounds__(kBlock) k_mark_boundary_slices(const int32_t *__restrict__ sh_lidx, int64_t n_sh,
+                                                                  int shift, const int32_t *__restrict__ row_group,
+                                                                  char *slice_flag)
+{
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (j >= n_sh) return;
+    const int64_t r = sh_lidx[j];
+    const int64_t unit = row_group ? static_cast<int64_t>(row_group[r]) : r;
+    slice_flag[unit >> shift] = 1;
+}
+
+// row -> index of its group (k_spmvg's lanes), from the group start rows
+__global__ void __launch_bounds__(kBlock) k_row_group_index(const int32_t *group_row0, int64_t n_groups, int32_t *row_group)
+{
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (g >= n_groups) return;
+    for (int32_t r = group_row0[g]; r < group_row0[g + 1]; ++r) row_group[r] = static_cast<int32_t>(g);
 }
 
 }  // namespace pfem

@@ -5,33 +5,24 @@ halo) and ``VecDot`` (MPI_Allreduce) for the reference (solverpetsc.F:447-476):
 
 * every rank assembles ONLY its own elements (``elem_proc_id == rank``,
   tetrapoissonparallelimpl1.F:829) into a local matrix over owned + ghost rows;
-* rows of interface dofs are therefore partial sums; each SpMV is followed by ONE
-  all-reduce of a packed interface vector (``n_iface_global`` doubles + the (p,Ap) scalar), and
-  the two remaining CG scalars ride in a second 2-double all-reduce;
-* the collective is supplied to the C library as a hook.  Here it is bound to
-  ``torch.distributed`` (backend "nccl" == RCCL over xGMI on the GPU box; "gloo" in the CPU
-  tests), operating in place on a device tensor that the library uses as exchange buffer.
+* rows of dofs that another rank also holds are therefore partial sums; every SpMV is followed by a
+  NEIGHBOUR exchange of those partials (each rank adds them in ascending rank order), overlapped with
+  the interior part of the SpMV, and the CG scalars ride in two small all-reduces;
+* transport: RCCL over xGMI, bound inside the C++ library (``pfem_solver_set_comm_rccl``) -- this
+  module only carries the 128-byte unique id from rank 0 to the others; or host hooks over a
+  ``torch.distributed`` group that works on host memory (gloo: the tests where ranks share a GPU).
 
-The interface plan (which dofs are shared, and their slot in the packed vector) is pure integer
-host logic and is what the world_size-2 gloo tests pin.
+The neighbour plan is pure integer host logic (``pfem_neighbour_plan``) and is what the world_size-2/3
+gloo tests pin on CPU.
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 
-
-def interface_plan(ghost_lists, row_ranges, rank):
-    """``ghost_lists[r]`` = ascending global dof ids rank r touches but does not own;
-    ``row_ranges[r] = (row_start, row_end)``.  Returns (shared_gid, shared_slot, n_iface_global)
-    for ``rank``: the interface is the union of all ghost lists, numbered ascending."""
-    iface = np.unique(np.concatenate([np.asarray(g, dtype=np.int64) for g in ghost_lists] + [np.empty(0, np.int64)]))
-    lo, hi = row_ranges[rank]
-    mine = np.asarray(ghost_lists[rank], dtype=np.int64)
-    touched = np.zeros(len(iface), bool)
-    touched |= (iface >= lo) & (iface < hi)                       # interface dofs this rank owns
-    touched[np.searchsorted(iface, mine)] = True                  # and its own ghosts
-    slots = np.nonzero(touched)[0].astype(np.int32)
-    return iface[slots], slots, int(len(iface))
+from . import host as H
+from .solver import rccl_unique_id
 
 
 def gather_ghost_lists(ghosts, dist):
@@ -41,84 +32,74 @@ def gather_ghost_lists(ghosts, dist):
     return out
 
 
-class TorchAllReduce:
-    """The all-reduce hook bound to torch.distributed on a torch-owned exchange tensor."""
-
-    def __init__(self, dist, xbuf):
-        self.dist = dist
-        self.xbuf = xbuf                         # 1-D float64 tensor on the solver's device
-        self.base = xbuf.data_ptr()
-        self.calls = 0
-        self.error = None
-
-    def __call__(self, ctx, buf, count, stream):
-        try:
-            off = (int(buf) - self.base) // 8
-            self.dist.all_reduce(self.xbuf[off:off + int(count)])    # SUM, in place, current stream
-            self.calls += 1
-            return 0
-        except Exception as e:   # never let an exception cross the C boundary
-            self.error = e
-            return 1
-
-
-class HostStagedAllReduce:
-    """The all-reduce hook for process groups that work on HOST memory (gloo): stream-sync, device -> host,
-    reduce to rank 0 + broadcast (every rank receives the same bits, whatever the group's all-reduce
-    algorithm), host -> device.  What pfemfort_amd/fortran/pfem_mpi.cpp does with MPI; used where several
-    ranks share one GPU (RCCL refuses two ranks on a device)."""
-
-    def __init__(self, dist, torch, xbuf, stream):
-        self.dist, self.torch = dist, torch
-        self.xbuf = xbuf
-        self.base = xbuf.data_ptr()
-        self.stream = stream                     # torch.cuda.Stream the solver was given
-        self.calls = 0
-        self.error = None
-        self.log = None                          # optional list of (call#, count) for call-sequence checks
-
-    def __call__(self, ctx, buf, count, stream):
-        try:
-            off = (int(buf) - self.base) // 8
-            view = self.xbuf[off:off + int(count)]
-            with self.torch.cuda.stream(self.stream):
-                self.stream.synchronize()
-                host = view.cpu()
-                self.dist.reduce(host, 0)
-                self.dist.broadcast(host, 0)
-                view.copy_(host)
-                self.stream.synchronize()
-            self.calls += 1
-            if self.log is not None:
-                self.log.append((self.calls, int(count)))
-            return 0
-        except Exception as e:   # never let an exception cross the C boundary
-            self.error = e
-            return 1
-
-
-def attach(solver, dist, torch, device, staged=False):
-    """Wire a solver that already holds its mesh to the process group: exchanges the ghost
-    lists, installs the interface plan, the exchange buffer and the all-reduce hook.
-    ``staged``: the group reduces host memory (gloo) -- the hook stages the exchange buffer through the host."""
+def plan_for(solver, dist):
+    """Exchange ghost lists and row blocks, derive this rank's neighbour plan."""
     rank, world = dist.get_rank(), dist.get_world_size()
-    ghosts = solver.ghosts()
-    lists = gather_ghost_lists(ghosts, dist)
+    lists = gather_ghost_lists(solver.ghosts(), dist)
     ranges = [None] * world
     dist.all_gather_object(ranges, (solver.row_start, solver.row_start + solver.size_local))
-    gid, slot, n_iface = interface_plan(lists, ranges, rank)
-    xbuf = torch.zeros(n_iface + 4, dtype=torch.float64, device=device)
+    return H.neighbour_plan(rank, ranges, lists)
+
+
+class HostHooks:
+    """Host-memory hooks over a ``torch.distributed`` group (gloo).  The all-reduce is reduce-to-rank-0 +
+    broadcast, so that every rank receives the same bits whatever algorithm the group would pick."""
+
+    def __init__(self, dist, torch):
+        self.dist, self.torch = dist, torch
+        self.calls = 0               # hook calls (all-reduces + exchanges)
+        self.error = None
+        self.log = None              # optional list of ("a"|"x", count) for call-sequence checks
+
+    def allreduce(self, ctx, buf, count):
+        try:
+            a = np.ctypeslib.as_array(buf, shape=(int(count),))
+            t = self.torch.from_numpy(a)
+            self.dist.reduce(t, 0)
+            self.dist.broadcast(t, 0)
+            self.calls += 1
+            if self.log is not None:
+                self.log.append(("a", int(count)))
+            return 0
+        except Exception as e:   # never let an exception cross the C boundary
+            self.error = e
+            return 1
+
+    def exchange(self, ctx, n_peers, peers, off, send, recv):
+        try:
+            n = int(off[n_peers])
+            s = self.torch.from_numpy(np.ctypeslib.as_array(send, shape=(n,)))
+            r = self.torch.from_numpy(np.ctypeslib.as_array(recv, shape=(n,)))
+            reqs = []
+            for k in range(n_peers):
+                lo, hi, q = int(off[k]), int(off[k + 1]), int(peers[k])
+                reqs.append(self.dist.isend(s[lo:hi], q))
+                reqs.append(self.dist.irecv(r[lo:hi], q))
+            for w in reqs:
+                w.wait()
+            self.calls += 1
+            if self.log is not None:
+                self.log.append(("x", n))
+            return 0
+        except Exception as e:
+            self.error = e
+            return 1
+
+
+def attach(solver, dist, torch=None, staged=False):
+    """Wire a solver that already holds its mesh (or, compat path, its pattern) to the process group: neighbour
+    plan + communication backend.  ``staged=False``: RCCL inside the library (one rank per GPU).
+    ``staged=True``: host hooks over the group (gloo; several ranks may share a GPU).  Returns the HostHooks
+    object (staged) or None."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    peers, off, gid = plan_for(solver, dist)
+    solver.setNeighbours(peers, off, gid)
     if staged:
-        stream = torch.cuda.Stream(device)
-        hook = HostStagedAllReduce(dist, torch, xbuf, stream)
-        solver.setStream(stream.cuda_stream)
-        solver._keep.append(stream)
-    else:
-        hook = TorchAllReduce(dist, xbuf)
-        if device.type == "cuda":
-            solver.setStream(torch.cuda.current_stream(device).cuda_stream)
-    solver.setExchangeBuffer(xbuf.data_ptr(), n_iface + 4)
-    solver.setInterface(gid, slot, n_iface)
-    solver.setComm(rank, world, hook)
-    solver._keep.extend([xbuf, hook])
-    return hook, n_iface
+        hooks = HostHooks(dist, torch)
+        solver.setCommHost(rank, world, hooks.allreduce, hooks.exchange)
+        solver._keep.append(hooks)
+        return hooks
+    ids = [rccl_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    solver.setCommRccl(rank, world, ids[0])
+    return None

@@ -181,7 +181,7 @@ def run_parallel(kind, mesh: H.Mesh, elem_proc_id, node_proc_id, dist, torch, el
         solver.setSpmvFormat(spmv)
     timers = {}
     solver.uploadMesh(kind, conn_loc, xyz_new, edof, dm.solnApplied)
-    hook, _ = PD.attach(solver, dist, torch, device, staged=staged)
+    hooks = PD.attach(solver, dist, torch, staged=staged)
     solver.buildPattern()                                                # :786-802
     t0 = time.perf_counter()
     solver.assemble(elemData, timeData)                                  # :817-884
@@ -189,8 +189,8 @@ def run_parallel(kind, mesh: H.Mesh, elem_proc_id, node_proc_id, dist, torch, el
     t0 = time.perf_counter()
     its, reason, rnorm = solver.factoriseAndSolve()                      # :898-902
     timers["solve_s"] = time.perf_counter() - t0
-    if getattr(hook, "error", None) is not None:
-        raise hook.error
+    if hooks is not None and hooks.error is not None:
+        raise hooks.error
     parts = [None] * world                                               # VecScatterCreateToAll (:922-932)
     dist.all_gather_object(parts, (rs, solver.getSolution()))
     u = np.empty(dm.size_global)

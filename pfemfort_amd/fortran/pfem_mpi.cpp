@@ -1,21 +1,24 @@
-// pfem_mpi.cpp -- MPI binding of libpfem_amd's multi-rank hooks, for hosts that are MPI programs
+// pfem_mpi.cpp -- MPI binding of libpfem_amd's multi-rank interface, for hosts that are MPI programs
 // (the reference's Fortran drivers under mpiexec: one MPI rank per GPU, or several ranks sharing one).
 //
 // Does for an MPI host what pfemfort_amd/distributed.py does for a torch.distributed host:
-//   * gathers every rank's ghost dof list and derives the interface plan (which dofs are shared, and
-//     their slot in the packed global interface vector) -- same rule as distributed.interface_plan;
-//   * installs an all-reduce hook (include/pfem_amd.h: pfem_allreduce_fn).  The hook stages the
-//     device buffer through the host and uses MPI_Reduce + MPI_Bcast rather than MPI_Allreduce: the
-//     solver keeps replicated ghost rows and takes its convergence decisions on every rank from the
-//     reduced scalars, so all ranks must receive THE SAME BITS, which MPI_Allreduce does not promise.
-// Replaces, for the reference, PETSc's MatAssemblyEnd stash exchange, the VecScatter inside MatMult
-// and the MPI_Allreduce inside VecDot (solverpetsc.F:447-476), and VecScatterCreateToAll (:922-932).
+//   * gathers every rank's ghost dof list and row block and derives the neighbour plan with the library's own
+//     pfem_neighbour_plan (who shares which dofs with whom);
+//   * installs the HOST communication backend (include/pfem_amd.h: pfem_solver_set_comm_host): the library
+//     stages its packed buffers through pinned memory and calls back here --
+//       exchange : MPI_Isend / MPI_Irecv with every neighbour, MPI_Waitall;
+//       allreduce: MPI_Reduce + MPI_Bcast rather than MPI_Allreduce -- the solver keeps replicated ghost rows and
+//                  takes its convergence decisions on every rank from the reduced scalars, so all ranks must receive
+//                  THE SAME BITS, which MPI_Allreduce does not promise.
+//     (Set PFEM_MPI_RCCL=1 to use RCCL for the transport instead, the unique id travelling by MPI_Bcast: one rank
+//     per GPU only.)
+// Replaces, for the reference, PETSc's MatAssemblyEnd stash exchange, the VecScatter inside MatMult and the
+// MPI_Allreduce inside VecDot (solverpetsc.F:447-476), and VecScatterCreateToAll (:922-932).
 #include <mpi.h>
-
-#include <hip/hip_runtime_api.h>
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/pfem_amd.h"
@@ -24,22 +27,34 @@ namespace {
 
 struct Ctx {
     MPI_Comm comm;
-    std::vector<double> host;
+    std::vector<MPI_Request> req;
 };
 
-int allreduce_hook(void *vctx, void *buf, int64_t count, void *stream)
+int allreduce_hook(void *vctx, double *buf, int64_t count)
 {
     Ctx *c = static_cast<Ctx *>(vctx);
     if (count <= 0) return 0;
     if (count > INT32_MAX) return 1;
-    c->host.resize(static_cast<size_t>(count) * 2);
-    double *in = c->host.data(), *out = in + count;
-    if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) return 1;
-    if (hipMemcpy(in, buf, sizeof(double) * count, hipMemcpyDeviceToHost) != hipSuccess) return 1;
-    if (MPI_Reduce(in, out, static_cast<int>(count), MPI_DOUBLE, MPI_SUM, 0, c->comm) != MPI_SUCCESS) return 1;
-    if (MPI_Bcast(out, static_cast<int>(count), MPI_DOUBLE, 0, c->comm) != MPI_SUCCESS) return 1;
-    if (hipMemcpy(buf, out, sizeof(double) * count, hipMemcpyHostToDevice) != hipSuccess) return 1;
+    int rank = 0;
+    MPI_Comm_rank(c->comm, &rank);
+    std::vector<double> out(static_cast<size_t>(count));
+    if (MPI_Reduce(buf, out.data(), static_cast<int>(count), MPI_DOUBLE, MPI_SUM, 0, c->comm) != MPI_SUCCESS) return 1;
+    if (rank == 0) std::copy(out.begin(), out.end(), buf);
+    if (MPI_Bcast(buf, static_cast<int>(count), MPI_DOUBLE, 0, c->comm) != MPI_SUCCESS) return 1;
     return 0;
+}
+
+int exchange_hook(void *vctx, int n_peers, const int *peers, const int64_t *off, const double *send, double *recv)
+{
+    Ctx *c = static_cast<Ctx *>(vctx);
+    c->req.assign(static_cast<size_t>(2 * n_peers), MPI_REQUEST_NULL);
+    for (int k = 0; k < n_peers; ++k) {
+        const int64_t cnt = off[k + 1] - off[k];
+        if (cnt > INT32_MAX) return 1;
+        if (MPI_Irecv(recv + off[k], static_cast<int>(cnt), MPI_DOUBLE, peers[k], 77, c->comm, &c->req[2 * k]) != MPI_SUCCESS) return 1;
+        if (MPI_Isend(send + off[k], static_cast<int>(cnt), MPI_DOUBLE, peers[k], 77, c->comm, &c->req[2 * k + 1]) != MPI_SUCCESS) return 1;
+    }
+    return MPI_Waitall(2 * n_peers, c->req.data(), MPI_STATUSES_IGNORE) == MPI_SUCCESS ? 0 : 1;
 }
 
 }  // namespace
@@ -60,40 +75,46 @@ extern "C" int pfem_mpi_attach(pfem_solver *s, int fcomm, int64_t row_start, int
     if (rc != PFEM_OK) return rc;
     std::vector<int64_t> mine(static_cast<size_t>(ng) + 1);
     if (ng) { rc = pfem_get_ghosts(s, &ng, mine.data()); if (rc != PFEM_OK) return rc; }
-    mine.resize(static_cast<size_t>(ng));
 
-    // every rank's ghost list and owned row range
+    // every rank's ghost list and owned row block
     std::vector<int> counts(world), displs(world);
     const int my_n = static_cast<int>(ng);
     MPI_Allgather(&my_n, 1, MPI_INT, counts.data(), 1, MPI_INT, comm);
-    int64_t total = 0;
-    for (int r = 0; r < world; ++r) { displs[r] = static_cast<int>(total); total += counts[r]; }
-    if (total > INT32_MAX) return PFEM_ERR_ARG;
-    std::vector<int64_t> all(static_cast<size_t>(total) + 1);
+    std::vector<int64_t> ghost_off(static_cast<size_t>(world) + 1, 0);
+    for (int r = 0; r < world; ++r) { displs[r] = static_cast<int>(ghost_off[r]); ghost_off[r + 1] = ghost_off[r] + counts[r]; }
+    if (ghost_off[world] > INT32_MAX) return PFEM_ERR_ARG;
+    std::vector<int64_t> all(static_cast<size_t>(ghost_off[world]) + 1);
     MPI_Allgatherv(mine.data(), my_n, MPI_INT64_T, all.data(), counts.data(), displs.data(), MPI_INT64_T, comm);
-    all.resize(static_cast<size_t>(total));
+    std::vector<int64_t> rs(world), re(world);
+    const int64_t my_rs = row_start, my_re = row_start + size_local;
+    MPI_Allgather(&my_rs, 1, MPI_INT64_T, rs.data(), 1, MPI_INT64_T, comm);
+    MPI_Allgather(&my_re, 1, MPI_INT64_T, re.data(), 1, MPI_INT64_T, comm);
 
-    // interface = union of all ghost lists, numbered ascending (identical on every rank)
-    std::vector<int64_t> iface(all);
-    std::sort(iface.begin(), iface.end());
-    iface.erase(std::unique(iface.begin(), iface.end()), iface.end());
-    // this rank touches: the interface dofs it owns, and its own ghosts
-    std::vector<int64_t> gid;
-    std::vector<int32_t> slot;
-    const int64_t lo = row_start, hi = row_start + size_local;
-    for (size_t k = 0; k < iface.size(); ++k) {
-        const int64_t g = iface[k];
-        const bool owned = g >= lo && g < hi;
-        if (owned || std::binary_search(mine.begin(), mine.end(), g)) {
-            gid.push_back(g);
-            slot.push_back(static_cast<int32_t>(k));
-        }
-    }
-    rc = pfem_solver_set_interface(s, static_cast<int64_t>(gid.size()), gid.data(), slot.data(),
-                                   static_cast<int64_t>(iface.size()));
+    int n_peers = 0;
+    int64_t total = 0;
+    rc = pfem_neighbour_plan(world, rank, rs.data(), re.data(), ghost_off.data(), all.data(), &n_peers, &total, nullptr, nullptr, nullptr);
     if (rc != PFEM_OK) return rc;
+    std::vector<int> peers(static_cast<size_t>(n_peers) + 1);
+    std::vector<int64_t> peer_off(static_cast<size_t>(n_peers) + 1, 0), gid(static_cast<size_t>(total) + 1);
+    if (n_peers) {
+        rc = pfem_neighbour_plan(world, rank, rs.data(), re.data(), ghost_off.data(), all.data(), &n_peers, &total, peers.data(),
+                                 peer_off.data(), gid.data());
+        if (rc != PFEM_OK) return rc;
+    }
+    rc = pfem_solver_set_neighbours(s, n_peers, peers.data(), peer_off.data(), gid.data());
+    if (rc != PFEM_OK) return rc;
+
+    const char *use_rccl = std::getenv("PFEM_MPI_RCCL");
+    if (use_rccl && use_rccl[0] == '1') {
+        char id[PFEM_RCCL_ID_BYTES] = {0};
+        if (rank == 0) { rc = pfem_rccl_unique_id(id); }
+        MPI_Bcast(&rc, 1, MPI_INT, 0, comm);
+        if (rc != PFEM_OK) return rc;
+        MPI_Bcast(id, PFEM_RCCL_ID_BYTES, MPI_BYTE, 0, comm);
+        return pfem_solver_set_comm_rccl(s, rank, world, id);
+    }
     Ctx *ctx = new Ctx{comm, {}};      // lives as long as the process: the solver keeps the pointer
-    return pfem_solver_set_comm(s, rank, world, allreduce_hook, ctx);
+    return pfem_solver_set_comm_host(s, rank, world, allreduce_hook, exchange_hook, ctx);
 }
 
 // VecScatterCreateToAll + VecGetArray: every rank receives the whole solution (size_global doubles)

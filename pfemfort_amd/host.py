@@ -239,6 +239,27 @@ def find_ghosts(edof, row_start, n_owned):
     return g
 
 
+def neighbour_plan(rank, row_ranges, ghost_lists):
+    """The neighbour plan of ``rank`` (include/pfem_amd.h, section 5; host-only integer logic):
+    ``row_ranges[r] = (row_start, row_end)`` and ``ghost_lists[r]`` = ascending global ghost dof ids of rank r.
+    Returns (peers int32[n], peer_off int64[n+1], shared_gid int64[peer_off[-1]])."""
+    world = len(row_ranges)
+    rs = np.ascontiguousarray([r[0] for r in row_ranges], dtype=np.int64)
+    re = np.ascontiguousarray([r[1] for r in row_ranges], dtype=np.int64)
+    lists = [np.ascontiguousarray(g, dtype=np.int64) for g in ghost_lists]
+    off = np.zeros(world + 1, np.int64)
+    off[1:] = np.cumsum([len(g) for g in lists])
+    allg = np.ascontiguousarray(np.concatenate(lists + [np.empty(0, np.int64)]))
+    npeers = C.c_int(0); total = C.c_int64(0)
+    L.check(L.lib().pfem_neighbour_plan(world, rank, _p(rs), _p(re), _p(off), _p(allg), C.byref(npeers), C.byref(total),
+                                        None, None, None), "pfem_neighbour_plan")
+    peers = np.zeros(npeers.value, np.int32); poff = np.zeros(npeers.value + 1, np.int64); gid = np.zeros(total.value, np.int64)
+    if npeers.value:
+        L.check(L.lib().pfem_neighbour_plan(world, rank, _p(rs), _p(re), _p(off), _p(allg), C.byref(npeers), C.byref(total),
+                                            _p(peers), _p(poff), _p(gid)), "pfem_neighbour_plan")
+    return peers, poff, gid
+
+
 def writeoutputvtk(ndim, coords, elemNodeConn, elem_procid, soln, fileName, ndof=None):
     """MODULE WriterVTK: writeoutputvtk (writervtk.F:33).  ``coords (ndim,nNode)``, ``elemNodeConn
     (npElem,nElem)`` 0-based, ``soln (nNode, ndof)`` or flat by node id."""

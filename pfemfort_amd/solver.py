@@ -251,16 +251,38 @@ class PetscSolver:
         L.check(L.lib().pfem_get_ghosts(self._h, C.byref(n), _p(g)), "pfem_get_ghosts")
         return g
 
-    def setComm(self, rank, nranks, allreduce_cb):
-        cb = L.ALLREDUCE_FN(allreduce_cb) if allreduce_cb is not None else L.ALLREDUCE_FN()
-        self._keep.append(cb)
-        L.check(L.lib().pfem_solver_set_comm(self._h, rank, nranks, cb, None), "pfem_solver_set_comm")
+    def setNeighbours(self, peers, peer_off, shared_gid):
+        """Install the neighbour plan (``host.neighbour_plan``)."""
+        pe = _i32(peers); off = np.ascontiguousarray(peer_off, dtype=np.int64); g = np.ascontiguousarray(shared_gid, dtype=np.int64)
+        L.check(L.lib().pfem_solver_set_neighbours(self._h, len(pe), _p(pe), _p(off), _p(g)), "pfem_solver_set_neighbours")
 
-    def setInterface(self, shared_gid, shared_slot, n_iface_global):
-        g = np.ascontiguousarray(shared_gid, dtype=np.int64); sl = _i32(shared_slot)
-        L.check(L.lib().pfem_solver_set_interface(self._h, len(g), _p(g), _p(sl), n_iface_global),
-                "pfem_solver_set_interface")
+    def setCommRccl(self, rank, nranks, unique_id: bytes):
+        """RCCL bound inside the library; ``unique_id`` = the 128 bytes of ``rccl_unique_id()`` from rank 0."""
+        assert len(unique_id) == L.RCCL_ID_BYTES
+        buf = C.create_string_buffer(bytes(unique_id), L.RCCL_ID_BYTES)
+        L.check(L.lib().pfem_solver_set_comm_rccl(self._h, rank, nranks, buf), "pfem_solver_set_comm_rccl")
 
-    def setExchangeBuffer(self, device_ptr, capacity):
-        L.check(L.lib().pfem_solver_set_exchange_buffer(self._h, C.c_void_p(device_ptr), capacity),
-                "pfem_solver_set_exchange_buffer")
+    def setCommHost(self, rank, nranks, allreduce_cb, exchange_cb):
+        """Host-memory hooks (gloo, MPI): ``allreduce_cb(ctx, buf, count)``, ``exchange_cb(ctx, n, peers, off, send, recv)``."""
+        a = L.HOST_ALLREDUCE_FN(allreduce_cb) if allreduce_cb is not None else L.HOST_ALLREDUCE_FN()
+        e = L.HOST_EXCHANGE_FN(exchange_cb) if exchange_cb is not None else L.HOST_EXCHANGE_FN()
+        self._keep.extend([a, e])
+        L.check(L.lib().pfem_solver_set_comm_host(self._h, rank, nranks, a, e, None), "pfem_solver_set_comm_host")
+
+    def commSelftest(self, count=1000):
+        """Collective transport check (stamped exchange with every other rank + a known all-reduce): wrong entries."""
+        bad = C.c_int64(0)
+        L.check(L.lib().pfem_solver_comm_selftest(self._h, count, C.byref(bad)), "pfem_solver_comm_selftest")
+        return bad.value
+
+    def commInfo(self):
+        npe = C.c_int(0); d = C.c_int64(0); b = C.c_int64(0); t = C.c_int64(0)
+        L.check(L.lib().pfem_solver_comm_info(self._h, C.byref(npe), C.byref(d), C.byref(b), C.byref(t)), "pfem_solver_comm_info")
+        return {"n_peers": npe.value, "doubles_per_exchange": d.value, "boundary_slices": b.value, "total_slices": t.value}
+
+
+def rccl_unique_id() -> bytes:
+    """ncclGetUniqueId through the library (rank 0 calls it and broadcasts the bytes)."""
+    buf = C.create_string_buffer(L.RCCL_ID_BYTES)
+    L.check(L.lib().pfem_rccl_unique_id(buf), "pfem_rccl_unique_id")
+    return buf.raw
