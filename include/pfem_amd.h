@@ -329,7 +329,7 @@ int pfem_neighbour_plan(int nranks, int rank, const int64_t *row_start, const in
                         const int64_t *ghost_off, const int64_t *ghost_gid, int *n_peers, int64_t *n_total,
                         int *peers, int64_t *peer_off, int64_t *shared_gid);
 /* install the plan (after pfem_mesh_upload, or after the first setZero of the compat path: the local numbering
- * must exist).  n_peers == 0 is legal (a rank that shares nothing still takes part in the scalar all-reduces).   */
+ * must exist; and after the communication backend, which tells the solver its rank).  n_peers == 0 is legal (a rank that shares nothing still takes part in the scalar all-reduces).   */
 int pfem_solver_set_neighbours(pfem_solver *s, int n_peers, const int *peers, const int64_t *peer_off,
                                const int64_t *shared_gid);
 /* Communication backend 1 -- RCCL over xGMI, bound inside the library (librccl is loaded at run time; nothing else

@@ -1544,6 +1544,10 @@ extern "C" int pfem_solver_set_neighbours(pfem_solver *s, int n_peers, const int
 {
     if (!s || n_peers < 0 || (n_peers && (!peers || !peer_off || !shared_gid))) return PFEM_ERR_ARG;
     if (!s->have_mesh && !s->have_pattern) return PFEM_ERR_STATE;   // local numbering must exist
+    if (!s->comm) {
+        set_last_error("pfem_solver_set_neighbours: set the communication backend first (it tells the solver its rank)");
+        return PFEM_ERR_STATE;
+    }
     PFEM_TRY(use_device(s));
     const int64_t total = n_peers ? peer_off[n_peers] : 0;
     if (total > INT32_MAX) return PFEM_ERR_ARG;

@@ -93,13 +93,14 @@ def attach(solver, dist, torch=None, staged=False):
     object (staged) or None."""
     rank, world = dist.get_rank(), dist.get_world_size()
     peers, off, gid = plan_for(solver, dist)
-    solver.setNeighbours(peers, off, gid)
+    hooks = None
     if staged:
         hooks = HostHooks(dist, torch)
         solver.setCommHost(rank, world, hooks.allreduce, hooks.exchange)
         solver._keep.append(hooks)
-        return hooks
-    ids = [rccl_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(ids, src=0)
-    solver.setCommRccl(rank, world, ids[0])
-    return None
+    else:
+        ids = [rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        solver.setCommRccl(rank, world, ids[0])
+    solver.setNeighbours(peers, off, gid)
+    return hooks

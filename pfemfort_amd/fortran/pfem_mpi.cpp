@@ -101,9 +101,6 @@ extern "C" int pfem_mpi_attach(pfem_solver *s, int fcomm, int64_t row_start, int
                                  peer_off.data(), gid.data());
         if (rc != PFEM_OK) return rc;
     }
-    rc = pfem_solver_set_neighbours(s, n_peers, peers.data(), peer_off.data(), gid.data());
-    if (rc != PFEM_OK) return rc;
-
     const char *use_rccl = std::getenv("PFEM_MPI_RCCL");
     if (use_rccl && use_rccl[0] == '1') {
         char id[PFEM_RCCL_ID_BYTES] = {0};
@@ -111,10 +108,13 @@ extern "C" int pfem_mpi_attach(pfem_solver *s, int fcomm, int64_t row_start, int
         MPI_Bcast(&rc, 1, MPI_INT, 0, comm);
         if (rc != PFEM_OK) return rc;
         MPI_Bcast(id, PFEM_RCCL_ID_BYTES, MPI_BYTE, 0, comm);
-        return pfem_solver_set_comm_rccl(s, rank, world, id);
+        rc = pfem_solver_set_comm_rccl(s, rank, world, id);
+    } else {
+        Ctx *ctx = new Ctx{comm, {}};      // lives as long as the process: the solver keeps the pointer
+        rc = pfem_solver_set_comm_host(s, rank, world, allreduce_hook, exchange_hook, ctx);
     }
-    Ctx *ctx = new Ctx{comm, {}};      // lives as long as the process: the solver keeps the pointer
-    return pfem_solver_set_comm_host(s, rank, world, allreduce_hook, exchange_hook, ctx);
+    if (rc != PFEM_OK) return rc;
+    return pfem_solver_set_neighbours(s, n_peers, peers.data(), peer_off.data(), gid.data());
 }
 
 // VecScatterCreateToAll + VecGetArray: every rank receives the whole solution (size_global doubles)
