@@ -546,16 +546,21 @@ int orc_csr_pattern(int64_t nElem, int nsize, const int32_t *edof, int64_t N,
                 if (col >= 0) keys[start[row] + cnt[row]++] = col;
             }
         }
-    rowptr[0] = 0;
+    /* sort + unique every row's candidates (rows are independent: threaded), then the row pointers, then the copy */
+#pragma omp parallel for schedule(dynamic, 4096) private(k) if (N > 100000)
     for (r = 0; r < N; ++r) {
         int64_t *seg = keys + start[r], n = cnt[r], u = 0;
         qsort(seg, (size_t)n, sizeof *seg, cmp_i64);
         for (k = 0; k < n; ++k)
-            if (k == 0 || seg[k] != seg[k - 1]) {
-                if (cols) cols[rowptr[r] + u] = (int32_t)seg[k];
-                ++u;
-            }
-        rowptr[r + 1] = rowptr[r] + u;
+            if (k == 0 || seg[k] != seg[k - 1]) seg[u++] = seg[k];
+        cnt[r] = u;
+    }
+    rowptr[0] = 0;
+    for (r = 0; r < N; ++r) rowptr[r + 1] = rowptr[r] + cnt[r];
+    if (cols) {
+#pragma omp parallel for schedule(static) private(k) if (N > 100000)
+        for (r = 0; r < N; ++r)
+            for (k = 0; k < cnt[r]; ++k) cols[rowptr[r] + k] = (int32_t)keys[start[r] + k];
     }
     free(keys);  free(start);  free(cnt);
     return ORC_OK;

@@ -33,7 +33,14 @@ subroutine PetscInitialize(file, ierr)
       case ("-ksp_atol");   read(val, *, iostat=io) pfem_opt_atol
       case ("-ksp_divtol"); read(val, *, iostat=io) pfem_opt_dtol
       case ("-ksp_max_it"); read(val, *, iostat=io) pfem_opt_maxits
-      case ("-pc_type");    if (trim(val) == "pbjacobi") pfem_opt_pc = 1
+      case ("-pc_type");    call pfem_set_pc_type(trim(val))
+      case ("-ksp_type")
+        if (trim(val) /= "cg") then        ! the reference hard-wires KSPCG (solverpetsc.F:187); nothing else is built
+          write(*,*) "pfem_amd: -ksp_type ", trim(val), " is not available (only cg, as the reference sets)"
+          stop " Aborting... unsupported -ksp_type"
+        end if
+      case default
+        write(*,*) "pfem_amd: option ", trim(key), " in ", trim(file), " is not understood and is IGNORED"
       end select
     end do
     close(97)
@@ -43,8 +50,22 @@ subroutine PetscInitialize(file, ierr)
   call get_environment_variable("PFEM_KSP_MAX_IT", val, status=io)
   if (io == 0 .and. len_trim(val) > 0) read(val, *, iostat=io) pfem_opt_maxits
   call get_environment_variable("PFEM_PC_TYPE", val, status=io)
-  if (io == 0 .and. trim(val) == "pbjacobi") pfem_opt_pc = 1
+  if (io == 0 .and. len_trim(val) > 0) call pfem_set_pc_type(trim(val))
 end subroutine PetscInitialize
+
+! -pc_type: what this library has.  Anything else stops loudly instead of silently running another solve.
+subroutine pfem_set_pc_type(val)
+  use petscvec
+  implicit none
+  character(len=*) :: val
+  select case (val)
+  case ("jacobi");   pfem_opt_pc = 0
+  case ("pbjacobi"); pfem_opt_pc = 1
+  case default
+    write(*,*) "pfem_amd: -pc_type ", val, " is not available (jacobi, pbjacobi)"
+    stop " Aborting... unsupported -pc_type"
+  end select
+end subroutine pfem_set_pc_type
 
 subroutine PetscFinalize(ierr)
   implicit none

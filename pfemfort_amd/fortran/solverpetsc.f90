@@ -61,6 +61,19 @@ contains
     ierr = pfem_mpi_pick_device(PETSC_COMM_WORLD, dev)
     if (ierr /= 0) call pfem_chkerr(ierr)
 #endif
+    me = 0
+#ifdef PFEM_WITH_MPI
+    call MPI_Comm_rank(PETSC_COMM_WORLD, me, ierr)
+#endif
+    ! one loud line: the reference sets KSPCG + PCBJACOBI (per-rank ILU(0)) at solverpetsc.F:187,206; this library runs
+    ! CG with the preconditioner named here, so iteration counts are not those of the reference's PETSc run
+    if (me == 0) then
+      if (pfem_opt_pc == 1) then
+        write(*,*) " pfem_amd: KSP = cg, PC = pbjacobi (node-block Jacobi) on the GPU; the reference's PCBJACOBI/ILU(0) is not reproduced"
+      else
+        write(*,*) " pfem_amd: KSP = cg, PC = jacobi on the GPU; the reference's PCBJACOBI/ILU(0) is not reproduced"
+      end if
+    end if
     this%row_start = rs
     this%size_local = size_local
     this%attached = .false.

@@ -13,7 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # tests, and every test that starts other processes (ranks sharing the device, mpiexec, bench.py) last,
 # so that a problem in the multi-process plumbing cannot keep a parity test from running.
 _ORDER = ["test_gpu_parity", "test_gpu_full_size", "test_golden_drivers", "test_oracle", "test_host", "test_abi",
-          "test_sanitize", "test_bench_contract", "test_fortran_drivers", "test_distributed"]
+          "test_sanitize", "test_bench_contract", "test_fortran_drivers", "test_fortran_boundary", "test_distributed"]
 
 
 def pytest_configure(config):

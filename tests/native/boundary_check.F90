@@ -1,0 +1,114 @@
+! boundary_check.F90 -- the build's OWN small Fortran host program for the drop-in boundary (test infrastructure).
+!
+! It talks to the library exactly the way a PFEMFort driver does -- the PETSc finclude files and modules, TYPE
+! PetscSolver of Module_SolverPetsc (initialise / setZero / factoriseAndSolve / free), the element modules
+! ElementUtilitiesPoisson / ElementUtilitiesElasticity3D, MatSetValues / VecSetValues with INSERT_VALUES and
+! ADD_VALUES, VecScatterCreateToAll + the legacy VecGetArray(xx_v, xx_i) -- but carries none of a driver's mesh
+! bookkeeping: the prepared problem (coordinates and connectivity in the new numbering, ElemDofArray, element
+! ownership, row blocks) is read from "problem.txt", written by tests/test_fortran_boundary.py.
+! Serial flavour: one process.  MPI flavour (-DPFEM_WITH_MPI, mpiexec -n P): every rank loops over the elements it
+! owns and passes GLOBAL indices, as tetrapoissonparallelimpl1.F:828-884 does.  Rank 0 writes "solution.txt".
+#include <petsc/finclude/petscsysdef.h>
+#include <petsc/finclude/petscvecdef.h>
+#include <petsc/finclude/petscmatdef.h>
+#include <petsc/finclude/petsckspdef.h>
+#include <petsc/finclude/petscpcdef.h>
+program boundary_check
+  use petscvec
+  use petscmat
+  use petscksp
+  use petscpc
+  use Module_SolverPetsc
+  use ElementUtilitiesPoisson
+  use ElementUtilitiesElasticity3D
+  implicit none
+  type(PetscSolver) :: solver
+  PetscErrorCode :: ierr
+  PetscInt :: me, nprocs
+  Vec :: vec_seq
+  VecScatter :: ctx
+  PetscScalar :: xx_v(1)
+  PetscOffset :: xx_i
+  integer :: ndof, nNode, nElem, ntot, nranks_file, nsize, e, a, d, i, j, k, node
+  integer, allocatable :: sizes(:), owner(:), conn(:,:), edof(:,:), rows(:), nnz_d(:), nnz_o(:)
+  double precision, allocatable :: xyz(:,:), applied(:), Kl(:,:), Fl(:), zeroK(:,:), valC(:), valDotC(:)
+  double precision :: xn(4), yn(4), zn(4), elemData(6), timeData(3), fact
+
+  call PetscInitialize("petsc_options.dat", ierr)
+  call MPI_Comm_rank(PETSC_COMM_WORLD, me, ierr)
+  call MPI_Comm_size(PETSC_COMM_WORLD, nprocs, ierr)
+
+  open(11, file="problem.txt", status="old", action="read")
+  read(11, *) ndof, nNode, nElem, ntot, nranks_file
+  if (nranks_file /= nprocs) stop "problem.txt was prepared for another number of ranks"
+  nsize = 4 * ndof
+  allocate(sizes(nprocs), owner(nElem), conn(4, nElem), edof(nsize, nElem), xyz(3, nNode), applied(nNode * ndof))
+  read(11, *) sizes
+  read(11, *) owner
+  read(11, *) xyz
+  read(11, *) conn
+  read(11, *) edof
+  read(11, *) applied
+  read(11, *) elemData
+  close(11)
+  timeData = (/ 0.0d0, 1.0d0, 0.0d0 /)
+
+  allocate(nnz_d(max(sizes(me + 1), 1)), nnz_o(max(sizes(me + 1), 1)))
+  nnz_d = 50; nnz_o = 25
+  call solver%initialise(sizes(me + 1), ntot, nnz_d, nnz_o)
+
+  allocate(rows(nsize), Kl(nsize, nsize), Fl(nsize), zeroK(nsize, nsize), valC(nsize), valDotC(nsize))
+  zeroK = 0.0d0; valC = 0.0d0; valDotC = 0.0d0
+
+  ! the pattern: zeros with INSERT_VALUES for every element this rank owns
+  do e = 1, nElem
+    if (owner(e) /= me) cycle
+    rows = edof(:, e)
+    call MatSetValues(solver%mtx, nsize, rows, nsize, rows, zeroK, INSERT_VALUES, ierr)
+  end do
+  call solver%setZero()
+
+  ! the element loop: element routine, matrix block, lifting of the prescribed values, vector
+  do e = 1, nElem
+    if (owner(e) /= me) cycle
+    do a = 1, 4
+      xn(a) = xyz(1, conn(a, e)); yn(a) = xyz(2, conn(a, e)); zn(a) = xyz(3, conn(a, e))
+    end do
+    if (ndof == 1) then
+      call StiffnessResidualPoissonLinearTetra(xn, yn, zn, elemData, timeData, valC, valDotC, Kl, Fl)
+    else
+      call StiffnessResidualElasticityLinearTetra(xn, yn, zn, elemData, timeData, valC, valDotC, Kl, Fl)
+    end if
+    rows = edof(:, e)
+    call MatSetValues(solver%mtx, nsize, rows, nsize, rows, Kl, ADD_VALUES, ierr)
+    do i = 1, nsize
+      if (rows(i) /= -1) cycle
+      node = conn((i - 1) / ndof + 1, e)
+      d = mod(i - 1, ndof) + 1
+      fact = applied((node - 1) * ndof + d)
+      do j = 1, nsize
+        if (rows(j) /= -1) Fl(j) = Fl(j) - Kl(j, i) * fact
+      end do
+    end do
+    call VecSetValues(solver%rhsVec, nsize, rows, Fl, ADD_VALUES, ierr)
+  end do
+
+  call solver%factoriseAndSolve()
+
+  call VecScatterCreateToAll(solver%solnVec, ctx, vec_seq, ierr)
+  call VecScatterBegin(ctx, solver%solnVec, vec_seq, INSERT_VALUES, SCATTER_FORWARD, ierr)
+  call VecScatterEnd(ctx, solver%solnVec, vec_seq, INSERT_VALUES, SCATTER_FORWARD, ierr)
+  call VecScatterDestroy(ctx, ierr)
+  call VecGetArray(vec_seq, xx_v, xx_i, ierr)
+  if (me == 0) then
+    open(12, file="solution.txt", status="unknown", action="write")
+    write(12, *) solver%its, solver%reason
+    do k = 1, ntot
+      write(12, '(ES25.17)') xx_v(xx_i + k)
+    end do
+    close(12)
+  end if
+  call VecRestoreArray(vec_seq, xx_v, xx_i, ierr)
+  call solver%free()
+  call PetscFinalize(ierr)
+end program boundary_check

@@ -1,12 +1,17 @@
-"""BASELINE.json's full-size configurations on the GPU, checked through size-independent
-properties (the oracle would need minutes at these sizes): closed-form problem sizes,
-the nodally-exact solution u = x^2+y^2+z^2, symmetry of the assembled operator through two SpMVs,
-gather == scatter assembly, run-to-run reproducibility, and the beam's published tip deflection.
+"""BASELINE.json's full-size configurations on the GPU (configs[1] tet100, configs[2] 200^3, configs[3] the beam)
+against the ORACLE at full size -- pattern and gather-assembled K, F bit-exact against the oracle's serial element
+loop (reference order), solution <= 1e-8 of the oracle's threaded Jacobi-PCG at rtol 1e-10 with the iteration count
+within +-1 -- and through size-independent properties: closed-form problem sizes, the nodally-exact
+solution u = x^2+y^2+z^2, symmetry of the assembled operator through two SpMVs, gather == scatter assembly,
+run-to-run reproducibility, and the beam's published tip deflection.
 """
+import os
+
 import numpy as np
 import pytest
 
 import pfemfort_amd as pf
+from oracle import pfem_oracle as O
 from pfemfort_amd import drivers as D
 from pfemfort_amd import host as H
 
@@ -29,9 +34,26 @@ def _solver(kind, mesh, rtol):
     return s, dm, xyz
 
 
+def _oracle_system(kind, mesh, elemData):
+    """The oracle's own path at full size: its generator, numbering, pattern and SERIAL element loop (one thread:
+    every matrix slot receives its contributions in the order of the reference's loop)."""
+    om = O.gen_box_tets(*mesh.box_args)
+    assert np.array_equal(om.xyz, mesh.xyz) and np.array_equal(om.conn, mesh.conn) and np.array_equal(om.bc_val, mesh.bc_val)
+    ndof = O.NDOF[kind]
+    dm = O.dof_numbering(om.nNode, ndof, om.bc_node, om.bc_dof, om.bc_val)
+    edof = O.elem_dof_array(om.conn, dm.NodeDofArrayNew)
+    O.set_threads(max(1, min(os.cpu_count() or 1, 64)))
+    rowptr, cols = O.csr_pattern(edof, dm.size_global)
+    O.set_threads(1)
+    vals, rhs = O.assemble(kind, om.xyz, om.conn, edof, dm.solnApplied, elemData, dm.size_global, rowptr, cols)
+    O.set_threads(max(1, min(os.cpu_count() or 1, 64)))
+    return rowptr, cols, vals, rhs
+
+
 @pytest.mark.parametrize("n,N,nnz", [(100, 970299, 14320447), (200, 7880599, 117260947)])   # configs[1], configs[2]
 def test_poisson_cube_full_size(n, N, nnz):
     mesh = H.gen_box_tets(-1, 1, n, -1, 1, n, -1, 1, n)
+    mesh.box_args = (-1, 1, n, -1, 1, n, -1, 1, n)
     assert mesh.nNode == (n + 1) ** 3 and mesh.nElem == 6 * n ** 3 and len(mesh.bc_node) == (n + 1) ** 3 - (n - 1) ** 3
     s, dm, xyz = _solver(pf.POISSON_TET, mesh, 1e-10)
     info = s.matrixInfo()
@@ -45,6 +67,10 @@ def test_poisson_cube_full_size(n, N, nnz):
     assert np.abs(v_sc - v_g).max() <= 1e-12 * np.abs(v_g).max()
     s.assemble(H.POISSON_ELEMDATA, H.TIMEDATA)
     assert np.array_equal(s.getCSR()[2], v_g)               # gather assembly is bit-reproducible
+    # the oracle at this size: same pattern, and K, F equal bit for bit (one writer per row, reference order)
+    o_rowptr, o_cols, o_vals, o_rhs = _oracle_system(O.POISSON_TET, mesh, O.POISSON_ELEMDATA)
+    assert np.array_equal(rowptr, o_rowptr) and np.array_equal(cols, o_cols)
+    assert np.array_equal(v_g, o_vals) and np.array_equal(s.getRHS(), o_rhs)
     # interior row of the uniform grid (x 1/h): 15 entries, diag 6.667/h', row sum 0
     r = N // 2
     row = v_g[rowptr[r]:rowptr[r + 1]]
@@ -64,6 +90,10 @@ def test_poisson_cube_full_size(n, N, nnz):
     h0 = s.getHistory()
     assert rn <= 1e-10 * h0[0] and len(h0) == its + 1
     u = s.getSolution()
+    xo, its_o, reason_o, rn_o, _ = O.pcg_jacobi(o_rowptr, o_cols, o_vals, o_rhs, rtol=1e-10)      # threaded oracle PCG
+    assert reason_o == 2 and abs(its - its_o) <= 1
+    assert np.abs(u - xo).max() <= 1e-8
+    del o_vals, o_cols, xo
     exact = (xyz[:, H.assy_for_soln(dm.NodeDofArrayNew)] ** 2).sum(0)
     assert np.abs(u - exact).max() < 2e-7                   # limited by the %.8f BC round trip (1.1e-7)
     assert -1e-6 < u.min() and u.max() <= 3.0               # docs image colour bar: 0 ... 3.00
@@ -73,6 +103,7 @@ def test_poisson_cube_full_size(n, N, nnz):
 
 def test_elasticity_beam_config4():
     mesh = H.gen_box_tets(-0.5, 0.5, 50, 0.0, 6.0, 300, -0.5, 0.5, 50, bc_mode=1, ndof=3)
+    mesh.box_args = (-0.5, 0.5, 50, 0.0, 6.0, 300, -0.5, 0.5, 50, 1, 3)
     assert (mesh.nNode, mesh.nElem, len(mesh.bc_node)) == (782901, 4500000, 7803)
     s, dm, xyz = _solver(pf.ELAST_TET, mesh, 1e-5)
     info = s.matrixInfo()
@@ -84,7 +115,12 @@ def test_elasticity_beam_config4():
     assert np.abs(v_sc - v_g).max() <= 1e-12 * np.abs(v_g).max() and np.abs(f_sc - f_g).max() <= 1e-12 * np.abs(f_g).max()
     s.assemble(H.ELAST_ELEMDATA, H.TIMEDATA)
     assert np.array_equal(s.getCSR()[2], v_g) and np.array_equal(s.getRHS(), f_g)   # bit-reproducible
-    del v_sc, v_g
+    # the oracle at this size (4.5 M elements, 103 M entries): pattern, K and F bit for bit
+    rowptr, cols, _ = s.getCSR()
+    o_rowptr, o_cols, o_vals, o_rhs = _oracle_system(O.ELAST_TET, mesh, O.ELAST_ELEMDATA)
+    assert np.array_equal(rowptr, o_rowptr) and np.array_equal(cols, o_cols)
+    assert np.array_equal(v_g, o_vals) and np.array_equal(f_g, o_rhs)
+    del v_sc, v_g, rowptr, cols
     N = dm.size_global
     rng = np.random.default_rng(4)
     x, y = rng.standard_normal(N), rng.standard_normal(N)
@@ -92,7 +128,14 @@ def test_elasticity_beam_config4():
     assert abs(x @ Ay - y @ Ax) <= 1e-9 * np.sqrt(N) * np.abs(Ax).max() * np.abs(y).max()
     its, reason, rn = s.factoriseAndSolve()
     assert reason == 2
+    # 5207 Jacobi iterations at rtol 1e-5 on an ill-conditioned beam: the oracle loop gets there within a few
+    # iterations of the device loop (different summation order inside the dots), the iterates agree to the tolerance
+    xo, its_o, reason_o, *_ = O.pcg_jacobi(o_rowptr, o_cols, o_vals, o_rhs, rtol=1e-5, maxits=100000)
+    assert reason_o == 2 and abs(its - its_o) <= max(5, its_o // 200)
+    u = s.getSolution()
+    assert np.abs(u - xo).max() <= 1e-3 * np.abs(xo).max()
+    del o_vals, o_cols, xo
     full = dm.solnApplied.copy()
-    full[H.assy_for_soln(dm.NodeDofArrayNew)] = s.getSolution()
+    full[H.assy_for_soln(dm.NodeDofArrayNew)] = u
     disp = np.linalg.norm(full.reshape(-1, 3), axis=1)
     assert abs(disp.max() - 0.82) < 0.01                    # docs/beam3Dtet5030050-nproc80-soln.jpg: 0.82
