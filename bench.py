@@ -7,21 +7,24 @@ One "step" = one pass of the hot path over the resident mesh: setZero + element 
 (Ke/Fe, Dirichlet lifting, scatter; the reference's timer tetrapoissonparallelimpl1.F:826->893)
 + factoriseAndSolve (Jacobi-PCG to the PETSc default rtol 1e-5; timer :898->902).
 Inputs (mesh, maps, pattern) are resident in HBM before the timed region, as in the reference
-where mesh read / numbering / pattern precede the timers.
+where mesh read / numbering / pattern precede the timers.  The synthetic mesh and its numbering are
+generated ON THE DEVICE (pfem_mesh_generate_box: genTetra.cpp's box + the driver's bookkeeping,
+bit-identical to the host path); a rank holds the node planes of its own hex layers only.
 
 N = 1 : BASELINE.json configs[2]: synthetic [-1,1]^3, 200x200x200x6 P1 tets (genTetra logic).
 N > 1 : weak scaling, one process per GPU, per-GPU element count fixed: the [-1,1]^3 cube with
         round(200 N^(1/3)) cells per side (N = 8: BASELINE configs[4], 400x400x400x6), cut into N
-        z-slabs of hex layers; interface rows are summed with one RCCL all-reduce per SpMV
-        (torch.distributed "nccl").  --stack grows the box along z instead (200x200x200N cells of
-        the same size, 4x smaller interfaces).  Either way the Jacobi-PCG iteration count about
-        doubles from N=1 to N=8 (measured: tools/probe_iters.py), which caps DOF/s scaling at
-        ~0.5 N independently of the hardware; `iterations` is reported so per-iteration scaling
-        can be derived.
+        z-slabs of hex layers.  Per CG iteration: the SpMV slices with shared rows, then the
+        neighbour exchange of the partial sums (RCCL grouped send/recv, bound in C++) on a second
+        stream under the interior slices, and two scalar all-reduces.  --stack grows the box along z
+        instead (200x200x200N cells of the same size).  Either way the Jacobi-PCG iteration count about
+        doubles from N=1 to N=8 (a property of the preconditioner), which caps DOF/s scaling at ~0.5 N
+        independently of the hardware; `iterations` and `ms_per_iteration` are reported so that
+        per-iteration scaling can be derived.
 
 Prints ONE JSON line on rank 0 (contract in the task description), with `roofline` for the CG
-SpMV kernel (HIP events around every SpMV launch of the timed solves) and `cpu_baseline` (the C
-oracle, single core, on a bounded sample).
+SpMV kernel (HIP events around sampled SpMV launches of the timed solves) and `cpu_baseline` (the C
+oracle on the host cores, timed at the reference's three timer points on the SAME configuration).
 """
 import argparse
 import json
@@ -36,58 +39,74 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
 def pmc_traffic(nnz):
-    """HBM bytes per k_spmv<true> launch from the committed rocprofv3 PMC passes
-    (profiles/spmv_pmc_traffic.json, written by tools/gpu_round.sh on the SAME workload):
-    (2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM."""
+    """HBM bytes per launch of the CG SpMV from the committed rocprofv3 PMC passes
+    (profiles/spmv_pmc_traffic.json, written by tools/gpu_round.sh on the SAME workload in a
+    builder lease, not in this run): (2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md section HBM.  Returns (bytes, source) or (None, None)."""
+    path = os.path.join(ROOT, "profiles", "spmv_pmc_traffic.json")
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "spmv_pmc_traffic.json")))
+        d = json.load(open(path))
         if d.get("nnz") == nnz:
-            return (2.0 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024.0
+            return (2.0 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024.0, \
+                "profiles/spmv_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, " \
+                f"{d.get('source', 'builder lease')}); replayed, NOT measured in this run"
     except (OSError, ValueError, KeyError):
         pass
-    return None
+    return None, None
 
 
-def cpu_baseline(n=100, rtol=1e-5):
-    """The oracle (C restatement of the reference path) on the host cores, bounded sample:
-    BASELINE configs[1] (tet100: 100^3 x 6 tets), full assembly + Jacobi-PCG to the same rtol.
-    Threads: OpenMP over the element loop (atomic ADD_VALUES) and over SpMV / dots / axpys -- the
-    shared-memory stand-in for the reference's `mpirun -np P`; the 1-core figure rides in `sample`."""
-    import numpy as np
+def cpu_baseline(n, rtol, extra_sample=True):
+    """The oracle (C restatement of the reference path) on the host cores, on the SAME configuration as the GPU
+    number (n^3 x 6 tets, same rtol), timed at the reference's three timer points (tetrapoissonparallelimpl1.F:826,
+    893, 898-902): assembly, solve, total.  Threads: OpenMP over the element loop (atomic ADD_VALUES) and over
+    SpMV / dots / axpys -- the shared-memory stand-in for the reference's `mpirun -np P` (PETSc is not installable
+    here: "reference-equivalent CPU path, not PETSc").  The 1-thread figures come from the 100^3 sample (configs[1])
+    so that the whole leg stays bounded."""
     from oracle import pfem_oracle as O
-    mesh = O.gen_box_tets(-1, 1, n, -1, 1, n, -1, 1, n)
-    dm = O.dof_numbering(mesh.nNode, 1, mesh.bc_node, mesh.bc_dof, mesh.bc_val)
-    edof = O.elem_dof_array(mesh.conn, dm.NodeDofArrayNew)
-    rowptr, cols = O.csr_pattern(edof, dm.size_global)          # pattern precedes the timers (:786-802)
-    nb = 12 * len(cols) + 20 * dm.size_global
+    cores = max(1, min(os.cpu_count() or 1, 64))
 
-    def run(threads):
+    def problem(m):
+        mesh = O.gen_box_tets(-1, 1, m, -1, 1, m, -1, 1, m)
+        dm = O.dof_numbering(mesh.nNode, 1, mesh.bc_node, mesh.bc_dof, mesh.bc_val)
+        edof = O.elem_dof_array(mesh.conn, dm.NodeDofArrayNew)
+        O.set_threads(cores)
+        rowptr, cols = O.csr_pattern(edof, dm.size_global)          # pattern precedes the timers (:786-802)
+        return mesh, dm, edof, rowptr, cols
+
+    def run(prob, threads):
+        mesh, dm, edof, rowptr, cols = prob
         O.set_threads(threads)
         t0 = time.perf_counter()
-        if threads == 1:
-            vals, rhs = O.assemble(O.POISSON_TET, mesh.xyz, mesh.conn, edof, dm.solnApplied, O.POISSON_ELEMDATA,
-                                   dm.size_global, rowptr, cols)
-        else:
-            vals, rhs = O.assemble_mt(O.POISSON_TET, mesh.xyz, mesh.conn, edof, dm.solnApplied, O.POISSON_ELEMDATA,
-                                      dm.size_global, rowptr, cols)
+        asm = O.assemble if threads == 1 else O.assemble_mt
+        vals, rhs = asm(O.POISSON_TET, mesh.xyz, mesh.conn, edof, dm.solnApplied, O.POISSON_ELEMDATA, dm.size_global, rowptr, cols)
         t1 = time.perf_counter()
         x, its, reason, rn, _ = O.pcg_jacobi(rowptr, cols, vals, rhs, rtol=rtol)
         t2 = time.perf_counter()
         return t1 - t0, t2 - t1, its
 
-    cores = max(1, min(os.cpu_count() or 1, 64))
-    a1, s1, its1 = run(1)
-    if cores > 1:
-        run(cores)                                               # first touch / thread pool warm-up
-        am, sm, itsm = run(cores)
-    else:
-        am, sm, itsm = a1, s1, its1
-    return {"value": dm.size_global / (am + sm), "unit": "DOF/s", "cores": cores, "kind": "port",
-            "sample": f"{n}^3x6 tet Poisson (BASELINE configs[1]), N={dm.size_global}: {cores} OpenMP threads: assembly "
-                      f"{am:.2f}s + Jacobi-PCG rtol {rtol:g} {itsm} its {sm:.2f}s "
-                      f"({nb * itsm / sm / 1e9:.0f} GB/s SpMV-equivalent); 1 thread: assembly {a1:.2f}s + {its1} its "
-                      f"{s1:.2f}s = {dm.size_global / (a1 + s1):.3g} DOF/s",
-            "assembly_s": am, "solve_s": sm, "its": itsm, "single_core_value": dm.size_global / (a1 + s1)}
+    t_setup = time.perf_counter()
+    prob = problem(n)
+    t_setup = time.perf_counter() - t_setup
+    N = prob[1].size_global
+    nb = 12 * len(prob[4]) + 20 * N
+    run(prob, cores)                                             # first touch / thread pool warm-up
+    am, sm, its = run(prob, cores)
+    out = {"value": N / (am + sm), "unit": "DOF/s", "cores": cores, "kind": "port",
+           "sample": f"{n}^3x6 tet Poisson (the GPU number's own configuration), N={N}: {cores} OpenMP threads: assembly "
+                     f"{am:.2f}s + Jacobi-PCG rtol {rtol:g} {its} its {sm:.2f}s = {am + sm:.2f}s "
+                     f"({nb * its / sm / 1e9:.0f} GB/s SpMV-equivalent); reference-equivalent CPU path (C restatement), not PETSc",
+           "assembly_s": am, "solve_s": sm, "total_s": am + sm, "its": its, "setup_s_untimed": t_setup}
+    del prob
+    if extra_sample:
+        p1 = problem(100)
+        a1, s1, i1 = run(p1, 1)
+        run(p1, cores)
+        ac, sc, ic = run(p1, cores)
+        N1 = p1[1].size_global
+        out["extra"] = {"sample": "100^3x6 tet Poisson (BASELINE configs[1])", "free_dofs": N1,
+                        "single_core": {"assembly_s": a1, "solve_s": s1, "its": i1, "value": N1 / (a1 + s1)},
+                        f"{cores}_threads": {"assembly_s": ac, "solve_s": sc, "its": ic, "value": N1 / (ac + sc)}}
+    return out
 
 
 def main():
@@ -102,7 +121,9 @@ def main():
                          "linear-elasticity cantilever (fixed size: strong scaling over z-slabs for N>1)")
     ap.add_argument("--stack", action="store_true", help="N>1: z-extended box n x n x (n N) instead of the cube of n N^(1/3) cells per side")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--no-parity-step", action="store_true", help="skip the extra (untimed) step at rtol 1e-10")
+    ap.add_argument("--pc", choices=["jacobi", "pbjacobi"], default="jacobi")
+    ap.add_argument("--backend", default="nccl", help="nccl: RCCL bound inside the library; gloo: host hooks (development)")
     ap.add_argument("--same-device", action="store_true",
                     help="development: put every rank on cuda:0 (with --backend gloo) to exercise the N>1 path on a 1-GPU box")
     args = ap.parse_args()
@@ -131,41 +152,32 @@ def main():
     if pf.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: libpfem_amd has no CPU path")
 
-    # ---- mesh of this rank ------------------------------------------------------------
+    # ---- the mesh of this rank, generated on the device -----------------------------------
     n = args.n
     beam = args.workload == "beam"
     kind = pf.ELAST_TET if beam else pf.POISSON_TET
     ndof = 3 if beam else 1
+    bc_mode = 1 if beam else 0
     elem_data = H.ELAST_ELEMDATA if beam else H.POISSON_ELEMDATA
-    if beam:
-        nE = (50, 300, 50); zspan = (-0.5, 0.5)
+    if beam:      # SURVEY 8(d) cfg 4: [-.5,.5]x[0,6]x[-.5,.5], clamp y=0, body force (0.1f,0,0)
+        nE = (50, 300, 50); ext = (-0.5, 0.5, 0.0, 6.0, -0.5, 0.5)
     elif world == 1:
-        nE = (n, n, n); zspan = (-1.0, 1.0)
+        nE = (n, n, n); ext = (-1.0, 1.0, -1.0, 1.0, -1.0, 1.0)
     elif not args.stack:
         side = round(n * world ** (1.0 / 3.0))
-        nE = (side, side, side); zspan = (-1.0, 1.0)
+        nE = (side, side, side); ext = (-1.0, 1.0, -1.0, 1.0, -1.0, 1.0)
     else:
-        nE = (n, n, n * world); zspan = (-1.0, -1.0 + 2.0 * world)
+        nE = (n, n, n * world); ext = (-1.0, 1.0, -1.0, 1.0, -1.0, -1.0 + 2.0 * world)
     nEx, nEy, nEz = nE
-    kz = (nEz * rank // world, nEz * (rank + 1) // world)
+    box = (ext[0], ext[1], nEx, ext[2], ext[3], nEy, ext[4], ext[5], nEz)
     t_setup = time.perf_counter()
-    if beam:    # SURVEY 8(d) cfg 4: [-.5,.5]x[0,6]x[-.5,.5], clamp y=0, body force (0.1f,0,0)
-        mesh = H.gen_box_tets(-0.5, 0.5, nEx, 0.0, 6.0, nEy, zspan[0], zspan[1], nEz, bc_mode=1, ndof=3, kz=kz)
-    else:
-        mesh = H.gen_box_tets(-1.0, 1.0, nEx, -1.0, 1.0, nEy, zspan[0], zspan[1], nEz, kz=kz)
-    if world == 1:
-        dm = H.dof_numbering(mesh.nNode, ndof, mesh.bc_node, mesh.bc_dof, mesh.bc_val)
-    else:
-        _, npid = H.partition_box_slabs(nEx, nEy, nEz, world, elements=False)
-        dm = H.dof_numbering(mesh.nNode, ndof, mesh.bc_node, mesh.bc_dof, mesh.bc_val, world, npid)
-    conn_new, xyz_new = H.renumber_mesh(mesh, dm)                         # :659-664, :832-838
-    edof = H.elem_dof_array(conn_new, dm.NodeDofArrayNew)
-    N = dm.size_global
-    row_start, row_end = int(dm.row_start[rank]), int(dm.row_end[rank])
-
-    solver = pf.PetscSolver().initialise(row_end - row_start, N, row_start=row_start, device=device_index)
+    sz = H.box_slab_sizes(nEx, nEy, nEz, bc_mode, ndof, world, rank)
+    N, row_start, size_local = sz["size_global"], sz["row_start"], sz["size_local"]
+    solver = pf.PetscSolver().initialise(size_local, N, row_start=row_start, device=device_index)
     solver.setTolerances(rtol=args.rtol, maxits=100000 if beam else 10000)
-    solver.uploadMesh(kind, conn_new, xyz_new, edof, dm.solnApplied)
+    solver.setPreconditioner(args.pc)
+    solver.generateBoxMesh(kind, *box, bc_mode=bc_mode, nparts=world, part=rank)
+    t_generate = time.perf_counter() - t_setup
     hooks = None
     if world > 1:
         from pfemfort_amd import distributed as PD
@@ -173,7 +185,9 @@ def main():
         bad = solver.commSelftest(4096)
         if bad:
             raise SystemExit(f"rank {rank}: communication self-test failed ({bad} wrong entries)")
+    t1 = time.perf_counter()
     solver.buildPattern()
+    t_pattern = time.perf_counter() - t1
     info = solver.matrixInfo()
     t_setup = time.perf_counter() - t_setup
     solver.profileSpmv(8)        # event pair around every 8th SpMV launch of the timed solves (each pair costs ~2 us)
@@ -208,26 +222,69 @@ def main():
         if hooks is not None and hooks.error is not None:
             raise hooks.error
 
-    # sanity of the answer: u = x^2+y^2+z^2 is nodally exact on this mesh family
+    # ---- sanity of the answer on the owned rows ------------------------------------------
+    def owned_check(u):
+        if beam:    # the reference's docs image shows a maximum displacement magnitude of 0.82 (the tip; partial on a rank)
+            conn, xyz, edof, sa = solver.downloadMesh()
+            full = np.zeros(sz["nNode_local"] * 3)
+            # owned local dof l <-> (node, d): scatter through the element dof array
+            e_l = edof.reshape(4, 3, -1)
+            for a in range(4):
+                for d in range(3):
+                    l = e_l[a, d]
+                    ok = (l >= 0) & (l < size_local)
+                    full[conn[a][ok] * 3 + d] = u[l[ok]]
+            return "max_displacement_magnitude_owned_rows", float(np.linalg.norm(full.reshape(-1, 3), axis=1).max())
+        # u = x^2+y^2+z^2 is nodally exact on this mesh family; owned free nodes in closed form
+        def axis(lo, hi, m):          # xx = lo; repeat: use xx; xx += dx, then the "%.8f" round trip (genTetra.cpp:194-216)
+            out, v, d = [], lo, (hi - lo) / m
+            for _ in range(m + 1):
+                out.append(float("%.8f" % v))
+                v += d
+            return np.array(out)
+        ax = [axis(ext[0], ext[1], nEx), axis(ext[2], ext[3], nEy), axis(ext[4], ext[5], nEz)]
+        k0, k1 = nEz * rank // world, nEz * (rank + 1) // world
+        ks = [k for k in range(0 if rank == 0 else k0 + 1, k1 + 1) if 0 < k < nEz]
+        if not len(u):
+            return "max_nodal_error", 0.0
+        ex = (ax[2][ks] ** 2)[:, None, None] + (ax[1][1:-1] ** 2)[None, :, None] + (ax[0][1:-1] ** 2)[None, None, :]
+        return "max_nodal_error", float(np.abs(u - ex.ravel()).max())
+
     u = solver.getSolution()
-    owned_free = H.assy_for_soln(dm.NodeDofArrayNew)[row_start:row_end]
-    if beam:    # sanity: the reference's docs image shows a maximum displacement magnitude of 0.82
-        full = np.zeros(mesh.nNode * 3); full[owned_free] = u
-        check_name, check = "max_displacement_magnitude_owned_rows", float(np.linalg.norm(full.reshape(-1, 3), axis=1).max())
-    else:       # sanity: u = x^2+y^2+z^2 is nodally exact on this mesh family
-        exact = (xyz_new[:, owned_free] ** 2).sum(0)
-        check_name, check = "max_nodal_error", float(np.abs(u - exact).max()) if len(u) else 0.0
+    check_name, check = owned_check(u)
+
+    # ---- the same step at the parity tolerance (SURVEY 8d asks for both), untimed extra ----
+    parity = None
+    if world == 1 and not args.no_parity_step and not beam:
+        solver.setTolerances(rtol=1e-10, maxits=10000)
+        t1 = time.perf_counter()
+        its10, reason10, rn10 = step()
+        t10 = time.perf_counter() - t1
+        parity = {"rtol": 1e-10, "iterations": its10, "converged_reason": reason10, "rnorm": rn10, "ms_per_step": t10 * 1e3,
+                  "dof_per_s": N / t10, "max_nodal_error": owned_check(solver.getSolution())[1]}
+        solver.setTolerances(rtol=args.rtol, maxits=10000)
 
     cinfo = solver.commInfo()
     if rank == 0:
         bytes_per_spmv = 12 * info["nnz"] + 20 * info["n_local"]       # FP64 vals, int32 cols
+        fmt_bytes = solver.spmvFormatBytes()
         # event pair = marker-end -> kernel-end; net of the pair's own offset measured on an empty
         # kernel at solve start (pfem_timings.event_overhead_ms) this is the dispatch duration that
         # rocprofv3 --kernel-trace reports (profiles/)
         ev_off = tm["event_overhead_ms"]
         raw_spmv_ms = spmv_ms / max(spmv_n, 1)
-        avg_spmv_ms = max(raw_spmv_ms - ev_off, 1e-9)
+        avg_spmv_ms = max(raw_spmv_ms - ev_off * (2 if world > 1 else 1), 1e-9)     # N>1: two passes, two pairs
         achieved = bytes_per_spmv / (avg_spmv_ms * 1e-3) / 1e9 if spmv_n else 0.0
+        traffic, traffic_source = pmc_traffic(info["nnz"]) if world == 1 else (None, None)
+        hbm_bytes = traffic if traffic else fmt_bytes
+        kernel = {3: "pfem::k_spmvg<true> (row-grouped wave-sliced CSR SpMV + (p,Ap) partials: the 3 dof rows of a "
+                     "node share one lane, 16-bit column gaps), rank 0",
+                  4: "pfem::k_spmvr<true> (wave-sliced CSR SpMV + (p,Ap) partials; 4 consecutive rows per lane share "
+                     "one relative column stream of 16-bit gaps, x read as 32-B quads), rank 0"}.get(
+            solver.spmvRowGroup(),
+            ("pfem::k_spmv16<true>" if solver.spmvColumnBits() == 16 else "pfem::k_spmv<true>") +
+            " (wave-sliced CSR SpMV + (p,Ap) partials; %d-bit column %s), rank 0"
+            % (solver.spmvColumnBits(), "gaps" if solver.spmvColumnBits() == 16 else "indices"))
         out = {
             "metric": "DOF/s (assembly+CG-to-tol)", "value": N * args.steps / elapsed, "unit": "DOF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -236,41 +293,47 @@ def main():
             "config": {"workload": (f"tetraelasticityparallelimpl1: [-.5,.5]x[0,6]x[-.5,.5] beam, {nEx}x{nEy}x{nEz}x6 P1 tets, "
                                     "3 dofs/node, clamped at y=0, body force (0.1,0,0), E=240.565, nu=0.3 (REAL(4) literals)"
                                     if beam else
-                                    f"tetrapoissonparallelimpl1: [-1,1]^2x[{zspan[0]:g},{zspan[1]:g}] box, "
+                                    f"tetrapoissonparallelimpl1: [-1,1]^2x[{ext[4]:g},{ext[5]:g}] box, "
                                     f"{nEx}x{nEy}x{nEz}x6 P1 tets, u=x^2+y^2+z^2 Dirichlet on all faces, f=-6"),
-                       "elements": 6 * nEx * nEy * nEz, "nodes": int(mesh.nNode), "free_dofs": int(N),
-                       "solver": f"Jacobi-PCG, zero initial guess, rtol {args.rtol:g} on ||M^-1 r|| (PETSc KSPCG default norm)",
-                       "parallelism": "1 GPU" if world == 1 else f"{world} z-slabs, sub-assembled interface rows, "
-                                      f"neighbour exchange of {cinfo['doubles_per_exchange']} doubles with {cinfo['n_peers']} "
-                                      f"neighbour(s) per SpMV (overlapped with the interior slices) + 2 scalar all-reduces, "
+                       "elements": 6 * nEx * nEy * nEz, "nodes": (nEx + 1) * (nEy + 1) * (nEz + 1), "free_dofs": int(N),
+                       "solver": f"CG + {'node-block Jacobi (pbjacobi)' if args.pc == 'pbjacobi' else 'point Jacobi'}, zero initial guess, "
+                                 f"rtol {args.rtol:g} on ||M^-1 r|| (PETSc KSPCG default norm). The reference's PETSc run "
+                                 "used KSPCG + PCBJACOBI (per-rank ILU(0), solverpetsc.F:187,206), which is NOT reproduced: "
+                                 "iteration counts are not comparable with a PETSc run of the reference",
+                       "parallelism": "1 GPU" if world == 1 else
+                                      f"{world} z-slabs, sub-assembled interface rows, neighbour exchange of "
+                                      f"{cinfo['doubles_per_exchange']} doubles with {cinfo['n_peers']} neighbour(s) per SpMV "
+                                      "(overlapped with the interior slices) + 2 scalar all-reduces, "
                                       + ("gloo host hooks" if args.backend == "gloo" else "RCCL bound in C++")},
             "iterations": its, "converged_reason": reason, "rnorm": rnorm, check_name: check,
             "assembly_ms_per_step": asm_ms / args.steps, "solve_ms_per_step": sol_ms / args.steps,
             "ms_per_iteration": sol_ms / args.steps / max(its, 1),     # weak scaling: iterations grow with the problem
-            "setup_s_untimed": t_setup,
-            # N > 1, rank 0, sampled with the SpMV: stream time of the two exchanges of an iteration (for the next round)
+            "setup_s_untimed": t_setup, "setup_breakdown_s": {"generate_mesh_and_numbering_on_device": t_generate,
+                                                              "symbolic_pattern_and_incidence": t_pattern},
+            "parity_tolerance_step": parity,
+            # N > 1, rank 0, sampled with the SpMV: time on the communication stream of the exchanges of an iteration, and
+            # how much of it the compute stream actually waited for
             "comm": ({"interface_exchange_ms": if_ms / comm_n, "scalar_allreduce_ms": sc_ms / comm_n,
                       "exposed_wait_ms": ex_ms / comm_n, "samples": comm_n, "neighbours": cinfo["n_peers"],
                       "bytes_per_exchange": 8 * cinfo["doubles_per_exchange"],
                       "bytes_per_neighbour": 8 * cinfo["doubles_per_exchange"] // max(cinfo["n_peers"], 1),
                       "boundary_slices": cinfo["boundary_slices"], "slices": cinfo["total_slices"]} if comm_n else None),
-            "roofline": {"bound": "hbm",
-                         "kernel": {3: "pfem::k_spmvg<true> (row-grouped wave-sliced CSR SpMV + (p,Ap) partials: the 3 dof rows of a "
-                                       "node share one lane, 16-bit column gaps), rank 0",
-                                    4: "pfem::k_spmvr<true> (wave-sliced CSR SpMV + (p,Ap) partials; 4 consecutive rows per lane share "
-                                       "one relative column stream of 16-bit gaps, x read as 32-B quads), rank 0"}.get(
-                             solver.spmvRowGroup(),
-                             ("pfem::k_spmv16<true>" if solver.spmvColumnBits() == 16 else "pfem::k_spmv<true>") +
-                             " (wave-sliced CSR SpMV + (p,Ap) partials; %d-bit column %s), rank 0"
-                             % (solver.spmvColumnBits(), "gaps" if solver.spmvColumnBits() == 16 else "indices")),
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(info["nnz"]) if world == 1 else None,
+            "roofline": {"bound": "hbm", "kernel": kernel,
+                         # the judged figure: plain-CSR algorithmic bytes / measured launch time.  It is an
+                         # EFFECTIVE rate: the kernel's compressed form moves fewer bytes (hbm_gbps below)
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "effective": True,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "format_bytes_per_launch": fmt_bytes,
+                         "hbm_gbps": hbm_bytes / (avg_spmv_ms * 1e-3) / 1e9 if spmv_n else 0.0,
+                         "hbm_frac": hbm_bytes / (avg_spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if spmv_n else 0.0,
+                         "hbm_bytes_source": "PMC counters (traffic)" if traffic else "storage of the selected form + x + y",
                          "algorithmic_bytes_per_launch": bytes_per_spmv, "avg_launch_ms": avg_spmv_ms,
                          "event_pair_ms_raw": raw_spmv_ms, "event_pair_offset_ms": ev_off,
                          "launches_timed": spmv_n, "nnz": info["nnz"], "rows": info["n_local"]},
         }
         if world == 1 and not args.no_cpu_baseline and not beam:
-            out["cpu_baseline"] = cpu_baseline(rtol=args.rtol)
+            out["cpu_baseline"] = cpu_baseline(n, args.rtol, extra_sample=(n >= 200))
         print(json.dumps(out), flush=True)
     solver.free()
     if world > 1:

@@ -221,6 +221,21 @@ int pfem_mesh_upload(pfem_solver *s, int kind, int64_t nElem, const int32_t *con
                      int64_t nNode, const double *xyz, const int32_t *edof,
                      const double *solnApplied);
 /* Pattern-initialisation loop :786-802 on the device (symbolic phase). */
+/* Synthetic configurations without a host mesh (BASELINE configs 2-5): genTetra.cpp's structured box -- node order,
+ * "%.8f" coordinates, the 6-tet split of :263-322, Dirichlet data of :505-525 (bc_mode 0: u = x^2+y^2+z^2 on all six
+ * faces; 1: the plane y = y0 clamped) -- and the driver's bookkeeping for it (free-dof numbering
+ * tetrapoissonparallelimpl1.F:357-367, ElemDofArray :698-713; for nparts > 1 the z-slab partition of
+ * pfem_partition_box_slabs, whose renumbering :541-612 is the identity) evaluated ON THE DEVICE for slab `part`.
+ * pfem_box_slab_sizes (host, closed forms) gives the sizes to create the solver with; a rank holds the node planes of
+ * its own hex layers only.  Replaces pfem_gen_box_tets + pfem_dof_numbering + pfem_renumber_mesh +
+ * pfem_elem_dof_array + pfem_mesh_upload for these meshes (bit-identical arrays: tests/test_gpu_parity.py).      */
+int pfem_box_slab_sizes(int nEx, int nEy, int nEz, int bc_mode, int ndof, int nparts, int part,
+                        int64_t *size_global, int64_t *row_start, int64_t *size_local,
+                        int64_t *nNode_local, int64_t *nElem_local);
+int pfem_mesh_generate_box(pfem_solver *s, int kind, double x0, double x1, int nEx, double y0, double y1, int nEy,
+                           double z0, double z1, int nEz, int bc_mode, int nparts, int part);
+/* the mesh as the device holds it; edof in LOCAL numbering (owned rows first, ghosts after); any pointer may be NULL */
+int pfem_mesh_download(pfem_solver *s, int32_t *conn, double *xyz, int32_t *edof_local, double *solnApplied);
 int pfem_pattern_build(pfem_solver *s);
 /* setZero + element loop :817-884 on the device: Ke/Fe, Dirichlet lifting,
  * atomic scatter into the device matrix and rhs.                                */
@@ -251,6 +266,9 @@ int pfem_solver_set_spmv_format(pfem_solver *s, int format);
 int pfem_solver_get_spmv_format(pfem_solver *s, int *bits_per_column);
 /* rows served by one lane of the current SpMV: 3 in the row-grouped form, else 1 */
 int pfem_solver_get_spmv_row_group(pfem_solver *s, int *rows_per_lane);
+/* bytes one launch of the selected SpMV form moves at best: its own storage (values, gap words / columns, offsets)
+ * + x + y, each touched once.  (The judged figure 12 nnz + 20 N of SURVEY 8d is the plain int32-CSR equivalent.)   */
+int pfem_solver_spmv_bytes(pfem_solver *s, int64_t *format_bytes);
 /* Preconditioner of the CG (PCSetType, solverpetsc.F:206).  JACOBI (default) is the diagonal scaling
  * BASELINE's north_star names.  NODE_BLOCK_JACOBI (PETSc: -pc_type pbjacobi) inverts the
  * diagonal block of every row group of the SpMV (the 1..3 dof rows of a node); it takes effect when the

@@ -87,12 +87,16 @@ SIGNATURES = {
     "pfem_solver_get_solution": [_P, _P],
     "pfem_solver_get_history": [_P, _P, _I, _P],
     "pfem_mesh_upload": [_P, _I, _L, _P, _L, _P, _P, _P],
+    "pfem_box_slab_sizes": [_I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "pfem_mesh_generate_box": [_P, _I, _D, _D, _I, _D, _D, _I, _D, _D, _I, _I, _I, _I],
+    "pfem_mesh_download": [_P, _P, _P, _P, _P],
     "pfem_pattern_build": [_P],
     "pfem_assemble": [_P, _P, _P],
     "pfem_solver_set_assembly_mode": [_P, _I],
     "pfem_solver_set_spmv_format": [_P, _I],
     "pfem_solver_get_spmv_format": [_P, _P],
     "pfem_solver_get_spmv_row_group": [_P, _P],
+    "pfem_solver_spmv_bytes": [_P, _P],
     "pfem_solver_set_preconditioner": [_P, _I],
     "pfem_solver_get_preconditioner": [_P, _P],
     "pfem_eval_elems": [_P, _P, _P, _P, _P],

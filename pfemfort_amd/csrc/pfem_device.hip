@@ -193,6 +193,7 @@ struct pfem_solver {
     int rows_threads = 0;    // block size of the LDS-row gather kernels (256/128/64), 0 = rows too long
     DevBuf<uint32_t> d_inc_slots;  // ... and the matrix entry index of each element node inside the node's rows
     int64_t nnz = 0, n_slices = 0, stored = 0;
+    int64_t gap_words = 0, g_gap_words = 0, r_gap_words = 0;      // 32-bit words of 16-bit column gaps (row / grouped / relative form)
     int max_row_len = 0;
     DevBuf<int64_t> d_rowptr, d_slice_off;
     DevBuf<int32_t> d_rowlen, d_cols;
@@ -532,6 +533,133 @@ extern "C" int pfem_mesh_upload(pfem_solver *s, int kind, int64_t nElem, const i
     s->have_mesh = true;
     s->have_pattern = false;
     s->tm.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return PFEM_OK;
+}
+
+// The synthetic configurations without a host mesh: genTetra.cpp's box (node order, "%.8f" coordinates, the 6-tet split,
+// Dirichlet data) and the driver's bookkeeping for it (free-dof numbering :357-367, ElemDofArray :698-713, and for
+// nparts > 1 the z-slab partition with its identity renumbering) evaluated on the device for slab `part`.  The solver
+// must have been created with the sizes pfem_box_slab_sizes reports.  Nothing of the whole grid is ever held: a rank
+// stores the node planes of its own hex layers only.
+extern "C" int pfem_mesh_generate_box(pfem_solver *s, int kind, double x0, double x1, int nEx, double y0, double y1, int nEy,
+                                      double z0, double z1, int nEz, int bc_mode, int nparts, int part)
+{
+    if (!s || (kind != PFEM_POISSON_TET && kind != PFEM_ELAST_TET)) return PFEM_ERR_ARG;
+    const int ndof = kind_ndof(kind);
+    int64_t size_global = 0, row_start = 0, size_local = 0, nNode = 0, nElem = 0;
+    PFEM_TRY(pfem_box_slab_sizes(nEx, nEy, nEz, bc_mode, ndof, nparts, part, &size_global, &row_start, &size_local, &nNode, &nElem));
+    if (size_global != s->size_global || row_start != s->row_start || size_local != s->n_owned) {
+        set_last_error("pfem_mesh_generate_box: the solver was not created with the sizes of pfem_box_slab_sizes");
+        return PFEM_ERR_ARG;
+    }
+    if (nNode > INT32_MAX || nElem >= (1LL << 31) / 4) return PFEM_ERR_ARG;
+    PFEM_TRY(use_device(s));
+    const auto t0 = std::chrono::steady_clock::now();
+    const int nNx = nEx + 1, nNy = nEy + 1, nNz = nEz + 1;
+    int k0, k1;
+    box_slab_layers(nEz, nparts, part, &k0, &k1);
+    const BoxAxes ax = box_axes(x0, x1, nEx, y0, y1, nEy, z0, z1, nEz);
+    MeshDev &m = s->mesh;
+    m.kind = kind;
+    m.npe = 4;
+    m.ndof = ndof;
+    m.nsize = 4 * ndof;
+    m.ndim = 3;
+    m.nElem = nElem;
+    m.nNode = nNode;
+    const int64_t ndofs = static_cast<int64_t>(m.nsize) * nElem;
+
+    // ghosts: the free dofs of node plane k0 when a lower slab owns it -- one contiguous run of global ids
+    s->ghost_gid.clear();
+    if (part > 0) {
+        int64_t first = 0;
+        for (int k = 0; k < k0; ++k) first += box_free_per_plane(nNx, nNy, nNz, bc_mode, ndof, k);
+        const int64_t cnt = box_free_per_plane(nNx, nNy, nNz, bc_mode, ndof, k0);
+        s->ghost_gid.resize(static_cast<size_t>(cnt));
+        for (int64_t g = 0; g < cnt; ++g) s->ghost_gid[static_cast<size_t>(g)] = first + g;
+    }
+    s->n_ghost = static_cast<int64_t>(s->ghost_gid.size());
+    s->n_loc = s->n_owned + s->n_ghost;
+    if (s->n_loc > INT32_MAX) return PFEM_ERR_ARG;
+
+    DevBuf<double> d_tab;
+    PFEM_TRY(d_tab.alloc(static_cast<size_t>(nNx + nNy + nNz)));
+    PFEM_HIP(hipMemcpyAsync(d_tab.p, ax.rounded[0].data(), sizeof(double) * nNx, hipMemcpyHostToDevice, s->stream));
+    PFEM_HIP(hipMemcpyAsync(d_tab.p + nNx, ax.rounded[1].data(), sizeof(double) * nNy, hipMemcpyHostToDevice, s->stream));
+    PFEM_HIP(hipMemcpyAsync(d_tab.p + nNx + nNy, ax.rounded[2].data(), sizeof(double) * nNz, hipMemcpyHostToDevice, s->stream));
+    PFEM_TRY(s->d_conn.alloc(static_cast<size_t>(4) * nElem));
+    PFEM_TRY(s->d_edof.alloc(static_cast<size_t>(ndofs)));
+    PFEM_TRY(s->d_xyz.alloc(static_cast<size_t>(3) * nNode));
+    PFEM_TRY(s->d_soln.alloc(static_cast<size_t>(ndof) * nNode));
+    const BoxDev b{nNx, nNy, nNz, k0, k1, bc_mode, ndof, d_tab.p, d_tab.p + nNx, d_tab.p + nNx + nNy};
+    hipLaunchKernelGGL(k_box_nodes, dim3(grid_for(nNode)), dim3(kBlock), 0, s->stream, b, nNode, s->d_xyz.p, s->d_soln.p);
+    PFEM_TRY(check_kernel("k_box_nodes"));
+    const int64_t nHex = nElem / 6;
+    hipLaunchKernelGGL(k_box_elems, dim3(grid_for(nHex)), dim3(kBlock), 0, s->stream, b, nHex, s->d_conn.p, s->d_edof.p);
+    PFEM_TRY(check_kernel("k_box_elems"));
+
+    // prescribed values of the slab's boundary nodes (bc_mode 0: u = x^2+y^2+z^2 through the float / "%.8f" round trips
+    // of genTetra.cpp:510-525, evaluated on the host for the few face nodes; bc_mode 1: zeros, already there)
+    if (bc_mode == 0) {
+        std::vector<int64_t> slot;
+        std::vector<double> val;
+        const int64_t plane = static_cast<int64_t>(nNx) * nNy;
+        for (int k = k0; k <= k1; ++k)
+            for (int j = 0; j < nNy; ++j) {
+                const bool edge_row = k == 0 || k == nNz - 1 || j == 0 || j == nNy - 1;
+                for (int i = 0; i < nNx; i += (edge_row ? 1 : std::max(1, nNx - 1))) {
+                    const double v = box_dirichlet_value(ax.raw[0][i], ax.raw[1][j], ax.raw[2][k]);
+                    const int64_t node = plane * (k - k0) + static_cast<int64_t>(nNx) * j + i;
+                    for (int d = 0; d < ndof; ++d) { slot.push_back(node * ndof + d); val.push_back(v); }
+                }
+            }
+        DevBuf<int64_t> d_slot;
+        DevBuf<double> d_val;
+        PFEM_TRY(d_slot.alloc(slot.size()));
+        PFEM_TRY(d_val.alloc(val.size()));
+        PFEM_HIP(hipMemcpyAsync(d_slot.p, slot.data(), sizeof(int64_t) * slot.size(), hipMemcpyHostToDevice, s->stream));
+        PFEM_HIP(hipMemcpyAsync(d_val.p, val.data(), sizeof(double) * val.size(), hipMemcpyHostToDevice, s->stream));
+        hipLaunchKernelGGL(k_box_bc, dim3(grid_for(static_cast<int64_t>(slot.size()))), dim3(kBlock), 0, s->stream,
+                           static_cast<const int64_t *>(d_slot.p), static_cast<const double *>(d_val.p),
+                           static_cast<int64_t>(slot.size()), s->d_soln.p);
+        PFEM_TRY(check_kernel("k_box_bc"));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+    }
+    if (s->n_ghost > 0 || s->row_start > 0) {
+        DevBuf<int64_t> d_ghost;
+        PFEM_TRY(d_ghost.alloc(static_cast<size_t>(s->n_ghost)));
+        if (s->n_ghost)
+            PFEM_HIP(hipMemcpyAsync(d_ghost.p, s->ghost_gid.data(), sizeof(int64_t) * s->n_ghost, hipMemcpyHostToDevice, s->stream));
+        hipLaunchKernelGGL(k_localize_dofs, dim3(grid_for(ndofs)), dim3(kBlock), 0, s->stream, s->d_edof.p, ndofs,
+                           s->row_start, s->n_owned, d_ghost.p, s->n_ghost);
+        PFEM_TRY(check_kernel("k_localize_dofs"));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+    }
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    m.conn = s->d_conn.p;
+    m.edof = s->d_edof.p;
+    m.xyz = s->d_xyz.p;
+    m.soln = s->d_soln.p;
+    s->have_mesh = true;
+    s->have_pattern = false;
+    s->have_plan = false;
+    s->tm.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return PFEM_OK;
+}
+
+// the mesh as the device holds it (tests: generated box against the host generator + bookkeeping); edof comes back in
+// LOCAL numbering (owned rows first, ghosts after)
+extern "C" int pfem_mesh_download(pfem_solver *s, int32_t *conn, double *xyz, int32_t *edof_local, double *solnApplied)
+{
+    if (!s) return PFEM_ERR_ARG;
+    if (!s->have_mesh) return PFEM_ERR_STATE;
+    PFEM_TRY(use_device(s));
+    const MeshDev &m = s->mesh;
+    if (conn) PFEM_HIP(hipMemcpyAsync(conn, s->d_conn.p, sizeof(int32_t) * m.npe * m.nElem, hipMemcpyDeviceToHost, s->stream));
+    if (xyz) PFEM_HIP(hipMemcpyAsync(xyz, s->d_xyz.p, sizeof(double) * m.ndim * m.nNode, hipMemcpyDeviceToHost, s->stream));
+    if (edof_local) PFEM_HIP(hipMemcpyAsync(edof_local, s->d_edof.p, sizeof(int32_t) * m.nsize * m.nElem, hipMemcpyDeviceToHost, s->stream));
+    if (solnApplied) PFEM_HIP(hipMemcpyAsync(solnApplied, s->d_soln.p, sizeof(double) * m.ndof * m.nNode, hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
     return PFEM_OK;
 }
 
@@ -1043,6 +1171,7 @@ int build_cols16(pfem_solver *s)
     int64_t total = 0;
     PFEM_HIP(hipMemcpyAsync(&total, s->d_slice_doff.p + s->n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, s->stream));
     PFEM_HIP(hipStreamSynchronize(s->stream));
+    s->gap_words = total;
     PFEM_TRY(s->d_col0.alloc(static_cast<size_t>(s->n_slices) * 64));
     PFEM_TRY(s->d_dwords.alloc(static_cast<size_t>(std::max<int64_t>(total, 1))));
     PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
@@ -1129,6 +1258,7 @@ int build_groups(pfem_solver *s)
     PFEM_HIP(hipStreamSynchronize(s->stream));
     s->g_stored = tot_e;
     PFEM_TRY(s->d_gcol0.alloc(static_cast<size_t>(s->n_gslices) * 64));
+    s->g_gap_words = tot_w;
     PFEM_TRY(s->d_gdwords.alloc(static_cast<size_t>(std::max<int64_t>(tot_w, 1))));
     PFEM_TRY(s->d_gvals.alloc(static_cast<size_t>(std::max<int64_t>(tot_e, 1)) * kGroupRows));
     hipLaunchKernelGGL(k_group_cols_fill, dim3(grid_for(s->n_gslices * 64)), dim3(kBlock), 0, s->stream, s->sell(),
@@ -1187,6 +1317,7 @@ int build_rel_groups(pfem_solver *s)
     PFEM_HIP(hipStreamSynchronize(s->stream));
     s->r_stored = tot_e;
     PFEM_TRY(s->d_rcol0.alloc(static_cast<size_t>(s->n_rslices) * 64));
+    s->r_gap_words = tot_w;
     PFEM_TRY(s->d_rdwords.alloc(static_cast<size_t>(std::max<int64_t>(tot_w, 1))));
     PFEM_TRY(s->d_rvals.alloc(static_cast<size_t>(std::max<int64_t>(tot_e, 1)) * kRelRows));
     hipLaunchKernelGGL(k_rel_cols_fill, dim3(grid_for(s->n_rslices * 64)), dim3(kBlock), 0, s->stream, s->sell(), s->n_rgroups,
@@ -1275,6 +1406,26 @@ extern "C" int pfem_solver_get_spmv_row_group(pfem_solver *s, int *rows_per_lane
 {
     if (!s || !rows_per_lane) return PFEM_ERR_ARG;
     *rows_per_lane = s->use_grouped() ? kGroupRows : (s->use_rel() ? kRelRows : 1);
+    return PFEM_OK;
+}
+
+// Bytes one launch of the selected SpMV form moves when every array is read / written exactly once: the form's own
+// storage (values, 16-bit gap words or int32 columns, first columns, slice offsets) + x + y.  What the HBM counters
+// should show at best; the judged "algorithmic" figure 12 nnz + 20 N is the plain-CSR equivalent.
+extern "C" int pfem_solver_spmv_bytes(pfem_solver *s, int64_t *format_bytes)
+{
+    if (!s || !format_bytes) return PFEM_ERR_ARG;
+    if (!s->have_pattern) return PFEM_ERR_STATE;
+    int64_t b = 16 * s->n_loc;                                             // x read, y written
+    if (s->use_grouped())
+        b += s->g_stored * kGroupRows * 8 + s->g_gap_words * 4 + s->n_gslices * (64 * 4 + 16) + (s->n_groups + 1) * 4;
+    else if (s->use_rel())
+        b += s->r_stored * kRelRows * 8 + s->r_gap_words * 4 + s->n_rslices * (64 * 4 + 16);
+    else if (s->cols16 && s->spmv_format != PFEM_SPMV_INT32)
+        b += s->stored * 8 + s->gap_words * 4 + s->n_slices * (64 * 4 + 16);
+    else
+        b += s->stored * 12 + s->n_slices * 8 + s->n_loc * 4;
+    *format_bytes = b;
     return PFEM_OK;
 }
 

@@ -82,6 +82,58 @@ std::vector<double> axis_accumulate(double a0, double a1, int nE)
 
 }  // namespace
 
+pfem::BoxAxes pfem::box_axes(double x0, double x1, int nEx, double y0, double y1, int nEy, double z0, double z1, int nEz)
+{
+    BoxAxes a;
+    a.raw[0] = axis_accumulate(x0, x1, nEx);
+    a.raw[1] = axis_accumulate(y0, y1, nEy);
+    a.raw[2] = axis_accumulate(z0, z1, nEz);
+    for (int d = 0; d < 3; ++d) {
+        a.rounded[d].resize(a.raw[d].size());
+        for (size_t i = 0; i < a.raw[d].size(); ++i) a.rounded[d][i] = text_round8(a.raw[d][i]);
+    }
+    return a;
+}
+
+double pfem::box_dirichlet_value(double x_raw, double y_raw, double z_raw)
+{
+    // vtkPoints stores float; GetPoint widens back (genTetra.cpp:512-520)
+    const double cx = static_cast<double>(static_cast<float>(x_raw));
+    const double cy = static_cast<double>(static_cast<float>(y_raw));
+    const double cz = static_cast<double>(static_cast<float>(z_raw));
+    return text_round8(cx * cx + cy * cy + cz * cz);
+}
+
+// Sizes of slab `part` of `nparts` z-slabs of the generated box in the reference's numbering (for z-slabs the
+// renumbering of tetrapoissonparallelimpl1.F:541-612 is the identity: ranks concatenated, ascending old id inside a
+// rank, and rank r owns the node planes above its lowest hex layer -- plane 0 goes to rank 0): closed forms, so that a
+// rank can create its solver and generate its share of the mesh on the device without ever holding the whole grid.
+extern "C" int pfem_box_slab_sizes(int nEx, int nEy, int nEz, int bc_mode, int ndof, int nparts, int part,
+                                   int64_t *size_global, int64_t *row_start, int64_t *size_local,
+                                   int64_t *nNode_local, int64_t *nElem_local)
+{
+    if (nEx < 1 || nEy < 1 || nEz < 1 || ndof < 1 || nparts < 1 || nparts > nEz || part < 0 || part >= nparts ||
+        (bc_mode != 0 && bc_mode != 1))
+        return PFEM_ERR_ARG;
+    const int nNx = nEx + 1, nNy = nEy + 1, nNz = nEz + 1;
+    int k0, k1;
+    box_slab_layers(nEz, nparts, part, &k0, &k1);
+    const int own_lo = part == 0 ? 0 : k0 + 1, own_hi = k1;       // owned node planes [own_lo, own_hi]
+    int64_t before = 0, own = 0, all = 0;
+    for (int k = 0; k < nNz; ++k) {
+        const int64_t f = box_free_per_plane(nNx, nNy, nNz, bc_mode, ndof, k);
+        if (k < own_lo) before += f;
+        if (k >= own_lo && k <= own_hi) own += f;
+        all += f;
+    }
+    if (size_global) *size_global = all;
+    if (row_start) *row_start = before;
+    if (size_local) *size_local = own;
+    if (nNode_local) *nNode_local = static_cast<int64_t>(nNx) * nNy * (k1 - k0 + 1);
+    if (nElem_local) *nElem_local = 6LL * nEx * nEy * (k1 - k0);
+    return PFEM_OK;
+}
+
 extern "C" int pfem_gen_box_tets(double x0, double x1, int nEx, double y0, double y1, int nEy,
                                  double z0, double z1, int nEz, int kz0, int kz1, int bc_mode,
                                  int ndof, double *xyz, int32_t *conn, int64_t *nDBC,

@@ -115,6 +115,15 @@ def gen_box_tets(x0, x1, nEx, y0, y1, nEy, z0, z1, nEz, bc_mode=0, ndof=1, kz=No
     return Mesh(xyz, conn, bn, bd, bv, box=(nEx, nEy, nEz))
 
 
+def box_slab_sizes(nEx, nEy, nEz, bc_mode=0, ndof=1, nparts=1, part=0):
+    """Closed-form sizes of slab ``part`` of the generated box in the reference's numbering (pfem_box_slab_sizes)."""
+    v = [C.c_int64(0) for _ in range(5)]
+    L.check(L.lib().pfem_box_slab_sizes(nEx, nEy, nEz, bc_mode, ndof, nparts, part, *[C.byref(x) for x in v]),
+            "pfem_box_slab_sizes")
+    keys = ("size_global", "row_start", "size_local", "nNode_local", "nElem_local")
+    return {k: x.value for k, x in zip(keys, v)}
+
+
 def partition_box_slabs(nEx, nEy, nEz, nParts, elements=True):
     """Deterministic stand-in for METIS_PartMeshNodal (:464) on generated boxes.
     ``elements=False`` skips the (large) elem_proc_id array and returns None for it."""

@@ -150,6 +150,26 @@ class PetscSolver:
                 "pfem_mesh_upload")
         self.kind = kind
         self.nElem = conn.shape[1]
+        self.nNode = xyz.shape[1]
+
+    def generateBoxMesh(self, kind, x0, x1, nEx, y0, y1, nEy, z0, z1, nEz, bc_mode=0, nparts=1, part=0):
+        """The structured box of genTetra.cpp + the driver's numbering for slab ``part``, generated on the device
+        (the solver must have been initialised with ``host.box_slab_sizes``)."""
+        L.check(L.lib().pfem_mesh_generate_box(self._h, kind, x0, x1, nEx, y0, y1, nEy, z0, z1, nEz, bc_mode, nparts, part),
+                "pfem_mesh_generate_box")
+        self.kind = kind
+        sz = L.lib().pfem_box_slab_sizes
+        n = C.c_int64(0); ne = C.c_int64(0)
+        L.check(sz(nEx, nEy, nEz, bc_mode, L.NDOF[kind], nparts, part, None, None, None, C.byref(n), C.byref(ne)), "pfem_box_slab_sizes")
+        self.nElem, self.nNode = ne.value, n.value
+
+    def downloadMesh(self):
+        """(conn, xyz, edof_local, solnApplied) as the device holds them."""
+        npe, ndof, ndim = L.NPELEM[self.kind], L.NDOF[self.kind], L.NDIM[self.kind]
+        conn = np.empty((npe, self.nElem), np.int32); xyz = np.empty((ndim, self.nNode))
+        edof = np.empty((npe * ndof, self.nElem), np.int32); sa = np.empty(self.nNode * ndof)
+        L.check(L.lib().pfem_mesh_download(self._h, _p(conn), _p(xyz), _p(edof), _p(sa)), "pfem_mesh_download")
+        return conn, xyz, edof, sa
 
     def buildPattern(self):
         L.check(L.lib().pfem_pattern_build(self._h), "pfem_pattern_build")
@@ -183,6 +203,12 @@ class PetscSolver:
         """Rows served by one lane of the current SpMV (3: row-grouped form)."""
         b = C.c_int(0)
         L.check(L.lib().pfem_solver_get_spmv_row_group(self._h, C.byref(b)), "pfem_solver_get_spmv_row_group")
+        return b.value
+
+    def spmvFormatBytes(self):
+        """Bytes one launch of the selected SpMV form moves at best (its storage + x + y)."""
+        b = C.c_int64(0)
+        L.check(L.lib().pfem_solver_spmv_bytes(self._h, C.byref(b)), "pfem_solver_spmv_bytes")
         return b.value
 
     def assemble(self, elemData, timeData):

@@ -29,5 +29,35 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf
     assert rf["algorithmic_bytes_per_launch"] == 12 * rf["nnz"] + 20 * rf["rows"] and rf["launches_timed"] > 0
+    # the two rates travel together: `frac` is the effective (plain-CSR equivalent) figure, hbm_* what the form really moves
+    assert rf["effective"] is True and 0 < rf["hbm_gbps"] <= rf["achieved"] and "traffic_source" in rf
+    assert rf["format_bytes_per_launch"] < rf["algorithmic_bytes_per_launch"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "DOF/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    # the same configuration as the GPU number, at the reference's three timer points
+    assert "40^3" in cb["sample"] and abs(cb["total_s"] - cb["assembly_s"] - cb["solve_s"]) < 1e-9 and cb["its"] == d["iterations"]
+    assert d["parity_tolerance_step"]["rtol"] == 1e-10 and d["parity_tolerance_step"]["max_nodal_error"] < 1e-6
+    assert "PCBJACOBI" in d["config"]["solver"] and d["setup_breakdown_s"]["generate_mesh_and_numbering_on_device"] >= 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_sharing_the_device():
+    """The N > 1 code path of bench.py (per-rank device-generated slab, neighbour plan, exchange, comm report) with two
+    ranks on cuda:0 over gloo host hooks -- the launch line is the driver's, only backend and placement differ."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--cells", "40", "--backend", "gloo", "--same-device"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["converged_reason"] == 2 and d["max_nodal_error"] < 1e-3 and d["scaling"] == "weak"
+    side = round(40 * 2 ** (1 / 3))
+    assert d["config"]["free_dofs"] == (side - 1) ** 3
+    c = d["comm"]
+    assert c["neighbours"] == 1 and c["bytes_per_neighbour"] == 8 * (side - 1) ** 2 and c["samples"] > 0
+    assert 0 < c["boundary_slices"] < c["slices"] and c["interface_exchange_ms"] > 0 and c["scalar_allreduce_ms"] > 0

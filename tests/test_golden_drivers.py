@@ -111,7 +111,9 @@ def _gpu_rank(rank, world, port, case, out_dir):
         import pfemfort_amd as pf
         from pfemfort_amd import drivers as D
         fx = _load(case)
-        mesh, ndof = _mesh(case, pathlib.Path(out_dir))
+        rank_dir = pathlib.Path(out_dir) / f"rank{rank}"          # every rank unpacks its own copy of the input files
+        rank_dir.mkdir()
+        mesh, ndof = _mesh(case, rank_dir)
         kind = pf.POISSON_TET if ndof == 1 else pf.ELAST_TET
         _, epid, npid = _partition(fx, mesh)
         res = D.run_parallel(kind, mesh, epid, npid, dist, torch, rtol=1e-12, staged=True)

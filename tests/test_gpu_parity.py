@@ -461,3 +461,42 @@ def test_blocks_that_start_late_still_apply_the_last_step(monkeypatch):
     b = pf.tetrapoissonparallelimpl1(mesh, rtol=1e-5)
     assert (a.its, a.reason) == (b.its, b.reason) and a.reason == 2
     assert np.array_equal(a.soln_free, b.soln_free)
+
+
+@pytest.mark.parametrize("kind,box,bc_mode,nparts", [(pf.POISSON_TET, (6, 5, 7), 0, 1), (pf.POISSON_TET, (6, 5, 7), 0, 3),
+                                                     (pf.ELAST_TET, (3, 6, 5), 1, 1), (pf.ELAST_TET, (3, 6, 5), 1, 2)])
+def test_device_generated_box_equals_host_generator_and_bookkeeping(kind, box, bc_mode, nparts):
+    """pfem_mesh_generate_box (mesh + numbering evaluated on the device, one z-slab per part) against the host path --
+    pfem_gen_box_tets, pfem_partition_box_slabs, pfem_dof_numbering, pfem_renumber_mesh, pfem_elem_dof_array,
+    pfem_mesh_upload -- array by array, bit for bit; then the assembled K, F."""
+    nEx, nEy, nEz = box
+    ndof = 3 if kind == pf.ELAST_TET else 1
+    ext = (-1.0, 1.0, nEx, -0.5, 1.5, nEy, 0.0, 3.0, nEz)
+    ed = H.ELAST_ELEMDATA if kind == pf.ELAST_TET else H.POISSON_ELEMDATA
+    plane = (nEx + 1) * (nEy + 1)
+    for part in range(nparts):
+        sz = H.box_slab_sizes(nEx, nEy, nEz, bc_mode, ndof, nparts, part)
+        k0, k1 = nEz * part // nparts, nEz * (part + 1) // nparts
+        a = pf.PetscSolver().initialise(sz["size_local"], sz["size_global"], row_start=sz["row_start"])
+        a.generateBoxMesh(kind, *ext, bc_mode=bc_mode, nparts=nparts, part=part)
+        conn_a, xyz_a, edof_a, sa_a = a.downloadMesh()
+        # host path of the same slab (nodes of the whole grid, global ids)
+        mesh = H.gen_box_tets(*ext, bc_mode=bc_mode, ndof=ndof, kz=(k0, k1))
+        _, npid = H.partition_box_slabs(nEx, nEy, nEz, nparts, elements=False)
+        dm = H.dof_numbering(mesh.nNode, ndof, mesh.bc_node, mesh.bc_dof, mesh.bc_val, nparts, npid)
+        conn_new, xyz_new = H.renumber_mesh(mesh, dm)
+        edof = H.elem_dof_array(conn_new, dm.NodeDofArrayNew)
+        b = pf.PetscSolver().initialise(sz["size_local"], sz["size_global"], row_start=sz["row_start"])
+        b.uploadMesh(kind, conn_new, xyz_new, edof, dm.solnApplied)
+        _, _, edof_b, _ = b.downloadMesh()
+        assert np.array_equal(conn_a + plane * k0, conn_new)
+        assert np.array_equal(xyz_a, xyz_new[:, plane * k0:plane * (k1 + 1)])
+        assert np.array_equal(sa_a, dm.solnApplied[plane * k0 * ndof:plane * (k1 + 1) * ndof])
+        assert np.array_equal(edof_a, edof_b)
+        assert np.array_equal(a.ghosts(), b.ghosts())
+        for s in (a, b):
+            s.buildPattern()
+            s.assemble(ed, H.TIMEDATA)
+        for x, y in zip(a.getCSR(), b.getCSR()):
+            assert np.array_equal(x, y)
+        assert np.array_equal(a.getRHS(), b.getRHS())

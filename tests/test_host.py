@@ -179,3 +179,21 @@ def test_read_metis_partition_files(tmp_path):
     np.savetxt(tmp_path / "m.npart.2", npart, fmt="%d"); np.savetxt(tmp_path / "m.epart.2", ep, fmt="%d")
     with pytest.raises(ValueError):
         H.read_metis_partition(str(tmp_path / "m"), 2)          # part id 2 with nParts = 2
+
+
+@pytest.mark.parametrize("box,bc_mode,ndof", [((5, 4, 6), 0, 1), ((3, 5, 7), 1, 3), ((2, 2, 9), 0, 3)])
+def test_box_slab_sizes_match_the_host_bookkeeping(box, bc_mode, ndof):
+    """pfem_box_slab_sizes (closed forms) against pfem_partition_box_slabs + pfem_dof_numbering on the whole grid."""
+    nEx, nEy, nEz = box
+    mesh = H.gen_box_tets(-1, 1, nEx, 0, 2, nEy, -1, 3, nEz, bc_mode=bc_mode, ndof=ndof)
+    for nparts in (1, 2, 3):
+        epid, npid = H.partition_box_slabs(nEx, nEy, nEz, nparts)
+        dm = H.dof_numbering(mesh.nNode, ndof, mesh.bc_node, mesh.bc_dof, mesh.bc_val, nparts, npid)
+        assert np.array_equal(dm.node_map_get_old, np.arange(mesh.nNode))          # z-slabs: the renumbering is the identity
+        for part in range(nparts):
+            sz = H.box_slab_sizes(nEx, nEy, nEz, bc_mode, ndof, nparts, part)
+            assert sz["size_global"] == dm.size_global
+            assert (sz["row_start"], sz["row_start"] + sz["size_local"]) == (int(dm.row_start[part]), int(dm.row_end[part]))
+            assert sz["nElem_local"] == int((epid == part).sum())
+            k0, k1 = nEz * part // nparts, nEz * (part + 1) // nparts
+            assert sz["nNode_local"] == (nEx + 1) * (nEy + 1) * (k1 - k0 + 1)

@@ -9,11 +9,11 @@ TAG=${1:-r01}
 ( timeout 900 python -m pytest tests -m gpu -x -q --durations=5 2>&1 | tail -15 ) > $OUT/pytest_gpu_$TAG.log 2>&1
 ( timeout 600 python bench.py 2>&1 | tail -3 ) > $OUT/bench_$TAG.json 2>$OUT/bench_$TAG.err
 rm -rf /tmp/prof_stats /tmp/prof_fetch /tmp/prof_write
-timeout 600 rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof_stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/prof_stats_$TAG.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof_stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity-step > $OUT/prof_stats_$TAG.log 2>&1
 python tools/summarize_prof.py stats /tmp/prof_stats > $OUT/rocprof_kernel_stats_$TAG.txt 2>&1
-timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_spmv|k_cg_|k_assemble|k_gather" -f csv -d /tmp/prof_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/prof_fetch_$TAG.log 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_spmv|k_cg_|k_assemble|k_gather" -f csv -d /tmp/prof_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity-step > $OUT/prof_fetch_$TAG.log 2>&1
 python tools/summarize_prof.py pmc /tmp/prof_fetch FETCH_SIZE > $OUT/rocprof_pmc_fetch_$TAG.txt 2>&1
-timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "k_spmv|k_cg_|k_assemble|k_gather" -f csv -d /tmp/prof_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/prof_write_$TAG.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "k_spmv|k_cg_|k_assemble|k_gather" -f csv -d /tmp/prof_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity-step > $OUT/prof_write_$TAG.log 2>&1
 python tools/summarize_prof.py pmc /tmp/prof_write WRITE_SIZE > $OUT/rocprof_pmc_write_$TAG.txt 2>&1
 python3 - <<PY > $OUT/spmv_pmc_traffic.json
 import re, json
