@@ -37,7 +37,7 @@ subroutine PetscInitialize(file, ierr)
       case ("-ksp_type")
         if (trim(val) /= "cg") then        ! the reference hard-wires KSPCG (solverpetsc.F:187); nothing else is built
           write(*,*) "pfem_amd: -ksp_type ", trim(val), " is not available (only cg, as the reference sets)"
-          stop " Aborting... unsupported -ksp_type"
+          error stop " Aborting... unsupported -ksp_type"
         end if
       case default
         write(*,*) "pfem_amd: option ", trim(key), " in ", trim(file), " is not understood and is IGNORED"
@@ -63,7 +63,7 @@ subroutine pfem_set_pc_type(val)
   case ("pbjacobi"); pfem_opt_pc = 1
   case default
     write(*,*) "pfem_amd: -pc_type ", val, " is not available (jacobi, pbjacobi)"
-    stop " Aborting... unsupported -pc_type"
+    error stop " Aborting... unsupported -pc_type"
   end select
 end subroutine pfem_set_pc_type
 
