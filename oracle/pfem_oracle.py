@@ -300,6 +300,20 @@ def pcg_jacobi(rowptr, cols, vals, b, rtol=1e-5, abstol=1e-50, dtol=1e5, maxits=
     return x, its.value, reason.value, rn.value, hist[:min(hist_len, its.value + 1)]
 
 
+def pcg_bjacobi_ilu0(rowptr, cols, vals, b, block_start=None, rtol=1e-5, abstol=1e-50, dtol=1e5, maxits=10000):
+    """CG with PETSc's PCBJACOBI default (ILU(0) on each rank's diagonal block, natural ordering): what the
+    reference's solverpetsc.F:187,206 sets.  ``block_start`` = row-block boundaries (default: one block)."""
+    N = len(rowptr) - 1
+    bs = np.ascontiguousarray([0, N] if block_start is None else block_start, dtype=np.int64)
+    x = np.empty(N)
+    its = C.c_int(0); reason = C.c_int(0); rn = C.c_double(0)
+    rc = lib().orc_pcg_bjacobi_ilu0(C.c_int64(N), _p(rowptr), _p(cols), _p(vals), _p(_f64(b)), _p(x), C.c_int(len(bs) - 1),
+                                    _p(bs), C.c_double(rtol), C.c_double(abstol), C.c_double(dtol), C.c_int(maxits),
+                                    C.byref(its), C.byref(reason), C.byref(rn))
+    assert rc == 0
+    return x, its.value, reason.value, rn.value
+
+
 def row_groups(rowptr, cols, max_rows=3):
     """First rows of the row groups a node-block preconditioner works on: consecutive rows with identical
     column sets (the dof rows of a node), at most ``max_rows`` per group; last entry = number of rows."""

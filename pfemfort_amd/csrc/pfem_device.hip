@@ -132,6 +132,8 @@ struct DevBuf {
     }
 };
 
+constexpr size_t kMaxLdsBytes = 163840;       // LDS a single gfx950 workgroup may declare (MI355X_MICROARCH.md)
+
 inline unsigned grid_for(int64_t n) { return static_cast<unsigned>(std::max<int64_t>(1, (n + kBlock - 1) / kBlock)); }
 inline unsigned vec_grid(int64_t n) { return static_cast<unsigned>(std::min<int64_t>(kMaxGrid, std::max<int64_t>(1, (n + kBlock - 1) / kBlock))); }
 inline unsigned spmv_grid(int64_t n_slices)
@@ -866,11 +868,16 @@ int build_incidence(pfem_solver *s)
     s->d_node_row.release();
     // The numeric kernels read packed per-incidence records.  The elasticity kinds accumulate one matrix row
     // per thread in LDS: the block size is the largest of 256/128/64 for which max_row_len*T doubles fit
-    // 64 KiB; rows longer than that keep the scatter form.
+    // 64 KiB (several blocks per CU), else the largest that fits the 160 KiB a gfx950 workgroup may declare (up to 320
+    // entries per row, so the 254 entries of the slot bytes -- 84 neighbour nodes with 3 dofs -- are the limit for all
+    // kinds); rows longer than that keep the scatter form.
     s->rows_threads = 0;
     if (s->max_row_len > 0)
-        for (int T = kBlock; T >= 64; T >>= 1)
-            if (static_cast<size_t>(s->max_row_len) * T * sizeof(double) <= 65536) { s->rows_threads = T; break; }
+        for (size_t cap : {static_cast<size_t>(65536), kMaxLdsBytes}) {
+            for (int T = kBlock; T >= 64 && !s->rows_threads; T >>= 1)
+                if (static_cast<size_t>(s->max_row_len) * T * sizeof(double) <= cap) s->rows_threads = T;
+            if (s->rows_threads) break;
+        }
     if (m.ndof > 1 && s->rows_threads == 0) {
         s->d_inc_slots.release();
         s->d_inc_ptr.release();
@@ -1006,17 +1013,26 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
         const int64_t nthr = static_cast<int64_t>(m.ndof) * m.nNode;
         const dim3 rgrid(static_cast<unsigned>((nthr + T - 1) / T)), rblock(T);
         const size_t rlds = static_cast<size_t>(s->max_row_len) * T * sizeof(double);
+        // more than 64 KiB of dynamic LDS has to be allowed per kernel
+        auto allow_lds = [&](const void *fn) -> int {
+            if (rlds > 65536) PFEM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(rlds)));
+            return PFEM_OK;
+        };
 #define PFEM_GATHER(KIND)                                                                                             \
-    if (use_lds) hipLaunchKernelGGL((k_gather_scalar<KIND, true>), rgrid, rblock, rlds, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, nrow, s->d_err.p); \
-    else hipLaunchKernelGGL((k_gather_scalar<KIND, false>), grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, nrow, s->d_err.p)
+    if (use_lds) {                                                                                                    \
+        PFEM_TRY(allow_lds(reinterpret_cast<const void *>(&k_gather_scalar<KIND, true>)));                            \
+        hipLaunchKernelGGL((k_gather_scalar<KIND, true>), rgrid, rblock, rlds, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, nrow, s->d_err.p); \
+    } else hipLaunchKernelGGL((k_gather_scalar<KIND, false>), grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, nrow, s->d_err.p)
         switch (m.kind) {
         case PFEM_POISSON_TET: PFEM_GATHER(PFEM_POISSON_TET); break;
         case PFEM_POISSON_TRIA: PFEM_GATHER(PFEM_POISSON_TRIA); break;
         case PFEM_POISSON_TRIA_INLINE: PFEM_GATHER(PFEM_POISSON_TRIA_INLINE); break;
         case PFEM_ELAST_TET:
+            PFEM_TRY(allow_lds(reinterpret_cast<const void *>(&k_gather_elast_rows)));
             hipLaunchKernelGGL(k_gather_elast_rows, rgrid, rblock, rlds, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, ifl, nrow, s->d_err.p);
             break;
         case PFEM_ELAST_TRIA:
+            PFEM_TRY(allow_lds(reinterpret_cast<const void *>(&k_gather_elast2d_rows)));
             hipLaunchKernelGGL(k_gather_elast2d_rows, rgrid, rblock, rlds, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, ifl, nrow, s->d_err.p);
             break;
         }

@@ -140,7 +140,7 @@ def _hub_mesh(npts, ndof):
 
 
 @pytest.mark.parametrize("npts,kind_name", [(24, "poisson"), (40, "poisson"), (100, "poisson"), (140, "poisson"), (200, "poisson"), (300, "poisson"),
-                                            (12, "elast"), (20, "elast"), (35, "elast"), (60, "elast"), (100, "elast")])
+                                            (12, "elast"), (20, "elast"), (35, "elast"), (60, "elast"), (100, "elast"), (125, "elast")])
 def test_gather_assembly_long_rows(npts, kind_name):
     from pfemfort_amd import drivers as D
     kind, ed, ndof = (pf.POISSON_TET, H.POISSON_ELEMDATA, 1) if kind_name == "poisson" else (pf.ELAST_TET, H.ELAST_ELEMDATA, 3)
@@ -155,7 +155,10 @@ def test_gather_assembly_long_rows(npts, kind_name):
     assert np.array_equal(rowptr, prob.rowptr) and np.array_equal(cols, prob.cols)
     maxlen = int(np.diff(rowptr).max())
     assert maxlen >= ndof * (npts + 1 - len(np.unique(mesh.bc_node)))       # the hub row really is that long
-    if maxlen <= 255 and (ndof == 1 or maxlen <= 128):
+    # gather wherever the rows fit: 254 entries (the slot bytes of the incidence records); the LDS row accumulators of
+    # the elasticity kernels take up to 160 KiB per workgroup = 320 entries, so the slot bytes are the limit there too
+    # (84 neighbour nodes with 3 dofs; it was 42 with 64 KiB)
+    if maxlen <= 254:
         assert np.array_equal(vals, prob.vals) and np.array_equal(s.getRHS(), prob.rhs)     # gather: bit-exact
     else:                                                 # scatter fallback: atomics reorder the sums
         assert np.abs(vals - prob.vals).max() <= K_RTOL * np.abs(prob.vals).max()
