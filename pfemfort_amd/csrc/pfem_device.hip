@@ -1628,7 +1628,13 @@ struct HostBackend final : CommBackend {
 
 int ensure_comm_stream(pfem_solver *s)
 {
-    if (!s->comm_stream) PFEM_HIP(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
+    if (!s->comm_stream) {
+        // highest priority: the small pack-free communication kernels must not queue behind the 30 000 blocks of the
+        // interior SpMV pass they are meant to run under
+        int least = 0, greatest = 0;
+        PFEM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        PFEM_HIP(hipStreamCreateWithPriority(&s->comm_stream, hipStreamNonBlocking, greatest));
+    }
     while (s->xev.size() < 32) {
         hipEvent_t e;
         PFEM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1721,7 +1727,10 @@ extern "C" int pfem_solver_set_neighbours(pfem_solver *s, int n_peers, const int
     const int64_t lo = s->row_start, hi = s->row_start + s->n_owned;
     std::vector<int32_t> send_lidx(static_cast<size_t>(total));
     for (int k = 0; k < n_peers; ++k) {
-        if (peers[k] < 0 || peers[k] == s->rank || (k && peers[k] <= peers[k - 1]) || peer_off[k] > peer_off[k + 1]) return PFEM_ERR_ARG;
+        // (timing probes only: PFEM_DEBUG_SELF_PEER lets a rank name ITSELF as neighbour, which exercises the whole
+        // exchange pipeline on one GPU -- the sums are then wrong by construction)
+        const bool self_ok = peers[k] == s->rank && std::getenv("PFEM_DEBUG_SELF_PEER") != nullptr;
+        if (peers[k] < 0 || (peers[k] == s->rank && !self_ok) || (k && peers[k] <= peers[k - 1]) || peer_off[k] > peer_off[k + 1]) return PFEM_ERR_ARG;
         for (int64_t i = peer_off[k]; i < peer_off[k + 1]; ++i) {
             const int64_t g = shared_gid[i];
             if (i > peer_off[k] && shared_gid[i - 1] >= g) return PFEM_ERR_ARG;

@@ -32,6 +32,8 @@ def _partition(mesh, world, how, H):
     blocks interleave in space).  Deterministic: every rank computes the same arrays."""
     if how == "slabs":
         return H.partition_box_slabs(*mesh.box, world)
+    if how == "idle":                  # the last rank gets nothing: no elements, no nodes, no rows
+        return H.partition_box_slabs(*mesh.box, world - 1)
     cen = mesh.xyz[:, mesh.conn].mean(axis=1)
     ang = np.arctan2(cen[1] - cen[1].mean() + 0.013, cen[0] - cen[0].mean() + 0.007)
     epid = np.minimum(((ang + np.pi) / (2 * np.pi) * world).astype(np.int32), world - 1)
@@ -254,7 +256,8 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                                                             ("poisson", 3, "sectors", "batched"), ("elast", 3, "sectors", "batched"),
                                                             ("poisson", 2, "slabs", "compat"), ("elast", 3, "sectors", "compat"),
                                                             ("elast", 2, "slabs", "pbjacobi"), ("elast", 3, "sectors", "pbjacobi"),
-                                                            ("poisson", 2, "slabs", "pbjacobi"), ("poisson", 3, "sectors", "int32")])
+                                                            ("poisson", 2, "slabs", "pbjacobi"), ("poisson", 3, "sectors", "int32"),
+                                                            ("poisson", 3, "idle", "batched"), ("elast", 3, "idle", "pbjacobi")])
 def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partition, mode):
     """2-3 ranks share cuda:0 (host-staged exchange over gloo): the product's multi-rank device loop against the
     ORACLE -- a direct solve of the oracle-assembled global system in the partition's new numbering, and the oracle's
@@ -307,7 +310,10 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
         assert int(d["calls"]) >= 3 * int(d["its"])
         kinds = np.array([s[0] for s in d["log"]])
         assert np.array_equal(kinds, np.array([s[0] for s in np.load(tmp_path / "rank0.npz")["log"]]))
-        assert int(d["n_peers"]) >= 1 and 0 < int(d["slices_b"]) <= int(d["slices"])
+        if partition == "idle" and r == world - 1:      # an idle rank owns nothing and shares nothing, but takes part in
+            assert int(d["n_peers"]) == 0 and int(d["re"]) == int(d["rs"])       # every all-reduce and agrees on the verdict
+        else:
+            assert int(d["n_peers"]) >= 1 and 0 < int(d["slices_b"]) <= int(d["slices"])
         if "x2" in d.files:
             got2[int(d["rs"]):int(d["re"])] = d["x2"]
             assert int(d["reason2"]) == 2
