@@ -320,6 +320,10 @@ typedef struct pfem_timings {
     int64_t comm_samples;   /* number of iterations both were sampled in                                             */
     double exposed_ms_total;/* of those: time the compute stream spent WAITING for the comm stream (not hidden by the
                              * interior SpMV), per sampled iteration                                                 */
+    int64_t graph_iterations; /* iterations of the last solve that were replayed from a hipGraph                       */
+    double host_enqueue_ms;   /* host time spent enqueueing the iterations of the last solve (without the per-chunk     */
+    int64_t host_enqueued_iterations; /* wait for the control block) and the number of iterations enqueued;            */
+    double host_comm_ms;      /* of it: time inside the communication backend's calls (RCCL launch cost)              */
 } pfem_timings;
 int pfem_get_timings(pfem_solver *s, pfem_timings *t);
 /* record an event pair around every SpMV launch of the next solves (bench.py) */
@@ -351,10 +355,11 @@ int pfem_neighbour_plan(int nranks, int rank, const int64_t *row_start, const in
 int pfem_solver_set_neighbours(pfem_solver *s, int n_peers, const int *peers, const int64_t *peer_off,
                                const int64_t *shared_gid);
 /* Communication backend 1 -- RCCL over xGMI, bound inside the library (librccl is loaded at run time; nothing else
- * needs it): rank 0 creates the unique id (128 bytes), the host program broadcasts it by whatever means it has
+ * needs it): rank 0 creates the unique ids (256 bytes), the host program broadcasts them by whatever means it has
  * (torch.distributed store, MPI_Bcast, a file) and every rank calls pfem_solver_set_comm_rccl.  The exchange is one
- * grouped ncclSend/ncclRecv per neighbour, the reductions ncclAllReduce, all on the solver's communication stream. */
-#define PFEM_RCCL_ID_BYTES 128
+ * grouped ncclSend/ncclRecv per neighbour on the solver's communication stream (under the interior SpMV); the
+ * reductions are ncclAllReduce on a second communicator, in order on the compute stream.                          */
+#define PFEM_RCCL_ID_BYTES 256     /* two ncclUniqueIds: one communicator for the exchange, one for the all-reduces */
 int pfem_rccl_unique_id(void *id_out);
 int pfem_solver_set_comm_rccl(pfem_solver *s, int rank, int nranks, const void *id);
 /* Communication backend 2 -- host hooks, for hosts whose transport works on HOST memory (MPI: the reference's own

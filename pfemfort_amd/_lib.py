@@ -39,14 +39,16 @@ class Timings(C.Structure):
     _fields_ = [("pattern_ms", C.c_double), ("assemble_ms", C.c_double), ("solve_ms", C.c_double),
                 ("spmv_ms_total", C.c_double), ("spmv_launches", C.c_int64), ("upload_ms", C.c_double),
                 ("event_overhead_ms", C.c_double), ("iface_ms_total", C.c_double), ("scalar_ms_total", C.c_double),
-                ("comm_samples", C.c_int64), ("exposed_ms_total", C.c_double)]
+                ("comm_samples", C.c_int64), ("exposed_ms_total", C.c_double),
+                ("graph_iterations", C.c_int64), ("host_enqueue_ms", C.c_double), ("host_enqueued_iterations", C.c_int64),
+                ("host_comm_ms", C.c_double)]
 
 
 # host hooks of the communication backend (include/pfem_amd.h, section 5)
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
 HOST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64),
                                C.POINTER(C.c_double), C.POINTER(C.c_double))
-RCCL_ID_BYTES = 128
+RCCL_ID_BYTES = 256
 
 _P = C.c_void_p
 _I, _L, _D = C.c_int, C.c_int64, C.c_double

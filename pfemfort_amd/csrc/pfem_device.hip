@@ -147,11 +147,14 @@ inline unsigned spmv_grid(int64_t n_slices)
 // ---------------------------------------------------------------------------
 // communication backend of a multi-rank solver (implementations further down)
 // ---------------------------------------------------------------------------
-// One interface, two backends.  Every call is made in the same order on all ranks and refers to the solver's
-// communication stream: the RCCL backend enqueues on it, the host backend synchronises with it.
+// One interface, two backends.  Two independent channels, each used in one order by all ranks on ONE stream:
+// the neighbour exchange on the solver's communication stream, the scalar all-reduces on its compute stream (they sit
+// between dependent kernels anyway).  The RCCL backend enqueues on the stream it is given (a communicator per channel,
+// so the two never serialise against each other); the host backend synchronises with it.
 struct CommBackend {
     virtual ~CommBackend() {}
     virtual const char *name() const = 0;
+    virtual bool capturable() const { return false; }      // may its calls be recorded by a HIP stream capture?
     // in-place SUM of n doubles at device pointer d; all ranks receive identical bits
     virtual int allreduce(double *d, int64_t n, hipStream_t st) = 0;
     // d_send[off[k]..off[k+1]) -> peers[k]; the same range of d_recv <- peers[k]
@@ -270,7 +273,8 @@ struct pfem_solver {
     DevBuf<double> d_r2, d_z;      // ... second residual buffer (ping-pong), z = Binv r, per-row (first row | size << 30)
     DevBuf<uint32_t> d_row_grp;
     bool block_pc_ok = true;       // multi-rank: the ranks agreed that their row groups coincide on shared dofs
-    bool block_pc() const { return pc == PFEM_PC_NODE_BLOCK_JACOBI && grouped && n_loc < (1LL << 30) && (nranks == 1 || block_pc_ok); }
+    // (a rank without rows -- an idle rank of a multi-rank run -- has no groups to disagree about)
+    bool block_pc() const { return pc == PFEM_PC_NODE_BLOCK_JACOBI && (grouped || n_loc == 0) && n_loc < (1LL << 30) && (nranks == 1 || block_pc_ok); }
     bool rhs_summed = false;
 
     // CG state
@@ -299,6 +303,7 @@ struct pfem_solver {
     std::vector<hipEvent_t> xev;                 // cross-stream events (no timing), used round-robin
     size_t xev_next = 0;
     bool have_plan = false;
+    bool multi_overlap = false;                  // see run_pcg: measured, the in-order form is faster on this stack
     std::vector<int> peers;
     std::vector<int64_t> peer_off;               // [n_peers+1] offsets into the send / receive buffers
     int64_t n_send = 0, n_sh = 0;                // doubles per exchange; distinct shared dofs of this rank
@@ -317,6 +322,10 @@ struct pfem_solver {
     hipGraphExec_t cg_graph[2] = {nullptr, nullptr};
     std::vector<uint64_t> cg_graph_key;
     bool cg_graph_off = false;
+    // multi-rank: kMultiGraphIters iterations (both streams, the RCCL calls included) as one graph
+    hipGraphExec_t mgraph = nullptr;
+    std::vector<uint64_t> mgraph_key;
+    bool mgraph_off = false;
     bool profile_spmv = false;
     int profile_every = 1;         // event pair around every profile_every-th SpMV launch of a solve
     std::vector<hipEvent_t> spmv_events;
@@ -419,6 +428,7 @@ extern "C" int pfem_solver_destroy(pfem_solver *s)
     for (hipEvent_t e : s->spmv_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : s->comm_events) (void)hipEventDestroy(e);
     if (s->comm_stream) (void)hipStreamSynchronize(s->comm_stream);
+    if (s->mgraph) { (void)hipGraphExecDestroy(s->mgraph); s->mgraph = nullptr; }   // holds captured RCCL launches
     delete s->comm;            // before the streams go: an RCCL communicator is destroyed here
     s->comm = nullptr;
     for (hipEvent_t e : s->xev) (void)hipEventDestroy(e);
@@ -429,6 +439,7 @@ extern "C" int pfem_solver_destroy(pfem_solver *s)
     if (s->h_err) (void)hipHostFree(s->h_err);
     for (auto &g : s->cg_graph)
         if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    if (s->mgraph) { (void)hipGraphExecDestroy(s->mgraph); s->mgraph = nullptr; }
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return PFEM_OK;
@@ -445,6 +456,8 @@ extern "C" int pfem_solver_set_stream(pfem_solver *s, void *hip_stream)
     s->stream = static_cast<hipStream_t>(hip_stream);
     s->cg_graph_key.clear();
     s->cg_graph_off = false;
+    s->mgraph_key.clear();
+    s->mgraph_off = false;
     return PFEM_OK;
 }
 
@@ -716,6 +729,7 @@ int pattern_from_keys(pfem_solver *s, DevBuf<uint64_t> &keys, int64_t nkeys)
     }
     const int64_t n = s->n_loc;
     s->cg_graph_key.clear();               // every array a captured CG iteration points at is about to be replaced
+    s->mgraph_key.clear();
     int bits = 1;
     while ((1LL << bits) < std::max<int64_t>(n, 2)) ++bits;
     const int end_bit = std::min(64, 32 + bits);
@@ -1212,6 +1226,7 @@ int build_cols16(pfem_solver *s)
 int build_groups(pfem_solver *s)
 {
     s->grouped = false;
+    s->n_groups = 0;
     s->group_vals_stale = true;
     const int64_t n = s->n_loc;
     if (!s->cols16 || n < 2 || n > INT_MAX) return PFEM_OK;
@@ -1543,10 +1558,16 @@ RcclApi *rccl_api()
 
 struct RcclBackend final : CommBackend {
     RcclApi *api;
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;       // neighbour exchange (grouped send/recv)
+    ncclComm_t comm_s = nullptr;     // scalar all-reduces
     explicit RcclBackend(RcclApi *a) : api(a) {}
-    ~RcclBackend() override { if (comm) (void)api->CommDestroy(comm); }
+    ~RcclBackend() override
+    {
+        if (comm) (void)api->CommDestroy(comm);
+        if (comm_s) (void)api->CommDestroy(comm_s);
+    }
     const char *name() const override { return "rccl"; }
+    bool capturable() const override { return true; }
     int fail(const char *what, ncclResult_t r)
     {
         set_last_error(std::string(what) + ": " + api->GetErrorString(r));
@@ -1554,7 +1575,7 @@ struct RcclBackend final : CommBackend {
     }
     int allreduce(double *d, int64_t n, hipStream_t st) override
     {
-        const ncclResult_t r = api->AllReduce(d, d, static_cast<size_t>(n), ncclDouble, ncclSum, comm, st);
+        const ncclResult_t r = api->AllReduce(d, d, static_cast<size_t>(n), ncclDouble, ncclSum, comm_s, st);
         return r == ncclSuccess ? PFEM_OK : fail("ncclAllReduce", r);
     }
     int exchange(int np, const int *peers, const int64_t *off, const double *d_send, double *d_recv, hipStream_t st) override
@@ -1649,6 +1670,9 @@ int ensure_comm_stream(pfem_solver *s)
 
 int install_backend(pfem_solver *s, int rank, int nranks, CommBackend *b)
 {
+    if (s->mgraph) { (void)hipGraphExecDestroy(s->mgraph); s->mgraph = nullptr; }
+    s->mgraph_key.clear();
+    s->mgraph_off = false;
     delete s->comm;
     s->comm = b;
     s->rank = rank;
@@ -1669,14 +1693,16 @@ int stream_follows(pfem_solver *s, hipStream_t to, hipStream_t from)
 
 extern "C" int pfem_rccl_unique_id(void *id_out)
 {
-    static_assert(sizeof(ncclUniqueId) == PFEM_RCCL_ID_BYTES, "ncclUniqueId size");
+    static_assert(2 * sizeof(ncclUniqueId) == PFEM_RCCL_ID_BYTES, "two ncclUniqueIds: exchange and all-reduce communicator");
     if (!id_out) return PFEM_ERR_ARG;
     RcclApi *api = rccl_api();
     if (!api) return PFEM_ERR_COMM;
-    ncclUniqueId id;
-    const ncclResult_t r = api->GetUniqueId(&id);
-    if (r != ncclSuccess) { set_last_error(std::string("ncclGetUniqueId: ") + api->GetErrorString(r)); return PFEM_ERR_COMM; }
-    std::memcpy(id_out, &id, sizeof id);
+    for (int c = 0; c < 2; ++c) {
+        ncclUniqueId id;
+        const ncclResult_t r = api->GetUniqueId(&id);
+        if (r != ncclSuccess) { set_last_error(std::string("ncclGetUniqueId: ") + api->GetErrorString(r)); return PFEM_ERR_COMM; }
+        std::memcpy(static_cast<char *>(id_out) + c * sizeof id, &id, sizeof id);
+    }
     return PFEM_OK;
 }
 
@@ -1686,14 +1712,14 @@ extern "C" int pfem_solver_set_comm_rccl(pfem_solver *s, int rank, int nranks, c
     PFEM_TRY(use_device(s));
     RcclApi *api = rccl_api();
     if (!api) return PFEM_ERR_COMM;
-    ncclUniqueId id;
-    std::memcpy(&id, id_bytes, sizeof id);
+    ncclUniqueId id[2];
+    std::memcpy(id, id_bytes, sizeof id);
     RcclBackend *b = new (std::nothrow) RcclBackend(api);
     if (!b) return PFEM_ERR_NOMEM;
-    const ncclResult_t r = api->CommInitRank(&b->comm, nranks, id, rank);
+    ncclResult_t r = api->CommInitRank(&b->comm, nranks, id[0], rank);
+    if (r == ncclSuccess) r = api->CommInitRank(&b->comm_s, nranks, id[1], rank);
     if (r != ncclSuccess) {
         const int rc = b->fail("ncclCommInitRank", r);
-        b->comm = nullptr;
         delete b;
         return rc;
     }
@@ -1811,8 +1837,8 @@ extern "C" int pfem_solver_comm_selftest(pfem_solver *s, int64_t count, int64_t 
     PFEM_HIP(hipStreamSynchronize(s->stream));
     PFEM_TRY(stream_follows(s, s->comm_stream, s->stream));
     PFEM_TRY(s->comm->exchange(np, peers.data(), off.data(), d_send.p, d_recv.p, s->comm_stream));
-    PFEM_TRY(s->comm->allreduce(d_red.p, 4, s->comm_stream));
     PFEM_TRY(stream_follows(s, s->stream, s->comm_stream));
+    PFEM_TRY(s->comm->allreduce(d_red.p, 4, s->stream));
     double red_out[4];
     PFEM_HIP(hipMemcpyAsync(h_recv.data(), d_recv.p, sizeof(double) * tot, hipMemcpyDeviceToHost, s->stream));
     PFEM_HIP(hipMemcpyAsync(red_out, d_red.p, sizeof red_out, hipMemcpyDeviceToHost, s->stream));
@@ -1865,12 +1891,10 @@ int exchange_sum(pfem_solver *s, double *v)
     return PFEM_OK;
 }
 
-// sbuf[at..at+n) <- sum over the ranks, result visible to the compute stream
+// sbuf[at..at+n) <- sum over the ranks, in order on the compute stream
 int scalar_allreduce(pfem_solver *s, int at, int n)
 {
-    PFEM_TRY(stream_follows(s, s->comm_stream, s->stream));
-    PFEM_TRY(s->comm->allreduce(s->d_sbuf.p + at, n, s->comm_stream));
-    return stream_follows(s, s->stream, s->comm_stream);
+    return s->comm->allreduce(s->d_sbuf.p + at, n, s->stream);
 }
 
 // which SpMV form the next launch uses (key of the slice lists and of the captured graph)
@@ -2145,6 +2169,142 @@ int run_pcg(pfem_solver *s)
         std::sort(cal.begin(), cal.end());
         s->tm.event_overhead_ms = cal[cal.size() / 2];
     }
+    // ---- one multi-rank iteration (point Jacobi), enqueued on the two streams; it_arg < 0: inside a graph ------------
+    // (1) the slices that hold shared rows, then pack; (2) the neighbour exchange on the communication stream while
+    // (3) the interior slices run; (4) (p,Ap) of this rank -> all-reduce, in order on the compute stream; (5) the compute
+    // stream waits for the exchange and adds the neighbours' partials in rank order; (6) update, the two other scalars
+    // all-reduced, direction.
+    // Two forms of the iteration.  In order (default): whole SpMV, pack, exchange, all-reduce ... on the compute stream.
+    // Overlapped (PFEM_MULTI_OVERLAP=1): the slices with shared rows first, the exchange on the communication stream under
+    // the interior slices, two stream hand-overs per iteration.  Measured on MI355X / ROCm 7.2 with the rank as its own
+    // neighbour (tools/probe_overlap.py, 200^3 per rank, 634 kB exchanged): in order 0.346 ms per iteration against 0.329 for
+    // the single-rank loop (exchange 14 us, both all-reduces 11 us); overlapped 0.676 ms -- the RCCL launch takes 90 us on the
+    // second stream, each hand-over 12-30 us, and the split SpMV loses 70 us to the concurrent copy kernel.  The
+    // overlapped form pays only where an exchange costs more than ~150 us.
+    const bool overlap = [&] {
+        const char *e = std::getenv("PFEM_MULTI_OVERLAP");
+        return e ? std::atoi(e) != 0 : s->multi_overlap;
+    }();
+    double host_comm_s = 0.0;       // host time inside the backend's calls (enqueue cost of the RCCL launches)
+    auto timed = [&](auto &&call) -> int {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = call();
+        host_comm_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return rc;
+    };
+    auto multi_iteration = [&](int it_arg, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t *cev) -> int {
+        unsigned nb_blocks = s->n_slices_b > 0 ? spmv_grid(s->n_slices_b) : 0;
+        unsigned ni_blocks = s->n_slices_i > 0 ? spmv_grid(s->n_slices_i) : 0;
+        if (!overlap) {
+            // everything in order on the compute stream: whole SpMV, pack, exchange, (p,Ap) all-reduce
+            launch_spmv<true>(s, s->d_p.p, s->d_w.p, n, part_pw, ctl, e0, e1);
+            nb_blocks = gs;
+            ni_blocks = 0;
+            if (s->n_send > 0)
+                hipLaunchKernelGGL(k_pack_send, dim3(grid_for(s->n_send)), block, 0, s->stream, static_cast<const double *>(s->d_w.p),
+                                   static_cast<const int32_t *>(s->d_send_lidx.p), s->n_send, s->d_send.p, static_cast<const CgCtl *>(ctl));
+            if (cev) PFEM_HIP(hipEventRecord(cev[0], s->stream));
+            PFEM_TRY(timed([&] { return s->comm->exchange(static_cast<int>(s->peers.size()), s->peers.data(), s->peer_off.data(), s->d_send.p,
+                                                          s->d_recv.p, s->stream); }));
+            if (cev) PFEM_HIP(hipEventRecord(cev[1], s->stream));
+            hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s->stream, static_cast<const double *>(part_pw),
+                               static_cast<const double *>(nullptr), static_cast<int>(nb_blocks), sbuf, static_cast<const CgCtl *>(ctl));
+            if (cev) PFEM_HIP(hipEventRecord(cev[2], s->stream));
+            PFEM_TRY(timed([&] { return s->comm->allreduce(sbuf, 1, s->stream); }));
+            if (cev) { PFEM_HIP(hipEventRecord(cev[3], s->stream)); PFEM_HIP(hipEventRecord(cev[6], s->stream)); PFEM_HIP(hipEventRecord(cev[7], s->stream)); }
+        } else {
+        if (s->n_slices_b > 0)
+            launch_spmv<true>(s, s->d_p.p, s->d_w.p, n, part_pw, ctl, e0, e1, SliceSel{s->d_slices_b.p, s->n_slices_b});
+        if (s->n_send > 0)
+            hipLaunchKernelGGL(k_pack_send, dim3(grid_for(s->n_send)), block, 0, s->stream, static_cast<const double *>(s->d_w.p),
+                               static_cast<const int32_t *>(s->d_send_lidx.p), s->n_send, s->d_send.p, static_cast<const CgCtl *>(ctl));
+        PFEM_TRY(stream_follows(s, s->comm_stream, s->stream));
+        if (cev) PFEM_HIP(hipEventRecord(cev[0], s->comm_stream));
+        PFEM_TRY(timed([&] { return s->comm->exchange(static_cast<int>(s->peers.size()), s->peers.data(), s->peer_off.data(), s->d_send.p,
+                                                      s->d_recv.p, s->comm_stream); }));
+        if (cev) PFEM_HIP(hipEventRecord(cev[1], s->comm_stream));
+        if (s->n_slices_i > 0)
+            launch_spmv<true>(s, s->d_p.p, s->d_w.p, n, part_pw + nb_blocks, ctl, e2, e3, SliceSel{s->d_slices_i.p, s->n_slices_i});
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s->stream, static_cast<const double *>(part_pw),
+                           static_cast<const double *>(nullptr), static_cast<int>(nb_blocks + ni_blocks), sbuf,
+                           static_cast<const CgCtl *>(ctl));
+        if (cev) PFEM_HIP(hipEventRecord(cev[2], s->stream));
+        PFEM_TRY(timed([&] { return s->comm->allreduce(sbuf, 1, s->stream); }));
+        if (cev) PFEM_HIP(hipEventRecord(cev[3], s->stream));
+        if (cev) PFEM_HIP(hipEventRecord(cev[6], s->stream));
+        PFEM_TRY(stream_follows(s, s->stream, s->comm_stream));
+        if (cev) PFEM_HIP(hipEventRecord(cev[7], s->stream));
+        }
+        if (s->n_sh > 0)
+            hipLaunchKernelGGL(k_unpack_sum, dim3(grid_for(s->n_sh)), block, 0, s->stream, s->d_w.p,
+                               static_cast<const int32_t *>(s->d_sh_lidx.p), static_cast<const int32_t *>(s->d_sh_ptr.p),
+                               static_cast<const int32_t *>(s->d_sh_src.p), s->n_sh, static_cast<const double *>(s->d_recv.p),
+                               static_cast<const CgCtl *>(ctl));
+        hipLaunchKernelGGL(k_cg_update, dim3(gv), block, 0, s->stream, ctl, it_arg, n, s->n_owned, static_cast<const double *>(part_pw),
+                           0, static_cast<const double *>(sbuf), s->d_p.p, s->d_w.p, s->d_dinv.p, s->d_x.p, s->d_r.p, part_rz, part_zz);
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s->stream, static_cast<const double *>(part_rz),
+                           static_cast<const double *>(part_zz), static_cast<int>(gv), sbuf + 2, static_cast<const CgCtl *>(ctl));
+        if (cev) PFEM_HIP(hipEventRecord(cev[4], s->stream));
+        PFEM_TRY(timed([&] { return s->comm->allreduce(sbuf + 2, 2, s->stream); }));
+        if (cev) PFEM_HIP(hipEventRecord(cev[5], s->stream));
+        hipLaunchKernelGGL(k_cg_direction, dim3(gv), block, dir_lds, s->stream, ctl, it_arg, n, part_rz, part_zz, static_cast<int>(gv),
+                           red2, s->d_r.p, s->d_dinv.p, s->d_p.p, s->d_hist.p, s->hist_cap, s->maxits, s->d_x.p);
+        return PFEM_OK;
+    };
+
+    // ---- multi-rank graph: kMultiGraphIters iterations across both streams, the RCCL launches included ----------------
+    // The host needs ~0.3-0.4 ms to enqueue one multi-rank iteration (ten kernels, two stream hand-overs, three RCCL calls);
+    // the GPU needs about as long to run it, so the loop is host-bound unless it is replayed from a graph
+    // (tools/probe_overlap.py).  Only with a backend whose calls may be captured (RCCL); falls back to stream launches if
+    // the capture is refused.
+    constexpr int kMultiGraphIters = 4;
+    bool use_mgraph = false;
+    {
+        const int graph_env = [] { const char *e = std::getenv("PFEM_CG_GRAPH"); return e ? std::atoi(e) : 1; }();
+        // Measured on MI355X / ROCm 7.2: a captured ncclAllReduce replays fine, a captured grouped ncclSend/ncclRecv
+        // crashes the process (tools/probe_overlap.py, rank as its own neighbour).  So the graph is used by default only
+        // when this rank has no neighbour to exchange with; PFEM_MULTI_GRAPH=1 forces it (RCCL builds that capture p2p).
+        const bool p2p_ok = s->peers.empty() || std::getenv("PFEM_MULTI_GRAPH") != nullptr;
+        if (multi && !bpc && graph_env && p2p_ok && !dir_lds && !s->mgraph_off && s->comm->capturable() && s->stream != nullptr) {
+            const std::vector<uint64_t> key = {
+                reinterpret_cast<uint64_t>(s->d_p.p), reinterpret_cast<uint64_t>(s->d_w.p), reinterpret_cast<uint64_t>(s->d_r.p),
+                reinterpret_cast<uint64_t>(s->d_x.p), reinterpret_cast<uint64_t>(s->d_dinv.p), reinterpret_cast<uint64_t>(s->d_part.p),
+                reinterpret_cast<uint64_t>(s->d_part_pw.p), reinterpret_cast<uint64_t>(ctl), reinterpret_cast<uint64_t>(s->d_hist.p),
+                reinterpret_cast<uint64_t>(s->d_vals.p), reinterpret_cast<uint64_t>(s->d_cols.p), reinterpret_cast<uint64_t>(s->d_rvals.p),
+                reinterpret_cast<uint64_t>(s->d_gvals.p), reinterpret_cast<uint64_t>(s->d_dwords.p), reinterpret_cast<uint64_t>(s->stream),
+                reinterpret_cast<uint64_t>(s->comm_stream), reinterpret_cast<uint64_t>(s->comm), reinterpret_cast<uint64_t>(s->d_send.p),
+                reinterpret_cast<uint64_t>(s->d_recv.p), reinterpret_cast<uint64_t>(sbuf), reinterpret_cast<uint64_t>(s->d_slices_b.p),
+                reinterpret_cast<uint64_t>(s->d_slices_i.p), reinterpret_cast<uint64_t>(s->d_send_lidx.p), reinterpret_cast<uint64_t>(s->d_sh_src.p),
+                static_cast<uint64_t>(s->hist_cap), static_cast<uint64_t>(s->maxits), static_cast<uint64_t>(n), static_cast<uint64_t>(s->n_owned),
+                static_cast<uint64_t>(s->n_send), static_cast<uint64_t>(s->n_sh), static_cast<uint64_t>(s->n_slices_b),
+                static_cast<uint64_t>(s->n_slices_i), static_cast<uint64_t>(gv), static_cast<uint64_t>(spmv_form(s))};
+            if (key != s->mgraph_key || !s->mgraph) {
+                if (s->mgraph) { (void)hipGraphExecDestroy(s->mgraph); s->mgraph = nullptr; }
+                s->mgraph_key.clear();
+                PFEM_HIP(hipStreamSynchronize(s->stream));
+                PFEM_HIP(hipStreamSynchronize(s->comm_stream));
+                bool ok = hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                if (ok) {
+                    for (int k = 0; k < kMultiGraphIters && ok; ++k) ok = multi_iteration(-1, nullptr, nullptr, nullptr, nullptr, nullptr) == PFEM_OK;
+                    hipGraph_t graph = nullptr;
+                    if (hipStreamEndCapture(s->stream, &graph) != hipSuccess || !graph) ok = false;
+                    if (ok && hipGraphInstantiate(&s->mgraph, graph, nullptr, nullptr, 0) != hipSuccess) ok = false;
+                    if (graph) (void)hipGraphDestroy(graph);
+                }
+                if (ok) {
+                    s->mgraph_key = key;
+                } else {        // capture refused (backend, stream kind): stream launches from now on
+                    (void)hipGetLastError();
+                    if (s->mgraph) { (void)hipGraphExecDestroy(s->mgraph); s->mgraph = nullptr; }
+                    s->mgraph_off = true;
+                }
+            }
+            use_mgraph = !s->mgraph_off && s->mgraph != nullptr;
+        }
+    }
+    s->tm.graph_iterations = 0;
+    s->tm.host_enqueue_ms = s->tm.host_comm_ms = 0.0;
+    s->tm.host_enqueued_iterations = 0;
     for (;;) {
         PFEM_HIP(hipMemcpyAsync(s->h_ctl, ctl, sizeof(CgCtl), hipMemcpyDeviceToHost, s->stream));
         PFEM_HIP(hipStreamSynchronize(s->stream));
@@ -2152,11 +2312,20 @@ int run_pcg(pfem_solver *s)
         if (h.flag != 0) break;
         if (it >= s->maxits) { h.flag = -3; break; }   // maxits == 0
         const int it_end = std::min(it + chunk, s->maxits);
+        const auto t_chunk = std::chrono::steady_clock::now();
+        const int it_chunk0 = it;
         for (; it < it_end; ++it) {
             // w = A p, partial (p, A_loc p) over ALL local rows (sub-assembled identity)
             hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
             const size_t ev_per = multi ? 4 : 2;      // multi: one pair for the boundary pass, one for the interior pass
             const bool sample = s->profile_spmv && it % s->profile_every == 0 && ev_used + ev_per <= 8192;
+            if (use_mgraph && !sample && it + kMultiGraphIters <= it_end &&
+                (!s->profile_spmv || it % s->profile_every + kMultiGraphIters <= s->profile_every)) {
+                PFEM_HIP(hipGraphLaunch(s->mgraph, s->stream));        // no sampled iteration inside the unit
+                it += kMultiGraphIters - 1;
+                s->tm.graph_iterations += kMultiGraphIters;
+                continue;
+            }
             if (sample) {
                 while (s->spmv_events.size() < ev_used + ev_per) {
                     hipEvent_t a;
@@ -2173,6 +2342,7 @@ int run_pcg(pfem_solver *s)
                 if (sample) launch_spmv<true>(s, s->d_p.p, s->d_w.p, n, part_pw, ctl, e0, e1);
                 PFEM_HIP(hipGraphLaunch(s->cg_graph[sample ? 1 : 0], s->stream));
                 it += kGraphIters - 1;
+                s->tm.graph_iterations += kGraphIters;
                 continue;
             }
             const double *red_pw = nullptr, *pw_parts = part_pw;
@@ -2187,10 +2357,12 @@ int run_pcg(pfem_solver *s)
                 cev = &s->comm_events[comm_used];
                 comm_used += 8;
             }
+            if (multi && !bpc) {
+                PFEM_TRY(multi_iteration(it, e0, e1, e2, e3, cev));
+                continue;
+            }
             if (multi) {
-                // (1) the slices that hold shared rows, then pack; (2) the neighbour exchange on the communication stream
-                // while (3) the interior slices run; (4) (p,Ap) of this rank -> all-reduce behind the exchange;
-                // (5) the compute stream waits for both and adds the neighbours' partials in rank order
+                // node-block Jacobi on several ranks: the same SpMV / exchange sequence, block kernels below
                 const unsigned nb_blocks = s->n_slices_b > 0 ? spmv_grid(s->n_slices_b) : 0;
                 const unsigned ni_blocks = s->n_slices_i > 0 ? spmv_grid(s->n_slices_i) : 0;
                 if (s->n_slices_b > 0)
@@ -2208,10 +2380,9 @@ int run_pcg(pfem_solver *s)
                 hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s->stream, static_cast<const double *>(part_pw),
                                    static_cast<const double *>(nullptr), static_cast<int>(nb_blocks + ni_blocks), sbuf,
                                    static_cast<const CgCtl *>(ctl));
-                PFEM_TRY(stream_follows(s, s->comm_stream, s->stream));
-                if (cev) PFEM_HIP(hipEventRecord(cev[2], s->comm_stream));
-                PFEM_TRY(s->comm->allreduce(sbuf, 1, s->comm_stream));
-                if (cev) PFEM_HIP(hipEventRecord(cev[3], s->comm_stream));
+                if (cev) PFEM_HIP(hipEventRecord(cev[2], s->stream));
+                PFEM_TRY(s->comm->allreduce(sbuf, 1, s->stream));
+                if (cev) PFEM_HIP(hipEventRecord(cev[3], s->stream));
                 if (cev) PFEM_HIP(hipEventRecord(cev[6], s->stream));
                 PFEM_TRY(stream_follows(s, s->stream, s->comm_stream));
                 if (cev) PFEM_HIP(hipEventRecord(cev[7], s->stream));
@@ -2236,11 +2407,10 @@ int run_pcg(pfem_solver *s)
             auto scalars23 = [&]() -> int {
                 hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s->stream, static_cast<const double *>(part_rz),
                                    static_cast<const double *>(part_zz), static_cast<int>(gv), sbuf + 2, static_cast<const CgCtl *>(ctl));
-                PFEM_TRY(stream_follows(s, s->comm_stream, s->stream));
-                if (cev) PFEM_HIP(hipEventRecord(cev[4], s->comm_stream));
-                PFEM_TRY(s->comm->allreduce(sbuf + 2, 2, s->comm_stream));
-                if (cev) PFEM_HIP(hipEventRecord(cev[5], s->comm_stream));
-                return stream_follows(s, s->stream, s->comm_stream);
+                if (cev) PFEM_HIP(hipEventRecord(cev[4], s->stream));
+                PFEM_TRY(s->comm->allreduce(sbuf + 2, 2, s->stream));
+                if (cev) PFEM_HIP(hipEventRecord(cev[5], s->stream));
+                return PFEM_OK;
             };
             if (bpc) {
                 // residual ping-pong: iteration `it` reads r_a, writes r_b
@@ -2258,12 +2428,14 @@ int run_pcg(pfem_solver *s)
             }
             hipLaunchKernelGGL(k_cg_update, dim3(gv), block, 0, s->stream, ctl, it, n, s->n_owned, pw_parts, pw_n,
                                red_pw, s->d_p.p, s->d_w.p, s->d_dinv.p, s->d_x.p, s->d_r.p, part_rz, part_zz);
-            if (multi) PFEM_TRY(scalars23());
             hipLaunchKernelGGL(k_cg_direction, dim3(gv), block, dir_lds, s->stream, ctl, it, n, part_rz, part_zz, static_cast<int>(gv),
                                red2, s->d_r.p, s->d_dinv.p, s->d_p.p, s->d_hist.p, s->hist_cap, s->maxits, s->d_x.p);
         }
         PFEM_TRY(check_kernel("pcg iteration"));
+        s->tm.host_enqueue_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_chunk).count();
+        s->tm.host_enqueued_iterations += it - it_chunk0;
     }
+    s->tm.host_comm_ms = host_comm_s * 1e3;
     s->last_its = h.its;
     s->last_reason = (h.flag == 2 && h.rn <= s->abstol) ? 3 : h.flag;
     s->last_rnorm = h.rn;
@@ -2275,7 +2447,9 @@ int run_pcg(pfem_solver *s)
     const size_t live = std::min(ev_used / ev_per, (static_cast<size_t>(h.its) + s->profile_every - 1) / s->profile_every);
     for (size_t k = 0; k < live; ++k) {
         for (size_t q = 0; q < ev_per; q += 2) {
-            if (multi && ((q == 0 && s->n_slices_b == 0) || (q == 2 && s->n_slices_i == 0))) continue;   // pass not launched
+            const bool split = multi && (bpc || overlap);          // boundary + interior pass, one event pair each
+            if (split && ((q == 0 && s->n_slices_b == 0) || (q == 2 && s->n_slices_i == 0))) continue;   // pass not launched
+            if (multi && !split && q == 2) continue;               // one pass over all slices
             float f = 0.f;
             PFEM_HIP(hipEventElapsedTime(&f, s->spmv_events[ev_per * k + q], s->spmv_events[ev_per * k + q + 1]));
             s->tm.spmv_ms_total += f;

@@ -9,7 +9,7 @@ halo) and ``VecDot`` (MPI_Allreduce) for the reference (solverpetsc.F:447-476):
   NEIGHBOUR exchange of those partials (each rank adds them in ascending rank order), overlapped with
   the interior part of the SpMV, and the CG scalars ride in two small all-reduces;
 * transport: RCCL over xGMI, bound inside the C++ library (``pfem_solver_set_comm_rccl``) -- this
-  module only carries the 128-byte unique id from rank 0 to the others; or host hooks over a
+  module only carries the 256 bytes of the two unique ids from rank 0 to the others; or host hooks over a
   ``torch.distributed`` group that works on host memory (gloo: the tests where ranks share a GPU).
 
 The neighbour plan is pure integer host logic (``pfem_neighbour_plan``) and is what the world_size-2/3

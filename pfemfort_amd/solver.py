@@ -283,7 +283,7 @@ class PetscSolver:
         L.check(L.lib().pfem_solver_set_neighbours(self._h, len(pe), _p(pe), _p(off), _p(g)), "pfem_solver_set_neighbours")
 
     def setCommRccl(self, rank, nranks, unique_id: bytes):
-        """RCCL bound inside the library; ``unique_id`` = the 128 bytes of ``rccl_unique_id()`` from rank 0."""
+        """RCCL bound inside the library; ``unique_id`` = the bytes of ``rccl_unique_id()`` from rank 0."""
         assert len(unique_id) == L.RCCL_ID_BYTES
         buf = C.create_string_buffer(bytes(unique_id), L.RCCL_ID_BYTES)
         L.check(L.lib().pfem_solver_set_comm_rccl(self._h, rank, nranks, buf), "pfem_solver_set_comm_rccl")

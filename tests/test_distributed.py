@@ -7,9 +7,9 @@ diagonal and right-hand side (oracle, this rank's elements only) over the plan a
 assembled global ones.  No restatement of the CG loop lives here: the device loop is tested on the GPU, below.
 
 GPU: 2-3 ranks share cuda:0; the library stages its packed buffers through pinned host memory and the hooks move
-them with gloo (what the MPI flavour does with MPI): the real C++/HIP multi-rank loop (boundary slices -> neighbour
-exchange overlapped with the interior slices -> rank-ordered sums -> two scalar all-reduces) against the ORACLE's
-direct solve and iteration count.  RCCL itself refuses two ranks on one device: it is exercised with world_size 1
+them with gloo (what the MPI flavour does with MPI): the real C++/HIP multi-rank loop (SpMV -> neighbour exchange ->
+rank-ordered sums -> two scalar all-reduces; in order, and in its overlapped form with boundary slices first)
+against the ORACLE's direct solve and iteration count.  RCCL itself refuses two ranks on one device: it is exercised with world_size 1
 (communicator, all-reduce, grouped send/recv to self, a solve whose scalars go through ncclAllReduce).
 """
 import os
@@ -196,6 +196,8 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
         from pfemfort_amd import distributed as PD
         from pfemfort_amd import host as H
         kind = pf.POISSON_TET if mesh_args["ndof"] == 1 else pf.ELAST_TET
+        if mesh_args.get("overlap"):        # the overlapped form of the iteration (boundary slices, second stream)
+            os.environ["PFEM_MULTI_OVERLAP"] = "1"
         mesh, dm, conn_loc, xyz_new, edof_g, rs, re = _rank_setup(rank, world, mesh_args, H)
         s = pf.PetscSolver().initialise(re - rs, dm.size_global, row_start=rs, device=0)
         s.setTolerances(rtol=1e-10)
@@ -257,7 +259,8 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                                                             ("poisson", 2, "slabs", "compat"), ("elast", 3, "sectors", "compat"),
                                                             ("elast", 2, "slabs", "pbjacobi"), ("elast", 3, "sectors", "pbjacobi"),
                                                             ("poisson", 2, "slabs", "pbjacobi"), ("poisson", 3, "sectors", "int32"),
-                                                            ("poisson", 3, "idle", "batched"), ("elast", 3, "idle", "pbjacobi")])
+                                                            ("poisson", 3, "idle", "batched"), ("elast", 3, "idle", "pbjacobi"),
+                                                            ("poisson", 2, "slabs", "overlap"), ("elast", 3, "sectors", "overlap")])
 def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partition, mode):
     """2-3 ranks share cuda:0 (host-staged exchange over gloo): the product's multi-rank device loop against the
     ORACLE -- a direct solve of the oracle-assembled global system in the partition's new numbering, and the oracle's
@@ -275,6 +278,8 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
         mesh_args["spmv"] = "grouped"
     if mode == "pbjacobi":            # node-block Jacobi on several ranks (blocks of shared nodes summed, groups voted)
         mesh_args["mode"], mesh_args["pc"] = "batched", "pbjacobi"
+    if mode == "overlap":             # boundary slices first, exchange on the second stream under the interior slices
+        mesh_args["mode"], mesh_args["overlap"] = "batched", True
     if mode == "int32":               # the int32-column SpMV form through the boundary / interior slice lists
         mesh_args["mode"], mesh_args["spmv"] = "batched", "int32"
     if mode == "compat":
@@ -307,13 +312,19 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
         got[int(d["rs"]):int(d["re"])] = d["x"]
         assert int(d["reason"]) == 2 and abs(int(d["its"]) - its_oracle) <= its_tol
         # per iteration: one exchange and two all-reduces; every rank issued the same KIND of call in the same order
-        assert int(d["calls"]) >= 3 * int(d["its"])
-        kinds = np.array([s[0] for s in d["log"]])
-        assert np.array_equal(kinds, np.array([s[0] for s in np.load(tmp_path / "rank0.npz")["log"]]))
+        idle = int(d["n_peers"]) == 0                        # a rank without neighbours has nothing to exchange
+        assert int(d["calls"]) >= (2 if idle else 3) * int(d["its"])
+        kinds = [s[0] for s in d["log"]]
+        kinds0 = [s[0] for s in np.load(tmp_path / "rank0.npz")["log"]]
+        if idle:
+            kinds0 = [k for k in kinds0 if k == "a"]
+        assert kinds == kinds0
         if partition == "idle" and r == world - 1:      # an idle rank owns nothing and shares nothing, but takes part in
             assert int(d["n_peers"]) == 0 and int(d["re"]) == int(d["rs"])       # every all-reduce and agrees on the verdict
         else:
-            assert int(d["n_peers"]) >= 1 and 0 < int(d["slices_b"]) <= int(d["slices"])
+            assert int(d["n_peers"]) >= 1
+            if mode in ("overlap", "pbjacobi") or mesh_args.get("pc"):
+                assert 0 < int(d["slices_b"]) <= int(d["slices"])
         if "x2" in d.files:
             got2[int(d["rs"]):int(d["re"])] = d["x2"]
             assert int(d["reason2"]) == 2

@@ -20,6 +20,8 @@ sys.path.insert(0, ROOT)
 
 
 def main():
+    import faulthandler
+    faulthandler.enable()
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     its = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     import torch.distributed as dist
@@ -38,11 +40,12 @@ def main():
     s.generateBoxMesh(pf.POISSON_TET, -1.0, 1.0, n, -1.0, 1.0, n, -1.0, 1.0, n)
     s.buildPattern()
     s.assemble(H.POISSON_ELEMDATA, H.TIMEDATA)
-    s.profileSpmv(4)
+    s.profileSpmv(32)
     s.factoriseAndSolve()
     i1, r1, _ = s.factoriseAndSolve()
     t1 = s.timings()
     single = {"iterations": i1, "reason": r1, "ms_per_iteration": t1["solve_ms"] / max(i1, 1),
+              "host_enqueue_ms_per_iteration": t1["host_enqueue_ms"] / max(t1["host_enqueued_iterations"], 1),
               "spmv_ms": t1["spmv_ms_total"] / max(t1["spmv_launches"], 1) - t1["event_overhead_ms"]}
     # the plan: one neighbour (this rank), sharing the first and the last free z-plane
     m = n - 1
@@ -65,7 +68,10 @@ def main():
                                "two_allreduces_ms_on_comm_stream": t2["scalar_ms_total"] / c,
                                "compute_stream_waited_ms": t2["exposed_ms_total"] / c, "samples": t2["comm_samples"],
                                "bytes_per_exchange": 8 * info["doubles_per_exchange"],
-                               "boundary_slices": info["boundary_slices"], "slices": info["total_slices"]}}
+                               "boundary_slices": info["boundary_slices"], "slices": info["total_slices"],
+                               "iterations_replayed_from_graph": t2["graph_iterations"],
+                               "host_enqueue_ms_per_iteration": t2["host_enqueue_ms"] / max(t2["host_enqueued_iterations"], 1),
+                               "host_ms_inside_rccl_calls_per_iteration": t2["host_comm_ms"] / max(t2["host_enqueued_iterations"], 1)}}
     print(json.dumps(out))
     s.free()
     dist.destroy_process_group()
