@@ -226,6 +226,7 @@ struct pfem_solver {
     }
     // SpMV-only relative row groups (k_spmvr): 4 consecutive rows, one relative column stream
     bool relgrouped = false;
+    bool rel_gap32 = false;        // ... with one 32-bit gap per entry (offsets further apart than 65535: k_spmvr32)
     int64_t n_rgroups = 0, n_rslices = 0, r_stored = 0;
     DevBuf<int32_t> d_rcol0;
     DevBuf<int64_t> d_rslice_off, d_rslice_doff;
@@ -1307,8 +1308,9 @@ int build_groups(pfem_solver *s)
 int build_rel_groups(pfem_solver *s)
 {
     s->relgrouped = false;
+    s->rel_gap32 = false;
     const int64_t n = s->n_loc;
-    if (!s->cols16 || s->grouped || n < kRelRows || n > INT_MAX - kRelRows) return PFEM_OK;
+    if (s->grouped || n < kRelRows || n > INT_MAX - kRelRows) return PFEM_OK;
     s->n_rgroups = (n + kRelRows - 1) / kRelRows;
     s->n_rslices = (s->n_rgroups + 63) / 64;
     DevBuf<int64_t> entries, words;
@@ -1321,9 +1323,10 @@ int build_rel_groups(pfem_solver *s)
     hipLaunchKernelGGL(k_rel_sizes, dim3(grid_for(s->n_rslices * 64)), dim3(kBlock), 0, s->stream, s->sell(), s->n_rgroups,
                        s->n_rslices, entries.p, s->d_err.p);
     PFEM_TRY(check_kernel("k_rel_sizes"));
-    int overflow = 0;
+    int overflow = 0;            // bit 0: a gap needs more than 16 bits; bit 1: a first column outside int32
     PFEM_TRY(fetch_err(s, &overflow));
     PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
+    const bool gap32 = (overflow & 1) != 0;
     const int nsl = static_cast<int>(s->n_rslices + 1);
     size_t tb = 0;
     PFEM_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, entries.p, s->d_rslice_off.p, nsl, s->stream));
@@ -1332,15 +1335,19 @@ int build_rel_groups(pfem_solver *s)
     int64_t tot_e = 0;
     PFEM_HIP(hipMemcpyAsync(&tot_e, s->d_rslice_off.p + s->n_rslices, sizeof(int64_t), hipMemcpyDeviceToHost, s->stream));
     PFEM_HIP(hipStreamSynchronize(s->stream));
-    // bytes streamed per SpMV: (8*kRelRows + 2) per union entry against (8 + 2) per stored entry of the row form
-    const double rel_bytes = static_cast<double>(tot_e) * (8.0 * kRelRows + 2.0), row_bytes = static_cast<double>(s->stored) * 10.0;
-    if (overflow || rel_bytes > 0.95 * row_bytes) {
+    // bytes streamed per SpMV: (8*kRelRows + 2 or 4) per union entry against (8 + 2) per stored entry of the 16-bit row
+    // form, (8 + 4) with int32 columns
+    const double rel_bytes = static_cast<double>(tot_e) * (8.0 * kRelRows + (gap32 ? 4.0 : 2.0));
+    const double row_bytes = static_cast<double>(s->stored) * (s->cols16 ? 10.0 : 12.0);
+    if ((overflow & 2) || rel_bytes > 0.95 * row_bytes) {
         s->d_rslice_off.release();
         s->d_rslice_doff.release();
         return PFEM_OK;
     }
-    hipLaunchKernelGGL(k_cols16_sizes, dim3(grid_for(s->n_rslices + 1)), dim3(kBlock), 0, s->stream,
-                       static_cast<const int64_t *>(s->d_rslice_off.p), s->n_rslices, words.p);
+    if (gap32) hipLaunchKernelGGL(k_gap32_sizes, dim3(grid_for(s->n_rslices + 1)), dim3(kBlock), 0, s->stream,
+                                  static_cast<const int64_t *>(s->d_rslice_off.p), s->n_rslices, words.p);
+    else hipLaunchKernelGGL(k_cols16_sizes, dim3(grid_for(s->n_rslices + 1)), dim3(kBlock), 0, s->stream,
+                            static_cast<const int64_t *>(s->d_rslice_off.p), s->n_rslices, words.p);
     PFEM_TRY(check_kernel("k_cols16_sizes"));
     PFEM_HIP(hipcub::DeviceScan::ExclusiveSum(temp.p, tb, words.p, s->d_rslice_doff.p, nsl, s->stream));
     int64_t tot_w = 0;
@@ -1351,12 +1358,18 @@ int build_rel_groups(pfem_solver *s)
     s->r_gap_words = tot_w;
     PFEM_TRY(s->d_rdwords.alloc(static_cast<size_t>(std::max<int64_t>(tot_w, 1))));
     PFEM_TRY(s->d_rvals.alloc(static_cast<size_t>(std::max<int64_t>(tot_e, 1)) * kRelRows));
-    hipLaunchKernelGGL(k_rel_cols_fill, dim3(grid_for(s->n_rslices * 64)), dim3(kBlock), 0, s->stream, s->sell(), s->n_rgroups,
-                       s->n_rslices, static_cast<const int64_t *>(s->d_rslice_off.p),
-                       static_cast<const int64_t *>(s->d_rslice_doff.p), s->d_rcol0.p, s->d_rdwords.p);
+    if (gap32)
+        hipLaunchKernelGGL(k_rel_cols_fill<true>, dim3(grid_for(s->n_rslices * 64)), dim3(kBlock), 0, s->stream, s->sell(), s->n_rgroups,
+                           s->n_rslices, static_cast<const int64_t *>(s->d_rslice_off.p),
+                           static_cast<const int64_t *>(s->d_rslice_doff.p), s->d_rcol0.p, s->d_rdwords.p);
+    else
+        hipLaunchKernelGGL(k_rel_cols_fill<false>, dim3(grid_for(s->n_rslices * 64)), dim3(kBlock), 0, s->stream, s->sell(), s->n_rgroups,
+                           s->n_rslices, static_cast<const int64_t *>(s->d_rslice_off.p),
+                           static_cast<const int64_t *>(s->d_rslice_doff.p), s->d_rcol0.p, s->d_rdwords.p);
     PFEM_TRY(check_kernel("k_rel_cols_fill"));
     PFEM_HIP(hipStreamSynchronize(s->stream));
     s->relgrouped = true;
+    s->rel_gap32 = gap32;
     return PFEM_OK;
 }
 
@@ -1364,8 +1377,12 @@ int build_rel_groups(pfem_solver *s)
 int refresh_group_vals(pfem_solver *s)
 {
     if (s->use_rel() && s->group_vals_stale) {
-        hipLaunchKernelGGL(k_rel_vals, dim3(static_cast<unsigned>(s->n_rslices)), dim3(kBlock), 0, s->stream, s->sell(), s->sellr(),
-                           s->d_rvals.p);
+        if (s->rel_gap32)
+            hipLaunchKernelGGL(k_rel_vals<true>, dim3(static_cast<unsigned>(s->n_rslices)), dim3(kBlock), 0, s->stream, s->sell(), s->sellr(),
+                               s->d_rvals.p);
+        else
+            hipLaunchKernelGGL(k_rel_vals<false>, dim3(static_cast<unsigned>(s->n_rslices)), dim3(kBlock), 0, s->stream, s->sell(), s->sellr(),
+                               s->d_rvals.p);
         PFEM_TRY(check_kernel("k_rel_vals"));
         s->group_vals_stale = false;
         return PFEM_OK;
@@ -1398,7 +1415,10 @@ void launch_spmv(pfem_solver *s, const double *x, double *y, int64_t n_dot, doub
         else hipLaunchKernelGGL(k_spmvg<WITH_DOT>, grid, block, 0, s->stream, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
     } else if (s->use_rel()) {
         SellRDev G = s->sellr();
-        if (e0) hipExtLaunchKernelGGL(k_spmvr<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
+        if (s->rel_gap32) {
+            if (e0) hipExtLaunchKernelGGL(k_spmvr32<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
+            else hipLaunchKernelGGL(k_spmvr32<WITH_DOT>, grid, block, 0, s->stream, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
+        } else if (e0) hipExtLaunchKernelGGL(k_spmvr<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
         else hipLaunchKernelGGL(k_spmvr<WITH_DOT>, grid, block, 0, s->stream, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
     } else if (s->cols16 && s->spmv_format != PFEM_SPMV_INT32) {
         Sell16Dev C{s->d_col0.p, s->d_dwords.p, s->d_slice_doff.p};
@@ -1415,7 +1435,8 @@ void launch_spmv(pfem_solver *s, const double *x, double *y, int64_t n_dot, doub
 extern "C" int pfem_solver_get_spmv_format(pfem_solver *s, int *bits_per_column)
 {
     if (!s || !bits_per_column) return PFEM_ERR_ARG;
-    *bits_per_column = (s->cols16 && s->spmv_format != PFEM_SPMV_INT32) ? 16 : 32;
+    if (s->use_rel()) *bits_per_column = s->rel_gap32 ? 32 : 16;
+    else *bits_per_column = (s->cols16 && s->spmv_format != PFEM_SPMV_INT32) ? 16 : 32;
     return PFEM_OK;
 }
 
@@ -1900,7 +1921,7 @@ int scalar_allreduce(pfem_solver *s, int at, int n)
 // which SpMV form the next launch uses (key of the slice lists and of the captured graph)
 inline int spmv_form(const pfem_solver *s)
 {
-    return s->use_grouped() ? 3 : (s->use_rel() ? 4 : ((s->cols16 && s->spmv_format != PFEM_SPMV_INT32) ? 2 : 1));
+    return s->use_grouped() ? 3 : (s->use_rel() ? (s->rel_gap32 ? 5 : 4) : ((s->cols16 && s->spmv_format != PFEM_SPMV_INT32) ? 2 : 1));
 }
 
 // boundary / interior slice lists of the SpMV form in use
@@ -1908,7 +1929,7 @@ int build_slice_lists(pfem_solver *s)
 {
     const int fmt = spmv_form(s);
     if (s->slices_fmt == fmt) return PFEM_OK;
-    const int64_t ns = fmt == 3 ? s->n_gslices : (fmt == 4 ? s->n_rslices : s->n_slices);
+    const int64_t ns = fmt == 3 ? s->n_gslices : (fmt >= 4 ? s->n_rslices : s->n_slices);
     std::vector<char> flag(static_cast<size_t>(std::max<int64_t>(ns, 1)), 0);
     if (s->n_sh > 0 && ns > 0) {
         DevBuf<char> d_flag;
@@ -1917,7 +1938,7 @@ int build_slice_lists(pfem_solver *s)
         PFEM_HIP(hipMemsetAsync(d_flag.p, 0, static_cast<size_t>(ns), s->stream));
         const int32_t *rg = nullptr;
         int shift = 6;                                  // 64 rows per slice
-        if (fmt == 4) shift = 8;                        // 64 groups of kRelRows = 4 consecutive rows
+        if (fmt == 4 || fmt == 5) shift = 8;            // 64 groups of kRelRows = 4 consecutive rows
         if (fmt == 3) {                                 // 64 groups of up to 3 rows: look the group up
             PFEM_TRY(d_row_group.alloc(static_cast<size_t>(s->n_loc)));
             hipLaunchKernelGGL(k_row_group_index, dim3(grid_for(s->n_groups)), dim3(kBlock), 0, s->stream,

@@ -1026,11 +1026,13 @@ __device__ inline void ctl_publish(CgCtl *ctl, int flag, int its)
 {
     const unsigned long long w = static_cast<unsigned long long>(static_cast<unsigned>(flag)) |
                                  (static_cast<unsigned long long>(static_cast<unsigned>(its)) << 32);
-    __atomic_store_n(reinterpret_cast<unsigned long long *>(&ctl->flag), w, __ATOMIC_RELAXED);
+    // agent scope: the readers are blocks of this device (the host reads the block after a stream sync)
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&ctl->flag), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ inline bool ctl_finished_before(const CgCtl *ctl, int it)
 {
-    const unsigned long long w = __atomic_load_n(reinterpret_cast<const unsigned long long *>(&ctl->flag), __ATOMIC_RELAXED);
+    const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(&ctl->flag), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
     return static_cast<int>(w & 0xffffffffu) != 0 && static_cast<int>(w >> 32) != it + 1;
 }
 
@@ -1101,6 +1103,16 @@ __global__ void __launch_bounds__(kBlock) k_cols16_sizes(const int64_t *slice_of
     if (s == n_slices) { slice_words[s] = 0; return; }
     const int width = static_cast<int>((slice_off[s + 1] - slice_off[s]) >> 6);
     slice_words[s] = 64LL * (width > 1 ? (width / 2) : 0);     // ceil((width-1)/2) == width/2
+}
+
+// 32-bit gaps (relative row groups whose offsets are further apart than 65535): one word per entry after the first
+__global__ void __launch_bounds__(kBlock) k_gap32_sizes(const int64_t *slice_off, int64_t n_slices, int64_t *slice_words)
+{
+    const int64_t s = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (s > n_slices) return;
+    if (s == n_slices) { slice_words[s] = 0; return; }
+    const int width = static_cast<int>((slice_off[s + 1] - slice_off[s]) >> 6);
+    slice_words[s] = 64LL * (width > 1 ? width - 1 : 0);
 }
 
 // one thread per row: first column + packed gaps; *overflow is set if a gap needs > 16 bits
@@ -1650,12 +1662,14 @@ __global__ void __launch_bounds__(kBlock) k_rel_sizes(SellDev A, int64_t n_group
         const int nr = static_cast<int>(min(static_cast<int64_t>(kRelRows), A.n_rows - r0));
         int64_t prev = 0;
         bool bad = false;
+        bool wide = false;
         u = rel_union_walk(A, r0, nr, [&](int k, int64_t o) {
-            if (k > 0 && o - prev > 65535) bad = true;
+            if (k > 0 && o - prev > 65535) wide = true;                  // needs the 32-bit gap stream
             if (k == 0 && (r0 + o < INT32_MIN || r0 + o > INT32_MAX)) bad = true;
             prev = o;
         });
-        if (bad) atomicMax(overflow, 1);
+        if (wide) atomicOr(overflow, 1);
+        if (bad) atomicOr(overflow, 2);
     }
     int c = u;
 #pragma unroll
@@ -1665,6 +1679,7 @@ __global__ void __launch_bounds__(kBlock) k_rel_sizes(SellDev A, int64_t n_group
     if (g == 0) entries[n_gslices] = 0;
 }
 
+template <bool GAP32>
 __global__ void __launch_bounds__(kBlock) k_rel_cols_fill(SellDev A, int64_t n_groups, int64_t n_gslices,
                                                            const int64_t *gslice_off, const int64_t *gslice_doff, int32_t *col0,
                                                            uint32_t *dwords)
@@ -1675,7 +1690,8 @@ __global__ void __launch_bounds__(kBlock) k_rel_cols_fill(SellDev A, int64_t n_g
     const int lane = static_cast<int>(g & 63);
     const int width = static_cast<int>((gslice_off[gs + 1] - gslice_off[gs]) >> 6);
     uint32_t *wp = dwords + gslice_doff[gs] + lane;
-    for (int j = 0; 2 * j + 1 < width; ++j) wp[64LL * j] = 0u;        // pads: gap 0
+    if (GAP32) { for (int j = 0; j + 1 < width; ++j) wp[64LL * j] = 0u; }
+    else { for (int j = 0; 2 * j + 1 < width; ++j) wp[64LL * j] = 0u; }        // pads: gap 0
     const int64_t r0 = g * kRelRows;
     col0[g] = static_cast<int32_t>(g < n_groups ? r0 : 0);          // empty group: any valid address
     if (g >= n_groups) return;
@@ -1683,6 +1699,7 @@ __global__ void __launch_bounds__(kBlock) k_rel_cols_fill(SellDev A, int64_t n_g
     int64_t prev = 0;
     rel_union_walk(A, r0, nr, [&](int k, int64_t o) {
         if (k == 0) col0[g] = static_cast<int32_t>(r0 + o);
+        else if (GAP32) wp[64LL * (k - 1)] = static_cast<uint32_t>(o - prev);
         else {
             const int j = (k - 1) >> 1, h = (k - 1) & 1;
             wp[64LL * j] |= (static_cast<uint32_t>(o - prev) & 0xffffu) << (16 * h);
@@ -1694,6 +1711,7 @@ __global__ void __launch_bounds__(kBlock) k_rel_cols_fill(SellDev A, int64_t n_g
 // matrix values, row form -> relative-group form (explicit zeros where a row lacks an offset); once per solve.
 // One 256-thread block per slice of 64 groups; wave p converts row r0+p of every group, so its stores are 512-B
 // runs and the four waves of the block share the row-form lines they read.
+template <bool GAP32>
 __global__ void __launch_bounds__(kBlock) k_rel_vals(SellDev A, SellRDev G, double *out)
 {
     static_assert(kBlock == 64 * kRelRows, "one wave per row of the group");
@@ -1713,8 +1731,11 @@ __global__ void __launch_bounds__(kBlock) k_rel_vals(SellDev A, SellRDev G, doub
     int j = 0;
     for (int k = 0; k < width; ++k) {
         if (k > 0) {
-            const uint32_t w = wp[64LL * ((k - 1) >> 1)];
-            c += ((k - 1) & 1) ? (w >> 16) : (w & 0xffffu);
+            if (GAP32) c += wp[64LL * (k - 1)];
+            else {
+                const uint32_t w = wp[64LL * ((k - 1) >> 1)];
+                c += ((k - 1) & 1) ? (w >> 16) : (w & 0xffffu);
+            }
         }
         double v = 0.0;
         while (j < len && A.cols[base + 64LL * j] < c) ++j;
@@ -1797,6 +1818,81 @@ __global__ void __launch_bounds__(kBlock) k_spmvr(SellRDev G, int64_t n_rows, co
                     acc[p] = __builtin_fma(__builtin_nontemporal_load(vp + 64 * (kRelRows * (2 * j + 2) + p)), xv[p], acc[p]);
             }
             c = c1;
+        }
+        const int64_t r0 = ((gs << 6) + lane) * kRelRows;
+#pragma unroll
+        for (int p = 0; p < kRelRows; ++p)
+            if (r0 + p < n_rows) {
+                y[r0 + p] = acc[p];
+                if (WITH_DOT && r0 + p < n_dot) dot = __builtin_fma(x[r0 + p], acc[p], dot);
+            }
+    }
+    if (WITH_DOT) {
+        const double t = block_sum(dot, sm);
+        if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    }
+}
+
+// The same kernel for offsets further apart than 65535 (400^3: the z-neighbour is 159 201 rows away): one 32-bit gap per
+// entry, 8 + 1 B per nonzero instead of 8 + 1/2 (the int32 row form costs 8 + 4).  Four entries per trip: 4 gap words one
+// trip ahead, 16 value loads + 4 x quads in flight.
+template <bool WITH_DOT>
+__global__ void __launch_bounds__(kBlock) k_spmvr32(SellRDev G, int64_t n_rows, const double *__restrict__ x,
+                                                     double *__restrict__ y, int64_t n_dot, double *partial, const CgCtl *ctl,
+                                                     SliceSel sel)
+{
+    __shared__ double sm[4];
+    if (WITH_DOT && ctl->flag != 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t gs = pick_slice(sel, (static_cast<int64_t>(blockIdx.x) << 2) + wave, G.n_gslices);
+    double dot = 0.0;
+    if (gs < G.n_gslices) {
+        const int64_t off = G.gslice_off[gs];
+        const int width = static_cast<int>((G.gslice_off[gs + 1] - off) >> 6);
+        const double *__restrict__ vp = G.vals + kRelRows * off + lane;
+        const uint32_t *__restrict__ wp = G.dwords + G.gslice_doff[gs] + lane;      // word k-1 = gap before entry k
+        int c = __builtin_nontemporal_load(G.col0 + (gs << 6) + lane);
+        double acc[kRelRows] = {0.0, 0.0, 0.0, 0.0};
+        if (width > 0) {
+            double xv[kRelRows];
+            load_x4(x, c, xv);
+#pragma unroll
+            for (int p = 0; p < kRelRows; ++p) acc[p] = __builtin_nontemporal_load(vp + 64 * p) * xv[p];
+        }
+        int k = 1;
+        uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+        if (k + 4 <= width) {
+            g0 = __builtin_nontemporal_load(wp + 64 * (k - 1)); g1 = __builtin_nontemporal_load(wp + 64 * k);
+            g2 = __builtin_nontemporal_load(wp + 64 * (k + 1)); g3 = __builtin_nontemporal_load(wp + 64 * (k + 2));
+        }
+        while (k + 4 <= width) {
+            const int c0 = c + static_cast<int>(g0), c1 = c0 + static_cast<int>(g1);
+            const int c2 = c1 + static_cast<int>(g2), c3 = c2 + static_cast<int>(g3);
+            double v[4][kRelRows], xv[4][kRelRows];
+            load_x4(x, c0, xv[0]); load_x4(x, c1, xv[1]); load_x4(x, c2, xv[2]); load_x4(x, c3, xv[3]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int p = 0; p < kRelRows; ++p) v[t][p] = __builtin_nontemporal_load(vp + 64 * (kRelRows * (k + t) + p));
+            c = c3;
+            k += 4;
+            if (k + 4 <= width) {
+                g0 = __builtin_nontemporal_load(wp + 64 * (k - 1)); g1 = __builtin_nontemporal_load(wp + 64 * k);
+                g2 = __builtin_nontemporal_load(wp + 64 * (k + 1)); g3 = __builtin_nontemporal_load(wp + 64 * (k + 2));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int p = 0; p < kRelRows; ++p) acc[p] = __builtin_fma(v[t][p], xv[t][p], acc[p]);
+        }
+        for (; k < width; ++k) {
+            c += static_cast<int>(__builtin_nontemporal_load(wp + 64 * (k - 1)));
+            double xv[kRelRows];
+            load_x4(x, c, xv);
+#pragma unroll
+            for (int p = 0; p < kRelRows; ++p)
+                acc[p] = __builtin_fma(__builtin_nontemporal_load(vp + 64 * (kRelRows * k + p)), xv[p], acc[p]);
         }
         const int64_t r0 = ((gs << 6) + lane) * kRelRows;
 #pragma unroll

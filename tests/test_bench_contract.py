@@ -61,3 +61,26 @@ def test_bench_two_ranks_sharing_the_device():
     c = d["comm"]
     assert c["neighbours"] == 1 and c["bytes_per_neighbour"] == 8 * (side - 1) ** 2 and c["samples"] > 0
     assert 0 < c["boundary_slices"] < c["slices"] and c["interface_exchange_ms"] > 0 and c["scalar_allreduce_ms"] > 0
+
+
+@pytest.mark.gpu
+def test_config5_at_full_size_with_eight_ranks_sharing_the_device():
+    """BASELINE configs[4] -- the 400x400x400x6 cube (384 M tets, 63.5 M free dofs) on 8 ranks -- functionally and at full
+    size on the one GPU a test box has: eight processes share the MI355X (8 GB each), exchange through gloo host hooks, and
+    solve the whole problem.  Not a performance figure; it pins the per-rank device generator, the neighbour plan
+    (one or two faces of 399^2 dofs), the 32-bit-gap relative-row-group SpMV that slabs of this size need, and the
+    multi-rank loop at the size the scaling run uses."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0",
+                        "--backend", "gloo", "--same-device"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    assert d["config"]["free_dofs"] == 63521199 and d["config"]["elements"] == 384000000 and d["n_gpus"] == 8
+    assert d["converged_reason"] == 2 and 600 < d["iterations"] < 800 and d["max_nodal_error"] < 1e-3
+    c = d["comm"]
+    assert c["bytes_per_neighbour"] == 8 * 399 ** 2 and c["neighbours"] == 1            # rank 0: one face
+    assert "k_spmvr32" in d["roofline"]["kernel"]

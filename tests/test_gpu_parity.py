@@ -503,3 +503,26 @@ def test_device_generated_box_equals_host_generator_and_bookkeeping(kind, box, b
         for x, y in zip(a.getCSR(), b.getCSR()):
             assert np.array_equal(x, y)
         assert np.array_equal(a.getRHS(), b.getRHS())
+
+
+def test_relative_row_groups_with_32bit_gaps():
+    """A plane of more than 65 535 free nodes (here 257^2; BASELINE config 5's slabs have 399^2): the z-neighbour is further
+    away than a 16-bit gap can say.  The relative-row-group SpMV then streams one 32-bit gap per entry (k_spmvr32) instead
+    of falling back to int32 columns per row: same products, same order, same bits; and the solve agrees with the oracle."""
+    mesh = H.gen_box_tets(-1, 1, 258, -1, 1, 258, -1, 1, 4)
+    s, dm = _device_problem(pf.POISSON_TET, mesh, H.POISSON_ELEMDATA)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(dm.size_global)
+    s.setSpmvFormat("int32")
+    y32 = s.spmv(x)
+    assert (s.spmvRowGroup(), s.spmvColumnBits()) == (1, 32)
+    s.setSpmvFormat("grouped")                                   # the group forms whatever the size
+    assert (s.spmvRowGroup(), s.spmvColumnBits()) == (4, 32)      # relative groups, 32-bit gap stream
+    assert np.array_equal(s.spmv(x), y32)
+    assert s.spmvFormatBytes() < 0.8 * (12 * s.matrixInfo()["nnz"] + 20 * dm.size_global)
+    s.setTolerances(rtol=1e-10)
+    its, reason, _ = s.factoriseAndSolve()
+    prob = O.setup_problem(O.POISSON_TET, _omesh(mesh))
+    xo, its_o, reason_o, *_ = O.pcg_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-10)
+    assert reason == reason_o == 2 and abs(its - its_o) <= 1
+    assert np.abs(s.getSolution() - xo).max() <= U_ATOL
