@@ -248,6 +248,10 @@ int pfem_assemble(pfem_solver *s, const double *elemData, const double *timeData
 #define PFEM_ASSEMBLY_GATHER 0
 #define PFEM_ASSEMBLY_SCATTER 1
 int pfem_solver_set_assembly_mode(pfem_solver *s, int mode);
+/* what pfem_assemble does with the current pattern: gather form in effect (1/0); nodes whose rows are too long for the
+ * gather records (> 255 entries: "hubs" -- their rows alone are assembled by a scatter pass with atomics, every other
+ * row keeps one writer); threads and LDS bytes per block of the row-accumulating gather kernels                      */
+int pfem_solver_assembly_info(pfem_solver *s, int *gather_form, int *hub_nodes, int *block_threads, int64_t *lds_bytes);
 /* Matrix encoding streamed by the SpMV.  AUTO uses 16-bit gaps between the ascending columns of a
  * row (4 + 2 B per entry instead of 4 B) whenever every gap of the pattern fits, and on top of that
  * serves consecutive rows with identical column sets (the dof rows of a node) from one lane with a

@@ -95,6 +95,7 @@ SIGNATURES = {
     "pfem_pattern_build": [_P],
     "pfem_assemble": [_P, _P, _P],
     "pfem_solver_set_assembly_mode": [_P, _I],
+    "pfem_solver_assembly_info": [_P, _P, _P, _P, _P],
     "pfem_solver_set_spmv_format": [_P, _I],
     "pfem_solver_get_spmv_format": [_P, _P],
     "pfem_solver_get_spmv_row_group": [_P, _P],

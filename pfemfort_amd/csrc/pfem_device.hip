@@ -196,6 +196,9 @@ struct pfem_solver {
     DevBuf<uint16_t> d_inc_flags;  // ... with the constrained-dof bits of the element (kinds with ndof > 1)
     DevBuf<int32_t> d_node_row;    // [nNode*ndof] matrix row of every node dof, -1 = no row
     int rows_threads = 0;    // block size of the LDS-row gather kernels (256/128/64), 0 = rows too long
+    int gather_row_len = 0;  // longest row the gather kernels own (hub rows excluded)
+    int n_hubs = 0;          // nodes whose rows exceed the slot bytes: assembled by the hub pass (atomics on those rows only)
+    DevBuf<uint8_t> d_node_hub;
     DevBuf<uint32_t> d_inc_slots;  // ... and the matrix entry index of each element node inside the node's rows
     int64_t nnz = 0, n_slices = 0, stored = 0;
     int64_t gap_words = 0, g_gap_words = 0, r_gap_words = 0;      // 32-bit words of 16-bit column gaps (row / grouped / relative form)
@@ -861,53 +864,53 @@ int build_incidence(pfem_solver *s)
                        static_cast<const int64_t *>(s->d_inc_ptr.p), s->d_inc_ea.p);
     PFEM_TRY(check_kernel("incidence"));
     PFEM_HIP(hipStreamSynchronize(s->stream));
-    // slot map: entry index of every (node row, element node) pair, so the numeric kernels never search
+    // slot map: entry index of every (node row, element node) pair, so the numeric kernels never search.  A node whose
+    // row is too long for a byte-sized entry index (> 255 entries: a "hub") is only marked: its rows are assembled
+    // by a scatter pass restricted to them, every other row keeps the one-writer gather form.
     PFEM_TRY(s->d_inc_slots.alloc(static_cast<size_t>(std::max<int64_t>(inc_total, 1))));
+    PFEM_TRY(s->d_node_hub.alloc(static_cast<size_t>(m.nNode)));
+    DevBuf<int> d_cnt;
+    PFEM_TRY(d_cnt.alloc(2));
+    PFEM_HIP(hipMemsetAsync(d_cnt.p, 0, 2 * sizeof(int), s->stream));
     PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
     hipLaunchKernelGGL(k_build_inc_slots, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m, s->sell(),
                        static_cast<const int64_t *>(s->d_inc_ptr.p), static_cast<const int32_t *>(s->d_inc_cnt.p),
-                       static_cast<const int32_t *>(s->d_inc_ea.p), s->d_inc_slots.p, s->d_err.p);
+                       static_cast<const int32_t *>(s->d_inc_ea.p), s->d_inc_slots.p, s->d_err.p, s->d_node_hub.p, d_cnt.p);
     PFEM_TRY(check_kernel("k_build_inc_slots"));
     int slot_err = 0;
     PFEM_TRY(fetch_err(s, &slot_err));
     if (slot_err == 2) return PFEM_ERR_PATTERN;
-    if (slot_err == 1) {          // a row with more than 255 entries: keep the scatter form
-        s->d_inc_slots.release();
-        s->d_inc_ptr.release();
-        s->d_inc_cnt.release();
-        s->d_inc_ea.release();
-        return PFEM_OK;
-    }
     s->d_inc_rec.release();
     s->d_inc_flags.release();
     s->d_node_row.release();
-    // The numeric kernels read packed per-incidence records.  The elasticity kinds accumulate one matrix row
-    // per thread in LDS: the block size is the largest of 256/128/64 for which max_row_len*T doubles fit
-    // 64 KiB (several blocks per CU), else the largest that fits the 160 KiB a gfx950 workgroup may declare (up to 320
-    // entries per row, so the 254 entries of the slot bytes -- 84 neighbour nodes with 3 dofs -- are the limit for all
-    // kinds); rows longer than that keep the scatter form.
-    s->rows_threads = 0;
-    if (s->max_row_len > 0)
-        for (size_t cap : {static_cast<size_t>(65536), kMaxLdsBytes}) {
-            for (int T = kBlock; T >= 64 && !s->rows_threads; T >>= 1)
-                if (static_cast<size_t>(s->max_row_len) * T * sizeof(double) <= cap) s->rows_threads = T;
-            if (s->rows_threads) break;
-        }
-    if (m.ndof > 1 && s->rows_threads == 0) {
-        s->d_inc_slots.release();
-        s->d_inc_ptr.release();
-        s->d_inc_cnt.release();
-        s->d_inc_ea.release();
-        return PFEM_OK;
-    }
     PFEM_TRY(s->d_inc_rec.alloc(static_cast<size_t>(std::max<int64_t>(inc_total, 1))));
     if (m.ndof > 1) PFEM_TRY(s->d_inc_flags.alloc(static_cast<size_t>(std::max<int64_t>(inc_total, 1))));
     PFEM_TRY(s->d_node_row.alloc(static_cast<size_t>(std::max<int64_t>(m.nNode * m.ndof, 1))));
     hipLaunchKernelGGL(k_build_inc_rec, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m,
                        static_cast<const int64_t *>(s->d_inc_ptr.p), static_cast<const int32_t *>(s->d_inc_cnt.p),
                        static_cast<const int32_t *>(s->d_inc_ea.p), static_cast<const uint32_t *>(s->d_inc_slots.p),
-                       s->d_inc_rec.p, m.ndof > 1 ? s->d_inc_flags.p : nullptr, s->d_node_row.p);
+                       s->d_inc_rec.p, m.ndof > 1 ? s->d_inc_flags.p : nullptr, s->d_node_row.p,
+                       static_cast<const uint8_t *>(s->d_node_hub.p));
     PFEM_TRY(check_kernel("k_build_inc_rec"));
+    // The elasticity kinds accumulate one matrix row per thread in LDS: the block size is the largest of 256/128/64 for
+    // which (longest gather row)*T doubles fit 64 KiB (several blocks per CU), else the largest that fits the 160 KiB a
+    // gfx950 workgroup may declare (320 entries at 64 threads, more than the 255 a non-hub row can have).
+    hipLaunchKernelGGL(k_max_gather_row, dim3(grid_for(m.nNode * m.ndof)), dim3(kBlock), 0, s->stream,
+                       static_cast<const int32_t *>(s->d_node_row.p), m.nNode * m.ndof, static_cast<const int32_t *>(s->d_rowlen.p), d_cnt.p + 1);
+    PFEM_TRY(check_kernel("k_max_gather_row"));
+    int h_cnt[2] = {0, 0};
+    PFEM_HIP(hipMemcpyAsync(h_cnt, d_cnt.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    s->n_hubs = h_cnt[0];
+    s->gather_row_len = h_cnt[1];
+    if (s->n_hubs == 0) s->d_node_hub.release();
+    s->rows_threads = 0;
+    if (s->gather_row_len > 0)
+        for (size_t cap : {static_cast<size_t>(65536), kMaxLdsBytes}) {
+            for (int T = kBlock; T >= 64 && !s->rows_threads; T >>= 1)
+                if (static_cast<size_t>(s->gather_row_len) * T * sizeof(double) <= cap) s->rows_threads = T;
+            if (s->rows_threads) break;
+        }
     PFEM_HIP(hipStreamSynchronize(s->stream));
     s->d_inc_ea.release();          // the lists the records came from are dropped
     s->d_inc_slots.release();
@@ -947,6 +950,20 @@ extern "C" int pfem_solver_set_assembly_mode(pfem_solver *s, int mode)
 {
     if (!s || (mode != PFEM_ASSEMBLY_GATHER && mode != PFEM_ASSEMBLY_SCATTER)) return PFEM_ERR_ARG;
     s->assembly_mode = mode;
+    return PFEM_OK;
+}
+
+// what pfem_assemble will do with the current pattern: gather (1) or scatter (0) form, the number of hub nodes whose
+// rows go through the restricted scatter pass, threads and LDS bytes per block of the row-accumulating gather kernels
+extern "C" int pfem_solver_assembly_info(pfem_solver *s, int *gather_form, int *hub_nodes, int *block_threads, int64_t *lds_bytes)
+{
+    if (!s) return PFEM_ERR_ARG;
+    if (!s->have_pattern) return PFEM_ERR_STATE;
+    const bool gather = s->assembly_mode == PFEM_ASSEMBLY_GATHER && s->have_incidence;
+    if (gather_form) *gather_form = gather ? 1 : 0;
+    if (hub_nodes) *hub_nodes = gather ? s->n_hubs : 0;
+    if (block_threads) *block_threads = gather ? s->rows_threads : 0;
+    if (lds_bytes) *lds_bytes = gather ? static_cast<int64_t>(s->gather_row_len) * s->rows_threads * 8 : 0;
     return PFEM_OK;
 }
 
@@ -1014,7 +1031,9 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
     // (elasticity: otherwise scatter; 1-dof kinds: otherwise read-modify-write in global memory)
     const bool use_lds = m.ndof == 1 && s->rows_threads > 0;
     const bool elast_rows = m.ndof > 1 && s->rows_threads > 0;
-    PFEM_TRY(zero_values(s, gather && (use_lds || elast_rows)));   // setZero, solverpetsc.F:222-246
+    // setZero, solverpetsc.F:222-246 (the value array needs no clearing when every row is stored whole by the gather
+    // kernels; hub rows, if any, are accumulated with atomics and do)
+    PFEM_TRY(zero_values(s, gather && (use_lds || elast_rows) && s->n_hubs == 0));
     if (gather) {
         // gather form: one thread per node, no atomics, bit-reproducible
         const dim3 grid(grid_for(m.nNode)), block(kBlock);
@@ -1027,7 +1046,7 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
         const int T = s->rows_threads > 0 ? s->rows_threads : kBlock;
         const int64_t nthr = static_cast<int64_t>(m.ndof) * m.nNode;
         const dim3 rgrid(static_cast<unsigned>((nthr + T - 1) / T)), rblock(T);
-        const size_t rlds = static_cast<size_t>(s->max_row_len) * T * sizeof(double);
+        const size_t rlds = static_cast<size_t>(s->gather_row_len) * T * sizeof(double);
         // more than 64 KiB of dynamic LDS has to be allowed per kernel
         auto allow_lds = [&](const void *fn) -> int {
             if (rlds > 65536) PFEM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(rlds)));
@@ -1053,25 +1072,28 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
         }
 #undef PFEM_GATHER
         PFEM_TRY(check_kernel("k_gather"));
-    } else if (m.nElem > 0) {
-        // scatter form: one thread per element, hardware f64 atomics
+    }
+    if (m.nElem > 0 && (!gather || s->n_hubs > 0)) {
+        // scatter form: one thread per element, hardware f64 atomics -- for the whole mesh, or (gather form with hub
+        // nodes) for the rows of the hubs only: elements that touch no hub leave at once
         const dim3 grid(grid_for(m.nElem)), block(kBlock);
         SellDev A = s->sell();
+        const uint8_t *only = gather ? s->d_node_hub.p : nullptr;
         switch (m.kind) {
         case PFEM_POISSON_TET:
-            hipLaunchKernelGGL(k_assemble_scalar<PFEM_POISSON_TET>, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, s->d_err.p);
+            hipLaunchKernelGGL(k_assemble_scalar<PFEM_POISSON_TET>, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, s->d_err.p, only);
             break;
         case PFEM_POISSON_TRIA:
-            hipLaunchKernelGGL(k_assemble_scalar<PFEM_POISSON_TRIA>, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, s->d_err.p);
+            hipLaunchKernelGGL(k_assemble_scalar<PFEM_POISSON_TRIA>, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, s->d_err.p, only);
             break;
         case PFEM_POISSON_TRIA_INLINE:
-            hipLaunchKernelGGL(k_assemble_scalar<PFEM_POISSON_TRIA_INLINE>, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, s->d_err.p);
+            hipLaunchKernelGGL(k_assemble_scalar<PFEM_POISSON_TRIA_INLINE>, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, s->d_err.p, only);
             break;
         case PFEM_ELAST_TET:
-            hipLaunchKernelGGL(k_assemble_elast, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, s->d_err.p);
+            hipLaunchKernelGGL(k_assemble_elast, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, s->d_err.p, only);
             break;
         case PFEM_ELAST_TRIA:
-            hipLaunchKernelGGL(k_assemble_elast2d, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, s->d_err.p);
+            hipLaunchKernelGGL(k_assemble_elast2d, grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, s->d_err.p, only);
             break;
         }
         PFEM_TRY(check_kernel("k_assemble"));

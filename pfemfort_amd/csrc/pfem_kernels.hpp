@@ -259,18 +259,23 @@ __device__ __forceinline__ void add_f64(double *p, double v)
 //   receives Klocal(j,i) (tetrapoissonparallelimpl1.F:851); lifting :859-870;
 //   VecSetValues :880.
 template <int KIND>
-__global__ void __launch_bounds__(kBlock) k_assemble_scalar(MeshDev m, SellDev A, double *rhs, ElemPrm prm, int *err)
+__global__ void __launch_bounds__(kBlock) k_assemble_scalar(MeshDev m, SellDev A, double *rhs, ElemPrm prm, int *err,
+                                                             const uint8_t *__restrict__ only_nodes)
 {
+    // only_nodes != nullptr: the hub pass of the gather form -- only the rows of flagged nodes are scattered
     constexpr int NPE = (KIND == PFEM_POISSON_TET) ? 4 : 3;
     const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (e >= m.nElem) return;
     int nd[NPE], dof[NPE];
     double x[NPE], y[NPE], z[NPE];
+    bool any = only_nodes == nullptr;
 #pragma unroll
     for (int a = 0; a < NPE; ++a) {
         nd[a] = m.conn[a * m.nElem + e];
         dof[a] = m.edof[a * m.nElem + e];
+        if (only_nodes && only_nodes[nd[a]]) any = true;
     }
+    if (!any) return;
 #pragma unroll
     for (int a = 0; a < NPE; ++a) {
         x[a] = m.xyz[nd[a]];
@@ -298,6 +303,7 @@ __global__ void __launch_bounds__(kBlock) k_assemble_scalar(MeshDev m, SellDev A
 #pragma unroll
     for (int i = 0; i < NPE; ++i) {
         if (dof[i] < 0) continue;
+        if (only_nodes && !only_nodes[nd[i]]) continue;
 #pragma unroll
         for (int j = 0; j < NPE; ++j) {
             if (dof[j] < 0) continue;
@@ -314,7 +320,8 @@ __global__ void __launch_bounds__(kBlock) k_assemble_scalar(MeshDev m, SellDev A
 // (pfem_elem.hpp: elast_block) straight into lifting + scatter.  A node's free dofs
 // are consecutive global ids, hence consecutive entries of a sorted row, so one
 // binary search per (row, node) serves up to three columns.
-__global__ void __launch_bounds__(kBlock) k_assemble_elast(MeshDev m, SellDev A, double *rhs, ElemPrm prm, int *err)
+__global__ void __launch_bounds__(kBlock) k_assemble_elast(MeshDev m, SellDev A, double *rhs, ElemPrm prm, int *err,
+                                                            const uint8_t *__restrict__ only_nodes)
 {
     const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (e >= m.nElem) return;
@@ -322,6 +329,7 @@ __global__ void __launch_bounds__(kBlock) k_assemble_elast(MeshDev m, SellDev A,
     double x[4], y[4], z[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) nd[a] = m.conn[a * m.nElem + e];
+    if (only_nodes && !(only_nodes[nd[0]] | only_nodes[nd[1]] | only_nodes[nd[2]] | only_nodes[nd[3]])) return;   // hub pass
 #pragma unroll
     for (int i = 0; i < 12; ++i) dof[i] = m.edof[i * m.nElem + e];
 #pragma unroll
@@ -368,6 +376,7 @@ __global__ void __launch_bounds__(kBlock) k_assemble_elast(MeshDev m, SellDev A,
             for (int p = 2; p >= 0; --p)
                 if (dof[3 * a + p] >= 0) firstp = p;
             if (firstp < 0) continue;
+            if (only_nodes && !only_nodes[nd[b]]) continue;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int row = dof[3 * b + q];
@@ -385,7 +394,7 @@ __global__ void __launch_bounds__(kBlock) k_assemble_elast(MeshDev m, SellDev A,
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i)
-        if (dof[i] >= 0) add_f64(&rhs[dof[i]], F[i]);
+        if (dof[i] >= 0 && (!only_nodes || only_nodes[nd[i / 3]])) add_f64(&rhs[dof[i]], F[i]);
 }
 
 // ---------------------------------------------------------------------------
@@ -461,10 +470,12 @@ __global__ void __launch_bounds__(kBlock) k_inc_fill(const uint64_t *keys, const
 // (row, column) pairs; the numeric kernels then never search.
 __global__ void __launch_bounds__(kBlock) k_build_inc_slots(MeshDev m, SellDev A, const int64_t *__restrict__ inc_ptr,
                                                              const int32_t *__restrict__ inc_cnt,
-                                                             const int32_t *__restrict__ inc_ea, uint32_t *inc_slots, int *err)
+                                                             const int32_t *__restrict__ inc_ea, uint32_t *inc_slots, int *err,
+                                                             uint8_t *node_hub, int *n_hubs)
 {
     const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (n >= m.nNode) return;
+    node_hub[n] = 0;
     // incidence lists are wave-sliced like the matrix: entry j of node n sits at
     // inc_ptr[n >> 6] + 64*j + (n & 63), so a wave reads one contiguous 256-B run per step
     const int cnt = inc_cnt[n];
@@ -479,7 +490,7 @@ __global__ void __launch_bounds__(kBlock) k_build_inc_slots(MeshDev m, SellDev A
     if (row < 0) { for (int64_t t = beg; t < end; t += 64) inc_slots[t] = 0xffffffffu; return; }
     const int64_t base = A.slice_off[row >> 6] + (row & 63);
     const int len = A.rowlen[row];
-    if (len > 255) { atomicMax(err, 1); return; }           // byte-sized entry index
+    if (len > 255) { node_hub[n] = 1; atomicAdd(n_hubs, 1); return; }   // byte-sized entry index: a hub, left to the hub pass
     for (int64_t t = beg; t < end; t += 64) {
         const int64_t e = inc_ea[t] >> 2;
         uint32_t w = 0;
@@ -512,12 +523,13 @@ __global__ void __launch_bounds__(kBlock) k_build_inc_rec(MeshDev m, const int64
                                                            const int32_t *__restrict__ inc_cnt,
                                                            const int32_t *__restrict__ inc_ea,
                                                            const uint32_t *__restrict__ inc_slots, int4 *inc_rec,
-                                                           uint16_t *inc_flags, int32_t *node_row)
+                                                           uint16_t *inc_flags, int32_t *node_row,
+                                                           const uint8_t *__restrict__ node_hub)
 {
     const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (n >= m.nNode) return;
     const int cnt = inc_cnt[n];
-    if (cnt == 0) {
+    if (cnt == 0 || node_hub[n]) {          // no incident element, or a hub (its rows belong to the hub pass)
         for (int p = 0; p < m.ndof; ++p) node_row[n * m.ndof + p] = -1;
         return;
     }
@@ -544,6 +556,16 @@ __global__ void __launch_bounds__(kBlock) k_build_inc_rec(MeshDev m, const int64
             inc_flags[t] = static_cast<uint16_t>(fl);
         }
     }
+}
+
+// longest matrix row among those the gather kernels own (hub rows excluded): sizes their LDS accumulators
+__global__ void __launch_bounds__(kBlock) k_max_gather_row(const int32_t *__restrict__ node_row, int64_t n, const int32_t *__restrict__ rowlen,
+                                                            int *out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int r = node_row[i];
+    if (r >= 0) atomicMax(out, rowlen[r]);
 }
 
 // The gather form never evaluates an element whose nodes are all constrained, but the
@@ -756,7 +778,8 @@ __global__ void __launch_bounds__(kBlock) k_gather_elast_rows(MeshDev m, SellDev
 // plane-stress elasticity on P1 triangles (2 dofs per node, next row 8f.1): same two
 // formulations as the tetrahedron kernels, 2x2 node blocks from elast2d_block_v
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_assemble_elast2d(MeshDev m, SellDev A, double *rhs, ElemPrm prm, int *err)
+__global__ void __launch_bounds__(kBlock) k_assemble_elast2d(MeshDev m, SellDev A, double *rhs, ElemPrm prm, int *err,
+                                                              const uint8_t *__restrict__ only_nodes)
 {
     const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (e >= m.nElem) return;
@@ -764,6 +787,7 @@ __global__ void __launch_bounds__(kBlock) k_assemble_elast2d(MeshDev m, SellDev 
     double x[3], y[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) nd[a] = m.conn[a * m.nElem + e];
+    if (only_nodes && !(only_nodes[nd[0]] | only_nodes[nd[1]] | only_nodes[nd[2]])) return;   // hub pass
 #pragma unroll
     for (int i = 0; i < 6; ++i) dof[i] = m.edof[i * m.nElem + e];
 #pragma unroll
@@ -799,6 +823,7 @@ __global__ void __launch_bounds__(kBlock) k_assemble_elast2d(MeshDev m, SellDev 
             // MatSetValues row-major read: entry (row = dof(2b+q), col = dof(2a+p)) += Klocal(2a+p,2b+q)
             const int firstp = dof[2 * a] >= 0 ? 0 : (dof[2 * a + 1] >= 0 ? 1 : -1);
             if (firstp < 0) continue;
+            if (only_nodes && !only_nodes[nd[b]]) continue;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int row = dof[2 * b + q];
@@ -816,7 +841,7 @@ __global__ void __launch_bounds__(kBlock) k_assemble_elast2d(MeshDev m, SellDev 
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i)
-        if (dof[i] >= 0) add_f64(&rhs[dof[i]], F[i]);
+        if (dof[i] >= 0 && (!only_nodes || only_nodes[nd[i / 2]])) add_f64(&rhs[dof[i]], F[i]);
 }
 
 // Plane-stress sibling of k_gather_elast_rows: one thread per (node, dof) row, 2x2 node blocks.

@@ -179,6 +179,12 @@ class PetscSolver:
         L.check(L.lib().pfem_solver_set_assembly_mode(self._h, {"gather": 0, "scatter": 1}[mode]),
                 "pfem_solver_set_assembly_mode")
 
+    def assemblyInfo(self):
+        """{"gather": bool, "hub_nodes": n, "block_threads": T, "lds_bytes": b} for the current pattern."""
+        g = C.c_int(0); h = C.c_int(0); t = C.c_int(0); b = C.c_int64(0)
+        L.check(L.lib().pfem_solver_assembly_info(self._h, C.byref(g), C.byref(h), C.byref(t), C.byref(b)), "pfem_solver_assembly_info")
+        return {"gather": bool(g.value), "hub_nodes": h.value, "block_threads": t.value, "lds_bytes": b.value}
+
     def setSpmvFormat(self, fmt):
         """"auto" (16-bit column gaps when they fit; row groups when the pattern has them and the system is large),
         "grouped" (row groups at any size), "gaps16" (16-bit gaps, one row per lane) or "int32"."""
