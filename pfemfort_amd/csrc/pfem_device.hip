@@ -1913,17 +1913,18 @@ namespace {
 
 // v[shared] <- sum over the ranks that hold the dof (ascending rank order), outside the iteration: the compute
 // stream packs, the communication stream exchanges, the compute stream unpacks
-int exchange_sum(pfem_solver *s, double *v)
+int exchange_sum(pfem_solver *s, double *v, bool second_stream)
 {
     if (s->n_send > 0) {
         hipLaunchKernelGGL(k_pack_send, dim3(grid_for(s->n_send)), dim3(kBlock), 0, s->stream, static_cast<const double *>(v),
                            static_cast<const int32_t *>(s->d_send_lidx.p), s->n_send, s->d_send.p, static_cast<const CgCtl *>(nullptr));
         PFEM_TRY(check_kernel("k_pack_send"));
     }
-    PFEM_TRY(stream_follows(s, s->comm_stream, s->stream));
-    PFEM_TRY(s->comm->exchange(static_cast<int>(s->peers.size()), s->peers.data(), s->peer_off.data(), s->d_send.p, s->d_recv.p,
-                               s->comm_stream));
-    PFEM_TRY(stream_follows(s, s->stream, s->comm_stream));
+    // the exchange goes where the iterations will put it (one stream per communicator for the whole solve)
+    hipStream_t xs = second_stream ? s->comm_stream : s->stream;
+    if (second_stream) PFEM_TRY(stream_follows(s, s->comm_stream, s->stream));
+    PFEM_TRY(s->comm->exchange(static_cast<int>(s->peers.size()), s->peers.data(), s->peer_off.data(), s->d_send.p, s->d_recv.p, xs));
+    if (second_stream) PFEM_TRY(stream_follows(s, s->stream, s->comm_stream));
     if (s->n_sh > 0) {
         hipLaunchKernelGGL(k_unpack_sum, dim3(grid_for(s->n_sh)), dim3(kBlock), 0, s->stream, v,
                            static_cast<const int32_t *>(s->d_sh_lidx.p), static_cast<const int32_t *>(s->d_sh_ptr.p),
@@ -1996,6 +1997,17 @@ int run_pcg(pfem_solver *s)
     const bool multi = s->nranks > 1 || (s->comm && s->have_plan && std::getenv("PFEM_FORCE_MULTI"));
     s->group_vals_stale = true;            // the row form may have been re-assembled since the last solve
     PFEM_TRY(refresh_group_vals(s));
+    // Two forms of the multi-rank iteration.  In order (default): whole SpMV, pack, exchange, all-reduce ... on the compute
+    // stream.  Overlapped (PFEM_MULTI_OVERLAP=1): the slices with shared rows first, the exchange on the communication
+    // stream under the interior slices, two stream hand-overs per iteration.  Measured on MI355X / ROCm 7.2 with the rank as
+    // its own neighbour (tools/probe_overlap.py, 200^3 per rank, 634 kB exchanged): in order 0.346 ms per iteration against
+    // 0.329 for the single-rank loop (exchange 14 us, both all-reduces 11 us); overlapped 0.676 ms -- the RCCL launch takes
+    // 90 us on the second stream, each hand-over 12-30 us, and the split SpMV loses 70 us to the concurrent copy kernel.
+    // The overlapped form pays only where an exchange costs more than ~150 us.
+    const bool overlap = [&] {
+        const char *e = std::getenv("PFEM_MULTI_OVERLAP");
+        return e ? std::atoi(e) != 0 : s->multi_overlap;
+    }();
     const unsigned gv = vec_grid(n), gs = spmv_blocks(s);
     const dim3 block(kBlock);
     SellDev A = s->sell();
@@ -2043,16 +2055,16 @@ int run_pcg(pfem_solver *s)
         if (s->block_pc()) {
             const uint32_t *rgp = s->d_row_grp.p;
             hipLaunchKernelGGL(k_group_sig, dim3(grid_for(n)), block, 0, s->stream, rgp, n, s->d_binv[0].p, s->d_binv[1].p);
-            PFEM_TRY(exchange_sum(s, s->d_binv[0].p));
-            PFEM_TRY(exchange_sum(s, s->d_binv[1].p));
+            PFEM_TRY(exchange_sum(s, s->d_binv[0].p, overlap));
+            PFEM_TRY(exchange_sum(s, s->d_binv[1].p, overlap));
             hipLaunchKernelGGL(k_group_sig_check, dim3(grid_for(n)), block, 0, s->stream, rgp, n,
                                static_cast<const double *>(s->d_binv[0].p), static_cast<const double *>(s->d_binv[1].p), bad);
             PFEM_TRY(check_kernel("k_group_sig_check"));
         } else {
             // no groups here: still take part in the two exchanges of the others (zeros), then vote no
             PFEM_HIP(hipMemsetAsync(s->d_w.p, 0, sizeof(double) * static_cast<size_t>(std::max<int64_t>(n, 1)), s->stream));
-            PFEM_TRY(exchange_sum(s, s->d_w.p));
-            PFEM_TRY(exchange_sum(s, s->d_w.p));
+            PFEM_TRY(exchange_sum(s, s->d_w.p, overlap));
+            PFEM_TRY(exchange_sum(s, s->d_w.p, overlap));
             const double one = 1.0;
             PFEM_HIP(hipMemcpyAsync(bad, &one, sizeof(double), hipMemcpyHostToDevice, s->stream));
         }
@@ -2070,9 +2082,9 @@ int run_pcg(pfem_solver *s)
                            s->d_binv[0].p, s->d_binv[1].p, s->d_binv[2].p);
         PFEM_TRY(check_kernel("k_extract_blocks"));
         if (multi) {
-            for (auto &b : s->d_binv) PFEM_TRY(exchange_sum(s, b.p));
+            for (auto &b : s->d_binv) PFEM_TRY(exchange_sum(s, b.p, overlap));
             if (!s->rhs_summed) {
-                PFEM_TRY(exchange_sum(s, s->d_rhs.p));
+                PFEM_TRY(exchange_sum(s, s->d_rhs.p, overlap));
                 s->rhs_summed = true;
             }
         }
@@ -2091,9 +2103,9 @@ int run_pcg(pfem_solver *s)
         PFEM_TRY(check_kernel("k_extract_diag"));
     }
     if (multi) {
-        PFEM_TRY(exchange_sum(s, s->d_dinv.p));
+        PFEM_TRY(exchange_sum(s, s->d_dinv.p, overlap));
         if (!s->rhs_summed) {
-            PFEM_TRY(exchange_sum(s, s->d_rhs.p));
+            PFEM_TRY(exchange_sum(s, s->d_rhs.p, overlap));
             s->rhs_summed = true;
         }
     }
@@ -2217,17 +2229,6 @@ int run_pcg(pfem_solver *s)
     // (3) the interior slices run; (4) (p,Ap) of this rank -> all-reduce, in order on the compute stream; (5) the compute
     // stream waits for the exchange and adds the neighbours' partials in rank order; (6) update, the two other scalars
     // all-reduced, direction.
-    // Two forms of the iteration.  In order (default): whole SpMV, pack, exchange, all-reduce ... on the compute stream.
-    // Overlapped (PFEM_MULTI_OVERLAP=1): the slices with shared rows first, the exchange on the communication stream under
-    // the interior slices, two stream hand-overs per iteration.  Measured on MI355X / ROCm 7.2 with the rank as its own
-    // neighbour (tools/probe_overlap.py, 200^3 per rank, 634 kB exchanged): in order 0.346 ms per iteration against 0.329 for
-    // the single-rank loop (exchange 14 us, both all-reduces 11 us); overlapped 0.676 ms -- the RCCL launch takes 90 us on the
-    // second stream, each hand-over 12-30 us, and the split SpMV loses 70 us to the concurrent copy kernel.  The
-    // overlapped form pays only where an exchange costs more than ~150 us.
-    const bool overlap = [&] {
-        const char *e = std::getenv("PFEM_MULTI_OVERLAP");
-        return e ? std::atoi(e) != 0 : s->multi_overlap;
-    }();
     double host_comm_s = 0.0;       // host time inside the backend's calls (enqueue cost of the RCCL launches)
     auto timed = [&](auto &&call) -> int {
         const auto t0 = std::chrono::steady_clock::now();
@@ -2235,7 +2236,8 @@ int run_pcg(pfem_solver *s)
         host_comm_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return rc;
     };
-    auto multi_iteration = [&](int it_arg, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t *cev) -> int {
+    // w = A_loc p, neighbour exchange, (p,Ap) all-reduced into sbuf[0], w[shared] summed in rank order
+    auto multi_spmv_exchange = [&](hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t *cev) -> int {
         unsigned nb_blocks = s->n_slices_b > 0 ? spmv_grid(s->n_slices_b) : 0;
         unsigned ni_blocks = s->n_slices_i > 0 ? spmv_grid(s->n_slices_i) : 0;
         if (!overlap) {
@@ -2283,6 +2285,10 @@ int run_pcg(pfem_solver *s)
                                static_cast<const int32_t *>(s->d_sh_lidx.p), static_cast<const int32_t *>(s->d_sh_ptr.p),
                                static_cast<const int32_t *>(s->d_sh_src.p), s->n_sh, static_cast<const double *>(s->d_recv.p),
                                static_cast<const CgCtl *>(ctl));
+        return PFEM_OK;
+    };
+    auto multi_iteration = [&](int it_arg, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t *cev) -> int {
+        PFEM_TRY(multi_spmv_exchange(e0, e1, e2, e3, cev));
         hipLaunchKernelGGL(k_cg_update, dim3(gv), block, 0, s->stream, ctl, it_arg, n, s->n_owned, static_cast<const double *>(part_pw),
                            0, static_cast<const double *>(sbuf), s->d_p.p, s->d_w.p, s->d_dinv.p, s->d_x.p, s->d_r.p, part_rz, part_zz);
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s->stream, static_cast<const double *>(part_rz),
@@ -2406,34 +2412,7 @@ int run_pcg(pfem_solver *s)
             }
             if (multi) {
                 // node-block Jacobi on several ranks: the same SpMV / exchange sequence, block kernels below
-                const unsigned nb_blocks = s->n_slices_b > 0 ? spmv_grid(s->n_slices_b) : 0;
-                const unsigned ni_blocks = s->n_slices_i > 0 ? spmv_grid(s->n_slices_i) : 0;
-                if (s->n_slices_b > 0)
-                    launch_spmv<true>(s, s->d_p.p, s->d_w.p, n, part_pw, ctl, e0, e1, SliceSel{s->d_slices_b.p, s->n_slices_b});
-                if (s->n_send > 0)
-                    hipLaunchKernelGGL(k_pack_send, dim3(grid_for(s->n_send)), block, 0, s->stream, static_cast<const double *>(s->d_w.p),
-                                       static_cast<const int32_t *>(s->d_send_lidx.p), s->n_send, s->d_send.p, static_cast<const CgCtl *>(ctl));
-                PFEM_TRY(stream_follows(s, s->comm_stream, s->stream));
-                if (cev) PFEM_HIP(hipEventRecord(cev[0], s->comm_stream));
-                PFEM_TRY(s->comm->exchange(static_cast<int>(s->peers.size()), s->peers.data(), s->peer_off.data(), s->d_send.p,
-                                           s->d_recv.p, s->comm_stream));
-                if (cev) PFEM_HIP(hipEventRecord(cev[1], s->comm_stream));
-                if (s->n_slices_i > 0)
-                    launch_spmv<true>(s, s->d_p.p, s->d_w.p, n, part_pw + nb_blocks, ctl, e2, e3, SliceSel{s->d_slices_i.p, s->n_slices_i});
-                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s->stream, static_cast<const double *>(part_pw),
-                                   static_cast<const double *>(nullptr), static_cast<int>(nb_blocks + ni_blocks), sbuf,
-                                   static_cast<const CgCtl *>(ctl));
-                if (cev) PFEM_HIP(hipEventRecord(cev[2], s->stream));
-                PFEM_TRY(s->comm->allreduce(sbuf, 1, s->stream));
-                if (cev) PFEM_HIP(hipEventRecord(cev[3], s->stream));
-                if (cev) PFEM_HIP(hipEventRecord(cev[6], s->stream));
-                PFEM_TRY(stream_follows(s, s->stream, s->comm_stream));
-                if (cev) PFEM_HIP(hipEventRecord(cev[7], s->stream));
-                if (s->n_sh > 0)
-                    hipLaunchKernelGGL(k_unpack_sum, dim3(grid_for(s->n_sh)), block, 0, s->stream, s->d_w.p,
-                                       static_cast<const int32_t *>(s->d_sh_lidx.p), static_cast<const int32_t *>(s->d_sh_ptr.p),
-                                       static_cast<const int32_t *>(s->d_sh_src.p), s->n_sh, static_cast<const double *>(s->d_recv.p),
-                                       static_cast<const CgCtl *>(ctl));
+                PFEM_TRY(multi_spmv_exchange(e0, e1, e2, e3, cev));
                 red_pw = sbuf;
             } else {
                 // with events: marker-end -> kernel-end of THIS launch (see event_overhead_ms)
@@ -2490,7 +2469,7 @@ int run_pcg(pfem_solver *s)
     const size_t live = std::min(ev_used / ev_per, (static_cast<size_t>(h.its) + s->profile_every - 1) / s->profile_every);
     for (size_t k = 0; k < live; ++k) {
         for (size_t q = 0; q < ev_per; q += 2) {
-            const bool split = multi && (bpc || overlap);          // boundary + interior pass, one event pair each
+            const bool split = multi && overlap;                   // boundary + interior pass, one event pair each
             if (split && ((q == 0 && s->n_slices_b == 0) || (q == 2 && s->n_slices_i == 0))) continue;   // pass not launched
             if (multi && !split && q == 2) continue;               // one pass over all slices
             float f = 0.f;
