@@ -48,6 +48,58 @@ int main(int argc, char **argv)
         std::vector<int64_t> gh(ng + 1);
         assert(pfem_find_ghosts(12 * nElem, edof.data(), rs[0], re[0] - rs[0], &ng, gh.data()) == 0);
         assert((parts == 1) == (ng == 0));
+        // closed-form slab sizes against the bookkeeping above (z-slabs: the renumbering is the identity)
+        for (int part = 0; part < parts; ++part) {
+            int64_t sg = 0, r0 = 0, sl = 0, nn = 0, nel = 0;
+            assert(pfem_box_slab_sizes(nEx, nEy, nEz, 1, ndof, parts, part, &sg, &r0, &sl, &nn, &nel) == 0);
+            assert(sg == N && r0 == rs[part] && r0 + sl == re[part]);
+            int64_t cnt = 0;
+            for (int64_t e = 0; e < nElem; ++e) cnt += epid[e] == part;
+            assert(nel == cnt);
+        }
+        // neighbour plan of every rank from everybody's ghost lists: symmetric, ascending, consistent with ownership
+        std::vector<std::vector<int64_t>> ghosts(parts);
+        std::vector<int64_t> goff(parts + 1, 0), gall;
+        for (int r = 0; r < parts; ++r) {
+            std::vector<int32_t> mine;
+            for (int64_t e = 0; e < nElem; ++e)
+                if (epid[e] == r) for (int i = 0; i < 12; ++i) mine.push_back(edof[i * nElem + e]);
+            int64_t k = 0;
+            assert(pfem_find_ghosts(static_cast<int64_t>(mine.size()), mine.data(), rs[r], re[r] - rs[r], &k, nullptr) == 0);
+            ghosts[r].resize(k + 1);
+            assert(pfem_find_ghosts(static_cast<int64_t>(mine.size()), mine.data(), rs[r], re[r] - rs[r], &k, ghosts[r].data()) == 0);
+            ghosts[r].resize(k);
+            goff[r + 1] = goff[r] + k;
+            gall.insert(gall.end(), ghosts[r].begin(), ghosts[r].end());
+        }
+        gall.push_back(0);
+        std::vector<std::vector<int>> peers(parts);
+        std::vector<std::vector<int64_t>> poff(parts), pgid(parts);
+        for (int r = 0; r < parts; ++r) {
+            int np = 0; int64_t tot = 0;
+            assert(pfem_neighbour_plan(parts, r, rs.data(), re.data(), goff.data(), gall.data(), &np, &tot, nullptr, nullptr, nullptr) == 0);
+            peers[r].resize(np + 1); poff[r].assign(np + 1, 0); pgid[r].resize(tot + 1);
+            if (np) assert(pfem_neighbour_plan(parts, r, rs.data(), re.data(), goff.data(), gall.data(), &np, &tot, peers[r].data(), poff[r].data(), pgid[r].data()) == 0);
+            peers[r].resize(np);
+            assert((parts == 1) == (np == 0));
+        }
+        for (int r = 0; r < parts; ++r)
+            for (size_t k = 0; k < peers[r].size(); ++k) {
+                const int q = peers[r][k];
+                size_t kq = 0;
+                while (kq < peers[q].size() && peers[q][kq] != r) ++kq;
+                assert(kq < peers[q].size());                                        // q names r too ...
+                const int64_t n = poff[r][k + 1] - poff[r][k];
+                assert(n == poff[q][kq + 1] - poff[q][kq]);                           // ... with the same list
+                assert(std::memcmp(&pgid[r][poff[r][k]], &pgid[q][poff[q][kq]], sizeof(int64_t) * n) == 0);
+            }
+    }
+    {   // malformed plans are refused
+        int64_t rs2[2] = {0, 4}, re2[2] = {4, 8}, off[3] = {0, 2, 2}, g[2] = {6, 5};
+        int np; int64_t tot;
+        assert(pfem_neighbour_plan(2, 0, rs2, re2, off, g, &np, &tot, nullptr, nullptr, nullptr) == PFEM_ERR_ARG);   // not ascending
+        assert(pfem_neighbour_plan(2, 2, rs2, re2, off, g, &np, &tot, nullptr, nullptr, nullptr) == PFEM_ERR_ARG);
+        assert(pfem_box_slab_sizes(4, 4, 4, 0, 1, 5, 0, nullptr, nullptr, nullptr, nullptr, nullptr) == PFEM_ERR_ARG);
     }
     assert(pfem_partition_box_slabs(nEx, nEy, nEz, nEz + 1, nullptr, nullptr) == PFEM_ERR_ARG);
     {   // out-of-range Dirichlet record is rejected, not written
