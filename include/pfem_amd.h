@@ -41,7 +41,7 @@ extern "C" {
 #define PFEM_ERR_NOMEM 6
 #define PFEM_ERR_DIVERGED 7   /* KSPConvergedReason < 0 (solverpetsc.F:481-483)      */
 #define PFEM_ERR_PATTERN 8    /* ADD_VALUES into a slot outside the inserted pattern  */
-#define PFEM_ERR_COMM 9       /* the all-reduce hook reported an error                */
+#define PFEM_ERR_COMM 9       /* the communication backend (RCCL / host hooks) failed */
 
 /* ---- element kinds ------------------------------------------------------ */
 #define PFEM_POISSON_TRIA 1        /* StiffnessResidualPoissonLinearTria  elementutilitiespoisson.F:23   */

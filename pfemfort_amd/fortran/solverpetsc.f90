@@ -100,7 +100,7 @@ contains
     if (ierr /= 0) call pfem_chkerr(ierr)
 #ifdef PFEM_WITH_MPI
     ! the first setZero finalises the pattern (MatAssembly of the INSERT_VALUES pass), and with it the
-    ! local numbering: exchange the ghost lists and install the interface plan + all-reduce hook
+    ! local numbering: exchange the ghost lists, install the neighbour plan and the communication backend
     if (.not. this%attached) then
       ierr = pfem_mpi_attach(pfem_h2p(this%mtx), PETSC_COMM_WORLD, this%row_start, this%size_local)
       if (ierr /= 0) call pfem_chkerr(ierr)
