@@ -45,11 +45,12 @@ def pmc_traffic(nnz):
     MI355X_MICROARCH.md section HBM.  Returns (bytes, source) or (None, None)."""
     path = os.path.join(ROOT, "profiles", "spmv_pmc_traffic.json")
     try:
-        d = json.load(open(path))
-        if d.get("nnz") == nnz:
-            return (2.0 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024.0, \
-                "profiles/spmv_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, " \
-                f"{d.get('source', 'builder lease')}); replayed, NOT measured in this run"
+        doc = json.load(open(path))
+        for d in doc.get("entries", [doc]):          # one entry per workload (keyed by the matrix's nnz)
+            if d.get("nnz") == nnz:
+                return (2.0 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024.0, \
+                    "profiles/spmv_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, " \
+                    f"{d.get('source', 'builder lease')}); replayed, NOT measured in this run"
     except (OSError, ValueError, KeyError):
         pass
     return None, None
