@@ -37,7 +37,7 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     # the same configuration as the GPU number, at the reference's three timer points
     assert "40^3" in cb["sample"] and abs(cb["total_s"] - cb["assembly_s"] - cb["solve_s"]) < 1e-9 and cb["its"] == d["iterations"]
     assert d["parity_tolerance_step"]["rtol"] == 1e-10 and d["parity_tolerance_step"]["max_nodal_error"] < 1e-6
-    assert "PCBJACOBI" in d["config"]["solver"] and d["setup_breakdown_s"]["generate_mesh_and_numbering_on_device"] >= 0
+    assert "PCBJACOBI" in d["config"]["solver"] and d["setup_breakdown_s"]["generate_mesh_and_numbering_on_device"] >= 0 and d["setup_s_untimed"] < 5
 
 
 @pytest.mark.gpu
