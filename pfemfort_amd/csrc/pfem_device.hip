@@ -734,6 +734,7 @@ int pattern_from_keys(pfem_solver *s, DevBuf<uint64_t> &keys, int64_t nkeys)
     const int64_t n = s->n_loc;
     s->cg_graph_key.clear();               // every array a captured CG iteration points at is about to be replaced
     s->mgraph_key.clear();
+    s->slices_fmt = -1;                    // ... and the boundary / interior slice lists belong to the old pattern
     int bits = 1;
     while ((1LL << bits) < std::max<int64_t>(n, 2)) ++bits;
     const int end_bit = std::min(64, 32 + bits);
