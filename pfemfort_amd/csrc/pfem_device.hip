@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1568,12 +1569,8 @@ struct RcclApi {
 
 // The copy of librccl already mapped into the process is taken if there is one (a torch host has its own; two RCCL
 // instances in one process would each claim the device's IPC resources), else the ROCm installation's.
-RcclApi *rccl_api()
+bool rccl_load(RcclApi &api)
 {
-    static RcclApi api;
-    static bool tried = false;
-    if (tried) return api.handle ? &api : nullptr;
-    tried = true;
     void *h = nullptr;
     if (const char *e = std::getenv("PFEM_RCCL_LIB")) h = dlopen(e, RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
@@ -1581,8 +1578,9 @@ RcclApi *rccl_api()
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) {
-        set_last_error(std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "?"));
-        return nullptr;
+        const char *why = dlerror();
+        set_last_error(std::string("librccl.so.1 could not be loaded: ") + (why ? why : "?"));
+        return false;
     }
     bool ok = true;
     auto sym = [&](const char *n) { void *p = dlsym(h, n); if (!p) { ok = false; set_last_error(std::string("librccl lacks ") + n); } return p; };
@@ -1595,9 +1593,17 @@ RcclApi *rccl_api()
     api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
     api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
-    if (!ok) return nullptr;
+    if (!ok) return false;
     api.handle = h;
-    return &api;
+    return true;
+}
+
+RcclApi *rccl_api()
+{
+    static RcclApi api;
+    static std::once_flag once;          // several solvers (threads) may ask at the same time
+    std::call_once(once, [] { (void)rccl_load(api); });
+    return api.handle ? &api : nullptr;
 }
 
 struct RcclBackend final : CommBackend {
@@ -1740,7 +1746,7 @@ extern "C" int pfem_rccl_unique_id(void *id_out)
     static_assert(2 * sizeof(ncclUniqueId) == PFEM_RCCL_ID_BYTES, "two ncclUniqueIds: exchange and all-reduce communicator");
     if (!id_out) return PFEM_ERR_ARG;
     RcclApi *api = rccl_api();
-    if (!api) return PFEM_ERR_COMM;
+    if (!api) { if (g_last_error.empty()) set_last_error("librccl.so.1 is not available in this process"); return PFEM_ERR_COMM; }
     for (int c = 0; c < 2; ++c) {
         ncclUniqueId id;
         const ncclResult_t r = api->GetUniqueId(&id);
@@ -1755,7 +1761,7 @@ extern "C" int pfem_solver_set_comm_rccl(pfem_solver *s, int rank, int nranks, c
     if (!s || nranks < 1 || rank < 0 || rank >= nranks || !id_bytes) return PFEM_ERR_ARG;
     PFEM_TRY(use_device(s));
     RcclApi *api = rccl_api();
-    if (!api) return PFEM_ERR_COMM;
+    if (!api) { if (g_last_error.empty()) set_last_error("librccl.so.1 is not available in this process"); return PFEM_ERR_COMM; }
     ncclUniqueId id[2];
     std::memcpy(id, id_bytes, sizeof id);
     RcclBackend *b = new (std::nothrow) RcclBackend(api);
