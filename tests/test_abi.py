@@ -57,3 +57,13 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "pfem_oracle" not in src and "liboracle" not in src and "orc_" not in src, f
+
+
+@pytest.mark.skipif(pf.device_count() > 0, reason="a GPU is present")
+def test_rccl_binding_loads_and_fails_loudly_without_gpu():
+    """librccl is bound at run time (dlopen, no link dependency): on a box without a GPU the library is found, its
+    symbols resolve, and ncclGetUniqueId's failure comes back as PFEM_ERR_COMM with RCCL's own text -- no crash."""
+    from pfemfort_amd.solver import rccl_unique_id
+    with pytest.raises(pf.PfemError) as ei:
+        rccl_unique_id()
+    assert ei.value.code == 9 and "ncclGetUniqueId" in str(ei.value)
