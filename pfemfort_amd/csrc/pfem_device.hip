@@ -1675,6 +1675,7 @@ struct HostBackend final : CommBackend {
     }
     int allreduce(double *d, int64_t n, hipStream_t st) override
     {
+        if (!ar) return PFEM_OK;               // a single rank may install the backend without hooks: the sum is the value
         PFEM_TRY(reserve(static_cast<size_t>(n)));
         PFEM_HIP(hipMemcpyAsync(h_send, d, sizeof(double) * n, hipMemcpyDeviceToHost, st));
         PFEM_HIP(hipStreamSynchronize(st));
@@ -1686,6 +1687,7 @@ struct HostBackend final : CommBackend {
     int exchange(int np, const int *peers, const int64_t *off, const double *d_send, double *d_recv, hipStream_t st) override
     {
         if (np == 0) return PFEM_OK;
+        if (!ex) { set_last_error("host backend without an exchange hook cannot serve neighbours"); return PFEM_ERR_COMM; }
         const int64_t n = off[np];
         PFEM_TRY(reserve(static_cast<size_t>(n)));
         PFEM_HIP(hipMemcpyAsync(h_send, d_send, sizeof(double) * n, hipMemcpyDeviceToHost, st));
