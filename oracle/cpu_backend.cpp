@@ -236,6 +236,15 @@ int pfem_solver_get_solution(pfem_solver *s, double *x_owned)
     return PFEM_OK;
 }
 
+// the device element loop has no stand-in here: the reference drivers never call it
+int pfem_mesh_upload(pfem_solver *, int, int64_t, const int32_t *, int64_t, const double *, const int32_t *, const double *)
+{
+    g_err = "the CPU trace backend has no batched path";
+    return PFEM_ERR_STATE;
+}
+int pfem_pattern_build(pfem_solver *) { g_err = "the CPU trace backend has no batched path"; return PFEM_ERR_STATE; }
+int pfem_assemble(pfem_solver *, const double *, const double *) { g_err = "the CPU trace backend has no batched path"; return PFEM_ERR_STATE; }
+
 // MPI flavour of the Fortran shim (pfemfort_amd/fortran/pfem_mpi.cpp provides these for the product)
 int pfem_mpi_attach(pfem_solver *, int, int64_t, int64_t) { return PFEM_OK; }
 int pfem_mpi_pick_device(int, int *device) { *device = 0; return PFEM_OK; }

@@ -110,6 +110,24 @@ module pfem_amd_c
       real(c_double) :: coords(*), soln(*)
       integer(c_int) :: conn(*), procid(*)
     end function
+    ! the element loop as one device call (the fast path of include/pfem_amd.h, section 4)
+    integer(c_int) function pfem_mesh_upload(s, kind, nElem, conn, nNode, xyz, edof, solnApplied) bind(C, name="pfem_mesh_upload")
+      import
+      type(c_ptr), value :: s
+      integer(c_int), value :: kind
+      integer(c_int64_t), value :: nElem, nNode
+      integer(c_int) :: conn(*), edof(*)          ! SoA = the column-major layout of elemNodeConn(nElem,npElem) / ElemDofArray(nElem,nsize); 0-based
+      real(c_double) :: xyz(*), solnApplied(*)    ! coords(nNode,ndim) column-major; solnApplied((node-1)*ndof+dof)
+    end function
+    integer(c_int) function pfem_pattern_build(s) bind(C, name="pfem_pattern_build")
+      import
+      type(c_ptr), value :: s
+    end function
+    integer(c_int) function pfem_assemble(s, elemData, timeData) bind(C, name="pfem_assemble")
+      import
+      type(c_ptr), value :: s
+      real(c_double) :: elemData(*), timeData(*)
+    end function
     function pfem_last_error_string() bind(C, name="pfem_last_error_string") result(p)
       import
       type(c_ptr) :: p

@@ -31,6 +31,9 @@ module Module_SolverPetsc
     procedure :: factorise
     procedure :: solve
     procedure :: factoriseAndSolve
+    ! not in the reference type: the driver's whole element loop (tetrapoissonparallelimpl1.F:786-884) as device calls
+    procedure :: uploadMeshToDevice
+    procedure :: assembleOnDevice
   end type PetscSolver
 
 contains
@@ -109,6 +112,53 @@ contains
 #endif
     call sync_status(this)
   end subroutine setZero
+
+  ! EXTENSION (no counterpart in solverpetsc.F): hand the rank's elements to the GPU once -- the driver's own arrays in
+  ! their own layout: elemNodeConn(nElem,npElem) with NEW 1-based node ids of the rank's elements, coords(nNode,ndim)
+  ! gathered through node_map_get_old, ElemDofArray(nElem,nsize) (0-based, -1 = Dirichlet), solnApplied -- and build the
+  ! pattern on the device.  Replaces the INSERT_VALUES loop (:786-802) and the first setZero (:817).
+  ! kind: 1 tria Poisson, 2 tet Poisson, 3 tet elasticity, 5 tria elasticity (include/pfem_amd.h).
+  subroutine uploadMeshToDevice(this, kind, elemNodeConn, coords, ElemDofArray, solnApplied)
+    class(PetscSolver) :: this
+    integer, intent(in) :: kind
+    integer, dimension(:,:), intent(in) :: elemNodeConn, ElemDofArray
+    double precision, dimension(:,:), intent(in) :: coords
+    double precision, dimension(:), intent(in) :: solnApplied
+    integer(c_int), allocatable :: conn0(:,:), edof(:,:)
+    double precision, allocatable :: xyz(:,:), sa(:)
+    integer :: ierr
+    conn0 = elemNodeConn - 1                      ! 0-based copy; column-major (nElem,npElem) IS the SoA layout of the ABI
+    edof = ElemDofArray
+    xyz = coords
+    sa = solnApplied
+    ierr = pfem_mesh_upload(pfem_h2p(this%mtx), int(kind, c_int), int(size(conn0, 1), c_int64_t), conn0, &
+                            int(size(xyz, 1), c_int64_t), xyz, edof, sa)
+    if (ierr /= 0) call pfem_chkerr(ierr)
+#ifdef PFEM_WITH_MPI
+    if (.not. this%attached) then                 ! the local numbering exists now: neighbour plan + communication backend
+      ierr = pfem_mpi_attach(pfem_h2p(this%mtx), PETSC_COMM_WORLD, this%row_start, this%size_local)
+      if (ierr /= 0) call pfem_chkerr(ierr)
+      this%attached = .true.
+    end if
+#endif
+    ierr = pfem_pattern_build(pfem_h2p(this%mtx))
+    if (ierr /= 0) call pfem_chkerr(ierr)
+    call sync_status(this)
+  end subroutine uploadMeshToDevice
+
+  ! EXTENSION: setZero + the element loop (:817-884: element routine, Dirichlet lifting, ADD_VALUES) as ONE device call
+  subroutine assembleOnDevice(this, elemData, timeData)
+    class(PetscSolver) :: this
+    double precision, dimension(:), intent(in) :: elemData, timeData
+    double precision :: ed(8), td(8)
+    integer :: ierr
+    ed = 0.0d0; td = 0.0d0
+    ed(1:min(size(elemData), 8)) = elemData(1:min(size(elemData), 8))
+    td(1:min(size(timeData), 8)) = timeData(1:min(size(timeData), 8))
+    ierr = pfem_assemble(pfem_h2p(this%mtx), ed, td)
+    if (ierr /= 0) call pfem_chkerr(ierr)
+    call sync_status(this)
+  end subroutine assembleOnDevice
 
   ! solverpetsc.F:254-278
   subroutine free(this)

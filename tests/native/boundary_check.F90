@@ -6,6 +6,8 @@
 ! ADD_VALUES, VecScatterCreateToAll + the legacy VecGetArray(xx_v, xx_i) -- but carries none of a driver's mesh
 ! bookkeeping: the prepared problem (coordinates and connectivity in the new numbering, ElemDofArray, element
 ! ownership, row blocks) is read from "problem.txt", written by tests/test_fortran_boundary.py.
+! PFEM_CHECK_MODE=device: the element loop runs on the GPU instead (PetscSolver%uploadMeshToDevice / %assembleOnDevice, the
+! build's extension of the type: one-thread-per-... kernels of the batched path driven from Fortran).
 ! Serial flavour: one process.  MPI flavour (-DPFEM_WITH_MPI, mpiexec -n P): every rank loops over the elements it
 ! owns and passes GLOBAL indices, as tetrapoissonparallelimpl1.F:828-884 does.  Rank 0 writes "solution.txt".
 #include <petsc/finclude/petscsysdef.h>
@@ -29,9 +31,10 @@ program boundary_check
   VecScatter :: ctx
   PetscScalar :: xx_v(1)
   PetscOffset :: xx_i
-  integer :: ndof, nNode, nElem, ntot, nranks_file, nsize, e, a, d, i, j, k, node
-  integer, allocatable :: sizes(:), owner(:), conn(:,:), edof(:,:), rows(:), nnz_d(:), nnz_o(:)
-  double precision, allocatable :: xyz(:,:), applied(:), Kl(:,:), Fl(:), zeroK(:,:), valC(:), valDotC(:)
+  integer :: ndof, nNode, nElem, ntot, nranks_file, nsize, e, a, d, i, j, k, node, nloc
+  integer, allocatable :: sizes(:), owner(:), conn(:,:), edof(:,:), rows(:), nnz_d(:), nnz_o(:), conn_loc(:,:), edof_loc(:,:)
+  double precision, allocatable :: xyz(:,:), applied(:), Kl(:,:), Fl(:), zeroK(:,:), valC(:), valDotC(:), coords(:,:)
+  character(len=32) :: mode
   double precision :: xn(4), yn(4), zn(4), elemData(6), timeData(3), fact
 
   call PetscInitialize("petsc_options.dat", ierr)
@@ -59,6 +62,23 @@ program boundary_check
 
   allocate(rows(nsize), Kl(nsize, nsize), Fl(nsize), zeroK(nsize, nsize), valC(nsize), valDotC(nsize))
   zeroK = 0.0d0; valC = 0.0d0; valDotC = 0.0d0
+
+  call get_environment_variable("PFEM_CHECK_MODE", mode)
+  if (trim(mode) == "device") then
+    ! the element loop on the GPU: the rank's elements in the driver's own array layout (nElem_local, npElem) etc.
+    nloc = count(owner == me)
+    allocate(conn_loc(nloc, 4), edof_loc(nloc, nsize), coords(nNode, 3))
+    k = 0
+    do e = 1, nElem
+      if (owner(e) /= me) cycle
+      k = k + 1
+      conn_loc(k, :) = conn(:, e)
+      edof_loc(k, :) = edof(:, e)
+    end do
+    coords = transpose(xyz)
+    call solver%uploadMeshToDevice(merge(2, 3, ndof == 1), conn_loc, coords, edof_loc, applied)
+    call solver%assembleOnDevice(elemData, timeData)
+  else
 
   ! the pattern: zeros with INSERT_VALUES for every element this rank owns
   do e = 1, nElem
@@ -92,6 +112,7 @@ program boundary_check
     end do
     call VecSetValues(solver%rhsVec, nsize, rows, Fl, ADD_VALUES, ierr)
   end do
+  end if
 
   call solver%factoriseAndSolve()
 

@@ -76,8 +76,12 @@ def test_boundary_program_fails_loudly_without_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["host_loop", "device"])
 @pytest.mark.parametrize("case,world", [("tet10", 1), ("tet10", 2), ("tet10", 3), ("beam", 1), ("beam", 2)])
-def test_fortran_host_program_on_gpu(tmp_path, golden_dir, case, world):
+def test_fortran_host_program_on_gpu(tmp_path, golden_dir, case, world, mode):
+    """mode host_loop: the driver's own element loop (element routine + MatSetValues / VecSetValues per element), the GPU
+    solves.  mode device: PetscSolver%uploadMeshToDevice + %assembleOnDevice -- the element loop itself runs in the HIP
+    kernels, called from Fortran."""
     exe = _exe(world > 1)
     if case == "tet10":
         mesh, ndof, kind = H.read_mesh(f"{golden_dir}/input/tet10"), 1, O.POISSON_TET
@@ -86,7 +90,7 @@ def test_fortran_host_program_on_gpu(tmp_path, golden_dir, case, world):
         mesh, ndof, kind = H.gen_box_tets(-0.5, 0.5, 3, 0.0, 6.0, 12, -0.5, 0.5, 3, bc_mode=1, ndof=3), 3, O.ELAST_TET
         fixture = f"beam3x12x3_elast_np{world}"
     dm, npid = _prepare(mesh, ndof, world, tmp_path / "problem.txt")
-    r = _run(exe, tmp_path, world, rtol="1e-12")
+    r = _run(exe, tmp_path, world, rtol="1e-12", env_extra={"PFEM_CHECK_MODE": mode})
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "Convergence in" in r.stdout and "PC = jacobi" in r.stdout
     lines = open(tmp_path / "solution.txt").read().split()
