@@ -377,3 +377,32 @@ def test_rccl_backend_world_size_1(tmp_path):
     assert int(d["bad"]) == 0
     assert int(d["reason"]) == 2 and abs(int(d["its"]) - ref.its) <= 1
     assert np.abs(d["x"] - ref.soln_free).max() <= 1e-9
+
+
+def test_neighbour_plan_against_brute_force_random_layouts():
+    """pfem_neighbour_plan on random layouts (row blocks of random sizes, including empty ones, random ghost sets) against
+    the definition: shared(r, q) = local(r) & local(q), peers = the ranks with a non-empty intersection."""
+    from hypothesis import given, settings, strategies as st
+    from pfemfort_amd import host as H
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.integers(1, 6), st.integers(0, 60), st.integers(0, 2 ** 31 - 1))
+    def check(world, n, seed):
+        rng = np.random.default_rng(seed)
+        cuts = np.sort(rng.integers(0, n + 1, world - 1))
+        bounds = np.concatenate([[0], cuts, [n]])
+        ranges = [(int(bounds[r]), int(bounds[r + 1])) for r in range(world)]
+        ghosts = []
+        for r in range(world):
+            outside = np.array([g for g in range(n) if not ranges[r][0] <= g < ranges[r][1]], np.int64)
+            k = int(rng.integers(0, len(outside) + 1)) if len(outside) else 0
+            ghosts.append(np.sort(rng.choice(outside, k, replace=False)) if k else np.empty(0, np.int64))
+        local = [set(range(*ranges[r])) | set(ghosts[r].tolist()) for r in range(world)]
+        for r in range(world):
+            peers, off, gid = H.neighbour_plan(r, ranges, ghosts)
+            want = [q for q in range(world) if q != r and local[r] & local[q]]
+            assert peers.tolist() == want
+            for k, q in enumerate(peers):
+                assert gid[off[k]:off[k + 1]].tolist() == sorted(local[r] & local[q])
+
+    check()
