@@ -34,6 +34,12 @@ def _partition(mesh, world, how, H):
         return H.partition_box_slabs(*mesh.box, world)
     if how == "idle":                  # the last rank gets nothing: no elements, no nodes, no rows
         return H.partition_box_slabs(*mesh.box, world - 1)
+    if how == "foreign":               # slabs, but some nodes deep inside slab 0 are OWNED by the last rank, which has no
+        epid, npid = H.partition_box_slabs(*mesh.box, world)         # element touching them: owned rows with an empty
+        inner = np.nonzero(npid == 0)[0]                             # local pattern, ghosts on the rank that assembles them
+        npid = npid.copy()
+        npid[inner[len(inner) // 3::17]] = world - 1
+        return epid, npid
     cen = mesh.xyz[:, mesh.conn].mean(axis=1)
     ang = np.arctan2(cen[1] - cen[1].mean() + 0.013, cen[0] - cen[0].mean() + 0.007)
     epid = np.minimum(((ang + np.pi) / (2 * np.pi) * world).astype(np.int32), world - 1)
@@ -260,7 +266,8 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                                                             ("elast", 2, "slabs", "pbjacobi"), ("elast", 3, "sectors", "pbjacobi"),
                                                             ("poisson", 2, "slabs", "pbjacobi"), ("poisson", 3, "sectors", "int32"),
                                                             ("poisson", 3, "idle", "batched"), ("elast", 3, "idle", "pbjacobi"),
-                                                            ("poisson", 2, "slabs", "overlap"), ("elast", 3, "sectors", "overlap")])
+                                                            ("poisson", 2, "slabs", "overlap"), ("elast", 3, "sectors", "overlap"),
+                                                            ("poisson", 2, "foreign", "batched"), ("elast", 3, "foreign", "compat")])
 def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partition, mode):
     """2-3 ranks share cuda:0 (host-staged exchange over gloo): the product's multi-rank device loop against the
     ORACLE -- a direct solve of the oracle-assembled global system in the partition's new numbering, and the oracle's
