@@ -186,6 +186,9 @@ def run_parallel(kind, mesh: H.Mesh, elem_proc_id, node_proc_id, dist, torch, el
     t0 = time.perf_counter()
     solver.assemble(elemData, timeData)                                  # :817-884
     timers["assembly_s"] = time.perf_counter() - t0
+    if mesh.force_node is not None and ndof > 1:                         # nodal forces :971-982 (intended row: see _run);
+        gdof = dm.NodeDofArrayNew[dm.node_map_get_new[mesh.force_node], mesh.force_dof]   # every rank offers all of them,
+        solver.addNodalForces(gdof, mesh.force_val)                      # the library keeps those of the rank's own rows
     t0 = time.perf_counter()
     its, reason, rnorm = solver.factoriseAndSolve()                      # :898-902
     timers["solve_s"] = time.perf_counter() - t0

@@ -149,3 +149,66 @@ def test_gpu_driver_harness_reproduces_temp_dat(case, tmp_path):
         assert np.array_equal(got[:, :2], want[:, :2])
         got, want = got[:, 2], want[:, 2]
     assert np.abs(got - want).max() <= 1e-8 * max(1.0, np.abs(want).max())
+
+
+# ---------------------------------------------------------------------------------------
+def _gpu_rank_2d(rank, world, port, which, out_dir):
+    import faulthandler
+    faulthandler.dump_traceback_later(240, exit=True)
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pfemfort_amd as pf
+        from pfemfort_amd import drivers as D
+        mesh, kind, ed = _mesh_2d(which, pf)
+        epid, npid = _sectors_2d(mesh, world)
+        res = D.run_parallel(kind, mesh, epid, npid, dist, torch, elemData=ed, rtol=1e-12, maxits=100000, staged=True)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "u.npy"), res.soln_free)
+    finally:
+        dist.destroy_process_group()
+
+
+def _mesh_2d(which, K):
+    if which == "tria20_poisson":
+        return H.read_mesh(os.path.join(HERE, "golden", "input", "tria20x20")), K.POISSON_TRIA, np.array([1.0, 1.0])
+    return H.read_mesh(os.path.join(HERE, "golden", "input", "cookmembranetria32")), K.ELAST_TRIA, H.ELAST2D_ELEMDATA
+
+
+def _sectors_2d(mesh, world):
+    cen = mesh.xyz[:, mesh.conn].mean(axis=1)
+    ang = np.arctan2(cen[1] - cen[1].mean() + 0.013, cen[0] - cen[0].mean() + 0.007)
+    epid = np.minimum(((ang + np.pi) / (2 * np.pi) * world).astype(np.int32), world - 1)
+    touch = np.zeros((world, mesh.nNode), bool)
+    for a in range(mesh.conn.shape[0]):
+        touch[epid, mesh.conn[a]] = True
+    npid = (np.random.default_rng(3).random((world, mesh.nNode)) * touch).argmax(axis=0).astype(np.int32)
+    return epid, npid
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,world", [("tria20_poisson", 2), ("cook_elasticity", 3)])
+def test_gpu_two_dimensional_siblings_on_several_ranks(which, world, tmp_path):
+    """The 2-D siblings of the path (triapoissonparallelimpl1 / triaelasticityparallelimpl1) through the same
+    multi-rank harness: irregular sector partition, nodal forces on Cook's membrane, against a direct solve of the
+    oracle-assembled system."""
+    import socket
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    import torch.multiprocessing as mp
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    mp.spawn(_gpu_rank_2d, args=(world, port, which, str(tmp_path)), nprocs=world, join=True)
+    mesh, kind, ed = _mesh_2d(which, O)
+    _, npid = _sectors_2d(mesh, world)
+    prob = O.setup_problem(kind, O.Mesh(mesh.xyz, mesh.conn, mesh.bc_node, mesh.bc_dof, mesh.bc_val), elemData=ed, nParts=world,
+                           node_proc_id=npid)
+    rhs = prob.rhs.copy()
+    if mesh.force_node is not None and which.startswith("cook"):
+        rhs[prob.dm.NodeDofArrayNew[prob.dm.node_map_get_new[mesh.force_node], mesh.force_dof]] += mesh.force_val
+    u = spl.spsolve(sp.csr_matrix((prob.vals, prob.cols, prob.rowptr)).tocsc(), rhs)
+    got = np.load(tmp_path / "u.npy")
+    assert np.abs(got - u).max() <= 1e-8 * max(1.0, np.abs(u).max())
