@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--no-parity-step", action="store_true", help="skip the extra (untimed) step at rtol 1e-10")
     ap.add_argument("--pc", choices=["jacobi", "pbjacobi"], default="jacobi")
     ap.add_argument("--backend", default="nccl", help="nccl: RCCL bound inside the library; gloo: host hooks (development)")
+    ap.add_argument("--simulate-rccl-failure", action="store_true", help="development: exercise the fallback to gloo host hooks")
     ap.add_argument("--same-device", action="store_true",
                     help="development: put every rank on cuda:0 (with --backend gloo) to exercise the N>1 path on a 1-GPU box")
     args = ap.parse_args()
@@ -191,12 +192,32 @@ def main():
     solver.generateBoxMesh(kind, *box, bc_mode=bc_mode, nparts=world, part=rank)
     t_generate = time.perf_counter() - t_setup
     hooks = None
+    transport = "gloo host hooks" if args.backend == "gloo" else "RCCL bound in C++"
     if world > 1:
         from pfemfort_amd import distributed as PD
-        hooks = PD.attach(solver, dist, torch, staged=(args.backend == "gloo"))   # RCCL inside the library unless gloo
-        bad = solver.commSelftest(4096)
-        if bad:
-            raise SystemExit(f"rank {rank}: communication self-test failed ({bad} wrong entries)")
+        # RCCL inside the library unless the group is gloo.  If RCCL cannot be brought up or fails the transport self-test
+        # on ANY rank, all ranks fall back together to host hooks over a gloo subgroup: slow, but a result.
+        why = None
+        if args.backend != "gloo" or args.simulate_rccl_failure:
+            try:
+                if args.simulate_rccl_failure:
+                    raise pf.PfemError(9, "simulated", "--simulate-rccl-failure")
+                hooks = PD.attach(solver, dist, torch, staged=False)
+                bad = solver.commSelftest(4096)
+                why = f"self-test: {bad} wrong entries" if bad else None
+            except pf.PfemError as e:
+                why = str(e)
+            votes = [None] * world
+            dist.all_gather_object(votes, why)
+            why = next((v for v in votes if v), None)
+        if args.backend == "gloo" or why:
+            grp = None if (args.backend == "gloo" and not why) else dist.new_group(backend="gloo")
+            hooks = PD.attach(solver, dist, torch, staged=True, group=grp)
+            bad = solver.commSelftest(4096)
+            if bad:
+                raise SystemExit(f"rank {rank}: communication self-test failed ({bad} wrong entries)")
+            if why:
+                transport = f"gloo host hooks (fallback: RCCL was not usable: {why})"
     t1 = time.perf_counter()
     solver.buildPattern()
     t_pattern = time.perf_counter() - t1
@@ -321,8 +342,7 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else
                                       f"{world} z-slabs, sub-assembled interface rows, neighbour exchange of "
                                       f"{cinfo['doubles_per_exchange']} doubles with {cinfo['n_peers']} neighbour(s) per SpMV "
-                                      "(overlapped with the interior slices) + 2 scalar all-reduces, "
-                                      + ("gloo host hooks" if args.backend == "gloo" else "RCCL bound in C++")},
+                                      "+ 2 scalar all-reduces, in order on the compute stream; transport: " + transport},
             "iterations": its, "converged_reason": reason, "rnorm": rnorm, check_name: check,
             "assembly_ms_per_step": asm_ms / args.steps, "solve_ms_per_step": sol_ms / args.steps,
             "ms_per_iteration": sol_ms / args.steps / max(its, 1),     # weak scaling: iterations grow with the problem

@@ -25,19 +25,19 @@ from . import host as H
 from .solver import rccl_unique_id
 
 
-def gather_ghost_lists(ghosts, dist):
+def gather_ghost_lists(ghosts, dist, group=None):
     """all_gather of variable-length int64 arrays through ``torch.distributed``."""
     out = [None] * dist.get_world_size()
-    dist.all_gather_object(out, np.asarray(ghosts, dtype=np.int64))
+    dist.all_gather_object(out, np.asarray(ghosts, dtype=np.int64), group=group)
     return out
 
 
-def plan_for(solver, dist):
+def plan_for(solver, dist, group=None):
     """Exchange ghost lists and row blocks, derive this rank's neighbour plan."""
     rank, world = dist.get_rank(), dist.get_world_size()
-    lists = gather_ghost_lists(solver.ghosts(), dist)
+    lists = gather_ghost_lists(solver.ghosts(), dist, group)
     ranges = [None] * world
-    dist.all_gather_object(ranges, (solver.row_start, solver.row_start + solver.size_local))
+    dist.all_gather_object(ranges, (solver.row_start, solver.row_start + solver.size_local), group=group)
     return H.neighbour_plan(rank, ranges, lists)
 
 
@@ -45,8 +45,8 @@ class HostHooks:
     """Host-memory hooks over a ``torch.distributed`` group (gloo).  The all-reduce is reduce-to-rank-0 +
     broadcast, so that every rank receives the same bits whatever algorithm the group would pick."""
 
-    def __init__(self, dist, torch):
-        self.dist, self.torch = dist, torch
+    def __init__(self, dist, torch, group=None):
+        self.dist, self.torch, self.group = dist, torch, group
         self.calls = 0               # hook calls (all-reduces + exchanges)
         self.error = None
         self.log = None              # optional list of ("a"|"x", count) for call-sequence checks
@@ -55,8 +55,8 @@ class HostHooks:
         try:
             a = np.ctypeslib.as_array(buf, shape=(int(count),))
             t = self.torch.from_numpy(a)
-            self.dist.reduce(t, 0)
-            self.dist.broadcast(t, 0)
+            self.dist.reduce(t, 0, group=self.group)
+            self.dist.broadcast(t, 0, group=self.group)
             self.calls += 1
             if self.log is not None:
                 self.log.append(("a", int(count)))
@@ -73,8 +73,8 @@ class HostHooks:
             reqs = []
             for k in range(n_peers):
                 lo, hi, q = int(off[k]), int(off[k + 1]), int(peers[k])
-                reqs.append(self.dist.isend(s[lo:hi], q))
-                reqs.append(self.dist.irecv(r[lo:hi], q))
+                reqs.append(self.dist.isend(s[lo:hi], q, group=self.group))
+                reqs.append(self.dist.irecv(r[lo:hi], q, group=self.group))
             for w in reqs:
                 w.wait()
             self.calls += 1
@@ -86,21 +86,21 @@ class HostHooks:
             return 1
 
 
-def attach(solver, dist, torch=None, staged=False):
+def attach(solver, dist, torch=None, staged=False, group=None):
     """Wire a solver that already holds its mesh (or, compat path, its pattern) to the process group: neighbour
     plan + communication backend.  ``staged=False``: RCCL inside the library (one rank per GPU).
-    ``staged=True``: host hooks over the group (gloo; several ranks may share a GPU).  Returns the HostHooks
-    object (staged) or None."""
+    ``staged=True``: host hooks over the group (gloo; several ranks may share a GPU); ``group``: a gloo subgroup when
+    the default group is not one.  Returns the HostHooks object (staged) or None."""
     rank, world = dist.get_rank(), dist.get_world_size()
-    peers, off, gid = plan_for(solver, dist)
+    peers, off, gid = plan_for(solver, dist, group)
     hooks = None
     if staged:
-        hooks = HostHooks(dist, torch)
+        hooks = HostHooks(dist, torch, group)
         solver.setCommHost(rank, world, hooks.allreduce, hooks.exchange)
         solver._keep.append(hooks)
     else:
         ids = [rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
+        dist.broadcast_object_list(ids, src=0, group=group)
         solver.setCommRccl(rank, world, ids[0])
     solver.setNeighbours(peers, off, gid)
     return hooks

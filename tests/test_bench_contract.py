@@ -50,12 +50,16 @@ def test_bench_two_ranks_sharing_the_device():
         port = so.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--cells", "40", "--backend", "gloo", "--same-device"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--cells", "40", "--backend", "gloo", "--same-device", "--simulate-rccl-failure"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["converged_reason"] == 2 and d["max_nodal_error"] < 1e-3 and d["scaling"] == "weak"
+    # (the run also went through bench.py's safety net: a rank reported RCCL unusable, all ranks fell back together to host
+    # hooks over a gloo subgroup)
+    assert "fallback: RCCL was not usable" in d["config"]["parallelism"]
     side = round(40 * 2 ** (1 / 3))
     assert d["config"]["free_dofs"] == (side - 1) ** 3
     c = d["comm"]
