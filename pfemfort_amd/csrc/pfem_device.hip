@@ -308,7 +308,7 @@ struct pfem_solver {
     std::vector<hipEvent_t> xev;                 // cross-stream events (no timing), used round-robin
     size_t xev_next = 0;
     bool have_plan = false;
-    bool multi_overlap = false;                  // see run_pcg: measured, the in-order form is faster on this stack
+    static constexpr int64_t kOverlapMinBytes = 512 * 1024;   // see run_pcg
     std::vector<int> peers;
     std::vector<int64_t> peer_off;               // [n_peers+1] offsets into the send / receive buffers
     int64_t n_send = 0, n_sh = 0;                // doubles per exchange; distinct shared dofs of this rank
@@ -1702,11 +1702,10 @@ struct HostBackend final : CommBackend {
 int ensure_comm_stream(pfem_solver *s)
 {
     if (!s->comm_stream) {
-        // highest priority: the small pack-free communication kernels must not queue behind the 30 000 blocks of the
-        // interior SpMV pass they are meant to run under
-        int least = 0, greatest = 0;
-        PFEM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        PFEM_HIP(hipStreamCreateWithPriority(&s->comm_stream, hipStreamNonBlocking, greatest));
+        // DEFAULT priority on purpose: with a high-priority communication stream the overlapped iteration took 0.68 ms
+        // instead of 0.37 ms (tools/probe_overlap.py, same box) -- every launch on the prioritised queue stalls the
+        // compute queue on this stack
+        PFEM_HIP(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
     }
     while (s->xev.size() < 32) {
         hipEvent_t e;
@@ -2006,16 +2005,17 @@ int run_pcg(pfem_solver *s)
     const bool multi = s->nranks > 1 || (s->comm && s->have_plan && std::getenv("PFEM_FORCE_MULTI"));
     s->group_vals_stale = true;            // the row form may have been re-assembled since the last solve
     PFEM_TRY(refresh_group_vals(s));
-    // Two forms of the multi-rank iteration.  In order (default): whole SpMV, pack, exchange, all-reduce ... on the compute
-    // stream.  Overlapped (PFEM_MULTI_OVERLAP=1): the slices with shared rows first, the exchange on the communication
-    // stream under the interior slices, two stream hand-overs per iteration.  Measured on MI355X / ROCm 7.2 with the rank as
-    // its own neighbour (tools/probe_overlap.py, 200^3 per rank, 634 kB exchanged): in order 0.346 ms per iteration against
-    // 0.329 for the single-rank loop (exchange 14 us, both all-reduces 11 us); overlapped 0.676 ms -- the RCCL launch takes
-    // 90 us on the second stream, each hand-over 12-30 us, and the split SpMV loses 70 us to the concurrent copy kernel.
-    // The overlapped form pays only where an exchange costs more than ~150 us.
+    // Two forms of the multi-rank iteration.  In order: whole SpMV, pack, exchange, all-reduce ... on the compute stream:
+    // costs the exchange itself.  Overlapped: the slices with shared rows first, the exchange on the communication stream
+    // under the interior slices, two stream hand-overs: costs ~27 us whatever the exchange takes, as long as it is shorter
+    // than the interior pass.  Measured on MI355X / ROCm 7.2 with the rank as its own neighbour (tools/probe_overlap.py,
+    // 200^3 per rank, 634 kB per exchange; single-rank loop 0.339 ms per iteration): in order 0.346 ms (exchange 14 us on
+    // the local device), overlapped 0.366 ms (exchange 83 us, hidden).  Over xGMI a 1.27 MB face costs several times
+    // the local copy, so exchanges of kOverlapMinBytes and more take the overlapped form; PFEM_MULTI_OVERLAP=0/1 overrides.
     const bool overlap = [&] {
         const char *e = std::getenv("PFEM_MULTI_OVERLAP");
-        return e ? std::atoi(e) != 0 : s->multi_overlap;
+        if (e) return std::atoi(e) != 0;
+        return s->nranks > 1 && s->n_send * 8 >= pfem_solver::kOverlapMinBytes;
     }();
     const unsigned gv = vec_grid(n), gs = spmv_blocks(s);
     const dim3 block(kBlock);

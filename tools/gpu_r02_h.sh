@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp; OUT=$GRAFT_REPO_ROOT/gpurun_out
-for ov in 1 0; do for n in 200 100; do
-( PFEM_MULTI_OVERLAP=$ov timeout 300 python tools/probe_overlap.py $n 200 2>$OUT/probe_ov.err | grep '^{' | tail -1 ) > $OUT/probe_overlap_${n}_ov$ov.json
-echo "overlap=$ov n=$n"; cat $OUT/probe_overlap_${n}_ov$ov.json
-done; done
+for pr in 0; do
+( PFEM_MULTI_OVERLAP=$pr timeout 300 python tools/probe_overlap.py 200 200 2>$OUT/probe_ov.err | grep '^{' | tail -1 ) > $OUT/probe_overlap_200_ov1_prio$pr.json
+echo "overlap=default(by size) run"; cat $OUT/probe_overlap_200_ov1_prio$pr.json
+done
