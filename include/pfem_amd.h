@@ -141,6 +141,12 @@ int pfem_assy_for_soln(int64_t nNode, int ndof, const int32_t *NodeDofArrayNew,
  * (elem_proc_id,node_proc_id) can be fed to pfem_dof_numbering instead.        */
 int pfem_partition_box_slabs(int nEx, int nEy, int nEz, int nParts,
                              int32_t *elem_proc_id, int32_t *node_proc_id);
+/* Recursive coordinate bisection of the element centroids (median splits along the longest axis, any nParts): a
+ * geometric stand-in for METIS_PartMeshNodal on meshes WITH coordinates; a node goes to the lowest part among the
+ * elements touching it.  conn SoA npElem x nElem, 0-based; xyz SoA ndim x nNode.  (A real METIS partition is taken
+ * through its files: PFEM_METIS_PREFIX / read_metis_partition.)                                                     */
+int pfem_partition_rcb(int64_t nNode, int ndim, const double *xyz, int64_t nElem, int npElem, const int32_t *conn,
+                       int nParts, int32_t *elem_proc_id, int32_t *node_proc_id);
 
 /* Mesh ingest, the step before the path: the three/four `.dat` files are whitespace-
  * separated ASCII tables, one record per line (tetrapoissonparallelimpl1.F:216-355).  `shape` counts

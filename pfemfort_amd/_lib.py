@@ -70,6 +70,7 @@ SIGNATURES = {
     "pfem_elem_dof_array": [_L, _I, _I, _P, _P, _P],
     "pfem_assy_for_soln": [_L, _I, _P, _P],
     "pfem_partition_box_slabs": [_I, _I, _I, _I, _P, _P],
+    "pfem_partition_rcb": [_L, _I, _P, _L, _I, _P, _I, _P, _P],
     "pfem_text_table_shape": [C.c_char_p, _L, _P, _P],
     "pfem_text_table_parse": [C.c_char_p, _L, _L, _I, _P],
     "pfem_write_vtk": [C.c_char_p, _I, _L, _L, _I, _I, _P, _P, _P, _P],

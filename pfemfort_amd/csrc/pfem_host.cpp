@@ -242,6 +242,65 @@ extern "C" int pfem_partition_box_slabs(int nEx, int nEy, int nEz, int nParts,
     return PFEM_OK;
 }
 
+// Recursive coordinate bisection: a geometric stand-in for METIS_PartMeshNodal (:464) on ANY mesh with coordinates
+// (METIS itself is a third-party library absent here; its output is taken through the file hook when available).
+// Elements are split by the median of their centroids along the longest axis of the current box, parts sized in
+// proportion (nparts need not be a power of two); a node goes to the lowest part among the elements that touch it, so
+// every owner assembles at least one element at its nodes.  Deterministic: ties are broken by element id.
+namespace {
+void rcb_split(std::vector<int64_t> &ids, int64_t lo, int64_t hi, int p0, int np, const double *cx, const double *cy,
+               const double *cz, int ndim, int32_t *epart)
+{
+    if (np == 1) {
+        for (int64_t i = lo; i < hi; ++i) epart[ids[i]] = p0;
+        return;
+    }
+    const double *c[3] = {cx, cy, cz};
+    int axis = 0;
+    double best = -1.0;
+    for (int d = 0; d < ndim; ++d) {
+        double mn = 1e300, mx = -1e300;
+        for (int64_t i = lo; i < hi; ++i) { mn = std::min(mn, c[d][ids[i]]); mx = std::max(mx, c[d][ids[i]]); }
+        if (mx - mn > best) { best = mx - mn; axis = d; }
+    }
+    const int npl = np / 2;
+    const int64_t mid = lo + (hi - lo) * npl / np;
+    const double *ca = c[axis];
+    std::nth_element(ids.begin() + lo, ids.begin() + mid, ids.begin() + hi, [ca](int64_t a, int64_t b) {
+        return ca[a] < ca[b] || (ca[a] == ca[b] && a < b);
+    });
+    rcb_split(ids, lo, mid, p0, npl, cx, cy, cz, ndim, epart);
+    rcb_split(ids, mid, hi, p0 + npl, np - npl, cx, cy, cz, ndim, epart);
+}
+}  // namespace
+
+extern "C" int pfem_partition_rcb(int64_t nNode, int ndim, const double *xyz, int64_t nElem, int npElem, const int32_t *conn,
+                                  int nParts, int32_t *elem_proc_id, int32_t *node_proc_id)
+{
+    if (nNode < 1 || (ndim != 2 && ndim != 3) || !xyz || nElem < 0 || npElem < 1 || (nElem && !conn) || nParts < 1 ||
+        !elem_proc_id || !node_proc_id)
+        return PFEM_ERR_ARG;
+    std::vector<double> cen(static_cast<size_t>(3) * std::max<int64_t>(nElem, 1), 0.0);
+    for (int64_t e = 0; e < nElem; ++e)
+        for (int a = 0; a < npElem; ++a) {
+            const int32_t n = conn[static_cast<int64_t>(a) * nElem + e];
+            if (n < 0 || n >= nNode) return PFEM_ERR_ARG;
+            for (int d = 0; d < ndim; ++d) cen[static_cast<size_t>(d) * nElem + e] += xyz[static_cast<int64_t>(d) * nNode + n] / npElem;
+        }
+    std::vector<int64_t> ids(static_cast<size_t>(nElem));
+    for (int64_t e = 0; e < nElem; ++e) ids[e] = e;
+    if (nElem > 0) rcb_split(ids, 0, nElem, 0, std::min<int64_t>(nParts, nElem), cen.data(), cen.data() + nElem, cen.data() + 2 * nElem, ndim, elem_proc_id);
+    for (int64_t n = 0; n < nNode; ++n) node_proc_id[n] = nParts;           // lowest adjacent part wins
+    for (int64_t e = 0; e < nElem; ++e)
+        for (int a = 0; a < npElem; ++a) {
+            int32_t &p = node_proc_id[conn[static_cast<int64_t>(a) * nElem + e]];
+            p = std::min(p, elem_proc_id[e]);
+        }
+    for (int64_t n = 0; n < nNode; ++n)
+        if (node_proc_id[n] == nParts) node_proc_id[n] = 0;                  // a node no element touches
+    return PFEM_OK;
+}
+
 // ---------------------------------------------------------------------------
 // 3. Dirichlet bookkeeping and (re)numbering (tetrapoissonparallelimpl1.F)
 // ---------------------------------------------------------------------------

@@ -133,6 +133,16 @@ def partition_box_slabs(nEx, nEy, nEz, nParts, elements=True):
     return epid, npid
 
 
+def partition_rcb(mesh, nParts):
+    """(elem_proc_id, node_proc_id) by recursive coordinate bisection of the element centroids: a geometric stand-in
+    for METIS_PartMeshNodal (:464) on any mesh with coordinates."""
+    xyz = _f64(mesh.xyz); conn = _i32(mesh.conn)
+    epid = np.empty(conn.shape[1], np.int32); npid = np.empty(xyz.shape[1], np.int32)
+    L.check(L.lib().pfem_partition_rcb(xyz.shape[1], xyz.shape[0], _p(xyz), conn.shape[1], conn.shape[0], _p(conn), nParts,
+                                       _p(epid), _p(npid)), "pfem_partition_rcb")
+    return epid, npid
+
+
 def read_metis_partition(prefix: str, nParts: int):
     """(elem_proc_id, node_proc_id) from the files METIS' ``mpmetis <mesh> nParts`` writes
     (``<prefix>.epart.<nParts>`` / ``<prefix>.npart.<nParts>``, one 0-based part per line): the

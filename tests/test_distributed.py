@@ -32,6 +32,8 @@ def _partition(mesh, world, how, H):
     blocks interleave in space).  Deterministic: every rank computes the same arrays."""
     if how == "slabs":
         return H.partition_box_slabs(*mesh.box, world)
+    if how == "rcb":                   # the build's own geometric partitioner (pfem_partition_rcb)
+        return H.partition_rcb(mesh, world)
     if how == "idle":                  # the last rank gets nothing: no elements, no nodes, no rows
         return H.partition_box_slabs(*mesh.box, world - 1)
     if how == "foreign":               # slabs, but some nodes deep inside slab 0 are OWNED by the last rank, which has no
@@ -141,7 +143,8 @@ def _cpu_worker(rank, world, port, kind_name, mesh_args, out_dir):
 
 
 @pytest.mark.parametrize("kind_name,world,partition", [("poisson", 2, "slabs"), ("elast", 2, "slabs"),
-                                                       ("poisson", 3, "sectors"), ("elast", 3, "sectors")])
+                                                       ("poisson", 3, "sectors"), ("elast", 3, "sectors"),
+                                                       ("poisson", 3, "rcb")])
 def test_gloo_neighbour_plan_sums_subassembled_rows(tmp_path, kind_name, world, partition):
     import torch.multiprocessing as mp
     from oracle import pfem_oracle as O
@@ -267,7 +270,8 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                                                             ("poisson", 2, "slabs", "pbjacobi"), ("poisson", 3, "sectors", "int32"),
                                                             ("poisson", 3, "idle", "batched"), ("elast", 3, "idle", "pbjacobi"),
                                                             ("poisson", 2, "slabs", "overlap"), ("elast", 3, "sectors", "overlap"),
-                                                            ("poisson", 2, "foreign", "batched"), ("elast", 3, "foreign", "compat")])
+                                                            ("poisson", 2, "foreign", "batched"), ("elast", 3, "foreign", "compat"),
+                                                            ("poisson", 3, "rcb", "batched"), ("elast", 3, "rcb", "overlap")])
 def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partition, mode):
     """2-3 ranks share cuda:0 (host-staged exchange over gloo): the product's multi-rank device loop against the
     ORACLE -- a direct solve of the oracle-assembled global system in the partition's new numbering, and the oracle's

@@ -197,3 +197,28 @@ def test_box_slab_sizes_match_the_host_bookkeeping(box, bc_mode, ndof):
             assert sz["nElem_local"] == int((epid == part).sum())
             k0, k1 = nEz * part // nparts, nEz * (part + 1) // nparts
             assert sz["nNode_local"] == (nEx + 1) * (nEy + 1) * (k1 - k0 + 1)
+
+
+@pytest.mark.parametrize("nparts", [1, 2, 3, 5, 8])
+def test_rcb_partition_is_balanced_compact_and_deterministic(tet10, nparts, golden_dir):
+    """pfem_partition_rcb: parts differ by at most one element per split level, every node's owner assembles an element
+    at it, the result does not depend on anything but the mesh, and on the 2-D Cook membrane too."""
+    for mesh in (tet10, H.read_mesh(f"{golden_dir}/input/cookmembranetria32")):
+        epid, npid = H.partition_rcb(mesh, nparts)
+        e2, n2 = H.partition_rcb(mesh, nparts)
+        assert np.array_equal(epid, e2) and np.array_equal(npid, n2)
+        cnt = np.bincount(epid, minlength=nparts)
+        assert cnt.min() >= mesh.nElem // nparts - 4 and cnt.max() <= -(-mesh.nElem // nparts) + 4 and len(cnt) == nparts
+        assert npid.min() >= 0 and npid.max() < nparts
+        touch = np.zeros((nparts, mesh.nNode), bool)
+        for a in range(mesh.conn.shape[0]):
+            touch[epid, mesh.conn[a]] = True
+        assert touch[npid, np.arange(mesh.nNode)].all()                     # the owner assembles at the node
+        # compact: the parts' bounding boxes overlap little -- far fewer interface nodes than a random assignment
+        if nparts > 1:
+            shared = (touch.sum(axis=0) > 1).sum()
+            rnd = np.random.default_rng(0).integers(0, nparts, mesh.nElem)
+            t2 = np.zeros((nparts, mesh.nNode), bool)
+            for a in range(mesh.conn.shape[0]):
+                t2[rnd, mesh.conn[a]] = True
+            assert shared < 0.5 * (t2.sum(axis=0) > 1).sum()
