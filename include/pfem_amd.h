@@ -162,6 +162,10 @@ int pfem_text_table_parse(const char *buf, int64_t len, int64_t rows, int cols, 
 int pfem_write_vtk(const char *path, int ndim, int64_t nElem, int64_t nNode, int npElem, int ndof,
                    const double *coords, const int32_t *conn, const int32_t *elem_procid,
                    const double *soln);
+/* temp.dat of the drivers: one record per free dof, " ii ind value" (tetrapoissonparallelimpl1.F:935-942) or, with
+ * ii = ind = NULL, the value alone (tetraelasticityparallelimpl1.F:1031-1046); values as %.16E.  Formatted on all host
+ * threads like pfem_write_vtk.                                                                                      */
+int pfem_write_temp_dat(const char *path, int64_t n, const int64_t *ii, const int64_t *ind, const double *val);
 
 /* ========================================================================= */
 /* 3. the solver object == TYPE PetscSolver (solverpetsc.F:72-105)            */

@@ -74,6 +74,7 @@ SIGNATURES = {
     "pfem_text_table_shape": [C.c_char_p, _L, _P, _P],
     "pfem_text_table_parse": [C.c_char_p, _L, _L, _I, _P],
     "pfem_write_vtk": [C.c_char_p, _I, _L, _L, _I, _I, _P, _P, _P, _P],
+    "pfem_write_temp_dat": [C.c_char_p, _L, _P, _P, _P],
     "pfem_solver_create": [_P, _L, _L, _L, _P, _P, _I],
     "pfem_solver_destroy": [_P],
     "pfem_solver_set_stream": [_P, _P],

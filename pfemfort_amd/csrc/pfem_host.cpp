@@ -4,7 +4,11 @@
 // without a GPU and are exercised by the CPU test-suite against the oracle.
 #include "pfem_internal.hpp"
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -503,6 +507,76 @@ extern "C" int pfem_neighbour_plan(int nranks, int rank, const int64_t *row_star
 // ---------------------------------------------------------------------------
 // 5. output step (after the path): legacy ASCII VTK, byte-compatible with writervtk.F:33-201
 // ---------------------------------------------------------------------------
+namespace {
+// "%12.6f" of v into dst (at least 400 bytes), returns the byte count.  Values of ordinary size take a short path that
+// is byte-identical to printf: r = v*1e6 rounded to an integer, accepted only when the exact residual v*1e6 - r (one
+// fma) is clearly inside (-1/2, 1/2) -- near a tie, for large or non-finite values, snprintf decides.
+inline int fmt_f12_6(char *dst, double v)
+{
+    const double a = std::fabs(v);
+    if (a < 9999.0) {
+        const double r = std::nearbyint(a * 1e6);
+        const double res = std::fma(a, 1e6, -r);
+        if (std::fabs(res) < 0.4999999) {
+            uint64_t q = static_cast<uint64_t>(r);
+            char tmp[12];
+            for (int k = 11; k >= 0; --k) {
+                if (k == 5) { tmp[k] = '.'; continue; }
+                tmp[k] = static_cast<char>('0' + q % 10);
+                q /= 10;
+            }
+            int lead = 0;                                   // blanks instead of leading zeros, one digit before the point
+            while (lead < 4 && tmp[lead] == '0') { tmp[lead] = ' '; ++lead; }
+            if (std::signbit(v)) tmp[lead - 1 >= 0 ? lead - 1 : 0] = '-';   // a < 9999: at least one blank is left
+            std::memcpy(dst, tmp, 12);
+            return 12;
+        }
+    }
+    return std::snprintf(dst, 400, "%12.6f", v);
+}
+
+// "%<width>d" for width <= 11
+inline int fmt_int(char *dst, int width, int32_t v)
+{
+    char tmp[12];
+    int n = 0;
+    uint32_t u = v < 0 ? 0u - static_cast<uint32_t>(v) : static_cast<uint32_t>(v);
+    do { tmp[n++] = static_cast<char>('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) tmp[n++] = '-';
+    int out = 0;
+    for (int k = n; k < width; ++k) dst[out++] = ' ';
+    while (n) dst[out++] = tmp[--n];
+    return out;
+}
+
+// Formats records [0,n) on all threads, block by block, and writes the blocks in order.  `fmt(dst, i)` returns the bytes
+// it wrote (never more than max_rec).
+template <class F>
+void emit_records(std::FILE *f, int64_t n, int max_rec, F fmt)
+{
+    int nt = 1;
+#ifdef _OPENMP
+    nt = std::max(1, omp_get_max_threads());
+#endif
+    const int64_t block = 4096;
+    nt = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(nt, (n + block - 1) / block)));
+    std::vector<std::vector<char>> bufs(static_cast<size_t>(nt));
+    std::vector<size_t> used(static_cast<size_t>(nt), 0);
+    for (auto &b : bufs) b.resize(static_cast<size_t>(block) * max_rec);
+    for (int64_t base = 0; base < n; base += block * nt) {
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+        for (int t = 0; t < nt; ++t) {
+            const int64_t b = base + t * block, e = std::min(n, b + block);
+            char *p = bufs[t].data();
+            for (int64_t i = b; i < e; ++i) p += fmt(p, i);
+            used[t] = b < e ? static_cast<size_t>(p - bufs[t].data()) : 0;
+        }
+        for (int t = 0; t < nt; ++t)
+            if (used[t]) std::fwrite(bufs[t].data(), 1, used[t], f);
+    }
+}
+}  // namespace
+
 extern "C" int pfem_write_vtk(const char *path, int ndim, int64_t nElem, int64_t nNode, int npElem, int ndof,
                               const double *coords /*SoA [d*nNode+n]*/, const int32_t *conn /*SoA, 0-based*/,
                               const int32_t *elem_procid, const double *soln /*[n*ndof+d]*/)
@@ -517,35 +591,64 @@ extern "C" int pfem_write_vtk(const char *path, int ndim, int64_t nElem, int64_t
     if (ncol == 0 || ncol > npElem) return PFEM_ERR_ARG;
     std::FILE *f = std::fopen(path, "w");
     if (!f) return PFEM_ERR_ARG;
-    std::vector<char> buf(1 << 22);
-    std::setvbuf(f, buf.data(), _IOFBF, buf.size());
     std::fputs("# vtk DataFile Version 4.0\n", f);               // '(A)'
     std::fputs("PoissonTwoD example\n", f);
     std::fputs(" ASCII\n", f);                                   // list-directed write(1,*): leading blank
     std::fputs("DATASET UNSTRUCTURED_GRID\n", f);
     std::fprintf(f, "POINTS %10lld float\n", static_cast<long long>(nNode));     // '(A,I10,A)'
-    for (int64_t n = 0; n < nNode; ++n)                          // '(F12.6,F12.6,F12.6)'
-        std::fprintf(f, "%12.6f%12.6f%12.6f\n", coords[n], coords[nNode + n], ndim == 3 ? coords[2 * nNode + n] : 0.0);
+    const auto triple = [](char *p, double a, double b, double c) {             // '(F12.6,F12.6,F12.6)'
+        char *q = p;
+        q += fmt_f12_6(q, a);
+        q += fmt_f12_6(q, b);
+        q += fmt_f12_6(q, c);
+        *q++ = '\n';
+        return static_cast<int>(q - p);
+    };
+    emit_records(f, nNode, 1204, [&](char *p, int64_t n) {
+        return triple(p, coords[n], coords[nNode + n], ndim == 3 ? coords[2 * nNode + n] : 0.0);
+    });
     std::fprintf(f, "CELLS %10lld%10lld\n", static_cast<long long>(nElem), static_cast<long long>(nElem * (npElem + 1)));
-    for (int64_t e = 0; e < nElem; ++e) {                        // 0-based ids, npElem first
-        std::fprintf(f, "%10d", npElem);
-        for (int a = 0; a < ncol; ++a) std::fprintf(f, "%10d", conn[a * nElem + e]);
-        std::fputc('\n', f);
-    }
+    emit_records(f, nElem, 16 * 8, [&](char *p, int64_t e) {     // 0-based ids, npElem first
+        char *q = p;
+        q += fmt_int(q, 10, npElem);
+        for (int a = 0; a < ncol; ++a) q += fmt_int(q, 10, conn[a * nElem + e]);
+        *q++ = '\n';
+        return static_cast<int>(q - p);
+    });
     std::fprintf(f, "CELL_TYPES%10lld\n", static_cast<long long>(nElem));
-    for (int64_t e = 0; e < nElem; ++e) std::fprintf(f, "%3d\n", cell_type);
+    emit_records(f, nElem, 16, [&](char *p, int64_t) { int k = fmt_int(p, 3, cell_type); p[k] = '\n'; return k + 1; });
     std::fprintf(f, "CELL_DATA%10lld\n", static_cast<long long>(nElem));
     std::fputs("SCALARS procid int 1\nLOOKUP_TABLE default\n", f);
-    for (int64_t e = 0; e < nElem; ++e) std::fprintf(f, "%3d\n", elem_procid[e]);
+    emit_records(f, nElem, 16, [&](char *p, int64_t e) { int k = fmt_int(p, 3, elem_procid[e]); p[k] = '\n'; return k + 1; });
     std::fprintf(f, "POINT_DATA%10lld\n", static_cast<long long>(nNode));
     if (ndof == 1) {
         std::fputs("SCALARS solution float 1\nLOOKUP_TABLE default\n", f);
-        for (int64_t n = 0; n < nNode; ++n) std::fprintf(f, "%12.6f\n", soln[n]);
+        emit_records(f, nNode, 404, [&](char *p, int64_t n) { int k = fmt_f12_6(p, soln[n]); p[k] = '\n'; return k + 1; });
     } else {
         std::fputs("VECTORS solution float\n", f);
-        for (int64_t n = 0; n < nNode; ++n)
-            std::fprintf(f, "%12.6f%12.6f%12.6f\n", soln[n * ndof], soln[n * ndof + 1], ndof == 2 ? 0.0 : soln[n * ndof + 2]);
+        emit_records(f, nNode, 1204, [&](char *p, int64_t n) {
+            return triple(p, soln[n * ndof], soln[n * ndof + 1], ndof == 2 ? 0.0 : soln[n * ndof + 2]);
+        });
     }
+    const bool ok = std::fflush(f) == 0 && !std::ferror(f);
+    std::fclose(f);
+    return ok ? PFEM_OK : PFEM_ERR_ARG;
+}
+
+// temp.dat of the drivers (tetrapoissonparallelimpl1.F:935-942: "ii, ind, value" per free dof; the elasticity driver
+// :1031-1046 writes the value alone): `ind` NULL selects the value-only form.  Numbers as the Python mirror printed them
+// before (" %11d %11d   %.16E"), which is what the fixtures of the reference's runs are compared through.
+extern "C" int pfem_write_temp_dat(const char *path, int64_t n, const int64_t *ii, const int64_t *ind, const double *val)
+{
+    if (!path || n < 0 || (n && !val) || ((ii == nullptr) != (ind == nullptr))) return PFEM_ERR_ARG;
+    std::FILE *f = std::fopen(path, "w");
+    if (!f) return PFEM_ERR_ARG;
+    if (ind)
+        emit_records(f, n, 96, [&](char *p, int64_t i) {
+            return std::snprintf(p, 96, " %11lld %11lld   %.16E\n", static_cast<long long>(ii[i]), static_cast<long long>(ind[i]), val[i]);
+        });
+    else
+        emit_records(f, n, 64, [&](char *p, int64_t i) { return std::snprintf(p, 64, "   %.16E\n", val[i]); });
     const bool ok = std::fflush(f) == 0 && !std::ferror(f);
     std::fclose(f);
     return ok ? PFEM_OK : PFEM_ERR_ARG;
@@ -559,28 +662,112 @@ namespace {
 inline bool is_blank(char c) { return c == ' ' || c == '\t' || c == '\r' || c == ','; }
 }
 
+namespace {
+// The buffer is cut into one piece per thread at record boundaries; both passes below walk the same pieces.
+struct TextPiece {
+    int64_t begin = 0, end = 0, rows = 0;
+    int first_tokens = 0, min_tokens = 1 << 30;
+};
+
+std::vector<TextPiece> text_pieces(const char *buf, int64_t len)
+{
+    int nt = 1;
+#ifdef _OPENMP
+    nt = std::max(1, omp_get_max_threads());
+#endif
+    nt = static_cast<int>(std::min<int64_t>(nt, std::max<int64_t>(1, len >> 16)));
+    std::vector<TextPiece> pc(static_cast<size_t>(nt));
+    for (int t = 0; t < nt; ++t) {
+        int64_t b = len * t / nt;
+        if (t > 0) {                                       // start after the newline that ends the record we fell into
+            while (b < len && buf[b - 1] != '\n') ++b;
+        }
+        pc[t].begin = b;
+        if (t > 0) pc[t - 1].end = b;
+    }
+    pc[nt - 1].end = len;
+    for (int t = 0; t + 1 < nt; ++t) pc[t].end = std::max(pc[t].end, pc[t].begin);
+#pragma omp parallel for schedule(static, 1)
+    for (int t = 0; t < nt; ++t) {
+        TextPiece &q = pc[t];
+        int64_t i = q.begin;
+        while (i < q.end) {
+            int tokens = 0;
+            while (i < q.end && buf[i] != '\n') {
+                while (i < q.end && is_blank(buf[i])) ++i;
+                if (i < q.end && buf[i] != '\n') {
+                    ++tokens;
+                    while (i < q.end && buf[i] != '\n' && !is_blank(buf[i])) ++i;
+                }
+            }
+            if (i < q.end) ++i;   // newline
+            if (tokens > 0) {
+                if (q.rows == 0) q.first_tokens = tokens;
+                q.min_tokens = std::min(q.min_tokens, tokens);
+                ++q.rows;
+            }
+        }
+    }
+    return pc;
+}
+
+// One number.  Plain decimals with at most 15 significant digits and at most 22 fractional digits -- every value the
+// mesh files hold ("%d", "%.8f") -- are converted exactly by one IEEE division (both operands are exact doubles, so the
+// quotient is the correctly rounded value strtod would return); anything else (exponents, Fortran D, long mantissas,
+// inf/nan) goes to strtod.
+inline bool parse_number(const char *&p, const char *end, double *out)
+{
+    static const double p10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                   1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    const char *t0 = p;
+    bool neg = false;
+    if (p < end && (*p == '-' || *p == '+')) { neg = *p == '-'; ++p; }
+    uint64_t mant = 0;
+    int digits = 0, frac = 0;
+    bool simple = true;
+    while (p < end && *p >= '0' && *p <= '9') { mant = mant * 10 + static_cast<uint64_t>(*p - '0'); if (mant || digits) ++digits; ++p; if (digits > 15) { simple = false; break; } }
+    const bool int_part = p > t0 + ((t0 < end && (*t0 == '-' || *t0 == '+')) ? 1 : 0);
+    bool frac_part = false;
+    if (simple && p < end && *p == '.') {
+        ++p;
+        while (p < end && *p >= '0' && *p <= '9') {
+            mant = mant * 10 + static_cast<uint64_t>(*p - '0');
+            if (mant || digits) ++digits;
+            ++frac; ++p; frac_part = true;
+            if (digits > 15 || frac > 22) { simple = false; break; }
+        }
+    }
+    if (simple && (int_part || frac_part) && (p >= end || *p == '\n' || is_blank(*p))) {
+        const double v = static_cast<double>(mant) / p10[frac];
+        *out = neg ? -v : v;
+        return true;
+    }
+    // general token: bounded, NUL-terminated copy for strtod
+    p = t0;
+    char tok[64];
+    int n = 0;
+    while (p < end && *p != '\n' && !is_blank(*p) && n < 63) tok[n++] = *p++;
+    tok[n] = 0;
+    for (int k = 0; k < n; ++k) if (tok[k] == 'D' || tok[k] == 'd') tok[k] = 'e';   // Fortran exponent
+    char *q = nullptr;
+    *out = std::strtod(tok, &q);
+    return q != tok;
+}
+}  // namespace
+
 extern "C" int pfem_text_table_shape(const char *buf, int64_t len, int64_t *rows, int *cols)
 {
     if (!buf || len < 0 || !rows || !cols) return PFEM_ERR_ARG;
+    const std::vector<TextPiece> pc = text_pieces(buf, len);
     int64_t r = 0;
-    int c0 = 0;
-    int64_t i = 0;
-    while (i < len) {
-        int tokens = 0;
-        while (i < len && buf[i] != '\n') {
-            while (i < len && is_blank(buf[i])) ++i;
-            if (i < len && buf[i] != '\n') {
-                ++tokens;
-                while (i < len && buf[i] != '\n' && !is_blank(buf[i])) ++i;
-            }
-        }
-        if (i < len) ++i;   // newline
-        if (tokens > 0) {
-            if (r == 0) c0 = tokens;
-            else if (tokens < c0) return PFEM_ERR_ARG;      // short record
-            ++r;
-        }
+    int c0 = 0, mn = 1 << 30;
+    for (const TextPiece &q : pc) {
+        if (q.rows == 0) continue;
+        if (r == 0) c0 = q.first_tokens;
+        mn = std::min(mn, q.min_tokens);
+        r += q.rows;
     }
+    if (r > 0 && mn < c0) return PFEM_ERR_ARG;              // short record
     *rows = r;
     *cols = c0;
     return PFEM_OK;
@@ -589,36 +776,30 @@ extern "C" int pfem_text_table_shape(const char *buf, int64_t len, int64_t *rows
 extern "C" int pfem_text_table_parse(const char *buf, int64_t len, int64_t rows, int cols, double *out)
 {
     if (!buf || len < 0 || rows < 0 || cols < 1 || !out) return PFEM_ERR_ARG;
-    // line starts of the non-empty records, then parse them in parallel
-    std::vector<int64_t> start;
-    start.reserve(static_cast<size_t>(rows));
-    int64_t i = 0;
-    while (i < len) {
-        int64_t j = i;
-        bool any = false;
-        while (j < len && buf[j] != '\n') { any = any || !is_blank(buf[j]); ++j; }
-        if (any) start.push_back(i);
-        i = j + 1;
-    }
-    if (static_cast<int64_t>(start.size()) != rows) return PFEM_ERR_ARG;
+    std::vector<TextPiece> pc = text_pieces(buf, len);
+    std::vector<int64_t> first(pc.size() + 1, 0);
+    for (size_t t = 0; t < pc.size(); ++t) first[t + 1] = first[t] + pc[t].rows;
+    if (first.back() != rows) return PFEM_ERR_ARG;
     int bad = 0;
-#pragma omp parallel for schedule(static) reduction(| : bad)
-    for (int64_t r = 0; r < rows; ++r) {
-        const char *p = buf + start[r];
-        const char *end = buf + len;
-        for (int c = 0; c < cols; ++c) {
+    const int np = static_cast<int>(pc.size());
+#pragma omp parallel for schedule(static, 1) reduction(| : bad)
+    for (int t = 0; t < np; ++t) {
+        const char *p = buf + pc[t].begin;
+        const char *end = buf + pc[t].end;
+        int64_t r = first[t];
+        while (p < end && !bad) {
             while (p < end && is_blank(*p)) ++p;
-            if (p >= end || *p == '\n') { bad |= 1; break; }
-            // tokens are short: copy to a bounded, NUL-terminated scratch for strtod
-            char tok[64];
-            int n = 0;
-            while (p < end && *p != '\n' && !is_blank(*p) && n < 63) tok[n++] = *p++;
-            tok[n] = 0;
-            for (int k = 0; k < n; ++k) if (tok[k] == 'D' || tok[k] == 'd') tok[k] = 'e';   // Fortran exponent
-            char *q = nullptr;
-            const double v = std::strtod(tok, &q);
-            if (q == tok) { bad |= 1; break; }
-            out[static_cast<int64_t>(c) * rows + r] = v;
+            if (p >= end) break;
+            if (*p == '\n') { ++p; continue; }             // empty line
+            for (int c = 0; c < cols; ++c) {
+                while (p < end && is_blank(*p)) ++p;
+                double v;
+                if (p >= end || *p == '\n' || !parse_number(p, end, &v)) { bad |= 1; break; }
+                out[static_cast<int64_t>(c) * rows + r] = v;
+            }
+            ++r;
+            while (p < end && *p != '\n') ++p;              // extra columns are ignored, as a list-directed READ does
+            if (p < end) ++p;
         }
     }
     return bad ? PFEM_ERR_ARG : PFEM_OK;

@@ -53,13 +53,7 @@ class Result:
         import os
         ndof = self.dm.NodeDofArrayNew.shape[1]
         ii, ind, val = self.temp_dat()
-        with open(os.path.join(directory, "temp.dat"), "w") as f:
-            if ndof == 1:
-                for a, b, c in zip(ii, ind, val):
-                    f.write(f" {a:11d} {b:11d}   {c:.16E}\n")
-            else:
-                for c in val:
-                    f.write(f"   {c:.16E}\n")
+        H.write_temp_dat(os.path.join(directory, "temp.dat"), val, *((ii, ind) if ndof == 1 else (None, None)))
         name = "Poisson-soln.vtk" if ndof == 1 else "Elasticity-soln.vtk"
         pid = np.zeros(self.mesh.nElem, np.int32) if elem_procid is None else elem_procid
         H.writeoutputvtk(self.mesh.xyz.shape[0], self.mesh.xyz, self.mesh.conn, pid, self.solnVTK, os.path.join(directory, name),

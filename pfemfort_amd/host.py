@@ -89,7 +89,11 @@ def read_mesh(prefix: str) -> Mesh:
                 return read_table(path)
         raise FileNotFoundError(f"{prefix}-{kind}.dat[.gz]")
     nodes, elems, bcs = load("nodes"), load("elems"), load("DirichBC")
-    m = Mesh(np.ascontiguousarray(nodes[:, 1:].T), np.ascontiguousarray((elems[:, 1:] - 1).T.astype(np.int32)),
+    # read_table hands back the transpose of a (columns, records) array: slice THAT, so every step below is a
+    # contiguous pass (the other order costs seconds at millions of elements)
+    conn = elems.T[1:].astype(np.int32)
+    conn -= 1
+    m = Mesh(np.ascontiguousarray(nodes.T[1:]), conn,
              (bcs[:, 0] - 1).astype(np.int32), (bcs[:, 1] - 1).astype(np.int32), bcs[:, 2].copy())
     try:                                    # optional 4th file (tetraelasticityparallelimpl1.F:207-214)
         fb = load("ForceBC")
@@ -277,6 +281,15 @@ def neighbour_plan(rank, row_ranges, ghost_lists):
         L.check(L.lib().pfem_neighbour_plan(world, rank, _p(rs), _p(re), _p(off), _p(allg), C.byref(npeers), C.byref(total),
                                             _p(peers), _p(poff), _p(gid)), "pfem_neighbour_plan")
     return peers, poff, gid
+
+
+def write_temp_dat(path, val, ii=None, ind=None):
+    """The drivers' ``temp.dat`` dump (tetrapoissonparallelimpl1.F:935-942; value-only form :1031-1046 of the
+    elasticity driver when ``ii``/``ind`` are None)."""
+    val = _f64(val)
+    if ii is not None:
+        ii = np.ascontiguousarray(ii, dtype=np.int64); ind = np.ascontiguousarray(ind, dtype=np.int64)
+    L.check(L.lib().pfem_write_temp_dat(str(path).encode(), val.size, _p(ii), _p(ind), _p(val)), "pfem_write_temp_dat")
 
 
 def writeoutputvtk(ndim, coords, elemNodeConn, elem_procid, soln, fileName, ndof=None):

@@ -222,3 +222,96 @@ def test_rcb_partition_is_balanced_compact_and_deterministic(tet10, nparts, gold
             for a in range(mesh.conn.shape[0]):
                 t2[rnd, mesh.conn[a]] = True
             assert shared < 0.5 * (t2.sum(axis=0) > 1).sum()
+
+
+def test_ascii_reader_numbers_bit_identical_to_strtod_many_pieces(tmp_path):
+    """The reader's fast decimal path (<= 15 significant digits) and its strtod fall-back against Python's float() --
+    itself correctly rounded -- on a file large enough to be cut into one piece per thread, with blank lines, ragged
+    spacing and records that straddle the cuts."""
+    rng = np.random.default_rng(5)
+    n = 60000
+    toks = []
+    for i in range(n):
+        k = i % 12
+        if k == 0:
+            t = "%d" % rng.integers(-2**31, 2**31)
+        elif k == 1:
+            t = "%.8f" % rng.uniform(-1e3, 1e3)
+        elif k == 2:
+            t = "%.15g" % rng.uniform(-1, 1)
+        elif k == 3:
+            t = "%.17g" % rng.uniform(-1, 1)                 # 17 digits: strtod path
+        elif k == 4:
+            t = "%.6e" % rng.uniform(-1e-30, 1e30)
+        elif k == 5:
+            t = ("%.6E" % rng.uniform(-1e5, 1e5)).replace("E", "D")
+        elif k == 6:
+            t = "." + "%d" % rng.integers(0, 10**9)
+        elif k == 7:
+            t = "%d." % rng.integers(0, 10**9)
+        elif k == 8:
+            t = "+0.000000000000000000000%d" % rng.integers(1, 10**6)    # > 22 fractional digits
+        elif k == 9:
+            t = "-0.0"
+        elif k == 10:
+            t = "123456789012345.6789"                       # 19 digits
+        else:
+            t = "999999999999999"                            # exactly 15 digits
+        toks.append(t)
+    lines = []
+    for r in range(n // 3):
+        sep = ["  ", "\t", ","][r % 3]
+        lines.append(" " * (r % 4) + sep.join(toks[3 * r:3 * r + 3]) + (" \r" if r % 5 == 0 else ""))
+        if r % 97 == 0:
+            lines.append("   ")
+    p = tmp_path / "big.dat"
+    p.write_text("\n".join(lines) + "\n")
+    assert p.stat().st_size > 8 * 65536                      # several pieces
+    got = H.read_table(str(p))
+    want = np.array([float(t.replace("D", "e")) for t in toks]).reshape(-1, 3)
+    assert got.shape == want.shape
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    # no trailing newline, a file of one record, and a token that is not a number
+    p.write_text("1 2 3")
+    assert np.array_equal(H.read_table(str(p)), [[1, 2, 3]])
+    p.write_text("1 2 x3\n")
+    with pytest.raises(pf.PfemError):
+        H.read_table(str(p))
+    p.write_text("1 2 3\n" * 30000 + "1 2\n" + "1 2 3\n" * 30000)      # a short record deep inside another piece
+    with pytest.raises(pf.PfemError):
+        H.read_table(str(p))
+
+
+def test_vtk_writer_numbers_identical_to_printf(tmp_path):
+    """The writer's short F12.6 path (and its snprintf fall-back near ties / for large values) against Python's
+    correctly rounded '%12.6f', over many blocks so that every thread formats some; temp.dat through the same emitter."""
+    rng = np.random.default_rng(11)
+    n = 50000
+    k = rng.integers(-10**7, 10**7, n)
+    vals = np.concatenate([
+        rng.uniform(-3, 3, n), rng.uniform(-9999.5, 9999.5, n), rng.uniform(-1e-6, 1e-6, n),
+        (2 * k + 1) * 0.5e-6,                                # decimal ties (not exact in binary: either side)
+        np.array([0.0, -0.0, 0.5e-6, 1.5e-6, 2.5e-6, -0.5e-6, 0.125, 0.0000005, 9998.9999995, 9998.99999949, -9998.9999995,
+                  99999.9999994, 123456.789, -123456.789, 1e15, 1e22, -1e-300, 5e-324, 0.4999995, 0.9999995, 9.9999995])])
+    nN = len(vals)
+    xyz = np.zeros((3, nN)); xyz[0] = vals; xyz[1] = vals[::-1]; xyz[2] = np.roll(vals, 7)
+    conn = np.zeros((4, 5), np.int32); conn[:, 3] = [nN - 1, 12345, 0, 7]
+    pid = np.array([0, 1, 22, 333, -4], np.int32)
+    out = tmp_path / "a.vtk"
+    H.writeoutputvtk(3, xyz, conn, pid, vals, str(out))
+    lines = out.read_text().split("\n")
+    assert lines[4] == "POINTS %10d float" % nN
+    for i in list(range(0, nN, 37)) + list(range(nN - 25, nN)):
+        assert lines[5 + i] == "%12.6f%12.6f%12.6f" % (xyz[0, i], xyz[1, i], xyz[2, i]), i
+    c0 = 5 + nN
+    assert lines[c0] == "CELLS %10d%10d" % (5, 25) and lines[c0 + 4] == "%10d%10d%10d%10d%10d" % (4, nN - 1, 12345, 0, 7)
+    assert lines[c0 + 6] == "CELL_TYPES%10d" % 5 and lines[c0 + 7] == " 10"
+    assert lines[c0 + 15:c0 + 20] == ["%3d" % v for v in pid]
+    s0 = lines.index("LOOKUP_TABLE default", c0 + 20) + 1
+    assert lines[s0:s0 + nN] == ["%12.6f" % v for v in vals]
+    t = tmp_path / "temp.dat"
+    H.write_temp_dat(str(t), vals, np.arange(1, nN + 1), np.arange(nN)[::-1] + 1)
+    got = t.read_text().split("\n")
+    assert got[:-1] == [" %11d %11d   %.16E" % (i + 1, nN - i, v) for i, v in enumerate(vals)] and got[-1] == ""
+    H.write_temp_dat(str(t), vals[:9000])
+    assert t.read_text() == "".join("   %.16E\n" % v for v in vals[:9000])
