@@ -2009,8 +2009,9 @@ int run_pcg(pfem_solver *s)
     // costs the exchange itself.  Overlapped: the slices with shared rows first, the exchange on the communication stream
     // under the interior slices, two stream hand-overs: costs ~27 us whatever the exchange takes, as long as it is shorter
     // than the interior pass.  Measured on MI355X / ROCm 7.2 with the rank as its own neighbour (tools/probe_overlap.py,
-    // 200^3 per rank, 634 kB per exchange; single-rank loop 0.339 ms per iteration): in order 0.346 ms (exchange 14 us on
-    // the local device), overlapped 0.366 ms (exchange 83 us, hidden).  Over xGMI a 1.27 MB face costs several times
+    // 200^3 per rank, 634 kB per exchange; single-rank loop 0.334 ms per iteration): in order 0.350 ms (exchange 14 us on
+    // the local device), overlapped 0.368 ms (exchange hidden; communication stream of DEFAULT priority -- a high-priority
+    // one made it 0.68 ms).  Over xGMI a 1.27 MB face costs several times
     // the local copy, so exchanges of kOverlapMinBytes and more take the overlapped form; PFEM_MULTI_OVERLAP=0/1 overrides.
     const bool overlap = [&] {
         const char *e = std::getenv("PFEM_MULTI_OVERLAP");
@@ -2311,10 +2312,11 @@ int run_pcg(pfem_solver *s)
     };
 
     // ---- multi-rank graph: kMultiGraphIters iterations across both streams, the RCCL launches included ----------------
-    // The host needs ~0.3-0.4 ms to enqueue one multi-rank iteration (ten kernels, two stream hand-overs, three RCCL calls);
-    // the GPU needs about as long to run it, so the loop is host-bound unless it is replayed from a graph
-    // (tools/probe_overlap.py).  Only with a backend whose calls may be captured (RCCL); falls back to stream launches if
-    // the capture is refused.
+    // The host needs 0.028 ms (in order) to 0.039 ms (overlapped) to enqueue one multi-rank iteration -- ten kernels, two
+    // stream hand-overs, three RCCL calls, 0.006 ms of it inside RCCL (profiles/r02/overlap_probe_200_*.json) -- against
+    // 0.35 ms of GPU time at 200^3 rows per rank: the loop turns host-bound only below ~50^3 rows per rank, and that is
+    // where a replayed graph would pay.  Only with a backend whose calls may be captured (RCCL); falls back to stream
+    // launches if the capture is refused.
     constexpr int kMultiGraphIters = 4;
     bool use_mgraph = false;
     {
