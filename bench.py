@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-step", action="store_true", help="skip the extra (untimed) step at rtol 1e-10")
     ap.add_argument("--pc", choices=["jacobi", "pbjacobi"], default="jacobi")
+    ap.add_argument("--single-reduction", action="store_true",
+                    help="KSPCGUseSingleReduction: one all-reduce per CG iteration instead of two (PETSc's opt-in form; off by default)")
     ap.add_argument("--backend", default="nccl", help="nccl: RCCL bound inside the library; gloo: host hooks (development)")
     ap.add_argument("--simulate-rccl-failure", action="store_true", help="development: exercise the fallback to gloo host hooks")
     ap.add_argument("--same-device", action="store_true",
@@ -190,6 +192,8 @@ def main():
     solver = pf.PetscSolver().initialise(size_local, N, row_start=row_start, device=device_index)
     solver.setTolerances(rtol=args.rtol, maxits=100000 if beam else 10000)
     solver.setPreconditioner(args.pc)
+    if args.single_reduction:
+        solver.setSingleReduction(True)
     solver.generateBoxMesh(kind, *box, bc_mode=bc_mode, nparts=world, part=rank)
     t_generate = time.perf_counter() - t_setup
     hooks = None
@@ -336,14 +340,14 @@ def main():
                                     f"tetrapoissonparallelimpl1: [-1,1]^2x[{ext[4]:g},{ext[5]:g}] box, "
                                     f"{nEx}x{nEy}x{nEz}x6 P1 tets, u=x^2+y^2+z^2 Dirichlet on all faces, f=-6"),
                        "elements": 6 * nEx * nEy * nEz, "nodes": (nEx + 1) * (nEy + 1) * (nEz + 1), "free_dofs": int(N),
-                       "solver": f"CG + {'node-block Jacobi (pbjacobi)' if args.pc == 'pbjacobi' else 'point Jacobi'}, zero initial guess, "
+                       "solver": f"CG{' (single-reduction form)' if args.single_reduction else ''} + {'node-block Jacobi (pbjacobi)' if args.pc == 'pbjacobi' else 'point Jacobi'}, zero initial guess, "
                                  f"rtol {args.rtol:g} on ||M^-1 r|| (PETSc KSPCG default norm). The reference's PETSc run "
                                  "used KSPCG + PCBJACOBI (per-rank ILU(0), solverpetsc.F:187,206), which is NOT reproduced: "
                                  "iteration counts are not comparable with a PETSc run of the reference",
                        "parallelism": "1 GPU" if world == 1 else
                                       f"{world} z-slabs, sub-assembled interface rows, neighbour exchange of "
                                       f"{cinfo['doubles_per_exchange']} doubles with {cinfo['n_peers']} neighbour(s) per SpMV "
-                                      "+ 2 scalar all-reduces, in order on the compute stream; transport: " + transport},
+                                      f"+ {1 if args.single_reduction and args.pc == 'jacobi' else 2} scalar all-reduce(s) per iteration; transport: " + transport},
             "iterations": its, "converged_reason": reason, "rnorm": rnorm, check_name: check,
             "assembly_ms_per_step": asm_ms / args.steps, "solve_ms_per_step": sol_ms / args.steps,
             "ms_per_iteration": sol_ms / args.steps / max(its, 1),     # weak scaling: iterations grow with the problem

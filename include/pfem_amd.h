@@ -294,6 +294,14 @@ int pfem_solver_spmv_bytes(pfem_solver *s, int64_t *format_bytes);
 #define PFEM_PC_NODE_BLOCK_JACOBI 1
 int pfem_solver_set_preconditioner(pfem_solver *s, int pc);
 int pfem_solver_get_preconditioner(pfem_solver *s, int *pc_in_effect);
+/* KSPCGUseSingleReduction / -ksp_cg_single_reduction (PETSc option of the KSPCG the reference creates, solverpetsc.F:187;
+ * off by default there and here): the Chronopoulos-Gear form of the same iteration -- s = A z instead of w = A p,
+ * (p,Ap) by recurrence -- so that (z,r), (z,s), (z,z) are reduced together: ONE all-reduce per iteration on several
+ * ranks instead of two, at the price of two more vectors of traffic per iteration and one more SpMV per solve.  Point
+ * Jacobi only (node-block Jacobi keeps the two-reduction loop).  on = 1 / 0, or -1: the environment variable
+ * PFEM_CG_SINGLE_REDUCTION decides (default off).  Same stopping rule and reasons; iterates agree with the default
+ * loop to rounding.                                                                                                    */
+int pfem_solver_set_cg_single_reduction(pfem_solver *s, int on);
 /* Specified nodal forces after the element loop (VecSetValue(rhsVec,row,fact,ADD_VALUES),
  * tetraelasticityparallelimpl1.F:971-982) for the batched path: GLOBAL free-dof ids (i.e.
  * NodeDofArrayNew(n,d)-1; the reference's own row formula ignores constrained dofs);

@@ -767,6 +767,74 @@ int orc_pcg_jacobi(int64_t N, const int64_t *rowptr, const int32_t *cols,
 }
 
 /* ------------------------------------------------------------------------ */
+/* The same Jacobi-PCG in PETSc's single-reduction form (KSPCGUseSingleReduction, */
+/* -ksp_cg_single_reduction; an option of the KSPCG that solverpetsc.F:187     */
+/* creates, off by default).  Third-party semantics restated from the published */
+/* algorithm (Chronopoulos & Gear 1989; PETSc is absent): S = A Z is formed     */
+/* after every preconditioner application, (Z,S), (Z,R) and (Z,Z) are taken at */
+/* one point, and                                                               */
+/*     b = beta/beta_old,  dpi = delta - beta^2 dpi_old / beta_old^2,            */
+/*     P = Z + b P,  W = S + b W,  a = beta/dpi,  X += a P,  R -= a W.           */
+/* Same stopping rule, iteration numbering and reasons as orc_pcg_jacobi.        */
+int orc_pcg_jacobi_single_reduction(int64_t N, const int64_t *rowptr, const int32_t *cols, const double *vals, const double *b,
+                                    double *x, double rtol, double abstol, double dtol, int maxits, int *its_out,
+                                    int *reason_out, double *rnorm_out, double *history, int hist_len)
+{
+    double *r, *z, *p, *w, *sv, *dinv, beta, beta_old = 0.0, delta, dpi = 0.0, rn0, rn, ttol;
+    int64_t i;
+    int its = 0, reason = 0;
+    r = (double *)malloc(sizeof(double) * 6 * (size_t)(N ? N : 1));
+    if (!r) return ORC_ERR_NOMEM;
+    z = r + N;  p = z + N;  w = p + N;  sv = w + N;  dinv = sv + N;
+    for (i = 0; i < N; ++i) {
+        double d = 0.0;
+        const int64_t k = csr_find(rowptr, cols, i, (int32_t)i);
+        if (k >= 0) d = vals[k];
+        dinv[i] = 1.0 / d;
+    }
+#pragma omp parallel for schedule(static) if (N > 200000)
+    for (i = 0; i < N; ++i) { x[i] = 0.0;  r[i] = b[i];  z[i] = r[i] * dinv[i]; }
+    orc_spmv(N, rowptr, cols, vals, z, sv);
+    delta = dotp(N, z, sv);
+    beta = dotp(N, r, z);
+    rn0 = sqrt(dotp(N, z, z));
+    rn = rn0;
+    if (history && hist_len > 0) history[0] = rn0;
+    ttol = fmax(rtol * rn0, abstol);
+    if (rn0 <= abstol) reason = 3;
+    else if (beta < 0.0) reason = -8;
+    while (!reason) {
+        double bb, a;
+        if (its >= maxits) { reason = -3; break; }
+        if (its == 0) { bb = 0.0;  dpi = delta; }
+        else { bb = beta / beta_old;  dpi = delta - beta * beta * dpi / (beta_old * beta_old); }
+        ++its;
+        if (!(dpi > 0.0)) { reason = -10; break; }
+        a = beta / dpi;
+#pragma omp parallel for schedule(static) if (N > 200000)
+        for (i = 0; i < N; ++i) {
+            p[i] = its == 1 ? z[i] : z[i] + bb * p[i];
+            w[i] = its == 1 ? sv[i] : sv[i] + bb * w[i];
+            x[i] += a * p[i];
+            r[i] -= a * w[i];
+            z[i] = r[i] * dinv[i];
+        }
+        orc_spmv(N, rowptr, cols, vals, z, sv);
+        beta_old = beta;
+        delta = dotp(N, z, sv);
+        beta = dotp(N, r, z);
+        rn = sqrt(dotp(N, z, z));
+        if (history && its < hist_len) history[its] = rn;
+        if (rn <= ttol) { reason = rn <= abstol ? 3 : 2; break; }
+        if (rn >= dtol * rn0) { reason = -4; break; }
+        if (beta < 0.0) { reason = -8; break; }
+    }
+    *its_out = its;  *reason_out = reason;  *rnorm_out = rn;
+    free(r);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
 /* CG with the preconditioner the reference actually sets: PCBJACOBI, whose    */
 /* default sub-solver is ILU(0) (solverpetsc.F:187, 206) -- one block per MPI */
 /* rank, natural ordering.  block_start[0..nblocks] = row blocks (ascending);  */

@@ -300,6 +300,19 @@ def pcg_jacobi(rowptr, cols, vals, b, rtol=1e-5, abstol=1e-50, dtol=1e5, maxits=
     return x, its.value, reason.value, rn.value, hist[:min(hist_len, its.value + 1)]
 
 
+def pcg_jacobi_single_reduction(rowptr, cols, vals, b, rtol=1e-5, abstol=1e-50, dtol=1e5, maxits=10000, hist_len=0):
+    """Jacobi-PCG in PETSc's single-reduction form (KSPCGUseSingleReduction)."""
+    N = len(rowptr) - 1
+    x = np.empty(N)
+    its = C.c_int(0); reason = C.c_int(0); rn = C.c_double(0)
+    hist = np.zeros(max(hist_len, 1))
+    rc = lib().orc_pcg_jacobi_single_reduction(C.c_int64(N), _p(rowptr), _p(cols), _p(vals), _p(_f64(b)), _p(x),
+                                               C.c_double(rtol), C.c_double(abstol), C.c_double(dtol), C.c_int(maxits),
+                                               C.byref(its), C.byref(reason), C.byref(rn), _p(hist), C.c_int(hist_len))
+    assert rc == 0
+    return x, its.value, reason.value, rn.value, hist[:min(hist_len, its.value + 1)]
+
+
 def pcg_bjacobi_ilu0(rowptr, cols, vals, b, block_start=None, rtol=1e-5, abstol=1e-50, dtol=1e5, maxits=10000):
     """CG with PETSc's PCBJACOBI default (ILU(0) on each rank's diagonal block, natural ordering): what the
     reference's solverpetsc.F:187,206 sets.  ``block_start`` = row-block boundaries (default: one block)."""

@@ -104,6 +104,7 @@ SIGNATURES = {
     "pfem_solver_spmv_bytes": [_P, _P],
     "pfem_solver_set_preconditioner": [_P, _I],
     "pfem_solver_get_preconditioner": [_P, _P],
+    "pfem_solver_set_cg_single_reduction": [_P, _I],
     "pfem_eval_elems": [_P, _P, _P, _P, _P],
     "pfem_rhs_add_values": [_P, _L, _P, _P],
     "pfem_matrix_info": [_P, _P, _P, _P, _P],

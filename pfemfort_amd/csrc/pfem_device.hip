@@ -276,6 +276,11 @@ struct pfem_solver {
     int pc = PFEM_PC_JACOBI;
     DevBuf<double> d_binv[3];      // node-block Jacobi: row (i - r0) of the inverse diagonal block, columns 0..2
     DevBuf<double> d_r2, d_z;      // ... second residual buffer (ping-pong), z = Binv r, per-row (first row | size << 30)
+    // single-reduction CG (pfem_solver_set_cg_single_reduction): z is the SpMV input (guarded), s = A z, and a second
+    // set of (r,z)/(z,z) partials because a step reads one set while it writes the next
+    GuardedVec d_zg;
+    DevBuf<double> d_sv, d_part1;
+    int single_reduction = -1;     // -1: PFEM_CG_SINGLE_REDUCTION decides (default off), 0 / 1: set by the caller
     DevBuf<uint32_t> d_row_grp;
     bool block_pc_ok = true;       // multi-rank: the ranks agreed that their row groups coincide on shared dofs
     // (a rank without rows -- an idle rank of a multi-rank run -- has no groups to disagree about)
@@ -1471,6 +1476,13 @@ extern "C" int pfem_solver_set_preconditioner(pfem_solver *s, int pc)
     return PFEM_OK;
 }
 
+extern "C" int pfem_solver_set_cg_single_reduction(pfem_solver *s, int on)
+{
+    if (!s) return PFEM_ERR_ARG;
+    s->single_reduction = on < 0 ? -1 : (on != 0);
+    return PFEM_OK;
+}
+
 extern "C" int pfem_solver_get_preconditioner(pfem_solver *s, int *pc_in_effect)
 {
     if (!s || !pc_in_effect) return PFEM_ERR_ARG;
@@ -1995,11 +2007,93 @@ int build_slice_lists(pfem_solver *s)
     return PFEM_OK;
 }
 
+// One multi-rank SpMV: yout = A_loc xin with the partials of (xin, A_loc xin) per block, the neighbour exchange of
+// yout[shared], one all-reduce of the scalars `reduce(nblocks)` has put at the head of sbuf (it returns how many), and
+// yout[shared] summed in rank order.  In order on the compute stream, or overlapped: (1) the slices that hold shared rows,
+// then pack; (2) the exchange on the communication stream while (3) the interior slices run; (4) the scalars, in order on
+// the compute stream; (5) the compute stream waits for the exchange and adds the neighbours' partials.
+template <class Reduce>
+int spmv_exchange(pfem_solver *s, const double *xin, double *yout, double *part_pw, unsigned gs, bool overlap, const CgCtl *ctl,
+                  hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t *cev, double *host_comm_s, Reduce &&reduce)
+{
+    const dim3 block(kBlock);
+    const int64_t n = s->n_loc;
+    double *sbuf = s->d_sbuf.p;
+    auto timed = [&](auto &&call) -> int {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = call();
+        *host_comm_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return rc;
+    };
+    auto exchange_on = [&](hipStream_t st) -> int {
+        return timed([&] { return s->comm->exchange(static_cast<int>(s->peers.size()), s->peers.data(), s->peer_off.data(), s->d_send.p,
+                                                    s->d_recv.p, st); });
+    };
+    auto pack = [&] {
+        if (s->n_send > 0)
+            hipLaunchKernelGGL(k_pack_send, dim3(grid_for(s->n_send)), block, 0, s->stream, static_cast<const double *>(yout),
+                               static_cast<const int32_t *>(s->d_send_lidx.p), s->n_send, s->d_send.p, ctl);
+    };
+    if (!overlap) {
+        launch_spmv<true>(s, xin, yout, n, part_pw, ctl, e0, e1);
+        pack();
+        if (cev) PFEM_HIP(hipEventRecord(cev[0], s->stream));
+        PFEM_TRY(exchange_on(s->stream));
+        if (cev) PFEM_HIP(hipEventRecord(cev[1], s->stream));
+        const int cnt = reduce(static_cast<int>(gs));
+        if (cev) PFEM_HIP(hipEventRecord(cev[2], s->stream));
+        PFEM_TRY(timed([&] { return s->comm->allreduce(sbuf, cnt, s->stream); }));
+        if (cev) { PFEM_HIP(hipEventRecord(cev[3], s->stream)); PFEM_HIP(hipEventRecord(cev[6], s->stream)); PFEM_HIP(hipEventRecord(cev[7], s->stream)); }
+    } else {
+        const unsigned nb_blocks = s->n_slices_b > 0 ? spmv_grid(s->n_slices_b) : 0;
+        const unsigned ni_blocks = s->n_slices_i > 0 ? spmv_grid(s->n_slices_i) : 0;
+        if (s->n_slices_b > 0) launch_spmv<true>(s, xin, yout, n, part_pw, ctl, e0, e1, SliceSel{s->d_slices_b.p, s->n_slices_b});
+        pack();
+        PFEM_TRY(stream_follows(s, s->comm_stream, s->stream));
+        if (cev) PFEM_HIP(hipEventRecord(cev[0], s->comm_stream));
+        PFEM_TRY(exchange_on(s->comm_stream));
+        if (cev) PFEM_HIP(hipEventRecord(cev[1], s->comm_stream));
+        if (s->n_slices_i > 0)
+            launch_spmv<true>(s, xin, yout, n, part_pw + nb_blocks, ctl, e2, e3, SliceSel{s->d_slices_i.p, s->n_slices_i});
+        const int cnt = reduce(static_cast<int>(nb_blocks + ni_blocks));
+        if (cev) PFEM_HIP(hipEventRecord(cev[2], s->stream));
+        PFEM_TRY(timed([&] { return s->comm->allreduce(sbuf, cnt, s->stream); }));
+        if (cev) PFEM_HIP(hipEventRecord(cev[3], s->stream));
+        if (cev) PFEM_HIP(hipEventRecord(cev[6], s->stream));
+        PFEM_TRY(stream_follows(s, s->stream, s->comm_stream));
+        if (cev) PFEM_HIP(hipEventRecord(cev[7], s->stream));
+    }
+    if (s->n_sh > 0)
+        hipLaunchKernelGGL(k_unpack_sum, dim3(grid_for(s->n_sh)), block, 0, s->stream, yout,
+                           static_cast<const int32_t *>(s->d_sh_lidx.p), static_cast<const int32_t *>(s->d_sh_ptr.p),
+                           static_cast<const int32_t *>(s->d_sh_src.p), s->n_sh, static_cast<const double *>(s->d_recv.p), ctl);
+    return PFEM_OK;
+}
+
 // ---------------------------------------------------------------------------
 // Jacobi-preconditioned CG on the device (KSPSolve, solverpetsc.F:476)
 // ---------------------------------------------------------------------------
+int run_pcg_single(pfem_solver *s);
+
+inline bool want_single_reduction(const pfem_solver *s)
+{
+    if (s->single_reduction >= 0) return s->single_reduction != 0;
+    const char *e = std::getenv("PFEM_CG_SINGLE_REDUCTION");
+    return e && std::atoi(e) != 0;
+}
+
+// in order / overlapped form of the multi-rank SpMV (see run_pcg)
+inline bool want_overlap(const pfem_solver *s)
+{
+    const char *e = std::getenv("PFEM_MULTI_OVERLAP");
+    if (e) return std::atoi(e) != 0;
+    return s->nranks > 1 && s->n_send * 8 >= pfem_solver::kOverlapMinBytes;
+}
+
 int run_pcg(pfem_solver *s)
 {
+    // the single-reduction form exists for point Jacobi only; node-block Jacobi keeps the two-reduction loop
+    if (want_single_reduction(s) && s->pc != PFEM_PC_NODE_BLOCK_JACOBI) return run_pcg_single(s);
     const int64_t n = s->n_loc;
     // test knob PFEM_FORCE_MULTI: a single rank with a backend and an (empty) plan takes the multi-rank loop too
     const bool multi = s->nranks > 1 || (s->comm && s->have_plan && std::getenv("PFEM_FORCE_MULTI"));
@@ -2013,11 +2107,7 @@ int run_pcg(pfem_solver *s)
     // the local device), overlapped 0.368 ms (exchange hidden; communication stream of DEFAULT priority -- a high-priority
     // one made it 0.68 ms).  Over xGMI a 1.27 MB face costs several times
     // the local copy, so exchanges of kOverlapMinBytes and more take the overlapped form; PFEM_MULTI_OVERLAP=0/1 overrides.
-    const bool overlap = [&] {
-        const char *e = std::getenv("PFEM_MULTI_OVERLAP");
-        if (e) return std::atoi(e) != 0;
-        return s->nranks > 1 && s->n_send * 8 >= pfem_solver::kOverlapMinBytes;
-    }();
+    const bool overlap = want_overlap(s);
     const unsigned gv = vec_grid(n), gs = spmv_blocks(s);
     const dim3 block(kBlock);
     SellDev A = s->sell();
@@ -2248,54 +2338,11 @@ int run_pcg(pfem_solver *s)
     };
     // w = A_loc p, neighbour exchange, (p,Ap) all-reduced into sbuf[0], w[shared] summed in rank order
     auto multi_spmv_exchange = [&](hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t *cev) -> int {
-        unsigned nb_blocks = s->n_slices_b > 0 ? spmv_grid(s->n_slices_b) : 0;
-        unsigned ni_blocks = s->n_slices_i > 0 ? spmv_grid(s->n_slices_i) : 0;
-        if (!overlap) {
-            // everything in order on the compute stream: whole SpMV, pack, exchange, (p,Ap) all-reduce
-            launch_spmv<true>(s, s->d_p.p, s->d_w.p, n, part_pw, ctl, e0, e1);
-            nb_blocks = gs;
-            ni_blocks = 0;
-            if (s->n_send > 0)
-                hipLaunchKernelGGL(k_pack_send, dim3(grid_for(s->n_send)), block, 0, s->stream, static_cast<const double *>(s->d_w.p),
-                                   static_cast<const int32_t *>(s->d_send_lidx.p), s->n_send, s->d_send.p, static_cast<const CgCtl *>(ctl));
-            if (cev) PFEM_HIP(hipEventRecord(cev[0], s->stream));
-            PFEM_TRY(timed([&] { return s->comm->exchange(static_cast<int>(s->peers.size()), s->peers.data(), s->peer_off.data(), s->d_send.p,
-                                                          s->d_recv.p, s->stream); }));
-            if (cev) PFEM_HIP(hipEventRecord(cev[1], s->stream));
+        return spmv_exchange(s, s->d_p.p, s->d_w.p, part_pw, gs, overlap, ctl, e0, e1, e2, e3, cev, &host_comm_s, [&](int nblocks) -> int {
             hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s->stream, static_cast<const double *>(part_pw),
-                               static_cast<const double *>(nullptr), static_cast<int>(nb_blocks), sbuf, static_cast<const CgCtl *>(ctl));
-            if (cev) PFEM_HIP(hipEventRecord(cev[2], s->stream));
-            PFEM_TRY(timed([&] { return s->comm->allreduce(sbuf, 1, s->stream); }));
-            if (cev) { PFEM_HIP(hipEventRecord(cev[3], s->stream)); PFEM_HIP(hipEventRecord(cev[6], s->stream)); PFEM_HIP(hipEventRecord(cev[7], s->stream)); }
-        } else {
-        if (s->n_slices_b > 0)
-            launch_spmv<true>(s, s->d_p.p, s->d_w.p, n, part_pw, ctl, e0, e1, SliceSel{s->d_slices_b.p, s->n_slices_b});
-        if (s->n_send > 0)
-            hipLaunchKernelGGL(k_pack_send, dim3(grid_for(s->n_send)), block, 0, s->stream, static_cast<const double *>(s->d_w.p),
-                               static_cast<const int32_t *>(s->d_send_lidx.p), s->n_send, s->d_send.p, static_cast<const CgCtl *>(ctl));
-        PFEM_TRY(stream_follows(s, s->comm_stream, s->stream));
-        if (cev) PFEM_HIP(hipEventRecord(cev[0], s->comm_stream));
-        PFEM_TRY(timed([&] { return s->comm->exchange(static_cast<int>(s->peers.size()), s->peers.data(), s->peer_off.data(), s->d_send.p,
-                                                      s->d_recv.p, s->comm_stream); }));
-        if (cev) PFEM_HIP(hipEventRecord(cev[1], s->comm_stream));
-        if (s->n_slices_i > 0)
-            launch_spmv<true>(s, s->d_p.p, s->d_w.p, n, part_pw + nb_blocks, ctl, e2, e3, SliceSel{s->d_slices_i.p, s->n_slices_i});
-        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s->stream, static_cast<const double *>(part_pw),
-                           static_cast<const double *>(nullptr), static_cast<int>(nb_blocks + ni_blocks), sbuf,
-                           static_cast<const CgCtl *>(ctl));
-        if (cev) PFEM_HIP(hipEventRecord(cev[2], s->stream));
-        PFEM_TRY(timed([&] { return s->comm->allreduce(sbuf, 1, s->stream); }));
-        if (cev) PFEM_HIP(hipEventRecord(cev[3], s->stream));
-        if (cev) PFEM_HIP(hipEventRecord(cev[6], s->stream));
-        PFEM_TRY(stream_follows(s, s->stream, s->comm_stream));
-        if (cev) PFEM_HIP(hipEventRecord(cev[7], s->stream));
-        }
-        if (s->n_sh > 0)
-            hipLaunchKernelGGL(k_unpack_sum, dim3(grid_for(s->n_sh)), block, 0, s->stream, s->d_w.p,
-                               static_cast<const int32_t *>(s->d_sh_lidx.p), static_cast<const int32_t *>(s->d_sh_ptr.p),
-                               static_cast<const int32_t *>(s->d_sh_src.p), s->n_sh, static_cast<const double *>(s->d_recv.p),
-                               static_cast<const CgCtl *>(ctl));
-        return PFEM_OK;
+                               static_cast<const double *>(nullptr), nblocks, sbuf, static_cast<const CgCtl *>(ctl));
+            return 1;                       // doubles to all-reduce, from sbuf[0]
+        });
     };
     auto multi_iteration = [&](int it_arg, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t *cev) -> int {
         PFEM_TRY(multi_spmv_exchange(e0, e1, e2, e3, cev));
@@ -2501,6 +2548,175 @@ int run_pcg(pfem_solver *s)
         s->tm.iface_ms_total += x;
         s->tm.scalar_ms_total += a1 + a2;
         s->tm.exposed_ms_total += w + a2;          // the second all-reduce sits between two dependent kernels: fully exposed
+        ++s->tm.comm_samples;
+    }
+    return PFEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// The same solve in its single-reduction form (k_cg1_step): per iteration one SpMV s = A z, ONE all-reduce of three
+// scalars on several ranks, one fused vector kernel.  Opt-in (pfem_solver_set_cg_single_reduction, -ksp_cg_single_reduction,
+// PFEM_CG_SINGLE_REDUCTION=1): it moves 12 instead of 10 vectors per iteration besides the matrix and needs one SpMV more
+// than the two-reduction loop to see the last norm, so it pays where the all-reduce latency does -- many ranks, few
+// rows per rank.  Same stopping rule, same reasons; iterates differ from the two-reduction loop in the last bits.
+// ---------------------------------------------------------------------------
+int run_pcg_single(pfem_solver *s)
+{
+    const int64_t n = s->n_loc;
+    const bool multi = s->nranks > 1 || (s->comm && s->have_plan && std::getenv("PFEM_FORCE_MULTI"));
+    s->group_vals_stale = true;
+    PFEM_TRY(refresh_group_vals(s));
+    const bool overlap = want_overlap(s);
+    const unsigned gv = vec_grid(n), gs = spmv_blocks(s);
+    const dim3 block(kBlock);
+    SellDev A = s->sell();
+    if (s->d_part_pw.n < gs + 2) PFEM_TRY(s->d_part_pw.alloc(gs + 2));
+    if (s->d_part1.n < 4 * static_cast<size_t>(kMaxGrid)) PFEM_TRY(s->d_part1.alloc(4 * static_cast<size_t>(kMaxGrid)));
+    if (s->d_zg.store.n < static_cast<size_t>(n) + 2 * kVecGuard) {
+        PFEM_TRY(s->d_zg.store.alloc(static_cast<size_t>(n) + 2 * kVecGuard));
+        PFEM_HIP(hipMemsetAsync(s->d_zg.store.p, 0, (static_cast<size_t>(n) + 2 * kVecGuard) * sizeof(double), s->stream));
+        s->d_zg.p = s->d_zg.store.p + kVecGuard;
+    }
+    if (s->d_sv.n < static_cast<size_t>(std::max<int64_t>(n, 1))) PFEM_TRY(s->d_sv.alloc(static_cast<size_t>(std::max<int64_t>(n, 1))));
+    double *part_pw = s->d_part_pw.p, *scal_pw = s->d_part.p + 2 * kMaxGrid, *sbuf = s->d_sbuf.p;
+    double *prz[2] = {s->d_part1.p, s->d_part1.p + 2 * kMaxGrid}, *pzz[2] = {s->d_part1.p + kMaxGrid, s->d_part1.p + 3 * kMaxGrid};
+    double *z = s->d_zg.p, *sv = s->d_sv.p;
+    CgCtl *ctl = s->d_ctl.p;
+    if (multi) {
+        if (!s->comm || !s->have_plan) {
+            set_last_error("a solver of a multi-rank run needs a communication backend (pfem_solver_set_comm_rccl / _host) "
+                           "and the neighbour plan (pfem_solver_set_neighbours) before the solve");
+            return PFEM_ERR_STATE;
+        }
+        PFEM_TRY(ensure_comm_stream(s));
+        PFEM_TRY(build_slice_lists(s));
+    }
+    if (s->hist_cap < s->maxits + 2) {
+        PFEM_TRY(s->d_hist.alloc(static_cast<size_t>(s->maxits) + 2));
+        s->hist_cap = s->maxits + 2;
+    }
+    PFEM_HIP(hipMemsetAsync(ctl, 0, sizeof(CgCtl), s->stream));
+    // Jacobi: dinv = 1 / diag(A); interface diagonals and rhs are summed over the ranks
+    if (n > 0) {
+        hipLaunchKernelGGL(k_extract_diag, dim3(grid_for(n)), block, 0, s->stream, A, s->d_dinv.p);
+        PFEM_TRY(check_kernel("k_extract_diag"));
+    }
+    if (multi) {
+        PFEM_TRY(exchange_sum(s, s->d_dinv.p, overlap));
+        if (!s->rhs_summed) {
+            PFEM_TRY(exchange_sum(s, s->d_rhs.p, overlap));
+            s->rhs_summed = true;
+        }
+    }
+    if (n > 0) {
+        hipLaunchKernelGGL(k_invert, dim3(grid_for(n)), block, 0, s->stream, s->d_dinv.p, n);
+        PFEM_TRY(check_kernel("k_invert"));
+    }
+    // x = 0, r = b, z = M^-1 b, first set of (r,z)/(z,z) partials
+    hipLaunchKernelGGL(k_cg_init, dim3(gv), block, 0, s->stream, n, s->n_owned, s->d_rhs.p, s->d_dinv.p, s->d_x.p, s->d_r.p, z, prz[0], pzz[0]);
+    PFEM_TRY(check_kernel("k_cg_init"));
+
+    const int chunk = [] { const char *e = std::getenv("PFEM_CG_CHUNK"); const int c = e ? std::atoi(e) : 0; return c > 0 ? c : 32; }();
+    size_t ev_used = 0, comm_used = 0;
+    double host_comm_s = 0.0;
+    s->tm.graph_iterations = 0;
+    s->tm.host_enqueue_ms = s->tm.host_comm_ms = 0.0;
+    s->tm.host_enqueued_iterations = 0;
+    const size_t ev_per = multi ? 4 : 2;
+    int it = 0;                                 // steps enqueued; step `it` judges iterate `it` and produces iterate it+1
+    CgCtl h{};
+    for (;;) {
+        PFEM_HIP(hipMemcpyAsync(s->h_ctl, ctl, sizeof(CgCtl), hipMemcpyDeviceToHost, s->stream));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+        h = *s->h_ctl;
+        if (h.flag != 0) break;
+        const int it_end = std::min(it + chunk, std::max(s->maxits, 0) + 1);      // step maxits only judges
+        if (it >= it_end) { h.flag = -3; break; }                     // not reached: step maxits sets the flag
+        const auto t_chunk = std::chrono::steady_clock::now();
+        const int it_chunk0 = it;
+        for (; it < it_end; ++it) {
+            hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, *cev = nullptr;
+            const bool sample = s->profile_spmv && it % s->profile_every == 0 && ev_used + ev_per <= 8192;
+            if (sample) {
+                while (s->spmv_events.size() < ev_used + ev_per) {
+                    hipEvent_t a;
+                    PFEM_HIP(hipEventCreate(&a));
+                    s->spmv_events.push_back(a);
+                }
+                e0 = s->spmv_events[ev_used];
+                e1 = s->spmv_events[ev_used + 1];
+                if (multi) { e2 = s->spmv_events[ev_used + 2]; e3 = s->spmv_events[ev_used + 3]; }
+                ev_used += ev_per;
+                if (multi && comm_used + 8 <= 8192) {
+                    while (s->comm_events.size() < comm_used + 8) {
+                        hipEvent_t e;
+                        PFEM_HIP(hipEventCreate(&e));
+                        s->comm_events.push_back(e);
+                    }
+                    cev = &s->comm_events[comm_used];
+                    comm_used += 8;
+                }
+            }
+            const double *in_rz = prz[it & 1], *in_zz = pzz[it & 1];
+            double *out_rz = prz[(it + 1) & 1], *out_zz = pzz[(it + 1) & 1];
+            const double *reduced = nullptr, *pw_parts = part_pw;
+            int pw_n = static_cast<int>(gs);
+            if (multi) {
+                PFEM_TRY(spmv_exchange(s, z, sv, part_pw, gs, overlap, ctl, e0, e1, e2, e3, cev, &host_comm_s, [&](int nblocks) -> int {
+                    hipLaunchKernelGGL(k_reduce_partials3, dim3(1), dim3(1024), 0, s->stream, static_cast<const double *>(part_pw), nblocks,
+                                       in_rz, in_zz, static_cast<int>(gv), sbuf, static_cast<const CgCtl *>(ctl));
+                    return 3;
+                }));
+                if (cev) { PFEM_HIP(hipEventRecord(cev[4], s->stream)); PFEM_HIP(hipEventRecord(cev[5], s->stream)); }   // no second all-reduce
+                reduced = sbuf;
+            } else {
+                launch_spmv<true>(s, z, sv, n, part_pw, ctl, e0, e1);
+                if (gs > kMaxGrid) {
+                    hipLaunchKernelGGL(k_fold_partials, dim3(kFoldBlocks), block, 0, s->stream, static_cast<const double *>(part_pw),
+                                       static_cast<int>(gs), scal_pw, static_cast<const CgCtl *>(ctl));
+                    pw_parts = scal_pw;
+                    pw_n = kFoldBlocks;
+                }
+            }
+            hipLaunchKernelGGL(k_cg1_step, dim3(gv), block, 0, s->stream, ctl, it, n, s->n_owned, pw_parts, pw_n, in_rz, in_zz,
+                               static_cast<int>(gv), reduced, static_cast<const double *>(s->d_dinv.p), z, static_cast<const double *>(sv),
+                               s->d_p.p, s->d_w.p, s->d_x.p, s->d_r.p, out_rz, out_zz, s->rtol, s->abstol, s->dtol, s->d_hist.p,
+                               s->hist_cap, s->maxits);
+        }
+        PFEM_TRY(check_kernel("single-reduction pcg iteration"));
+        s->tm.host_enqueue_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_chunk).count();
+        s->tm.host_enqueued_iterations += it - it_chunk0;
+    }
+    s->tm.host_comm_ms = host_comm_s * 1e3;
+    s->last_its = h.its;
+    s->last_reason = (h.flag == 2 && h.rn <= s->abstol) ? 3 : h.flag;
+    s->last_rnorm = h.rn;
+    // sampled SpMV launches that did work: steps 0 .. its (the last one only judged)
+    s->tm.spmv_ms_total = 0.0;
+    s->tm.spmv_launches = 0;
+    const size_t live = std::min(ev_used / ev_per, (static_cast<size_t>(h.its) + 1 + s->profile_every - 1) / s->profile_every);
+    for (size_t k = 0; k < live; ++k) {
+        for (size_t q = 0; q < ev_per; q += 2) {
+            const bool split = multi && overlap;
+            if (split && ((q == 0 && s->n_slices_b == 0) || (q == 2 && s->n_slices_i == 0))) continue;
+            if (multi && !split && q == 2) continue;
+            float f = 0.f;
+            PFEM_HIP(hipEventElapsedTime(&f, s->spmv_events[ev_per * k + q], s->spmv_events[ev_per * k + q + 1]));
+            s->tm.spmv_ms_total += f;
+        }
+        ++s->tm.spmv_launches;
+    }
+    s->tm.iface_ms_total = s->tm.scalar_ms_total = s->tm.exposed_ms_total = 0.0;
+    s->tm.comm_samples = 0;
+    for (size_t k = 0; k < std::min(comm_used / 8, live); ++k) {
+        hipEvent_t *c = &s->comm_events[8 * k];
+        float x = 0.f, a1 = 0.f, w = 0.f;
+        PFEM_HIP(hipEventElapsedTime(&x, c[0], c[1]));
+        PFEM_HIP(hipEventElapsedTime(&a1, c[2], c[3]));
+        PFEM_HIP(hipEventElapsedTime(&w, c[6], c[7]));
+        s->tm.iface_ms_total += x;
+        s->tm.scalar_ms_total += a1;
+        s->tm.exposed_ms_total += w;
         ++s->tm.comm_samples;
     }
     return PFEM_OK;

@@ -1040,6 +1040,7 @@ struct CgCtl {            // device-resident control block of the CG iteration
     int its_dir;          // iteration index handed from k_cg_update to k_cg_direction (graph launches carry no `it`);
                           // -2 once the update kernel has seen the solve finished
     int pad_;
+    double dpi[2];        // single-reduction form: (p,Ap) by recurrence, ping-pong by iteration parity
 };
 static_assert(offsetof(CgCtl, flag) % 8 == 0 && offsetof(CgCtl, its) == offsetof(CgCtl, flag) + 4, "flag/its share a word");
 
@@ -1619,6 +1620,105 @@ __global__ void __launch_bounds__(kBlock) k_cg_direction(CgCtl *ctl, int it_arg,
         __builtin_nontemporal_store(__builtin_fma(alpha, pi, __builtin_nontemporal_load(x + i)), x + i);
         p[i] = __builtin_fma(bb, pi, r[i] * dinv[i]);
     }
+}
+
+// ---------------------------------------------------------------------------
+// Single-reduction form of the same iteration (Chronopoulos & Gear; PETSc: KSPCGUseSingleReduction,
+// -ksp_cg_single_reduction): s = A z is formed instead of w = A p, so that (z,r), (z,s) and (z,z) are all known at ONE
+// point of the iteration -- one all-reduce per iteration on several ranks instead of two -- and
+//     b = beta/beta_old,  (p,Ap) = (z,s) - beta^2 (p,Ap)_old / beta_old^2,  a = beta/(p,Ap),
+//     p = z + b p,  w = s + b w  (= A p by recurrence),  x += a p,  r -= a w,  z = M^-1 r.
+// Step `it` first judges the iterate that step it-1 produced (its norm is only known now, one SpMV later than in the
+// two-reduction loop: the price PETSc's variant pays too), then advances.  Every block derives the same verdict from the
+// same bits, so a block that starts late and finds the lead block's verdict already published does what it would have
+// decided itself.  The (r,z)/(z,z) partials are read and written in the same launch: two sets, by iteration parity.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_reduce_partials3(const double *part0, int n0, const double *part1, const double *part2,
+                                                            int n12, double *out, const CgCtl *ctl)
+{
+    __shared__ double sm[16];
+    if (ctl && ctl->flag != 0) return;
+    for (int j = 0; j < 3; ++j) {
+        const double *part = j == 0 ? part0 : (j == 1 ? part1 : part2);
+        const int n = j == 0 ? n0 : n12;
+        double a = 0.0;
+        for (int i = threadIdx.x; i < n; i += 1024) a += part[i];
+        a = wave_sum(a);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < 16; ++w) t += sm[w];
+            out[j] = t;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_cg1_step(CgCtl *ctl, int it, int64_t n, int64_t n_owned, const double *part_zs, int n_zs,
+                                                      const double *part_rz, const double *part_zz, int nparts,
+                                                      const double *reduced /* [(z,s), (r,z), (z,z)] summed over the ranks, or null */,
+                                                      const double *__restrict__ dinv, double *__restrict__ z,
+                                                      const double *__restrict__ sv, double *__restrict__ p, double *__restrict__ w,
+                                                      double *__restrict__ x, double *__restrict__ r, double *out_rz, double *out_zz,
+                                                      double rtol, double abstol, double dtol, double *hist, int hist_cap, int maxits)
+{
+    __shared__ double sm[4];
+    if (ctl->flag != 0) return;
+    double zs, rz, zz;
+    if (reduced) { zs = reduced[0]; rz = reduced[1]; zz = reduced[2]; }
+    else { zs = sum_partials(part_zs, n_zs, sm); rz = sum_partials(part_rz, nparts, sm); zz = sum_partials(part_zz, nparts, sm); }
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    const double rn = sqrt(zz);
+    int flag = 0;
+    if (it == 0 && rn <= abstol) flag = 3;
+    else if (it > 0 && rn <= ctl->ttol) flag = 2;                    // KSP_CONVERGED_RTOL (or ATOL, resolved on the host)
+    else if (it > 0 && rn >= ctl->dtol * ctl->rn0) flag = -4;
+    else if (rz < 0.0) flag = -8;                                    // KSP_DIVERGED_INDEFINITE_PC
+    else if (it >= maxits) flag = -3;
+    if (lead) {
+        if (it == 0) { ctl->rn0 = rn; ctl->ttol = fmax(rtol * rn, abstol); ctl->dtol = dtol; }
+        ctl->rn = rn;
+        if (it < hist_cap) hist[it] = rn;
+    }
+    if (flag != 0) {
+        if (lead) ctl_publish(ctl, flag, it);
+        return;
+    }
+    double b = 0.0, dpi = zs;
+    if (it > 0) {
+        const double beta_old = ctl->beta[(it + 1) & 1], dpi_old = ctl->dpi[(it + 1) & 1];
+        b = rz / beta_old;
+        dpi = zs - rz * rz * dpi_old / (beta_old * beta_old);
+    }
+    if (!(dpi > 0.0)) {                          // KSP_DIVERGED_INDEFINITE_MAT: x is not advanced
+        if (lead) ctl_publish(ctl, -10, it + 1);
+        return;
+    }
+    const double a = rz / dpi;
+    if (lead) {
+        ctl->beta[it & 1] = rz;
+        ctl->dpi[it & 1] = dpi;
+        ctl->alpha = a;
+        ctl_publish(ctl, 0, it);
+    }
+    double nrz = 0.0, nzz = 0.0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const double zi = z[i], si = sv[i];
+        const double pi = it ? __builtin_fma(b, p[i], zi) : zi;
+        const double wi = it ? __builtin_fma(b, w[i], si) : si;
+        p[i] = pi;
+        w[i] = wi;
+        __builtin_nontemporal_store(__builtin_fma(a, pi, __builtin_nontemporal_load(x + i)), x + i);
+        const double ri = __builtin_fma(-a, wi, r[i]);
+        r[i] = ri;
+        const double zn = ri * dinv[i];
+        z[i] = zn;
+        if (i < n_owned) { nrz = __builtin_fma(ri, zn, nrz); nzz = __builtin_fma(zn, zn, nzz); }
+    }
+    const double t0 = block_sum(nrz, sm), t1 = block_sum(nzz, sm);
+    if (threadIdx.x == 0) { out_rz[blockIdx.x] = t0; out_zz[blockIdx.x] = t1; }
 }
 
 // ---------------------------------------------------------------------------

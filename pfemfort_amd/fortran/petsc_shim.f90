@@ -26,14 +26,20 @@ subroutine PetscInitialize(file, ierr)
       line = adjustl(line)
       if (len_trim(line) == 0 .or. line(1:1) == '#') cycle
       n = index(trim(line), ' ')
-      if (n == 0) cycle
-      key = line(1:n-1); val = adjustl(line(n+1:))
+      if (n == 0) then                      ! a flag without a value (-ksp_cg_single_reduction)
+        key = trim(line); val = ""
+      else
+        key = line(1:n-1); val = adjustl(line(n+1:))
+      end if
       select case (trim(key))
       case ("-ksp_rtol");   read(val, *, iostat=io) pfem_opt_rtol
       case ("-ksp_atol");   read(val, *, iostat=io) pfem_opt_atol
       case ("-ksp_divtol"); read(val, *, iostat=io) pfem_opt_dtol
       case ("-ksp_max_it"); read(val, *, iostat=io) pfem_opt_maxits
       case ("-pc_type");    call pfem_set_pc_type(trim(val))
+      case ("-ksp_cg_single_reduction")     ! KSPCGUseSingleReduction: one all-reduce per iteration
+        pfem_opt_single = 1
+        if (trim(val) == "0" .or. trim(val) == "false" .or. trim(val) == "no") pfem_opt_single = 0
       case ("-ksp_type")
         if (trim(val) /= "cg") then        ! the reference hard-wires KSPCG (solverpetsc.F:187); nothing else is built
           write(*,*) "pfem_amd: -ksp_type ", trim(val), " is not available (only cg, as the reference sets)"

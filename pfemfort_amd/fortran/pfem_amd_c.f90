@@ -45,6 +45,11 @@ module pfem_amd_c
       type(c_ptr), value :: s
       integer(c_int), value :: pc
     end function
+    integer(c_int) function pfem_solver_set_cg_single_reduction(s, on) bind(C, name="pfem_solver_set_cg_single_reduction")
+      import
+      type(c_ptr), value :: s
+      integer(c_int), value :: on
+    end function
     integer(c_int) function pfem_solver_set_zero(s) bind(C, name="pfem_solver_set_zero")
       import
       type(c_ptr), value :: s

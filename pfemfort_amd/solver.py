@@ -199,6 +199,12 @@ class PetscSolver:
         """"jacobi" (default; PCJACOBI) or "pbjacobi" (node-block Jacobi, PETSc's -pc_type pbjacobi)."""
         L.check(L.lib().pfem_solver_set_preconditioner(self._h, {"jacobi": 0, "pbjacobi": 1}[pc]), "pfem_solver_set_preconditioner")
 
+    def setSingleReduction(self, on=True):
+        """KSPCGUseSingleReduction (-ksp_cg_single_reduction): one all-reduce per CG iteration instead of two
+        (``None``: leave it to PFEM_CG_SINGLE_REDUCTION)."""
+        L.check(L.lib().pfem_solver_set_cg_single_reduction(self._h, -1 if on is None else int(bool(on))),
+                "pfem_solver_set_cg_single_reduction")
+
     def preconditioner(self):
         """The preconditioner the next solve uses ("pbjacobi" needs 3-dof row groups and one rank)."""
         b = C.c_int(0)

@@ -213,6 +213,8 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
         if mesh_args.get("pc"):
             s.setPreconditioner(mesh_args["pc"])
         s.setSpmvFormat(mesh_args.get("spmv", "auto"))
+        if mesh_args.get("single"):         # KSPCGUseSingleReduction: one all-reduce (of three scalars) per iteration
+            s.setSingleReduction(True)
         ed = H.ELAST_ELEMDATA if kind == pf.ELAST_TET else H.POISSON_ELEMDATA
         if mesh_args.get("mode", "batched") == "batched":
             s.uploadMesh(kind, conn_loc, xyz_new, edof_g, dm.solnApplied)
@@ -271,7 +273,9 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                                                             ("poisson", 3, "idle", "batched"), ("elast", 3, "idle", "pbjacobi"),
                                                             ("poisson", 2, "slabs", "overlap"), ("elast", 3, "sectors", "overlap"),
                                                             ("poisson", 2, "foreign", "batched"), ("elast", 3, "foreign", "compat"),
-                                                            ("poisson", 3, "rcb", "batched"), ("elast", 3, "rcb", "overlap")])
+                                                            ("poisson", 3, "rcb", "batched"), ("elast", 3, "rcb", "overlap"),
+                                                            ("poisson", 2, "slabs", "single"), ("elast", 3, "sectors", "single"),
+                                                            ("poisson", 3, "rcb", "single_overlap"), ("elast", 3, "idle", "single")])
 def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partition, mode):
     """2-3 ranks share cuda:0 (host-staged exchange over gloo): the product's multi-rank device loop against the
     ORACLE -- a direct solve of the oracle-assembled global system in the partition's new numbering, and the oracle's
@@ -291,6 +295,8 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
         mesh_args["mode"], mesh_args["pc"] = "batched", "pbjacobi"
     if mode == "overlap":             # boundary slices first, exchange on the second stream under the interior slices
         mesh_args["mode"], mesh_args["overlap"] = "batched", True
+    if mode in ("single", "single_overlap"):      # the single-reduction form of the iteration, in order / overlapped
+        mesh_args["mode"], mesh_args["single"], mesh_args["overlap"] = "batched", True, mode == "single_overlap"
     if mode == "int32":               # the int32-column SpMV form through the boundary / interior slice lists
         mesh_args["mode"], mesh_args["spmv"] = "batched", "int32"
     if mode == "compat":
@@ -305,7 +311,9 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
                            node_proc_id=npid)
     lu = spl.splu(sp.csr_matrix((prob.vals, prob.cols, prob.rowptr)).tocsc())
     u = lu.solve(prob.rhs)
-    _, its_oracle, reason_oracle, *_ = O.pcg_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-10)
+    single = bool(mesh_args.get("single"))
+    _, its_oracle, reason_oracle, *_ = (O.pcg_jacobi_single_reduction if single else O.pcg_jacobi)(
+        prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-10)
     assert reason_oracle == 2
     its_tol = 3
     if mode == "pbjacobi":
@@ -324,7 +332,12 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
         assert int(d["reason"]) == 2 and abs(int(d["its"]) - its_oracle) <= its_tol
         # per iteration: one exchange and two all-reduces; every rank issued the same KIND of call in the same order
         idle = int(d["n_peers"]) == 0                        # a rank without neighbours has nothing to exchange
-        assert int(d["calls"]) >= (2 if idle else 3) * int(d["its"])
+        assert int(d["calls"]) >= (2 if idle else 3) * int(d["its"]) if not single else True
+        if single:                                           # ONE all-reduce per step; steps = its + 1 (the last one judges)
+            n_all = sum(1 for s in d["log"] if s[0] == "a")
+            setup_allreduces = 0                              # point Jacobi: the set-up exchanges need no all-reduce
+            assert n_all - setup_allreduces <= int(d["its"]) + 1 + 32     # + the tail of the last 32-step chunk
+            assert n_all >= int(d["its"]) + 1
         kinds = [s[0] for s in d["log"]]
         kinds0 = [s[0] for s in np.load(tmp_path / "rank0.npz")["log"]]
         if idle:

@@ -535,3 +535,61 @@ def test_relative_row_groups_with_32bit_gaps():
     xo, its_o, reason_o, *_ = O.pcg_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-10)
     assert reason == reason_o == 2 and abs(its - its_o) <= 1
     assert np.abs(s.getSolution() - xo).max() <= U_ATOL
+
+
+@pytest.mark.parametrize("name", ["tet10", "tria20", "beam", "cube40"])
+def test_single_reduction_cg_matches_its_oracle(name, request, monkeypatch):
+    """KSPCGUseSingleReduction (pfem_solver_set_cg_single_reduction / PFEM_CG_SINGLE_REDUCTION): the device loop against
+    the oracle's restatement of the same recurrences -- iteration count +-1, residual history, reasons -- and against
+    the converged two-reduction solution."""
+    monkeypatch.setenv("PFEM_CG_SINGLE_REDUCTION", "1")
+    if name == "cube40":                    # large enough for the relative row groups and a folded (p,Ap)
+        mesh = H.gen_box_tets(-1, 1, 40, -1, 1, 40, -1, 1, 40)
+        run, kind, kw = pf.tetrapoissonparallelimpl1, O.POISSON_TET, {}
+    else:
+        mesh = request.getfixturevalue(name)
+        run, kind, kw = {"tet10": (pf.tetrapoissonparallelimpl1, O.POISSON_TET, {}),
+                         "tria20": (pf.triapoissonserialimpl1, O.POISSON_TRIA_INLINE, {"elemData": np.array([1.0, 1.0, 0.0])}),
+                         "beam": (pf.tetraelasticityparallelimpl1, O.ELAST_TET, {})}[name]
+    prob = O.setup_problem(kind, _omesh(mesh), **kw)
+    for rtol in (1e-5, 1e-10):
+        res = run(mesh, rtol=rtol)
+        x, its, reason, rn, hist = O.pcg_jacobi_single_reduction(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=rtol, hist_len=4000)
+        assert res.reason == reason == 2 and abs(res.its - its) <= (3 if name == "beam" else 1)
+        h = res.solver.getHistory()
+        n = min(len(h), len(hist))
+        assert n >= min(its, res.its)
+        if name != "beam":                   # (the slender beam amplifies rounding differences along the history)
+            assert np.allclose(h[:n], hist[:n], rtol=1e-6)
+        if rtol == 1e-10:
+            xc, *_ = O.pcg_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-12)
+            assert np.abs(res.soln_free - xc).max() <= U_ATOL * max(1.0, np.abs(xc).max())
+    # iteration limit, as the two-reduction loop reports it
+    r = run(mesh, rtol=1e-14, maxits=5)
+    assert (r.its, r.reason) == (5, -3)
+    x5, its5, reason5, *_ = O.pcg_jacobi_single_reduction(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-14, maxits=5)
+    assert np.allclose(r.soln_free, x5, rtol=1e-10, atol=1e-13)
+
+
+def test_single_reduction_cg_edge_reasons():
+    """Zero right-hand side (converged at iteration 0), an indefinite matrix (-10 at iteration 1) and the setter
+    overriding the environment, in the single-reduction form."""
+    n = 50
+    s = pf.PetscSolver().initialise(n, n)
+    s.setSingleReduction(True)
+    idx = np.arange(n, dtype=np.int32)
+    for i in range(n):
+        c = [j for j in (i - 1, i, i + 1) if 0 <= j < n]
+        s.MatSetValues([i], c, np.zeros(len(c)), pf.solver.INSERT_VALUES)
+    s.setZero()
+    for i in range(n):
+        c = [j for j in (i - 1, i, i + 1) if 0 <= j < n]
+        s.MatSetValues([i], c, np.array([2.0 if j == i else 3.0 for j in c]), pf.solver.ADD_VALUES)
+    assert s.factoriseAndSolve()[:2] == (0, 3)                        # b = 0
+    s.VecSetValues(idx, (-1.0) ** np.arange(n), pf.solver.ADD_VALUES)
+    its, reason, _ = s.factoriseAndSolve()
+    rowptr, cols, vals = s.getCSR()
+    _, its_o, reason_o, *_ = O.pcg_jacobi_single_reduction(rowptr, cols, vals, s.getRHS(), rtol=1e-5)
+    assert reason == reason_o == -10 and its == its_o == 1
+    s.setTolerances(rtol=1e-5, maxits=0)
+    assert s.factoriseAndSolve()[:2] == (0, -3)

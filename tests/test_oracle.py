@@ -155,3 +155,30 @@ def test_beam_config4_small_cousin():
     # cantilever under body force (0.1,0,0): beam theory qL^4/8EI = 0.81; the coarse P1
     # mesh locks, so only sign/order of magnitude is asserted here
     assert 0.05 < tip[:, 0].mean() < 0.9
+
+
+def test_single_reduction_pcg_restatement(tet10, tria20):
+    """orc_pcg_jacobi_single_reduction (PETSc's KSPCGUseSingleReduction recurrences) against the two-reduction loop and
+    a direct solve: same solution, same stopping iteration to +-1, the same residual history to rounding, same reasons."""
+    for p in (O.setup_problem(O.POISSON_TET, tet10), O.setup_problem(O.POISSON_TRIA_INLINE, tria20, elemData=np.array([1.0, 1.0, 0.0]))):
+        N = p.dm.size_global
+        u = spl.spsolve(sp.csr_matrix((p.vals, p.cols, p.rowptr), shape=(N, N)).tocsc(), p.rhs)
+        for rtol in (1e-5, 1e-10):
+            x2, its2, reason2, rn2, h2 = O.pcg_jacobi(p.rowptr, p.cols, p.vals, p.rhs, rtol=rtol, hist_len=400)
+            x1, its1, reason1, rn1, h1 = O.pcg_jacobi_single_reduction(p.rowptr, p.cols, p.vals, p.rhs, rtol=rtol, hist_len=400)
+            assert reason1 == reason2 == 2 and abs(its1 - its2) <= 1
+            n = min(len(h1), len(h2))
+            assert np.allclose(h1[:n], h2[:n], rtol=1e-6)
+            if rtol == 1e-10:
+                assert np.abs(x1 - u).max() < 1e-8
+    p = O.setup_problem(O.POISSON_TET, tet10)
+    assert O.pcg_jacobi_single_reduction(p.rowptr, p.cols, p.vals, p.rhs, rtol=1e-10, maxits=7)[1:3] == (7, -3)
+    assert O.pcg_jacobi_single_reduction(p.rowptr, p.cols, p.vals, p.rhs, rtol=1e-10, maxits=0)[1:3] == (0, -3)
+    assert O.pcg_jacobi_single_reduction(p.rowptr, p.cols, p.vals, 0 * p.rhs)[1:3] == (0, 3)
+    assert O.pcg_jacobi_single_reduction(p.rowptr, p.cols, -p.vals, p.rhs)[2] == -8        # (r, M^-1 r) < 0
+    v = p.vals.copy()
+    v[p.rowptr[5]:p.rowptr[5 + 1]][p.cols[p.rowptr[5]:p.rowptr[6]] != 5] *= 40.0           # keeps the diagonal positive
+    v2 = sp.csr_matrix((v, p.cols, p.rowptr), shape=(729, 729)); v2 = ((v2 + v2.T) * 0.5).tocsr(); v2.sort_indices()
+    r1 = O.pcg_jacobi_single_reduction(v2.indptr.astype(np.int64), v2.indices.astype(np.int32), v2.data, p.rhs, rtol=1e-12)
+    r2 = O.pcg_jacobi(v2.indptr.astype(np.int64), v2.indices.astype(np.int32), v2.data, p.rhs, rtol=1e-12)
+    assert r1[2] == r2[2] == -10                                                              # indefinite matrix
