@@ -180,6 +180,7 @@ struct pfem_solver {
     bool have_mesh = false;
     DevBuf<int32_t> d_conn, d_edof;
     DevBuf<double> d_xyz, d_soln;
+    DevBuf<double4> d_node4;       // {x, y, z, solnApplied} per node for the Poisson-tet gather kernel (built with the incidence)
 
     // local numbering
     int64_t n_loc = 0, n_ghost = 0;
@@ -921,6 +922,12 @@ int build_incidence(pfem_solver *s)
     PFEM_HIP(hipStreamSynchronize(s->stream));
     s->d_inc_ea.release();          // the lists the records came from are dropped
     s->d_inc_slots.release();
+    s->d_node4.release();
+    if (m.kind == PFEM_POISSON_TET && m.nNode > 0) {
+        PFEM_TRY(s->d_node4.alloc(static_cast<size_t>(m.nNode)));
+        hipLaunchKernelGGL(k_pack_node4, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m, s->d_node4.p);
+        PFEM_TRY(check_kernel("k_pack_node4"));
+    }
     // orientation test of every element, once per mesh
     PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
     hipLaunchKernelGGL(k_check_jacobian, dim3(grid_for(m.nElem)), dim3(kBlock), 0, s->stream, m, s->d_err.p);
@@ -1054,6 +1061,10 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
         const int64_t nthr = static_cast<int64_t>(m.ndof) * m.nNode;
         const dim3 rgrid(static_cast<unsigned>((nthr + T - 1) / T)), rblock(T);
         const size_t rlds = static_cast<size_t>(s->gather_row_len) * T * sizeof(double);
+        // XCD-contiguous block order for the kernels that gather neighbour coordinates (xcd_contiguous_block)
+        const bool xcd = rgrid.x >= 64 && !std::getenv("PFEM_DEBUG_GATHER_PLAIN_ORDER");
+        const unsigned xcd_per = xcd ? (rgrid.x + 7u) / 8u : 0u;
+        const dim3 xgrid(xcd ? 8u * xcd_per : rgrid.x);
         // more than 64 KiB of dynamic LDS has to be allowed per kernel
         auto allow_lds = [&](const void *fn) -> int {
             if (rlds > 65536) PFEM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(rlds)));
@@ -1065,12 +1076,21 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
         hipLaunchKernelGGL((k_gather_scalar<KIND, true>), rgrid, rblock, rlds, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, nrow, s->d_err.p); \
     } else hipLaunchKernelGGL((k_gather_scalar<KIND, false>), grid, block, 0, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, nrow, s->d_err.p)
         switch (m.kind) {
-        case PFEM_POISSON_TET: PFEM_GATHER(PFEM_POISSON_TET); break;
+        case PFEM_POISSON_TET:
+            if (use_lds && s->d_node4.p && !std::getenv("PFEM_DEBUG_GATHER_SOA")) {
+                PFEM_TRY(allow_lds(reinterpret_cast<const void *>(&k_gather_poisson_tet4)));
+                hipLaunchKernelGGL(k_gather_poisson_tet4, xgrid, rblock, rlds, s->stream, m.nNode, A, s->d_rhs.p, prm, ip, ic, irec, nrow,
+                                   static_cast<const double4 *>(s->d_node4.p), s->d_err.p, xcd_per);
+            } else {
+                PFEM_GATHER(PFEM_POISSON_TET);
+            }
+            break;
         case PFEM_POISSON_TRIA: PFEM_GATHER(PFEM_POISSON_TRIA); break;
         case PFEM_POISSON_TRIA_INLINE: PFEM_GATHER(PFEM_POISSON_TRIA_INLINE); break;
         case PFEM_ELAST_TET:
             PFEM_TRY(allow_lds(reinterpret_cast<const void *>(&k_gather_elast_rows)));
-            hipLaunchKernelGGL(k_gather_elast_rows, rgrid, rblock, rlds, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, ifl, nrow, s->d_err.p);
+            // (plain block order: the XCD-contiguous one measured 3 % slower on the beam, 1.605 against 1.56 ms)
+            hipLaunchKernelGGL(k_gather_elast_rows, rgrid, rblock, rlds, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, ifl, nrow, s->d_err.p, 0u);
             break;
         case PFEM_ELAST_TRIA:
             PFEM_TRY(allow_lds(reinterpret_cast<const void *>(&k_gather_elast2d_rows)));

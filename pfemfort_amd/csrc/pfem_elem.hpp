@@ -84,6 +84,39 @@ PFEM_HD void tet_geometry(const double x[4], const double y[4], const double z[4
     g.jac = jac;
 }
 
+// The same geometry without the reference's literal products by 0.0 / 1.0 / -1.0 and its zero-initialised sums (117 of
+// the 168 operations above).  For finite coordinates every NONZERO result has the same bits: x + (+-0) = x, x * -1.0 = -x,
+// and the remaining additions are the same additions in the same order ((-x2) + x3 = x3 - x2 exactly).  What may differ is
+// the SIGN OF A ZERO entry (the literal form turns -0 into +0 at its first `0.0 +`).  A signed zero can only travel on as
+// a signed zero (no division by it short of a degenerate element, which the reference cannot assemble either), and every
+// value the gather kernels build from these is ADDED to an accumulator that starts at +0.0, where +-0 changes nothing:
+// assembled K and F have the same bits either way.  Used by the gather kernels only; the per-element entry points and
+// pfem_eval_elems keep the literal form above.  (tests/native: lean == literal up to the sign of zeros, -0.0 coordinates
+// included; tests/test_gpu_*: assembled K, F bit-exact against the oracle's literal serial loop.)
+PFEM_HD void tet_geometry_lean(const double x[4], const double y[4], const double z[4], TetGeom &g)
+{
+    const double b11 = x[0] - x[2], b21 = x[1] - x[2], b31 = x[3] - x[2];
+    const double b12 = y[0] - y[2], b22 = y[1] - y[2], b32 = y[3] - y[2];
+    const double b13 = z[0] - z[2], b23 = z[1] - z[2], b33 = z[3] - z[2];
+    double jac = b11 * (b22 * b33 - b23 * b32);
+    jac = jac + b12 * (b23 * b31 - b21 * b33);
+    jac = jac + b13 * (b21 * b32 - b22 * b31);
+    const double di = 1.0 / jac;
+    const double i11 = +di * (b22 * b33 - b23 * b32);
+    const double i21 = -di * (b21 * b33 - b23 * b31);
+    const double i31 = +di * (b21 * b32 - b22 * b31);
+    const double i12 = -di * (b12 * b33 - b13 * b32);
+    const double i22 = +di * (b11 * b33 - b13 * b31);
+    const double i32 = -di * (b11 * b32 - b12 * b31);
+    const double i13 = +di * (b12 * b23 - b13 * b22);
+    const double i23 = -di * (b11 * b23 - b13 * b21);
+    const double i33 = +di * (b11 * b22 - b12 * b21);
+    g.gx[0] = i11;  g.gx[1] = i12;  g.gx[2] = (-i11 - i12) - i13;  g.gx[3] = i13;
+    g.gy[0] = i21;  g.gy[1] = i22;  g.gy[2] = (-i21 - i22) - i23;  g.gy[3] = i23;
+    g.gz[0] = i31;  g.gz[1] = i32;  g.gz[2] = (-i31 - i32) - i33;  g.gz[3] = i33;
+    g.jac = jac;
+}
+
 // Poisson on a P1 tet, one Gauss point (1/4,1/4,1/4), source term -6
 // [elementutilitiespoisson.F:107-193].  K column-major 4x4.  Returns false when the
 // reference would STOP on a negative Jacobian [:157].
@@ -158,6 +191,37 @@ PFEM_HD bool poisson_tet_node(const double x[4], const double y[4], const double
 #pragma unroll
         for (int j = 0; j < 4; ++j)        // Klocal(a,j)
             Krow[j] = 0.0 + af * (b1a * (kx * g.gx[j]) + b2a * (ky * g.gy[j]) + b3a * (kz * g.gz[j]));
+    }
+    return true;
+}
+
+// poisson_tet_node() on the lean geometry for valC = 0 (what the drivers pass, and all the gather kernel ever sees): the
+// du terms vanish (b * (+0) = +-0, f - (+-0) = f) and the `0.0 +` of the literal form only turns a -0 into +0 -- again the
+// same bits for every nonzero result (see tet_geometry_lean).
+PFEM_HD bool poisson_tet_node_lean(const double x[4], const double y[4], const double z[4], double kx, double ky, double kz,
+                                   double af, int a, bool need_row, double Kcol[4], double Krow[4], double &Fa)
+{
+    TetGeom g;
+    tet_geometry_lean(x, y, z, g);
+    if (g.jac < 0.0) return false;
+    const double dvol = kGaussWtTet * g.jac;
+    double gxa = g.gx[0], gya = g.gy[0], gza = g.gz[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i == a) { gxa = g.gx[i]; gya = g.gy[i]; gza = g.gz[i]; }
+    const double Na = a == 2 ? 1.0 - 0.25 - 0.25 - 0.25 : 0.25;
+    const double b1a = gxa * dvol, b2a = gya * dvol, b3a = gza * dvol;
+    Fa = (Na * dvol) * -6.0;
+    const double cx = kx * gxa, cy = ky * gya, cz = kz * gza;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {          // Klocal(j,a)
+        const double b1 = g.gx[j] * dvol, b2 = g.gy[j] * dvol, b3 = g.gz[j] * dvol;
+        Kcol[j] = af * (b1 * cx + b2 * cy + b3 * cz);
+    }
+    if (need_row) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)        // Klocal(a,j)
+            Krow[j] = af * (b1a * (kx * g.gx[j]) + b2a * (ky * g.gy[j]) + b3a * (kz * g.gz[j]));
     }
     return true;
 }

@@ -598,6 +598,16 @@ __global__ void __launch_bounds__(kBlock) k_check_jacobian(MeshDev m, int *err)
     if (neg) atomicMax(err, PFEM_ERR_NEG_JAC);
 }
 
+// Workgroups are handed to the 8 XCDs round-robin (block b runs on XCD b % 8), each with its own L2.  The gather kernels
+// read the coordinates of a node's neighbours, i.e. of the node chunks a line or a plane away: with the plain order those
+// chunks are worked on by OTHER XCDs, and every XCD fetches every coordinate line it needs itself (PMC at cfg 3: 4.2 GB
+// of fabric reads for 0.26 GB of coordinates).  Giving each XCD one contiguous eighth of the chunks keeps a chunk's
+// neighbours in the same L2.  `per` = ceil(chunks / 8); the launch has 8 * per blocks, those past the end leave.
+__device__ __forceinline__ int64_t xcd_contiguous_block(unsigned b, unsigned per, bool remap)
+{
+    return remap ? static_cast<int64_t>(b & 7u) * per + (b >> 3) : static_cast<int64_t>(b);
+}
+
 // LDSACC: the node's row is accumulated in LDS (entry k of thread t at acc[k*T + t], T = block
 // size: conflict free) and written out once, coalesced, instead of ~6 global read-modify-writes
 // per entry; the caller provides maxlen*T*8 bytes of dynamic LDS.  Same additions in the same order.
@@ -655,7 +665,7 @@ __global__ void __launch_bounds__(kBlock) k_gather_scalar(MeshDev m, SellDev A, 
             for (int i = 0; i < NPE; ++i) any_fixed |= fixed[i];
 #pragma unroll
             for (int i = 0; i < NPE; ++i) Krow[i] = 0.0;
-            ok = poisson_tet_node(x, y, z, prm.ed[0], prm.ed[1], prm.ed[2], prm.af, valC, a, any_fixed, Kcol, Krow, f);
+            ok = poisson_tet_node_lean(x, y, z, prm.ed[0], prm.ed[1], prm.ed[2], prm.af, a, any_fixed, Kcol, Krow, f);
         } else {
             double K[NPE * NPE], F[NPE];
             if constexpr (KIND == PFEM_POISSON_TRIA)
@@ -688,6 +698,77 @@ __global__ void __launch_bounds__(kBlock) k_gather_scalar(MeshDev m, SellDev A, 
     rhs[row] = facc;
 }
 
+// {x, y, z, solnApplied} of every node side by side (32 B): one sector per gathered node instead of three or four
+__global__ void __launch_bounds__(kBlock) k_pack_node4(MeshDev m, double4 *__restrict__ out)
+{
+    const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (n >= m.nNode) return;
+    out[n] = double4{m.xyz[n], m.xyz[m.nNode + n], m.xyz[2 * m.nNode + n], m.ndof == 1 ? m.soln[n] : 0.0};
+}
+
+// k_gather_scalar<PFEM_POISSON_TET, true> with its two memory habits changed (same arithmetic, same order of additions):
+// the coordinates and the Dirichlet value of a node come from ONE 32-B record (k_pack_node4) instead of four arrays
+// -- the gathers, not the streamed incidence records, were what kept this kernel waiting: 9 scattered 8-B reads per visit
+// -- and the next incidence record is already in flight while an element is evaluated.
+__global__ void __launch_bounds__(kBlock) k_gather_poisson_tet4(int64_t nNode, SellDev A, double *rhs, ElemPrm prm,
+                                                                 const int64_t *__restrict__ inc_ptr,
+                                                                 const int32_t *__restrict__ inc_cnt,
+                                                                 const int4 *__restrict__ inc_rec,
+                                                                 const int32_t *__restrict__ node_row,
+                                                                 const double4 *__restrict__ node4, int *err,
+                                                                 unsigned xcd_per)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_acc[];
+    const int T = blockDim.x;
+    const int64_t n = xcd_contiguous_block(blockIdx.x, xcd_per, xcd_per != 0) * T + threadIdx.x;
+    if (n >= nNode) return;
+    const int row = node_row[n];
+    if (row < 0) return;
+    const int cnt = inc_cnt[n];
+    const int64_t beg = inc_ptr[n >> 6] + (n & 63), end = beg + 64LL * cnt;
+    const int64_t base = A.slice_off[row >> 6] + (row & 63);
+    const int len = A.rowlen[row];
+    double facc = 0.0;
+    double *acc = lds_acc + threadIdx.x;
+    for (int k = 0; k < len; ++k) acc[k * T] = 0.0;
+    int4 next = cnt > 0 ? inc_rec[beg] : int4{0, 0, 0, 0};
+    for (int64_t t = beg; t < end; t += 64) {
+        const int4 rc = next;
+        if (t + 64 < end) next = inc_rec[t + 64];
+        const uint32_t slots = static_cast<uint32_t>(rc.w);
+        const int a = static_cast<int>((static_cast<uint32_t>(rc.x) >> 31) | ((static_cast<uint32_t>(rc.y) >> 31) << 1));
+        const int o[3] = {rc.x & 0x7fffffff, rc.y & 0x7fffffff, rc.z};
+        double x[4], y[4], z[4], ud[4];
+        bool fixed[4], any_fixed = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = i < a ? i : (i > 0 ? i - 1 : 0);
+            const int nd = (i == a) ? static_cast<int>(n) : o[q];
+            const double4 c = node4[nd];
+            x[i] = c.x; y[i] = c.y; z[i] = c.z; ud[i] = c.w;
+            fixed[i] = ((slots >> (8 * i)) & 0xffu) == 0xffu;
+            any_fixed |= fixed[i];
+        }
+        double Krow[4] = {0.0, 0.0, 0.0, 0.0}, Kcol[4], f = 0.0;
+        if (!poisson_tet_node_lean(x, y, z, prm.ed[0], prm.ed[1], prm.ed[2], prm.af, a, any_fixed, Kcol, Krow, f)) {
+            atomicMax(err, PFEM_ERR_NEG_JAC);
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)            // Flocal(a) -= Klocal(a,i)*u_D(i)   (:859-870)
+            if (fixed[i]) f = f - Krow[i] * ud[i];
+        facc += f;                             // VecSetValues(ADD_VALUES) :880
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {          // entry (row, dof_j) += Klocal(j,a)   (:851, row-major read)
+            if (fixed[j]) continue;
+            const uint32_t k = (slots >> (8 * j)) & 0xffu;
+            acc[k * T] += Kcol[j];
+        }
+    }
+    for (int k = 0; k < len; ++k) A.vals[base + (static_cast<int64_t>(k) << 6)] = acc[k * T];
+    rhs[row] = facc;
+}
+
 // Elasticity gather, one thread per (node, dof) ROW: the row is accumulated in LDS (entry k of
 // thread t at acc[k*T + t]: conflict free; T = blockDim.x chosen so maxlen*T doubles fit) and
 // stored once, coalesced -- no read-modify-write of the matrix in global memory (what bounded
@@ -698,11 +779,11 @@ __global__ void __launch_bounds__(kBlock) k_gather_elast_rows(MeshDev m, SellDev
                                                                const int32_t *__restrict__ inc_cnt,
                                                                const int4 *__restrict__ inc_rec,
                                                                const uint16_t *__restrict__ inc_flags,
-                                                               const int32_t *__restrict__ node_row, int *err)
+                                                               const int32_t *__restrict__ node_row, int *err, unsigned xcd_per)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];
     const int T = blockDim.x;
-    const int64_t tid = static_cast<int64_t>(blockIdx.x) * T + threadIdx.x;
+    const int64_t tid = xcd_contiguous_block(blockIdx.x, xcd_per, xcd_per != 0) * T + threadIdx.x;
     if (tid >= 3 * m.nNode) return;
     const int64_t n = tid / 3;
     const int p = static_cast<int>(tid - 3 * n);
@@ -734,7 +815,7 @@ __global__ void __launch_bounds__(kBlock) k_gather_elast_rows(MeshDev m, SellDev
             z[i] = m.xyz[2 * m.nNode + nd[i]];
         }
         TetGeom g;
-        tet_geometry(x, y, z, g);
+        tet_geometry_lean(x, y, z, g);    // zero signs aside, the literal geometry (pfem_elem.hpp)
         if (g.jac < 0.0) { atomicMax(err, PFEM_ERR_NEG_JAC); return; }
         const double dvol = kGaussWtTet * g.jac;
         double ax = g.gx[0], ay = g.gy[0], az = g.gz[0];

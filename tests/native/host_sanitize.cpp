@@ -132,6 +132,47 @@ int main(int argc, char **argv)
         int c = pfem_poisson_tria_ke(x, y, ed, td, vc, K, F), d = pfem_elast_tria_ke(x, y, ed, td, vc, K, F);
         assert((c == 0 || c == PFEM_ERR_NEG_JAC) && c == d);
     }
+    {   // The lean geometry / node routine of the gather kernels against the literal ones: every nonzero result has the
+        // same bits, a zero may differ in sign only.  Random elements, structured-box elements (many exactly zero
+        // differences) and coordinates that are -0.0 (what "-0.00000000" in a node file parses to).
+        auto same = [](double a, double b) { return std::memcmp(&a, &b, 8) == 0 || (a == 0.0 && b == 0.0); };
+        std::mt19937 r2(11);
+        std::normal_distribution<double> g2(0, 1);
+        const double grid[5] = {-1.0, -0.5, -0.0, 0.0, 0.5};
+        long zeros_seen = 0;
+        for (int rep = 0; rep < 20000; ++rep) {
+            double x[4], y[4], z[4];
+            for (int i = 0; i < 4; ++i) {
+                if (rep & 1) { x[i] = g2(r2); y[i] = g2(r2); z[i] = g2(r2); }
+                else { x[i] = grid[r2() % 5]; y[i] = grid[r2() % 5]; z[i] = grid[r2() % 5]; }
+            }
+            pfem::TetGeom a, b;
+            pfem::tet_geometry(x, y, z, a);
+            pfem::tet_geometry_lean(x, y, z, b);
+            if (!(a.jac != 0.0) || !std::isfinite(1.0 / a.jac)) continue;      // degenerate: neither form is meaningful
+            assert(same(a.jac, b.jac));
+            for (int i = 0; i < 4; ++i) {
+                assert(same(a.gx[i], b.gx[i]) && same(a.gy[i], b.gy[i]) && same(a.gz[i], b.gz[i]));
+                zeros_seen += (a.gx[i] == 0.0) + (a.gy[i] == 0.0) + (a.gz[i] == 0.0);
+            }
+            const double vz[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int an = 0; an < 4; ++an) {
+                double kc[4], kr[4], fa = 0.0, kc2[4], kr2[4], fa2 = 0.0;
+                const bool ok = pfem::poisson_tet_node(x, y, z, 1.5, 0.5, 2.0, 0.75, vz, an, true, kc, kr, fa);
+                assert(pfem::poisson_tet_node_lean(x, y, z, 1.5, 0.5, 2.0, 0.75, an, true, kc2, kr2, fa2) == ok);
+                if (!ok) continue;
+                assert(same(fa, fa2));
+                for (int j = 0; j < 4; ++j) assert(same(kc[j], kc2[j]) && same(kr[j], kr2[j]));
+                // ... and what reaches the matrix: an accumulator that starts at +0.0 ends with the same bits
+                for (int j = 0; j < 4; ++j) {
+                    double acc1 = 0.0, acc2 = 0.0;
+                    acc1 += kc[j]; acc2 += kc2[j];
+                    assert(std::memcmp(&acc1, &acc2, 8) == 0);
+                }
+            }
+        }
+        assert(zeros_seen > 1000);          // the zero-sign cases were really exercised
+    }
     assert(pfem_poisson_tet_ke(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == PFEM_ERR_ARG);
     // --- ASCII ingest: ragged / empty / unterminated / huge tokens ------------------------------
     for (const char *txt : {"", "\n\n", "1 2 3", "1 2 3\n4 5 6\n", " 1\t2  3 \r\n4 5 6 7 8\n", "1 2 3\n4 5\n", "x y z\n",

@@ -1,0 +1,14 @@
+#!/bin/bash
+set -u
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp; OUT=$GRAFT_REPO_ROOT/gpurun_out
+( timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_full_size.py -m gpu -x -q 2>&1 | tail -15 ) > $OUT/pytest_lean2.log 2>&1
+tail -5 $OUT/pytest_lean2.log
+for soa in 1 0 1 0; do
+  if [ $soa = 1 ]; then export PFEM_DEBUG_GATHER_SOA=1; else unset PFEM_DEBUG_GATHER_SOA; fi
+  ( timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-step 2>$OUT/bench_lean.err | grep '^{' | tail -1 ) > $OUT/bench_lean2_soa$soa.json
+  python - "$OUT/bench_lean2_soa$soa.json" $soa <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1]))
+print("soa", sys.argv[2], {k:d.get(k) for k in ("value","ms_per_step","assembly_ms_per_step","solve_ms_per_step")})
+PY
+done
