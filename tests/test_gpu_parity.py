@@ -593,3 +593,35 @@ def test_single_reduction_cg_edge_reasons():
     assert reason == reason_o == -10 and its == its_o == 1
     s.setTolerances(rtol=1e-5, maxits=0)
     assert s.factoriseAndSolve()[:2] == (0, -3)
+
+
+def test_gather_kernel_variants_agree_bit_for_bit(monkeypatch):
+    """The tet-Poisson gather assembly ships in two kernels (32-B node records + XCD-contiguous chunk order; the generic
+    structure-of-arrays kernel the 2-D kinds also use) and two block orders: the same additions in the same order, so
+    the same bits -- and the oracle's literal serial loop, which keeps the reference's products by 0 and 1."""
+    mesh = H.gen_box_tets(-1, 1, 33, -1, 1, 29, -1, 1, 31)           # 31 k nodes: > 64 blocks, so the XCD order is on
+    # some coordinates become -0.0 (what "-0.00000000" in a node file parses to): the lean geometry's only difference
+    xyz = mesh.xyz.copy()
+    xyz[xyz == 0.0] = -0.0
+    rng = np.random.default_rng(4)
+    extra = rng.choice(mesh.nNode, 300, replace=False).astype(np.int32)   # interior Dirichlet nodes: lifting inside the box
+    mesh = H.Mesh(xyz, mesh.conn, np.concatenate([mesh.bc_node, extra]), np.zeros(len(mesh.bc_node) + 300, np.int32),
+                  np.concatenate([mesh.bc_val, rng.standard_normal(300)]))
+    from pfemfort_amd import drivers as D
+    dm, conn_new, xyz_new, edof = D._setup(pf.POISSON_TET, mesh)
+    prob = O.setup_problem(O.POISSON_TET, _omesh(mesh))
+    got = {}
+    for name, env in (("node4_xcd", {}), ("node4_plain", {"PFEM_DEBUG_GATHER_PLAIN_ORDER": "1"}), ("soa", {"PFEM_DEBUG_GATHER_SOA": "1"})):
+        for k in ("PFEM_DEBUG_GATHER_PLAIN_ORDER", "PFEM_DEBUG_GATHER_SOA"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = pf.PetscSolver().initialise(dm.size_global, dm.size_global)
+        s.uploadMesh(pf.POISSON_TET, conn_new, xyz_new, edof, dm.solnApplied)
+        s.buildPattern()
+        s.assemble(H.POISSON_ELEMDATA, H.TIMEDATA)
+        got[name] = (s.getCSR()[2], s.getRHS())
+        s.free()
+    for name, (vals, rhs) in got.items():
+        assert np.array_equal(vals.view(np.uint64), prob.vals.view(np.uint64)), name      # bits, zero signs included
+        assert np.array_equal(rhs.view(np.uint64), prob.rhs.view(np.uint64)), name
