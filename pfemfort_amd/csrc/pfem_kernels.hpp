@@ -731,21 +731,45 @@ __global__ void __launch_bounds__(kBlock) k_gather_poisson_tet4(int64_t nNode, S
     double facc = 0.0;
     double *acc = lds_acc + threadIdx.x;
     for (int k = 0; k < len; ++k) acc[k * T] = 0.0;
-    int4 next = cnt > 0 ? inc_rec[beg] : int4{0, 0, 0, 0};
-    for (int64_t t = beg; t < end; t += 64) {
-        const int4 rc = next;
-        if (t + 64 < end) next = inc_rec[t + 64];
-        const uint32_t slots = static_cast<uint32_t>(rc.w);
+    // Two visits ahead: while element t is evaluated, the four node records of element t+1 and the incidence record of
+    // element t+2 are in flight (the node loads depend on the incidence record, the arithmetic on the node loads).
+    const auto node_ids = [n](const int4 &rc, int nd[4]) {
         const int a = static_cast<int>((static_cast<uint32_t>(rc.x) >> 31) | ((static_cast<uint32_t>(rc.y) >> 31) << 1));
         const int o[3] = {rc.x & 0x7fffffff, rc.y & 0x7fffffff, rc.z};
-        double x[4], y[4], z[4], ud[4];
-        bool fixed[4], any_fixed = false;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int q = i < a ? i : (i > 0 ? i - 1 : 0);
-            const int nd = (i == a) ? static_cast<int>(n) : o[q];
-            const double4 c = node4[nd];
-            x[i] = c.x; y[i] = c.y; z[i] = c.z; ud[i] = c.w;
+            nd[i] = (i == a) ? static_cast<int>(n) : o[q];
+        }
+        return a;
+    };
+    int4 rc_next = cnt > 0 ? inc_rec[beg] : int4{0, 0, 0, 0};
+    int4 rc_next2 = cnt > 1 ? inc_rec[beg + 64] : int4{0, 0, 0, 0};
+    double4 cn[4];
+    {
+        int nd[4];
+        node_ids(rc_next, nd);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cn[i] = cnt > 0 ? node4[nd[i]] : double4{0.0, 0.0, 0.0, 0.0};
+    }
+    for (int64_t t = beg; t < end; t += 64) {
+        const int4 rc = rc_next;
+        double x[4], y[4], z[4], ud[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = cn[i].x; y[i] = cn[i].y; z[i] = cn[i].z; ud[i] = cn[i].w; }
+        rc_next = rc_next2;
+        if (t + 64 < end) {
+            int nd[4];
+            node_ids(rc_next, nd);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cn[i] = node4[nd[i]];
+            if (t + 128 < end) rc_next2 = inc_rec[t + 128];
+        }
+        const uint32_t slots = static_cast<uint32_t>(rc.w);
+        const int a = static_cast<int>((static_cast<uint32_t>(rc.x) >> 31) | ((static_cast<uint32_t>(rc.y) >> 31) << 1));
+        bool fixed[4], any_fixed = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
             fixed[i] = ((slots >> (8 * i)) & 0xffu) == 0xffu;
             any_fixed |= fixed[i];
         }
