@@ -558,7 +558,7 @@ void emit_records(std::FILE *f, int64_t n, int max_rec, F fmt)
 #ifdef _OPENMP
     nt = std::max(1, omp_get_max_threads());
 #endif
-    const int64_t block = 4096;
+    const int64_t block = std::max<int64_t>(64, std::min<int64_t>(4096, (1 << 20) / max_rec));   // ~1 MiB per thread
     nt = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(nt, (n + block - 1) / block)));
     std::vector<std::vector<char>> bufs(static_cast<size_t>(nt));
     std::vector<size_t> used(static_cast<size_t>(nt), 0);
