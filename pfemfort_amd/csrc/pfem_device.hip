@@ -19,6 +19,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <deque>
 #include <vector>
 
 #include "pfem_internal.hpp"
@@ -180,6 +181,7 @@ struct pfem_solver {
     bool have_mesh = false;
     DevBuf<int32_t> d_conn, d_edof;
     DevBuf<double> d_xyz, d_soln;
+    int sort_end_bit = 64;         // radix-sort bits that matter in a (row << 32 | col) key (use_sort_bits)
     DevBuf<double4> d_node4;       // {x, y, z, solnApplied} per node for the Poisson-tet gather kernel (built with the incidence)
 
     // local numbering
@@ -731,6 +733,15 @@ int build_cols16(pfem_solver *s);
 int build_groups(pfem_solver *s);
 int build_rel_groups(pfem_solver *s);
 
+// significant bits of a (row << 32 | col) key of this solver's local numbering
+int use_sort_bits(pfem_solver *s)
+{
+    int bits = 1;
+    while ((1LL << bits) < std::max<int64_t>(s->n_loc, 2)) ++bits;
+    s->sort_end_bit = std::min(64, 32 + bits);
+    return PFEM_OK;
+}
+
 // keys: device array of `nkeys` (row<<32|col) keys, kNoKey = ignore.  Consumed.
 int pattern_from_keys(pfem_solver *s, DevBuf<uint64_t> &keys, int64_t nkeys)
 {
@@ -742,9 +753,8 @@ int pattern_from_keys(pfem_solver *s, DevBuf<uint64_t> &keys, int64_t nkeys)
     s->cg_graph_key.clear();               // every array a captured CG iteration points at is about to be replaced
     s->mgraph_key.clear();
     s->slices_fmt = -1;                    // ... and the boundary / interior slice lists belong to the old pattern
-    int bits = 1;
-    while ((1LL << bits) < std::max<int64_t>(n, 2)) ++bits;
-    const int end_bit = std::min(64, 32 + bits);
+    PFEM_TRY(use_sort_bits(s));
+    const int end_bit = s->sort_end_bit;
     DevBuf<uint64_t> sorted;
     DevBuf<int> d_num;
     DevBuf<char> temp;
@@ -945,13 +955,69 @@ extern "C" int pfem_pattern_build(pfem_solver *s)
     if (!s->have_mesh) return PFEM_ERR_STATE;
     PFEM_TRY(use_device(s));
     const MeshDev &m = s->mesh;
-    const int64_t nkeys = static_cast<int64_t>(m.nsize) * m.nsize * m.nElem;
+    const int64_t per_elem = static_cast<int64_t>(m.nsize) * m.nsize;
+    int64_t nkeys = per_elem * m.nElem;
     DevBuf<uint64_t> keys;
-    PFEM_TRY(keys.alloc(static_cast<size_t>(std::max<int64_t>(nkeys, 1))));
     PFEM_HIP(hipEventRecord(s->ev0, s->stream));
-    if (m.nElem > 0) {
-        hipLaunchKernelGGL(k_emit_keys, dim3(grid_for(m.nElem)), dim3(kBlock), 0, s->stream, m, keys.p);
-        PFEM_TRY(check_kernel("k_emit_keys"));
+    // test knob: elements per range (forces the ranged path on a small mesh)
+    const int64_t range_env = [] { const char *e = std::getenv("PFEM_DEBUG_PATTERN_RANGE"); return e ? std::atoll(e) : 0LL; }();
+    if (nkeys <= INT_MAX && range_env <= 0) {
+        PFEM_TRY(keys.alloc(static_cast<size_t>(std::max<int64_t>(nkeys, 1))));
+        if (m.nElem > 0) {
+            hipLaunchKernelGGL(k_emit_keys, dim3(grid_for(m.nElem)), dim3(kBlock), 0, s->stream, m, keys.p);
+            PFEM_TRY(check_kernel("k_emit_keys"));
+        }
+    } else {
+        // More element-matrix entries than one sort call can index (config 5 on ONE device: 6.1e9): the keys of one
+        // element range at a time are sorted and made unique, and the union of those lists -- a little more than
+        // the nonzeros -- goes through pattern_from_keys like the keys of a small mesh.
+        const int64_t range = range_env > 0 ? range_env : std::min<int64_t>(INT_MAX / per_elem, 1LL << 26);
+        PFEM_TRY(use_sort_bits(s));
+        std::deque<DevBuf<uint64_t>> parts;          // (not movable: a deque constructs in place and never relocates)
+        std::vector<int64_t> part_n;
+        DevBuf<uint64_t> raw, sorted;
+        DevBuf<int> d_num;
+        DevBuf<char> temp;
+        PFEM_TRY(raw.alloc(static_cast<size_t>(std::min(range, m.nElem) * per_elem)));
+        PFEM_TRY(sorted.alloc(raw.n));
+        PFEM_TRY(d_num.alloc(1));
+        int64_t total = 0;
+        for (int64_t e0 = 0; e0 < m.nElem; e0 += range) {
+            const int64_t ne = std::min(range, m.nElem - e0);
+            const int ni = static_cast<int>(ne * per_elem);
+            hipLaunchKernelGGL(k_emit_keys_range, dim3(grid_for(ne)), dim3(kBlock), 0, s->stream, m, e0, ne, raw.p);
+            PFEM_TRY(check_kernel("k_emit_keys_range"));
+            size_t tb = 0, tb2 = 0;
+            PFEM_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, raw.p, sorted.p, ni, 0, s->sort_end_bit, s->stream));
+            PFEM_HIP(hipcub::DeviceSelect::Unique(nullptr, tb2, sorted.p, raw.p, d_num.p, ni, s->stream));
+            if (std::max(tb, tb2) > temp.n) { PFEM_HIP(hipStreamSynchronize(s->stream)); PFEM_TRY(temp.alloc(std::max(tb, tb2))); }
+            PFEM_HIP(hipcub::DeviceRadixSort::SortKeys(temp.p, tb, raw.p, sorted.p, ni, 0, s->sort_end_bit, s->stream));
+            PFEM_HIP(hipcub::DeviceSelect::Unique(temp.p, tb2, sorted.p, raw.p, d_num.p, ni, s->stream));
+            int num = 0;
+            PFEM_HIP(hipMemcpyAsync(&num, d_num.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+            PFEM_HIP(hipStreamSynchronize(s->stream));
+            parts.emplace_back();
+            PFEM_TRY(parts.back().alloc(static_cast<size_t>(std::max(num, 1))));
+            PFEM_HIP(hipMemcpyAsync(parts.back().p, raw.p, sizeof(uint64_t) * static_cast<size_t>(num), hipMemcpyDeviceToDevice, s->stream));
+            part_n.push_back(num);
+            total += num;
+        }
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+        raw.release();
+        sorted.release();
+        temp.release();
+        if (total > INT_MAX) {
+            set_last_error("pfem_pattern_build: more than 2^31-1 distinct matrix entries on one device");
+            return PFEM_ERR_ARG;
+        }
+        PFEM_TRY(keys.alloc(static_cast<size_t>(std::max<int64_t>(total, 1))));
+        int64_t at = 0;
+        for (size_t c = 0; c < parts.size(); ++c) {
+            PFEM_HIP(hipMemcpyAsync(keys.p + at, parts[c].p, sizeof(uint64_t) * static_cast<size_t>(part_n[c]), hipMemcpyDeviceToDevice, s->stream));
+            at += part_n[c];
+        }
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+        nkeys = total;
     }
     PFEM_TRY(pattern_from_keys(s, keys, nkeys));
     PFEM_TRY(build_incidence(s));

@@ -99,6 +99,24 @@ __global__ void __launch_bounds__(kBlock) k_emit_keys(MeshDev m, uint64_t *keys)
         }
 }
 
+// the same for elements [e0, e0 + ne): meshes whose nsize^2 * nElem keys exceed what one sort call can index are
+// processed in element ranges (pfem_pattern_build)
+__global__ void __launch_bounds__(kBlock) k_emit_keys_range(MeshDev m, int64_t e0, int64_t ne, uint64_t *keys)
+{
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (t >= ne) return;
+    const int64_t e = e0 + t;
+    int32_t dof[12];
+    for (int i = 0; i < m.nsize; ++i) dof[i] = m.edof[i * m.nElem + e];
+    for (int i = 0; i < m.nsize; ++i)
+        for (int j = 0; j < m.nsize; ++j) {
+            const bool ok = dof[i] >= 0 && dof[j] >= 0;
+            keys[(static_cast<int64_t>(i) * m.nsize + j) * ne + t] =
+                ok ? (static_cast<uint64_t>(static_cast<uint32_t>(dof[i])) << 32) | static_cast<uint32_t>(dof[j])
+                   : kNoKey;
+        }
+}
+
 // rowptr from the sorted unique keys (rows without entries get empty ranges)
 __global__ void __launch_bounds__(kBlock) k_row_bounds(const uint64_t *keys, int64_t nnz, int64_t n_rows,
                                                         int64_t *rowptr)

@@ -625,3 +625,25 @@ def test_gather_kernel_variants_agree_bit_for_bit(monkeypatch):
     for name, (vals, rhs) in got.items():
         assert np.array_equal(vals.view(np.uint64), prob.vals.view(np.uint64)), name      # bits, zero signs included
         assert np.array_equal(rhs.view(np.uint64), prob.rhs.view(np.uint64)), name
+
+
+@pytest.mark.parametrize("name,per_range", [("tet10", 1000), ("tet10", 6000), ("beam", 37)])
+def test_pattern_built_in_element_ranges(name, per_range, request, monkeypatch):
+    """Meshes with more than 2^31-1 element-matrix entries per device (config 5 alone on one MI355X: 6.1e9) get their
+    pattern from element ranges, each sorted and made unique on its own (pfem_pattern_build).  Forced here on small
+    meshes: pattern, K and F equal the oracle's bit for bit, as on the one-pass path."""
+    monkeypatch.setenv("PFEM_DEBUG_PATTERN_RANGE", str(per_range))
+    mesh = request.getfixturevalue(name)
+    kind, ed = (pf.POISSON_TET, H.POISSON_ELEMDATA) if name == "tet10" else (pf.ELAST_TET, H.ELAST_ELEMDATA)
+    from pfemfort_amd import drivers as D
+    dm, conn_new, xyz_new, edof = D._setup(kind, mesh)
+    s = pf.PetscSolver().initialise(dm.size_global, dm.size_global)
+    s.uploadMesh(kind, conn_new, xyz_new, edof, dm.solnApplied)
+    s.buildPattern()
+    s.assemble(ed, H.TIMEDATA)
+    prob = O.setup_problem(kind, _omesh(mesh), elemData=ed)
+    rowptr, cols, vals = s.getCSR()
+    assert np.array_equal(rowptr, prob.rowptr) and np.array_equal(cols, prob.cols)
+    assert np.array_equal(vals, prob.vals) and np.array_equal(s.getRHS(), prob.rhs)
+    its, reason, _ = s.factoriseAndSolve()
+    assert reason == 2
