@@ -88,3 +88,18 @@ def test_config5_at_full_size_with_eight_ranks_sharing_the_device():
     c = d["comm"]
     assert c["bytes_per_neighbour"] == 8 * 399 ** 2 and c["neighbours"] == 1            # rank 0: one face
     assert "k_spmvr32" in d["roofline"]["kernel"]
+
+
+@pytest.mark.gpu
+def test_config5_at_full_size_alone_on_one_device():
+    """BASELINE configs[4] solved by ONE rank on one MI355X (288 GB): 63.5 M free dofs, 949 M nonzeros, 6.1e9
+    element-matrix entries -- more than one sort call indexes, so the pattern comes from element ranges.  Same problem
+    as the eight-rank test above: the same answer (nodal error of the %.8f boundary data), the same iteration count to
+    a few (one rank sums in a different order than eight), and the strong-scaling baseline of SURVEY 8(e)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cells", "400", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-parity-step"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    assert d["config"]["free_dofs"] == 63521199 and d["config"]["elements"] == 384000000 and d["n_gpus"] == 1
+    assert d["converged_reason"] == 2 and 700 < d["iterations"] < 740 and d["max_nodal_error"] < 1e-3
+    assert d["roofline"]["nnz"] == 949001947 and "k_spmvr32" in d["roofline"]["kernel"]
