@@ -21,7 +21,9 @@ N > 1 : weak scaling, one process per GPU, per-GPU element count fixed: the [-1,
         instead (200x200x200N cells of the same size).  Either way the Jacobi-PCG iteration count about
         doubles from N=1 to N=8 (a property of the preconditioner), which caps DOF/s scaling at ~0.5 N
         independently of the hardware; `iterations` and `ms_per_iteration` are reported so that
-        per-iteration scaling can be derived.
+        per-iteration scaling can be derived.  --strong keeps the whole problem at --cells per side instead
+        (--cells 400 --strong: BASELINE configs[4] on N ranks; alone on one GPU it takes 2.06 s per step,
+        profiles/r02/bench_cfg5_400cube_single_gpu.json).
 
 Prints ONE JSON line on rank 0 (contract in the task description), with `roofline` for the CG
 SpMV kernel (HIP events around sampled SpMV launches of the timed solves) and `cpu_baseline` (the C
@@ -121,6 +123,8 @@ def main():
     ap.add_argument("--workload", choices=["poisson", "beam"], default="poisson",
                     help="poisson: BASELINE configs[2] (the headline metric); beam: configs[3], the 50x300x50x6-tet "
                          "linear-elasticity cantilever (fixed size: strong scaling over z-slabs for N>1)")
+    ap.add_argument("--strong", action="store_true",
+                    help="N>1: keep the WHOLE problem at --cells per side (strong scaling; e.g. --cells 400 = BASELINE config 5 on N ranks)")
     ap.add_argument("--stack", action="store_true", help="N>1: z-extended box n x n x (n N) instead of the cube of n N^(1/3) cells per side")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-step", action="store_true", help="skip the extra (untimed) step at rtol 1e-10")
@@ -167,6 +171,8 @@ def main():
     if beam:      # SURVEY 8(d) cfg 4: [-.5,.5]x[0,6]x[-.5,.5], clamp y=0, body force (0.1f,0,0)
         nE = (50, 300, 50); ext = (-0.5, 0.5, 0.0, 6.0, -0.5, 0.5)
     elif world == 1:
+        nE = (n, n, n); ext = (-1.0, 1.0, -1.0, 1.0, -1.0, 1.0)
+    elif args.strong:
         nE = (n, n, n); ext = (-1.0, 1.0, -1.0, 1.0, -1.0, 1.0)
     elif not args.stack:
         side = round(n * world ** (1.0 / 3.0))
@@ -332,7 +338,7 @@ def main():
         out = {
             "metric": "DOF/s (assembly+CG-to-tol)", "value": N * args.steps / elapsed, "unit": "DOF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if beam else "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if (beam or args.strong) else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"tetraelasticityparallelimpl1: [-.5,.5]x[0,6]x[-.5,.5] beam, {nEx}x{nEy}x{nEz}x6 P1 tets, "
                                     "3 dofs/node, clamped at y=0, body force (0.1,0,0), E=240.565, nu=0.3 (REAL(4) literals)"

@@ -1,1 +1,1 @@
-cd "$GRAFT_REPO_ROOT"; timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "variants_agree" 2>&1 | tail -15
+cd "$GRAFT_REPO_ROOT"; timeout 900 python -m pytest tests/test_bench_contract.py -m gpu -x -q -k "alone_on_one_device" 2>&1 | tail -8
