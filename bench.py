@@ -264,6 +264,7 @@ def main():
         if_ms += tm["iface_ms_total"]; sc_ms += tm["scalar_ms_total"]; ex_ms += tm["exposed_ms_total"]; comm_n += tm["comm_samples"]
     sync()
     elapsed = time.perf_counter() - t0
+    mem = pf.device_memory(device_index)             # mesh, pattern, incidence, both SpMV forms, vectors: all resident
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -362,6 +363,8 @@ def main():
                                                               "symbolic_pattern_and_incidence_second_build": t_pattern2,
                                                               "hip_context_and_code_object_load_on_a_tiny_problem_not_in_setup": t_init},
             "parity_tolerance_step": parity,
+            "device_memory_gb": {"in_use_rank0_device": round((mem["total_bytes"] - mem["free_bytes"]) / 1e9, 2),
+                                 "total": round(mem["total_bytes"] / 1e9, 2)},
             # N > 1, rank 0, sampled with the SpMV: time on the communication stream of the exchanges of an iteration, and
             # how much of it the compute stream actually waited for
             "comm": ({"interface_exchange_ms": if_ms / comm_n, "scalar_allreduce_ms": sc_ms / comm_n,

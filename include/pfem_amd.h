@@ -73,6 +73,8 @@ const char *pfem_last_error_string(void);
 int pfem_device_count(int *n);
 int pfem_device_info(int device, char *name, int name_len, int *compute_units,
                      int64_t *hbm_bytes, int *clock_khz);
+/* free / total device memory right now (hipMemGetInfo): what a mesh of a given size leaves of the 288 GB             */
+int pfem_device_memory(int device, int64_t *free_bytes, int64_t *total_bytes);
 
 /* ========================================================================= */
 /* 1. per-element routines, host, one element per call.                       */

@@ -6,7 +6,7 @@ thin host-side mirror of the reference's Fortran interface.  No CPU fallback exi
 """
 from . import _lib, host  # noqa: F401
 from ._lib import (ELAST_TET, ELAST_TRIA, POISSON_TET, POISSON_TRIA, POISSON_TRIA_INLINE, PfemError,  # noqa: F401
-                   device_count, device_info)
+                   device_count, device_info, device_memory)
 from .drivers import (tetraelasticityparallelimpl1, tetrapoissonparallelimpl1,  # noqa: F401
                       triaelasticityparallelimpl1, triapoissonparallelimpl1, triapoissonserialimpl1)
 from .solver import PetscSolver  # noqa: F401

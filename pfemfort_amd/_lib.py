@@ -60,6 +60,7 @@ SIGNATURES = {
     "pfem_last_error_string": [],
     "pfem_device_count": [_P],
     "pfem_device_info": [_I, _P, _I, _P, _P, _P],
+    "pfem_device_memory": [_I, _P, _P],
     "pfem_poisson_tria_ke": [_P] * 7,
     "pfem_poisson_tet_ke": [_P] * 8,
     "pfem_elast_tet_ke": [_P] * 8,
@@ -163,6 +164,13 @@ def device_count() -> int:
     n = C.c_int(0)
     check(lib().pfem_device_count(C.byref(n)), "pfem_device_count")
     return n.value
+
+
+def device_memory(device: int = 0) -> dict:
+    """Free and total device memory in bytes (hipMemGetInfo)."""
+    f = C.c_int64(0); t = C.c_int64(0)
+    check(lib().pfem_device_memory(device, C.byref(f), C.byref(t)), "pfem_device_memory")
+    return {"free_bytes": f.value, "total_bytes": t.value}
 
 
 def device_info(device: int = 0) -> dict:

@@ -99,6 +99,24 @@ extern "C" int pfem_device_info(int device, char *name, int name_len, int *compu
     return PFEM_OK;
 }
 
+extern "C" int pfem_device_memory(int device, int64_t *free_bytes, int64_t *total_bytes)
+{
+    int c = 0;
+    pfem_device_count(&c);
+    if (c == 0) return PFEM_ERR_NOGPU;
+    if (device < 0 || device >= c) return PFEM_ERR_ARG;
+    int prev = 0;
+    PFEM_HIP(hipGetDevice(&prev));
+    PFEM_HIP(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    const hipError_t e = hipMemGetInfo(&f, &t);
+    (void)hipSetDevice(prev);
+    PFEM_HIP(e);
+    if (free_bytes) *free_bytes = static_cast<int64_t>(f);
+    if (total_bytes) *total_bytes = static_cast<int64_t>(t);
+    return PFEM_OK;
+}
+
 // ---------------------------------------------------------------------------
 // device buffers
 // ---------------------------------------------------------------------------
