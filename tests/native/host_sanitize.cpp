@@ -192,6 +192,32 @@ int main(int argc, char **argv)
         assert(pfem_write_vtk(p.c_str(), 3, nElem, nNode, 4, 3, xyz.data(), conn.data(), pid.data(), sol.data()) == 0);
         assert(pfem_write_vtk("/nonexistent-dir/x.vtk", 3, nElem, nNode, 4, 1, xyz.data(), conn.data(), pid.data(), sol.data()) == PFEM_ERR_ARG);
         std::remove(p.c_str());
+        // wide and non-finite values take the snprintf path of the F12.6 formatter
+        std::vector<double> odd(nNode, 0.0);
+        for (int64_t i = 0; i < nNode; ++i) odd[i] = (i % 5 == 0) ? 1e300 : ((i % 5 == 1) ? -123456.789 : ((i % 5 == 2) ? std::nan("") : 0.4999995));
+        assert(pfem_write_vtk(p.c_str(), 3, nElem, nNode, 4, 1, xyz.data(), conn.data(), pid.data(), odd.data()) == 0);
+        std::remove(p.c_str());
+        // temp.dat: both record forms, empty input, argument errors
+        std::vector<int64_t> ii(nNode), ind(nNode);
+        for (int64_t i = 0; i < nNode; ++i) { ii[i] = i + 1; ind[i] = nNode - i; }
+        const std::string t = tmp + "/temp.dat";
+        assert(pfem_write_temp_dat(t.c_str(), nNode, ii.data(), ind.data(), odd.data()) == 0);
+        assert(pfem_write_temp_dat(t.c_str(), nNode, nullptr, nullptr, odd.data()) == 0);
+        assert(pfem_write_temp_dat(t.c_str(), 0, nullptr, nullptr, nullptr) == 0);
+        assert(pfem_write_temp_dat(t.c_str(), nNode, ii.data(), nullptr, odd.data()) == PFEM_ERR_ARG);
+        assert(pfem_write_temp_dat("/nonexistent-dir/t.dat", 1, nullptr, nullptr, odd.data()) == PFEM_ERR_ARG);
+        std::remove(t.c_str());
+    }
+    {   // recursive coordinate bisection: more parts than elements, one part, 2-D input, bad connectivity
+        std::vector<int32_t> ep(nElem), np(nNode);
+        for (int parts : {1, 2, 3, 7, 64})
+            assert(pfem_partition_rcb(nNode, 3, xyz.data(), nElem, 4, conn.data(), parts, ep.data(), np.data()) == 0);
+        assert(pfem_partition_rcb(nNode, 2, xyz.data(), nElem, 4, conn.data(), 3, ep.data(), np.data()) == 0);
+        std::vector<int32_t> bad(conn);
+        bad[5] = static_cast<int32_t>(nNode);
+        assert(pfem_partition_rcb(nNode, 3, xyz.data(), nElem, 4, bad.data(), 3, ep.data(), np.data()) == PFEM_ERR_ARG);
+        assert(pfem_partition_rcb(nNode, 3, xyz.data(), 0, 4, nullptr, 3, ep.data(), np.data()) == 0);
+        assert(pfem_partition_rcb(nNode, 4, xyz.data(), nElem, 4, conn.data(), 3, ep.data(), np.data()) == PFEM_ERR_ARG);
     }
     std::puts("host_sanitize: ok");
     return 0;
