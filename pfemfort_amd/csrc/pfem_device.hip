@@ -2681,6 +2681,9 @@ int run_pcg_single(pfem_solver *s)
         PFEM_HIP(hipMemsetAsync(s->d_zg.store.p, 0, (static_cast<size_t>(n) + 2 * kVecGuard) * sizeof(double), s->stream));
         s->d_zg.p = s->d_zg.store.p + kVecGuard;
     }
+    // the guard bands around THIS solve's n rows (the buffer may be longer than a new, smaller local system needs)
+    PFEM_HIP(hipMemsetAsync(s->d_zg.store.p, 0, kVecGuard * sizeof(double), s->stream));
+    PFEM_HIP(hipMemsetAsync(s->d_zg.p + n, 0, kVecGuard * sizeof(double), s->stream));
     if (s->d_sv.n < static_cast<size_t>(std::max<int64_t>(n, 1))) PFEM_TRY(s->d_sv.alloc(static_cast<size_t>(std::max<int64_t>(n, 1))));
     double *part_pw = s->d_part_pw.p, *scal_pw = s->d_part.p + 2 * kMaxGrid, *sbuf = s->d_sbuf.p;
     double *prz[2] = {s->d_part1.p, s->d_part1.p + 2 * kMaxGrid}, *pzz[2] = {s->d_part1.p + kMaxGrid, s->d_part1.p + 3 * kMaxGrid};
