@@ -331,7 +331,9 @@ def main():
                      "node share one lane, 16-bit column gaps), rank 0",
                   4: ("pfem::k_spmvr32<true>" if solver.spmvColumnBits() == 32 else "pfem::k_spmvr<true>") +
                      " (wave-sliced CSR SpMV + (p,Ap) partials; 4 consecutive rows per lane share one relative column stream of "
-                     f"{solver.spmvColumnBits()}-bit gaps, x read as 32-B quads), rank 0"}.get(
+                     f"{solver.spmvColumnBits()}-bit gaps" +
+                     (f" with a table of the {solver.spmvGapTable()} distinct gaps beyond 32767" if solver.spmvGapTable() else "") +
+                     ", x read as 32-B quads), rank 0"}.get(
             solver.spmvRowGroup(),
             ("pfem::k_spmv16<true>" if solver.spmvColumnBits() == 16 else "pfem::k_spmv<true>") +
             " (wave-sliced CSR SpMV + (p,Ap) partials; %d-bit column %s), rank 0"

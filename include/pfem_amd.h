@@ -282,6 +282,10 @@ int pfem_solver_set_spmv_format(pfem_solver *s, int format);
 int pfem_solver_get_spmv_format(pfem_solver *s, int *bits_per_column);
 /* rows served by one lane of the current SpMV: 3 in the row-grouped form, else 1 */
 int pfem_solver_get_spmv_row_group(pfem_solver *s, int *rows_per_lane);
+/* Relative row groups whose pattern has gaps beyond 65535 (planes of more than 65 535 nodes): number of entries of the
+ * table of distinct large gaps when the 16-bit DICTIONARY form is in use (codes >= 0x8000 index the table; at most
+ * 256 distinct gaps of 32768 and more), 0 otherwise (literal 16-bit gaps, 32-bit gaps, or another form).            */
+int pfem_solver_get_spmv_gap_table(pfem_solver *s, int *entries);
 /* bytes one launch of the selected SpMV form moves at best: its own storage (values, gap words / columns, offsets)
  * + x + y, each touched once.  (The judged figure 12 nnz + 20 N of SURVEY 8d is the plain int32-CSR equivalent.)   */
 int pfem_solver_spmv_bytes(pfem_solver *s, int64_t *format_bytes);

@@ -252,6 +252,8 @@ struct pfem_solver {
     // SpMV-only relative row groups (k_spmvr): 4 consecutive rows, one relative column stream
     bool relgrouped = false;
     bool rel_gap32 = false;        // ... with one 32-bit gap per entry (offsets further apart than 65535: k_spmvr32)
+    bool rel_dict = false;         // ... or 16-bit codes with a table of the few distinct large gaps (k_spmvr<., true>)
+    DevBuf<uint32_t> d_gap_table;
     int64_t n_rgroups = 0, n_rslices = 0, r_stored = 0;
     DevBuf<int32_t> d_rcol0;
     DevBuf<int64_t> d_rslice_off, d_rslice_doff;
@@ -272,6 +274,7 @@ struct pfem_solver {
         G.col0 = d_rcol0.p;
         G.dwords = d_rdwords.p;
         G.gslice_doff = d_rslice_doff.p;
+        G.gap_table = d_gap_table.p;
         return G;
     }
     SellGDev sellg() const
@@ -1442,6 +1445,7 @@ int build_rel_groups(pfem_solver *s)
 {
     s->relgrouped = false;
     s->rel_gap32 = false;
+    s->rel_dict = false;
     const int64_t n = s->n_loc;
     if (s->grouped || n < kRelRows || n > INT_MAX - kRelRows) return PFEM_OK;
     s->n_rgroups = (n + kRelRows - 1) / kRelRows;
@@ -1459,7 +1463,21 @@ int build_rel_groups(pfem_solver *s)
     int overflow = 0;            // bit 0: a gap needs more than 16 bits; bit 1: a first column outside int32
     PFEM_TRY(fetch_err(s, &overflow));
     PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
-    const bool gap32 = (overflow & 1) != 0;
+    bool gap32 = (overflow & 1) != 0;
+    bool dict = false;
+    if (gap32 && !std::getenv("PFEM_DEBUG_REL_GAP32")) {
+        // gaps beyond 65535: if the large gaps take few distinct values (every regularly numbered mesh), keep 16-bit
+        // codes and a table of those values instead of one 32-bit gap per entry
+        PFEM_TRY(s->d_gap_table.alloc(kGapTable));
+        PFEM_HIP(hipMemsetAsync(s->d_gap_table.p, 0, kGapTable * sizeof(uint32_t), s->stream));
+        hipLaunchKernelGGL(k_rel_gap_table, dim3(grid_for(s->n_rgroups)), dim3(kBlock), 0, s->stream, s->sell(), s->n_rgroups,
+                           s->d_gap_table.p, s->d_err.p);
+        PFEM_TRY(check_kernel("k_rel_gap_table"));
+        int tbl_overflow = 0;
+        PFEM_TRY(fetch_err(s, &tbl_overflow));
+        PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
+        if (!(tbl_overflow & 4)) { dict = true; gap32 = false; }
+    }
     const int nsl = static_cast<int>(s->n_rslices + 1);
     size_t tb = 0;
     PFEM_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, entries.p, s->d_rslice_off.p, nsl, s->stream));
@@ -1491,18 +1509,20 @@ int build_rel_groups(pfem_solver *s)
     s->r_gap_words = tot_w;
     PFEM_TRY(s->d_rdwords.alloc(static_cast<size_t>(std::max<int64_t>(tot_w, 1))));
     PFEM_TRY(s->d_rvals.alloc(static_cast<size_t>(std::max<int64_t>(tot_e, 1)) * kRelRows));
-    if (gap32)
-        hipLaunchKernelGGL(k_rel_cols_fill<true>, dim3(grid_for(s->n_rslices * 64)), dim3(kBlock), 0, s->stream, s->sell(), s->n_rgroups,
-                           s->n_rslices, static_cast<const int64_t *>(s->d_rslice_off.p),
-                           static_cast<const int64_t *>(s->d_rslice_doff.p), s->d_rcol0.p, s->d_rdwords.p);
-    else
-        hipLaunchKernelGGL(k_rel_cols_fill<false>, dim3(grid_for(s->n_rslices * 64)), dim3(kBlock), 0, s->stream, s->sell(), s->n_rgroups,
-                           s->n_rslices, static_cast<const int64_t *>(s->d_rslice_off.p),
-                           static_cast<const int64_t *>(s->d_rslice_doff.p), s->d_rcol0.p, s->d_rdwords.p);
+#define PFEM_REL_FILL(MODE)                                                                                                       \
+    hipLaunchKernelGGL(k_rel_cols_fill<MODE>, dim3(grid_for(s->n_rslices * 64)), dim3(kBlock), 0, s->stream, s->sell(), s->n_rgroups, \
+                       s->n_rslices, static_cast<const int64_t *>(s->d_rslice_off.p),                                             \
+                       static_cast<const int64_t *>(s->d_rslice_doff.p), s->d_rcol0.p, s->d_rdwords.p,                            \
+                       static_cast<const uint32_t *>(s->d_gap_table.p))
+    if (gap32) PFEM_REL_FILL(kGap32);
+    else if (dict) PFEM_REL_FILL(kGapDict16);
+    else PFEM_REL_FILL(kGapLit16);
+#undef PFEM_REL_FILL
     PFEM_TRY(check_kernel("k_rel_cols_fill"));
     PFEM_HIP(hipStreamSynchronize(s->stream));
     s->relgrouped = true;
     s->rel_gap32 = gap32;
+    s->rel_dict = dict;
     return PFEM_OK;
 }
 
@@ -1510,12 +1530,10 @@ int build_rel_groups(pfem_solver *s)
 int refresh_group_vals(pfem_solver *s)
 {
     if (s->use_rel() && s->group_vals_stale) {
-        if (s->rel_gap32)
-            hipLaunchKernelGGL(k_rel_vals<true>, dim3(static_cast<unsigned>(s->n_rslices)), dim3(kBlock), 0, s->stream, s->sell(), s->sellr(),
-                               s->d_rvals.p);
-        else
-            hipLaunchKernelGGL(k_rel_vals<false>, dim3(static_cast<unsigned>(s->n_rslices)), dim3(kBlock), 0, s->stream, s->sell(), s->sellr(),
-                               s->d_rvals.p);
+        const dim3 vg(static_cast<unsigned>(s->n_rslices));
+        if (s->rel_gap32) hipLaunchKernelGGL(k_rel_vals<kGap32>, vg, dim3(kBlock), 0, s->stream, s->sell(), s->sellr(), s->d_rvals.p);
+        else if (s->rel_dict) hipLaunchKernelGGL(k_rel_vals<kGapDict16>, vg, dim3(kBlock), 0, s->stream, s->sell(), s->sellr(), s->d_rvals.p);
+        else hipLaunchKernelGGL(k_rel_vals<kGapLit16>, vg, dim3(kBlock), 0, s->stream, s->sell(), s->sellr(), s->d_rvals.p);
         PFEM_TRY(check_kernel("k_rel_vals"));
         s->group_vals_stale = false;
         return PFEM_OK;
@@ -1551,8 +1569,11 @@ void launch_spmv(pfem_solver *s, const double *x, double *y, int64_t n_dot, doub
         if (s->rel_gap32) {
             if (e0) hipExtLaunchKernelGGL(k_spmvr32<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
             else hipLaunchKernelGGL(k_spmvr32<WITH_DOT>, grid, block, 0, s->stream, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
-        } else if (e0) hipExtLaunchKernelGGL(k_spmvr<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
-        else hipLaunchKernelGGL(k_spmvr<WITH_DOT>, grid, block, 0, s->stream, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
+        } else if (s->rel_dict) {
+            if (e0) hipExtLaunchKernelGGL((k_spmvr<WITH_DOT, true>), grid, block, 0, s->stream, e0, e1, 0, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
+            else hipLaunchKernelGGL((k_spmvr<WITH_DOT, true>), grid, block, 0, s->stream, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
+        } else if (e0) hipExtLaunchKernelGGL((k_spmvr<WITH_DOT, false>), grid, block, 0, s->stream, e0, e1, 0, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
+        else hipLaunchKernelGGL((k_spmvr<WITH_DOT, false>), grid, block, 0, s->stream, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
     } else if (s->cols16 && s->spmv_format != PFEM_SPMV_INT32) {
         Sell16Dev C{s->d_col0.p, s->d_dwords.p, s->d_slice_doff.p};
         if (e0) hipExtLaunchKernelGGL(k_spmv16<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, A, C, x, y, n_dot, partial, ctl, sel);
@@ -1570,6 +1591,20 @@ extern "C" int pfem_solver_get_spmv_format(pfem_solver *s, int *bits_per_column)
     if (!s || !bits_per_column) return PFEM_ERR_ARG;
     if (s->use_rel()) *bits_per_column = s->rel_gap32 ? 32 : 16;
     else *bits_per_column = (s->cols16 && s->spmv_format != PFEM_SPMV_INT32) ? 16 : 32;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_get_spmv_gap_table(pfem_solver *s, int *entries)
+{
+    if (!s || !entries) return PFEM_ERR_ARG;
+    if (!s->have_pattern) return PFEM_ERR_STATE;
+    *entries = 0;
+    if (s->use_rel() && s->rel_dict) {
+        PFEM_TRY(use_device(s));
+        std::vector<uint32_t> t(kGapTable);
+        PFEM_HIP(hipMemcpy(t.data(), s->d_gap_table.p, sizeof(uint32_t) * kGapTable, hipMemcpyDeviceToHost));
+        for (uint32_t v : t) *entries += v != 0u;
+    }
     return PFEM_OK;
 }
 
@@ -2068,7 +2103,7 @@ int scalar_allreduce(pfem_solver *s, int at, int n)
 // which SpMV form the next launch uses (key of the slice lists and of the captured graph)
 inline int spmv_form(const pfem_solver *s)
 {
-    return s->use_grouped() ? 3 : (s->use_rel() ? (s->rel_gap32 ? 5 : 4) : ((s->cols16 && s->spmv_format != PFEM_SPMV_INT32) ? 2 : 1));
+    return s->use_grouped() ? 3 : (s->use_rel() ? (s->rel_gap32 ? 5 : (s->rel_dict ? 6 : 4)) : ((s->cols16 && s->spmv_format != PFEM_SPMV_INT32) ? 2 : 1));
 }
 
 // boundary / interior slice lists of the SpMV form in use
@@ -2085,7 +2120,7 @@ int build_slice_lists(pfem_solver *s)
         PFEM_HIP(hipMemsetAsync(d_flag.p, 0, static_cast<size_t>(ns), s->stream));
         const int32_t *rg = nullptr;
         int shift = 6;                                  // 64 rows per slice
-        if (fmt == 4 || fmt == 5) shift = 8;            // 64 groups of kRelRows = 4 consecutive rows
+        if (fmt >= 4) shift = 8;                        // 64 groups of kRelRows = 4 consecutive rows
         if (fmt == 3) {                                 // 64 groups of up to 3 rows: look the group up
             PFEM_TRY(d_row_group.alloc(static_cast<size_t>(s->n_loc)));
             hipLaunchKernelGGL(k_row_group_index, dim3(grid_for(s->n_groups)), dim3(kBlock), 0, s->stream,

@@ -1865,7 +1865,35 @@ struct SellRDev {
     const int32_t *col0;         // [64 * n_gslices] c_0 = r0 + (smallest relative offset); may be < 0
     const uint32_t *dwords;      // packed 16-bit gaps between the ascending relative offsets
     const int64_t *gslice_doff;
+    const uint32_t *gap_table;   // dictionary form: a 16-bit code >= 0x8000 stands for gap_table[code & 0x7fff]
 };
+
+// Dictionary form of the 16-bit gap stream, for patterns with gaps beyond 65535 (planes of more than 65 535 nodes: a
+// slab of config 5) that have FEW DISTINCT large gaps -- any regularly numbered mesh has a handful: gaps below 32768
+// are stored as they are, every other gap as 0x8000 | its index in a per-matrix table of at most kGapTable values.
+// 8 + 1/2 B per nonzero like the literal 16-bit form (the 32-bit form costs 8 + 1); more distinct gaps: 32-bit form.
+constexpr int kGapTable = 256;
+enum RelGapMode { kGapLit16 = 0, kGap32 = 1, kGapDict16 = 2 };
+
+__device__ inline void gap_table_insert(uint32_t *tbl, uint32_t gap, int *overflow)
+{
+    for (int i = 0; i < kGapTable; ++i) {
+        const uint32_t cur = __hip_atomic_load(&tbl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == gap) return;
+        if (cur == 0u) {
+            const uint32_t old = atomicCAS(&tbl[i], 0u, gap);
+            if (old == 0u || old == gap) return;
+        }
+    }
+    atomicOr(overflow, 4);       // more distinct large gaps than the table holds
+}
+__device__ inline uint32_t gap_table_code(const uint32_t *tbl, uint32_t gap)
+{
+    if (gap < 0x8000u) return gap;
+    for (int i = 0; i < kGapTable; ++i)
+        if (tbl[i] == gap) return 0x8000u | static_cast<uint32_t>(i);
+    return 0u;                   // not reached: every large gap was inserted by k_rel_gap_table
+}
 
 // Walks the union of the relative column lists of rows r0 .. r0+nr-1 in ascending order and calls
 // f(k, offset).  Returns the union size.
@@ -1927,11 +1955,29 @@ __global__ void __launch_bounds__(kBlock) k_rel_sizes(SellDev A, int64_t n_group
     if (g == 0) entries[n_gslices] = 0;
 }
 
-template <bool GAP32>
+// second walk, only for patterns with a gap beyond 65535: the distinct gaps of 32768 and more
+__global__ void __launch_bounds__(kBlock) k_rel_gap_table(SellDev A, int64_t n_groups, uint32_t *tbl, int *overflow)
+{
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (g >= n_groups) return;
+    const int64_t r0 = g * kRelRows;
+    const int nr = static_cast<int>(min(static_cast<int64_t>(kRelRows), A.n_rows - r0));
+    int64_t prev = 0;
+    rel_union_walk(A, r0, nr, [&](int k, int64_t o) {
+        if (k > 0 && o - prev >= 0x8000) {
+            if (o - prev > 0xffffffffLL) atomicOr(overflow, 4);
+            else gap_table_insert(tbl, static_cast<uint32_t>(o - prev), overflow);
+        }
+        prev = o;
+    });
+}
+
+template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_rel_cols_fill(SellDev A, int64_t n_groups, int64_t n_gslices,
                                                            const int64_t *gslice_off, const int64_t *gslice_doff, int32_t *col0,
-                                                           uint32_t *dwords)
+                                                           uint32_t *dwords, const uint32_t *gap_table)
 {
+    constexpr bool GAP32 = MODE == kGap32;
     const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     const int64_t gs = g >> 6;
     if (gs >= n_gslices) return;
@@ -1950,7 +1996,9 @@ __global__ void __launch_bounds__(kBlock) k_rel_cols_fill(SellDev A, int64_t n_g
         else if (GAP32) wp[64LL * (k - 1)] = static_cast<uint32_t>(o - prev);
         else {
             const int j = (k - 1) >> 1, h = (k - 1) & 1;
-            wp[64LL * j] |= (static_cast<uint32_t>(o - prev) & 0xffffu) << (16 * h);
+            const uint32_t code = MODE == kGapDict16 ? gap_table_code(gap_table, static_cast<uint32_t>(o - prev))
+                                                     : static_cast<uint32_t>(o - prev);
+            wp[64LL * j] |= (code & 0xffffu) << (16 * h);
         }
         prev = o;
     });
@@ -1959,9 +2007,10 @@ __global__ void __launch_bounds__(kBlock) k_rel_cols_fill(SellDev A, int64_t n_g
 // matrix values, row form -> relative-group form (explicit zeros where a row lacks an offset); once per solve.
 // One 256-thread block per slice of 64 groups; wave p converts row r0+p of every group, so its stores are 512-B
 // runs and the four waves of the block share the row-form lines they read.
-template <bool GAP32>
+template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_rel_vals(SellDev A, SellRDev G, double *out)
 {
+    constexpr bool GAP32 = MODE == kGap32;
     static_assert(kBlock == 64 * kRelRows, "one wave per row of the group");
     const int64_t gs = blockIdx.x;
     if (gs >= G.n_gslices) return;
@@ -1982,7 +2031,8 @@ __global__ void __launch_bounds__(kBlock) k_rel_vals(SellDev A, SellRDev G, doub
             if (GAP32) c += wp[64LL * (k - 1)];
             else {
                 const uint32_t w = wp[64LL * ((k - 1) >> 1)];
-                c += ((k - 1) & 1) ? (w >> 16) : (w & 0xffffu);
+                const uint32_t code = ((k - 1) & 1) ? (w >> 16) : (w & 0xffffu);
+                c += (MODE == kGapDict16 && (code & 0x8000u)) ? G.gap_table[code & (kGapTable - 1)] : code;
             }
         }
         double v = 0.0;
@@ -2002,13 +2052,23 @@ __device__ __forceinline__ void load_x4(const double *__restrict__ x, int c, dou
     xv[0] = a.x; xv[1] = a.y; xv[2] = b.x; xv[3] = b.y;
 }
 
-template <bool WITH_DOT>
+template <bool WITH_DOT, bool DICT = false>
 __global__ void __launch_bounds__(kBlock) k_spmvr(SellRDev G, int64_t n_rows, const double *__restrict__ x,
                                                    double *__restrict__ y, int64_t n_dot, double *partial, const CgCtl *ctl,
                                                    SliceSel sel)
 {
     __shared__ double sm[4];
+    __shared__ uint32_t gap_tbl[DICT ? kGapTable : 1];
     if (WITH_DOT && ctl->flag != 0) return;
+    if (DICT) {
+        static_assert(kGapTable == kBlock, "one table entry per thread");
+        gap_tbl[DICT ? threadIdx.x : 0] = G.gap_table[threadIdx.x];
+        __syncthreads();
+    }
+    // a 16-bit code of the gap stream -> the gap (dictionary form: codes with the top bit set index the table)
+    const auto gap_of = [&](uint32_t code) -> int {
+        return (DICT && (code & 0x8000u)) ? static_cast<int>(gap_tbl[DICT ? (code & (kGapTable - 1)) : 0]) : static_cast<int>(code);
+    };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t gs = pick_slice(sel, (static_cast<int64_t>(blockIdx.x) << 2) + wave, G.n_gslices);
     double dot = 0.0;
@@ -2033,8 +2093,8 @@ __global__ void __launch_bounds__(kBlock) k_spmvr(SellRDev G, int64_t n_rows, co
         uint32_t w0 = 0, w1 = 0;
         if (2 * (j + 2) < width) { w0 = __builtin_nontemporal_load(wp + 64 * j); w1 = __builtin_nontemporal_load(wp + 64 * (j + 1)); }
         while (2 * (j + 2) < width) {
-            const int c0 = c + static_cast<int>(w0 & 0xffffu), c1 = c0 + static_cast<int>(w0 >> 16);
-            const int c2 = c1 + static_cast<int>(w1 & 0xffffu), c3 = c2 + static_cast<int>(w1 >> 16);
+            const int c0 = c + gap_of(w0 & 0xffffu), c1 = c0 + gap_of(w0 >> 16);
+            const int c2 = c1 + gap_of(w1 & 0xffffu), c3 = c2 + gap_of(w1 >> 16);
             double v[4][kRelRows], xv[4][kRelRows];
             load_x4(x, c0, xv[0]); load_x4(x, c1, xv[1]); load_x4(x, c2, xv[2]); load_x4(x, c3, xv[3]);
 #pragma unroll
@@ -2052,8 +2112,8 @@ __global__ void __launch_bounds__(kBlock) k_spmvr(SellRDev G, int64_t n_rows, co
         }
         for (; j < nw; ++j) {
             const uint32_t w0 = __builtin_nontemporal_load(wp + 64 * j);
-            const int c0 = c + static_cast<int>(w0 & 0xffffu);
-            const int c1 = c0 + static_cast<int>(w0 >> 16);
+            const int c0 = c + gap_of(w0 & 0xffffu);
+            const int c1 = c0 + gap_of(w0 >> 16);
             double xv[kRelRows];
             load_x4(x, c0, xv);
 #pragma unroll

@@ -195,6 +195,12 @@ class PetscSolver:
         L.check(L.lib().pfem_solver_get_spmv_format(self._h, C.byref(b)), "pfem_solver_get_spmv_format")
         return b.value
 
+    def spmvGapTable(self):
+        """Entries of the table of distinct large gaps (dictionary form of the relative row groups), 0 otherwise."""
+        b = C.c_int(0)
+        L.check(L.lib().pfem_solver_get_spmv_gap_table(self._h, C.byref(b)), "pfem_solver_get_spmv_gap_table")
+        return b.value
+
     def setPreconditioner(self, pc):
         """"jacobi" (default; PCJACOBI) or "pbjacobi" (node-block Jacobi, PETSc's -pc_type pbjacobi)."""
         L.check(L.lib().pfem_solver_set_preconditioner(self._h, {"jacobi": 0, "pbjacobi": 1}[pc]), "pfem_solver_set_preconditioner")

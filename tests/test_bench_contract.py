@@ -72,7 +72,7 @@ def test_config5_at_full_size_with_eight_ranks_sharing_the_device():
     """BASELINE configs[4] -- the 400x400x400x6 cube (384 M tets, 63.5 M free dofs) on 8 ranks -- functionally and at full
     size on the one GPU a test box has: eight processes share the MI355X (8 GB each), exchange through gloo host hooks, and
     solve the whole problem.  Not a performance figure; it pins the per-rank device generator, the neighbour plan
-    (one or two faces of 399^2 dofs), the 32-bit-gap relative-row-group SpMV that slabs of this size need, and the
+    (one or two faces of 399^2 dofs), the relative-row-group SpMV with a table of the large gaps that slabs of this size need, and the
     multi-rank loop at the size the scaling run uses."""
     import socket
     with socket.socket() as so:
@@ -87,7 +87,7 @@ def test_config5_at_full_size_with_eight_ranks_sharing_the_device():
     assert d["converged_reason"] == 2 and 600 < d["iterations"] < 800 and d["max_nodal_error"] < 1e-3
     c = d["comm"]
     assert c["bytes_per_neighbour"] == 8 * 399 ** 2 and c["neighbours"] == 1            # rank 0: one face
-    assert "k_spmvr32" in d["roofline"]["kernel"]
+    assert "k_spmvr<true>" in d["roofline"]["kernel"] and "table of the" in d["roofline"]["kernel"]    # dictionary form
 
 
 @pytest.mark.gpu
@@ -102,4 +102,4 @@ def test_config5_at_full_size_alone_on_one_device():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1])
     assert d["config"]["free_dofs"] == 63521199 and d["config"]["elements"] == 384000000 and d["n_gpus"] == 1
     assert d["converged_reason"] == 2 and 700 < d["iterations"] < 740 and d["max_nodal_error"] < 1e-3
-    assert d["roofline"]["nnz"] == 949001947 and "k_spmvr32" in d["roofline"]["kernel"]
+    assert d["roofline"]["nnz"] == 949001947 and "table of the" in d["roofline"]["kernel"]

@@ -514,10 +514,15 @@ def test_device_generated_box_equals_host_generator_and_bookkeeping(kind, box, b
         assert np.array_equal(a.getRHS(), b.getRHS())
 
 
-def test_relative_row_groups_with_32bit_gaps():
+@pytest.mark.parametrize("form", ["dictionary", "gap32"])
+def test_relative_row_groups_beyond_16bit_gaps(form, monkeypatch):
     """A plane of more than 65 535 free nodes (here 257^2; BASELINE config 5's slabs have 399^2): the z-neighbour is further
-    away than a 16-bit gap can say.  The relative-row-group SpMV then streams one 32-bit gap per entry (k_spmvr32) instead
-    of falling back to int32 columns per row: same products, same order, same bits; and the solve agrees with the oracle."""
+    away than a 16-bit gap can say.  The relative-row-group SpMV keeps 16-bit codes with a table of the few distinct
+    large gaps (k_spmvr<., true>) or -- forced here, and whenever the table overflows -- streams one 32-bit gap per entry
+    (k_spmvr32) instead of falling back to int32 columns per row: same products, same order, same bits; and the solve
+    agrees with the oracle."""
+    if form == "gap32":
+        monkeypatch.setenv("PFEM_DEBUG_REL_GAP32", "1")
     mesh = H.gen_box_tets(-1, 1, 258, -1, 1, 258, -1, 1, 4)
     s, dm = _device_problem(pf.POISSON_TET, mesh, H.POISSON_ELEMDATA)
     rng = np.random.default_rng(11)
@@ -526,15 +531,47 @@ def test_relative_row_groups_with_32bit_gaps():
     y32 = s.spmv(x)
     assert (s.spmvRowGroup(), s.spmvColumnBits()) == (1, 32)
     s.setSpmvFormat("grouped")                                   # the group forms whatever the size
-    assert (s.spmvRowGroup(), s.spmvColumnBits()) == (4, 32)      # relative groups, 32-bit gap stream
+    assert (s.spmvRowGroup(), s.spmvColumnBits()) == (4, 16 if form == "dictionary" else 32)
+    assert (1 <= s.spmvGapTable() <= 16) if form == "dictionary" else s.spmvGapTable() == 0    # a handful of plane-sized gaps
     assert np.array_equal(s.spmv(x), y32)
-    assert s.spmvFormatBytes() < 0.8 * (12 * s.matrixInfo()["nnz"] + 20 * dm.size_global)
+    nnz = s.matrixInfo()["nnz"]
+    assert s.spmvFormatBytes() < (0.76 if form == "dictionary" else 0.8) * (12 * nnz + 20 * dm.size_global)
     s.setTolerances(rtol=1e-10)
     its, reason, _ = s.factoriseAndSolve()
     prob = O.setup_problem(O.POISSON_TET, _omesh(mesh))
     xo, its_o, reason_o, *_ = O.pcg_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-10)
     assert reason == reason_o == 2 and abs(its - its_o) <= 1
     assert np.abs(s.getSolution() - xo).max() <= U_ATOL
+
+
+def test_relative_row_groups_with_many_distinct_large_gaps():
+    """More distinct gaps >= 32768 than the 256-entry table holds (a band that wanders: 489 different far offsets, each
+    constant over 512 rows): the table overflows and the 32-bit gap stream is taken; y equals the int32 row form bit for
+    bit.  Through MatSetValues, so the compat path's patterns reach the group forms too."""
+    n = 250000
+    s = pf.PetscSolver().initialise(n, n)
+    rng = np.random.default_rng(3)
+    far = 66000 + 97 * ((np.arange(n) // 512) % 600)           # 489 blocks of 512 rows: 489 distinct gaps beyond 65535
+    I, A = pf.solver.INSERT_VALUES, pf.solver.ADD_VALUES
+    rows_cols = []
+    for i in range(n):
+        c = [j for j in (i - 1, i, i + 1, i + int(far[i])) if 0 <= j < n]
+        rows_cols.append(np.array(c, np.int32))
+        s.MatSetValues([i], rows_cols[-1], np.zeros(len(c)), I)
+    s.setZero()
+    for i in range(n):
+        s.MatSetValues([i], rows_cols[i], rng.standard_normal(len(rows_cols[i])), A)
+    s.VecSetValues(np.arange(8, dtype=np.int32), np.ones(8), A)
+    s.setTolerances(rtol=1e-5, maxits=1)
+    s.factoriseAndSolve()                      # pushes the staged matrix to the device (the random matrix is not SPD:
+    x = rng.standard_normal(n)                 # whatever the verdict of that one iteration, only the SpMV is compared)
+    s.setSpmvFormat("int32")
+    y32 = s.spmv(x)
+    s.setSpmvFormat("grouped")
+    assert (s.spmvRowGroup(), s.spmvColumnBits()) == (4, 32)
+    assert np.array_equal(s.spmv(x), y32)
+    rowptr, cols, vals = s.getCSR()
+    assert np.abs(y32 - O.spmv(rowptr, cols, vals, x)).max() <= 1e-13 * np.abs(y32).max()
 
 
 @pytest.mark.parametrize("name", ["tet10", "tria20", "beam", "cube40"])

@@ -1,3 +1,2 @@
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -5
-timeout 600 python bench.py --steps 2 --warmup 1 --single-reduction --no-cpu-baseline --no-parity-step 2>&1 | grep '^{' | tail -1 | cut -c1-300
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_bench_contract.py tests/test_distributed.py -m gpu -x -q -k "relative_row_groups or config5 or contract or overlap or rccl" 2>&1 | tail -8
