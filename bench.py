@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--workload", choices=["poisson", "beam"], default="poisson",
                     help="poisson: BASELINE configs[2] (the headline metric); beam: configs[3], the 50x300x50x6-tet "
                          "linear-elasticity cantilever (fixed size: strong scaling over z-slabs for N>1)")
+    ap.add_argument("--beam-scale", type=int, default=1,
+                    help="beam workload: cells per direction multiplied by this (2: 100x600x100, 36.4 M dofs -- beyond literal 16-bit column gaps)")
     ap.add_argument("--strong", action="store_true",
                     help="N>1: keep the WHOLE problem at --cells per side (strong scaling; e.g. --cells 400 = BASELINE config 5 on N ranks)")
     ap.add_argument("--stack", action="store_true", help="N>1: z-extended box n x n x (n N) instead of the cube of n N^(1/3) cells per side")
@@ -169,7 +171,7 @@ def main():
     bc_mode = 1 if beam else 0
     elem_data = H.ELAST_ELEMDATA if beam else H.POISSON_ELEMDATA
     if beam:      # SURVEY 8(d) cfg 4: [-.5,.5]x[0,6]x[-.5,.5], clamp y=0, body force (0.1f,0,0)
-        nE = (50, 300, 50); ext = (-0.5, 0.5, 0.0, 6.0, -0.5, 0.5)
+        nE = (50 * args.beam_scale, 300 * args.beam_scale, 50 * args.beam_scale); ext = (-0.5, 0.5, 0.0, 6.0, -0.5, 0.5)
     elif world == 1:
         nE = (n, n, n); ext = (-1.0, 1.0, -1.0, 1.0, -1.0, 1.0)
     elif args.strong:

@@ -254,6 +254,8 @@ struct pfem_solver {
     bool rel_gap32 = false;        // ... with one 32-bit gap per entry (offsets further apart than 65535: k_spmvr32)
     bool rel_dict = false;         // ... or 16-bit codes with a table of the few distinct large gaps (k_spmvr<., true>)
     DevBuf<uint32_t> d_gap_table;
+    bool row_dict = false;         // the same for the row form and the 3-row form (k_spmv16 / k_spmvg <., true>): gaps between the
+    DevBuf<uint32_t> d_row_gap_table;   // consecutive columns of a row
     int64_t n_rgroups = 0, n_rslices = 0, r_stored = 0;
     DevBuf<int32_t> d_rcol0;
     DevBuf<int64_t> d_rslice_off, d_rslice_doff;
@@ -288,6 +290,7 @@ struct pfem_solver {
         G.col0 = d_gcol0.p;
         G.dwords = d_gdwords.p;
         G.gslice_doff = d_gslice_doff.p;
+        G.gap_table = d_row_gap_table.p;
         return G;
     }
 
@@ -1322,6 +1325,7 @@ namespace {
 int build_cols16(pfem_solver *s)
 {
     s->cols16 = false;
+    s->row_dict = false;
     if (s->n_slices == 0) return PFEM_OK;
     DevBuf<int64_t> words;
     DevBuf<char> temp;
@@ -1342,13 +1346,31 @@ int build_cols16(pfem_solver *s)
     PFEM_TRY(s->d_col0.alloc(static_cast<size_t>(s->n_slices) * 64));
     PFEM_TRY(s->d_dwords.alloc(static_cast<size_t>(std::max<int64_t>(total, 1))));
     PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
-    hipLaunchKernelGGL(k_cols16_fill, dim3(grid_for(s->n_slices * 64)), dim3(kBlock), 0, s->stream, s->sell(), s->d_slice_doff.p,
-                       s->d_col0.p, s->d_dwords.p, s->d_err.p);
+    hipLaunchKernelGGL(k_cols16_fill<false>, dim3(grid_for(s->n_slices * 64)), dim3(kBlock), 0, s->stream, s->sell(), s->d_slice_doff.p,
+                       s->d_col0.p, s->d_dwords.p, s->d_err.p, static_cast<const uint32_t *>(nullptr));
     PFEM_TRY(check_kernel("k_cols16_fill"));
     int overflow = 0;
     PFEM_TRY(fetch_err(s, &overflow));
     PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
-    if (overflow) {     // some gap needs more than 16 bits: keep the int32 kernel
+    if (overflow && !std::getenv("PFEM_DEBUG_NO_ROW_GAP_TABLE")) {
+        // a gap beyond 65535: 16-bit codes with a table of the distinct large gaps, if those are few
+        PFEM_TRY(s->d_row_gap_table.alloc(kGapTable));
+        PFEM_HIP(hipMemsetAsync(s->d_row_gap_table.p, 0, kGapTable * sizeof(uint32_t), s->stream));
+        hipLaunchKernelGGL(k_row_gap_table, dim3(grid_for(s->n_loc)), dim3(kBlock), 0, s->stream, s->sell(), s->d_row_gap_table.p, s->d_err.p);
+        PFEM_TRY(check_kernel("k_row_gap_table"));
+        int tbl_overflow = 0;
+        PFEM_TRY(fetch_err(s, &tbl_overflow));
+        PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
+        if (!(tbl_overflow & 4)) {
+            hipLaunchKernelGGL(k_cols16_fill<true>, dim3(grid_for(s->n_slices * 64)), dim3(kBlock), 0, s->stream, s->sell(),
+                               s->d_slice_doff.p, s->d_col0.p, s->d_dwords.p, s->d_err.p, static_cast<const uint32_t *>(s->d_row_gap_table.p));
+            PFEM_TRY(check_kernel("k_cols16_fill<dict>"));
+            PFEM_TRY(fetch_err(s, &overflow));         // (a negative gap -- columns not ascending -- would still refuse)
+            PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
+            s->row_dict = overflow == 0;
+        }
+    }
+    if (overflow) {     // some gap needs more than 16 bits and the table does not apply: keep the int32 kernel
         s->d_col0.release();
         s->d_dwords.release();
         s->d_slice_doff.release();
@@ -1432,7 +1454,7 @@ int build_groups(pfem_solver *s)
     hipLaunchKernelGGL(k_group_cols_fill, dim3(grid_for(s->n_gslices * 64)), dim3(kBlock), 0, s->stream, s->sell(),
                        static_cast<const int32_t *>(s->d_group_row0.p), s->n_groups, s->n_gslices,
                        static_cast<const int64_t *>(s->d_gslice_off.p), static_cast<const int64_t *>(s->d_gslice_doff.p),
-                       s->d_gcol0.p, s->d_gdwords.p);
+                       s->d_gcol0.p, s->d_gdwords.p, s->row_dict ? static_cast<const uint32_t *>(s->d_row_gap_table.p) : nullptr);
     PFEM_TRY(check_kernel("k_group_cols_fill"));
     PFEM_HIP(hipStreamSynchronize(s->stream));
     s->grouped = true;
@@ -1562,8 +1584,11 @@ void launch_spmv(pfem_solver *s, const double *x, double *y, int64_t n_dot, doub
     SellDev A = s->sell();
     if (s->use_grouped()) {
         SellGDev G = s->sellg();
-        if (e0) hipExtLaunchKernelGGL(k_spmvg<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
-        else hipLaunchKernelGGL(k_spmvg<WITH_DOT>, grid, block, 0, s->stream, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
+        if (s->row_dict) {
+            if (e0) hipExtLaunchKernelGGL((k_spmvg<WITH_DOT, true>), grid, block, 0, s->stream, e0, e1, 0, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
+            else hipLaunchKernelGGL((k_spmvg<WITH_DOT, true>), grid, block, 0, s->stream, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
+        } else if (e0) hipExtLaunchKernelGGL((k_spmvg<WITH_DOT, false>), grid, block, 0, s->stream, e0, e1, 0, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
+        else hipLaunchKernelGGL((k_spmvg<WITH_DOT, false>), grid, block, 0, s->stream, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
     } else if (s->use_rel()) {
         SellRDev G = s->sellr();
         if (s->rel_gap32) {
@@ -1575,9 +1600,12 @@ void launch_spmv(pfem_solver *s, const double *x, double *y, int64_t n_dot, doub
         } else if (e0) hipExtLaunchKernelGGL((k_spmvr<WITH_DOT, false>), grid, block, 0, s->stream, e0, e1, 0, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
         else hipLaunchKernelGGL((k_spmvr<WITH_DOT, false>), grid, block, 0, s->stream, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
     } else if (s->cols16 && s->spmv_format != PFEM_SPMV_INT32) {
-        Sell16Dev C{s->d_col0.p, s->d_dwords.p, s->d_slice_doff.p};
-        if (e0) hipExtLaunchKernelGGL(k_spmv16<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, A, C, x, y, n_dot, partial, ctl, sel);
-        else hipLaunchKernelGGL(k_spmv16<WITH_DOT>, grid, block, 0, s->stream, A, C, x, y, n_dot, partial, ctl, sel);
+        Sell16Dev C{s->d_col0.p, s->d_dwords.p, s->d_slice_doff.p, s->d_row_gap_table.p};
+        if (s->row_dict) {
+            if (e0) hipExtLaunchKernelGGL((k_spmv16<WITH_DOT, true>), grid, block, 0, s->stream, e0, e1, 0, A, C, x, y, n_dot, partial, ctl, sel);
+            else hipLaunchKernelGGL((k_spmv16<WITH_DOT, true>), grid, block, 0, s->stream, A, C, x, y, n_dot, partial, ctl, sel);
+        } else if (e0) hipExtLaunchKernelGGL((k_spmv16<WITH_DOT, false>), grid, block, 0, s->stream, e0, e1, 0, A, C, x, y, n_dot, partial, ctl, sel);
+        else hipLaunchKernelGGL((k_spmv16<WITH_DOT, false>), grid, block, 0, s->stream, A, C, x, y, n_dot, partial, ctl, sel);
     } else {
         if (e0) hipExtLaunchKernelGGL(k_spmv<WITH_DOT>, grid, block, 0, s->stream, e0, e1, 0, A, x, y, n_dot, partial, ctl, sel);
         else hipLaunchKernelGGL(k_spmv<WITH_DOT>, grid, block, 0, s->stream, A, x, y, n_dot, partial, ctl, sel);
@@ -1599,10 +1627,12 @@ extern "C" int pfem_solver_get_spmv_gap_table(pfem_solver *s, int *entries)
     if (!s || !entries) return PFEM_ERR_ARG;
     if (!s->have_pattern) return PFEM_ERR_STATE;
     *entries = 0;
-    if (s->use_rel() && s->rel_dict) {
+    const bool row_form16 = !s->use_rel() && (s->use_grouped() || (s->cols16 && s->spmv_format != PFEM_SPMV_INT32));
+    const uint32_t *tbl = (s->use_rel() && s->rel_dict) ? s->d_gap_table.p : ((row_form16 && s->row_dict) ? s->d_row_gap_table.p : nullptr);
+    if (tbl) {
         PFEM_TRY(use_device(s));
         std::vector<uint32_t> t(kGapTable);
-        PFEM_HIP(hipMemcpy(t.data(), s->d_gap_table.p, sizeof(uint32_t) * kGapTable, hipMemcpyDeviceToHost));
+        PFEM_HIP(hipMemcpy(t.data(), tbl, sizeof(uint32_t) * kGapTable, hipMemcpyDeviceToHost));
         for (uint32_t v : t) *entries += v != 0u;
     }
     return PFEM_OK;

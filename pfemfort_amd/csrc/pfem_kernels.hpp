@@ -1238,10 +1238,48 @@ __global__ void __launch_bounds__(kBlock) k_spmv(SellDev A, const double *__rest
 // (structured cfg 3: max gap 39 202; checked when the pattern is built), otherwise the int32
 // kernel above runs.  Same products, same summation order -> bit-identical y.
 // ---------------------------------------------------------------------------
+// Dictionary form of a 16-bit gap stream, for patterns with gaps beyond 65535 (numbering planes of more than 65 535
+// dofs: a slab of config 5, an elasticity mesh of more than 21 845 nodes per plane) that have FEW DISTINCT large gaps
+// -- any regularly numbered mesh has a handful: gaps below 32768 are stored as they are, every other gap as
+// 0x8000 | its index in a per-matrix table of at most kGapTable values, which every SpMV block copies to LDS.  Same
+// bytes per nonzero as the literal 16-bit form; more distinct gaps than the table holds: 32-bit gaps (relative row
+// groups) or int32 columns (row forms).
+constexpr int kGapTable = 256;
+enum RelGapMode { kGapLit16 = 0, kGap32 = 1, kGapDict16 = 2 };
+
+__device__ inline void gap_table_insert(uint32_t *tbl, uint32_t gap, int *overflow)
+{
+    for (int i = 0; i < kGapTable; ++i) {
+        const uint32_t cur = __hip_atomic_load(&tbl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == gap) return;
+        if (cur == 0u) {
+            const uint32_t old = atomicCAS(&tbl[i], 0u, gap);
+            if (old == 0u || old == gap) return;
+        }
+    }
+    atomicOr(overflow, 4);       // more distinct large gaps than the table holds
+}
+__device__ inline uint32_t gap_table_code(const uint32_t *tbl, uint32_t gap)
+{
+    if (gap < 0x8000u) return gap;
+    for (int i = 0; i < kGapTable; ++i)
+        if (tbl[i] == gap) return 0x8000u | static_cast<uint32_t>(i);
+    return 0u;                   // not reached: every large gap was inserted by k_rel_gap_table
+}
+
+// a 16-bit code of a gap stream -> the gap
+template <bool DICT>
+__device__ __forceinline__ int gap16(uint32_t code, const uint32_t *tbl)
+{
+    if constexpr (DICT) return (code & 0x8000u) ? static_cast<int>(tbl[code & (kGapTable - 1)]) : static_cast<int>(code);
+    else return static_cast<int>(code);
+}
+
 struct Sell16Dev {
     const int32_t *col0;        // [64 * n_slices]
     const uint32_t *dwords;     // packed gaps
     const int64_t *slice_doff;  // [n_slices+1], in words
+    const uint32_t *gap_table;  // dictionary form (see above), else unused
 };
 
 // words per slice = 64 * ceil((width-1)/2); one thread per slice
@@ -1265,8 +1303,9 @@ __global__ void __launch_bounds__(kBlock) k_gap32_sizes(const int64_t *slice_off
 }
 
 // one thread per row: first column + packed gaps; *overflow is set if a gap needs > 16 bits
+template <bool DICT>
 __global__ void __launch_bounds__(kBlock) k_cols16_fill(SellDev A, const int64_t *slice_doff, int32_t *col0,
-                                                         uint32_t *dwords, int *overflow)
+                                                         uint32_t *dwords, int *overflow, const uint32_t *gap_table)
 {
     const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     const int64_t s = r >> 6;
@@ -1288,8 +1327,8 @@ __global__ void __launch_bounds__(kBlock) k_cols16_fill(SellDev A, const int64_t
             if (k < len) {
                 const int c = cp[64 * k];
                 const int64_t g = static_cast<int64_t>(c) - prev;
-                if (g < 0 || g > 65535) bad = true;
-                gap = static_cast<uint32_t>(g) & 0xffffu;
+                if (g < 0 || (!DICT && g > 65535)) bad = true;
+                gap = (DICT ? gap_table_code(gap_table, static_cast<uint32_t>(g)) : static_cast<uint32_t>(g)) & 0xffffu;
                 prev = c;
             }
             w |= gap << (16 * h);
@@ -1299,10 +1338,23 @@ __global__ void __launch_bounds__(kBlock) k_cols16_fill(SellDev A, const int64_t
     if (bad) atomicMax(overflow, 1);
 }
 
+// the distinct gaps of 32768 and more between consecutive columns of a row (patterns whose literal 16-bit form overflowed)
+__global__ void __launch_bounds__(kBlock) k_row_gap_table(SellDev A, uint32_t *tbl, int *overflow)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (r >= A.n_rows) return;
+    const int len = A.rowlen[r];
+    const int32_t *cp = A.cols + A.slice_off[r >> 6] + (r & 63);
+    for (int k = 1; k < len; ++k) {
+        const int64_t g = static_cast<int64_t>(cp[64LL * k]) - cp[64LL * (k - 1)];
+        if (g >= 0x8000) gap_table_insert(tbl, static_cast<uint32_t>(g), overflow);
+    }
+}
+
 // W words = 2W consecutive entries (all inside the slice: caller guarantees 2*(j+W) < width)
-template <int W>
+template <int W, bool DICT>
 __device__ __forceinline__ void spmv16_trip(const double *__restrict__ vp, const uint32_t *__restrict__ wp,
-                                            const double *__restrict__ x, int &j, int &c, double &acc)
+                                            const double *__restrict__ x, int &j, int &c, double &acc, const uint32_t *tbl)
 {
     uint32_t w[W];
     double v[2 * W], xv[2 * W];
@@ -1313,9 +1365,9 @@ __device__ __forceinline__ void spmv16_trip(const double *__restrict__ vp, const
     int cc = c;
 #pragma unroll
     for (int t = 0; t < W; ++t) {
-        cc += static_cast<int>(w[t] & 0xffffu);
+        cc += gap16<DICT>(w[t] & 0xffffu, tbl);
         xv[2 * t] = x[cc];
-        cc += static_cast<int>(w[t] >> 16);
+        cc += gap16<DICT>(w[t] >> 16, tbl);
         xv[2 * t + 1] = x[cc];
     }
     // (no scheduling barrier here: measured 252 -> 266 us; it pays in the multi-row kernels below)
@@ -1325,13 +1377,19 @@ __device__ __forceinline__ void spmv16_trip(const double *__restrict__ vp, const
     j += W;
 }
 
-template <bool WITH_DOT>
+template <bool WITH_DOT, bool DICT = false>
 __global__ void __launch_bounds__(kBlock) k_spmv16(SellDev A, Sell16Dev C, const double *__restrict__ x,
                                                     double *__restrict__ y, int64_t n_dot, double *partial,
                                                     const CgCtl *ctl, SliceSel sel)
 {
     __shared__ double sm[4];
+    __shared__ uint32_t tbl[DICT ? kGapTable : 1];
     if (WITH_DOT && ctl->flag != 0) return;
+    if (DICT) {
+        static_assert(kGapTable == kBlock, "one table entry per thread");
+        tbl[DICT ? threadIdx.x : 0] = C.gap_table[threadIdx.x];
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t s = pick_slice(sel, (static_cast<int64_t>(blockIdx.x) << 2) + wave, A.n_slices);
     double dot = 0.0;
@@ -1347,13 +1405,13 @@ __global__ void __launch_bounds__(kBlock) k_spmv16(SellDev A, Sell16Dev C, const
         int j = 0;
         // cascade of trip sizes: all streaming loads of a trip are issued before the first use, so
         // a wave keeps up to 8 words + 16 values (+16 gathers) in flight
-        while (2 * (j + 8) < width) spmv16_trip<8>(vp, wp, x, j, c, acc);
-        if (2 * (j + 4) < width) spmv16_trip<4>(vp, wp, x, j, c, acc);
-        if (2 * (j + 2) < width) spmv16_trip<2>(vp, wp, x, j, c, acc);
+        while (2 * (j + 8) < width) spmv16_trip<8, DICT>(vp, wp, x, j, c, acc, tbl);
+        if (2 * (j + 4) < width) spmv16_trip<4, DICT>(vp, wp, x, j, c, acc, tbl);
+        if (2 * (j + 2) < width) spmv16_trip<2, DICT>(vp, wp, x, j, c, acc, tbl);
         for (; j < nw; ++j) {
             const uint32_t w0 = __builtin_nontemporal_load(wp + 64 * j);
-            const int c0 = c + static_cast<int>(w0 & 0xffffu);
-            const int c1 = c0 + static_cast<int>(w0 >> 16);
+            const int c0 = c + gap16<DICT>(w0 & 0xffffu, tbl);
+            const int c1 = c0 + gap16<DICT>(w0 >> 16, tbl);
             acc = __builtin_fma(__builtin_nontemporal_load(vp + 64 * (2 * j + 1)), x[c0], acc);
             if (2 * j + 2 < width) acc = __builtin_fma(__builtin_nontemporal_load(vp + 64 * (2 * j + 2)), x[c1], acc);
             c = c1;
@@ -1389,6 +1447,7 @@ struct SellGDev {
     const int32_t *col0;         // [64 * n_gslices]
     const uint32_t *dwords;      // packed gaps of the group's column list
     const int64_t *gslice_doff;  // [n_gslices+1] in words
+    const uint32_t *gap_table;   // dictionary form, else unused
 };
 
 // run_start[r] = r if row r cannot share a group with row r-1 (different length or columns), else 0;
@@ -1429,7 +1488,8 @@ __global__ void __launch_bounds__(kBlock) k_gslice_sizes(const int32_t *group_ro
 // first column + packed 16-bit gaps of every group's column list (that of its first row)
 __global__ void __launch_bounds__(kBlock) k_group_cols_fill(SellDev A, const int32_t *group_row0, int64_t n_groups,
                                                              int64_t n_gslices, const int64_t *gslice_off,
-                                                             const int64_t *gslice_doff, int32_t *col0, uint32_t *dwords)
+                                                             const int64_t *gslice_doff, int32_t *col0, uint32_t *dwords,
+                                                             const uint32_t *gap_table /* dictionary form, else null */)
 {
     const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     const int64_t gs = g >> 6;
@@ -1452,7 +1512,8 @@ __global__ void __launch_bounds__(kBlock) k_group_cols_fill(SellDev A, const int
             const int k = 2 * j + 1 + h;
             if (k < len) {
                 const int c = cp[64LL * k];
-                w |= (static_cast<uint32_t>(c - prev) & 0xffffu) << (16 * h);   // fits: checked on the row form
+                const uint32_t gap = static_cast<uint32_t>(c - prev);           // fits / is in the table: checked on the row form
+                w |= ((gap_table ? gap_table_code(gap_table, gap) : gap) & 0xffffu) << (16 * h);
                 prev = c;
             }
         }
@@ -1483,9 +1544,10 @@ __global__ void __launch_bounds__(kBlock) k_group_vals(SellDev A, SellGDev G, do
 }
 
 // W words = 2W consecutive entries of kGroupRows rows (caller guarantees 2*(j+W) < width)
-template <int W>
+template <int W, bool DICT>
 __device__ __forceinline__ void spmvg_trip(const double *__restrict__ vp, const uint32_t *__restrict__ wp,
-                                           const double *__restrict__ x, int &j, int &c, double (&acc)[kGroupRows])
+                                           const double *__restrict__ x, int &j, int &c, double (&acc)[kGroupRows],
+                                           const uint32_t *tbl)
 {
     uint32_t w[W];
     double v[2 * W][kGroupRows], xv[2 * W];
@@ -1498,8 +1560,8 @@ __device__ __forceinline__ void spmvg_trip(const double *__restrict__ vp, const 
             v[t][p] = __builtin_nontemporal_load(vp + 64 * (kGroupRows * (2 * j + 1 + t) + p));
 #pragma unroll
     for (int t = 0; t < W; ++t) {
-        const int c0 = c + static_cast<int>(w[t] & 0xffffu);
-        const int c1 = c0 + static_cast<int>(w[t] >> 16);
+        const int c0 = c + gap16<DICT>(w[t] & 0xffffu, tbl);
+        const int c1 = c0 + gap16<DICT>(w[t] >> 16, tbl);
         xv[2 * t] = x[c0];
         xv[2 * t + 1] = x[c1];
         c = c1;
@@ -1512,13 +1574,18 @@ __device__ __forceinline__ void spmvg_trip(const double *__restrict__ vp, const 
     j += W;
 }
 
-template <bool WITH_DOT>
+template <bool WITH_DOT, bool DICT = false>
 __global__ void __launch_bounds__(kBlock) k_spmvg(SellGDev G, int64_t n_rows, const double *__restrict__ x,
                                                    double *__restrict__ y, int64_t n_dot, double *partial, const CgCtl *ctl,
                                                    SliceSel sel)
 {
     __shared__ double sm[4];
+    __shared__ uint32_t tbl[DICT ? kGapTable : 1];
     if (WITH_DOT && ctl->flag != 0) return;
+    if (DICT) {
+        tbl[DICT ? threadIdx.x : 0] = G.gap_table[threadIdx.x];
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t gs = pick_slice(sel, (static_cast<int64_t>(blockIdx.x) << 2) + wave, G.n_gslices);
     double dot = 0.0;
@@ -1538,12 +1605,12 @@ __global__ void __launch_bounds__(kBlock) k_spmvg(SellGDev G, int64_t n_rows, co
         }
         const int nw = width / 2;
         int j = 0;
-        while (2 * (j + 4) < width) spmvg_trip<4>(vp, wp, x, j, c, acc);
-        if (2 * (j + 2) < width) spmvg_trip<2>(vp, wp, x, j, c, acc);
+        while (2 * (j + 4) < width) spmvg_trip<4, DICT>(vp, wp, x, j, c, acc, tbl);
+        if (2 * (j + 2) < width) spmvg_trip<2, DICT>(vp, wp, x, j, c, acc, tbl);
         for (; j < nw; ++j) {
             const uint32_t w0 = __builtin_nontemporal_load(wp + 64 * j);
-            const int c0 = c + static_cast<int>(w0 & 0xffffu);
-            const int c1 = c0 + static_cast<int>(w0 >> 16);
+            const int c0 = c + gap16<DICT>(w0 & 0xffffu, tbl);
+            const int c1 = c0 + gap16<DICT>(w0 >> 16, tbl);
             const double x0 = x[c0];
 #pragma unroll
             for (int p = 0; p < kGroupRows; ++p)
@@ -1867,33 +1934,6 @@ struct SellRDev {
     const int64_t *gslice_doff;
     const uint32_t *gap_table;   // dictionary form: a 16-bit code >= 0x8000 stands for gap_table[code & 0x7fff]
 };
-
-// Dictionary form of the 16-bit gap stream, for patterns with gaps beyond 65535 (planes of more than 65 535 nodes: a
-// slab of config 5) that have FEW DISTINCT large gaps -- any regularly numbered mesh has a handful: gaps below 32768
-// are stored as they are, every other gap as 0x8000 | its index in a per-matrix table of at most kGapTable values.
-// 8 + 1/2 B per nonzero like the literal 16-bit form (the 32-bit form costs 8 + 1); more distinct gaps: 32-bit form.
-constexpr int kGapTable = 256;
-enum RelGapMode { kGapLit16 = 0, kGap32 = 1, kGapDict16 = 2 };
-
-__device__ inline void gap_table_insert(uint32_t *tbl, uint32_t gap, int *overflow)
-{
-    for (int i = 0; i < kGapTable; ++i) {
-        const uint32_t cur = __hip_atomic_load(&tbl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == gap) return;
-        if (cur == 0u) {
-            const uint32_t old = atomicCAS(&tbl[i], 0u, gap);
-            if (old == 0u || old == gap) return;
-        }
-    }
-    atomicOr(overflow, 4);       // more distinct large gaps than the table holds
-}
-__device__ inline uint32_t gap_table_code(const uint32_t *tbl, uint32_t gap)
-{
-    if (gap < 0x8000u) return gap;
-    for (int i = 0; i < kGapTable; ++i)
-        if (tbl[i] == gap) return 0x8000u | static_cast<uint32_t>(i);
-    return 0u;                   // not reached: every large gap was inserted by k_rel_gap_table
-}
 
 // Walks the union of the relative column lists of rows r0 .. r0+nr-1 in ascending order and calls
 // f(k, offset).  Returns the union size.

@@ -684,3 +684,43 @@ def test_pattern_built_in_element_ranges(name, per_range, request, monkeypatch):
     assert np.array_equal(vals, prob.vals) and np.array_equal(s.getRHS(), prob.rhs)
     its, reason, _ = s.factoriseAndSolve()
     assert reason == 2
+
+
+@pytest.mark.parametrize("table", [True, False])
+def test_row_forms_beyond_16bit_gaps(table, monkeypatch):
+    """Three dofs per node and a numbering plane of 151 x 151 nodes: the gap to the next plane's columns is 68 403 dofs,
+    more than a literal 16-bit gap holds.  The row form and the 3-row form keep their 16-bit streams through the table of
+    distinct large gaps (k_spmv16 / k_spmvg <., true>); without it (round 1, and whenever the table overflows) the solver
+    drops to int32 columns per row.  Same products, same order: bit-identical y; K, F equal the oracle's; the solve agrees."""
+    if not table:
+        monkeypatch.setenv("PFEM_DEBUG_NO_ROW_GAP_TABLE", "1")
+    mesh = H.gen_box_tets(-0.5, 0.5, 150, 0.0, 1.0, 150, -0.01, 0.01, 3, bc_mode=1, ndof=3)
+    s, dm = _device_problem(pf.ELAST_TET, mesh, H.ELAST_ELEMDATA)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(dm.size_global)
+    s.setSpmvFormat("int32")
+    y32 = s.spmv(x)
+    assert (s.spmvRowGroup(), s.spmvColumnBits(), s.spmvGapTable()) == (1, 32, 0)
+    s.setSpmvFormat("grouped")
+    if table:
+        assert (s.spmvRowGroup(), s.spmvColumnBits()) == (3, 16) and 1 <= s.spmvGapTable() <= 64
+    else:
+        assert s.spmvRowGroup() != 3          # no 3-row form without 16-bit row streams (the relative groups may step in)
+    assert np.array_equal(s.spmv(x), y32)
+    s.setSpmvFormat("gaps16")                                   # one row per lane
+    assert (s.spmvRowGroup(), s.spmvColumnBits()) == ((1, 16) if table else (1, 32))
+    assert np.array_equal(s.spmv(x), y32)
+    if table:
+        nnz = s.matrixInfo()["nnz"]
+        s.setSpmvFormat("grouped")                              # ("auto" keeps a system this small in the row form)
+        assert s.spmvRowGroup() == 3 and s.spmvFormatBytes() < 0.78 * (12 * nnz + 20 * dm.size_global)
+        prob = O.setup_problem(O.ELAST_TET, _omesh(mesh))
+        rowptr, cols, vals = s.getCSR()
+        assert np.array_equal(cols, prob.cols) and np.array_equal(vals, prob.vals) and np.array_equal(s.getRHS(), prob.rhs)
+        # (a thin clamped plate: Jacobi-PCG would need ~1e5 iterations -- the first 60 iterates are compared instead)
+        s.setTolerances(rtol=1e-30, maxits=60)
+        its, reason, _ = s.factoriseAndSolve()
+        xo, its_o, reason_o, rn_o, hist_o = O.pcg_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-30, maxits=60, hist_len=61)
+        assert (its, reason) == (its_o, reason_o) == (60, -3)
+        assert np.abs(s.getSolution() - xo).max() <= 1e-9 * np.abs(xo).max()
+        assert np.allclose(s.getHistory()[:61], hist_o, rtol=1e-8)
