@@ -694,7 +694,7 @@ def test_row_forms_beyond_16bit_gaps(table, monkeypatch):
     drops to int32 columns per row.  Same products, same order: bit-identical y; K, F equal the oracle's; the solve agrees."""
     if not table:
         monkeypatch.setenv("PFEM_DEBUG_NO_ROW_GAP_TABLE", "1")
-    mesh = H.gen_box_tets(-0.5, 0.5, 150, 0.0, 1.0, 150, -0.01, 0.01, 3, bc_mode=1, ndof=3)
+    mesh = H.gen_box_tets(-0.5, 0.5, 150, 0.0, 1.0, 150, -0.01, 0.01, 1, bc_mode=1, ndof=3)
     s, dm = _device_problem(pf.ELAST_TET, mesh, H.ELAST_ELEMDATA)
     rng = np.random.default_rng(5)
     x = rng.standard_normal(dm.size_global)
