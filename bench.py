@@ -329,17 +329,20 @@ def main():
         achieved = bytes_per_spmv / (avg_spmv_ms * 1e-3) / 1e9 if spmv_n else 0.0
         traffic, traffic_source = pmc_traffic(info["nnz"]) if world == 1 else (None, None)
         hbm_bytes = traffic if traffic else fmt_bytes
-        kernel = {3: "pfem::k_spmvg<true> (row-grouped wave-sliced CSR SpMV + (p,Ap) partials: the 3 dof rows of a "
-                     "node share one lane, 16-bit column gaps), rank 0",
-                  4: ("pfem::k_spmvr32<true>" if solver.spmvColumnBits() == 32 else "pfem::k_spmvr<true>") +
+        # names as rocprofv3 prints them: k_spmvr / k_spmvg / k_spmv16 <WITH_DOT, gap table>, k_spmvr32 / k_spmv <WITH_DOT>
+        tbl = solver.spmvGapTable()
+        tname = "true" if tbl else "false"
+        tnote = f" with a table of the {tbl} distinct gaps beyond 32767" if tbl else ""
+        bits = solver.spmvColumnBits()
+        kernel = {3: f"pfem::k_spmvg<true, {tname}> (row-grouped wave-sliced CSR SpMV + (p,Ap) partials: the 3 dof rows of a "
+                     f"node share one lane, 16-bit column gaps{tnote}), rank 0",
+                  4: ("pfem::k_spmvr32<true>" if bits == 32 else f"pfem::k_spmvr<true, {tname}>") +
                      " (wave-sliced CSR SpMV + (p,Ap) partials; 4 consecutive rows per lane share one relative column stream of "
-                     f"{solver.spmvColumnBits()}-bit gaps" +
-                     (f" with a table of the {solver.spmvGapTable()} distinct gaps beyond 32767" if solver.spmvGapTable() else "") +
-                     ", x read as 32-B quads), rank 0"}.get(
+                     f"{bits}-bit gaps{tnote}, x read as 32-B quads), rank 0"}.get(
             solver.spmvRowGroup(),
-            ("pfem::k_spmv16<true>" if solver.spmvColumnBits() == 16 else "pfem::k_spmv<true>") +
-            " (wave-sliced CSR SpMV + (p,Ap) partials; %d-bit column %s), rank 0"
-            % (solver.spmvColumnBits(), "gaps" if solver.spmvColumnBits() == 16 else "indices"))
+            (f"pfem::k_spmv16<true, {tname}>" if bits == 16 else "pfem::k_spmv<true>") +
+            " (wave-sliced CSR SpMV + (p,Ap) partials; %d-bit column %s%s), rank 0"
+            % (bits, "gaps" if bits == 16 else "indices", tnote))
         out = {
             "metric": "DOF/s (assembly+CG-to-tol)", "value": N * args.steps / elapsed, "unit": "DOF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -87,7 +87,7 @@ def test_config5_at_full_size_with_eight_ranks_sharing_the_device():
     assert d["converged_reason"] == 2 and 600 < d["iterations"] < 800 and d["max_nodal_error"] < 1e-3
     c = d["comm"]
     assert c["bytes_per_neighbour"] == 8 * 399 ** 2 and c["neighbours"] == 1            # rank 0: one face
-    assert "k_spmvr<true>" in d["roofline"]["kernel"] and "table of the" in d["roofline"]["kernel"]    # dictionary form
+    assert "k_spmvr<true, true>" in d["roofline"]["kernel"] and "table of the" in d["roofline"]["kernel"]    # dictionary form
 
 
 @pytest.mark.gpu

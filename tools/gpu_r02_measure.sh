@@ -26,7 +26,7 @@ python3 - <<PY > $OUT/spmv_pmc_traffic.json
 import json
 def val(path):
     for line in open(path):
-        if "k_spmv" in line and "<true>" in line:
+        if "k_spmv" in line and "<true" in line:
             return float(line.split()[-1])
 ent = []
 for name, bench in (("poisson", "$OUT/bench_$TAG.json"), ("beam", "$OUT/bench_beam_$TAG.json")):
