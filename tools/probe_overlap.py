@@ -6,7 +6,8 @@ the communication stream under the interior slices -> ncclAllReduce -> rank-orde
 only times are reported: per-iteration time against the single-rank loop, time of the exchange and of the all-reduces
 on the communication stream, and how long the compute stream waited for them.
 
-    python tools/probe_overlap.py [cells=200] [iterations=200] > out.json
+    python tools/probe_overlap.py [cells=200] [iterations=200] [cells_z=cells] > out.json
+    (cells=400 cells_z=50: one rank's share of BASELINE config 5 -- 7.8 M rows, two faces of 399^2 dofs)
 """
 import json
 import os
@@ -24,6 +25,7 @@ def main():
     faulthandler.enable()
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     its = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    nz = int(sys.argv[3]) if len(sys.argv) > 3 else n
     import torch.distributed as dist
     import pfemfort_amd as pf
     from pfemfort_amd import host as H
@@ -33,11 +35,11 @@ def main():
         port = so.getsockname()[1]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=0, world_size=1)
-    sz = H.box_slab_sizes(n, n, n)
+    sz = H.box_slab_sizes(n, n, nz)
     N = sz["size_global"]
     s = pf.PetscSolver().initialise(N, N)
     s.setTolerances(rtol=1e-30, maxits=its)            # a fixed number of iterations
-    s.generateBoxMesh(pf.POISSON_TET, -1.0, 1.0, n, -1.0, 1.0, n, -1.0, 1.0, n)
+    s.generateBoxMesh(pf.POISSON_TET, -1.0, 1.0, n, -1.0, 1.0, n, -1.0, -1.0 + 2.0 * nz / n, nz)
     s.buildPattern()
     s.assemble(H.POISSON_ELEMDATA, H.TIMEDATA)
     s.profileSpmv(32)
@@ -61,7 +63,7 @@ def main():
     c = max(t2["comm_samples"], 1)
     info = s.commInfo()
     out = {"what": "multi-rank iteration pipeline with the rank as its own neighbour (timing only; sums wrong by construction)",
-           "cells": n, "free_dofs": N, "single_rank_loop": single,
+           "cells": [n, n, nz], "free_dofs": N, "spmv_rows_per_lane_and_gap_table": [s.spmvRowGroup(), s.spmvGapTable()], "single_rank_loop": single,
            "multi_rank_loop": {"iterations": i2, "reason": r2, "ms_per_iteration": t2["solve_ms"] / max(i2, 1),
                                "spmv_boundary_plus_interior_ms": t2["spmv_ms_total"] / max(t2["spmv_launches"], 1) - 2 * t2["event_overhead_ms"],
                                "exchange_ms_on_comm_stream": t2["iface_ms_total"] / c,
