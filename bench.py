@@ -15,9 +15,9 @@ N = 1 : BASELINE.json configs[2]: synthetic [-1,1]^3, 200x200x200x6 P1 tets (gen
 N > 1 : weak scaling, one process per GPU, per-GPU element count fixed: the [-1,1]^3 cube with
         round(200 N^(1/3)) cells per side (N = 8: BASELINE configs[4], 400x400x400x6), cut into N
         z-slabs of hex layers.  Per CG iteration: SpMV, the neighbour exchange of the partial sums
-        (RCCL grouped send/recv, bound in C++; for faces of 512 KiB and more the slices with shared
-        rows run first and the exchange goes to a second stream under the interior slices) and two
-        scalar all-reduces.  --stack grows the box along z
+        (RCCL grouped send/recv, bound in C++, in order on the compute stream; PFEM_MULTI_OVERLAP=1 -- and
+        by default exchanges of 4 MiB and more -- run the slices with shared rows first and put the
+        exchange on a second stream under the interior slices) and two scalar all-reduces.  --stack grows the box along z
         instead (200x200x200N cells of the same size).  Either way the Jacobi-PCG iteration count about
         doubles from N=1 to N=8 (a property of the preconditioner), which caps DOF/s scaling at ~0.5 N
         independently of the hardware; `iterations` and `ms_per_iteration` are reported so that

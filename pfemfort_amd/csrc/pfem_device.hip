@@ -340,7 +340,7 @@ struct pfem_solver {
     std::vector<hipEvent_t> xev;                 // cross-stream events (no timing), used round-robin
     size_t xev_next = 0;
     bool have_plan = false;
-    static constexpr int64_t kOverlapMinBytes = 512 * 1024;   // see run_pcg
+    static constexpr int64_t kOverlapMinBytes = 4 * 1024 * 1024;   // per exchange, all neighbours together; see run_pcg
     std::vector<int> peers;
     std::vector<int64_t> peer_off;               // [n_peers+1] offsets into the send / receive buffers
     int64_t n_send = 0, n_sh = 0;                // doubles per exchange; distinct shared dofs of this rank
@@ -2274,8 +2274,12 @@ int run_pcg(pfem_solver *s)
     // than the interior pass.  Measured on MI355X / ROCm 7.2 with the rank as its own neighbour (tools/probe_overlap.py,
     // 200^3 per rank, 634 kB per exchange; single-rank loop 0.334 ms per iteration): in order 0.350 ms (exchange 14 us on
     // the local device), overlapped 0.368 ms (exchange hidden; communication stream of DEFAULT priority -- a high-priority
-    // one made it 0.68 ms).  Over xGMI a 1.27 MB face costs several times
-    // the local copy, so exchanges of kOverlapMinBytes and more take the overlapped form; PFEM_MULTI_OVERLAP=0/1 overrides.
+    // one made it 0.68 ms); at the size of one rank's share of config 5 (7.8 M rows, 2.5 MB per exchange) 0.335 against
+    // 0.359 ms.  The overlapped form therefore costs 18-24 us; a face of B bytes over one xGMI link (nominally ~50 GB/s per
+    // direction) plus ~10 us of launch latency costs the in-order form about as much from B ~ 0.7-1 MB per neighbour:
+    // config 5's 1.27 MB faces sit AT the break-even.  With nothing to gain there, the in-order form -- every call strictly
+    // ordered on one stream, the same on every rank -- is the default below kOverlapMinBytes per exchange, the overlapped
+    // one above (never measured over xGMI by the builder); PFEM_MULTI_OVERLAP=0/1 overrides.
     const bool overlap = want_overlap(s);
     const unsigned gv = vec_grid(n), gs = spmv_blocks(s);
     const dim3 block(kBlock);
