@@ -48,6 +48,9 @@ def test_no_gpu_means_loud_failure_not_fallback():
     assert ei.value.code == _lib.ERR_NOGPU and "no CPU fallback" in str(ei.value)
     with pytest.raises(pf.PfemError):
         pf.device_info(0)
+    with pytest.raises(pf.PfemError) as ei:
+        pf.device_memory(0)
+    assert ei.value.code == _lib.ERR_NOGPU
 
 
 def test_product_never_imports_the_oracle():

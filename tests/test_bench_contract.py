@@ -103,3 +103,29 @@ def test_config5_at_full_size_alone_on_one_device():
     assert d["config"]["free_dofs"] == 63521199 and d["config"]["elements"] == 384000000 and d["n_gpus"] == 1
     assert d["converged_reason"] == 2 and 700 < d["iterations"] < 740 and d["max_nodal_error"] < 1e-3
     assert d["roofline"]["nnz"] == 949001947 and "table of the" in d["roofline"]["kernel"]
+
+
+@pytest.mark.gpu
+def test_strong_scaling_flag_keeps_the_problem():
+    """`--strong`: N ranks solve the problem one rank solves (here 60^3 on 1 and on 2 ranks sharing the device): same
+    free dofs, the same answer, "scaling": "strong"; and the line reports the device memory in use."""
+    import socket
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cells", "60", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--no-parity-step"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-3000:]
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cells", "60", "--strong",
+                          "--steps", "1", "--warmup", "0", "--backend", "gloo", "--same-device", "--no-cpu-baseline", "--no-parity-step"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-3000:]
+    d2 = json.loads([ln for ln in two.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    assert d1["config"]["free_dofs"] == d2["config"]["free_dofs"] == 59 ** 3
+    assert (d1["scaling"], d2["scaling"], d2["n_gpus"]) == ("weak", "strong", 2)
+    assert d1["converged_reason"] == d2["converged_reason"] == 2 and abs(d1["iterations"] - d2["iterations"]) <= 2
+    assert abs(d1["max_nodal_error"] - d2["max_nodal_error"]) < 1e-6
+    m = d1["device_memory_gb"]
+    assert 0 < m["in_use_rank0_device"] < m["total"] and m["total"] > 200
