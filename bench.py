@@ -8,25 +8,29 @@ One "step" = one pass of the hot path over the resident mesh: setZero + element 
 + factoriseAndSolve (Jacobi-PCG to the PETSc default rtol 1e-5; timer :898->902).
 Inputs (mesh, maps, pattern) are resident in HBM before the timed region, as in the reference
 where mesh read / numbering / pattern precede the timers.  The synthetic mesh and its numbering are
-generated ON THE DEVICE (pfem_mesh_generate_box: genTetra.cpp's box + the driver's bookkeeping,
+generated ON THE DEVICE (pfem_mesh_generate_box_axis: genTetra.cpp's box + the driver's bookkeeping,
 bit-identical to the host path); a rank holds the node planes of its own hex layers only.
 
 N = 1 : BASELINE.json configs[2]: synthetic [-1,1]^3, 200x200x200x6 P1 tets (genTetra logic).
-N > 1 : weak scaling, one process per GPU, per-GPU element count fixed: the [-1,1]^3 cube with
-        round(200 N^(1/3)) cells per side (N = 8: BASELINE configs[4], 400x400x400x6), cut into N
-        z-slabs of hex layers.  Per CG iteration: SpMV, the neighbour exchange of the partial sums
-        (RCCL grouped send/recv, bound in C++, in order on the compute stream; PFEM_MULTI_OVERLAP=1 -- and
-        by default exchanges of 4 MiB and more -- run the slices with shared rows first and put the
-        exchange on a second stream under the interior slices) and two scalar all-reduces.  --stack grows the box along z
-        instead (200x200x200N cells of the same size).  Either way the Jacobi-PCG iteration count about
-        doubles from N=1 to N=8 (a property of the preconditioner), which caps DOF/s scaling at ~0.5 N
-        independently of the hardware; `iterations` and `ms_per_iteration` are reported so that
-        per-iteration scaling can be derived.  --strong keeps the whole problem at --cells per side instead
-        (--cells 400 --strong: BASELINE configs[4] on N ranks; alone on one GPU it takes 2.06 s per step,
-        profiles/r02/bench_cfg5_400cube_single_gpu.json).
+N > 1 : one process per GPU.  Started either by a launcher (python -m torch.distributed.run --nproc-per-node N bench.py
+        --gpus N ..., RANK / LOCAL_RANK / WORLD_SIZE in the environment) or plainly as `python bench.py --gpus N`: the
+        parent then starts the N ranks itself, before it has touched the GPU, relays their one JSON line and returns
+        their exit code.  Weak scaling, per-GPU element count fixed: the [-1,1]^3 cube with round(200 N^(1/3)) cells per
+        side (N = 8: BASELINE configs[4], 400x400x400x6), cut into N slabs of hex layers along its longest axis (cubes:
+        z; the beam of --workload beam: across its length, y).  Per CG iteration: SpMV, the neighbour exchange of the
+        partial sums (RCCL grouped send/recv, bound in C++, in order on the compute stream; exchanges of 4 MiB and more
+        run the slices with shared rows first and put the exchange on a second stream under the interior slices -- the
+        form is voted by all ranks) and two scalar all-reduces.  The Jacobi-PCG iteration count about doubles from N=1
+        to N=8 (a property of the preconditioner), which caps weak DOF/s scaling at ~0.5 N independently of the
+        hardware, so the line also carries (a) `per_iteration_efficiency`: rows per GPU and per millisecond of CG
+        iteration against the committed N=1 figure, and (b) `strong_cfg5`: BASELINE config 5 (400^3 x 6 tets, which fits
+        one MI355X: 2.02 s per step, profiles/r02/bench_cfg5_400cube_single_gpu.json) solved by the same N ranks, with
+        its speed-up over that single-GPU step -- the >= 6x-at-8-GPUs evidence.  `comm` says what carried the run:
+        transport, ncclCommCount, every rank's device, the fallback reason if gloo host hooks had to be taken.
+        --strong keeps the whole problem at --cells per side instead; --stack grows the box along z.
 
 Prints ONE JSON line on rank 0 (contract in the task description), with `roofline` for the CG
-SpMV kernel (HIP events around sampled SpMV launches of the timed solves) and `cpu_baseline` (the C
+SpMV kernel (raw HIP event pairs around sampled SpMV launches of the timed solves) and `cpu_baseline` (the C
 oracle on the host cores, timed at the reference's three timer points on the SAME configuration).
 """
 import argparse
@@ -113,7 +117,64 @@ def cpu_baseline(n, rtol, extra_sample=True):
     return out
 
 
-def main():
+def self_launch(args):
+    """Parent of an N > 1 run started as `python bench.py --gpus N ...` (the form the driver uses for N = 1): starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same
+    arguments>` as a CHILD process (never an exec: this process stays a plain waiter and never touches the GPU), passes
+    the children's stdout and stderr through, and returns their exit code.  A watchdog kills the whole process group if
+    the ranks' own faulthandler timeout did not end them.  If the RCCL attempt ends without a result line (a rank died or
+    timed out in the bring-up), the job is started ONCE more, in fresh processes, over gloo host hooks -- slow, but a
+    number, and the line says why (`comm.fallback_reason`)."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+
+    def attempt(extra):
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
+        proc = subprocess.Popen(cmd, env=env, cwd=ROOT, start_new_session=True, stdout=subprocess.PIPE, text=True)
+        got_line = []
+
+        def relay():
+            for ln in proc.stdout:
+                if ln.lstrip().startswith("{"):
+                    got_line.append(True)
+                sys.stdout.write(ln)
+                sys.stdout.flush()
+        th = threading.Thread(target=relay, daemon=True)
+        th.start()
+        try:
+            rc = proc.wait(timeout=args.rank_timeout + 120.0)
+        except subprocess.TimeoutExpired:
+            print(f"bench.py: the {args.gpus} ranks did not finish within {args.rank_timeout + 120:.0f} s: killing them", file=sys.stderr)
+            rc = 124
+        except KeyboardInterrupt:
+            rc = 130
+        if proc.poll() is None:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            proc.wait()
+        th.join(timeout=10.0)
+        return rc, bool(got_line)
+
+    rc, ok = attempt([])
+    if rc not in (0, 130) and not ok and args.backend == "nccl" and not args.no_relaunch:
+        print(f"bench.py: the RCCL attempt ended with exit code {rc} and no result line; starting the ranks once more over "
+              "gloo host hooks", file=sys.stderr)
+        rc, ok = attempt(["--backend", "gloo", "--fallback-note", f"a first attempt over RCCL ended with exit code {rc} and no result"])
+    return rc
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -122,12 +183,18 @@ def main():
     ap.add_argument("--rtol", type=float, default=1e-5, help="PETSc default (the reference sets none)")
     ap.add_argument("--workload", choices=["poisson", "beam"], default="poisson",
                     help="poisson: BASELINE configs[2] (the headline metric); beam: configs[3], the 50x300x50x6-tet "
-                         "linear-elasticity cantilever (fixed size: strong scaling over z-slabs for N>1)")
+                         "linear-elasticity cantilever (fixed size: strong scaling for N>1, cut across its length)")
     ap.add_argument("--beam-scale", type=int, default=1,
                     help="beam workload: cells per direction multiplied by this (2: 100x600x100, 36.4 M dofs -- beyond literal 16-bit column gaps)")
+    ap.add_argument("--axis", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="N>1: axis the box is cut along (0 x, 1 y, 2 z; -1: the one with the most hex layers, ties to z -- the "
+                         "beam is cut across y, cubes across z)")
     ap.add_argument("--strong", action="store_true",
                     help="N>1: keep the WHOLE problem at --cells per side (strong scaling; e.g. --cells 400 = BASELINE config 5 on N ranks)")
     ap.add_argument("--stack", action="store_true", help="N>1: z-extended box n x n x (n N) instead of the cube of n N^(1/3) cells per side")
+    ap.add_argument("--no-strong-block", action="store_true",
+                    help="N>1 weak runs: skip the extra strong-scaling measurement (the cube of 2 x --cells per side -- BASELINE "
+                         "config 5 at the default 200 -- on the same N ranks) reported as `strong_cfg5`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-step", action="store_true", help="skip the extra (untimed) step at rtol 1e-10")
     ap.add_argument("--pc", choices=["jacobi", "pbjacobi"], default="jacobi")
@@ -137,81 +204,76 @@ def main():
     ap.add_argument("--simulate-rccl-failure", action="store_true", help="development: exercise the fallback to gloo host hooks")
     ap.add_argument("--same-device", action="store_true",
                     help="development: put every rank on cuda:0 (with --backend gloo) to exercise the N>1 path on a 1-GPU box")
-    args = ap.parse_args()
+    ap.add_argument("--no-relaunch", action="store_true", help="self-launched N>1 runs: do not retry over gloo when the RCCL attempt dies")
+    ap.add_argument("--fallback-note", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--debug-die-rank", type=int, default=-1, help=argparse.SUPPRESS)     # tests: this rank exits(3) after the rendezvous
+    ap.add_argument("--bringup-timeout", type=float, default=420.0,
+                    help="seconds the communicator bring-up + transport self-test of an N>1 run may take before the rank gives up")
+    ap.add_argument("--rank-timeout", type=float, default=1500.0,
+                    help="seconds after which a rank that is still running dumps every thread's traceback and exits non-zero "
+                         "(a hung collective must not hang the job)")
+    return ap.parse_args()
+
+
+def single_gpu_reference():
+    """Committed single-GPU figures the N > 1 line is read against (profiles/single_gpu_reference.json: which driver /
+    builder record each one comes from is named there)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "single_gpu_reference.json")))
+    except (OSError, ValueError):
+        return {}
+
+
+class Job:
+    """What every case of this process shares: the rank's place in the job, the modules, and the transport verdict."""
+
+    def __init__(self, args):
+        self.args = args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device_index = self.local_rank if (self.world > 1 and not args.same_device) else 0
+        self.dist = self.torch = None
+        self.gloo_group = None          # host-hook group once RCCL was found unusable (or the default group is gloo)
+        self.fallback_reason = args.fallback_note
+        self.rccl_dead = False
+
+
+def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=False):
+    """One configuration through the whole hot path on this job's ranks: device-generated slab, transport, pattern,
+    `warmup` + `steps` steps (assembly + solve) bracketed by barriers; returns everything the JSON line needs."""
+    import faulthandler
 
     import numpy as np
     import pfemfort_amd as pf
     from pfemfort_amd import host as H
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-
-    dist = torch = None
-    device_index = local_rank if (world > 1 and not args.same_device) else 0
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(device_index)
-        dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", device_index)
-                                if args.backend == "nccl" else None)
-
-    if pf.device_count() < 1:
-        raise SystemExit("bench.py needs an MI355X: libpfem_amd has no CPU path")
-
-    # ---- the mesh of this rank, generated on the device -----------------------------------
-    n = args.n
-    beam = args.workload == "beam"
+    args, world, rank, dist, torch = J.args, J.world, J.rank, J.dist, J.torch
     kind = pf.ELAST_TET if beam else pf.POISSON_TET
     ndof = 3 if beam else 1
     bc_mode = 1 if beam else 0
     elem_data = H.ELAST_ELEMDATA if beam else H.POISSON_ELEMDATA
-    if beam:      # SURVEY 8(d) cfg 4: [-.5,.5]x[0,6]x[-.5,.5], clamp y=0, body force (0.1f,0,0)
-        nE = (50 * args.beam_scale, 300 * args.beam_scale, 50 * args.beam_scale); ext = (-0.5, 0.5, 0.0, 6.0, -0.5, 0.5)
-    elif world == 1:
-        nE = (n, n, n); ext = (-1.0, 1.0, -1.0, 1.0, -1.0, 1.0)
-    elif args.strong:
-        nE = (n, n, n); ext = (-1.0, 1.0, -1.0, 1.0, -1.0, 1.0)
-    elif not args.stack:
-        side = round(n * world ** (1.0 / 3.0))
-        nE = (side, side, side); ext = (-1.0, 1.0, -1.0, 1.0, -1.0, 1.0)
-    else:
-        nE = (n, n, n * world); ext = (-1.0, 1.0, -1.0, 1.0, -1.0, -1.0 + 2.0 * world)
     nEx, nEy, nEz = nE
     box = (ext[0], ext[1], nEx, ext[2], ext[3], nEy, ext[4], ext[5], nEz)
-    # the first HIP calls of a process create the device context and load the code objects of every kernel family on
-    # first use (0.3 - 1 s, depending on how cold the box is): not part of the mesh setup, so a tiny problem is run
-    # through the whole path first and its time is reported separately
-    t_init = time.perf_counter()
-    w = pf.PetscSolver().initialise(*[H.box_slab_sizes(8, 8, 8, bc_mode, ndof)[k] for k in ("size_local", "size_global")], device=device_index)
-    w.generateBoxMesh(kind, 0.0, 1.0, 8, 0.0, 1.0, 8, 0.0, 1.0, 8, bc_mode=bc_mode)
-    w.buildPattern()
-    w.assemble(elem_data, H.TIMEDATA)
-    w.factoriseAndSolve()
-    w.free()
-    t_init = time.perf_counter() - t_init
+    R = {"nE": nE, "ext": ext, "beam": beam, "steps": steps, "warmup": warmup, "rtol": rtol}
+
     t_setup = time.perf_counter()
-    sz = H.box_slab_sizes(nEx, nEy, nEz, bc_mode, ndof, world, rank)
+    sz = H.box_slab_sizes(nEx, nEy, nEz, bc_mode, ndof, world, rank, axis=args.axis)
+    axis = sz["axis"]
     N, row_start, size_local = sz["size_global"], sz["row_start"], sz["size_local"]
-    solver = pf.PetscSolver().initialise(size_local, N, row_start=row_start, device=device_index)
-    solver.setTolerances(rtol=args.rtol, maxits=100000 if beam else 10000)
+    solver = pf.PetscSolver().initialise(size_local, N, row_start=row_start, device=J.device_index)
+    solver.setTolerances(rtol=rtol, maxits=100000 if beam else 10000)
     solver.setPreconditioner(args.pc)
     if args.single_reduction:
         solver.setSingleReduction(True)
-    solver.generateBoxMesh(kind, *box, bc_mode=bc_mode, nparts=world, part=rank)
-    t_generate = time.perf_counter() - t_setup
+    solver.generateBoxMesh(kind, *box, bc_mode=bc_mode, nparts=world, part=rank, axis=axis)
+    R["t_generate"] = time.perf_counter() - t_setup
     hooks = None
-    transport = "gloo host hooks" if args.backend == "gloo" else "RCCL bound in C++"
     if world > 1:
         from pfemfort_amd import distributed as PD
         # RCCL inside the library unless the group is gloo.  If RCCL cannot be brought up or fails the transport self-test
         # on ANY rank, all ranks fall back together to host hooks over a gloo subgroup: slow, but a result.
         why = None
-        if args.backend != "gloo" or args.simulate_rccl_failure:
+        if (args.backend != "gloo" and not J.rccl_dead) or (args.simulate_rccl_failure and not J.rccl_dead):
             try:
                 if args.simulate_rccl_failure:
                     raise pf.PfemError(9, "simulated", "--simulate-rccl-failure")
@@ -223,25 +285,42 @@ def main():
             votes = [None] * world
             dist.all_gather_object(votes, why)
             why = next((v for v in votes if v), None)
-        if args.backend == "gloo" or why:
-            grp = None if (args.backend == "gloo" and not why) else dist.new_group(backend="gloo")
-            hooks = PD.attach(solver, dist, torch, staged=True, group=grp)
+            if why:
+                J.rccl_dead = True
+                J.fallback_reason = f"RCCL was not usable: {why}"
+        if args.backend == "gloo" or J.rccl_dead:
+            if J.gloo_group is None and args.backend != "gloo":
+                J.gloo_group = dist.new_group(backend="gloo")
+            hooks = PD.attach(solver, dist, torch, staged=True, group=J.gloo_group)
             bad = solver.commSelftest(4096)
             if bad:
                 raise SystemExit(f"rank {rank}: communication self-test failed ({bad} wrong entries)")
-            if why:
-                transport = f"gloo host hooks (fallback: RCCL was not usable: {why})"
+        faulthandler.dump_traceback_later(args.rank_timeout, exit=True)        # bring-up done: the full leash
+        # what is carrying the run, from the transport itself (ncclCommCount etc.), one entry per rank
+        me = solver.commDescribe()
+        try:
+            pr = torch.cuda.get_device_properties(J.device_index)
+            me["device_name"] = pr.name
+            me["device_uuid"] = str(getattr(pr, "uuid", "")) or None
+            me["pci_bus_id"] = getattr(pr, "pci_bus_id", None)
+        except Exception:           # noqa: BLE001 -- reporting only
+            pass
+        me.update(rank=rank, local_rank=J.local_rank, device_index=J.device_index, pid=os.getpid(),
+                  layers=[sz["layer0"], sz["layer1"]], size_local=size_local)
+        R["ranks_report"] = [None] * world
+        dist.all_gather_object(R["ranks_report"], me)
     t1 = time.perf_counter()
     solver.buildPattern()
-    t_pattern = time.perf_counter() - t1
+    R["t_pattern"] = time.perf_counter() - t1
     info = solver.matrixInfo()
-    t_setup = time.perf_counter() - t_setup
+    R["t_setup"] = time.perf_counter() - t_setup
     # the first build also pays for the first multi-GB device allocations of the process (0.05 - 1 s from box to box);
     # a second build of the same pattern shows the symbolic phase itself
     t1 = time.perf_counter()
     solver.buildPattern()
-    t_pattern2 = time.perf_counter() - t1
-    solver.profileSpmv(8)        # event pair around every 8th SpMV launch of the timed solves (each pair costs ~2 us)
+    R["t_pattern2"] = time.perf_counter() - t1
+    if profile:
+        solver.profileSpmv(8)        # event pair around every 8th SpMV launch of the timed solves (each pair costs ~2 us)
 
     def step():
         solver.assemble(elem_data, H.TIMEDATA)
@@ -253,22 +332,27 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     sync()
-    spmv_ms = 0.0; spmv_n = 0; asm_ms = 0.0; sol_ms = 0.0; if_ms = 0.0; sc_ms = 0.0; ex_ms = 0.0; comm_n = 0
+    acc = dict(spmv_ms=0.0, spmv_n=0, asm_ms=0.0, sol_ms=0.0, if_ms=0.0, sc_ms=0.0, ex_ms=0.0, comm_n=0, enq_ms=0.0, enq_n=0, hostcomm_ms=0.0)
+    its = reason = 0
+    rnorm = 0.0
+    tm = None
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         its, reason, rnorm = step()
         tm = solver.timings()
-        spmv_ms += tm["spmv_ms_total"]; spmv_n += tm["spmv_launches"]
-        asm_ms += tm["assemble_ms"]; sol_ms += tm["solve_ms"]
-        if_ms += tm["iface_ms_total"]; sc_ms += tm["scalar_ms_total"]; ex_ms += tm["exposed_ms_total"]; comm_n += tm["comm_samples"]
+        acc["spmv_ms"] += tm["spmv_ms_total"]; acc["spmv_n"] += tm["spmv_launches"]
+        acc["asm_ms"] += tm["assemble_ms"]; acc["sol_ms"] += tm["solve_ms"]
+        acc["if_ms"] += tm["iface_ms_total"]; acc["sc_ms"] += tm["scalar_ms_total"]; acc["ex_ms"] += tm["exposed_ms_total"]
+        acc["comm_n"] += tm["comm_samples"]
+        acc["enq_ms"] += tm["host_enqueue_ms"]; acc["enq_n"] += tm["host_enqueued_iterations"]; acc["hostcomm_ms"] += tm["host_comm_ms"]
     sync()
     elapsed = time.perf_counter() - t0
-    mem = pf.device_memory(device_index)             # mesh, pattern, incidence, both SpMV forms, vectors: all resident
+    R["mem"] = pf.device_memory(J.device_index)      # mesh, pattern, incidence, both SpMV forms, vectors: all resident
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         if hooks is not None and hooks.error is not None:
@@ -288,65 +372,186 @@ def main():
                     full[conn[a][ok] * 3 + d] = u[l[ok]]
             return "max_displacement_magnitude_owned_rows", float(np.linalg.norm(full.reshape(-1, 3), axis=1).max())
         # u = x^2+y^2+z^2 is nodally exact on this mesh family; owned free nodes in closed form
-        def axis(lo, hi, m):          # xx = lo; repeat: use xx; xx += dx, then the "%.8f" round trip (genTetra.cpp:194-216)
+
+        def axis_tab(lo, hi, m):      # xx = lo; repeat: use xx; xx += dx, then the "%.8f" round trip (genTetra.cpp:194-216)
             out, v, d = [], lo, (hi - lo) / m
             for _ in range(m + 1):
                 out.append(float("%.8f" % v))
                 v += d
             return np.array(out)
-        ax = [axis(ext[0], ext[1], nEx), axis(ext[2], ext[3], nEy), axis(ext[4], ext[5], nEz)]
-        k0, k1 = nEz * rank // world, nEz * (rank + 1) // world
-        ks = [k for k in range(0 if rank == 0 else k0 + 1, k1 + 1) if 0 < k < nEz]
+        ax = [axis_tab(ext[0], ext[1], nEx), axis_tab(ext[2], ext[3], nEy), axis_tab(ext[4], ext[5], nEz)]
+        idx = [np.arange(1, m) for m in nE]                  # interior nodes of every axis ...
+        l0, l1 = sz["layer0"], sz["layer1"]                  # ... of the owned node planes along the cut axis
+        idx[axis] = np.array([c for c in range(0 if rank == 0 else l0 + 1, l1 + 1) if 0 < c < nE[axis]], dtype=int)
         if not len(u):
             return "max_nodal_error", 0.0
-        ex = (ax[2][ks] ** 2)[:, None, None] + (ax[1][1:-1] ** 2)[None, :, None] + (ax[0][1:-1] ** 2)[None, None, :]
+        ex = (ax[2][idx[2]] ** 2)[:, None, None] + (ax[1][idx[1]] ** 2)[None, :, None] + (ax[0][idx[0]] ** 2)[None, None, :]
         return "max_nodal_error", float(np.abs(u - ex.ravel()).max())
 
-    u = solver.getSolution()
-    check_name, check = owned_check(u)
+    R["check_name"], R["check"] = owned_check(solver.getSolution())
 
     # ---- the same step at the parity tolerance (SURVEY 8d asks for both), untimed extra ----
-    parity = None
-    if world == 1 and not args.no_parity_step and not beam:
+    R["parity"] = None
+    if parity_step:
         solver.setTolerances(rtol=1e-10, maxits=10000)
         t1 = time.perf_counter()
         its10, reason10, rn10 = step()
         t10 = time.perf_counter() - t1
-        parity = {"rtol": 1e-10, "iterations": its10, "converged_reason": reason10, "rnorm": rn10, "ms_per_step": t10 * 1e3,
-                  "dof_per_s": N / t10, "max_nodal_error": owned_check(solver.getSolution())[1]}
-        solver.setTolerances(rtol=args.rtol, maxits=10000)
+        R["parity"] = {"rtol": 1e-10, "iterations": its10, "converged_reason": reason10, "rnorm": rn10, "ms_per_step": t10 * 1e3,
+                       "dof_per_s": N / t10, "max_nodal_error": owned_check(solver.getSolution())[1]}
+        solver.setTolerances(rtol=rtol, maxits=10000)
 
-    cinfo = solver.commInfo()
+    R.update(N=int(N), sz=sz, axis=axis, elapsed=elapsed, its=its, reason=reason, rnorm=rnorm, acc=acc, info=info,
+             event_overhead_ms=tm["event_overhead_ms"] if tm else 0.0, cinfo=solver.commInfo(),
+             fmt_bytes=solver.spmvFormatBytes(), gap_table=solver.spmvGapTable(), bits=solver.spmvColumnBits(),
+             row_group=solver.spmvRowGroup(), final=solver.commDescribe() if world > 1 else None,
+             ms_per_step=elapsed / steps * 1e3, ms_per_iteration=acc["sol_ms"] / steps / max(its, 1))
+    solver.free()
+    return R
+
+
+def comm_block(J, R):
+    """`comm` of an N > 1 line: the proof of what ran (backend and rank count as the transport's own communicators report
+    them, every rank's device) and what an iteration exchanges."""
+    rr, final, cinfo, acc = R["ranks_report"], R["final"], R["cinfo"], R["acc"]
+    counts = sorted({r["backend_ranks"] for r in rr})
+    out = {
+        "transport": {"rccl": "rccl", "host": "gloo-host-hooks"}.get(final["backend"], final["backend"]),
+        # ncclCommCount on every rank (-1: host hooks have no communicator)
+        "rccl_comm_count": counts[0] if len(counts) == 1 else counts,
+        "rccl_version": rr[0]["backend_version"],
+        "fallback_reason": J.fallback_reason,
+        "spmv_form": {0: "in order", 1: "overlapped", -1: "not voted"}[final["overlapped_form"]],
+        "ranks": [{k: r.get(k) for k in ("rank", "local_rank", "device_index", "solver_device", "backend_device", "backend_ranks",
+                                          "device_name", "device_uuid", "pci_bus_id", "pid", "layers", "size_local")} for r in rr],
+        "distinct_devices": len({(r.get("device_uuid") or r.get("pci_bus_id") or r["device_index"]) for r in rr}),
+        "neighbours": cinfo["n_peers"], "bytes_per_exchange": 8 * cinfo["doubles_per_exchange"],
+        "bytes_per_neighbour": 8 * cinfo["doubles_per_exchange"] // max(cinfo["n_peers"], 1),
+        "boundary_slices": cinfo["boundary_slices"], "slices": cinfo["total_slices"], "samples": acc["comm_n"],
+        "host_enqueue_us_per_iteration": 1e3 * acc["enq_ms"] / max(acc["enq_n"], 1),
+        "host_us_inside_transport_calls_per_iteration": 1e3 * acc["hostcomm_ms"] / max(acc["enq_n"], 1)}
+    if acc["comm_n"]:           # rank 0, sampled with the SpMV
+        out.update({"interface_exchange_ms": acc["if_ms"] / acc["comm_n"], "scalar_allreduce_ms": acc["sc_ms"] / acc["comm_n"],
+                    "exposed_wait_ms": acc["ex_ms"] / acc["comm_n"]})
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process has not touched the GPU (nothing but argparse so
+        # far) and never will -- it starts N fresh rank processes through torch.distributed.run, relays their output and
+        # exits with their code
+        raise SystemExit(self_launch(args))
+
+    import faulthandler
+    faulthandler.enable()
+    # os._exit(1) after the dump; the bring-up of an N>1 run (rendezvous, RCCL communicators, transport self-test) gets a
+    # shorter leash so that a hung first collective ends the attempt while a retry is still worth it
+    faulthandler.dump_traceback_later(min(args.rank_timeout, args.bringup_timeout) if args.gpus > 1 else args.rank_timeout, exit=True)
+
+    import pfemfort_amd as pf
+    from pfemfort_amd import host as H
+
+    J = Job(args)
+    world, rank = J.world, J.rank
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        J.torch, J.dist = torch, dist
+        torch.cuda.set_device(J.device_index)
+        dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", J.device_index)
+                                if args.backend == "nccl" else None)
+    if pf.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: libpfem_amd has no CPU path")
+    if world > 1 and rank == args.debug_die_rank:
+        os._exit(3)
+
+    # ---- the configuration ---------------------------------------------------------------
+    n = args.n
+    beam = args.workload == "beam"
+    cube = (-1.0, 1.0, -1.0, 1.0, -1.0, 1.0)
+    if beam:      # SURVEY 8(d) cfg 4: [-.5,.5]x[0,6]x[-.5,.5], clamp y=0, body force (0.1f,0,0)
+        nE = (50 * args.beam_scale, 300 * args.beam_scale, 50 * args.beam_scale); ext = (-0.5, 0.5, 0.0, 6.0, -0.5, 0.5)
+    elif world == 1 or args.strong:
+        nE = (n, n, n); ext = cube
+    elif not args.stack:
+        side = round(n * world ** (1.0 / 3.0))
+        nE = (side, side, side); ext = cube
+    else:
+        nE = (n, n, n * world); ext = (-1.0, 1.0, -1.0, 1.0, -1.0, -1.0 + 2.0 * world)
+    # the first HIP calls of a process create the device context and load the code objects of every kernel family on
+    # first use (0.3 - 1 s, depending on how cold the box is): not part of the mesh setup, so a tiny problem is run
+    # through the whole path first and its time is reported separately
+    t_init = time.perf_counter()
+    kind = pf.ELAST_TET if beam else pf.POISSON_TET
+    w = pf.PetscSolver().initialise(*[H.box_slab_sizes(8, 8, 8, 1 if beam else 0, 3 if beam else 1)[k] for k in ("size_local", "size_global")],
+                                    device=J.device_index)
+    w.generateBoxMesh(kind, 0.0, 1.0, 8, 0.0, 1.0, 8, 0.0, 1.0, 8, bc_mode=1 if beam else 0)
+    w.buildPattern()
+    w.assemble(H.ELAST_ELEMDATA if beam else H.POISSON_ELEMDATA, H.TIMEDATA)
+    w.factoriseAndSolve()
+    w.free()
+    t_init = time.perf_counter() - t_init
+
+    R = run_case(J, beam, nE, ext, args.steps, args.warmup, args.rtol, profile=True,
+                 parity_step=(world == 1 and not args.no_parity_step and not beam))
+    weak = not (beam or args.strong)
+    # ---- N > 1, weak run: the strong-scaling companion.  The cube of 2 x --cells per side (at the default 200: BASELINE
+    # config 5, 400^3 x 6 tets, which fits ONE MI355X: profiles/r02/bench_cfg5_400cube_single_gpu.json) on the same N
+    # ranks -- the >= 6x-at-8-GPUs evidence next to the weak figure, whose Jacobi iteration count grows with the problem.
+    S = None
+    if world > 1 and weak and not args.stack and not args.no_strong_block:
+        side = 2 * n
+        if nE == (side, side, side):
+            S = R                       # N = 8: the weak configuration IS that cube
+        else:
+            S = run_case(J, False, (side, side, side), cube, max(1, min(args.steps, 2)), 1, args.rtol, profile=False)
+
+    nEx, nEy, nEz = nE
+    N, its, acc, info, cinfo, sz = R["N"], R["its"], R["acc"], R["info"], R["cinfo"], R["sz"]
     if rank == 0:
+        ref1 = single_gpu_reference()
         bytes_per_spmv = 12 * info["nnz"] + 20 * info["n_local"]       # SURVEY 8(d): FP64 vals, int32 cols
-        fmt_bytes = solver.spmvFormatBytes()
-        # event pair = marker-end -> kernel-end; net of the pair's own offset measured on an empty
-        # kernel at solve start (pfem_timings.event_overhead_ms) this is the dispatch duration that
-        # rocprofv3 --kernel-trace reports (profiles/)
-        ev_off = tm["event_overhead_ms"]
-        raw_spmv_ms = spmv_ms / max(spmv_n, 1)
-        avg_spmv_ms = max(raw_spmv_ms - ev_off * (2 if world > 1 else 1), 1e-9)     # N>1: two passes, two pairs
-        achieved = bytes_per_spmv / (avg_spmv_ms * 1e-3) / 1e9 if spmv_n else 0.0
+        fmt_bytes = R["fmt_bytes"]
+        # The event pair of a sampled launch reports marker-end -> kernel-end.  `avg_launch_ms` is that RAW figure: it is
+        # the one rocprofv3 --kernel-trace agrees with (profiles/r02: 209.97 us traced, 209.98 us raw pairs in the driver's
+        # run).  The offset of an empty kernel timed the same way is reported for information only and NOT subtracted
+        # (round 2 did, and overstated the fraction by 0.02).
+        raw_spmv_ms = acc["spmv_ms"] / max(acc["spmv_n"], 1)
+        avg_spmv_ms = max(raw_spmv_ms, 1e-9)
+        achieved = bytes_per_spmv / (avg_spmv_ms * 1e-3) / 1e9 if acc["spmv_n"] else 0.0
         traffic, traffic_source = pmc_traffic(info["nnz"]) if world == 1 else (None, None)
         hbm_bytes = traffic if traffic else fmt_bytes
         # names as rocprofv3 prints them: k_spmvr / k_spmvg / k_spmv16 <WITH_DOT, gap table>, k_spmvr32 / k_spmv <WITH_DOT>
-        tbl = solver.spmvGapTable()
+        tbl = R["gap_table"]
         tname = "true" if tbl else "false"
         tnote = f" with a table of the {tbl} distinct gaps beyond 32767" if tbl else ""
-        bits = solver.spmvColumnBits()
+        bits = R["bits"]
         kernel = {3: f"pfem::k_spmvg<true, {tname}> (row-grouped wave-sliced CSR SpMV + (p,Ap) partials: the 3 dof rows of a "
                      f"node share one lane, 16-bit column gaps{tnote}), rank 0",
                   4: ("pfem::k_spmvr32<true>" if bits == 32 else f"pfem::k_spmvr<true, {tname}>") +
                      " (wave-sliced CSR SpMV + (p,Ap) partials; 4 consecutive rows per lane share one relative column stream of "
                      f"{bits}-bit gaps{tnote}, x read as 32-B quads), rank 0"}.get(
-            solver.spmvRowGroup(),
+            R["row_group"],
             (f"pfem::k_spmv16<true, {tname}>" if bits == 16 else "pfem::k_spmv<true>") +
             " (wave-sliced CSR SpMV + (p,Ap) partials; %d-bit column %s%s), rank 0"
             % (bits, "gaps" if bits == 16 else "indices", tnote))
+        axis_name = "xyz"[R["axis"]]
+        cross = [m + 1 for d, m in enumerate(nE) if d != R["axis"]]
+        partition = None
+        if world > 1:
+            rr = R["ranks_report"]
+            partition = {"axis": axis_name, "hex_layers_per_rank": [r["layers"][1] - r["layers"][0] for r in rr],
+                         "face_nodes": cross[0] * cross[1],
+                         "face_bytes_per_neighbour": 8 * cinfo["doubles_per_exchange"] // max(cinfo["n_peers"], 1),
+                         "rows_per_rank": [r["size_local"] for r in rr]}
         out = {
-            "metric": "DOF/s (assembly+CG-to-tol)", "value": N * args.steps / elapsed, "unit": "DOF/s",
+            "metric": "DOF/s (assembly+CG-to-tol)", "value": N * args.steps / R["elapsed"], "unit": "DOF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if (beam or args.strong) else "weak",
+            "ms_per_step": R["ms_per_step"], "higher_is_better": True, "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"tetraelasticityparallelimpl1: [-.5,.5]x[0,6]x[-.5,.5] beam, {nEx}x{nEy}x{nEz}x6 P1 tets, "
                                     "3 dofs/node, clamped at y=0, body force (0.1,0,0), E=240.565, nu=0.3 (REAL(4) literals)"
@@ -359,26 +564,21 @@ def main():
                                  "used KSPCG + PCBJACOBI (per-rank ILU(0), solverpetsc.F:187,206), which is NOT reproduced: "
                                  "iteration counts are not comparable with a PETSc run of the reference",
                        "parallelism": "1 GPU" if world == 1 else
-                                      f"{world} z-slabs, sub-assembled interface rows, neighbour exchange of "
+                                      f"{world} slabs of hex layers across {axis_name}, sub-assembled interface rows, neighbour exchange of "
                                       f"{cinfo['doubles_per_exchange']} doubles with {cinfo['n_peers']} neighbour(s) per SpMV "
-                                      f"+ {1 if args.single_reduction and args.pc == 'jacobi' else 2} scalar all-reduce(s) per iteration; transport: " + transport},
-            "iterations": its, "converged_reason": reason, "rnorm": rnorm, check_name: check,
-            "assembly_ms_per_step": asm_ms / args.steps, "solve_ms_per_step": sol_ms / args.steps,
-            "ms_per_iteration": sol_ms / args.steps / max(its, 1),     # weak scaling: iterations grow with the problem
-            "setup_s_untimed": t_setup, "setup_breakdown_s": {"generate_mesh_and_numbering_on_device": t_generate,
-                                                              "symbolic_pattern_and_incidence": t_pattern,
-                                                              "symbolic_pattern_and_incidence_second_build": t_pattern2,
-                                                              "hip_context_and_code_object_load_on_a_tiny_problem_not_in_setup": t_init},
-            "parity_tolerance_step": parity,
-            "device_memory_gb": {"in_use_rank0_device": round((mem["total_bytes"] - mem["free_bytes"]) / 1e9, 2),
-                                 "total": round(mem["total_bytes"] / 1e9, 2)},
-            # N > 1, rank 0, sampled with the SpMV: time on the communication stream of the exchanges of an iteration, and
-            # how much of it the compute stream actually waited for
-            "comm": ({"interface_exchange_ms": if_ms / comm_n, "scalar_allreduce_ms": sc_ms / comm_n,
-                      "exposed_wait_ms": ex_ms / comm_n, "samples": comm_n, "neighbours": cinfo["n_peers"],
-                      "bytes_per_exchange": 8 * cinfo["doubles_per_exchange"],
-                      "bytes_per_neighbour": 8 * cinfo["doubles_per_exchange"] // max(cinfo["n_peers"], 1),
-                      "boundary_slices": cinfo["boundary_slices"], "slices": cinfo["total_slices"]} if comm_n else None),
+                                      f"+ {1 if args.single_reduction and args.pc == 'jacobi' else 2} scalar all-reduce(s) per iteration",
+                       "partition": partition},
+            "iterations": its, "converged_reason": R["reason"], "rnorm": R["rnorm"], R["check_name"]: R["check"],
+            "assembly_ms_per_step": acc["asm_ms"] / args.steps, "solve_ms_per_step": acc["sol_ms"] / args.steps,
+            "ms_per_iteration": R["ms_per_iteration"],     # weak scaling: iterations grow with the problem
+            "setup_s_untimed": R["t_setup"], "setup_breakdown_s": {"generate_mesh_and_numbering_on_device": R["t_generate"],
+                                                                   "symbolic_pattern_and_incidence": R["t_pattern"],
+                                                                   "symbolic_pattern_and_incidence_second_build": R["t_pattern2"],
+                                                                   "hip_context_and_code_object_load_on_a_tiny_problem_not_in_setup": t_init},
+            "parity_tolerance_step": R["parity"],
+            "device_memory_gb": {"in_use_rank0_device": round((R["mem"]["total_bytes"] - R["mem"]["free_bytes"]) / 1e9, 2),
+                                 "total": round(R["mem"]["total_bytes"] / 1e9, 2)},
+            "comm": comm_block(J, R) if world > 1 else None,
             "roofline": {"bound": "hbm", "kernel": kernel,
                          # the judged figure: plain-CSR algorithmic bytes / measured launch time.  It is an
                          # EFFECTIVE rate: the kernel's compressed form moves fewer bytes (hbm_gbps below)
@@ -386,20 +586,45 @@ def main():
                          "effective": True,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "format_bytes_per_launch": fmt_bytes,
-                         "hbm_gbps": hbm_bytes / (avg_spmv_ms * 1e-3) / 1e9 if spmv_n else 0.0,
-                         "hbm_frac": hbm_bytes / (avg_spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if spmv_n else 0.0,
+                         "hbm_gbps": hbm_bytes / (avg_spmv_ms * 1e-3) / 1e9 if acc["spmv_n"] else 0.0,
+                         "hbm_frac": hbm_bytes / (avg_spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if acc["spmv_n"] else 0.0,
                          "hbm_bytes_source": "PMC counters (traffic)" if traffic else "storage of the selected form + x + y",
                          "algorithmic_bytes_per_launch": bytes_per_spmv, "avg_launch_ms": avg_spmv_ms,
-                         "event_pair_ms_raw": raw_spmv_ms, "event_pair_offset_ms": ev_off,
-                         "launches_timed": spmv_n, "nnz": info["nnz"], "rows": info["n_local"]},
+                         "avg_launch_source": "raw HIP event pairs around every 8th SpMV launch of the timed solves, on the solver's stream",
+                         "event_pair_offset_ms_not_subtracted": R["event_overhead_ms"],
+                         "launches_timed": acc["spmv_n"], "nnz": info["nnz"], "rows": info["n_local"]},
         }
+        if world > 1:
+            # how to read an N > 1 line: (1) per-iteration efficiency -- rows per GPU and millisecond of iteration against
+            # the committed N = 1 figure (independent of the iteration count, which Jacobi makes grow with the problem);
+            # (2) the strong-scaling companion on BASELINE config 5
+            r1 = ref1.get("cfg3_200cube", {})
+            if r1.get("ms_per_iteration") and r1.get("free_dofs"):
+                rate1 = r1["free_dofs"] / r1["ms_per_iteration"]
+                out["per_iteration_efficiency"] = {
+                    "value": (N / world / R["ms_per_iteration"]) / rate1,
+                    "definition": "(free dofs per GPU / ms per CG iteration) of this run / the same of the N=1 run",
+                    "n1_ms_per_iteration": r1["ms_per_iteration"], "n1_free_dofs": r1["free_dofs"], "n1_source": r1.get("source")}
+            if S is not None:
+                r5 = ref1.get("cfg5_400cube", {})
+                is5 = S["nE"] == (400, 400, 400)
+                out["strong_cfg5"] = {
+                    "workload": "tetrapoissonparallelimpl1: [-1,1]^3, %dx%dx%dx6 P1 tets%s" % (*S["nE"], " (BASELINE config 5)" if is5 else ""),
+                    "is_baseline_config5": is5, "free_dofs": S["N"], "n_gpus": world, "steps": S["steps"], "warmup": S["warmup"],
+                    "same_run_as_value": S is R,
+                    "ms_per_step": S["ms_per_step"], "dof_per_s": S["N"] / (S["ms_per_step"] * 1e-3), "iterations": S["its"],
+                    "converged_reason": S["reason"], "ms_per_iteration": S["ms_per_iteration"], S["check_name"]: S["check"],
+                    "single_gpu_ms_per_step": r5.get("ms_per_step") if is5 else None,
+                    "single_gpu_source": r5.get("source") if is5 else None,
+                    "speedup_vs_single_gpu": (r5["ms_per_step"] / S["ms_per_step"]) if (is5 and r5.get("ms_per_step")) else None,
+                    "bytes_per_neighbour": 8 * S["cinfo"]["doubles_per_exchange"] // max(S["cinfo"]["n_peers"], 1)}
         if world == 1 and not args.no_cpu_baseline and not beam:
             out["cpu_baseline"] = cpu_baseline(n, args.rtol, extra_sample=(n >= 200))
         print(json.dumps(out), flush=True)
-    solver.free()
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        J.dist.barrier()
+        J.dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
 
 
 if __name__ == "__main__":

@@ -143,6 +143,9 @@ int pfem_assy_for_soln(int64_t nNode, int ndof, const int32_t *NodeDofArrayNew,
  * (elem_proc_id,node_proc_id) can be fed to pfem_dof_numbering instead.        */
 int pfem_partition_box_slabs(int nEx, int nEy, int nEz, int nParts,
                              int32_t *elem_proc_id, int32_t *node_proc_id);
+/* the same along any axis (0 x, 1 y, 2 z; -1: the axis with the most hex layers, ties to z) */
+int pfem_partition_box_slabs_axis(int nEx, int nEy, int nEz, int axis, int nParts,
+                                  int32_t *elem_proc_id, int32_t *node_proc_id);
 /* Recursive coordinate bisection of the element centroids (median splits along the longest axis, any nParts): a
  * geometric stand-in for METIS_PartMeshNodal on meshes WITH coordinates; a node goes to the lowest part among the
  * elements touching it.  conn SoA npElem x nElem, 0-based; xyz SoA ndim x nNode.  (A real METIS partition is taken
@@ -246,6 +249,18 @@ int pfem_box_slab_sizes(int nEx, int nEy, int nEz, int bc_mode, int ndof, int np
                         int64_t *nNode_local, int64_t *nElem_local);
 int pfem_mesh_generate_box(pfem_solver *s, int kind, double x0, double x1, int nEx, double y0, double y1, int nEy,
                            double z0, double z1, int nEz, int bc_mode, int nparts, int part);
+/* The same for slabs of hex layers along ANY axis (0 x, 1 y, 2 z; -1: the axis with the most hex layers, ties to z) --
+ * what a graph partitioner (METIS_PartMeshNodal, tetraelasticityparallelimpl1.F:522-529) does with a slender body:
+ * BASELINE config 4's 50x300x50 beam is cut across its length (37-38 layers per rank on 8 ranks, faces of 51x51 nodes).
+ * The reference's renumbering (:541-612: ranks concatenated, ascending old id inside a rank) is no longer the identity
+ * for x- or y-slabs; the device evaluates it in closed form, bit-identical to pfem_partition_box_slabs_axis +
+ * pfem_dof_numbering + pfem_renumber_mesh + pfem_elem_dof_array on the host (tests/test_gpu_parity.py).
+ * axis_used / layer0 / layer1 (may be NULL): the axis taken and the slab's hex layers [layer0, layer1).           */
+int pfem_box_slab_sizes_axis(int nEx, int nEy, int nEz, int bc_mode, int ndof, int axis, int nparts, int part,
+                             int64_t *size_global, int64_t *row_start, int64_t *size_local,
+                             int64_t *nNode_local, int64_t *nElem_local, int *axis_used, int *layer0, int *layer1);
+int pfem_mesh_generate_box_axis(pfem_solver *s, int kind, double x0, double x1, int nEx, double y0, double y1, int nEy,
+                                double z0, double z1, int nEz, int bc_mode, int axis, int nparts, int part);
 /* the mesh as the device holds it; edof in LOCAL numbering (owned rows first, ghosts after); any pointer may be NULL */
 int pfem_mesh_download(pfem_solver *s, int32_t *conn, double *xyz, int32_t *edof_local, double *solnApplied);
 int pfem_pattern_build(pfem_solver *s);
@@ -409,6 +424,12 @@ int pfem_solver_comm_selftest(pfem_solver *s, int64_t count, int64_t *bad);
  * how many of the SpMV's slices hold shared rows (they run first) out of how many                                  */
 int pfem_solver_comm_info(pfem_solver *s, int *n_peers, int64_t *doubles_per_exchange, int64_t *boundary_slices,
                           int64_t *total_slices);
+/* What carries the multi-rank solve, as the transport reports it (replaces what `-log_view` / MPI_Comm_size would tell a
+ * PETSc user, solverpetsc.F:447-476): backend name ("rccl", "host", "none"), ncclCommCount / ncclCommCuDevice /
+ * ncclGetVersion of the bound communicators (-1 for host hooks), the device the solver runs on, and the form of the
+ * multi-rank SpMV all ranks agreed on for the current plan (0 in order, 1 overlapped, -1 before the first solve).     */
+int pfem_solver_comm_describe(pfem_solver *s, char *backend, int backend_len, int *backend_ranks, int *backend_device,
+                              int *backend_version, int *solver_device, int *overlapped_form);
 /* host-only helper (no GPU needed): ascending unique global dof ids in edof[0..count) that
  * lie outside the owned block [row_start,row_start+n_owned); two-call (NULL -> count).  */
 int pfem_find_ghosts(int64_t count, const int32_t *edof, int64_t row_start, int64_t n_owned,

@@ -71,6 +71,7 @@ SIGNATURES = {
     "pfem_elem_dof_array": [_L, _I, _I, _P, _P, _P],
     "pfem_assy_for_soln": [_L, _I, _P, _P],
     "pfem_partition_box_slabs": [_I, _I, _I, _I, _P, _P],
+    "pfem_partition_box_slabs_axis": [_I, _I, _I, _I, _I, _P, _P],
     "pfem_partition_rcb": [_L, _I, _P, _L, _I, _P, _I, _P, _P],
     "pfem_text_table_shape": [C.c_char_p, _L, _P, _P],
     "pfem_text_table_parse": [C.c_char_p, _L, _L, _I, _P],
@@ -94,6 +95,8 @@ SIGNATURES = {
     "pfem_mesh_upload": [_P, _I, _L, _P, _L, _P, _P, _P],
     "pfem_box_slab_sizes": [_I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "pfem_mesh_generate_box": [_P, _I, _D, _D, _I, _D, _D, _I, _D, _D, _I, _I, _I, _I],
+    "pfem_box_slab_sizes_axis": [_I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "pfem_mesh_generate_box_axis": [_P, _I, _D, _D, _I, _D, _D, _I, _D, _D, _I, _I, _I, _I, _I],
     "pfem_mesh_download": [_P, _P, _P, _P, _P],
     "pfem_pattern_build": [_P],
     "pfem_assemble": [_P, _P, _P],
@@ -123,6 +126,7 @@ SIGNATURES = {
     "pfem_solver_set_comm_rccl": [_P, _I, _I, _P],
     "pfem_solver_set_comm_host": [_P, _I, _I, HOST_ALLREDUCE_FN, HOST_EXCHANGE_FN, _P],
     "pfem_solver_comm_info": [_P, _P, _P, _P, _P],
+    "pfem_solver_comm_describe": [_P, _P, _I, _P, _P, _P, _P, _P],
     "pfem_solver_comm_selftest": [_P, _L, _P],
     "pfem_get_ghosts": [_P, _P, _P],
     "pfem_find_ghosts": [_L, _P, _L, _L, _P, _P],

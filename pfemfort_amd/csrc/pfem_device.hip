@@ -175,6 +175,9 @@ struct CommBackend {
     virtual ~CommBackend() {}
     virtual const char *name() const = 0;
     virtual bool capturable() const { return false; }      // may its calls be recorded by a HIP stream capture?
+    // what the transport itself reports: ranks of its communicator (ncclCommCount), the device it is bound to
+    // (ncclCommCuDevice), the library version (ncclGetVersion); -1 where the backend has no such notion
+    virtual void describe(int *ranks, int *device, int *version) const { *ranks = -1; *device = -1; *version = -1; }
     // in-place SUM of n doubles at device pointer d; all ranks receive identical bits
     virtual int allreduce(double *d, int64_t n, hipStream_t st) = 0;
     // d_send[off[k]..off[k+1]) -> peers[k]; the same range of d_recv <- peers[k]
@@ -341,6 +344,7 @@ struct pfem_solver {
     size_t xev_next = 0;
     bool have_plan = false;
     static constexpr int64_t kOverlapMinBytes = 4 * 1024 * 1024;   // per exchange, all neighbours together; see run_pcg
+    int overlap_agreed = -1;                     // in-order (0) / overlapped (1) form voted by all ranks for this plan; -1: not yet
     std::vector<int> peers;
     std::vector<int64_t> peer_off;               // [n_peers+1] offsets into the send / receive buffers
     int64_t n_send = 0, n_sh = 0;                // doubles per exchange; distinct shared dofs of this rank
@@ -476,7 +480,6 @@ extern "C" int pfem_solver_destroy(pfem_solver *s)
     if (s->h_err) (void)hipHostFree(s->h_err);
     for (auto &g : s->cg_graph)
         if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
-    if (s->mgraph) { (void)hipGraphExecDestroy(s->mgraph); s->mgraph = nullptr; }
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return PFEM_OK;
@@ -590,26 +593,25 @@ extern "C" int pfem_mesh_upload(pfem_solver *s, int kind, int64_t nElem, const i
 
 // The synthetic configurations without a host mesh: genTetra.cpp's box (node order, "%.8f" coordinates, the 6-tet split,
 // Dirichlet data) and the driver's bookkeeping for it (free-dof numbering :357-367, ElemDofArray :698-713, and for
-// nparts > 1 the z-slab partition with its identity renumbering) evaluated on the device for slab `part`.  The solver
-// must have been created with the sizes pfem_box_slab_sizes reports.  Nothing of the whole grid is ever held: a rank
-// stores the node planes of its own hex layers only.
-extern "C" int pfem_mesh_generate_box(pfem_solver *s, int kind, double x0, double x1, int nEx, double y0, double y1, int nEy,
-                                      double z0, double z1, int nEz, int bc_mode, int nparts, int part)
+// nparts > 1 the slab partition along `axis` with the reference's renumbering :541-612 -- the identity for z-slabs)
+// evaluated on the device for slab `part`.  The solver must have been created with the sizes pfem_box_slab_sizes_axis
+// reports.  Nothing of the whole grid is ever held: a rank stores the node planes of its own hex layers only.
+extern "C" int pfem_mesh_generate_box_axis(pfem_solver *s, int kind, double x0, double x1, int nEx, double y0, double y1, int nEy,
+                                           double z0, double z1, int nEz, int bc_mode, int axis, int nparts, int part)
 {
     if (!s || (kind != PFEM_POISSON_TET && kind != PFEM_ELAST_TET)) return PFEM_ERR_ARG;
     const int ndof = kind_ndof(kind);
-    int64_t size_global = 0, row_start = 0, size_local = 0, nNode = 0, nElem = 0;
-    PFEM_TRY(pfem_box_slab_sizes(nEx, nEy, nEz, bc_mode, ndof, nparts, part, &size_global, &row_start, &size_local, &nNode, &nElem));
-    if (size_global != s->size_global || row_start != s->row_start || size_local != s->n_owned) {
-        set_last_error("pfem_mesh_generate_box: the solver was not created with the sizes of pfem_box_slab_sizes");
+    BoxSlab sl;
+    PFEM_TRY(box_slab(nEx, nEy, nEz, bc_mode, ndof, axis, nparts, part, &sl));
+    const int64_t nNode = sl.nNode(), nElem = sl.nElem();
+    if (sl.size_global != s->size_global || sl.own.start != s->row_start || sl.own.dofs(ndof) != s->n_owned) {
+        set_last_error("pfem_mesh_generate_box: the solver was not created with the sizes of pfem_box_slab_sizes(_axis)");
         return PFEM_ERR_ARG;
     }
-    if (nNode > INT32_MAX || nElem >= (1LL << 31) / 4) return PFEM_ERR_ARG;
+    if (nNode > INT32_MAX || nElem >= (1LL << 31) / 4 || sl.size_global > INT32_MAX) return PFEM_ERR_ARG;
     PFEM_TRY(use_device(s));
     const auto t0 = std::chrono::steady_clock::now();
     const int nNx = nEx + 1, nNy = nEy + 1, nNz = nEz + 1;
-    int k0, k1;
-    box_slab_layers(nEz, nparts, part, &k0, &k1);
     const BoxAxes ax = box_axes(x0, x1, nEx, y0, y1, nEy, z0, z1, nEz);
     MeshDev &m = s->mesh;
     m.kind = kind;
@@ -620,15 +622,24 @@ extern "C" int pfem_mesh_generate_box(pfem_solver *s, int kind, double x0, doubl
     m.nElem = nElem;
     m.nNode = nNode;
     const int64_t ndofs = static_cast<int64_t>(m.nsize) * nElem;
+    const int a = sl.axis;
+    const int off[3] = {a == 0 ? sl.l0 : 0, a == 1 ? sl.l0 : 0, a == 2 ? sl.l0 : 0};
 
-    // ghosts: the free dofs of node plane k0 when a lower slab owns it -- one contiguous run of global ids
+    // ghosts: the free dofs of node plane l0 when the slab below owns it, in that rank's numbering; ascending global id
+    // (lexicographic (k,j,i) is monotone in the id) -- one contiguous run for z-slabs, one run per k for y-slabs
     s->ghost_gid.clear();
     if (part > 0) {
-        int64_t first = 0;
-        for (int k = 0; k < k0; ++k) first += box_free_per_plane(nNx, nNy, nNz, bc_mode, ndof, k);
-        const int64_t cnt = box_free_per_plane(nNx, nNy, nNz, bc_mode, ndof, k0);
-        s->ghost_gid.resize(static_cast<size_t>(cnt));
-        for (int64_t g = 0; g < cnt; ++g) s->ghost_gid[static_cast<size_t>(g)] = first + g;
+        const BoxOwner &o = sl.prev;
+        int lo[3] = {o.lo[0], o.lo[1], o.lo[2]}, hi[3] = {o.lo[0] + o.cnt[0] - 1, o.lo[1] + o.cnt[1] - 1, o.lo[2] + o.cnt[2] - 1};
+        if (sl.l0 >= lo[a] && sl.l0 <= hi[a]) {
+            lo[a] = hi[a] = sl.l0;
+            for (int k = lo[2]; k <= hi[2]; ++k)
+                for (int j = lo[1]; j <= hi[1]; ++j)
+                    for (int i = lo[0]; i <= hi[0]; ++i) {
+                        const int64_t node = (static_cast<int64_t>(k - o.lo[2]) * o.cnt[1] + (j - o.lo[1])) * o.cnt[0] + (i - o.lo[0]);
+                        for (int d = 0; d < ndof; ++d) s->ghost_gid.push_back(o.start + node * ndof + d);
+                    }
+        }
     }
     s->n_ghost = static_cast<int64_t>(s->ghost_gid.size());
     s->n_loc = s->n_owned + s->n_ghost;
@@ -643,7 +654,19 @@ extern "C" int pfem_mesh_generate_box(pfem_solver *s, int kind, double x0, doubl
     PFEM_TRY(s->d_edof.alloc(static_cast<size_t>(ndofs)));
     PFEM_TRY(s->d_xyz.alloc(static_cast<size_t>(3) * nNode));
     PFEM_TRY(s->d_soln.alloc(static_cast<size_t>(ndof) * nNode));
-    const BoxDev b{nNx, nNy, nNz, k0, k1, bc_mode, ndof, d_tab.p, d_tab.p + nNx, d_tab.p + nNx + nNy};
+    BoxDev b{};
+    for (int d = 0; d < 3; ++d) {
+        b.N[d] = sl.N[d];
+        b.Ln[d] = sl.Ln(d);
+        b.Le[d] = sl.Le(d);
+        b.own.lo[d] = sl.own.lo[d]; b.own.cnt[d] = sl.own.cnt[d];
+        b.prev.lo[d] = sl.prev.lo[d]; b.prev.cnt[d] = sl.prev.cnt[d];
+    }
+    b.own.start = sl.own.start;
+    b.prev.start = sl.prev.start;
+    b.axis = a; b.l0 = sl.l0; b.l1 = sl.l1; b.own_lo = sl.own_lo;
+    b.bc_mode = bc_mode; b.ndof = ndof;
+    b.X = d_tab.p; b.Y = d_tab.p + nNx; b.Z = d_tab.p + nNx + nNy;
     hipLaunchKernelGGL(k_box_nodes, dim3(grid_for(nNode)), dim3(kBlock), 0, s->stream, b, nNode, s->d_xyz.p, s->d_soln.p);
     PFEM_TRY(check_kernel("k_box_nodes"));
     const int64_t nHex = nElem / 6;
@@ -655,14 +678,21 @@ extern "C" int pfem_mesh_generate_box(pfem_solver *s, int kind, double x0, doubl
     if (bc_mode == 0) {
         std::vector<int64_t> slot;
         std::vector<double> val;
-        const int64_t plane = static_cast<int64_t>(nNx) * nNy;
-        for (int k = k0; k <= k1; ++k)
-            for (int j = 0; j < nNy; ++j) {
+        const int Ln0 = sl.Ln(0), Ln1 = sl.Ln(1), Ln2 = sl.Ln(2);
+        for (int kl = 0; kl < Ln2; ++kl)
+            for (int jl = 0; jl < Ln1; ++jl) {
+                const int k = off[2] + kl, j = off[1] + jl;
                 const bool edge_row = k == 0 || k == nNz - 1 || j == 0 || j == nNy - 1;
-                for (int i = 0; i < nNx; i += (edge_row ? 1 : std::max(1, nNx - 1))) {
-                    const double v = box_dirichlet_value(ax.raw[0][i], ax.raw[1][j], ax.raw[2][k]);
-                    const int64_t node = plane * (k - k0) + static_cast<int64_t>(nNx) * j + i;
+                auto put = [&](int il) {
+                    const double v = box_dirichlet_value(ax.raw[0][off[0] + il], ax.raw[1][j], ax.raw[2][k]);
+                    const int64_t node = (static_cast<int64_t>(kl) * Ln1 + jl) * Ln0 + il;
                     for (int d = 0; d < ndof; ++d) { slot.push_back(node * ndof + d); val.push_back(v); }
+                };
+                if (edge_row) {
+                    for (int il = 0; il < Ln0; ++il) put(il);
+                } else {            // only the two x-faces, where the slab reaches them (Ln0 >= 2)
+                    if (off[0] == 0) put(0);
+                    if (off[0] + Ln0 - 1 == nNx - 1) put(Ln0 - 1);
                 }
             }
         DevBuf<int64_t> d_slot;
@@ -697,6 +727,12 @@ extern "C" int pfem_mesh_generate_box(pfem_solver *s, int kind, double x0, doubl
     s->have_plan = false;
     s->tm.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return PFEM_OK;
+}
+
+extern "C" int pfem_mesh_generate_box(pfem_solver *s, int kind, double x0, double x1, int nEx, double y0, double y1, int nEy,
+                                      double z0, double z1, int nEz, int bc_mode, int nparts, int part)
+{
+    return pfem_mesh_generate_box_axis(s, kind, x0, x1, nEx, y0, y1, nEy, z0, z1, nEz, bc_mode, 2, nparts, part);
 }
 
 // the mesh as the device holds it (tests: generated box against the host generator + bookkeeping); edof comes back in
@@ -1746,6 +1782,10 @@ struct RcclApi {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    // optional (reporting only)
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
 };
 
 // The copy of librccl already mapped into the process is taken if there is one (a torch host has its own; two RCCL
@@ -1775,6 +1815,9 @@ bool rccl_load(RcclApi &api)
     api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
     if (!ok) return false;
+    api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(h, "ncclCommCount"));
+    api.CommCuDevice = reinterpret_cast<decltype(api.CommCuDevice)>(dlsym(h, "ncclCommCuDevice"));
+    api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(dlsym(h, "ncclGetVersion"));
     api.handle = h;
     return true;
 }
@@ -1799,6 +1842,16 @@ struct RcclBackend final : CommBackend {
     }
     const char *name() const override { return "rccl"; }
     bool capturable() const override { return true; }
+    void describe(int *ranks, int *device, int *version) const override
+    {
+        *ranks = *device = *version = -1;
+        int a = 0, b = 0;
+        // both communicators must agree on the rank count, else report the smaller one (a broken bring-up shows)
+        if (api->CommCount && comm && comm_s && api->CommCount(comm, &a) == ncclSuccess && api->CommCount(comm_s, &b) == ncclSuccess)
+            *ranks = std::min(a, b);
+        if (api->CommCuDevice && comm && api->CommCuDevice(comm, &a) == ncclSuccess) *device = a;
+        if (api->GetVersion && api->GetVersion(&a) == ncclSuccess) *version = a;
+    }
     int fail(const char *what, ncclResult_t r)
     {
         set_last_error(std::string(what) + ": " + api->GetErrorString(r));
@@ -1905,8 +1958,13 @@ int install_backend(pfem_solver *s, int rank, int nranks, CommBackend *b)
     if (s->mgraph) { (void)hipGraphExecDestroy(s->mgraph); s->mgraph = nullptr; }
     s->mgraph_key.clear();
     s->mgraph_off = false;
+    if (s->comm) {      // nothing of the previous backend may still be in flight when its communicators go
+        if (s->stream) (void)hipStreamSynchronize(s->stream);
+        if (s->comm_stream) (void)hipStreamSynchronize(s->comm_stream);
+    }
     delete s->comm;
     s->comm = b;
+    s->overlap_agreed = -1;
     s->rank = rank;
     s->nranks = nranks;
     return ensure_comm_stream(s);
@@ -2035,6 +2093,7 @@ extern "C" int pfem_solver_set_neighbours(pfem_solver *s, int n_peers, const int
     if (!sh_src.empty()) PFEM_HIP(hipMemcpy(s->d_sh_src.p, sh_src.data(), sizeof(int32_t) * sh_src.size(), hipMemcpyHostToDevice));
     s->have_plan = true;
     s->slices_fmt = -1;
+    s->overlap_agreed = -1;
     return PFEM_OK;
 }
 
@@ -2095,6 +2154,31 @@ extern "C" int pfem_solver_comm_info(pfem_solver *s, int *n_peers, int64_t *doub
     if (doubles_per_exchange) *doubles_per_exchange = s->n_send;
     if (boundary_slices) *boundary_slices = s->slices_fmt >= 0 ? s->n_slices_b : 0;
     if (total_slices) *total_slices = s->slices_fmt >= 0 ? s->n_slices_b + s->n_slices_i : 0;
+    return PFEM_OK;
+}
+
+// What is actually carrying the multi-rank solve, as the transport itself reports it (bench.py prints this next to the
+// number): backend name ("rccl" / "host" / "none"), the rank count and device of the RCCL communicators (ncclCommCount,
+// ncclCommCuDevice; -1 for host hooks), the RCCL version, the device this solver runs on, and the form of the multi-rank
+// SpMV the ranks agreed on (0 in order, 1 overlapped, -1 before the first solve).
+extern "C" int pfem_solver_comm_describe(pfem_solver *s, char *backend, int backend_len, int *backend_ranks, int *backend_device,
+                                         int *backend_version, int *solver_device, int *overlapped_form)
+{
+    if (!s) return PFEM_ERR_ARG;
+    int r = -1, d = -1, v = -1;
+    if (s->comm) s->comm->describe(&r, &d, &v);
+    if (backend && backend_len > 0) {
+        std::strncpy(backend, s->comm ? s->comm->name() : "none", static_cast<size_t>(backend_len) - 1);
+        backend[backend_len - 1] = 0;
+    }
+    if (backend_ranks) *backend_ranks = r;
+    if (backend_device) *backend_device = d;
+    if (backend_version) *backend_version = v;
+    if (solver_device) *solver_device = s->device;
+    if (overlapped_form) {
+        const char *e = std::getenv("PFEM_MULTI_OVERLAP");
+        *overlapped_form = e ? (std::atoi(e) != 0) : s->overlap_agreed;
+    }
     return PFEM_OK;
 }
 
@@ -2251,12 +2335,30 @@ inline bool want_single_reduction(const pfem_solver *s)
     return e && std::atoi(e) != 0;
 }
 
-// in order / overlapped form of the multi-rank SpMV (see run_pcg)
-inline bool want_overlap(const pfem_solver *s)
+// in order / overlapped form of the multi-rank SpMV (see run_pcg).  The size rule looks at the bytes of an exchange, and
+// end slabs have one neighbour where interior slabs have two: the ranks of one solve could pick different forms (and
+// drive the exchange communicator from different streams).  So the form is VOTED once per plan: overlapped if any rank's
+// exchange reaches kOverlapMinBytes.  Collective on the all-reduce channel; every rank calls it at the same point of
+// its first solve with a plan.  PFEM_MULTI_OVERLAP=0/1 overrides (read by every rank of a job alike).
+int agree_overlap(pfem_solver *s, bool multi, bool *overlap)
 {
+    *overlap = false;
     const char *e = std::getenv("PFEM_MULTI_OVERLAP");
-    if (e) return std::atoi(e) != 0;
-    return s->nranks > 1 && s->n_send * 8 >= pfem_solver::kOverlapMinBytes;
+    if (e) { *overlap = std::atoi(e) != 0; return PFEM_OK; }
+    if (!multi || s->nranks < 2 || !s->comm) return PFEM_OK;
+    if (s->overlap_agreed < 0) {
+        PFEM_TRY(ensure_comm_stream(s));
+        const double mine = s->n_send * 8 >= pfem_solver::kOverlapMinBytes ? 1.0 : 0.0;
+        double sum = 0.0;
+        PFEM_HIP(hipMemcpyAsync(s->d_sbuf.p + 1, &mine, sizeof(double), hipMemcpyHostToDevice, s->stream));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+        PFEM_TRY(s->comm->allreduce(s->d_sbuf.p + 1, 1, s->stream));
+        PFEM_HIP(hipMemcpyAsync(&sum, s->d_sbuf.p + 1, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+        s->overlap_agreed = sum > 0.0 ? 1 : 0;
+    }
+    *overlap = s->overlap_agreed == 1;
+    return PFEM_OK;
 }
 
 int run_pcg(pfem_solver *s)
@@ -2280,7 +2382,8 @@ int run_pcg(pfem_solver *s)
     // config 5's 1.27 MB faces sit AT the break-even.  With nothing to gain there, the in-order form -- every call strictly
     // ordered on one stream, the same on every rank -- is the default below kOverlapMinBytes per exchange, the overlapped
     // one above (never measured over xGMI by the builder); PFEM_MULTI_OVERLAP=0/1 overrides.
-    const bool overlap = want_overlap(s);
+    bool overlap = false;
+    PFEM_TRY(agree_overlap(s, multi, &overlap));
     const unsigned gv = vec_grid(n), gs = spmv_blocks(s);
     const dim3 block(kBlock);
     SellDev A = s->sell();
@@ -2739,7 +2842,8 @@ int run_pcg_single(pfem_solver *s)
     const bool multi = s->nranks > 1 || (s->comm && s->have_plan && std::getenv("PFEM_FORCE_MULTI"));
     s->group_vals_stale = true;
     PFEM_TRY(refresh_group_vals(s));
-    const bool overlap = want_overlap(s);
+    bool overlap = false;
+    PFEM_TRY(agree_overlap(s, multi, &overlap));
     const unsigned gv = vec_grid(n), gs = spmv_blocks(s);
     const dim3 block(kBlock);
     SellDev A = s->sell();

@@ -108,34 +108,35 @@ double pfem::box_dirichlet_value(double x_raw, double y_raw, double z_raw)
     return text_round8(cx * cx + cy * cy + cz * cz);
 }
 
-// Sizes of slab `part` of `nparts` z-slabs of the generated box in the reference's numbering (for z-slabs the
-// renumbering of tetrapoissonparallelimpl1.F:541-612 is the identity: ranks concatenated, ascending old id inside a
-// rank, and rank r owns the node planes above its lowest hex layer -- plane 0 goes to rank 0): closed forms, so that a
-// rank can create its solver and generate its share of the mesh on the device without ever holding the whole grid.
+// Sizes of slab `part` of `nparts` slabs of the generated box, cut along `axis` (0 x, 1 y, 2 z, -1: the axis with the
+// most hex layers), in the reference's renumbering (tetrapoissonparallelimpl1.F:541-612: ranks concatenated, ascending
+// old id inside a rank; rank r owns the node planes above its lowest hex layer -- plane 0 goes to rank 0; for z-slabs
+// that renumbering is the identity): closed forms, so that a rank can create its solver and generate its share of the
+// mesh on the device without ever holding the whole grid.
+extern "C" int pfem_box_slab_sizes_axis(int nEx, int nEy, int nEz, int bc_mode, int ndof, int axis, int nparts, int part,
+                                        int64_t *size_global, int64_t *row_start, int64_t *size_local,
+                                        int64_t *nNode_local, int64_t *nElem_local, int *axis_used, int *layer0, int *layer1)
+{
+    BoxSlab b;
+    const int rc = box_slab(nEx, nEy, nEz, bc_mode, ndof, axis, nparts, part, &b);
+    if (rc != PFEM_OK) return rc;
+    if (size_global) *size_global = b.size_global;
+    if (row_start) *row_start = b.own.start;
+    if (size_local) *size_local = b.own.dofs(ndof);
+    if (nNode_local) *nNode_local = b.nNode();
+    if (nElem_local) *nElem_local = b.nElem();
+    if (axis_used) *axis_used = b.axis;
+    if (layer0) *layer0 = b.l0;
+    if (layer1) *layer1 = b.l1;
+    return PFEM_OK;
+}
+
 extern "C" int pfem_box_slab_sizes(int nEx, int nEy, int nEz, int bc_mode, int ndof, int nparts, int part,
                                    int64_t *size_global, int64_t *row_start, int64_t *size_local,
                                    int64_t *nNode_local, int64_t *nElem_local)
 {
-    if (nEx < 1 || nEy < 1 || nEz < 1 || ndof < 1 || nparts < 1 || nparts > nEz || part < 0 || part >= nparts ||
-        (bc_mode != 0 && bc_mode != 1))
-        return PFEM_ERR_ARG;
-    const int nNx = nEx + 1, nNy = nEy + 1, nNz = nEz + 1;
-    int k0, k1;
-    box_slab_layers(nEz, nparts, part, &k0, &k1);
-    const int own_lo = part == 0 ? 0 : k0 + 1, own_hi = k1;       // owned node planes [own_lo, own_hi]
-    int64_t before = 0, own = 0, all = 0;
-    for (int k = 0; k < nNz; ++k) {
-        const int64_t f = box_free_per_plane(nNx, nNy, nNz, bc_mode, ndof, k);
-        if (k < own_lo) before += f;
-        if (k >= own_lo && k <= own_hi) own += f;
-        all += f;
-    }
-    if (size_global) *size_global = all;
-    if (row_start) *row_start = before;
-    if (size_local) *size_local = own;
-    if (nNode_local) *nNode_local = static_cast<int64_t>(nNx) * nNy * (k1 - k0 + 1);
-    if (nElem_local) *nElem_local = 6LL * nEx * nEy * (k1 - k0);
-    return PFEM_OK;
+    return pfem_box_slab_sizes_axis(nEx, nEy, nEz, bc_mode, ndof, 2, nparts, part, size_global, row_start, size_local,
+                                    nNode_local, nElem_local, nullptr, nullptr, nullptr);
 }
 
 extern "C" int pfem_gen_box_tets(double x0, double x1, int nEx, double y0, double y1, int nEy,
@@ -221,29 +222,46 @@ extern "C" int pfem_gen_box_tets(double x0, double x1, int nEx, double y0, doubl
     return PFEM_OK;
 }
 
-extern "C" int pfem_partition_box_slabs(int nEx, int nEy, int nEz, int nParts,
-                                        int32_t *elem_proc_id, int32_t *node_proc_id)
+extern "C" int pfem_partition_box_slabs_axis(int nEx, int nEy, int nEz, int axis, int nParts,
+                                             int32_t *elem_proc_id, int32_t *node_proc_id)
 {
-    if (nEx < 1 || nEy < 1 || nEz < 1 || nParts < 1 || nParts > nEz) return PFEM_ERR_ARG;
-    std::vector<int32_t> layer_part(nEz);
+    if (nEx < 1 || nEy < 1 || nEz < 1 || nParts < 1 || axis > 2) return PFEM_ERR_ARG;
+    const int a = box_slab_axis(nEx, nEy, nEz, axis);
+    const int E[3] = {nEx, nEy, nEz};
+    if (nParts > E[a]) return PFEM_ERR_ARG;
+    std::vector<int32_t> layer_part(E[a]);
     for (int p = 0; p < nParts; ++p) {
-        const int lo = static_cast<int>(static_cast<int64_t>(p) * nEz / nParts);
-        const int hi = static_cast<int>(static_cast<int64_t>(p + 1) * nEz / nParts);
+        int lo, hi;
+        box_slab_layers(E[a], nParts, p, &lo, &hi);
         for (int k = lo; k < hi; ++k) layer_part[k] = p;
     }
     if (elem_proc_id) {
-        const int64_t per_layer = 6LL * nEx * nEy;
+#pragma omp parallel for schedule(static)
         for (int k = 0; k < nEz; ++k)
-            std::fill(elem_proc_id + per_layer * k, elem_proc_id + per_layer * (k + 1), layer_part[k]);
+            for (int j = 0; j < nEy; ++j)
+                for (int i = 0; i < nEx; ++i) {
+                    const int c[3] = {i, j, k};
+                    const int64_t hex = (static_cast<int64_t>(k) * nEy + j) * nEx + i;
+                    std::fill(elem_proc_id + 6 * hex, elem_proc_id + 6 * hex + 6, layer_part[c[a]]);
+                }
     }
     if (node_proc_id) {
-        // node plane k is touched by hex layers k-1 and k: the lowest part wins
-        const int64_t plane = static_cast<int64_t>(nEx + 1) * (nEy + 1);
+        // node plane c is touched by hex layers c-1 and c: the lowest part wins
+#pragma omp parallel for schedule(static)
         for (int k = 0; k <= nEz; ++k)
-            std::fill(node_proc_id + plane * k, node_proc_id + plane * (k + 1),
-                      layer_part[k > 0 ? k - 1 : 0]);
+            for (int j = 0; j <= nEy; ++j)
+                for (int i = 0; i <= nEx; ++i) {
+                    const int c[3] = {i, j, k};
+                    node_proc_id[(static_cast<int64_t>(k) * (nEy + 1) + j) * (nEx + 1) + i] = layer_part[c[a] > 0 ? c[a] - 1 : 0];
+                }
     }
     return PFEM_OK;
+}
+
+extern "C" int pfem_partition_box_slabs(int nEx, int nEy, int nEz, int nParts,
+                                        int32_t *elem_proc_id, int32_t *node_proc_id)
+{
+    return pfem_partition_box_slabs_axis(nEx, nEy, nEz, 2, nParts, elem_proc_id, node_proc_id);
 }
 
 // Recursive coordinate bisection: a geometric stand-in for METIS_PartMeshNodal (:464) on ANY mesh with coordinates

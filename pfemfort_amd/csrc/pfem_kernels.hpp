@@ -184,60 +184,67 @@ __global__ void __launch_bounds__(kBlock) k_localize_dofs(int32_t *edof, int64_t
 }
 
 // ---------------------------------------------------------------------------
-// structured box generated on the device (genTetra.cpp's mesh + the driver's numbering for one z-slab)
+// structured box generated on the device (genTetra.cpp's mesh + the driver's numbering for one slab along any axis)
 // ---------------------------------------------------------------------------
+struct BoxOwnerDev {
+    int64_t start;            // global id of the first free dof of the owning rank
+    int lo[3], cnt[3];        // its box of free nodes, numbered x-fastest
+};
 struct BoxDev {
-    int nNx, nNy, nNz;        // nodes per side of the WHOLE box
-    int k0, k1;               // hex layers [k0,k1) of this slab; local node planes k0..k1
+    int N[3];                 // nodes per side of the WHOLE box
+    int axis, l0, l1;         // hex layers [l0,l1) of this slab along `axis`; local node planes l0..l1
+    int own_lo;               // first node plane along `axis` that this rank owns (plane l0 belongs to the rank below)
     int bc_mode, ndof;
+    int Ln[3], Le[3];         // local node / hex box
+    BoxOwnerDev own, prev;    // the reference's renumbering: ranks concatenated, ascending old id inside a rank
     const double *X, *Y, *Z;  // axis tables as read back from the "%.8f" node file
 };
 
-// global free-dof id of (i,j,k,d) in the reference's numbering (free dofs counted scanning nodes x-fastest), -1 if
-// constrained.  bc_mode 0: all six faces; 1: the plane j == 0.
+// global free-dof id of (i,j,k,d) in the reference's numbering (free dofs counted scanning the NEW node order:
+// rank by rank, lexicographic (k,j,i) inside a rank), -1 if constrained.  bc_mode 0: all six faces; 1: the plane j == 0.
 __device__ __forceinline__ int32_t box_dof(const BoxDev &b, int i, int j, int k, int d)
 {
-    if (b.bc_mode == 0) {
-        if (i == 0 || j == 0 || k == 0 || i == b.nNx - 1 || j == b.nNy - 1 || k == b.nNz - 1) return -1;
-        const int64_t node = (static_cast<int64_t>(k - 1) * (b.nNy - 2) + (j - 1)) * (b.nNx - 2) + (i - 1);
-        return static_cast<int32_t>(node * b.ndof + d);
-    }
-    if (j == 0) return -1;
-    const int64_t node = (static_cast<int64_t>(k) * (b.nNy - 1) + (j - 1)) * b.nNx + i;
-    return static_cast<int32_t>(node * b.ndof + d);
+    const int c[3] = {i, j, k};
+    const BoxOwnerDev &o = c[b.axis] >= b.own_lo ? b.own : b.prev;
+    const int a0 = i - o.lo[0], a1 = j - o.lo[1], a2 = k - o.lo[2];
+    if (a0 < 0 || a1 < 0 || a2 < 0 || a0 >= o.cnt[0] || a1 >= o.cnt[1] || a2 >= o.cnt[2]) return -1;
+    const int64_t node = (static_cast<int64_t>(a2) * o.cnt[1] + a1) * o.cnt[0] + a0;
+    return static_cast<int32_t>(o.start + node * b.ndof + d);
 }
 
-// coordinates of the slab's nodes (local id = (k-k0)*plane + j*nNx + i), prescribed values cleared
+// coordinates of the slab's nodes (local id x-fastest over the local node box), prescribed values cleared
 __global__ void __launch_bounds__(kBlock) k_box_nodes(BoxDev b, int64_t nNode, double *xyz, double *soln)
 {
     const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (n >= nNode) return;
-    const int64_t plane = static_cast<int64_t>(b.nNx) * b.nNy;
+    const int64_t plane = static_cast<int64_t>(b.Ln[0]) * b.Ln[1];
     const int k = static_cast<int>(n / plane), rem = static_cast<int>(n % plane);
-    const int j = rem / b.nNx, i = rem % b.nNx;
-    xyz[n] = b.X[i];
-    xyz[nNode + n] = b.Y[j];
-    xyz[2 * nNode + n] = b.Z[b.k0 + k];
+    const int j = rem / b.Ln[0], i = rem % b.Ln[0];
+    const int o0 = b.axis == 0 ? b.l0 : 0, o1 = b.axis == 1 ? b.l0 : 0, o2 = b.axis == 2 ? b.l0 : 0;
+    xyz[n] = b.X[o0 + i];
+    xyz[nNode + n] = b.Y[o1 + j];
+    xyz[2 * nNode + n] = b.Z[o2 + k];
     for (int d = 0; d < b.ndof; ++d) soln[n * b.ndof + d] = 0.0;
 }
 
 // six tets per hex in genTetra.cpp's order and orientation (:263-322): connectivity (local node ids) and the
-// element dof array (GLOBAL dof ids, -1 = constrained), both SoA
+// element dof array (GLOBAL dof ids, -1 = constrained), both SoA.  Local hexes in ascending global element id.
 __global__ void __launch_bounds__(kBlock) k_box_elems(BoxDev b, int64_t nHex, int32_t *conn, int32_t *edof)
 {
     const int64_t h = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (h >= nHex) return;
-    const int nEx = b.nNx - 1, nEy = b.nNy - 1;
-    const int i = static_cast<int>(h % nEx), j = static_cast<int>((h / nEx) % nEy), kl = static_cast<int>(h / (static_cast<int64_t>(nEx) * nEy));
-    const int64_t plane = static_cast<int64_t>(b.nNx) * b.nNy, nElem = 6 * nHex;
+    const int i = static_cast<int>(h % b.Le[0]), j = static_cast<int>((h / b.Le[0]) % b.Le[1]),
+              k = static_cast<int>(h / (static_cast<int64_t>(b.Le[0]) * b.Le[1]));
+    const int o0 = b.axis == 0 ? b.l0 : 0, o1 = b.axis == 1 ? b.l0 : 0, o2 = b.axis == 2 ? b.l0 : 0;
+    const int64_t plane = static_cast<int64_t>(b.Ln[0]) * b.Ln[1], nElem = 6 * nHex;
     const int split[6][4] = {{0, 1, 3, 5}, {0, 3, 2, 5}, {2, 3, 7, 5}, {4, 6, 7, 2}, {4, 7, 5, 2}, {0, 4, 5, 2}};
     for (int t = 0; t < 6; ++t) {
         const int64_t e = 6 * h + t;
         for (int a = 0; a < 4; ++a) {
             const int c = split[t][a];
-            const int ci = i + (c & 1), cj = j + ((c >> 1) & 1), ck = kl + ((c >> 2) & 1);
-            conn[a * nElem + e] = static_cast<int32_t>(plane * ck + static_cast<int64_t>(b.nNx) * cj + ci);
-            for (int d = 0; d < b.ndof; ++d) edof[(a * b.ndof + d) * nElem + e] = box_dof(b, ci, cj, b.k0 + ck, d);
+            const int ci = i + (c & 1), cj = j + ((c >> 1) & 1), ck = k + ((c >> 2) & 1);
+            conn[a * nElem + e] = static_cast<int32_t>(plane * ck + static_cast<int64_t>(b.Ln[0]) * cj + ci);
+            for (int d = 0; d < b.ndof; ++d) edof[(a * b.ndof + d) * nElem + e] = box_dof(b, o0 + ci, o1 + cj, o2 + ck, d);
         }
     }
 }

@@ -86,7 +86,25 @@ class HostHooks:
             return 1
 
 
-def attach(solver, dist, torch=None, staged=False, group=None):
+def broadcast_rccl_id(dist, group=None, make_id=rccl_unique_id):
+    """Rank 0 creates the two ncclUniqueIds and every rank receives them -- or every rank raises the SAME error.
+    The creation can fail on rank 0 alone (librccl not loadable, ncclGetUniqueId refused): rank 0 must not leave the
+    collective the others are waiting in, so a (status, bytes) pair is ALWAYS broadcast and all ranks raise or return
+    together, before any further collective (the MPI binding, pfem_mpi.cpp, broadcasts its rc the same way)."""
+    from ._lib import ERR_COMM, PfemError
+    msg = [None, None]
+    if dist.get_rank() == 0:
+        try:
+            msg = [None, make_id()]
+        except Exception as e:      # noqa: BLE001 -- whatever it was, the other ranks must hear of it
+            msg = [f"{type(e).__name__}: {e}", None]
+    dist.broadcast_object_list(msg, src=0, group=group)
+    if msg[0] is not None:
+        raise PfemError(ERR_COMM, "pfem_rccl_unique_id on rank 0", msg[0])
+    return msg[1]
+
+
+def attach(solver, dist, torch=None, staged=False, group=None, make_id=rccl_unique_id):
     """Wire a solver that already holds its mesh (or, compat path, its pattern) to the process group: neighbour
     plan + communication backend.  ``staged=False``: RCCL inside the library (one rank per GPU).
     ``staged=True``: host hooks over the group (gloo; several ranks may share a GPU); ``group``: a gloo subgroup when
@@ -99,8 +117,6 @@ def attach(solver, dist, torch=None, staged=False, group=None):
         solver.setCommHost(rank, world, hooks.allreduce, hooks.exchange)
         solver._keep.append(hooks)
     else:
-        ids = [rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0, group=group)
-        solver.setCommRccl(rank, world, ids[0])
+        solver.setCommRccl(rank, world, broadcast_rccl_id(dist, group, make_id))
     solver.setNeighbours(peers, off, gid)
     return hooks

@@ -119,21 +119,24 @@ def gen_box_tets(x0, x1, nEx, y0, y1, nEy, z0, z1, nEz, bc_mode=0, ndof=1, kz=No
     return Mesh(xyz, conn, bn, bd, bv, box=(nEx, nEy, nEz))
 
 
-def box_slab_sizes(nEx, nEy, nEz, bc_mode=0, ndof=1, nparts=1, part=0):
-    """Closed-form sizes of slab ``part`` of the generated box in the reference's numbering (pfem_box_slab_sizes)."""
+def box_slab_sizes(nEx, nEy, nEz, bc_mode=0, ndof=1, nparts=1, part=0, axis=2):
+    """Closed-form sizes of slab ``part`` of the generated box in the reference's numbering (pfem_box_slab_sizes_axis).
+    ``axis``: 0 x, 1 y, 2 z (default), -1: the axis with the most hex layers; the dict also names the axis taken and the
+    slab's hex layers."""
     v = [C.c_int64(0) for _ in range(5)]
-    L.check(L.lib().pfem_box_slab_sizes(nEx, nEy, nEz, bc_mode, ndof, nparts, part, *[C.byref(x) for x in v]),
-            "pfem_box_slab_sizes")
-    keys = ("size_global", "row_start", "size_local", "nNode_local", "nElem_local")
-    return {k: x.value for k, x in zip(keys, v)}
+    w = [C.c_int(0) for _ in range(3)]
+    L.check(L.lib().pfem_box_slab_sizes_axis(nEx, nEy, nEz, bc_mode, ndof, axis, nparts, part, *[C.byref(x) for x in v + w]),
+            "pfem_box_slab_sizes_axis")
+    keys = ("size_global", "row_start", "size_local", "nNode_local", "nElem_local", "axis", "layer0", "layer1")
+    return {k: x.value for k, x in zip(keys, v + w)}
 
 
-def partition_box_slabs(nEx, nEy, nEz, nParts, elements=True):
-    """Deterministic stand-in for METIS_PartMeshNodal (:464) on generated boxes.
-    ``elements=False`` skips the (large) elem_proc_id array and returns None for it."""
+def partition_box_slabs(nEx, nEy, nEz, nParts, elements=True, axis=2):
+    """Deterministic stand-in for METIS_PartMeshNodal (:464) on generated boxes: slabs of hex layers along ``axis``
+    (-1: the longest).  ``elements=False`` skips the (large) elem_proc_id array and returns None for it."""
     epid = np.empty(6 * nEx * nEy * nEz, np.int32) if elements else None
     npid = np.empty((nEx + 1) * (nEy + 1) * (nEz + 1), np.int32)
-    L.check(L.lib().pfem_partition_box_slabs(nEx, nEy, nEz, nParts, _p(epid), _p(npid)), "pfem_partition_box_slabs")
+    L.check(L.lib().pfem_partition_box_slabs_axis(nEx, nEy, nEz, axis, nParts, _p(epid), _p(npid)), "pfem_partition_box_slabs_axis")
     return epid, npid
 
 

@@ -152,15 +152,17 @@ class PetscSolver:
         self.nElem = conn.shape[1]
         self.nNode = xyz.shape[1]
 
-    def generateBoxMesh(self, kind, x0, x1, nEx, y0, y1, nEy, z0, z1, nEz, bc_mode=0, nparts=1, part=0):
-        """The structured box of genTetra.cpp + the driver's numbering for slab ``part``, generated on the device
-        (the solver must have been initialised with ``host.box_slab_sizes``)."""
-        L.check(L.lib().pfem_mesh_generate_box(self._h, kind, x0, x1, nEx, y0, y1, nEy, z0, z1, nEz, bc_mode, nparts, part),
-                "pfem_mesh_generate_box")
+    def generateBoxMesh(self, kind, x0, x1, nEx, y0, y1, nEy, z0, z1, nEz, bc_mode=0, nparts=1, part=0, axis=2):
+        """The structured box of genTetra.cpp + the driver's numbering for slab ``part`` of ``nparts`` along ``axis``
+        (0 x, 1 y, 2 z, -1 the longest), generated on the device (the solver must have been initialised with
+        ``host.box_slab_sizes`` for the same axis)."""
+        L.check(L.lib().pfem_mesh_generate_box_axis(self._h, kind, x0, x1, nEx, y0, y1, nEy, z0, z1, nEz, bc_mode, axis, nparts, part),
+                "pfem_mesh_generate_box_axis")
         self.kind = kind
-        sz = L.lib().pfem_box_slab_sizes
+        sz = L.lib().pfem_box_slab_sizes_axis
         n = C.c_int64(0); ne = C.c_int64(0)
-        L.check(sz(nEx, nEy, nEz, bc_mode, L.NDOF[kind], nparts, part, None, None, None, C.byref(n), C.byref(ne)), "pfem_box_slab_sizes")
+        L.check(sz(nEx, nEy, nEz, bc_mode, L.NDOF[kind], axis, nparts, part, None, None, None, C.byref(n), C.byref(ne), None, None, None),
+                "pfem_box_slab_sizes_axis")
         self.nElem, self.nNode = ne.value, n.value
 
     def downloadMesh(self):
@@ -323,6 +325,18 @@ class PetscSolver:
         npe = C.c_int(0); d = C.c_int64(0); b = C.c_int64(0); t = C.c_int64(0)
         L.check(L.lib().pfem_solver_comm_info(self._h, C.byref(npe), C.byref(d), C.byref(b), C.byref(t)), "pfem_solver_comm_info")
         return {"n_peers": npe.value, "doubles_per_exchange": d.value, "boundary_slices": b.value, "total_slices": t.value}
+
+
+    def commDescribe(self):
+        """What carries the multi-rank solve, as the transport reports it: backend ("rccl" / "host" / "none"), the rank
+        count / device / version of the bound RCCL communicators (ncclCommCount, ncclCommCuDevice, ncclGetVersion; -1
+        for host hooks), the solver's device, the agreed SpMV form (0 in order, 1 overlapped, -1 not voted yet)."""
+        name = C.create_string_buffer(32)
+        r, d, v, sd, ov = (C.c_int(0) for _ in range(5))
+        L.check(L.lib().pfem_solver_comm_describe(self._h, name, 32, C.byref(r), C.byref(d), C.byref(v), C.byref(sd), C.byref(ov)),
+                "pfem_solver_comm_describe")
+        return {"backend": name.value.decode(), "backend_ranks": r.value, "backend_device": d.value, "backend_version": v.value,
+                "solver_device": sd.value, "overlapped_form": ov.value}
 
 
 def rccl_unique_id() -> bytes:

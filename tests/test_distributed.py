@@ -32,6 +32,8 @@ def _partition(mesh, world, how, H):
     blocks interleave in space).  Deterministic: every rank computes the same arrays."""
     if how == "slabs":
         return H.partition_box_slabs(*mesh.box, world)
+    if how in ("xslabs", "yslabs"):    # slabs of hex layers across x / y: the renumbering is no longer the identity
+        return H.partition_box_slabs(*mesh.box, world, axis="xyz".index(how[0]))
     if how == "rcb":                   # the build's own geometric partitioner (pfem_partition_rcb)
         return H.partition_rcb(mesh, world)
     if how == "idle":                  # the last rank gets nothing: no elements, no nodes, no rows
@@ -172,6 +174,42 @@ def test_gloo_neighbour_plan_sums_subassembled_rows(tmp_path, kind_name, world, 
     assert tot == N
 
 
+def _id_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pfemfort_amd as pf
+        from pfemfort_amd import distributed as PD
+
+        def broken():                  # only ever called on rank 0
+            raise pf.PfemError(9, "pfem_rccl_unique_id", "injected: librccl.so.1 could not be loaded")
+        seen = None
+        try:
+            PD.broadcast_rccl_id(dist, make_id=broken)
+        except pf.PfemError as e:
+            seen = str(e)
+        # the very next collective must still line up on every rank (bench.py's vote)
+        votes = [None] * world
+        dist.all_gather_object(votes, seen)
+        ok = PD.broadcast_rccl_id(dist, make_id=lambda: b"x" * 256)      # and a healthy rank 0 reaches everybody
+        np.savez(os.path.join(out_dir, f"id{rank}.npz"), seen=str(seen), votes=np.array([str(v) for v in votes]), ok=len(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_id_failure_on_rank0_alone_reaches_every_rank(tmp_path):
+    """Round-2 advisory: the unique id is created on rank 0 only; if that fails there, rank 0 used to leave the
+    broadcast the others were waiting in and the job hung.  Now a (status, id) pair is always broadcast: every rank
+    raises the same error, and the next collective (the fallback vote of bench.py) lines up."""
+    import torch.multiprocessing as mp
+    mp.spawn(_id_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        d = np.load(tmp_path / f"id{r}.npz")
+        assert "injected" in str(d["seen"]) and "rank 0" in str(d["seen"])
+        assert all("injected" in v for v in d["votes"]) and int(d["ok"]) == 256
+
+
 def test_neighbour_plan_small_example():
     from pfemfort_amd import host as H
     # rank0 owns [0,5), rank1 [5,9), rank2 [9,12); ghosts are what each touches but does not own
@@ -207,8 +245,17 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
         kind = pf.POISSON_TET if mesh_args["ndof"] == 1 else pf.ELAST_TET
         if mesh_args.get("overlap"):        # the overlapped form of the iteration (boundary slices, second stream)
             os.environ["PFEM_MULTI_OVERLAP"] = "1"
-        mesh, dm, conn_loc, xyz_new, edof_g, rs, re = _rank_setup(rank, world, mesh_args, H)
-        s = pf.PetscSolver().initialise(re - rs, dm.size_global, row_start=rs, device=0)
+        devgen = mesh_args.get("mode") == "devgen"     # the rank's slab generated on the device (bench.py's path), any axis
+        if devgen:
+            b = mesh_args["box"]
+            cells = (b[2], b[5], b[8])
+            axis = "xyz".index(mesh_args["partition"][0]) if mesh_args["partition"] in ("xslabs", "yslabs") else 2
+            sz = H.box_slab_sizes(*cells, mesh_args["bc_mode"], mesh_args["ndof"], world, rank, axis=axis)
+            rs, re = sz["row_start"], sz["row_start"] + sz["size_local"]
+            s = pf.PetscSolver().initialise(sz["size_local"], sz["size_global"], row_start=rs, device=0)
+        else:
+            mesh, dm, conn_loc, xyz_new, edof_g, rs, re = _rank_setup(rank, world, mesh_args, H)
+            s = pf.PetscSolver().initialise(re - rs, dm.size_global, row_start=rs, device=0)
         s.setTolerances(rtol=1e-10)
         if mesh_args.get("pc"):
             s.setPreconditioner(mesh_args["pc"])
@@ -216,7 +263,12 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
         if mesh_args.get("single"):         # KSPCGUseSingleReduction: one all-reduce (of three scalars) per iteration
             s.setSingleReduction(True)
         ed = H.ELAST_ELEMDATA if kind == pf.ELAST_TET else H.POISSON_ELEMDATA
-        if mesh_args.get("mode", "batched") == "batched":
+        if devgen:
+            s.generateBoxMesh(kind, *mesh_args["box"], bc_mode=mesh_args["bc_mode"], nparts=world, part=rank, axis=axis)
+            hooks = PD.attach(s, dist, torch, staged=True)
+            s.buildPattern()
+            s.assemble(ed, H.TIMEDATA)
+        elif mesh_args.get("mode", "batched") == "batched":
             s.uploadMesh(kind, conn_loc, xyz_new, edof_g, dm.solnApplied)
             hooks = PD.attach(s, dist, torch, staged=True)
             s.buildPattern()
@@ -275,7 +327,10 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                                                             ("poisson", 2, "foreign", "batched"), ("elast", 3, "foreign", "compat"),
                                                             ("poisson", 3, "rcb", "batched"), ("elast", 3, "rcb", "overlap"),
                                                             ("poisson", 2, "slabs", "single"), ("elast", 3, "sectors", "single"),
-                                                            ("poisson", 3, "rcb", "single_overlap"), ("elast", 3, "idle", "single")])
+                                                            ("poisson", 3, "rcb", "single_overlap"), ("elast", 3, "idle", "single"),
+                                                            ("poisson", 3, "yslabs", "batched"), ("elast", 3, "yslabs", "devgen"),
+                                                            ("poisson", 2, "xslabs", "devgen"), ("poisson", 3, "slabs", "devgen"),
+                                                            ("elast", 2, "xslabs", "batched")])
 def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partition, mode):
     """2-3 ranks share cuda:0 (host-staged exchange over gloo): the product's multi-rank device loop against the
     ORACLE -- a direct solve of the oracle-assembled global system in the partition's new numbering, and the oracle's
@@ -289,6 +344,8 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
                  {"box": (-0.5, 0.5, 3, 0.0, 3.0, 8, -0.5, 0.5, 6), "bc_mode": 1, "ndof": 3})
     mesh_args["partition"] = partition
     mesh_args["mode"] = mode
+    if mode == "devgen":              # bench.py's path: every rank generates its slab (along the partition's axis) on the device
+        mesh_args["mode"] = "devgen"
     if world == 3 or mode != "batched":   # the row-group SpMV forms ("auto" keeps systems this small in the row form)
         mesh_args["spmv"] = "grouped"
     if mode == "pbjacobi":            # node-block Jacobi on several ranks (blocks of shared nodes summed, groups voted)

@@ -514,6 +514,60 @@ def test_device_generated_box_equals_host_generator_and_bookkeeping(kind, box, b
         assert np.array_equal(a.getRHS(), b.getRHS())
 
 
+@pytest.mark.parametrize("kind,box,bc_mode,nparts,axis", [(pf.POISSON_TET, (6, 5, 7), 0, 3, 0), (pf.POISSON_TET, (6, 5, 7), 0, 2, 1),
+                                                          (pf.ELAST_TET, (3, 7, 4), 1, 3, 1), (pf.ELAST_TET, (5, 3, 4), 1, 2, 0),
+                                                          (pf.ELAST_TET, (3, 7, 4), 1, 3, -1), (pf.POISSON_TET, (4, 4, 4), 0, 2, -1)])
+def test_device_generated_box_along_any_axis_equals_host_path(kind, box, bc_mode, nparts, axis):
+    """pfem_mesh_generate_box_axis: slabs of hex layers across x or y (BASELINE config 4's beam is cut across its length)
+    renumber the mesh like the reference does for any partition (tetrapoissonparallelimpl1.F:541-612: ranks concatenated,
+    ascending old id inside a rank) -- no longer the identity.  The device evaluates that numbering in closed form;
+    here it is compared with the host path driven by the same node_proc_id (pfem_partition_box_slabs_axis,
+    pfem_dof_numbering, pfem_renumber_mesh, pfem_elem_dof_array, pfem_mesh_upload): connectivity, coordinates,
+    prescribed values through the node map, the element dof array, the ghosts, then pattern, K and F -- bit for bit."""
+    nEx, nEy, nEz = box
+    ndof = 3 if kind == pf.ELAST_TET else 1
+    ext = (-1.0, 1.0, nEx, -0.5, 1.5, nEy, 0.0, 3.0, nEz)
+    ed = H.ELAST_ELEMDATA if kind == pf.ELAST_TET else H.POISSON_ELEMDATA
+    mesh = H.gen_box_tets(*ext, bc_mode=bc_mode, ndof=ndof)
+    epid, npid = H.partition_box_slabs(nEx, nEy, nEz, nparts, axis=axis)
+    dm = H.dof_numbering(mesh.nNode, ndof, mesh.bc_node, mesh.bc_dof, mesh.bc_val, nparts, npid)
+    conn_new, xyz_new = H.renumber_mesh(mesh, dm)
+    used = None
+    for part in range(nparts):
+        sz = H.box_slab_sizes(nEx, nEy, nEz, bc_mode, ndof, nparts, part, axis=axis)
+        used = sz["axis"]
+        assert used == (axis if axis >= 0 else (1 if box == (3, 7, 4) else 2))            # the longest axis, ties to z
+        a = pf.PetscSolver().initialise(sz["size_local"], sz["size_global"], row_start=sz["row_start"])
+        a.generateBoxMesh(kind, *ext, bc_mode=bc_mode, nparts=nparts, part=part, axis=axis)
+        conn_a, xyz_a, edof_a, sa_a = a.downloadMesh()
+        # local node (x-fastest over the slab's node box) -> old id -> new id
+        l0, l1 = sz["layer0"], sz["layer1"]
+        rng = [np.arange(nEx + 1), np.arange(nEy + 1), np.arange(nEz + 1)]
+        rng[used] = np.arange(l0, l1 + 1)
+        kk, jj, ii = np.meshgrid(rng[2], rng[1], rng[0], indexing="ij")
+        old = ((kk * (nEy + 1) + jj) * (nEx + 1) + ii).ravel()
+        new = dm.node_map_get_new[old]
+        mine = np.nonzero(epid == part)[0]
+        conn_loc = np.ascontiguousarray(conn_new[:, mine])
+        assert np.array_equal(new[conn_a], conn_loc)
+        assert np.array_equal(xyz_a, xyz_new[:, new])
+        assert np.array_equal(sa_a.reshape(-1, ndof), dm.solnApplied.reshape(-1, ndof)[new])
+        edof = H.elem_dof_array(conn_loc, dm.NodeDofArrayNew)
+        b = pf.PetscSolver().initialise(sz["size_local"], sz["size_global"], row_start=sz["row_start"])
+        b.uploadMesh(kind, conn_loc, xyz_new, edof, dm.solnApplied)
+        _, _, edof_b, _ = b.downloadMesh()
+        assert np.array_equal(edof_a, edof_b)
+        assert np.array_equal(a.ghosts(), b.ghosts())
+        assert (sz["row_start"], sz["row_start"] + sz["size_local"]) == (dm.row_start[part], dm.row_end[part])
+        for s in (a, b):
+            s.buildPattern()
+            s.assemble(ed, H.TIMEDATA)
+        for x, y in zip(a.getCSR(), b.getCSR()):
+            assert np.array_equal(x, y)
+        assert np.array_equal(a.getRHS(), b.getRHS())
+        assert np.array_equal(a.localToGlobal(), b.localToGlobal())
+
+
 @pytest.mark.parametrize("form", ["dictionary", "gap32"])
 def test_relative_row_groups_beyond_16bit_gaps(form, monkeypatch):
     """A plane of more than 65 535 free nodes (here 257^2; BASELINE config 5's slabs have 399^2): the z-neighbour is further
