@@ -59,8 +59,14 @@ def lib() -> C.CDLL:
     return _lib
 
 
+def ref_available() -> bool:
+    """Is the flang-compiled reference built?  Does NOT load it (a skipif may ask at import time)."""
+    return os.path.exists(os.path.join(_HERE, "_ref", "libpfem_ref.so"))
+
+
 def ref_lib():
-    """The flang-compiled reference routines, or None when not built."""
+    """The flang-compiled reference routines, or None when not built.  Loaded on first use only, by the CPU tests that
+    pin the restatement against it; nothing in the GPU suite calls this."""
     global _ref
     if _ref is None:
         path = os.path.join(_HERE, "_ref", "libpfem_ref.so")

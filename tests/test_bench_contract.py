@@ -85,7 +85,7 @@ def test_config5_at_full_size_with_eight_ranks_sharing_the_device():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1])
     assert d["config"]["free_dofs"] == 63521199 and d["config"]["elements"] == 384000000 and d["n_gpus"] == 8
-    assert d["converged_reason"] == 2 and abs(d["iterations"] - 720) <= 5 and d["max_nodal_error"] < 2.5e-4
+    assert d["converged_reason"] == 2 and abs(d["iterations"] - 720) <= 5 and d["max_nodal_error"] < 3e-4
     sc = d["strong_cfg5"]               # N = 8: the weak configuration IS config 5 -- the same run, read against one GPU
     assert sc["is_baseline_config5"] and sc["same_run_as_value"] and sc["single_gpu_ms_per_step"] > 1900
     assert abs(sc["speedup_vs_single_gpu"] - sc["single_gpu_ms_per_step"] / d["ms_per_step"]) < 1e-9
@@ -106,7 +106,7 @@ def test_config5_at_full_size_alone_on_one_device():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1])
     assert d["config"]["free_dofs"] == 63521199 and d["config"]["elements"] == 384000000 and d["n_gpus"] == 1
-    assert d["converged_reason"] == 2 and abs(d["iterations"] - 720) <= 2 and d["max_nodal_error"] < 2.5e-4
+    assert d["converged_reason"] == 2 and abs(d["iterations"] - 720) <= 2 and d["max_nodal_error"] < 3e-4
     # the parity setting at full size: rtol 1e-10 leaves only the error of the "%.8f" boundary data
     pt = d["parity_tolerance_step"]
     assert pt["converged_reason"] == 2 and pt["max_nodal_error"] < 2e-7 and 1250 < pt["iterations"] < 1400

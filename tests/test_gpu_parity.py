@@ -551,7 +551,11 @@ def test_device_generated_box_along_any_axis_equals_host_path(kind, box, bc_mode
         conn_loc = np.ascontiguousarray(conn_new[:, mine])
         assert np.array_equal(new[conn_a], conn_loc)
         assert np.array_equal(xyz_a, xyz_new[:, new])
-        assert np.array_equal(sa_a.reshape(-1, ndof), dm.solnApplied.reshape(-1, ndof)[new])
+        # prescribed values: the reference re-enters them at the new ids WITHOUT clearing the old slots (:668-677, SURVEY
+        # A.2 step 4 -- only Dirichlet-typed slots are ever read), the device never writes those stale entries
+        dirichlet = dm.NodeDofArrayNew[new] < 0
+        assert np.array_equal(sa_a.reshape(-1, ndof)[dirichlet], dm.solnApplied.reshape(-1, ndof)[new][dirichlet])
+        assert not sa_a.reshape(-1, ndof)[~dirichlet].any()
         edof = H.elem_dof_array(conn_loc, dm.NodeDofArrayNew)
         b = pf.PetscSolver().initialise(sz["size_local"], sz["size_global"], row_start=sz["row_start"])
         b.uploadMesh(kind, conn_loc, xyz_new, edof, dm.solnApplied)

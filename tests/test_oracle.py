@@ -51,7 +51,7 @@ def test_elast_tria_bit_exact_vs_reference_golden(gold, golden_dir):
     assert np.abs(K - K.transpose(0, 2, 1)).max() < 1e-12 * np.abs(K).max()
 
 
-@pytest.mark.skipif(O.ref_lib() is None, reason="oracle/_ref not built (needs /root/reference + flang)")
+@pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (needs /root/reference + flang)")
 def test_elements_bit_exact_vs_live_reference(tet10):
     for kind, ed in ((O.POISSON_TET, O.POISSON_ELEMDATA), (O.ELAST_TET, O.ELAST_ELEMDATA)):
         K, F = O.eval_elems(kind, tet10.xyz, tet10.conn[:, :500], ed)
