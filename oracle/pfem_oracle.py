@@ -333,6 +333,96 @@ def pcg_bjacobi_ilu0(rowptr, cols, vals, b, block_start=None, rtol=1e-5, abstol=
     return x, its.value, reason.value, rn.value
 
 
+def pcg_amg(rowptr, cols, vals, b, aggregates, cheb_degree=2, eig_ratio=8.0, coarse_scale=1.0, rtol=1e-5, abstol=1e-50, dtol=1e5,
+            maxits=10000, dense_limit=128, coarsest_sweeps=8):
+    """CG preconditioned by one V(1,1) cycle of plain-aggregation multigrid: the restatement of the product's -pc_type gamg
+    solve (pfemfort_amd/csrc/pfem_amg.inc) in numpy / scipy.sparse, GIVEN the aggregates (``aggregates[l][i]`` = coarse dof
+    of dof i of level l; the product forms them by pairwise matching and hands them over for this check).  Everything else
+    is restated: piecewise-constant prolongation P, Galerkin operators P^T A P, Chebyshev smoothing of degree
+    ``cheb_degree`` on D^-1 A over [lmax/eig_ratio, lmax] with lmax = max_i sum_j |a_ij| / a_ii (Gershgorin), a dense solve
+    on the last level when it has at most ``dense_limit`` rows (else Chebyshev of degree ``coarsest_sweeps``), and the PCG
+    loop with PETSc's KSPCG semantics (preconditioned norm, test after the update).
+    Returns (x, its, reason, rnorm, history)."""
+    import scipy.sparse as sp
+    N = len(rowptr) - 1
+    A = sp.csr_matrix((np.asarray(vals, dtype=np.float64), np.asarray(cols), np.asarray(rowptr)), shape=(N, N))
+    levels = [A]
+    P = []
+    for agg in aggregates:
+        agg = np.asarray(agg, dtype=np.int64)
+        nc = int(agg.max()) + 1
+        Pl = sp.csr_matrix((np.ones(len(agg)), (np.arange(len(agg)), agg)), shape=(len(agg), nc))
+        P.append(Pl)
+        levels.append((Pl.T @ levels[-1] @ Pl).tocsr())
+    dinv, lam = [], []
+    for Al in levels:
+        d = Al.diagonal()
+        dinv.append(1.0 / d)
+        lam.append(float((abs(Al) @ np.ones(Al.shape[0]) / d).max()))
+    dense = len(levels) > 1 and levels[-1].shape[0] <= dense_limit
+    Ainv = np.linalg.inv(levels[-1].toarray()) if dense else None
+
+    def smooth(l, x, rhs, deg):
+        Al, d = levels[l], dinv[l]
+        lmax = lam[l]; lmin = lmax / eig_ratio
+        theta, delta = 0.5 * (lmax + lmin), 0.5 * (lmax - lmin)
+        sigma = theta / delta
+        rho = 1.0 / sigma
+        r = rhs.copy() if x is None else rhs - Al @ x
+        dd = d * r / theta
+        x = dd.copy() if x is None else x + dd
+        for _ in range(1, deg):
+            r = r - Al @ dd
+            rho_new = 1.0 / (2.0 * sigma - rho)
+            dd = rho_new * rho * dd + (2.0 * rho_new / delta) * (d * r)
+            x = x + dd
+            rho = rho_new
+        return x
+
+    def cycle(l, rhs):
+        if l == len(levels) - 1:
+            if dense:
+                return Ainv @ rhs
+            return smooth(l, None, rhs, cheb_degree if len(levels) == 1 else coarsest_sweeps)
+        x = smooth(l, None, rhs, cheb_degree)
+        rc = P[l].T @ (rhs - levels[l] @ x)
+        x = x + coarse_scale * (P[l] @ cycle(l + 1, rc))
+        return smooth(l, x, rhs, cheb_degree)
+
+    b = _f64(b)
+    x = np.zeros(N)
+    r = b.copy()
+    z = cycle(0, r)
+    beta = float(r @ z)
+    rn0 = float(np.sqrt(z @ z))
+    hist = [rn0]
+    if rn0 <= abstol:
+        return x, 0, 3, rn0, np.array(hist)
+    ttol = max(rtol * rn0, abstol)
+    p = z.copy()
+    for it in range(1, maxits + 1):
+        w = A @ p
+        pw = float(p @ w)
+        if not pw > 0.0:
+            return x, it - 1, -10, hist[-1], np.array(hist)
+        alpha = beta / pw
+        x += alpha * p
+        r -= alpha * w
+        z = cycle(0, r)
+        bn = float(r @ z)
+        rn = float(np.sqrt(z @ z))
+        hist.append(rn)
+        if rn <= ttol:
+            return x, it, 2, rn, np.array(hist)
+        if rn >= dtol * rn0:
+            return x, it, -4, rn, np.array(hist)
+        if bn < 0.0:
+            return x, it, -8, rn, np.array(hist)
+        p = z + (bn / beta) * p
+        beta = bn
+    return x, maxits, -3, hist[-1], np.array(hist)
+
+
 def row_groups(rowptr, cols, max_rows=3):
     """First rows of the row groups a node-block preconditioner works on: consecutive rows with identical
     column sets (the dof rows of a node), at most ``max_rows`` per group; last entry = number of rows."""

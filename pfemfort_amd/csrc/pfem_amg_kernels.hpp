@@ -1,0 +1,494 @@
+// pfem_amg_kernels.hpp -- gfx950 kernels of the aggregation-multigrid preconditioner (-pc_type gamg; pfem_amg.inc holds the
+// host side and the design notes).  Included by pfem_kernels.hpp's users after it; everything lives in namespace pfem.
+#pragma once
+
+namespace pfem {
+
+// ---------------------------------------------------------------------------
+// symbolic phase: strength graph, pairwise matching, aggregates, Galerkin maps
+// ---------------------------------------------------------------------------
+// Symmetric priority of the edge {i,j} of the strength graph: a node proposes to its best free neighbour and two nodes
+// that propose to each other are matched (locally dominant edges: the maximal edge is always mutual, so every round
+// makes progress).  Priority, most significant first: (1) the coupling strength s = -w_ij / sqrt(w_ii w_jj) in eighths
+// of an octave -- couplings that differ by rounding only tie; (2) index distance, closer first: on a mesh numbered
+// line by line this makes ties pair along the numbering direction, so three passes build 2x2x2 bricks instead of random
+// octets; (3) parity of the lower index: of the two neighbours of a node on a line exactly one forms an "even" edge, so
+// the whole line pairs up in ONE round; (4) a hash of the pair.  Positive couplings (w >= 0) are not eligible.
+__device__ __forceinline__ int64_t amg_edge_key(int32_t i, int32_t j, double w, double di, double dj)
+{
+    if (!(w < 0.0) || !(di > 0.0) || !(dj > 0.0)) return -1;
+    const double s = -w / sqrt(di * dj);
+    int b = static_cast<int>(floor(8.0 * log2(s))) + 2048;
+    b = b < 1 ? 1 : (b > 4095 ? 4095 : b);
+    const int64_t lo = i < j ? i : j, hi = i < j ? j : i;
+    const int64_t close = 0x7fffffffLL - (hi - lo);
+    const int64_t par = (lo & 1) == 0;
+    const int64_t h = ((lo * 2654435761LL + hi * 40503LL) >> 7) & 0x7ffffLL;
+    return (static_cast<int64_t>(b) << 51) | (close << 20) | (par << 19) | h;
+}
+
+// every free node proposes to its best free neighbour
+__global__ void __launch_bounds__(kBlock) k_amg_match_pick(int64_t n, const int64_t *__restrict__ gptr, const int32_t *__restrict__ gcol,
+                                                            const double *__restrict__ gw, const double *__restrict__ gdiag,
+                                                            const int32_t *__restrict__ match, int32_t *__restrict__ cand)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    int32_t best = -1;
+    if (match[i] < 0) {
+        int64_t bk = -1;
+        const double di = gdiag[i];
+        for (int64_t q = gptr[i]; q < gptr[i + 1]; ++q) {
+            const int32_t j = gcol[q];
+            if (j == i || match[j] >= 0) continue;
+            const int64_t k = amg_edge_key(static_cast<int32_t>(i), j, gw[q], di, gdiag[j]);
+            if (k > bk) { bk = k; best = j; }
+        }
+    }
+    cand[i] = best;
+}
+
+// mutual proposals become pairs (root = the lower index)
+__global__ void __launch_bounds__(kBlock) k_amg_match_commit(int64_t n, const int32_t *__restrict__ cand, int32_t *__restrict__ match)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int32_t j = cand[i];
+    if (j >= 0 && cand[j] == static_cast<int32_t>(i)) match[i] = j < i ? j : static_cast<int32_t>(i);
+}
+
+// nodes left over stay alone; flag the roots
+__global__ void __launch_bounds__(kBlock) k_amg_match_finish(int64_t n, int32_t *__restrict__ match, int32_t *__restrict__ is_root)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    if (match[i] < 0) match[i] = static_cast<int32_t>(i);
+    is_root[i] = match[i] == static_cast<int32_t>(i);
+}
+
+// aggregate id of a node = rank of its root among the roots; composed with the map of the earlier passes
+__global__ void __launch_bounds__(kBlock) k_amg_agg_ids(int64_t n, const int32_t *__restrict__ match, const int32_t *__restrict__ root_rank,
+                                                         int32_t *__restrict__ agg)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n) agg[i] = root_rank[match[i]];
+}
+__global__ void __launch_bounds__(kBlock) k_amg_compose(int64_t n, int32_t *__restrict__ total, const int32_t *__restrict__ step)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n) total[i] = step[total[i]];
+}
+__global__ void __launch_bounds__(kBlock) k_amg_iota(int64_t n, int32_t *__restrict__ v)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n) v[i] = static_cast<int32_t>(i);
+}
+
+// first-pass strength graph of a matrix whose dofs are grouped in nodes (node_of, up to `bs` dofs each): one key per
+// stored entry, (node(row) << 32 | node(col)) with the SQUARED entry (reduced by key, then -sqrt: the Frobenius norm of
+// the node block).  Padding entries of the wave-sliced storage get the sentinel key.
+__global__ void __launch_bounds__(kBlock) k_amg_emit_node_keys(SellDev A, const int32_t *__restrict__ node_of, uint64_t *__restrict__ keys,
+                                                                double *__restrict__ vals)
+{
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;      // one thread per row, entries strided by 64
+    if (t >= A.n_slices * 64) return;
+    const int64_t sl = t >> 6;
+    const int64_t off = A.slice_off[sl];
+    const int width = static_cast<int>((A.slice_off[sl + 1] - off) >> 6);
+    const int len = t < A.n_rows ? A.rowlen[t] : 0;
+    const int32_t nr = t < A.n_rows ? node_of[t] : 0;
+    for (int k = 0; k < width; ++k) {
+        const int64_t q = off + 64LL * k + (t & 63);
+        if (k < len) {
+            const double v = A.vals[q];
+            keys[q] = (static_cast<uint64_t>(static_cast<uint32_t>(nr)) << 32) | static_cast<uint32_t>(node_of[A.cols[q]]);
+            vals[q] = v * v;
+        } else {
+            keys[q] = ~0ull;
+            vals[q] = 0.0;
+        }
+    }
+}
+
+// reduced node keys -> graph arrays: columns, weights (-norm off the diagonal), diagonal norms
+__global__ void __launch_bounds__(kBlock) k_amg_graph_from_keys(int64_t m, const uint64_t *__restrict__ ukeys, const double *__restrict__ sums,
+                                                                 int squared, int32_t *__restrict__ gcol, double *__restrict__ gw,
+                                                                 double *__restrict__ gdiag)
+{
+    const int64_t q = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (q >= m) return;
+    const uint64_t k = ukeys[q];
+    const int32_t r = static_cast<int32_t>(k >> 32), c = static_cast<int32_t>(k & 0xffffffffu);
+    const double v = sums[q];
+    gcol[q] = c;
+    if (r == c) {
+        gdiag[r] = squared ? sqrt(v) : v;
+        gw[q] = 0.0;
+    } else {
+        gw[q] = squared ? -sqrt(v) : v;
+    }
+}
+
+// the graph of the next matching pass: edge {i,j} -> {agg(i), agg(j)}, weights summed by key afterwards.  Entry q of the
+// CSR graph; the diagonal rides along as one more key per node (index nnz + i).  An edge INSIDE an aggregate adds to the
+// aggregate's diagonal (Galerkin) for scalar problems; for node blocks, whose weights are norms, it is dropped.
+__global__ void __launch_bounds__(kBlock) k_amg_emit_coarse_graph(int64_t n, int64_t nnz, const int64_t *__restrict__ gptr,
+                                                                   const int32_t *__restrict__ gcol, const double *__restrict__ gw,
+                                                                   const double *__restrict__ gdiag, const int32_t *__restrict__ agg,
+                                                                   int blocks, uint64_t *__restrict__ keys, double *__restrict__ vals)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t ai = static_cast<uint32_t>(agg[i]);
+    for (int64_t q = gptr[i]; q < gptr[i + 1]; ++q) {
+        const int32_t j = gcol[q];
+        const uint64_t aj = static_cast<uint32_t>(agg[j]);
+        keys[q] = (ai << 32) | aj;
+        vals[q] = (j == i) ? 0.0 : ((ai == aj && blocks) ? 0.0 : gw[q]);
+    }
+    keys[nnz + i] = (ai << 32) | ai;
+    vals[nnz + i] = gdiag[i];
+}
+
+// coarse dof of a fine dof: the (aggregate of its node, its component) pairs that occur, numbered in ascending order
+__global__ void __launch_bounds__(kBlock) k_amg_mark_cdofs(int64_t n, const int32_t *__restrict__ node_of, const int32_t *__restrict__ comp_of,
+                                                            const int32_t *__restrict__ node_agg, int bs, int32_t *__restrict__ flag)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int64_t nd = node_of ? node_of[i] : i;
+    flag[static_cast<int64_t>(node_agg[nd]) * bs + (comp_of ? comp_of[i] : 0)] = 1;
+}
+__global__ void __launch_bounds__(kBlock) k_amg_assign_cdofs(int64_t n, const int32_t *__restrict__ node_of, const int32_t *__restrict__ comp_of,
+                                                              const int32_t *__restrict__ node_agg, int bs, const int32_t *__restrict__ rank,
+                                                              int32_t *__restrict__ agg)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int64_t nd = node_of ? node_of[i] : i;
+    agg[i] = rank[static_cast<int64_t>(node_agg[nd]) * bs + (comp_of ? comp_of[i] : 0)];
+}
+// node / component of every coarse dof (the next level's node_of / comp_of)
+__global__ void __launch_bounds__(kBlock) k_amg_coarse_nodes(int64_t nslots, int bs, const int32_t *__restrict__ flag, const int32_t *__restrict__ rank,
+                                                              int32_t *__restrict__ node_of_c, int32_t *__restrict__ comp_of_c)
+{
+    const int64_t q = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (q >= nslots || !flag[q]) return;
+    node_of_c[rank[q]] = static_cast<int32_t>(q / bs);
+    comp_of_c[rank[q]] = static_cast<int32_t>(q % bs);
+}
+
+// component of a dof inside its node (row - first row of its group)
+__global__ void __launch_bounds__(kBlock) k_amg_comp_of(int64_t n, const int32_t *__restrict__ node_of, const int32_t *__restrict__ group_row0,
+                                                         int32_t *__restrict__ comp_of)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n) comp_of[i] = static_cast<int32_t>(i - group_row0[node_of[i]]);
+}
+// int32 run lengths -> int64 (one extra zero at the end), scanned in place afterwards
+__global__ void __launch_bounds__(kBlock) k_amg_widen(int64_t n_out, int64_t n_in, const int32_t *__restrict__ in, int64_t *__restrict__ out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n_out) out[i] = i < n_in ? in[i] : 0;
+}
+
+// members of every coarse dof: histogram, then (after the scan) the sorted member list comes from a stable sort by agg
+__global__ void __launch_bounds__(kBlock) k_amg_count(int64_t n, const int32_t *__restrict__ agg, int32_t *__restrict__ cnt)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n) atomicAdd(&cnt[agg[i]], 1);
+}
+
+// Galerkin product with piecewise-constant prolongation: coarse entry (agg(r), agg(c)) = sum of the fine entries that map
+// to it.  One key per stored fine entry with its storage slot as payload (sorted by key afterwards; the radix sort is
+// stable, so the slots of one coarse entry stay in ascending order: the numeric sum has a fixed order).
+__global__ void __launch_bounds__(kBlock) k_amg_emit_rap_keys(SellDev A, const int32_t *__restrict__ agg, uint64_t *__restrict__ keys,
+                                                               int32_t *__restrict__ slots)
+{
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (t >= A.n_slices * 64) return;
+    const int64_t sl = t >> 6;
+    const int64_t off = A.slice_off[sl];
+    const int width = static_cast<int>((A.slice_off[sl + 1] - off) >> 6);
+    const int len = t < A.n_rows ? A.rowlen[t] : 0;
+    const uint64_t ar = t < A.n_rows ? static_cast<uint32_t>(agg[t]) : 0u;
+    for (int k = 0; k < width; ++k) {
+        const int64_t q = off + 64LL * k + (t & 63);
+        keys[q] = k < len ? ((ar << 32) | static_cast<uint32_t>(agg[A.cols[q]])) : ~0ull;
+        slots[q] = static_cast<int32_t>(q);
+    }
+}
+
+// storage slot of every coarse entry (unique keys in ascending order = row-major order of the coarse matrix)
+__global__ void __launch_bounds__(kBlock) k_amg_dst_slots(int64_t nnz_c, const uint64_t *__restrict__ ukeys, const int64_t *__restrict__ rowptr,
+                                                           const int64_t *__restrict__ slice_off, int64_t *__restrict__ dst)
+{
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (c >= nnz_c) return;
+    const int64_t row = static_cast<int64_t>(ukeys[c] >> 32);
+    dst[c] = slice_off[row >> 6] + 64LL * (c - rowptr[row]) + (row & 63);
+}
+
+// ---------------------------------------------------------------------------
+// numeric phase (every solve): coarse values, smoother data, the dense inverse of the coarsest operator
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_amg_galerkin(int64_t nnz_c, const int64_t *__restrict__ src_ptr, const int32_t *__restrict__ src_slot,
+                                                          const int64_t *__restrict__ dst, const double *__restrict__ fine_vals,
+                                                          double *__restrict__ coarse_vals)
+{
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (c >= nnz_c) return;
+    double a = 0.0;
+    for (int64_t q = src_ptr[c]; q < src_ptr[c + 1]; ++q) a += fine_vals[src_slot[q]];
+    coarse_vals[dst[c]] = a;
+}
+
+// inverse diagonal and the Gershgorin bound max_i sum_j |a_ij| / a_ii >= lambda_max(D^-1 A), one pass over the matrix
+__global__ void __launch_bounds__(kBlock) k_amg_diag_bound(SellDev A, double *__restrict__ dinv, double *__restrict__ part_max)
+{
+    __shared__ double sm[4];
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    double ratio = 0.0;
+    if (r < A.n_slices * 64) {
+        const int64_t sl = r >> 6;
+        const int64_t off = A.slice_off[sl];
+        const int width = static_cast<int>((A.slice_off[sl + 1] - off) >> 6);
+        double d = 0.0, s = 0.0;
+        for (int k = 0; k < width; ++k) {
+            const int64_t q = off + 64LL * k + (r & 63);
+            const double v = A.vals[q];
+            if (A.cols[q] == static_cast<int32_t>(r) && v != 0.0) d += v;      // padding points at the own row with value 0
+            s += fabs(v);
+        }
+        if (r < A.n_rows) {
+            const bool ok = d > 0.0;
+            dinv[r] = ok ? 1.0 / d : 1.0;
+            ratio = ok ? s / d : 1.0;
+        }
+    }
+    // block maximum (wave shuffles, then the four waves)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ratio = fmax(ratio, __shfl_xor(ratio, o, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = ratio;
+    __syncthreads();
+    if (threadIdx.x == 0) part_max[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+}
+__global__ void __launch_bounds__(1024) k_amg_max(const double *__restrict__ part, int64_t n, double *out)
+{
+    __shared__ double sm[16];
+    double a = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) a = fmax(a, part[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a = fmax(a, __shfl_xor(a, o, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t = fmax(t, sm[w]);
+        out[0] = t;
+    }
+}
+
+// coarsest operator (n <= kAmgDense rows) -> dense, inverted in LDS by Gauss-Jordan without pivoting (SPD), one block
+constexpr int kAmgDense = 128;
+__global__ void __launch_bounds__(1024) k_amg_dense_inverse(SellDev A, double *__restrict__ inv)
+{
+    extern __shared__ double M[];                   // n x n
+    __shared__ double colp[kAmgDense];
+    const int n = static_cast<int>(A.n_rows);
+    for (int q = threadIdx.x; q < n * n; q += 1024) M[q] = 0.0;
+    __syncthreads();
+    for (int r = threadIdx.x; r < n; r += 1024) {
+        const int64_t base = A.slice_off[r >> 6] + (r & 63);
+        const int len = A.rowlen[r];
+        for (int k = 0; k < len; ++k) M[r * n + A.cols[base + 64LL * k]] = A.vals[base + 64LL * k];
+    }
+    __syncthreads();
+    for (int p = 0; p < n; ++p) {
+        const double piv = 1.0 / M[p * n + p];
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 1024) colp[i] = M[i * n + p];
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += 1024)
+            if (j != p) M[p * n + j] *= piv;
+        __syncthreads();
+        for (int q = threadIdx.x; q < n * n; q += 1024) {
+            const int i = q / n, j = q - i * n;
+            if (i != p && j != p) M[q] = __builtin_fma(-colp[i], M[p * n + j], M[q]);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 1024) M[i * n + p] = i == p ? piv : -colp[i] * piv;
+        __syncthreads();
+    }
+    for (int q = threadIdx.x; q < n * n; q += 1024) inv[q] = M[q];
+}
+// x = inv * b (one block, one thread per row; the inverse of an SPD matrix is symmetric: column access is coalesced)
+__global__ void __launch_bounds__(kAmgDense) k_amg_dense_apply(int n, const double *__restrict__ inv, const double *__restrict__ b,
+                                                                double *__restrict__ x, const CgCtl *ctl)
+{
+    __shared__ double sb[kAmgDense];
+    if (ctl && ctl->flag != 0) return;
+    const int i = threadIdx.x;
+    if (i < n) sb[i] = b[i];
+    __syncthreads();
+    if (i >= n) return;
+    double a = 0.0;
+    for (int j = 0; j < n; ++j) a = __builtin_fma(inv[j * n + i], sb[j], a);
+    x[i] = a;
+}
+
+// ---------------------------------------------------------------------------
+// V-cycle vector kernels.  Chebyshev smoothing on D^-1 A over [lmax/ratio, lmax] (lmax: device scalar `lam`):
+//   theta = (lmax+lmin)/2, delta = (lmax-lmin)/2, sigma = theta/delta, rho_0 = 1/sigma, rho_k = 1/(2 sigma - rho_{k-1})
+//   d_0 = D^-1 r / theta,  d_k = rho_k rho_{k-1} d_{k-1} + 2 rho_k/delta D^-1 (r - A(d_0+...+d_{k-1}))    x += d_k
+// Every kernel leaves at once when the solve has finished (the tail of a chunk of enqueued iterations).
+// ---------------------------------------------------------------------------
+struct ChebCoef { double c_first, c_dd, c_r; };
+__device__ __forceinline__ ChebCoef cheb_coef(double lmax, double ratio, int step)
+{
+    const double lmin = lmax / ratio, theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+    double rho = 1.0 / sigma, rho_new = rho;
+    ChebCoef c{1.0 / theta, 0.0, 0.0};
+    for (int k = 1; k <= step; ++k) {
+        rho_new = 1.0 / (2.0 * sigma - rho);
+        c.c_dd = rho_new * rho;
+        c.c_r = 2.0 * rho_new / delta;
+        rho = rho_new;
+    }
+    return c;
+}
+
+// step 0.  zero_guess: r = b, x = dd = D^-1 b / theta.  Else t = A x on entry: r = b - t (stored when more steps follow),
+// dd = D^-1 r / theta, x += dd.
+__global__ void __launch_bounds__(kBlock) k_amg_cheb_first(int64_t n, const double *__restrict__ b, const double *__restrict__ t,
+                                                            const double *__restrict__ dinv, const double *__restrict__ lam, double ratio,
+                                                            double *__restrict__ r_out, double *__restrict__ dd, double *__restrict__ x,
+                                                            const CgCtl *ctl)
+{
+    if (ctl && ctl->flag != 0) return;
+    const ChebCoef c = cheb_coef(lam[0], ratio, 0);
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const double ri = t ? b[i] - t[i] : b[i];
+        const double di = c.c_first * dinv[i] * ri;
+        if (r_out) r_out[i] = ri;
+        dd[i] = di;
+        x[i] = t ? x[i] + di : di;
+    }
+}
+// step k >= 1.  t = A dd on entry: r -= t, dd = c_dd dd + c_r D^-1 r, x += dd.  `r_in` may be the right-hand side itself
+// (zero-guess pre-smoothing: the residual before this step is b); r_out / dd_out null when no step follows.
+__global__ void __launch_bounds__(kBlock) k_amg_cheb_next(int64_t n, int step, const double *r_in, const double *__restrict__ t,
+                                                           const double *__restrict__ dinv, const double *__restrict__ lam, double ratio,
+                                                           double *r_out, const double *dd_in, double *dd_out,      // in / out may be one array
+                                                           double *__restrict__ x, const CgCtl *ctl)
+{
+    if (ctl && ctl->flag != 0) return;
+    const ChebCoef c = cheb_coef(lam[0], ratio, step);
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const double ri = r_in[i] - t[i];
+        const double di = __builtin_fma(c.c_dd, dd_in[i], c.c_r * dinv[i] * ri);
+        if (r_out) r_out[i] = ri;
+        if (dd_out) dd_out[i] = di;
+        x[i] += di;
+    }
+}
+
+// restriction of the residual b - t (t = A x): the right-hand side of the next level, one thread per coarse dof.  The
+// member indices of an aggregate (up to 8 from three passes of pairing) are fetched first, then all values: 16 loads in
+// flight per lane instead of a chain of dependent pairs; summed in ascending member order either way.
+__global__ void __launch_bounds__(kBlock) k_amg_restrict(int64_t nc, const int32_t *__restrict__ mem_ptr, const int32_t *__restrict__ mem_idx,
+                                                          const double *__restrict__ b, const double *__restrict__ t, double *__restrict__ bc,
+                                                          const CgCtl *ctl)
+{
+    if (ctl && ctl->flag != 0) return;
+    const int64_t a = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (a >= nc) return;
+    const int q0 = mem_ptr[a], q1 = mem_ptr[a + 1];
+    double acc = 0.0;
+    int q = q0;
+    for (; q + 8 <= q1; q += 8) {
+        int idx[8];
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) idx[k] = mem_idx[q + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = b[idx[k]] - t[idx[k]];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += v[k];
+    }
+    if (q < q1) {
+        int idx[8];
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) idx[k] = q + k < q1 ? mem_idx[q + k] : -1;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = idx[k] >= 0 ? b[idx[k]] - t[idx[k]] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (idx[k] >= 0) acc += v[k];
+    }
+    bc[a] = acc;
+}
+// coarse-grid correction x += scale * P xc
+__global__ void __launch_bounds__(kBlock) k_amg_prolong(int64_t n, const int32_t *__restrict__ agg, const double *__restrict__ xc, double scale,
+                                                         double *__restrict__ x, const CgCtl *ctl)
+{
+    if (ctl && ctl->flag != 0) return;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock)
+        x[i] = __builtin_fma(scale, xc[agg[i]], x[i]);
+}
+
+// ---------------------------------------------------------------------------
+// PCG with a stored z = M^-1 r (the V-cycle writes it): PETSc KSPCG semantics as in k_cg_update / k_cg_direction
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_pc_init(int64_t n, const double *__restrict__ b, double *__restrict__ x, double *__restrict__ r)
+{
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        x[i] = 0.0;
+        r[i] = b[i];
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_pc_copy(int64_t n, const double *__restrict__ z, double *__restrict__ p)
+{
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) p[i] = z[i];
+}
+// alpha = beta/(p,w); x += alpha p; r -= alpha w.  A breakdown (p,w) <= 0 is handed to the dots kernel through ctl->pad_.
+__global__ void __launch_bounds__(kBlock) k_pc_update(CgCtl *ctl, int it, int64_t n, const double *part_pw, int nparts,
+                                                       const double *__restrict__ p, const double *__restrict__ w, double *__restrict__ x,
+                                                       double *__restrict__ r)
+{
+    __shared__ double sm[4];
+    if (ctl->flag != 0) return;
+    const double pw = sum_partials(part_pw, nparts, sm);
+    if (!(pw > 0.0)) {                      // KSP_DIVERGED_INDEFINITE_MAT
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->its = it; ctl->pad_ = 1; }
+        return;
+    }
+    const double alpha = ctl->beta[it & 1] / pw;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        x[i] = __builtin_fma(alpha, p[i], x[i]);
+        r[i] = __builtin_fma(-alpha, w[i], r[i]);
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_pc_dots(const CgCtl *ctl, int64_t n, int64_t n_owned, const double *__restrict__ r,
+                                                     const double *__restrict__ z, double *part_rz, double *part_zz)
+{
+    __shared__ double sm[4];
+    if (ctl && ctl->flag != 0) return;
+    if (ctl && ctl->pad_ != 0) {            // breakdown flagged by k_pc_update: k_cg_direction_b turns zz < 0 into -10
+        if (threadIdx.x == 0) { part_rz[blockIdx.x] = 0.0; part_zz[blockIdx.x] = -1.0; }
+        return;
+    }
+    double rz = 0.0, zz = 0.0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        if (i < n_owned) {
+            const double zi = z[i];
+            rz = __builtin_fma(r[i], zi, rz);
+            zz = __builtin_fma(zi, zi, zz);
+        }
+    }
+    const double a = block_sum(rz, sm), c = block_sum(zz, sm);
+    if (threadIdx.x == 0) { part_rz[blockIdx.x] = a; part_zz[blockIdx.x] = c; }
+}
+
+}  // namespace pfem

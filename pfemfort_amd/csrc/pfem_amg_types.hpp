@@ -1,0 +1,40 @@
+// pfem_amg_types.hpp -- data of the aggregation-multigrid preconditioner (see pfem_amg.inc); included by pfem_device.hip
+// after DevBuf and before the solver object, which owns one hierarchy.
+#pragma once
+
+struct AmgLevel {
+    int64_t n = 0, n_slices = 0, stored = 0, nnz = 0;
+    bool fine = false;                    // level 0: the solver's own matrix (and its SpMV forms)
+    // matrix of a coarse level: wave-sliced CSR like the fine one, int32 columns
+    DevBuf<int64_t> slice_off, rowptr;
+    DevBuf<int32_t> rowlen, cols;
+    DevBuf<double> vals;
+    // dofs grouped in nodes (elasticity: 3 per node): null = every dof its own node
+    int bs = 1;
+    int64_t n_nodes = 0;
+    DevBuf<int32_t> node_of, comp_of;
+    // transfer to the next level (piecewise-constant prolongation)
+    int64_t nc = 0;
+    DevBuf<int32_t> agg;                  // [n]  coarse dof of every dof
+    DevBuf<int32_t> mem_ptr, mem_idx;     // [nc+1], [n]  members of every coarse dof, ascending
+    // numeric Galerkin product into the next level
+    int64_t nnz_c = 0;
+    DevBuf<int64_t> src_ptr;              // [nnz_c+1]
+    DevBuf<int32_t> src_slot;             // storage slots of this level's matrix, grouped by coarse entry
+    DevBuf<int64_t> dst_slot;             // [nnz_c] storage slot in the next level's matrix
+    // smoother and work vectors (x and dd are SpMV inputs: on level 0 they carry the guard bands of the fast SpMV forms)
+    DevBuf<double> dinv, t, r, b, x_store, dd_store, lam, part_max;
+    double *x = nullptr, *dd = nullptr;
+    double lam_host = 0.0;
+};
+
+struct Amg {
+    std::vector<std::unique_ptr<AmgLevel>> lev;      // lev[0] = fine ... lev.back() = coarsest
+    DevBuf<double> dense_inv;                        // inverse of the coarsest operator (n <= kAmgDense)
+    bool dense = false;
+    bool symbolic_ok = false;
+    double symbolic_ms = 0.0, numeric_ms = 0.0;
+    int cheb_degree = 2;
+    double eig_ratio = 8.0, coarse_scale = 1.5;       // over-correction of the piecewise-constant coarse space (Braess 1995)
+    int coarsest_sweeps = 8;                         // Chebyshev degree on the last level when it is too large for the dense inverse
+};

@@ -20,10 +20,12 @@
 #include <mutex>
 #include <string>
 #include <deque>
+#include <memory>
 #include <vector>
 
 #include "pfem_internal.hpp"
 #include "pfem_kernels.hpp"
+#include "pfem_amg_kernels.hpp"
 
 using namespace pfem;
 
@@ -151,6 +153,8 @@ struct DevBuf {
         return PFEM_OK;
     }
 };
+
+#include "pfem_amg_types.hpp"
 
 constexpr size_t kMaxLdsBytes = 163840;       // LDS a single gfx950 workgroup may declare (MI355X_MICROARCH.md)
 
@@ -304,6 +308,7 @@ struct pfem_solver {
         double *p = nullptr;
     } d_p;
     int pc = PFEM_PC_JACOBI;
+    std::unique_ptr<Amg> amg;      // -pc_type gamg: the hierarchy (pfem_amg.inc); rebuilt when the pattern changes
     DevBuf<double> d_binv[3];      // node-block Jacobi: row (i - r0) of the inverse diagonal block, columns 0..2
     DevBuf<double> d_r2, d_z;      // ... second residual buffer (ping-pong), z = Binv r, per-row (first row | size << 30)
     // single-reduction CG (pfem_solver_set_cg_single_reduction): z is the SpMV input (guarded), s = A z, and a second
@@ -813,6 +818,7 @@ int pattern_from_keys(pfem_solver *s, DevBuf<uint64_t> &keys, int64_t nkeys)
     s->cg_graph_key.clear();               // every array a captured CG iteration points at is about to be replaced
     s->mgraph_key.clear();
     s->slices_fmt = -1;                    // ... and the boundary / interior slice lists belong to the old pattern
+    if (s->amg) s->amg->symbolic_ok = false;   // ... and so does the multigrid hierarchy
     PFEM_TRY(use_sort_bits(s));
     const int end_bit = s->sort_end_bit;
     DevBuf<uint64_t> sorted;
@@ -1676,7 +1682,7 @@ extern "C" int pfem_solver_get_spmv_gap_table(pfem_solver *s, int *entries)
 
 extern "C" int pfem_solver_set_preconditioner(pfem_solver *s, int pc)
 {
-    if (!s || (pc != PFEM_PC_JACOBI && pc != PFEM_PC_NODE_BLOCK_JACOBI)) return PFEM_ERR_ARG;
+    if (!s || (pc != PFEM_PC_JACOBI && pc != PFEM_PC_NODE_BLOCK_JACOBI && pc != PFEM_PC_GAMG)) return PFEM_ERR_ARG;
     s->pc = pc;
     return PFEM_OK;
 }
@@ -1691,7 +1697,7 @@ extern "C" int pfem_solver_set_cg_single_reduction(pfem_solver *s, int on)
 extern "C" int pfem_solver_get_preconditioner(pfem_solver *s, int *pc_in_effect)
 {
     if (!s || !pc_in_effect) return PFEM_ERR_ARG;
-    *pc_in_effect = s->block_pc() ? PFEM_PC_NODE_BLOCK_JACOBI : PFEM_PC_JACOBI;
+    *pc_in_effect = (s->pc == PFEM_PC_GAMG && s->nranks == 1) ? PFEM_PC_GAMG : (s->block_pc() ? PFEM_PC_NODE_BLOCK_JACOBI : PFEM_PC_JACOBI);
     return PFEM_OK;
 }
 
@@ -2327,6 +2333,7 @@ int spmv_exchange(pfem_solver *s, const double *xin, double *yout, double *part_
 // Jacobi-preconditioned CG on the device (KSPSolve, solverpetsc.F:476)
 // ---------------------------------------------------------------------------
 int run_pcg_single(pfem_solver *s);
+#include "pfem_amg.inc"
 
 inline bool want_single_reduction(const pfem_solver *s)
 {
@@ -2364,6 +2371,7 @@ int agree_overlap(pfem_solver *s, bool multi, bool *overlap)
 int run_pcg(pfem_solver *s)
 {
     // the single-reduction form exists for point Jacobi only; node-block Jacobi keeps the two-reduction loop
+    if (amg_in_effect(s)) return run_pcg_amg(s);
     if (want_single_reduction(s) && s->pc != PFEM_PC_NODE_BLOCK_JACOBI) return run_pcg_single(s);
     const int64_t n = s->n_loc;
     // test knob PFEM_FORCE_MULTI: a single rank with a backend and an (empty) plan takes the multi-rank loop too
@@ -3235,6 +3243,51 @@ extern "C" int pfem_solver_get_history(pfem_solver *s, double *hist, int n, int 
         PFEM_HIP(hipStreamSynchronize(s->stream));
     }
     *n_written = std::max(avail, 0);
+    return PFEM_OK;
+}
+
+// ---- -pc_type gamg: what the hierarchy looks like, its aggregates (for the oracle's restatement), its knobs ------------
+extern "C" int pfem_solver_amg_info(pfem_solver *s, int max_levels, int *n_levels, int64_t *rows, int64_t *nnz, double *lambda_max,
+                                    double *symbolic_ms, double *numeric_ms, int *cheb_degree, double *eig_ratio, double *coarse_scale)
+{
+    if (!s || !n_levels) return PFEM_ERR_ARG;
+    *n_levels = 0;
+    if (!s->amg || !s->amg->symbolic_ok) return PFEM_OK;
+    PFEM_TRY(use_device(s));
+    const Amg &M = *s->amg;
+    *n_levels = static_cast<int>(M.lev.size());
+    for (int l = 0; l < *n_levels && l < max_levels; ++l) {
+        const AmgLevel &L = *M.lev[static_cast<size_t>(l)];
+        if (rows) rows[l] = L.n;
+        if (nnz) nnz[l] = L.nnz;
+        if (lambda_max) PFEM_HIP(hipMemcpy(&lambda_max[l], L.lam.p, sizeof(double), hipMemcpyDeviceToHost));
+    }
+    if (symbolic_ms) *symbolic_ms = M.symbolic_ms;
+    if (numeric_ms) *numeric_ms = M.numeric_ms;
+    if (cheb_degree) *cheb_degree = M.cheb_degree;
+    if (eig_ratio) *eig_ratio = M.eig_ratio;
+    if (coarse_scale) *coarse_scale = M.coarse_scale;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_amg_aggregates(pfem_solver *s, int level, int32_t *agg)
+{
+    if (!s || !agg || level < 0) return PFEM_ERR_ARG;
+    if (!s->amg || !s->amg->symbolic_ok || static_cast<size_t>(level) + 1 >= s->amg->lev.size()) return PFEM_ERR_STATE;
+    PFEM_TRY(use_device(s));
+    const AmgLevel &L = *s->amg->lev[static_cast<size_t>(level)];
+    PFEM_HIP(hipMemcpy(agg, L.agg.p, sizeof(int32_t) * static_cast<size_t>(L.n), hipMemcpyDeviceToHost));
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_set_amg_options(pfem_solver *s, int cheb_degree, double eig_ratio, double coarse_scale)
+{
+    if (!s || cheb_degree < 1 || cheb_degree > 6 || !(eig_ratio > 1.0) || !(coarse_scale > 0.0)) return PFEM_ERR_ARG;
+    if (!s->amg) s->amg.reset(new (std::nothrow) Amg());
+    if (!s->amg) return PFEM_ERR_NOMEM;
+    s->amg->cheb_degree = cheb_degree;
+    s->amg->eig_ratio = eig_ratio;
+    s->amg->coarse_scale = coarse_scale;
     return PFEM_OK;
 }
 

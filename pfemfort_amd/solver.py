@@ -204,8 +204,9 @@ class PetscSolver:
         return b.value
 
     def setPreconditioner(self, pc):
-        """"jacobi" (default; PCJACOBI) or "pbjacobi" (node-block Jacobi, PETSc's -pc_type pbjacobi)."""
-        L.check(L.lib().pfem_solver_set_preconditioner(self._h, {"jacobi": 0, "pbjacobi": 1}[pc]), "pfem_solver_set_preconditioner")
+        """"jacobi" (default; PCJACOBI), "pbjacobi" (node-block Jacobi, PETSc's -pc_type pbjacobi) or "gamg" (plain-aggregation
+        multigrid V-cycle, PETSc's -pc_type gamg; one rank)."""
+        L.check(L.lib().pfem_solver_set_preconditioner(self._h, {"jacobi": 0, "pbjacobi": 1, "gamg": 2}[pc]), "pfem_solver_set_preconditioner")
 
     def setSingleReduction(self, on=True):
         """KSPCGUseSingleReduction (-ksp_cg_single_reduction): one all-reduce per CG iteration instead of two
@@ -217,7 +218,28 @@ class PetscSolver:
         """The preconditioner the next solve uses ("pbjacobi" needs 3-dof row groups and one rank)."""
         b = C.c_int(0)
         L.check(L.lib().pfem_solver_get_preconditioner(self._h, C.byref(b)), "pfem_solver_get_preconditioner")
-        return ("jacobi", "pbjacobi")[b.value]
+        return ("jacobi", "pbjacobi", "gamg")[b.value]
+
+    def setAmgOptions(self, cheb_degree=2, eig_ratio=8.0, coarse_scale=1.0):
+        """-pc_gamg knobs: Chebyshev degree, lmax/lmin of the smoothing interval, scaling of the coarse-grid correction."""
+        L.check(L.lib().pfem_solver_set_amg_options(self._h, cheb_degree, eig_ratio, coarse_scale), "pfem_solver_set_amg_options")
+
+    def amgInfo(self):
+        """The multigrid hierarchy of the last ``gamg`` solve: rows / nonzeros / eigenvalue bound per level, phase times."""
+        mx = 16
+        nl = C.c_int(0); rows = (C.c_int64 * mx)(); nnz = (C.c_int64 * mx)(); lam = (C.c_double * mx)()
+        sym = C.c_double(0); num = C.c_double(0); deg = C.c_int(0); ratio = C.c_double(0); scale = C.c_double(0)
+        L.check(L.lib().pfem_solver_amg_info(self._h, mx, C.byref(nl), rows, nnz, lam, C.byref(sym), C.byref(num), C.byref(deg),
+                                             C.byref(ratio), C.byref(scale)), "pfem_solver_amg_info")
+        n = nl.value
+        return {"levels": n, "rows": list(rows[:n]), "nnz": list(nnz[:n]), "lambda_max": list(lam[:n]), "symbolic_ms": sym.value,
+                "numeric_ms": num.value, "cheb_degree": deg.value, "eig_ratio": ratio.value, "coarse_scale": scale.value}
+
+    def amgAggregates(self, level, n_rows):
+        """Coarse dof of every dof of ``level`` (``n_rows`` = amgInfo()["rows"][level])."""
+        a = np.empty(n_rows, np.int32)
+        L.check(L.lib().pfem_solver_amg_aggregates(self._h, level, _p(a)), "pfem_solver_amg_aggregates")
+        return a
 
     def spmvRowGroup(self):
         """Rows served by one lane of the current SpMV (3: row-grouped form)."""

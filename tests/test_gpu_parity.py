@@ -782,3 +782,110 @@ def test_row_forms_beyond_16bit_gaps(table, monkeypatch):
         assert (its, reason) == (its_o, reason_o) == (60, -3)
         assert np.abs(s.getSolution() - xo).max() <= 1e-9 * np.abs(xo).max()
         assert np.allclose(s.getHistory()[:61], hist_o, rtol=1e-8)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# -pc_type gamg: plain-aggregation multigrid as the preconditioner of the CG (pfem_amg.inc)
+# ---------------------------------------------------------------------------------------------------------------
+def _gamg_vs_oracle(s, rtol=1e-10):
+    """Solve with gamg on the device, then restate the SAME solve on the CPU (oracle.pcg_amg) with the aggregates the
+    device formed: iteration count, residual history and solution."""
+    s.setTolerances(rtol=rtol, maxits=10000)
+    s.setPreconditioner("gamg")
+    its, reason, rn = s.factoriseAndSolve()
+    assert s.preconditioner() == "gamg"
+    info = s.amgInfo()
+    aggs = [s.amgAggregates(l, info["rows"][l]) for l in range(info["levels"] - 1)]
+    rowptr, cols, vals = s.getCSR()
+    xo, ito, ro, rno, hist = O.pcg_amg(rowptr, cols, vals, s.getRHS(), aggs, cheb_degree=info["cheb_degree"], eig_ratio=info["eig_ratio"],
+                                       coarse_scale=info["coarse_scale"], rtol=rtol)
+    x = s.getSolution()
+    h = s.getHistory()
+    assert (reason, ro) == (2, 2) and abs(its - ito) <= 1, (its, ito)
+    m = min(len(h), len(hist), 30)       # rounding differences grow along a long CG run (Cook's membrane: 100+ iterations)
+    assert np.abs(h[:m] - hist[:m]).max() <= 1e-6 * hist[0]
+    assert np.abs(x - xo).max() <= 1e-9 * max(1.0, np.abs(xo).max())
+    return its, info, aggs, x
+
+
+@pytest.mark.parametrize("case", ["tet10", "cube30", "beam", "cook", "compat"])
+def test_gamg_solve_equals_oracle_restatement(case, tet10, beam, golden_dir):
+    """-pc_type gamg on file meshes and generated boxes, scalar and 3-dof problems, the batched and the MatSetValues path:
+    the device hierarchy (matching aggregates, Galerkin sums, Gershgorin bounds, Chebyshev V-cycle, dense bottom solve) and
+    its PCG loop against the oracle's restatement given the same aggregates; against a direct solve; fewer iterations than
+    point Jacobi; aggregates are what three passes of pairing can produce."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    if case == "compat":
+        res = pf.tetrapoissonparallelimpl1(tet10, mode="compat", rtol=1e-10)
+        s, its_j = res.solver, res.its
+    else:
+        kind, mesh, ed = {"tet10": (pf.POISSON_TET, tet10, H.POISSON_ELEMDATA),
+                          "cube30": (pf.POISSON_TET, H.gen_box_tets(-1, 1, 30, -1, 1, 30, -1, 1, 30), H.POISSON_ELEMDATA),
+                          "beam": (pf.ELAST_TET, beam, H.ELAST_ELEMDATA),
+                          "cook": (pf.ELAST_TRIA, H.read_mesh(f"{golden_dir}/input/cookmembranetria32"), H.ELAST2D_ELEMDATA)}[case]
+        s, dm = _device_problem(kind, mesh, ed)
+        if case == "beam":
+            s.setSpmvFormat("grouped")          # the 3-row node groups (and with them the node-wise aggregation) at this size too
+            s.buildPattern()
+            s.assemble(ed, H.TIMEDATA)
+        if case == "cook" and mesh.force_node is not None:
+            s.addNodalForces(dm.NodeDofArrayNew[dm.node_map_get_new[mesh.force_node], mesh.force_dof], mesh.force_val)
+        s.setTolerances(rtol=1e-10, maxits=20000)
+        its_j, reason_j, _ = s.factoriseAndSolve()
+        assert reason_j == 2
+    its, info, aggs, x = _gamg_vs_oracle(s)
+    assert its < its_j, (its, its_j)
+    rowptr, cols, vals = s.getCSR()
+    u = spl.spsolve(sp.csr_matrix((vals, cols, rowptr)).tocsc(), s.getRHS())
+    assert np.abs(x - u).max() <= 1e-8 * max(1.0, np.abs(u).max())
+    # hierarchy: every level at least 1.25x smaller, the last one small enough for the dense inverse; aggregates of at most
+    # 8 nodes (x 3 dofs each on the beam, whose dofs stay with their node)
+    rows = info["rows"]
+    assert info["levels"] >= 2 and all(10 * b <= 8 * a for a, b in zip(rows, rows[1:])) and rows[-1] <= 128
+    bs = 3 if case == "beam" else 1
+    for a, n_c in zip(aggs, rows[1:]):
+        cnt = np.bincount(a)
+        assert len(cnt) == n_c and cnt.min() >= 1 and cnt.max() <= 8
+    if case == "beam":                          # the three dofs of a node share their aggregate, one coarse dof per component
+        a0 = aggs[0].reshape(-1, 3)
+        assert np.array_equal(a0[:, 1], a0[:, 0] + 1) and np.array_equal(a0[:, 2], a0[:, 0] + 2) and not (a0[:, 0] % 3).any()
+    if case == "cube30":                        # a lattice numbered line by line: mostly 2x2x2 bricks
+        assert (np.bincount(aggs[0]) == 8).mean() > 0.7 and its <= 0.3 * its_j
+    assert all(1.0 < lam < 8.0 for lam in info["lambda_max"])
+
+
+def test_gamg_reasons_and_reuse():
+    """KSP reasons through the gamg loop (0 iterations on b = 0, the iteration limit), a second solve with NEW values on
+    the same pattern (aggregates reused, Galerkin sums redone: the solution scales with the operator), and a new pattern
+    (hierarchy rebuilt)."""
+    mesh = H.gen_box_tets(-1, 1, 14, -1, 1, 12, -1, 1, 10)
+    s, dm = _device_problem(pf.POISSON_TET, mesh, H.POISSON_ELEMDATA)
+    s.setPreconditioner("gamg")
+    s.setTolerances(rtol=1e-10)
+    its, reason, _ = s.factoriseAndSolve()
+    x1 = s.getSolution()
+    sym1 = s.amgInfo()["symbolic_ms"]
+    assert reason == 2 and its < 25
+    s.setTolerances(rtol=1e-10, maxits=2)
+    assert s.factoriseAndSolve()[:2] == (2, -3)
+    s.setTolerances(rtol=1e-10)
+    s.assemble(np.array([2.0, 2.0, 2.0]), H.TIMEDATA)              # kx = ky = kz = 2: K doubles; so does the lifted part of F
+    rhs2 = s.getRHS()
+    its2, reason2, _ = s.factoriseAndSolve()
+    assert reason2 == 2 and abs(its2 - its) <= 1 and s.amgInfo()["symbolic_ms"] == sym1          # same aggregates
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    rowptr, cols, vals = s.getCSR()
+    u2 = spl.spsolve(sp.csr_matrix((vals, cols, rowptr)).tocsc(), rhs2)
+    assert np.abs(s.getSolution() - u2).max() <= 1e-8 * np.abs(u2).max() and np.abs(x1).max() > 0
+    s.buildPattern()                                                # a new pattern: the hierarchy is rebuilt
+    s.assemble(H.POISSON_ELEMDATA, H.TIMEDATA)
+    its3, reason3, _ = s.factoriseAndSolve()
+    assert (its3, reason3) == (its, 2) and np.array_equal(s.getSolution(), x1)
+    # b = 0 (the beam without its body force): converged before the first iteration, KSP_CONVERGED_ATOL
+    ed0 = H.ELAST_ELEMDATA.copy()
+    ed0[3:] = 0.0
+    z, _ = _device_problem(pf.ELAST_TET, H.gen_box_tets(-0.5, 0.5, 3, 0.0, 6.0, 12, -0.5, 0.5, 3, bc_mode=1, ndof=3), ed0)
+    z.setPreconditioner("gamg")
+    assert z.factoriseAndSolve()[:2] == (0, 3) and not z.getSolution().any()

@@ -182,3 +182,28 @@ def test_single_reduction_pcg_restatement(tet10, tria20):
     r1 = O.pcg_jacobi_single_reduction(v2.indptr.astype(np.int64), v2.indices.astype(np.int32), v2.data, p.rhs, rtol=1e-12)
     r2 = O.pcg_jacobi(v2.indptr.astype(np.int64), v2.indices.astype(np.int32), v2.data, p.rhs, rtol=1e-12)
     assert r1[2] == r2[2] == -10                                                              # indefinite matrix
+
+
+def test_amg_pcg_restatement(tet10):
+    """The oracle's restatement of the product's -pc_type gamg solve (oracle.pcg_amg: Galerkin operators from GIVEN
+    aggregates, Chebyshev smoothing with the Gershgorin bound, V(1,1) cycle, dense solve at the bottom, PETSc's KSPCG
+    stopping rule): an SPD preconditioner, so CG converges to the direct solution in fewer iterations than with the
+    diagonal; with no coarse level at all the cycle is the Chebyshev polynomial of D^-1 A."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    prob = O.setup_problem(O.POISSON_TET, tet10)
+    A = sp.csr_matrix((prob.vals, prob.cols, prob.rowptr))
+    u = spl.spsolve(A.tocsc(), prob.rhs)
+    _, its_j, *_ = O.pcg_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-10)
+    n = A.shape[0]                       # 729 = 9^3 free nodes: bricks of 2x2x2 nodes, then pairs of bricks
+    i = np.arange(n)
+    brick = ((i // 81) // 2) * 25 + (((i // 9) % 9) // 2) * 5 + (i % 9) // 2
+    aggs = [brick, np.arange(125) // 2]
+    x, its, reason, rn, hist = O.pcg_amg(prob.rowptr, prob.cols, prob.vals, prob.rhs, aggs, rtol=1e-10)
+    assert reason == 2 and its < its_j // 2 and len(hist) == its + 1 and hist[-1] == rn <= 1e-10 * hist[0]
+    assert np.abs(x - u).max() <= 1e-9 * np.abs(u).max()
+    x1, its1, reason1, *_ = O.pcg_amg(prob.rowptr, prob.cols, prob.vals, prob.rhs, [], rtol=1e-10)
+    assert reason1 == 2 and its < its1 < its_j and np.abs(x1 - u).max() <= 1e-9 * np.abs(u).max()
+    # stopping rule: zero right-hand side, iteration limit
+    assert O.pcg_amg(prob.rowptr, prob.cols, prob.vals, 0 * prob.rhs, aggs)[1:3] == (0, 3)
+    assert O.pcg_amg(prob.rowptr, prob.cols, prob.vals, prob.rhs, aggs, rtol=1e-14, maxits=3)[1:3] == (3, -3)
