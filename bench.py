@@ -197,7 +197,12 @@ def parse_args():
                          "config 5 at the default 200 -- on the same N ranks) reported as `strong_cfg5`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-step", action="store_true", help="skip the extra (untimed) step at rtol 1e-10")
-    ap.add_argument("--pc", choices=["jacobi", "pbjacobi"], default="jacobi")
+    ap.add_argument("--pc", choices=["jacobi", "pbjacobi", "gamg"], default="gamg",
+                    help="preconditioner of the CG (PCSetType, solverpetsc.F:206; the reference: PCBJACOBI/ILU(0)).  gamg (default): "
+                         "plain-aggregation multigrid V-cycle, on several ranks block Jacobi over the ranks with one hierarchy per "
+                         "rank; jacobi: the diagonal (north_star's baseline preconditioner; always measured too and reported as "
+                         "`jacobi_step`); pbjacobi: node-block Jacobi")
+    ap.add_argument("--no-jacobi-step", action="store_true", help="skip the extra point-Jacobi measurement reported as `jacobi_step`")
     ap.add_argument("--single-reduction", action="store_true",
                     help="KSPCGUseSingleReduction: one all-reduce per CG iteration instead of two (PETSc's opt-in form; off by default)")
     ap.add_argument("--backend", default="nccl", help="nccl: RCCL bound inside the library; gloo: host hooks (development)")
@@ -239,7 +244,7 @@ class Job:
         self.rccl_dead = False
 
 
-def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=False):
+def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=False, pc=None):
     """One configuration through the whole hot path on this job's ranks: device-generated slab, transport, pattern,
     `warmup` + `steps` steps (assembly + solve) bracketed by barriers; returns everything the JSON line needs."""
     import faulthandler
@@ -262,7 +267,8 @@ def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=Fa
     N, row_start, size_local = sz["size_global"], sz["row_start"], sz["size_local"]
     solver = pf.PetscSolver().initialise(size_local, N, row_start=row_start, device=J.device_index)
     solver.setTolerances(rtol=rtol, maxits=100000 if beam else 10000)
-    solver.setPreconditioner(args.pc)
+    pc = pc or args.pc
+    solver.setPreconditioner(pc)
     if args.single_reduction:
         solver.setSingleReduction(True)
     solver.generateBoxMesh(kind, *box, bc_mode=bc_mode, nparts=world, part=rank, axis=axis)
@@ -319,8 +325,8 @@ def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=Fa
     t1 = time.perf_counter()
     solver.buildPattern()
     R["t_pattern2"] = time.perf_counter() - t1
-    if profile:
-        solver.profileSpmv(8)        # event pair around every 8th SpMV launch of the timed solves (each pair costs ~2 us)
+    if profile:      # event pair around every 8th (gamg: every 2nd) SpMV launch of the CG loop of the timed solves (a pair costs ~2 us)
+        solver.profileSpmv(2 if pc == "gamg" else 8)
 
     def step():
         solver.assemble(elem_data, H.TIMEDATA)
@@ -401,6 +407,9 @@ def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=Fa
                        "dof_per_s": N / t10, "max_nodal_error": owned_check(solver.getSolution())[1]}
         solver.setTolerances(rtol=rtol, maxits=10000)
 
+    R["pc"] = pc
+    R["pc_in_effect"] = solver.preconditioner()
+    R["amg"] = solver.amgInfo() if R["pc_in_effect"] == "gamg" else None
     R.update(N=int(N), sz=sz, axis=axis, elapsed=elapsed, its=its, reason=reason, rnorm=rnorm, acc=acc, info=info,
              event_overhead_ms=tm["event_overhead_ms"] if tm else 0.0, cinfo=solver.commInfo(),
              fmt_bytes=solver.spmvFormatBytes(), gap_table=solver.spmvGapTable(), bits=solver.spmvColumnBits(),
@@ -499,6 +508,10 @@ def main():
     R = run_case(J, beam, nE, ext, args.steps, args.warmup, args.rtol, profile=True,
                  parity_step=(world == 1 and not args.no_parity_step and not beam))
     weak = not (beam or args.strong)
+    # ---- the same configuration with north_star's own preconditioner, the diagonal: a shorter, separately timed run
+    Jac = None
+    if R["pc"] != "jacobi" and not args.no_jacobi_step:
+        Jac = run_case(J, beam, nE, ext, max(1, min(args.steps, 3)), 1, args.rtol, profile=False, pc="jacobi")
     # ---- N > 1, weak run: the strong-scaling companion.  The cube of 2 x --cells per side (at the default 200: BASELINE
     # config 5, 400^3 x 6 tets, which fits ONE MI355X: profiles/r02/bench_cfg5_400cube_single_gpu.json) on the same N
     # ranks -- the >= 6x-at-8-GPUs evidence next to the weak figure, whose Jacobi iteration count grows with the problem.
@@ -559,10 +572,15 @@ def main():
                                     f"tetrapoissonparallelimpl1: [-1,1]^2x[{ext[4]:g},{ext[5]:g}] box, "
                                     f"{nEx}x{nEy}x{nEz}x6 P1 tets, u=x^2+y^2+z^2 Dirichlet on all faces, f=-6"),
                        "elements": 6 * nEx * nEy * nEz, "nodes": (nEx + 1) * (nEy + 1) * (nEz + 1), "free_dofs": int(N),
-                       "solver": f"CG{' (single-reduction form)' if args.single_reduction else ''} + {'node-block Jacobi (pbjacobi)' if args.pc == 'pbjacobi' else 'point Jacobi'}, zero initial guess, "
-                                 f"rtol {args.rtol:g} on ||M^-1 r|| (PETSc KSPCG default norm). The reference's PETSc run "
+                       "solver": f"CG{' (single-reduction form)' if args.single_reduction else ''} + " +
+                                 {"pbjacobi": "node-block Jacobi (pbjacobi)", "jacobi": "point Jacobi",
+                                  "gamg": "plain-aggregation multigrid V(1,1) cycle (-pc_type gamg: pairwise-matching aggregates, Galerkin coarse "
+                                          "operators re-summed in every solve, Chebyshev(2) smoothing, dense bottom solve" +
+                                          ("; block Jacobi over the ranks, one hierarchy per rank" if world > 1 else "") + ")"}[R["pc_in_effect"]] +
+                                 f", zero initial guess, rtol {args.rtol:g} on ||M^-1 r|| (PETSc KSPCG default norm). The reference's PETSc run "
                                  "used KSPCG + PCBJACOBI (per-rank ILU(0), solverpetsc.F:187,206), which is NOT reproduced: "
-                                 "iteration counts are not comparable with a PETSc run of the reference",
+                                 "iteration counts are not comparable with a PETSc run of the reference; north_star's CG + point Jacobi is "
+                                 "measured next to it (`jacobi_step`)",
                        "parallelism": "1 GPU" if world == 1 else
                                       f"{world} slabs of hex layers across {axis_name}, sub-assembled interface rows, neighbour exchange of "
                                       f"{cinfo['doubles_per_exchange']} doubles with {cinfo['n_peers']} neighbour(s) per SpMV "
@@ -576,6 +594,18 @@ def main():
                                                                    "symbolic_pattern_and_incidence_second_build": R["t_pattern2"],
                                                                    "hip_context_and_code_object_load_on_a_tiny_problem_not_in_setup": t_init},
             "parity_tolerance_step": R["parity"],
+            "preconditioner": ({"name": R["pc_in_effect"], "levels": R["amg"]["levels"], "rows_per_level": R["amg"]["rows"],
+                                "nnz_per_level": R["amg"]["nnz"], "gershgorin_lambda_max": R["amg"]["lambda_max"],
+                                "operator_complexity": sum(R["amg"]["nnz"]) / max(R["amg"]["nnz"][0], 1),
+                                "cheb_degree": R["amg"]["cheb_degree"], "eig_ratio": R["amg"]["eig_ratio"], "coarse_scale": R["amg"]["coarse_scale"],
+                                "numeric_setup_ms_per_solve_inside_the_timer": R["amg"]["numeric_ms"],
+                                "symbolic_setup_ms_once_per_pattern": R["amg"]["symbolic_ms"],
+                                "symbolic_setup_where": "first solve after a pattern build (a warm-up step; with --warmup 0 the first timed step)",
+                                "scope": "rank 0's block" if world > 1 else "the whole matrix"} if R["amg"] else {"name": R["pc_in_effect"]}),
+            "jacobi_step": ({"preconditioner": "point Jacobi (north_star's)", "steps": Jac["steps"], "warmup": Jac["warmup"],
+                             "ms_per_step": Jac["ms_per_step"], "dof_per_s": Jac["N"] / (Jac["ms_per_step"] * 1e-3), "iterations": Jac["its"],
+                             "converged_reason": Jac["reason"], "ms_per_iteration": Jac["ms_per_iteration"], Jac["check_name"]: Jac["check"],
+                             "speedup_of_value_over_it": Jac["ms_per_step"] / R["ms_per_step"]} if Jac else None),
             "device_memory_gb": {"in_use_rank0_device": round((R["mem"]["total_bytes"] - R["mem"]["free_bytes"]) / 1e9, 2),
                                  "total": round(R["mem"]["total_bytes"] / 1e9, 2)},
             "comm": comm_block(J, R) if world > 1 else None,
@@ -598,7 +628,7 @@ def main():
             # how to read an N > 1 line: (1) per-iteration efficiency -- rows per GPU and millisecond of iteration against
             # the committed N = 1 figure (independent of the iteration count, which Jacobi makes grow with the problem);
             # (2) the strong-scaling companion on BASELINE config 5
-            r1 = ref1.get("cfg3_200cube", {})
+            r1 = ref1.get("cfg3_200cube_" + R["pc_in_effect"], {})
             if r1.get("ms_per_iteration") and r1.get("free_dofs"):
                 rate1 = r1["free_dofs"] / r1["ms_per_iteration"]
                 out["per_iteration_efficiency"] = {
@@ -606,12 +636,12 @@ def main():
                     "definition": "(free dofs per GPU / ms per CG iteration) of this run / the same of the N=1 run",
                     "n1_ms_per_iteration": r1["ms_per_iteration"], "n1_free_dofs": r1["free_dofs"], "n1_source": r1.get("source")}
             if S is not None:
-                r5 = ref1.get("cfg5_400cube", {})
+                r5 = ref1.get("cfg5_400cube_" + S["pc_in_effect"], {})
                 is5 = S["nE"] == (400, 400, 400)
                 out["strong_cfg5"] = {
                     "workload": "tetrapoissonparallelimpl1: [-1,1]^3, %dx%dx%dx6 P1 tets%s" % (*S["nE"], " (BASELINE config 5)" if is5 else ""),
                     "is_baseline_config5": is5, "free_dofs": S["N"], "n_gpus": world, "steps": S["steps"], "warmup": S["warmup"],
-                    "same_run_as_value": S is R,
+                    "same_run_as_value": S is R, "preconditioner": S["pc_in_effect"],
                     "ms_per_step": S["ms_per_step"], "dof_per_s": S["N"] / (S["ms_per_step"] * 1e-3), "iterations": S["its"],
                     "converged_reason": S["reason"], "ms_per_iteration": S["ms_per_iteration"], S["check_name"]: S["check"],
                     "single_gpu_ms_per_step": r5.get("ms_per_step") if is5 else None,

@@ -333,16 +333,14 @@ def pcg_bjacobi_ilu0(rowptr, cols, vals, b, block_start=None, rtol=1e-5, abstol=
     return x, its.value, reason.value, rn.value
 
 
-def pcg_amg(rowptr, cols, vals, b, aggregates, cheb_degree=2, eig_ratio=8.0, coarse_scale=1.0, rtol=1e-5, abstol=1e-50, dtol=1e5,
-            maxits=10000, dense_limit=128, coarsest_sweeps=8):
-    """CG preconditioned by one V(1,1) cycle of plain-aggregation multigrid: the restatement of the product's -pc_type gamg
-    solve (pfemfort_amd/csrc/pfem_amg.inc) in numpy / scipy.sparse, GIVEN the aggregates (``aggregates[l][i]`` = coarse dof
-    of dof i of level l; the product forms them by pairwise matching and hands them over for this check).  Everything else
-    is restated: piecewise-constant prolongation P, Galerkin operators P^T A P, Chebyshev smoothing of degree
-    ``cheb_degree`` on D^-1 A over [lmax/eig_ratio, lmax] with lmax = max_i sum_j |a_ij| / a_ii (Gershgorin), a dense solve
-    on the last level when it has at most ``dense_limit`` rows (else Chebyshev of degree ``coarsest_sweeps``), and the PCG
-    loop with PETSc's KSPCG semantics (preconditioned norm, test after the update).
-    Returns (x, its, reason, rnorm, history)."""
+def amg_cycle(rowptr, cols, vals, aggregates, cheb_degree=2, eig_ratio=8.0, coarse_scale=1.5, dense_limit=128, coarsest_sweeps=8):
+    """z = M^-1 r of the product's -pc_type gamg (pfemfort_amd/csrc/pfem_amg.inc), restated in numpy / scipy.sparse GIVEN the
+    aggregates (``aggregates[l][i]`` = coarse dof of dof i of level l; the product forms them by pairwise matching and
+    hands them over for this check).  Everything else is restated: piecewise-constant prolongation P, Galerkin operators
+    P^T A P, Chebyshev smoothing of degree ``cheb_degree`` on D^-1 A over [lmax/eig_ratio, lmax] with the Gershgorin bound
+    lmax = max_i sum_j |a_ij| / a_ii, one symmetric V(1,1) cycle with the coarse correction scaled by ``coarse_scale``, a
+    dense solve on the last level when it has at most ``dense_limit`` rows (else Chebyshev of degree ``coarsest_sweeps``).
+    Returns the function r -> z."""
     import scipy.sparse as sp
     N = len(rowptr) - 1
     A = sp.csr_matrix((np.asarray(vals, dtype=np.float64), np.asarray(cols), np.asarray(rowptr)), shape=(N, N))
@@ -389,10 +387,19 @@ def pcg_amg(rowptr, cols, vals, b, aggregates, cheb_degree=2, eig_ratio=8.0, coa
         x = x + coarse_scale * (P[l] @ cycle(l + 1, rc))
         return smooth(l, x, rhs, cheb_degree)
 
+    return lambda r: cycle(0, r)
+
+
+def pcg_with(rowptr, cols, vals, b, M, rtol=1e-5, abstol=1e-50, dtol=1e5, maxits=10000):
+    """CG with PETSc's KSPCG semantics (zero initial guess, preconditioned norm, test after the update)
+    and ANY symmetric positive definite preconditioner ``M``: r -> z.  Returns (x, its, reason, rnorm, history)."""
+    import scipy.sparse as sp
+    N = len(rowptr) - 1
+    A = sp.csr_matrix((np.asarray(vals, dtype=np.float64), np.asarray(cols), np.asarray(rowptr)), shape=(N, N))
     b = _f64(b)
     x = np.zeros(N)
     r = b.copy()
-    z = cycle(0, r)
+    z = M(r)
     beta = float(r @ z)
     rn0 = float(np.sqrt(z @ z))
     hist = [rn0]
@@ -408,7 +415,7 @@ def pcg_amg(rowptr, cols, vals, b, aggregates, cheb_degree=2, eig_ratio=8.0, coa
         alpha = beta / pw
         x += alpha * p
         r -= alpha * w
-        z = cycle(0, r)
+        z = M(r)
         bn = float(r @ z)
         rn = float(np.sqrt(z @ z))
         hist.append(rn)
@@ -421,6 +428,29 @@ def pcg_amg(rowptr, cols, vals, b, aggregates, cheb_degree=2, eig_ratio=8.0, coa
         p = z + (bn / beta) * p
         beta = bn
     return x, maxits, -3, hist[-1], np.array(hist)
+
+
+def pcg_amg(rowptr, cols, vals, b, aggregates, cheb_degree=2, eig_ratio=8.0, coarse_scale=1.5, rtol=1e-5, abstol=1e-50, dtol=1e5,
+            maxits=10000, dense_limit=128, coarsest_sweeps=8):
+    """CG preconditioned by one V(1,1) cycle of plain-aggregation multigrid on the whole matrix: amg_cycle + pcg_with."""
+    M = amg_cycle(rowptr, cols, vals, aggregates, cheb_degree, eig_ratio, coarse_scale, dense_limit, coarsest_sweeps)
+    return pcg_with(rowptr, cols, vals, b, M, rtol, abstol, dtol, maxits)
+
+
+def pcg_bjacobi_amg(rowptr, cols, vals, b, blocks, rtol=1e-5, abstol=1e-50, dtol=1e5, maxits=10000, **amg):
+    """The product's multi-rank form of -pc_type gamg: block Jacobi over the ranks' row blocks, every block preconditioned by
+    the V-cycle of ITS OWN matrix -- ``blocks`` = [(row_start, (rowptr_r, cols_r, vals_r), aggregates_r), ...], where the block
+    matrix is the rank's owned diagonal block as the rank assembled it from its own elements (the interface rows lack the
+    neighbour's share; PETSc's PCBJACOBI would use the assembled block).  CG on the assembled global matrix."""
+    cyc = [(rs, len(m[0]) - 1, amg_cycle(*m, aggs, **amg)) for rs, m, aggs in blocks if len(m[0]) > 1]      # an idle rank has no block
+
+    def M(r):
+        z = np.zeros_like(r)
+        for rs, nr, c in cyc:
+            if nr:
+                z[rs:rs + nr] = c(r[rs:rs + nr])
+        return z
+    return pcg_with(rowptr, cols, vals, b, M, rtol, abstol, dtol, maxits)
 
 
 def row_groups(rowptr, cols, max_rows=3):

@@ -87,8 +87,8 @@ __global__ void __launch_bounds__(kBlock) k_amg_iota(int64_t n, int32_t *__restr
 // first-pass strength graph of a matrix whose dofs are grouped in nodes (node_of, up to `bs` dofs each): one key per
 // stored entry, (node(row) << 32 | node(col)) with the SQUARED entry (reduced by key, then -sqrt: the Frobenius norm of
 // the node block).  Padding entries of the wave-sliced storage get the sentinel key.
-__global__ void __launch_bounds__(kBlock) k_amg_emit_node_keys(SellDev A, const int32_t *__restrict__ node_of, uint64_t *__restrict__ keys,
-                                                                double *__restrict__ vals)
+__global__ void __launch_bounds__(kBlock) k_amg_emit_node_keys(SellDev A, const int32_t *__restrict__ node_of, int32_t col_limit, int squared,
+                                                                uint64_t *__restrict__ keys, double *__restrict__ vals)
 {
     const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;      // one thread per row, entries strided by 64
     if (t >= A.n_slices * 64) return;
@@ -96,13 +96,14 @@ __global__ void __launch_bounds__(kBlock) k_amg_emit_node_keys(SellDev A, const 
     const int64_t off = A.slice_off[sl];
     const int width = static_cast<int>((A.slice_off[sl + 1] - off) >> 6);
     const int len = t < A.n_rows ? A.rowlen[t] : 0;
-    const int32_t nr = t < A.n_rows ? node_of[t] : 0;
+    const int32_t nr = t < A.n_rows ? (node_of ? node_of[t] : static_cast<int32_t>(t)) : 0;
     for (int k = 0; k < width; ++k) {
         const int64_t q = off + 64LL * k + (t & 63);
-        if (k < len) {
+        const int32_t c = k < len ? A.cols[q] : col_limit;
+        if (c < col_limit) {                 // columns from col_limit on are another rank's dofs (ghosts): not in this block
             const double v = A.vals[q];
-            keys[q] = (static_cast<uint64_t>(static_cast<uint32_t>(nr)) << 32) | static_cast<uint32_t>(node_of[A.cols[q]]);
-            vals[q] = v * v;
+            keys[q] = (static_cast<uint64_t>(static_cast<uint32_t>(nr)) << 32) | static_cast<uint32_t>(node_of ? node_of[c] : c);
+            vals[q] = squared ? v * v : v;
         } else {
             keys[q] = ~0ull;
             vals[q] = 0.0;
@@ -202,8 +203,8 @@ __global__ void __launch_bounds__(kBlock) k_amg_count(int64_t n, const int32_t *
 // Galerkin product with piecewise-constant prolongation: coarse entry (agg(r), agg(c)) = sum of the fine entries that map
 // to it.  One key per stored fine entry with its storage slot as payload (sorted by key afterwards; the radix sort is
 // stable, so the slots of one coarse entry stay in ascending order: the numeric sum has a fixed order).
-__global__ void __launch_bounds__(kBlock) k_amg_emit_rap_keys(SellDev A, const int32_t *__restrict__ agg, uint64_t *__restrict__ keys,
-                                                               int32_t *__restrict__ slots)
+__global__ void __launch_bounds__(kBlock) k_amg_emit_rap_keys(SellDev A, const int32_t *__restrict__ agg, int32_t col_limit,
+                                                               uint64_t *__restrict__ keys, int32_t *__restrict__ slots)
 {
     const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (t >= A.n_slices * 64) return;
@@ -214,7 +215,8 @@ __global__ void __launch_bounds__(kBlock) k_amg_emit_rap_keys(SellDev A, const i
     const uint64_t ar = t < A.n_rows ? static_cast<uint32_t>(agg[t]) : 0u;
     for (int k = 0; k < width; ++k) {
         const int64_t q = off + 64LL * k + (t & 63);
-        keys[q] = k < len ? ((ar << 32) | static_cast<uint32_t>(agg[A.cols[q]])) : ~0ull;
+        const int32_t c = k < len ? A.cols[q] : col_limit;
+        keys[q] = c < col_limit ? ((ar << 32) | static_cast<uint32_t>(agg[c])) : ~0ull;     // ghost columns: not in this rank's block
         slots[q] = static_cast<int32_t>(q);
     }
 }
@@ -244,7 +246,7 @@ __global__ void __launch_bounds__(kBlock) k_amg_galerkin(int64_t nnz_c, const in
 }
 
 // inverse diagonal and the Gershgorin bound max_i sum_j |a_ij| / a_ii >= lambda_max(D^-1 A), one pass over the matrix
-__global__ void __launch_bounds__(kBlock) k_amg_diag_bound(SellDev A, double *__restrict__ dinv, double *__restrict__ part_max)
+__global__ void __launch_bounds__(kBlock) k_amg_diag_bound(SellDev A, int32_t col_limit, double *__restrict__ dinv, double *__restrict__ part_max)
 {
     __shared__ double sm[4];
     const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -257,8 +259,9 @@ __global__ void __launch_bounds__(kBlock) k_amg_diag_bound(SellDev A, double *__
         for (int k = 0; k < width; ++k) {
             const int64_t q = off + 64LL * k + (r & 63);
             const double v = A.vals[q];
-            if (A.cols[q] == static_cast<int32_t>(r) && v != 0.0) d += v;      // padding points at the own row with value 0
-            s += fabs(v);
+            const int32_t c = A.cols[q];
+            if (c == static_cast<int32_t>(r) && v != 0.0) d += v;      // padding points at the own row with value 0
+            if (c < col_limit) s += fabs(v);                           // ghost columns are not part of this rank's block
         }
         if (r < A.n_rows) {
             const bool ok = d > 0.0;
@@ -453,13 +456,13 @@ __global__ void __launch_bounds__(kBlock) k_pc_copy(int64_t n, const double *__r
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) p[i] = z[i];
 }
 // alpha = beta/(p,w); x += alpha p; r -= alpha w.  A breakdown (p,w) <= 0 is handed to the dots kernel through ctl->pad_.
-__global__ void __launch_bounds__(kBlock) k_pc_update(CgCtl *ctl, int it, int64_t n, const double *part_pw, int nparts,
+__global__ void __launch_bounds__(kBlock) k_pc_update(CgCtl *ctl, int it, int64_t n, const double *part_pw, int nparts, const double *reduced_pw,
                                                        const double *__restrict__ p, const double *__restrict__ w, double *__restrict__ x,
                                                        double *__restrict__ r)
 {
     __shared__ double sm[4];
     if (ctl->flag != 0) return;
-    const double pw = sum_partials(part_pw, nparts, sm);
+    const double pw = reduced_pw ? *reduced_pw : sum_partials(part_pw, nparts, sm);
     if (!(pw > 0.0)) {                      // KSP_DIVERGED_INDEFINITE_MAT
         if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->its = it; ctl->pad_ = 1; }
         return;

@@ -1697,7 +1697,7 @@ extern "C" int pfem_solver_set_cg_single_reduction(pfem_solver *s, int on)
 extern "C" int pfem_solver_get_preconditioner(pfem_solver *s, int *pc_in_effect)
 {
     if (!s || !pc_in_effect) return PFEM_ERR_ARG;
-    *pc_in_effect = (s->pc == PFEM_PC_GAMG && s->nranks == 1) ? PFEM_PC_GAMG : (s->block_pc() ? PFEM_PC_NODE_BLOCK_JACOBI : PFEM_PC_JACOBI);
+    *pc_in_effect = s->pc == PFEM_PC_GAMG ? PFEM_PC_GAMG : (s->block_pc() ? PFEM_PC_NODE_BLOCK_JACOBI : PFEM_PC_JACOBI);
     return PFEM_OK;
 }
 
@@ -2333,7 +2333,6 @@ int spmv_exchange(pfem_solver *s, const double *xin, double *yout, double *part_
 // Jacobi-preconditioned CG on the device (KSPSolve, solverpetsc.F:476)
 // ---------------------------------------------------------------------------
 int run_pcg_single(pfem_solver *s);
-#include "pfem_amg.inc"
 
 inline bool want_single_reduction(const pfem_solver *s)
 {
@@ -2367,6 +2366,8 @@ int agree_overlap(pfem_solver *s, bool multi, bool *overlap)
     *overlap = s->overlap_agreed == 1;
     return PFEM_OK;
 }
+
+#include "pfem_amg.inc"
 
 int run_pcg(pfem_solver *s)
 {

@@ -35,9 +35,15 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "DOF/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
     # the same configuration as the GPU number, at the reference's three timer points
-    assert "40^3" in cb["sample"] and abs(cb["total_s"] - cb["assembly_s"] - cb["solve_s"]) < 1e-9 and cb["its"] == d["iterations"]
+    assert "40^3" in cb["sample"] and abs(cb["total_s"] - cb["assembly_s"] - cb["solve_s"]) < 1e-9 and cb["its"] == d["jacobi_step"]["iterations"]
     assert d["parity_tolerance_step"]["rtol"] == 1e-10 and d["parity_tolerance_step"]["max_nodal_error"] < 1e-6
-    assert "PCBJACOBI" in d["config"]["solver"] and d["setup_breakdown_s"]["generate_mesh_and_numbering_on_device"] >= 0 and d["setup_s_untimed"] < 5
+    # the default preconditioner is the multigrid V-cycle; north_star's point Jacobi is measured next to it
+    pcb, js = d["preconditioner"], d["jacobi_step"]
+    assert pcb["name"] == "gamg" and pcb["levels"] >= 3 and pcb["rows_per_level"][0] == d["config"]["free_dofs"] and pcb["rows_per_level"][-1] <= 128
+    assert 1.0 < pcb["operator_complexity"] < 1.3 and pcb["numeric_setup_ms_per_solve_inside_the_timer"] > 0
+    assert js["converged_reason"] == 2 and d["iterations"] < js["iterations"] / 3 and js["max_nodal_error"] < 1e-3
+    assert abs(js["speedup_of_value_over_it"] - js["ms_per_step"] / d["ms_per_step"]) < 1e-9
+    assert "PCBJACOBI" in d["config"]["solver"] and "gamg" in d["config"]["solver"] and d["setup_breakdown_s"]["generate_mesh_and_numbering_on_device"] >= 0 and d["setup_s_untimed"] < 5
 
 
 @pytest.mark.gpu
@@ -81,13 +87,13 @@ def test_config5_at_full_size_with_eight_ranks_sharing_the_device():
         port = so.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0",
-                        "--backend", "gloo", "--same-device"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+                        "--backend", "gloo", "--same-device", "--pc", "jacobi"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1])
     assert d["config"]["free_dofs"] == 63521199 and d["config"]["elements"] == 384000000 and d["n_gpus"] == 8
     assert d["converged_reason"] == 2 and abs(d["iterations"] - 720) <= 5 and d["max_nodal_error"] < 3e-4
     sc = d["strong_cfg5"]               # N = 8: the weak configuration IS config 5 -- the same run, read against one GPU
-    assert sc["is_baseline_config5"] and sc["same_run_as_value"] and sc["single_gpu_ms_per_step"] > 1900
+    assert sc["is_baseline_config5"] and sc["same_run_as_value"] and sc["single_gpu_ms_per_step"] > 1900 and sc["preconditioner"] == "jacobi"
     assert abs(sc["speedup_vs_single_gpu"] - sc["single_gpu_ms_per_step"] / d["ms_per_step"]) < 1e-9
     c = d["comm"]
     assert len(c["ranks"]) == 8 and c["distinct_devices"] == 1 and [r["layers"] for r in c["ranks"]] == [[50 * r, 50 * r + 50] for r in range(8)]
@@ -102,7 +108,7 @@ def test_config5_at_full_size_alone_on_one_device():
     as the eight-rank test above: the same answer (nodal error of the %.8f boundary data), the same iteration count to
     a few (one rank sums in a different order than eight), and the strong-scaling baseline of SURVEY 8(e)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cells", "400", "--steps", "1", "--warmup", "0",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+                        "--no-cpu-baseline", "--pc", "jacobi"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1])
     assert d["config"]["free_dofs"] == 63521199 and d["config"]["elements"] == 384000000 and d["n_gpus"] == 1
@@ -119,7 +125,7 @@ def test_strong_scaling_flag_keeps_the_problem():
     free dofs, the same answer, "scaling": "strong"; and the line reports the device memory in use."""
     import socket
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cells", "60", "--steps", "1", "--warmup", "0",
-                          "--no-cpu-baseline", "--no-parity-step"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--no-cpu-baseline", "--no-parity-step", "--pc", "jacobi"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-3000:]
     d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.strip().startswith("{")][-1])
     with socket.socket() as so:
@@ -127,7 +133,7 @@ def test_strong_scaling_flag_keeps_the_problem():
         port = so.getsockname()[1]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cells", "60", "--strong",
-                          "--steps", "1", "--warmup", "0", "--backend", "gloo", "--same-device", "--no-cpu-baseline", "--no-parity-step"],
+                          "--steps", "1", "--warmup", "0", "--backend", "gloo", "--same-device", "--no-cpu-baseline", "--no-parity-step", "--pc", "jacobi"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-3000:]
     d2 = json.loads([ln for ln in two.stdout.splitlines() if ln.strip().startswith("{")][-1])
@@ -157,8 +163,9 @@ def test_plain_invocation_with_two_gpus_launches_its_own_ranks():
     assert c["transport"] == "gloo-host-hooks" and c["fallback_reason"] is None and c["spmv_form"] == "in order"
     assert [(x["rank"], x["device_index"], x["solver_device"]) for x in c["ranks"]] == [(0, 0, 0), (1, 0, 0)]
     assert len({x["pid"] for x in c["ranks"]}) == 2 and c["distinct_devices"] == 1
+    assert d["preconditioner"]["name"] == "gamg" and d["preconditioner"]["scope"] == "rank 0's block" and d["jacobi_step"]["iterations"] > 2 * d["iterations"]
     e = d["per_iteration_efficiency"]
-    assert e["value"] > 0 and e["n1_free_dofs"] == 7880599 and "BENCH_r02" in e["n1_source"]
+    assert e["value"] > 0 and e["n1_free_dofs"] == 7880599 and "profiles/r03" in e["n1_source"]
     sc = d["strong_cfg5"]
     assert sc["free_dofs"] == 79 ** 3 and not sc["is_baseline_config5"] and sc["speedup_vs_single_gpu"] is None
     assert sc["converged_reason"] == 2 and sc["n_gpus"] == 2 and sc["max_nodal_error"] < 1e-3 and not sc["same_run_as_value"]
@@ -185,7 +192,7 @@ def test_beam_on_eight_ranks_is_cut_across_its_length():
     z-layers with 368 KB faces; same tip displacement and iteration count as one rank."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--same-device", "--backend", "gloo",
-                        "--workload", "beam", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+                        "--workload", "beam", "--steps", "1", "--warmup", "0", "--pc", "jacobi"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1])
     pt = d["config"]["partition"]

@@ -306,6 +306,18 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
             s.VecSetValues(own, 0.25 * np.ones(len(own)), ADD_VALUES)
             its2, reason2, _ = s.factoriseAndSolve()
             extra = {"x2": s.getSolution(), "its2": its2, "reason2": reason2}
+        if mesh_args.get("pc") == "gamg":
+            # the rank's own hierarchy, for the oracle's restatement: its owned diagonal block as assembled here, its aggregates
+            ai = s.amgInfo()
+            rp, cc, vv = s.getCSR()
+            no = re - rs
+            keep = np.zeros(len(cc), bool)
+            for i in range(no):
+                keep[rp[i]:rp[i + 1]] = cc[rp[i]:rp[i + 1]] < no
+            brp = np.concatenate([[0], np.cumsum([keep[rp[i]:rp[i + 1]].sum() for i in range(no)])]).astype(np.int64)
+            extra.update(blk_rowptr=brp, blk_cols=cc[:rp[no]][keep[:rp[no]]], blk_vals=vv[:rp[no]][keep[:rp[no]]], amg_levels=ai["levels"],
+                         amg_rows=np.array(ai["rows"]), amg_opts=np.array([ai["cheb_degree"], ai["eig_ratio"], ai["coarse_scale"]]),
+                         **{f"agg{l}": s.amgAggregates(l, ai["rows"][l]) for l in range(ai["levels"] - 1)})
         info = s.commInfo()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=x1, rs=rs, re=re, its=its, reason=reason,
                  pc=s.preconditioner(), calls=hooks.calls, log=np.array([f"{k}{c}" for k, c in hooks.log]),
@@ -330,7 +342,9 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                                                             ("poisson", 3, "rcb", "single_overlap"), ("elast", 3, "idle", "single"),
                                                             ("poisson", 3, "yslabs", "batched"), ("elast", 3, "yslabs", "devgen"),
                                                             ("poisson", 2, "xslabs", "devgen"), ("poisson", 3, "slabs", "devgen"),
-                                                            ("elast", 2, "xslabs", "batched")])
+                                                            ("elast", 2, "xslabs", "batched"),
+                                                            ("poisson", 2, "slabs", "gamg"), ("poisson", 3, "rcb", "gamg"),
+                                                            ("elast", 3, "yslabs", "gamg"), ("poisson", 3, "idle", "gamg_overlap")])
 def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partition, mode):
     """2-3 ranks share cuda:0 (host-staged exchange over gloo): the product's multi-rank device loop against the
     ORACLE -- a direct solve of the oracle-assembled global system in the partition's new numbering, and the oracle's
@@ -344,6 +358,8 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
                  {"box": (-0.5, 0.5, 3, 0.0, 3.0, 8, -0.5, 0.5, 6), "bc_mode": 1, "ndof": 3})
     mesh_args["partition"] = partition
     mesh_args["mode"] = mode
+    if mode in ("gamg", "gamg_overlap"):   # block Jacobi over the ranks, every block its own multigrid hierarchy (-pc_type gamg)
+        mesh_args["mode"], mesh_args["pc"], mesh_args["overlap"] = ("devgen" if partition == "yslabs" else "batched"), "gamg", mode == "gamg_overlap"
     if mode == "devgen":              # bench.py's path: every rank generates its slab (along the partition's axis) on the device
         mesh_args["mode"] = "devgen"
     if world == 3 or mode != "batched":   # the row-group SpMV forms ("auto" keeps systems this small in the row form)
@@ -373,6 +389,20 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
         prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-10)
     assert reason_oracle == 2
     its_tol = 3
+    if mesh_args.get("pc") == "gamg":
+        # the oracle's restatement of the block preconditioner (every rank's V-cycle on its own block, its own aggregates)
+        blocks = []
+        for r in range(world):
+            d = np.load(tmp_path / f"rank{r}.npz")
+            assert str(d["pc"]) == "gamg"
+            aggs = [d[f"agg{l}"] for l in range(int(d["amg_levels"]) - 1)]
+            blocks.append((int(d["rs"]), (d["blk_rowptr"], d["blk_cols"], d["blk_vals"]), aggs))
+            deg, ratio, scale = np.load(tmp_path / "rank0.npz")["amg_opts"]
+        its_jacobi = its_oracle
+        _, its_oracle, reason_oracle, *_ = O.pcg_bjacobi_amg(prob.rowptr, prob.cols, prob.vals, prob.rhs, blocks, rtol=1e-10, cheb_degree=int(deg),
+                                                             eig_ratio=float(ratio), coarse_scale=float(scale))
+        assert reason_oracle == 2 and its_oracle < its_jacobi
+        its_tol = 2
     if mode == "pbjacobi":
         want = "pbjacobi" if kind_name == "elast" else "jacobi"      # Poisson has no multi-row groups: all ranks fall back
         assert all(str(np.load(tmp_path / f"rank{r}.npz")["pc"]) == want for r in range(world))
