@@ -575,7 +575,7 @@ def main():
                        "solver": f"CG{' (single-reduction form)' if args.single_reduction else ''} + " +
                                  {"pbjacobi": "node-block Jacobi (pbjacobi)", "jacobi": "point Jacobi",
                                   "gamg": "plain-aggregation multigrid V(1,1) cycle (-pc_type gamg: pairwise-matching aggregates, Galerkin coarse "
-                                          "operators re-summed in every solve, Chebyshev(2) smoothing, dense bottom solve" +
+                                          "operators re-summed in every solve, Chebyshev smoothing, dense bottom solve" +
                                           ("; block Jacobi over the ranks, one hierarchy per rank" if world > 1 else "") + ")"}[R["pc_in_effect"]] +
                                  f", zero initial guess, rtol {args.rtol:g} on ||M^-1 r|| (PETSc KSPCG default norm). The reference's PETSc run "
                                  "used KSPCG + PCBJACOBI (per-rank ILU(0), solverpetsc.F:187,206), which is NOT reproduced: "
@@ -597,7 +597,7 @@ def main():
             "preconditioner": ({"name": R["pc_in_effect"], "levels": R["amg"]["levels"], "rows_per_level": R["amg"]["rows"],
                                 "nnz_per_level": R["amg"]["nnz"], "gershgorin_lambda_max": R["amg"]["lambda_max"],
                                 "operator_complexity": sum(R["amg"]["nnz"]) / max(R["amg"]["nnz"][0], 1),
-                                "cheb_degree": R["amg"]["cheb_degree"], "eig_ratio": R["amg"]["eig_ratio"], "coarse_scale": R["amg"]["coarse_scale"],
+                                "cheb_degree": R["amg"]["cheb_degree"], "cheb_degree_on_the_assembled_matrix": R["amg"]["fine_degree"], "eig_ratio": R["amg"]["eig_ratio"], "coarse_scale": R["amg"]["coarse_scale"],
                                 "numeric_setup_ms_per_solve_inside_the_timer": R["amg"]["numeric_ms"],
                                 "symbolic_setup_ms_once_per_pattern": R["amg"]["symbolic_ms"],
                                 "symbolic_setup_where": "first solve after a pattern build (a warm-up step; with --warmup 0 the first timed step)",

@@ -316,23 +316,25 @@ int pfem_solver_spmv_bytes(pfem_solver *s, int64_t *format_bytes);
 /* GAMG (PETSc: -pc_type gamg, reachable from the reference through KSPSetFromOptions / petsc_options.dat,
  * solverpetsc.F:191-206): plain-aggregation algebraic multigrid, one V(1,1) cycle per CG iteration -- aggregates of up to
  * 8 nodes from three passes of pairwise matching on the strength graph, piecewise-constant prolongation (one coarse
- * vector per dof component), Galerkin coarse operators re-summed in every solve, Chebyshev(2) smoothing on D^-1 A with a
- * Gershgorin bound, dense inverse at the coarsest level.  The reference's own PCBJACOBI/ILU(0) needs 110 / 1 122
+ * vector per dof component), Galerkin coarse operators re-summed in every solve, Chebyshev smoothing on D^-1 A with a
+ * Gershgorin bound (degree 1 on the assembled matrix, 2 below), dense inverse at the coarsest level.  The reference's own PCBJACOBI/ILU(0) needs 110 / 1 122
  * iterations on BASELINE configs 3 / 4 and point Jacobi 370 / 5 207; this needs ~20 / ~300 at ~5 SpMV-equivalents each.
  * Aggregates are formed from the values of the first solve after a pattern build and reused while the pattern lives
- * (-pc_gamg_reuse_interpolation true).  One rank only: on several ranks JACOBI stays in effect.                         */
+ * (-pc_gamg_reuse_interpolation true).  Several ranks: block Jacobi over the ranks, one hierarchy per rank on its owned
+ * diagonal block as assembled from its own elements (PETSc: -pc_type bjacobi -sub_pc_type gamg).                          */
 #define PFEM_PC_GAMG 2
 int pfem_solver_set_preconditioner(pfem_solver *s, int pc);
 int pfem_solver_get_preconditioner(pfem_solver *s, int *pc_in_effect);
 /* GAMG hierarchy of the last solve: number of levels, rows / nonzeros / eigenvalue bound of each (arrays of max_levels),
  * time of the symbolic phase (once per pattern) and of the numeric phase of the last solve (inside its timer), the knobs */
 int pfem_solver_amg_info(pfem_solver *s, int max_levels, int *n_levels, int64_t *rows, int64_t *nnz, double *lambda_max,
-                         double *symbolic_ms, double *numeric_ms, int *cheb_degree, double *eig_ratio, double *coarse_scale);
+                         double *symbolic_ms, double *numeric_ms, int *cheb_degree, int *fine_degree, double *eig_ratio, double *coarse_scale);
 /* coarse dof of every dof of `level` (0 = the assembled matrix); what the oracle's restatement of the cycle is given */
 int pfem_solver_amg_aggregates(pfem_solver *s, int level, int32_t *agg);
-/* -pc_gamg knobs: Chebyshev degree (1..6, default 2), lmax/lmin of the smoothing interval (default 8), scaling of the
- * coarse-grid correction (default 1)                                                                                 */
-int pfem_solver_set_amg_options(pfem_solver *s, int cheb_degree, double eig_ratio, double coarse_scale);
+/* -pc_gamg knobs: Chebyshev degree on the coarse levels (1..6, default 2) and on the assembled matrix itself (0 = the same;
+ * default 1: there an SpMV is dearest), lmax/lmin of the smoothing interval (default 8), scaling of the coarse-grid
+ * correction (default 1.5: the over-correction a piecewise-constant coarse space wants)                              */
+int pfem_solver_set_amg_options(pfem_solver *s, int cheb_degree, int fine_degree, double eig_ratio, double coarse_scale);
 /* KSPCGUseSingleReduction / -ksp_cg_single_reduction (PETSc option of the KSPCG the reference creates, solverpetsc.F:187;
  * off by default there and here): the Chronopoulos-Gear form of the same iteration -- s = A z instead of w = A p,
  * (p,Ap) by recurrence -- so that (z,r), (z,s), (z,z) are reduced together: ONE all-reduce per iteration on several

@@ -333,11 +333,12 @@ def pcg_bjacobi_ilu0(rowptr, cols, vals, b, block_start=None, rtol=1e-5, abstol=
     return x, its.value, reason.value, rn.value
 
 
-def amg_cycle(rowptr, cols, vals, aggregates, cheb_degree=2, eig_ratio=8.0, coarse_scale=1.5, dense_limit=128, coarsest_sweeps=8):
+def amg_cycle(rowptr, cols, vals, aggregates, cheb_degree=2, eig_ratio=8.0, coarse_scale=1.5, dense_limit=128, coarsest_sweeps=8,
+              fine_degree=1):
     """z = M^-1 r of the product's -pc_type gamg (pfemfort_amd/csrc/pfem_amg.inc), restated in numpy / scipy.sparse GIVEN the
     aggregates (``aggregates[l][i]`` = coarse dof of dof i of level l; the product forms them by pairwise matching and
     hands them over for this check).  Everything else is restated: piecewise-constant prolongation P, Galerkin operators
-    P^T A P, Chebyshev smoothing of degree ``cheb_degree`` on D^-1 A over [lmax/eig_ratio, lmax] with the Gershgorin bound
+    P^T A P, Chebyshev smoothing of degree ``cheb_degree`` (``fine_degree`` on the matrix itself) on D^-1 A over [lmax/eig_ratio, lmax] with the Gershgorin bound
     lmax = max_i sum_j |a_ij| / a_ii, one symmetric V(1,1) cycle with the coarse correction scaled by ``coarse_scale``, a
     dense solve on the last level when it has at most ``dense_limit`` rows (else Chebyshev of degree ``coarsest_sweeps``).
     Returns the function r -> z."""
@@ -382,10 +383,11 @@ def amg_cycle(rowptr, cols, vals, aggregates, cheb_degree=2, eig_ratio=8.0, coar
             if dense:
                 return Ainv @ rhs
             return smooth(l, None, rhs, cheb_degree if len(levels) == 1 else coarsest_sweeps)
-        x = smooth(l, None, rhs, cheb_degree)
+        deg = fine_degree if (l == 0 and fine_degree) else cheb_degree
+        x = smooth(l, None, rhs, deg)
         rc = P[l].T @ (rhs - levels[l] @ x)
         x = x + coarse_scale * (P[l] @ cycle(l + 1, rc))
-        return smooth(l, x, rhs, cheb_degree)
+        return smooth(l, x, rhs, deg)
 
     return lambda r: cycle(0, r)
 
@@ -431,9 +433,9 @@ def pcg_with(rowptr, cols, vals, b, M, rtol=1e-5, abstol=1e-50, dtol=1e5, maxits
 
 
 def pcg_amg(rowptr, cols, vals, b, aggregates, cheb_degree=2, eig_ratio=8.0, coarse_scale=1.5, rtol=1e-5, abstol=1e-50, dtol=1e5,
-            maxits=10000, dense_limit=128, coarsest_sweeps=8):
+            maxits=10000, dense_limit=128, coarsest_sweeps=8, fine_degree=1):
     """CG preconditioned by one V(1,1) cycle of plain-aggregation multigrid on the whole matrix: amg_cycle + pcg_with."""
-    M = amg_cycle(rowptr, cols, vals, aggregates, cheb_degree, eig_ratio, coarse_scale, dense_limit, coarsest_sweeps)
+    M = amg_cycle(rowptr, cols, vals, aggregates, cheb_degree, eig_ratio, coarse_scale, dense_limit, coarsest_sweeps, fine_degree)
     return pcg_with(rowptr, cols, vals, b, M, rtol, abstol, dtol, maxits)
 
 

@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(kBlock) k_amg_cheb_first(int64_t n, const doub
         const double ri = t ? b[i] - t[i] : b[i];
         const double di = c.c_first * dinv[i] * ri;
         if (r_out) r_out[i] = ri;
-        dd[i] = di;
+        if (dd) dd[i] = di;                  // null when no step follows (degree 1): nobody reads it
         x[i] = t ? x[i] + di : di;
     }
 }

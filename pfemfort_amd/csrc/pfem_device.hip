@@ -3249,7 +3249,7 @@ extern "C" int pfem_solver_get_history(pfem_solver *s, double *hist, int n, int 
 
 // ---- -pc_type gamg: what the hierarchy looks like, its aggregates (for the oracle's restatement), its knobs ------------
 extern "C" int pfem_solver_amg_info(pfem_solver *s, int max_levels, int *n_levels, int64_t *rows, int64_t *nnz, double *lambda_max,
-                                    double *symbolic_ms, double *numeric_ms, int *cheb_degree, double *eig_ratio, double *coarse_scale)
+                                    double *symbolic_ms, double *numeric_ms, int *cheb_degree, int *fine_degree, double *eig_ratio, double *coarse_scale)
 {
     if (!s || !n_levels) return PFEM_ERR_ARG;
     *n_levels = 0;
@@ -3266,6 +3266,7 @@ extern "C" int pfem_solver_amg_info(pfem_solver *s, int max_levels, int *n_level
     if (symbolic_ms) *symbolic_ms = M.symbolic_ms;
     if (numeric_ms) *numeric_ms = M.numeric_ms;
     if (cheb_degree) *cheb_degree = M.cheb_degree;
+    if (fine_degree) *fine_degree = M.fine_degree > 0 ? M.fine_degree : M.cheb_degree;
     if (eig_ratio) *eig_ratio = M.eig_ratio;
     if (coarse_scale) *coarse_scale = M.coarse_scale;
     return PFEM_OK;
@@ -3281,12 +3282,14 @@ extern "C" int pfem_solver_amg_aggregates(pfem_solver *s, int level, int32_t *ag
     return PFEM_OK;
 }
 
-extern "C" int pfem_solver_set_amg_options(pfem_solver *s, int cheb_degree, double eig_ratio, double coarse_scale)
+extern "C" int pfem_solver_set_amg_options(pfem_solver *s, int cheb_degree, int fine_degree, double eig_ratio, double coarse_scale)
 {
-    if (!s || cheb_degree < 1 || cheb_degree > 6 || !(eig_ratio > 1.0) || !(coarse_scale > 0.0)) return PFEM_ERR_ARG;
+    if (!s || cheb_degree < 1 || cheb_degree > 6 || fine_degree < 0 || fine_degree > 6 || !(eig_ratio > 1.0) || !(coarse_scale > 0.0)) return PFEM_ERR_ARG;
     if (!s->amg) s->amg.reset(new (std::nothrow) Amg());
     if (!s->amg) return PFEM_ERR_NOMEM;
     s->amg->cheb_degree = cheb_degree;
+    s->amg->fine_degree = fine_degree;
+    s->amg->graph_key.clear();
     s->amg->eig_ratio = eig_ratio;
     s->amg->coarse_scale = coarse_scale;
     return PFEM_OK;

@@ -67,8 +67,9 @@ subroutine pfem_set_pc_type(val)
   select case (val)
   case ("jacobi");   pfem_opt_pc = 0
   case ("pbjacobi"); pfem_opt_pc = 1
+  case ("gamg");     pfem_opt_pc = 2
   case default
-    write(*,*) "pfem_amd: -pc_type ", val, " is not available (jacobi, pbjacobi)"
+    write(*,*) "pfem_amd: -pc_type ", val, " is not available (jacobi, pbjacobi, gamg)"
     error stop " Aborting... unsupported -pc_type"
   end select
 end subroutine pfem_set_pc_type

@@ -71,7 +71,9 @@ contains
     ! one loud line: the reference sets KSPCG + PCBJACOBI (per-rank ILU(0)) at solverpetsc.F:187,206; this library runs
     ! CG with the preconditioner named here, so iteration counts are not those of the reference's PETSc run
     if (me == 0) then
-      if (pfem_opt_pc == 1) then
+      if (pfem_opt_pc == 2) then
+        write(*,*) " pfem_amd: KSP = cg, PC = gamg (plain-aggregation multigrid V-cycle) on the GPU; the reference's PCBJACOBI/ILU(0) is not reproduced"
+      else if (pfem_opt_pc == 1) then
         write(*,*) " pfem_amd: KSP = cg, PC = pbjacobi (node-block Jacobi) on the GPU; the reference's PCBJACOBI/ILU(0) is not reproduced"
       else
         write(*,*) " pfem_amd: KSP = cg, PC = jacobi on the GPU; the reference's PCBJACOBI/ILU(0) is not reproduced"

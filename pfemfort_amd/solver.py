@@ -220,20 +220,21 @@ class PetscSolver:
         L.check(L.lib().pfem_solver_get_preconditioner(self._h, C.byref(b)), "pfem_solver_get_preconditioner")
         return ("jacobi", "pbjacobi", "gamg")[b.value]
 
-    def setAmgOptions(self, cheb_degree=2, eig_ratio=8.0, coarse_scale=1.0):
-        """-pc_gamg knobs: Chebyshev degree, lmax/lmin of the smoothing interval, scaling of the coarse-grid correction."""
-        L.check(L.lib().pfem_solver_set_amg_options(self._h, cheb_degree, eig_ratio, coarse_scale), "pfem_solver_set_amg_options")
+    def setAmgOptions(self, cheb_degree=2, fine_degree=1, eig_ratio=8.0, coarse_scale=1.5):
+        """-pc_gamg knobs: Chebyshev degree on the coarse levels / on the assembled matrix (0: the same), lmax/lmin of the
+        smoothing interval, scaling of the coarse-grid correction."""
+        L.check(L.lib().pfem_solver_set_amg_options(self._h, cheb_degree, fine_degree, eig_ratio, coarse_scale), "pfem_solver_set_amg_options")
 
     def amgInfo(self):
         """The multigrid hierarchy of the last ``gamg`` solve: rows / nonzeros / eigenvalue bound per level, phase times."""
         mx = 16
         nl = C.c_int(0); rows = (C.c_int64 * mx)(); nnz = (C.c_int64 * mx)(); lam = (C.c_double * mx)()
-        sym = C.c_double(0); num = C.c_double(0); deg = C.c_int(0); ratio = C.c_double(0); scale = C.c_double(0)
+        sym = C.c_double(0); num = C.c_double(0); deg = C.c_int(0); fdeg = C.c_int(0); ratio = C.c_double(0); scale = C.c_double(0)
         L.check(L.lib().pfem_solver_amg_info(self._h, mx, C.byref(nl), rows, nnz, lam, C.byref(sym), C.byref(num), C.byref(deg),
-                                             C.byref(ratio), C.byref(scale)), "pfem_solver_amg_info")
+                                             C.byref(fdeg), C.byref(ratio), C.byref(scale)), "pfem_solver_amg_info")
         n = nl.value
         return {"levels": n, "rows": list(rows[:n]), "nnz": list(nnz[:n]), "lambda_max": list(lam[:n]), "symbolic_ms": sym.value,
-                "numeric_ms": num.value, "cheb_degree": deg.value, "eig_ratio": ratio.value, "coarse_scale": scale.value}
+                "numeric_ms": num.value, "cheb_degree": deg.value, "fine_degree": fdeg.value, "eig_ratio": ratio.value, "coarse_scale": scale.value}
 
     def amgAggregates(self, level, n_rows):
         """Coarse dof of every dof of ``level`` (``n_rows`` = amgInfo()["rows"][level])."""

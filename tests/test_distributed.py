@@ -316,7 +316,7 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                 keep[rp[i]:rp[i + 1]] = cc[rp[i]:rp[i + 1]] < no
             brp = np.concatenate([[0], np.cumsum([keep[rp[i]:rp[i + 1]].sum() for i in range(no)])]).astype(np.int64)
             extra.update(blk_rowptr=brp, blk_cols=cc[:rp[no]][keep[:rp[no]]], blk_vals=vv[:rp[no]][keep[:rp[no]]], amg_levels=ai["levels"],
-                         amg_rows=np.array(ai["rows"]), amg_opts=np.array([ai["cheb_degree"], ai["eig_ratio"], ai["coarse_scale"]]),
+                         amg_rows=np.array(ai["rows"]), amg_opts=np.array([ai["cheb_degree"], ai["eig_ratio"], ai["coarse_scale"], ai["fine_degree"]]),
                          **{f"agg{l}": s.amgAggregates(l, ai["rows"][l]) for l in range(ai["levels"] - 1)})
         info = s.commInfo()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=x1, rs=rs, re=re, its=its, reason=reason,
@@ -397,10 +397,10 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
             assert str(d["pc"]) == "gamg"
             aggs = [d[f"agg{l}"] for l in range(int(d["amg_levels"]) - 1)]
             blocks.append((int(d["rs"]), (d["blk_rowptr"], d["blk_cols"], d["blk_vals"]), aggs))
-            deg, ratio, scale = np.load(tmp_path / "rank0.npz")["amg_opts"]
+            deg, ratio, scale, fdeg = np.load(tmp_path / "rank0.npz")["amg_opts"]
         its_jacobi = its_oracle
         _, its_oracle, reason_oracle, *_ = O.pcg_bjacobi_amg(prob.rowptr, prob.cols, prob.vals, prob.rhs, blocks, rtol=1e-10, cheb_degree=int(deg),
-                                                             eig_ratio=float(ratio), coarse_scale=float(scale))
+                                                             eig_ratio=float(ratio), coarse_scale=float(scale), fine_degree=int(fdeg))
         assert reason_oracle == 2 and its_oracle < its_jacobi
         its_tol = 2
     if mode == "pbjacobi":

@@ -122,6 +122,12 @@ def test_fortran_host_program_pc_type_pbjacobi_and_unknown_options(tmp_path):
     assert r0.returncode == 0 and r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-2000:]
     assert "PC = pbjacobi" in r1.stdout and u1[0] < u0[0]                 # fewer iterations
     assert np.abs(u1[2:] - u0[2:]).max() < 1e-8 * max(1.0, np.abs(u0[2:]).max())
+    # -pc_type gamg from the options file: the multigrid V-cycle, from the Fortran host program, far fewer iterations
+    (tmp_path / "petsc_options.dat").write_text("-ksp_type cg\n-pc_type gamg\n")
+    r3 = _run(exe, tmp_path, 1)
+    u3 = np.array(open(tmp_path / "solution.txt").read().split(), dtype=float)
+    assert r3.returncode == 0 and "PC = gamg" in r3.stdout and u3[1] == 2 and u3[0] < 0.5 * u1[0], r3.stdout[-2000:] + r3.stderr[-2000:]
+    assert np.abs(u3[2:] - u0[2:]).max() < 1e-8 * max(1.0, np.abs(u0[2:]).max())
     (tmp_path / "petsc_options.dat").write_text("-pc_type ilu\n")
     r2 = _run(exe, tmp_path, 1)
     assert r2.returncode != 0 and "-pc_type ilu is not available" in (r2.stdout + r2.stderr).replace("  ", " ")

@@ -797,7 +797,7 @@ def _gamg_vs_oracle(s, rtol=1e-10):
     info = s.amgInfo()
     aggs = [s.amgAggregates(l, info["rows"][l]) for l in range(info["levels"] - 1)]
     rowptr, cols, vals = s.getCSR()
-    xo, ito, ro, rno, hist = O.pcg_amg(rowptr, cols, vals, s.getRHS(), aggs, cheb_degree=info["cheb_degree"], eig_ratio=info["eig_ratio"],
+    xo, ito, ro, rno, hist = O.pcg_amg(rowptr, cols, vals, s.getRHS(), aggs, cheb_degree=info["cheb_degree"], fine_degree=info["fine_degree"], eig_ratio=info["eig_ratio"],
                                        coarse_scale=info["coarse_scale"], rtol=rtol)
     x = s.getSolution()
     h = s.getHistory()

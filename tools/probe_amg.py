@@ -47,7 +47,7 @@ def run(spec, check_oracle):
                 rhs = s.getRHS()
                 aggs = [s.amgAggregates(l, info["rows"][l]) for l in range(info["levels"] - 1)]
                 sizes = [np.bincount(np.bincount(a)).tolist() for a in aggs]
-                xo, ito, ro, rno, hist = O.pcg_amg(rowptr, cols, vals, rhs, aggs, cheb_degree=info["cheb_degree"], eig_ratio=info["eig_ratio"],
+                xo, ito, ro, rno, hist = O.pcg_amg(rowptr, cols, vals, rhs, aggs, cheb_degree=info["cheb_degree"], fine_degree=info["fine_degree"], eig_ratio=info["eig_ratio"],
                                                    coarse_scale=info["coarse_scale"])
                 out[pc]["oracle"] = {"its": ito, "reason": ro, "max_abs_diff": float(np.abs(x - xo).max()), "aggregate_size_histograms": sizes,
                                      "history_rel_diff": float(np.abs(s.getHistory()[:len(hist)] - hist[:len(s.getHistory())]).max() / hist[0])}
