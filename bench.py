@@ -195,6 +195,12 @@ def parse_args():
     ap.add_argument("--no-strong-block", action="store_true",
                     help="N>1 weak runs: skip the extra strong-scaling measurement (the cube of 2 x --cells per side -- BASELINE "
                          "config 5 at the default 200 -- on the same N ranks) reported as `strong_cfg5`")
+    ap.add_argument("--numbering", choices=["lattice", "rcb8", "shuffle"], default="lattice",
+                    help="N=1: node numbering of the SAME mesh.  lattice: genTetra's own (line by line; the generator runs on the "
+                         "device); rcb8: the reference's renumbering for 8 ranks (tetrapoissonparallelimpl1.F:500-679: parts "
+                         "concatenated) of a recursive-coordinate-bisection partition, solved on one rank; shuffle: a random "
+                         "permutation of the node ids -- the worst case of an unstructured mesh file.  Mesh built on the host and "
+                         "uploaded (untimed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-step", action="store_true", help="skip the extra (untimed) step at rtol 1e-10")
     ap.add_argument("--pc", choices=["jacobi", "pbjacobi", "gamg"], default="gamg",
@@ -271,7 +277,26 @@ def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=Fa
     solver.setPreconditioner(pc)
     if args.single_reduction:
         solver.setSingleReduction(True)
-    solver.generateBoxMesh(kind, *box, bc_mode=bc_mode, nparts=world, part=rank, axis=axis)
+    dm_host = mesh_host = None
+    if args.numbering == "lattice" or world > 1:
+        solver.generateBoxMesh(kind, *box, bc_mode=bc_mode, nparts=world, part=rank, axis=axis)
+    else:
+        # the same mesh under another node numbering: host generator, renumbering, upload (all untimed setup)
+        mesh_host = H.gen_box_tets(*box, bc_mode=bc_mode, ndof=ndof)
+        if args.numbering == "shuffle":
+            perm = np.random.default_rng(2024).permutation(mesh_host.nNode).astype(np.int32)      # old id -> shuffled id
+            xyz = np.empty_like(mesh_host.xyz)
+            xyz[:, perm] = mesh_host.xyz
+            mesh_host = H.Mesh(xyz, perm[mesh_host.conn], perm[mesh_host.bc_node], mesh_host.bc_dof, mesh_host.bc_val, box=mesh_host.box)
+            dm_host = H.dof_numbering(mesh_host.nNode, ndof, mesh_host.bc_node, mesh_host.bc_dof, mesh_host.bc_val)
+        else:
+            _, npid = H.partition_rcb(mesh_host, 8)
+            dm_host = H.dof_numbering(mesh_host.nNode, ndof, mesh_host.bc_node, mesh_host.bc_dof, mesh_host.bc_val, 8, npid)
+        conn_new, xyz_new = H.renumber_mesh(mesh_host, dm_host)
+        edof = H.elem_dof_array(conn_new, dm_host.NodeDofArrayNew)
+        solver.uploadMesh(kind, conn_new, xyz_new, edof, dm_host.solnApplied)
+        R["xyz_free"] = xyz_new[:, H.assy_for_soln(dm_host.NodeDofArrayNew) // ndof]
+        del conn_new, edof
     R["t_generate"] = time.perf_counter() - t_setup
     hooks = None
     if world > 1:
@@ -377,6 +402,8 @@ def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=Fa
                     ok = (l >= 0) & (l < size_local)
                     full[conn[a][ok] * 3 + d] = u[l[ok]]
             return "max_displacement_magnitude_owned_rows", float(np.linalg.norm(full.reshape(-1, 3), axis=1).max())
+        if "xyz_free" in R:          # another numbering: the coordinates of the free nodes came with the host mesh
+            return "max_nodal_error", float(np.abs(u - (R["xyz_free"] ** 2).sum(0)).max())
         # u = x^2+y^2+z^2 is nodally exact on this mesh family; owned free nodes in closed form
 
         def axis_tab(lo, hi, m):      # xx = lo; repeat: use xx; xx += dx, then the "%.8f" round trip (genTetra.cpp:194-216)
@@ -415,6 +442,7 @@ def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=Fa
              fmt_bytes=solver.spmvFormatBytes(), gap_table=solver.spmvGapTable(), bits=solver.spmvColumnBits(),
              row_group=solver.spmvRowGroup(), final=solver.commDescribe() if world > 1 else None,
              ms_per_step=elapsed / steps * 1e3, ms_per_iteration=acc["sol_ms"] / steps / max(its, 1))
+    R.pop("xyz_free", None)
     solver.free()
     return R
 
@@ -452,6 +480,12 @@ def main():
         # far) and never will -- it starts N fresh rank processes through torch.distributed.run, relays their output and
         # exits with their code
         raise SystemExit(self_launch(args))
+
+    # stdout carries ONE JSON line and nothing else: libraries that print to the C stdout of a rank (gloo announces its
+    # peers there) are sent to stderr, the line goes out through a duplicate of the original descriptor
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import faulthandler
     faulthandler.enable()
@@ -536,7 +570,7 @@ def main():
         raw_spmv_ms = acc["spmv_ms"] / max(acc["spmv_n"], 1)
         avg_spmv_ms = max(raw_spmv_ms, 1e-9)
         achieved = bytes_per_spmv / (avg_spmv_ms * 1e-3) / 1e9 if acc["spmv_n"] else 0.0
-        traffic, traffic_source = pmc_traffic(info["nnz"]) if world == 1 else (None, None)
+        traffic, traffic_source = pmc_traffic(info["nnz"]) if (world == 1 and args.numbering == "lattice") else (None, None)
         hbm_bytes = traffic if traffic else fmt_bytes
         # names as rocprofv3 prints them: k_spmvr / k_spmvg / k_spmv16 <WITH_DOT, gap table>, k_spmvr32 / k_spmv <WITH_DOT>
         tbl = R["gap_table"]
@@ -585,7 +619,7 @@ def main():
                                       f"{world} slabs of hex layers across {axis_name}, sub-assembled interface rows, neighbour exchange of "
                                       f"{cinfo['doubles_per_exchange']} doubles with {cinfo['n_peers']} neighbour(s) per SpMV "
                                       f"+ {1 if args.single_reduction and args.pc == 'jacobi' else 2} scalar all-reduce(s) per iteration",
-                       "partition": partition},
+                       "partition": partition, "numbering": args.numbering},
             "iterations": its, "converged_reason": R["reason"], "rnorm": R["rnorm"], R["check_name"]: R["check"],
             "assembly_ms_per_step": acc["asm_ms"] / args.steps, "solve_ms_per_step": acc["sol_ms"] / args.steps,
             "ms_per_iteration": R["ms_per_iteration"],     # weak scaling: iterations grow with the problem
@@ -650,7 +684,8 @@ def main():
                     "bytes_per_neighbour": 8 * S["cinfo"]["doubles_per_exchange"] // max(S["cinfo"]["n_peers"], 1)}
         if world == 1 and not args.no_cpu_baseline and not beam:
             out["cpu_baseline"] = cpu_baseline(n, args.rtol, extra_sample=(n >= 200))
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if world > 1:
         J.dist.barrier()
         J.dist.destroy_process_group()

@@ -400,8 +400,9 @@ __global__ void __launch_bounds__(kBlock) k_amg_cheb_next(int64_t n, int step, c
 // member indices of an aggregate (up to 8 from three passes of pairing) are fetched first, then all values: 16 loads in
 // flight per lane instead of a chain of dependent pairs; summed in ascending member order either way.
 __global__ void __launch_bounds__(kBlock) k_amg_restrict(int64_t nc, const int32_t *__restrict__ mem_ptr, const int32_t *__restrict__ mem_idx,
-                                                          const double *__restrict__ b, const double *__restrict__ t, double *__restrict__ bc,
-                                                          const CgCtl *ctl)
+                                                          const double *__restrict__ b, const double *__restrict__ t /* null: b IS the residual */,
+                                                          double *__restrict__ bc, const double *__restrict__ dinv_c, const double *__restrict__ lam_c,
+                                                          double ratio, double *__restrict__ dd_c, double *__restrict__ x_c, const CgCtl *ctl)
 {
     if (ctl && ctl->flag != 0) return;
     const int64_t a = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -415,7 +416,7 @@ __global__ void __launch_bounds__(kBlock) k_amg_restrict(int64_t nc, const int32
 #pragma unroll
         for (int k = 0; k < 8; ++k) idx[k] = mem_idx[q + k];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = b[idx[k]] - t[idx[k]];
+        for (int k = 0; k < 8; ++k) v[k] = t ? b[idx[k]] - t[idx[k]] : b[idx[k]];
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc += v[k];
     }
@@ -425,12 +426,17 @@ __global__ void __launch_bounds__(kBlock) k_amg_restrict(int64_t nc, const int32
 #pragma unroll
         for (int k = 0; k < 8; ++k) idx[k] = q + k < q1 ? mem_idx[q + k] : -1;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = idx[k] >= 0 ? b[idx[k]] - t[idx[k]] : 0.0;
+        for (int k = 0; k < 8; ++k) v[k] = idx[k] >= 0 ? (t ? b[idx[k]] - t[idx[k]] : b[idx[k]]) : 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
             if (idx[k] >= 0) acc += v[k];
     }
     bc[a] = acc;
+    if (dd_c) {          // step 0 of the next level's pre-smoothing (zero guess), what k_amg_cheb_first would do there
+        const double di = cheb_coef(lam_c[0], ratio, 0).c_first * dinv_c[a] * acc;
+        dd_c[a] = di;
+        x_c[a] = di;
+    }
 }
 // coarse-grid correction x += scale * P xc
 __global__ void __launch_bounds__(kBlock) k_amg_prolong(int64_t n, const int32_t *__restrict__ agg, const double *__restrict__ xc, double scale,
@@ -439,6 +445,168 @@ __global__ void __launch_bounds__(kBlock) k_amg_prolong(int64_t n, const int32_t
     if (ctl && ctl->flag != 0) return;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock)
         x[i] = __builtin_fma(scale, xc[agg[i]], x[i]);
+}
+
+// ---------------------------------------------------------------------------
+// Coarse levels: the SpMV with the vector step that follows it as its epilogue (row form, one lane per row), so that a
+// level of the cycle costs 6 launches instead of 10 -- these levels are too small to fill the chip and every launch has a
+// floor of several microseconds.  Same products, same order, same expressions as k_spmv + k_amg_cheb_*: same bits.
+//   kEpNextLast: acc = (A dd)_i;  r = r_in - acc;  d = c_dd dd_i + c_r dinv_i r;  x_i = (x_i [+ dd_i]) + d   (last Chebyshev step;
+//                add_dd0: step 0 left x untouched because x was the SpMV input of kEpFirstRes)
+//   kEpResid:    acc = (A x)_i;   r_i = b_i - acc                                     (residual for the restriction)
+//   kEpFirstRes: acc = (A x)_i;   r_i = b_i - acc;  dd_i = c_first dinv_i r_i         (step 0 with a guess; x is added later)
+// ---------------------------------------------------------------------------
+enum AmgEpilogue { kEpNextLast = 0, kEpResid = 1, kEpFirstRes = 2 };
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_amg_spmv_ep(SellDev A, const double *__restrict__ xin, const double *r_in, const double *__restrict__ dinv,
+                                                         const double *__restrict__ lam, double ratio, int step, int add_dd0, double *r_out,
+                                                         double *dd_out, double *x, const CgCtl *ctl)
+{
+    if (ctl && ctl->flag != 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t s = (static_cast<int64_t>(blockIdx.x) << 2) + wave;
+    if (s >= A.n_slices) return;
+    const int64_t off = A.slice_off[s];
+    const int width = static_cast<int>((A.slice_off[s + 1] - off) >> 6);
+    const int32_t *__restrict__ cp = A.cols + off + lane;
+    const double *__restrict__ vp = A.vals + off + lane;
+    double acc = 0.0;
+    int k = 0;
+    for (; k + 4 <= width; k += 4) {
+        int c[4];
+        double v[4], xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c[j] = cp[64 * (k + j)]; v[j] = vp[64 * (k + j)]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = xin[c[j]];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_fma(v[j], xv[j], acc);
+    }
+    for (; k < width; ++k) acc = __builtin_fma(vp[64 * k], xin[cp[64 * k]], acc);
+    const int64_t i = (s << 6) + lane;
+    if (i >= A.n_rows) return;
+    if (MODE == kEpResid) {
+        r_out[i] = r_in[i] - acc;
+    } else if (MODE == kEpFirstRes) {
+        const double ri = r_in[i] - acc;
+        r_out[i] = ri;
+        dd_out[i] = cheb_coef(lam[0], ratio, 0).c_first * dinv[i] * ri;
+    } else {
+        const ChebCoef c = cheb_coef(lam[0], ratio, step);
+        const double ri = r_in[i] - acc;
+        const double d0 = xin[i];
+        const double di = __builtin_fma(c.c_dd, d0, c.c_r * dinv[i] * ri);
+        double xv = x[i];
+        if (add_dd0) xv += d0;
+        x[i] = xv + di;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The bottom of the cycle in ONE launch: every level of at most kAmgTailRows rows is walked by a single workgroup
+// (block-wide barriers instead of kernel boundaries).  At 200^3 that is 3 of the 8 levels (644, 235, 169 rows): 30
+// launches of a few microseconds each become one.  Same operations in the same order as the level-by-level kernels:
+// same bits.  The limit is low on purpose: one workgroup is latency-bound -- with 4096 rows (a 3350-row level inside)
+// the tail took 294 us per cycle, MORE than the 40 launches it replaced (profiles/r03/rocprofv3_kernel_stats_gamg_tail4096.txt).
+// ---------------------------------------------------------------------------
+constexpr int kAmgTailRows = 1024;
+constexpr int kAmgTailLevels = 8;
+struct AmgTailLevel {
+    SellDev A;
+    const double *dinv, *lam;
+    double *x, *dd, *t, *r, *b;
+    const int32_t *agg, *mem_ptr, *mem_idx;
+    int64_t n, nc;
+};
+struct AmgTail {
+    int nlev, deg, coarsest_deg, dense_n;
+    const double *dense_inv;
+    double ratio, scale;
+    AmgTailLevel lev[kAmgTailLevels];
+};
+
+__device__ inline void tail_spmv(const SellDev &A, const double *x, double *y)
+{
+    for (int64_t i = threadIdx.x; i < A.n_rows; i += 1024) {
+        const int64_t off = A.slice_off[i >> 6];
+        const int width = static_cast<int>((A.slice_off[(i >> 6) + 1] - off) >> 6);
+        const int32_t *cp = A.cols + off + (i & 63);
+        const double *vp = A.vals + off + (i & 63);
+        double acc = 0.0;
+        for (int k = 0; k < width; ++k) acc = __builtin_fma(vp[64 * k], x[cp[64 * k]], acc);
+        y[i] = acc;
+    }
+    __syncthreads();
+}
+// Chebyshev smoothing exactly as amg_smooth enqueues it (k_amg_cheb_first / k_amg_cheb_next)
+__device__ inline void tail_smooth(const AmgTailLevel &L, const double *b, bool zero_guess, int deg, double ratio)
+{
+    const double lmax = L.lam[0];
+    if (!zero_guess) tail_spmv(L.A, L.x, L.t);
+    const ChebCoef c0 = cheb_coef(lmax, ratio, 0);
+    for (int64_t i = threadIdx.x; i < L.n; i += 1024) {
+        const double ri = zero_guess ? b[i] : b[i] - L.t[i];
+        const double di = c0.c_first * L.dinv[i] * ri;
+        if (deg > 1 && !zero_guess) L.r[i] = ri;
+        if (deg > 1) L.dd[i] = di;
+        L.x[i] = zero_guess ? di : L.x[i] + di;
+    }
+    __syncthreads();
+    const double *r_in = zero_guess ? b : L.r;
+    for (int k = 1; k < deg; ++k) {
+        tail_spmv(L.A, L.dd, L.t);
+        const ChebCoef c = cheb_coef(lmax, ratio, k);
+        const bool more = k + 1 < deg;
+        for (int64_t i = threadIdx.x; i < L.n; i += 1024) {
+            const double ri = r_in[i] - L.t[i];
+            const double di = __builtin_fma(c.c_dd, L.dd[i], c.c_r * L.dinv[i] * ri);
+            if (more) { L.r[i] = ri; L.dd[i] = di; }
+            L.x[i] += di;
+        }
+        __syncthreads();
+        r_in = L.r;
+    }
+}
+__global__ void __launch_bounds__(1024) k_amg_tail(AmgTail T, const CgCtl *ctl)
+{
+    if (ctl && ctl->flag != 0) return;
+    const int nl = T.nlev;
+    for (int l = 0; l < nl; ++l) {
+        const AmgTailLevel &L = T.lev[l];
+        if (l == nl - 1) {
+            if (T.dense_n > 0) {
+                const int n = T.dense_n;
+                for (int i = threadIdx.x; i < n; i += 1024) {
+                    double a = 0.0;
+                    for (int j = 0; j < n; ++j) a = __builtin_fma(T.dense_inv[j * n + i], L.b[j], a);
+                    L.x[i] = a;
+                }
+                __syncthreads();
+            } else {
+                tail_smooth(L, L.b, true, T.coarsest_deg, T.ratio);
+            }
+            break;
+        }
+        const AmgTailLevel &C = T.lev[l + 1];
+        tail_smooth(L, L.b, true, T.deg, T.ratio);
+        tail_spmv(L.A, L.x, L.t);
+        for (int64_t a = threadIdx.x; a < C.n; a += 1024) {
+            double acc = 0.0;
+            for (int q = L.mem_ptr[a]; q < L.mem_ptr[a + 1]; ++q) {
+                const int i = L.mem_idx[q];
+                acc += L.b[i] - L.t[i];
+            }
+            C.b[a] = acc;
+        }
+        __syncthreads();
+    }
+    for (int l = nl - 2; l >= 0; --l) {
+        const AmgTailLevel &L = T.lev[l];
+        const AmgTailLevel &C = T.lev[l + 1];
+        for (int64_t i = threadIdx.x; i < L.n; i += 1024) L.x[i] = __builtin_fma(T.scale, C.x[L.agg[i]], L.x[i]);
+        __syncthreads();
+        tail_smooth(L, L.b, false, T.deg, T.ratio);
+    }
 }
 
 // ---------------------------------------------------------------------------

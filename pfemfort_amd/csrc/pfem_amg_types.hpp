@@ -43,5 +43,7 @@ struct Amg {
     std::vector<uint64_t> graph_key;
     bool graph_off = false;
     ~Amg() { if (graph) (void)hipGraphExecDestroy(graph); }
+    int tail_from = -1;                              // first level of the single-launch tail of the cycle (-1: none)
+    bool fused = true;                               // fused SpMV epilogues on the coarse levels + the tail kernel (PFEM_AMG_FUSED=0: off)
     int coarsest_sweeps = 8;                         // Chebyshev degree on the last level when it is too large for the dense inverse
 };

@@ -1037,7 +1037,7 @@ extern "C" int pfem_pattern_build(pfem_solver *s)
         // More element-matrix entries than one sort call can index (config 5 on ONE device: 6.1e9): the keys of one
         // element range at a time are sorted and made unique, and the union of those lists -- a little more than
         // the nonzeros -- goes through pattern_from_keys like the keys of a small mesh.
-        const int64_t range = range_env > 0 ? range_env : std::min<int64_t>(INT_MAX / per_elem, 1LL << 26);
+        const int64_t range = std::min<int64_t>(range_env > 0 ? range_env : (1LL << 26), INT_MAX / per_elem);     // one sort call indexes < 2^31 keys
         PFEM_TRY(use_sort_bits(s));
         std::deque<DevBuf<uint64_t>> parts;          // (not movable: a deque constructs in place and never relocates)
         std::vector<int64_t> part_n;
@@ -1493,13 +1493,17 @@ int build_groups(pfem_solver *s)
     s->g_gap_words = tot_w;
     PFEM_TRY(s->d_gdwords.alloc(static_cast<size_t>(std::max<int64_t>(tot_w, 1))));
     PFEM_TRY(s->d_gvals.alloc(static_cast<size_t>(std::max<int64_t>(tot_e, 1)) * kGroupRows));
+    PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
     hipLaunchKernelGGL(k_group_cols_fill, dim3(grid_for(s->n_gslices * 64)), dim3(kBlock), 0, s->stream, s->sell(),
                        static_cast<const int32_t *>(s->d_group_row0.p), s->n_groups, s->n_gslices,
                        static_cast<const int64_t *>(s->d_gslice_off.p), static_cast<const int64_t *>(s->d_gslice_doff.p),
-                       s->d_gcol0.p, s->d_gdwords.p, s->row_dict ? static_cast<const uint32_t *>(s->d_row_gap_table.p) : nullptr);
+                       s->d_gcol0.p, s->d_gdwords.p, s->row_dict ? static_cast<const uint32_t *>(s->d_row_gap_table.p) : nullptr, s->d_err.p);
     PFEM_TRY(check_kernel("k_group_cols_fill"));
+    int miss = 0;
+    PFEM_TRY(fetch_err(s, &miss));
+    PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
     PFEM_HIP(hipStreamSynchronize(s->stream));
-    s->grouped = true;
+    s->grouped = miss == 0;          // a gap missing from the table: the row form stays (never wrong columns)
     return PFEM_OK;
 }
 
@@ -1577,13 +1581,18 @@ int build_rel_groups(pfem_solver *s)
     hipLaunchKernelGGL(k_rel_cols_fill<MODE>, dim3(grid_for(s->n_rslices * 64)), dim3(kBlock), 0, s->stream, s->sell(), s->n_rgroups, \
                        s->n_rslices, static_cast<const int64_t *>(s->d_rslice_off.p),                                             \
                        static_cast<const int64_t *>(s->d_rslice_doff.p), s->d_rcol0.p, s->d_rdwords.p,                            \
-                       static_cast<const uint32_t *>(s->d_gap_table.p))
+                       static_cast<const uint32_t *>(s->d_gap_table.p), s->d_err.p)
+    PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
     if (gap32) PFEM_REL_FILL(kGap32);
     else if (dict) PFEM_REL_FILL(kGapDict16);
     else PFEM_REL_FILL(kGapLit16);
 #undef PFEM_REL_FILL
     PFEM_TRY(check_kernel("k_rel_cols_fill"));
+    int miss = 0;
+    PFEM_TRY(fetch_err(s, &miss));
+    PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
     PFEM_HIP(hipStreamSynchronize(s->stream));
+    if (miss) return PFEM_OK;        // a gap missing from the table: the row form stays (never wrong columns)
     s->relgrouped = true;
     s->rel_gap32 = gap32;
     s->rel_dict = dict;

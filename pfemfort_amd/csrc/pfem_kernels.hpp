@@ -1266,12 +1266,16 @@ __device__ inline void gap_table_insert(uint32_t *tbl, uint32_t gap, int *overfl
     }
     atomicOr(overflow, 4);       // more distinct large gaps than the table holds
 }
-__device__ inline uint32_t gap_table_code(const uint32_t *tbl, uint32_t gap)
+// Every large gap of a pattern is put into the table by the walk that precedes the fill (k_row_gap_table /
+// k_rel_gap_table).  Should the two walks ever disagree, a gap would be missing here: that is flagged (`miss`), and the
+// builder drops the dictionary form instead of shipping a zero gap, i.e. wrong columns.
+__device__ inline uint32_t gap_table_code(const uint32_t *tbl, uint32_t gap, int *miss)
 {
     if (gap < 0x8000u) return gap;
     for (int i = 0; i < kGapTable; ++i)
         if (tbl[i] == gap) return 0x8000u | static_cast<uint32_t>(i);
-    return 0u;                   // not reached: every large gap was inserted by k_rel_gap_table
+    atomicMax(miss, 1);
+    return 0u;
 }
 
 // a 16-bit code of a gap stream -> the gap
@@ -1335,7 +1339,7 @@ __global__ void __launch_bounds__(kBlock) k_cols16_fill(SellDev A, const int64_t
                 const int c = cp[64 * k];
                 const int64_t g = static_cast<int64_t>(c) - prev;
                 if (g < 0 || (!DICT && g > 65535)) bad = true;
-                gap = (DICT ? gap_table_code(gap_table, static_cast<uint32_t>(g)) : static_cast<uint32_t>(g)) & 0xffffu;
+                gap = (DICT ? gap_table_code(gap_table, static_cast<uint32_t>(g), overflow) : static_cast<uint32_t>(g)) & 0xffffu;
                 prev = c;
             }
             w |= gap << (16 * h);
@@ -1496,7 +1500,7 @@ __global__ void __launch_bounds__(kBlock) k_gslice_sizes(const int32_t *group_ro
 __global__ void __launch_bounds__(kBlock) k_group_cols_fill(SellDev A, const int32_t *group_row0, int64_t n_groups,
                                                              int64_t n_gslices, const int64_t *gslice_off,
                                                              const int64_t *gslice_doff, int32_t *col0, uint32_t *dwords,
-                                                             const uint32_t *gap_table /* dictionary form, else null */)
+                                                             const uint32_t *gap_table /* dictionary form, else null */, int *miss)
 {
     const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     const int64_t gs = g >> 6;
@@ -1520,7 +1524,7 @@ __global__ void __launch_bounds__(kBlock) k_group_cols_fill(SellDev A, const int
             if (k < len) {
                 const int c = cp[64LL * k];
                 const uint32_t gap = static_cast<uint32_t>(c - prev);           // fits / is in the table: checked on the row form
-                w |= ((gap_table ? gap_table_code(gap_table, gap) : gap) & 0xffffu) << (16 * h);
+                w |= ((gap_table ? gap_table_code(gap_table, gap, miss) : gap) & 0xffffu) << (16 * h);
                 prev = c;
             }
         }
@@ -2022,7 +2026,7 @@ __global__ void __launch_bounds__(kBlock) k_rel_gap_table(SellDev A, int64_t n_g
 template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_rel_cols_fill(SellDev A, int64_t n_groups, int64_t n_gslices,
                                                            const int64_t *gslice_off, const int64_t *gslice_doff, int32_t *col0,
-                                                           uint32_t *dwords, const uint32_t *gap_table)
+                                                           uint32_t *dwords, const uint32_t *gap_table, int *miss)
 {
     constexpr bool GAP32 = MODE == kGap32;
     const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -2043,7 +2047,7 @@ __global__ void __launch_bounds__(kBlock) k_rel_cols_fill(SellDev A, int64_t n_g
         else if (GAP32) wp[64LL * (k - 1)] = static_cast<uint32_t>(o - prev);
         else {
             const int j = (k - 1) >> 1, h = (k - 1) & 1;
-            const uint32_t code = MODE == kGapDict16 ? gap_table_code(gap_table, static_cast<uint32_t>(o - prev))
+            const uint32_t code = MODE == kGapDict16 ? gap_table_code(gap_table, static_cast<uint32_t>(o - prev), miss)
                                                      : static_cast<uint32_t>(o - prev);
             wp[64LL * j] |= (code & 0xffffu) << (16 * h);
         }

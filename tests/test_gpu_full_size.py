@@ -71,6 +71,17 @@ def test_poisson_cube_full_size(n, N, nnz):
     o_rowptr, o_cols, o_vals, o_rhs = _oracle_system(O.POISSON_TET, mesh, O.POISSON_ELEMDATA)
     assert np.array_equal(rowptr, o_rowptr) and np.array_equal(cols, o_cols)
     assert np.array_equal(v_g, o_vals) and np.array_equal(s.getRHS(), o_rhs)
+    # bench.py's own path at this size: mesh + numbering GENERATED ON THE DEVICE (pfem_mesh_generate_box_axis), same bits
+    sz = H.box_slab_sizes(n, n, n)
+    g = pf.PetscSolver().initialise(sz["size_local"], sz["size_global"])
+    g.generateBoxMesh(pf.POISSON_TET, -1, 1, n, -1, 1, n, -1, 1, n)
+    g.buildPattern()
+    g.assemble(H.POISSON_ELEMDATA, H.TIMEDATA)
+    g_rowptr, g_cols, g_vals = g.getCSR()
+    assert np.array_equal(g_rowptr, o_rowptr) and np.array_equal(g_cols, o_cols) and np.array_equal(g_vals, o_vals)
+    assert np.array_equal(g.getRHS(), o_rhs)
+    g.free()
+    del g_rowptr, g_cols, g_vals
     # interior row of the uniform grid (x 1/h): 15 entries, diag 6.667/h', row sum 0
     r = N // 2
     row = v_g[rowptr[r]:rowptr[r + 1]]
@@ -99,6 +110,16 @@ def test_poisson_cube_full_size(n, N, nnz):
     assert -1e-6 < u.min() and u.max() <= 3.0               # docs image colour bar: 0 ... 3.00
     its2, _, _ = s.factoriseAndSolve()
     assert its2 == its and np.array_equal(s.getSolution(), u)   # the solve is bit-reproducible too
+    # -pc_type gamg at full size: the same answer (both solves stop at rtol 1e-10 of their own preconditioned norm) in a
+    # small fraction of the iterations; the hierarchy ends at a level the dense inverse takes; bit-reproducible
+    s.setPreconditioner("gamg")
+    its_g, reason_g, _ = s.factoriseAndSolve()
+    ug = s.getSolution()
+    info = s.amgInfo()
+    assert reason_g == 2 and its_g <= its // 8 and np.abs(ug - u).max() <= 2e-8 and np.abs(ug - exact).max() < 2e-7
+    assert info["rows"][0] == N and info["rows"][1] < N / 6 and sum(info["nnz"]) < 1.25 * nnz
+    its_g2, _, _ = s.factoriseAndSolve()
+    assert its_g2 == its_g and np.array_equal(s.getSolution(), ug)
 
 
 def test_elasticity_beam_config4():
