@@ -14,22 +14,26 @@ namespace pfem {
 // line by line this makes ties pair along the numbering direction, so three passes build 2x2x2 bricks instead of random
 // octets; (3) parity of the lower index: of the two neighbours of a node on a line exactly one forms an "even" edge, so
 // the whole line pairs up in ONE round; (4) a hash of the pair.  Positive couplings (w >= 0) are not eligible.
-__device__ __forceinline__ int64_t amg_edge_key(int32_t i, int32_t j, double w, double di, double dj)
+__device__ __forceinline__ int64_t amg_edge_key(int32_t i, int32_t j, int32_t hi_, int32_t hj_, double w, double di, double dj)
 {
     if (!(w < 0.0) || !(di > 0.0) || !(dj > 0.0)) return -1;
     const double s = -w / sqrt(di * dj);
     int b = static_cast<int>(floor(8.0 * log2(s))) + 2048;
     b = b < 1 ? 1 : (b > 4095 ? 4095 : b);
-    const int64_t lo = i < j ? i : j, hi = i < j ? j : i;
+    // (2), (3) on the nodes' PLACE ALONG A SPACE-FILLING CURVE when the mesh came with coordinates (hi_, hj_: Morton ranks,
+    // halved from pass to pass and from level to level), else on their indices
+    const int64_t lo = hi_ < hj_ ? hi_ : hj_, hi = hi_ < hj_ ? hj_ : hi_;
     const int64_t close = 0x7fffffffLL - (hi - lo);
     const int64_t par = (lo & 1) == 0;
-    const int64_t h = ((lo * 2654435761LL + hi * 40503LL) >> 7) & 0x7ffffLL;
+    const int64_t a = i < j ? i : j, c = i < j ? j : i;
+    const int64_t h = ((a * 2654435761LL + c * 40503LL) >> 7) & 0x7ffffLL;
     return (static_cast<int64_t>(b) << 51) | (close << 20) | (par << 19) | h;
 }
 
 // every free node proposes to its best free neighbour
 __global__ void __launch_bounds__(kBlock) k_amg_match_pick(int64_t n, const int64_t *__restrict__ gptr, const int32_t *__restrict__ gcol,
                                                             const double *__restrict__ gw, const double *__restrict__ gdiag,
+                                                            const int32_t *__restrict__ hint /* null: the index */,
                                                             const int32_t *__restrict__ match, int32_t *__restrict__ cand)
 {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -38,10 +42,11 @@ __global__ void __launch_bounds__(kBlock) k_amg_match_pick(int64_t n, const int6
     if (match[i] < 0) {
         int64_t bk = -1;
         const double di = gdiag[i];
+        const int32_t hi_ = hint ? hint[i] : static_cast<int32_t>(i);
         for (int64_t q = gptr[i]; q < gptr[i + 1]; ++q) {
             const int32_t j = gcol[q];
             if (j == i || match[j] >= 0) continue;
-            const int64_t k = amg_edge_key(static_cast<int32_t>(i), j, gw[q], di, gdiag[j]);
+            const int64_t k = amg_edge_key(static_cast<int32_t>(i), j, hi_, hint ? hint[j] : j, gw[q], di, gdiag[j]);
             if (k > bk) { bk = k; best = j; }
         }
     }
@@ -77,6 +82,22 @@ __global__ void __launch_bounds__(kBlock) k_amg_compose(int64_t n, int32_t *__re
 {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (i < n) total[i] = step[total[i]];
+}
+// place of an aggregate along the curve = the lowest place of its members, halved (a pair of curve neighbours 2k, 2k+1 -> k)
+__global__ void __launch_bounds__(kBlock) k_amg_hint_coarsen(int64_t n, const int32_t *__restrict__ hint, const int32_t *__restrict__ agg,
+                                                              int32_t *__restrict__ hint_c)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n) atomicMin(&hint_c[agg[i]], (hint ? hint[i] : static_cast<int32_t>(i)) >> 1);
+}
+// place of a node = place of its first dof / dofs per node
+__global__ void __launch_bounds__(kBlock) k_amg_node_hint(int64_t n, const int32_t *__restrict__ node_of, const int32_t *__restrict__ comp_of,
+                                                           const int32_t *__restrict__ dof_rank, int bs, int32_t *__restrict__ hint)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    if (!node_of) hint[i] = dof_rank[i];
+    else if (comp_of[i] == 0) hint[node_of[i]] = dof_rank[i] / bs;
 }
 __global__ void __launch_bounds__(kBlock) k_amg_iota(int64_t n, int32_t *__restrict__ v)
 {

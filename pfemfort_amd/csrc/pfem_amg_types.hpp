@@ -13,6 +13,7 @@ struct AmgLevel {
     int bs = 1;
     int64_t n_nodes = 0;
     DevBuf<int32_t> node_of, comp_of;
+    DevBuf<int32_t> hint;                 // [n_nodes] place of every node along a space-filling curve (empty: the index), for the pairing
     // transfer to the next level (piecewise-constant prolongation)
     int64_t nc = 0;
     DevBuf<int32_t> agg;                  // [n]  coarse dof of every dof

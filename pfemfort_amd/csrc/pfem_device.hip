@@ -212,6 +212,11 @@ struct pfem_solver {
     // local numbering
     int64_t n_loc = 0, n_ghost = 0;
     std::vector<int64_t> ghost_gid;
+    // internal renumbering of the owned dofs (meshes whose numbering has no locality; invisible at the ABI):
+    // perm[external local dof] = internal local dof, iperm = its inverse; empty = identity
+    bool reordered = false;
+    DevBuf<int32_t> d_perm;
+    std::vector<int32_t> h_perm, h_iperm;
 
     // matrix
     bool have_pattern = false;
@@ -538,6 +543,157 @@ extern "C" int pfem_get_timings(pfem_solver *s, pfem_timings *t)
 // ---------------------------------------------------------------------------
 // mesh upload
 // ---------------------------------------------------------------------------
+namespace {
+
+// A mesh file may number its nodes in any order.  When the numbering has no locality -- an element's dofs lie a large
+// fraction of the vector apart -- every x gather of the SpMV misses the caches (measured on the config-3 mesh under a random
+// node permutation: SpMV 2.05 ms against 0.21 ms, profiles/r03/bench_numbering_shuffle.json).  The owned dofs are then
+// renumbered INTERNALLY along a Morton curve through the node coordinates (dofs of a node stay together); every entry point
+// that takes or returns dof-indexed data translates, so the ABI keeps the caller's numbering, and K, F (summed per row in
+// element order, whatever the row is called) keep their bits.  PFEM_REORDER=0 / 1 forces it off / on; otherwise it is
+// taken when the mean index spread of an element exceeds 1/16 of the owned block.  The generated boxes
+// (pfem_mesh_generate_box) and the reference's partition renumbering are line-by-line numberings and are left alone: the
+// fastest SpMV forms live on them.
+int maybe_reorder(pfem_solver *s, const int32_t *edof_global, const double *xyz)
+{
+    s->reordered = false;
+    s->h_perm.clear();
+    s->h_iperm.clear();
+    const MeshDev &m = s->mesh;
+    const int64_t no = s->n_owned;
+    const char *env = std::getenv("PFEM_REORDER");
+    int want = env ? (std::atoi(env) != 0 ? 1 : 0) : -1;
+    if (no < 2 || m.nElem < 1) return PFEM_OK;
+    if (want < 0) {
+        if (no < 4096) return PFEM_OK;
+        const int64_t stride = std::max<int64_t>(1, m.nElem / 200000);
+        double sum = 0.0;
+        int64_t cnt = 0;
+        for (int64_t e = 0; e < m.nElem; e += stride) {
+            int64_t lo = INT64_MAX, hi = -1;
+            for (int q = 0; q < m.nsize; ++q) {
+                const int64_t g = edof_global[static_cast<int64_t>(q) * m.nElem + e];
+                if (g < s->row_start || g >= s->row_start + no) continue;
+                lo = std::min(lo, g);
+                hi = std::max(hi, g);
+            }
+            if (hi >= lo) { sum += static_cast<double>(hi - lo); ++cnt; }
+        }
+        want = (cnt > 0 && sum / static_cast<double>(cnt) > static_cast<double>(no) / 16.0) ? 1 : 0;
+    }
+    if (!want) return PFEM_OK;
+    double lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1};
+    for (int d = 0; d < m.ndim; ++d) {
+        const double *c = xyz + static_cast<int64_t>(d) * m.nNode;
+        const auto mm = std::minmax_element(c, c + m.nNode);
+        lo[d] = *mm.first;
+        hi[d] = *mm.second;
+    }
+    double sc[3];
+    for (int d = 0; d < 3; ++d) sc[d] = hi[d] > lo[d] ? 2097151.0 / (hi[d] - lo[d]) : 0.0;
+    DevBuf<uint64_t> keys, skeys;
+    DevBuf<int32_t> iota, order;
+    DevBuf<char> temp;
+    PFEM_TRY(keys.alloc(static_cast<size_t>(no)));
+    PFEM_TRY(skeys.alloc(static_cast<size_t>(no)));
+    PFEM_TRY(iota.alloc(static_cast<size_t>(no)));
+    PFEM_TRY(order.alloc(static_cast<size_t>(no)));
+    PFEM_TRY(s->d_perm.alloc(static_cast<size_t>(no)));
+    PFEM_HIP(hipMemsetAsync(keys.p, 0xff, sizeof(uint64_t) * no, s->stream));     // dofs no element touches go last
+    hipLaunchKernelGGL(k_morton_keys, dim3(grid_for(m.nElem * m.npe)), dim3(kBlock), 0, s->stream, m, no, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], keys.p);
+    hipLaunchKernelGGL(k_amg_iota, dim3(grid_for(no)), dim3(kBlock), 0, s->stream, no, iota.p);
+    PFEM_TRY(check_kernel("k_morton_keys"));
+    size_t tb = 0;
+    const int ni = static_cast<int>(no);
+    PFEM_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys.p, skeys.p, iota.p, order.p, ni, 0, 64, s->stream));
+    PFEM_TRY(temp.alloc(tb));
+    PFEM_HIP(hipcub::DeviceRadixSort::SortPairs(temp.p, tb, keys.p, skeys.p, iota.p, order.p, ni, 0, 64, s->stream));
+    hipLaunchKernelGGL(k_perm_from_order, dim3(grid_for(no)), dim3(kBlock), 0, s->stream, no, static_cast<const int32_t *>(order.p), s->d_perm.p);
+    const int64_t ndofs = static_cast<int64_t>(m.nsize) * m.nElem;
+    hipLaunchKernelGGL(k_apply_perm, dim3(grid_for(ndofs)), dim3(kBlock), 0, s->stream, s->d_edof.p, ndofs, no, static_cast<const int32_t *>(s->d_perm.p));
+    PFEM_TRY(check_kernel("k_apply_perm"));
+    s->h_perm.resize(static_cast<size_t>(no));
+    s->h_iperm.resize(static_cast<size_t>(no));
+    PFEM_HIP(hipMemcpyAsync(s->h_perm.data(), s->d_perm.p, sizeof(int32_t) * no, hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipMemcpyAsync(s->h_iperm.data(), order.p, sizeof(int32_t) * no, hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    s->reordered = true;
+    return PFEM_OK;
+}
+
+// Morton rank of every owned dof of the uploaded / generated mesh (rank[l] = place of dof l when the owned dofs are
+// sorted along the curve through their nodes; the dofs of a node are adjacent).  Bounding box from the device copy.
+int morton_rank(pfem_solver *s, DevBuf<int32_t> &rank)
+{
+    const MeshDev &m = s->mesh;
+    const int64_t no = s->n_owned;
+    if (!s->have_mesh || no < 1 || m.nElem < 1) return PFEM_ERR_STATE;
+    double lo[3] = {0, 0, 0}, sc[3] = {0, 0, 0};
+    {
+        DevBuf<double> d_mm;
+        DevBuf<char> tmp;
+        PFEM_TRY(d_mm.alloc(2));
+        for (int d = 0; d < m.ndim; ++d) {
+            const double *c = m.xyz + static_cast<int64_t>(d) * m.nNode;
+            size_t tb = 0, tb2 = 0;
+            PFEM_HIP(hipcub::DeviceReduce::Min(nullptr, tb, c, d_mm.p, static_cast<int>(m.nNode), s->stream));
+            PFEM_HIP(hipcub::DeviceReduce::Max(nullptr, tb2, c, d_mm.p + 1, static_cast<int>(m.nNode), s->stream));
+            if (std::max(tb, tb2) > tmp.n) PFEM_TRY(tmp.alloc(std::max(tb, tb2)));
+            PFEM_HIP(hipcub::DeviceReduce::Min(tmp.p, tb, c, d_mm.p, static_cast<int>(m.nNode), s->stream));
+            PFEM_HIP(hipcub::DeviceReduce::Max(tmp.p, tb2, c, d_mm.p + 1, static_cast<int>(m.nNode), s->stream));
+            double mm[2];
+            PFEM_HIP(hipMemcpyAsync(mm, d_mm.p, sizeof mm, hipMemcpyDeviceToHost, s->stream));
+            PFEM_HIP(hipStreamSynchronize(s->stream));
+            lo[d] = mm[0];
+            sc[d] = mm[1] > mm[0] ? 2097151.0 / (mm[1] - mm[0]) : 0.0;
+        }
+    }
+    DevBuf<uint64_t> keys, skeys;
+    DevBuf<int32_t> iota, order;
+    DevBuf<char> temp;
+    PFEM_TRY(keys.alloc(static_cast<size_t>(no)));
+    PFEM_TRY(skeys.alloc(static_cast<size_t>(no)));
+    PFEM_TRY(iota.alloc(static_cast<size_t>(no)));
+    PFEM_TRY(order.alloc(static_cast<size_t>(no)));
+    PFEM_TRY(rank.alloc(static_cast<size_t>(no)));
+    PFEM_HIP(hipMemsetAsync(keys.p, 0xff, sizeof(uint64_t) * no, s->stream));
+    hipLaunchKernelGGL(k_morton_keys, dim3(grid_for(m.nElem * m.npe)), dim3(kBlock), 0, s->stream, m, no, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], keys.p);
+    hipLaunchKernelGGL(k_amg_iota, dim3(grid_for(no)), dim3(kBlock), 0, s->stream, no, iota.p);
+    PFEM_TRY(check_kernel("k_morton_keys"));
+    size_t tb = 0;
+    const int ni = static_cast<int>(no);
+    PFEM_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys.p, skeys.p, iota.p, order.p, ni, 0, 64, s->stream));
+    PFEM_TRY(temp.alloc(tb));
+    PFEM_HIP(hipcub::DeviceRadixSort::SortPairs(temp.p, tb, keys.p, skeys.p, iota.p, order.p, ni, 0, 64, s->stream));
+    hipLaunchKernelGGL(k_perm_from_order, dim3(grid_for(no)), dim3(kBlock), 0, s->stream, no, static_cast<const int32_t *>(order.p), rank.p);
+    PFEM_TRY(check_kernel("k_perm_from_order"));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    return PFEM_OK;
+}
+
+// external local dof index -> internal (identity unless the mesh was renumbered internally)
+inline int32_t to_internal(const pfem_solver *s, int64_t l) { return (s->reordered && l < s->n_owned) ? s->h_perm[static_cast<size_t>(l)] : static_cast<int32_t>(l); }
+inline int32_t to_external(const pfem_solver *s, int64_t l) { return (s->reordered && l < s->n_owned) ? s->h_iperm[static_cast<size_t>(l)] : static_cast<int32_t>(l); }
+
+// device vector in internal numbering -> host array in the caller's numbering
+int download_external(pfem_solver *s, const double *d_vec, double *out, int64_t n)
+{
+    if (!s->reordered) {
+        PFEM_HIP(hipMemcpyAsync(out, d_vec, sizeof(double) * n, hipMemcpyDeviceToHost, s->stream));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+        return PFEM_OK;
+    }
+    DevBuf<double> tmp;
+    PFEM_TRY(tmp.alloc(static_cast<size_t>(std::max<int64_t>(n, 1))));
+    hipLaunchKernelGGL(k_gather_perm, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, n, s->n_owned, static_cast<const int32_t *>(s->d_perm.p), d_vec, tmp.p);
+    PFEM_TRY(check_kernel("k_gather_perm"));
+    PFEM_HIP(hipMemcpyAsync(out, tmp.p, sizeof(double) * n, hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    return PFEM_OK;
+}
+
+}  // namespace
+
 extern "C" int pfem_mesh_upload(pfem_solver *s, int kind, int64_t nElem, const int32_t *conn,
                                 int64_t nNode, const double *xyz, const int32_t *edof,
                                 const double *solnApplied)
@@ -590,6 +746,7 @@ extern "C" int pfem_mesh_upload(pfem_solver *s, int kind, int64_t nElem, const i
     m.edof = s->d_edof.p;
     m.xyz = s->d_xyz.p;
     m.soln = s->d_soln.p;
+    PFEM_TRY(maybe_reorder(s, edof, xyz));
     s->have_mesh = true;
     s->have_pattern = false;
     s->tm.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -727,6 +884,9 @@ extern "C" int pfem_mesh_generate_box_axis(pfem_solver *s, int kind, double x0, 
     m.edof = s->d_edof.p;
     m.xyz = s->d_xyz.p;
     m.soln = s->d_soln.p;
+    s->reordered = false;
+    s->h_perm.clear();
+    s->h_iperm.clear();
     s->have_mesh = true;
     s->have_pattern = false;
     s->have_plan = false;
@@ -753,6 +913,9 @@ extern "C" int pfem_mesh_download(pfem_solver *s, int32_t *conn, double *xyz, in
     if (edof_local) PFEM_HIP(hipMemcpyAsync(edof_local, s->d_edof.p, sizeof(int32_t) * m.nsize * m.nElem, hipMemcpyDeviceToHost, s->stream));
     if (solnApplied) PFEM_HIP(hipMemcpyAsync(solnApplied, s->d_soln.p, sizeof(double) * m.ndof * m.nNode, hipMemcpyDeviceToHost, s->stream));
     PFEM_HIP(hipStreamSynchronize(s->stream));
+    if (edof_local && s->reordered)        // the caller's local numbering
+        for (int64_t i = 0; i < static_cast<int64_t>(m.nsize) * m.nElem; ++i)
+            if (edof_local[i] >= 0) edof_local[i] = to_external(s, edof_local[i]);
     return PFEM_OK;
 }
 
@@ -1282,7 +1445,7 @@ extern "C" int pfem_rhs_add_values(pfem_solver *s, int64_t n, const int64_t *gdo
         if (gdof[i] < 0) continue;
         if (gdof[i] >= s->size_global) return PFEM_ERR_ARG;
         if (gdof[i] < s->row_start || gdof[i] >= s->row_start + s->n_owned) continue;
-        idx.push_back(static_cast<int32_t>(gdof[i] - s->row_start));
+        idx.push_back(to_internal(s, gdof[i] - s->row_start));
         val.push_back(v[i]);
     }
     if (idx.empty()) return PFEM_OK;
@@ -1345,6 +1508,41 @@ extern "C" int pfem_get_csr(pfem_solver *s, int64_t *rowptr, int32_t *cols, doub
         PFEM_HIP(hipStreamSynchronize(s->stream));
     }
     PFEM_HIP(hipStreamSynchronize(s->stream));
+    if (s->reordered) {
+        // the matrix lives in the internal numbering: hand it out in the caller's (rows in external order, the columns of a
+        // row translated and ascending again -- what PETSc's AIJ would hold for the caller's indices)
+        const int64_t n = s->n_loc;
+        std::vector<int64_t> ip(static_cast<size_t>(n) + 1);
+        std::vector<int32_t> ic(static_cast<size_t>(s->nnz));
+        std::vector<double> iv(vals ? static_cast<size_t>(s->nnz) : 0);
+        PFEM_HIP(hipMemcpy(ip.data(), s->d_rowptr.p, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost));
+        if (!cols) {          // the columns are needed for the order even when the caller wants values only
+            DevBuf<int32_t> dc;
+            PFEM_TRY(dc.alloc(static_cast<size_t>(s->nnz)));
+            hipLaunchKernelGGL(k_sell_to_csr, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->sell(), s->d_rowptr.p, dc.p, static_cast<double *>(nullptr));
+            PFEM_HIP(hipMemcpy(ic.data(), dc.p, sizeof(int32_t) * s->nnz, hipMemcpyDeviceToHost));
+        } else {
+            std::copy(cols, cols + s->nnz, ic.begin());
+        }
+        if (vals) std::copy(vals, vals + s->nnz, iv.begin());
+        std::vector<int64_t> ep(static_cast<size_t>(n) + 1, 0);
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t r = to_internal(s, i);
+            ep[static_cast<size_t>(i) + 1] = ep[static_cast<size_t>(i)] + (ip[static_cast<size_t>(r) + 1] - ip[static_cast<size_t>(r)]);
+        }
+        std::vector<std::pair<int32_t, double>> row;
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t r = to_internal(s, i), b = ip[static_cast<size_t>(r)], e = ip[static_cast<size_t>(r) + 1];
+            row.clear();
+            for (int64_t q = b; q < e; ++q) row.emplace_back(to_external(s, ic[static_cast<size_t>(q)]), vals ? iv[static_cast<size_t>(q)] : 0.0);
+            std::sort(row.begin(), row.end(), [](const std::pair<int32_t, double> &a, const std::pair<int32_t, double> &c) { return a.first < c.first; });
+            for (size_t k = 0; k < row.size(); ++k) {
+                if (cols) cols[ep[static_cast<size_t>(i)] + static_cast<int64_t>(k)] = row[k].first;
+                if (vals) vals[ep[static_cast<size_t>(i)] + static_cast<int64_t>(k)] = row[k].second;
+            }
+        }
+        if (rowptr) std::copy(ep.begin(), ep.end(), rowptr);
+    }
     return PFEM_OK;
 }
 
@@ -1353,9 +1551,7 @@ extern "C" int pfem_get_rhs(pfem_solver *s, double *rhs_local)
     if (!s || !rhs_local) return PFEM_ERR_ARG;
     if (!s->have_pattern) return PFEM_ERR_STATE;
     PFEM_TRY(use_device(s));
-    PFEM_HIP(hipMemcpyAsync(rhs_local, s->d_rhs.p, sizeof(double) * s->n_loc, hipMemcpyDeviceToHost, s->stream));
-    PFEM_HIP(hipStreamSynchronize(s->stream));
-    return PFEM_OK;
+    return download_external(s, s->d_rhs.p, rhs_local, s->n_loc);
 }
 
 // ---------------------------------------------------------------------------
@@ -1750,14 +1946,17 @@ extern "C" int pfem_spmv(pfem_solver *s, const double *x, double *y)
     if (!s->have_pattern) return PFEM_ERR_STATE;
     PFEM_TRY(use_device(s));
     const size_t nb = sizeof(double) * static_cast<size_t>(s->n_loc);
-    PFEM_HIP(hipMemcpyAsync(s->d_p.p, x, nb, hipMemcpyHostToDevice, s->stream));
+    std::vector<double> xi;
+    if (s->reordered) {                     // the caller's numbering -> the internal one
+        xi.assign(x, x + s->n_loc);
+        for (int64_t i = 0; i < s->n_owned; ++i) xi[static_cast<size_t>(s->h_perm[static_cast<size_t>(i)])] = x[i];
+    }
+    PFEM_HIP(hipMemcpyAsync(s->d_p.p, s->reordered ? xi.data() : x, nb, hipMemcpyHostToDevice, s->stream));
     s->group_vals_stale = true;
     PFEM_TRY(refresh_group_vals(s));
     launch_spmv<false>(s, s->d_p.p, s->d_w.p, 0, nullptr, nullptr);
     PFEM_TRY(check_kernel("k_spmv"));
-    PFEM_HIP(hipMemcpyAsync(y, s->d_w.p, nb, hipMemcpyDeviceToHost, s->stream));
-    PFEM_HIP(hipStreamSynchronize(s->stream));
-    return PFEM_OK;
+    return download_external(s, s->d_w.p, y, s->n_loc);
 }
 
 extern "C" int pfem_bench_spmv(pfem_solver *s, int reps, double *ms_per_launch)
@@ -2065,7 +2264,7 @@ extern "C" int pfem_solver_set_neighbours(pfem_solver *s, int n_peers, const int
         for (int64_t i = peer_off[k]; i < peer_off[k + 1]; ++i) {
             const int64_t g = shared_gid[i];
             if (i > peer_off[k] && shared_gid[i - 1] >= g) return PFEM_ERR_ARG;
-            if (g >= lo && g < hi) { send_lidx[i] = static_cast<int32_t>(g - lo); continue; }
+            if (g >= lo && g < hi) { send_lidx[i] = to_internal(s, g - lo); continue; }
             auto it = std::lower_bound(s->ghost_gid.begin(), s->ghost_gid.end(), g);
             if (it == s->ghost_gid.end() || *it != g) { set_last_error("neighbour plan names a dof this rank does not hold"); return PFEM_ERR_ARG; }
             send_lidx[i] = static_cast<int32_t>(s->n_owned + (it - s->ghost_gid.begin()));
@@ -3238,9 +3437,7 @@ extern "C" int pfem_solver_get_solution(pfem_solver *s, double *x_owned)
     if (!s || !x_owned) return PFEM_ERR_ARG;
     if (!s->have_pattern) return PFEM_ERR_STATE;
     PFEM_TRY(use_device(s));
-    PFEM_HIP(hipMemcpyAsync(x_owned, s->d_x.p, sizeof(double) * s->n_owned, hipMemcpyDeviceToHost, s->stream));
-    PFEM_HIP(hipStreamSynchronize(s->stream));
-    return PFEM_OK;
+    return download_external(s, s->d_x.p, x_owned, s->n_owned);
 }
 
 extern "C" int pfem_solver_get_history(pfem_solver *s, double *hist, int n, int *n_written)
@@ -3288,6 +3485,10 @@ extern "C" int pfem_solver_amg_aggregates(pfem_solver *s, int level, int32_t *ag
     PFEM_TRY(use_device(s));
     const AmgLevel &L = *s->amg->lev[static_cast<size_t>(level)];
     PFEM_HIP(hipMemcpy(agg, L.agg.p, sizeof(int32_t) * static_cast<size_t>(L.n), hipMemcpyDeviceToHost));
+    if (level == 0 && s->reordered) {          // level 0 is indexed by the caller's dofs
+        std::vector<int32_t> in(agg, agg + L.n);
+        for (int64_t i = 0; i < L.n; ++i) agg[i] = in[static_cast<size_t>(to_internal(s, i))];
+    }
     return PFEM_OK;
 }
 

@@ -184,6 +184,58 @@ __global__ void __launch_bounds__(kBlock) k_localize_dofs(int32_t *edof, int64_t
 }
 
 // ---------------------------------------------------------------------------
+// internal renumbering of the owned dofs of an uploaded mesh whose numbering has no locality (Morton order of the nodes)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t morton_spread21(uint64_t v)
+{
+    v &= 0x1fffffull;
+    v = (v | (v << 32)) & 0x1f00000000ffffull;
+    v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+// key of every owned dof = Morton code of its node (21 bits per axis inside the bounding box); the dofs of a node share
+// the key and stay in their order (the sort that follows is stable)
+__global__ void __launch_bounds__(kBlock) k_morton_keys(MeshDev m, int64_t n_owned, double x0, double y0, double z0, double sx, double sy,
+                                                         double sz, uint64_t *__restrict__ keys)
+{
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (t >= m.nElem * m.npe) return;
+    const int64_t e = t % m.nElem;
+    const int a = static_cast<int>(t / m.nElem);
+    const int32_t nd = m.conn[a * m.nElem + e];
+    const double px = (m.xyz[nd] - x0) * sx, py = (m.xyz[m.nNode + nd] - y0) * sy;
+    const double pz = m.ndim > 2 ? (m.xyz[2 * m.nNode + nd] - z0) * sz : 0.0;
+    const uint64_t key = morton_spread21(static_cast<uint64_t>(px)) | (morton_spread21(static_cast<uint64_t>(py)) << 1) |
+                         (morton_spread21(static_cast<uint64_t>(pz)) << 2);
+    for (int d = 0; d < m.ndof; ++d) {
+        const int32_t l = m.edof[(a * m.ndof + d) * m.nElem + e];
+        if (l >= 0 && l < n_owned) keys[l] = key;          // every visit of a dof writes the same value
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_perm_from_order(int64_t n, const int32_t *__restrict__ order, int32_t *__restrict__ perm)
+{
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (k < n) perm[order[k]] = static_cast<int32_t>(k);
+}
+__global__ void __launch_bounds__(kBlock) k_apply_perm(int32_t *__restrict__ edof, int64_t count, int64_t n_owned, const int32_t *__restrict__ perm)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= count) return;
+    const int32_t l = edof[i];
+    if (l >= 0 && l < n_owned) edof[i] = perm[l];
+}
+// out[i] = in[perm[i]] over the owned part, the rest copied
+__global__ void __launch_bounds__(kBlock) k_gather_perm(int64_t n, int64_t n_owned, const int32_t *__restrict__ perm, const double *__restrict__ in,
+                                                         double *__restrict__ out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n) out[i] = in[i < n_owned ? perm[i] : i];
+}
+
+// ---------------------------------------------------------------------------
 // structured box generated on the device (genTetra.cpp's mesh + the driver's numbering for one slab along any axis)
 // ---------------------------------------------------------------------------
 struct BoxOwnerDev {

@@ -919,3 +919,60 @@ def test_gamg_fused_cycle_equals_level_by_level_kernels(case, beam, monkeypatch)
     for key in (("0", "1"), ("1", "0")):
         b = out[key]
         assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+
+
+def _shuffled(mesh, seed=7):
+    """The same mesh under a random node numbering (what an arbitrary mesh file may look like)."""
+    perm = np.random.default_rng(seed).permutation(mesh.nNode).astype(np.int32)       # old id -> new id
+    xyz = np.empty_like(mesh.xyz)
+    xyz[:, perm] = mesh.xyz
+    return H.Mesh(xyz, perm[mesh.conn], perm[mesh.bc_node], mesh.bc_dof, mesh.bc_val, box=mesh.box)
+
+
+@pytest.mark.parametrize("kind_name", ["poisson", "elast"])
+def test_internal_renumbering_is_invisible_at_the_boundary(kind_name, monkeypatch):
+    """A mesh whose node numbering has no locality is renumbered INSIDE the library (Morton order of the nodes, owned dofs
+    only; taken automatically when an element's dofs lie far apart, PFEM_REORDER=0/1 forces it) -- and nothing of it shows
+    at the ABI: pattern, K and F come back in the caller's numbering with the same bits as without the renumbering (and as
+    the oracle's serial loop), SpMV / solution / element dof array / aggregates are indexed by the caller's dofs, the
+    solve gives the same answer; and the SpMV form that the renumbered matrix allows is a 16-bit one again."""
+    if kind_name == "poisson":
+        kind, ed, okind = pf.POISSON_TET, H.POISSON_ELEMDATA, O.POISSON_TET
+        mesh = _shuffled(H.gen_box_tets(-1, 1, 22, -1, 1, 20, -1, 1, 24))
+    else:
+        kind, ed, okind = pf.ELAST_TET, H.ELAST_ELEMDATA, O.ELAST_TET
+        mesh = _shuffled(H.gen_box_tets(-0.5, 0.5, 8, 0.0, 6.0, 40, -0.5, 0.5, 8, bc_mode=1, ndof=3))
+    out = {}
+    for reorder in ("0", "auto"):
+        if reorder == "auto":
+            monkeypatch.delenv("PFEM_REORDER", raising=False)
+        else:
+            monkeypatch.setenv("PFEM_REORDER", reorder)
+        s, dm = _device_problem(kind, mesh, ed)
+        rowptr, cols, vals = s.getCSR()
+        rng = np.random.default_rng(3)
+        x = rng.standard_normal(dm.size_global)
+        _, _, edof_l, _ = s.downloadMesh()
+        s.setTolerances(rtol=1e-10, maxits=20000)
+        its, reason, _ = s.factoriseAndSolve()
+        u = s.getSolution()
+        s.setPreconditioner("gamg")
+        its_g, reason_g, _ = s.factoriseAndSolve()
+        ug = s.getSolution()
+        agg0 = s.amgAggregates(0, dm.size_global)
+        out[reorder] = dict(rowptr=rowptr, cols=cols, vals=vals, rhs=s.getRHS(), y=s.spmv(x), edof=edof_l, its=its, u=u, its_g=its_g, ug=ug,
+                            agg0=agg0, bits=s.spmvColumnBits(), reasons=(reason, reason_g))
+        s.free()
+    a, b = out["0"], out["auto"]
+    for k in ("rowptr", "cols", "vals", "rhs", "edof"):
+        assert np.array_equal(a[k], b[k]), k
+    prob = O.setup_problem(okind, O.Mesh(mesh.xyz, mesh.conn, mesh.bc_node, mesh.bc_dof, mesh.bc_val))
+    assert np.array_equal(b["rowptr"], prob.rowptr) and np.array_equal(b["cols"], prob.cols)
+    assert np.array_equal(b["vals"], prob.vals) and np.array_equal(b["rhs"], prob.rhs)
+    scale = np.abs(a["y"]).max()
+    assert np.abs(a["y"] - b["y"]).max() <= 1e-12 * scale                      # a row sums its products in another order
+    assert a["reasons"] == b["reasons"] == (2, 2) and abs(a["its"] - b["its"]) <= max(2, a["its"] // 50)
+    assert np.abs(a["u"] - b["u"]).max() <= 1e-8 * max(1.0, np.abs(a["u"]).max())
+    assert np.abs(b["ug"] - b["u"]).max() <= 1e-8 * max(1.0, np.abs(a["u"]).max())
+    # the aggregates are indexed by the caller's dofs; the multigrid solve is at least as good as on the scrambled numbering
+    assert b["bits"] == 16 and b["its_g"] <= a["its_g"] + 2 and len(np.unique(b["agg0"])) == b["agg0"].max() + 1
