@@ -99,10 +99,15 @@ def cpu_baseline(n, rtol, extra_sample=True):
     nb = 12 * len(prob[4]) + 20 * N
     run(prob, cores)                                             # first touch / thread pool warm-up
     am, sm, its = run(prob, cores)
+    O.set_threads(cores)
+    triad = O.stream_triad_gbps()
     out = {"value": N / (am + sm), "unit": "DOF/s", "cores": cores, "kind": "port",
+           "preconditioner": "point Jacobi (the GPU's jacobi_step is the like-for-like figure; `value` runs -pc_type gamg)",
+           "host_stream_triad_gbps": triad,
            "sample": f"{n}^3x6 tet Poisson (the GPU number's own configuration), N={N}: {cores} OpenMP threads: assembly "
                      f"{am:.2f}s + Jacobi-PCG rtol {rtol:g} {its} its {sm:.2f}s = {am + sm:.2f}s "
-                     f"({nb * its / sm / 1e9:.0f} GB/s SpMV-equivalent); reference-equivalent CPU path (C restatement), not PETSc",
+                     f"({nb * its / sm / 1e9:.0f} GB/s SpMV-equivalent; the host's STREAM triad with the same threads: {triad:.0f} GB/s); "
+                     "reference-equivalent CPU path (C restatement), not PETSc",
            "assembly_s": am, "solve_s": sm, "total_s": am + sm, "its": its, "setup_s_untimed": t_setup}
     del prob
     if extra_sample:

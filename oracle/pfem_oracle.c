@@ -31,6 +31,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 #include <string.h>
 
 #define ORC_OK 0
@@ -685,6 +686,32 @@ int orc_assemble_mt(int kind, int64_t nElem, const int32_t *conn, int64_t nNode,
 /* semantics are third-party knowledge: PETSc 3.6-era, left-preconditioned,  */
 /* KSP_NORM_PRECONDITIONED, zero initial guess per solverpetsc.F:459).       */
 /* ------------------------------------------------------------------------ */
+
+/* STREAM triad a = b + q*c on the host with the OpenMP threads of the baseline (first touch by the same threads): the
+ * memory bandwidth the CPU figures of bench.py should be read against.  Test infrastructure, not a restatement. */
+double orc_stream_triad_gbps(int64_t n, int reps)
+{
+    double *a = (double *)malloc(sizeof(double) * (size_t)n), *b = (double *)malloc(sizeof(double) * (size_t)n),
+           *c = (double *)malloc(sizeof(double) * (size_t)n);
+    double best = 0.0;
+    int64_t i;
+    int r;
+    if (!a || !b || !c) { free(a); free(b); free(c); return 0.0; }
+#pragma omp parallel for schedule(static)
+    for (i = 0; i < n; ++i) { a[i] = 0.0; b[i] = 1.0; c[i] = 2.0; }
+    for (r = 0; r < reps; ++r) {
+        struct timespec t0, t1;
+        double dt;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+#pragma omp parallel for schedule(static)
+        for (i = 0; i < n; ++i) a[i] = b[i] + 3.0 * c[i];
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        dt = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+        if (dt > 0.0 && 24.0e-9 * (double)n / dt > best) best = 24.0e-9 * (double)n / dt;
+    }
+    free(a); free(b); free(c);
+    return best;
+}
 
 void orc_spmv(int64_t N, const int64_t *rowptr, const int32_t *cols, const double *vals,
               const double *x, double *y)

@@ -551,7 +551,7 @@ namespace {
 // renumbered INTERNALLY along a Morton curve through the node coordinates (dofs of a node stay together); every entry point
 // that takes or returns dof-indexed data translates, so the ABI keeps the caller's numbering, and K, F (summed per row in
 // element order, whatever the row is called) keep their bits.  PFEM_REORDER=0 / 1 forces it off / on; otherwise it is
-// taken when the mean index spread of an element exceeds 1/16 of the owned block.  The generated boxes
+// taken when most elements have no two nodes whose dofs lie within a few thousand places of each other.  The generated boxes
 // (pfem_mesh_generate_box) and the reference's partition renumbering are line-by-line numberings and are left alone: the
 // fastest SpMV forms live on them.
 int maybe_reorder(pfem_solver *s, const int32_t *edof_global, const double *xyz)
@@ -565,21 +565,27 @@ int maybe_reorder(pfem_solver *s, const int32_t *edof_global, const double *xyz)
     int want = env ? (std::atoi(env) != 0 ? 1 : 0) : -1;
     if (no < 2 || m.nElem < 1) return PFEM_OK;
     if (want < 0) {
+        // "no locality" = the nodes of an element have nothing to do with each other in the numbering: in a line-by-line
+        // (lattice, partition-renumbered, Morton, advancing-front ...) numbering most elements hold two nodes whose dofs are a
+        // few places apart, under a random numbering none does.  (The index SPREAD of an element says nothing: a thin lattice
+        // slab has a spread of a third of the vector and runs the fastest SpMV form there is.)
         if (no < 4096) return PFEM_OK;
         const int64_t stride = std::max<int64_t>(1, m.nElem / 200000);
-        double sum = 0.0;
-        int64_t cnt = 0;
+        const int64_t near = 2048LL * m.ndof;
+        int64_t far_elems = 0, cnt = 0;
         for (int64_t e = 0; e < m.nElem; e += stride) {
-            int64_t lo = INT64_MAX, hi = -1;
-            for (int q = 0; q < m.nsize; ++q) {
-                const int64_t g = edof_global[static_cast<int64_t>(q) * m.nElem + e];
-                if (g < s->row_start || g >= s->row_start + no) continue;
-                lo = std::min(lo, g);
-                hi = std::max(hi, g);
+            int64_t best = INT64_MAX;
+            int owned = 0;
+            int64_t g[8];
+            for (int a = 0; a < m.npe && a < 8; ++a) {
+                const int64_t v = edof_global[static_cast<int64_t>(a * m.ndof) * m.nElem + e];     // component 0 of node a
+                if (v < s->row_start || v >= s->row_start + no) continue;
+                for (int b = 0; b < owned; ++b) best = std::min<int64_t>(best, std::llabs(v - g[b]));
+                g[owned++] = v;
             }
-            if (hi >= lo) { sum += static_cast<double>(hi - lo); ++cnt; }
+            if (owned >= 2) { ++cnt; far_elems += best > near; }
         }
-        want = (cnt > 0 && sum / static_cast<double>(cnt) > static_cast<double>(no) / 16.0) ? 1 : 0;
+        want = (cnt > 0 && 2 * far_elems > cnt) ? 1 : 0;
     }
     if (!want) return PFEM_OK;
     double lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1};

@@ -409,7 +409,7 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
         _, its_oracle, reason_oracle, *_ = O.pcg_bjacobi_amg(prob.rowptr, prob.cols, prob.vals, prob.rhs, blocks, rtol=1e-10, cheb_degree=int(deg),
                                                              eig_ratio=float(ratio), coarse_scale=float(scale), fine_degree=int(fdeg))
         assert reason_oracle == 2 and (its_oracle < its_jacobi or kind_name == "elast")     # (tiny beam blocks: no gain to expect)
-        its_tol = 2
+        its_tol = max(2, its_oracle // 50)          # (runs of hundreds of iterations on the little beam: +-2 %)
     if mode == "pbjacobi":
         want = "pbjacobi" if kind_name == "elast" else "jacobi"      # Poisson has no multi-row groups: all ranks fall back
         assert all(str(np.load(tmp_path / f"rank{r}.npz")["pc"]) == want for r in range(world))
