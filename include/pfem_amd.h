@@ -333,7 +333,7 @@ int pfem_solver_amg_info(pfem_solver *s, int max_levels, int *n_levels, int64_t 
 int pfem_solver_amg_aggregates(pfem_solver *s, int level, int32_t *agg);
 /* -pc_gamg knobs: Chebyshev degree on the coarse levels (1..6, default 2) and on the assembled matrix itself (0 = the same;
  * default 1: there an SpMV is dearest), lmax/lmin of the smoothing interval (default 8), scaling of the coarse-grid
- * correction (default 1.8: the over-correction a piecewise-constant coarse space wants, Braess 1995)                              */
+ * correction (default 1.5: the over-correction a piecewise-constant coarse space wants)                              */
 int pfem_solver_set_amg_options(pfem_solver *s, int cheb_degree, int fine_degree, double eig_ratio, double coarse_scale);
 /* KSPCGUseSingleReduction / -ksp_cg_single_reduction (PETSc option of the KSPCG the reference creates, solverpetsc.F:187;
  * off by default there and here): the Chronopoulos-Gear form of the same iteration -- s = A z instead of w = A p,

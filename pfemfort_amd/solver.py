@@ -220,7 +220,7 @@ class PetscSolver:
         L.check(L.lib().pfem_solver_get_preconditioner(self._h, C.byref(b)), "pfem_solver_get_preconditioner")
         return ("jacobi", "pbjacobi", "gamg")[b.value]
 
-    def setAmgOptions(self, cheb_degree=2, fine_degree=1, eig_ratio=8.0, coarse_scale=1.8):
+    def setAmgOptions(self, cheb_degree=2, fine_degree=1, eig_ratio=8.0, coarse_scale=1.5):
         """-pc_gamg knobs: Chebyshev degree on the coarse levels / on the assembled matrix (0: the same), lmax/lmin of the
         smoothing interval, scaling of the coarse-grid correction."""
         L.check(L.lib().pfem_solver_set_amg_options(self._h, cheb_degree, fine_degree, eig_ratio, coarse_scale), "pfem_solver_set_amg_options")
