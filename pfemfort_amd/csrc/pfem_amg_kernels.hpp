@@ -14,12 +14,13 @@ namespace pfem {
 // line by line this makes ties pair along the numbering direction, so three passes build 2x2x2 bricks instead of random
 // octets; (3) parity of the lower index: of the two neighbours of a node on a line exactly one forms an "even" edge, so
 // the whole line pairs up in ONE round; (4) a hash of the pair.  Positive couplings (w >= 0) are not eligible.
-__device__ __forceinline__ int64_t amg_edge_key(int32_t i, int32_t j, int32_t hi_, int32_t hj_, double w, double di, double dj)
+__device__ __forceinline__ int64_t amg_edge_key(int32_t i, int32_t j, int32_t hi_, int32_t hj_, double w, double di, double dj, int flat)
 {
     if (!(w < 0.0) || !(di > 0.0) || !(dj > 0.0)) return -1;
     const double s = -w / sqrt(di * dj);
     int b = static_cast<int>(floor(8.0 * log2(s))) + 2048;
     b = b < 1 ? 1 : (b > 4095 ? 4095 : b);
+    if (flat) b = 1;                     // lab knob PFEM_AMG_NO_STRENGTH: every negative coupling equally strong
     // (2), (3) on the nodes' PLACE ALONG A SPACE-FILLING CURVE when the mesh came with coordinates (hi_, hj_: Morton ranks,
     // halved from pass to pass and from level to level), else on their indices
     const int64_t lo = hi_ < hj_ ? hi_ : hj_, hi = hi_ < hj_ ? hj_ : hi_;
@@ -33,7 +34,7 @@ __device__ __forceinline__ int64_t amg_edge_key(int32_t i, int32_t j, int32_t hi
 // every free node proposes to its best free neighbour
 __global__ void __launch_bounds__(kBlock) k_amg_match_pick(int64_t n, const int64_t *__restrict__ gptr, const int32_t *__restrict__ gcol,
                                                             const double *__restrict__ gw, const double *__restrict__ gdiag,
-                                                            const int32_t *__restrict__ hint /* null: the index */,
+                                                            const int32_t *__restrict__ hint /* null: the index */, int flat,
                                                             const int32_t *__restrict__ match, int32_t *__restrict__ cand)
 {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -46,7 +47,7 @@ __global__ void __launch_bounds__(kBlock) k_amg_match_pick(int64_t n, const int6
         for (int64_t q = gptr[i]; q < gptr[i + 1]; ++q) {
             const int32_t j = gcol[q];
             if (j == i || match[j] >= 0) continue;
-            const int64_t k = amg_edge_key(static_cast<int32_t>(i), j, hi_, hint ? hint[j] : j, gw[q], di, gdiag[j]);
+            const int64_t k = amg_edge_key(static_cast<int32_t>(i), j, hi_, hint ? hint[j] : j, gw[q], di, gdiag[j], flat);
             if (k > bk) { bk = k; best = j; }
         }
     }
