@@ -133,6 +133,30 @@ __global__ void __launch_bounds__(kBlock) k_amg_emit_node_keys(SellDev A, const 
     }
 }
 
+// runs of equal keys in a sorted array: flag the run heads, (scan), scatter head key + head position, sum each run in order
+__global__ void __launch_bounds__(kBlock) k_amg_run_heads(int64_t n, const uint64_t *__restrict__ skeys, int32_t *__restrict__ head)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n) head[i] = (i == 0 || skeys[i] != skeys[i - 1]) ? 1 : 0;
+    if (i == n) head[n] = 0;
+}
+__global__ void __launch_bounds__(kBlock) k_amg_run_scatter(int64_t n, const uint64_t *__restrict__ skeys, const int32_t *__restrict__ head,
+                                                             const int32_t *__restrict__ rank, uint64_t *__restrict__ ukeys, int64_t *__restrict__ start)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n && head[i]) { ukeys[rank[i]] = skeys[i]; start[rank[i]] = i; }
+    if (i == n) start[rank[n]] = n;
+}
+__global__ void __launch_bounds__(kBlock) k_amg_run_sums(int64_t m, const int64_t *__restrict__ start, const double *__restrict__ svals,
+                                                          double *__restrict__ sums)
+{
+    const int64_t u = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (u >= m) return;
+    double a = 0.0;
+    for (int64_t q = start[u]; q < start[u + 1]; ++q) a += svals[q];
+    sums[u] = a;
+}
+
 // reduced node keys -> graph arrays: columns, weights (-norm off the diagonal), diagonal norms
 __global__ void __launch_bounds__(kBlock) k_amg_graph_from_keys(int64_t m, const uint64_t *__restrict__ ukeys, const double *__restrict__ sums,
                                                                  int squared, int32_t *__restrict__ gcol, double *__restrict__ gw,

@@ -20,6 +20,7 @@
 #include <mutex>
 #include <string>
 #include <deque>
+#include <map>
 #include <memory>
 #include <vector>
 
@@ -124,6 +125,9 @@ extern "C" int pfem_device_memory(int device, int64_t *free_bytes, int64_t *tota
 // ---------------------------------------------------------------------------
 namespace {
 
+// (A per-process pool of freed blocks was tried in round 3 against the multi-second hipMalloc stalls of config 5's
+// symbolic phases -- profiles/r03/symbolic_phase_stalls_cfg5.txt -- and dropped: the stalls sit in the FIRST allocation of
+// a size, which a pool cannot avoid.)
 template <class T>
 struct DevBuf {
     T *p = nullptr;
@@ -132,6 +136,7 @@ struct DevBuf {
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
+    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
     void release()
     {
         if (p) (void)hipFree(p);
@@ -153,6 +158,7 @@ struct DevBuf {
         return PFEM_OK;
     }
 };
+inline void pool_trim() {}
 
 #include "pfem_amg_types.hpp"
 
@@ -492,6 +498,7 @@ extern "C" int pfem_solver_destroy(pfem_solver *s)
         if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
+    pool_trim();                 // the solver's buffers really go back to the device
     return PFEM_OK;
 }
 
@@ -1258,6 +1265,8 @@ extern "C" int pfem_pattern_build(pfem_solver *s)
     PFEM_TRY(build_incidence(s));
     PFEM_HIP(hipEventRecord(s->ev1, s->stream));
     PFEM_TRY(elapsed(s, &s->tm.pattern_ms));
+    keys.release();
+    pool_trim();                 // the symbolic phase's temporaries go back to the device
     return PFEM_OK;
 }
 

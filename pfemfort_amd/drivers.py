@@ -80,7 +80,7 @@ def _finish(kind, mesh, dm, solver, its, reason, rnorm, timers, u_free):
     return Result(kind, mesh, dm, solver, u_free, solnVTK, its, reason, rnorm, timers)
 
 
-def _run(kind, mesh, elemData, timeData, mode, rtol, maxits, verbose):
+def _run(kind, mesh, elemData, timeData, mode, rtol, maxits, verbose, pc=None):
     dm, conn_new, xyz_new, edof = _setup(kind, mesh)
     N = dm.size_global
     nsize = edof.shape[0]
@@ -90,6 +90,8 @@ def _run(kind, mesh, elemData, timeData, mode, rtol, maxits, verbose):
     n1 = min(50, N)                                                      # :762-773 (accepted, unused)
     solver.initialise(N, N, np.full(N, n1, np.int32), np.full(N, min(25, N), np.int32))   # :779
     solver.setTolerances(rtol=rtol, maxits=maxits)
+    if pc:                                                               # KSPSetFromOptions: -pc_type (solverpetsc.F:191-206)
+        solver.setPreconditioner(pc)
     if mode == "batched":
         solver.uploadMesh(kind, conn_new, xyz_new, edof, dm.solnApplied)
         solver.buildPattern()                                            # :786-802
@@ -197,39 +199,39 @@ def run_parallel(kind, mesh: H.Mesh, elem_proc_id, node_proc_id, dist, torch, el
     return _finish(kind, mesh, dm, solver, its, reason, rnorm, timers, u)
 
 
-def tetrapoissonparallelimpl1(mesh: H.Mesh | str, mode="batched", rtol=1e-5, maxits=10000, verbose=False) -> Result:
+def tetrapoissonparallelimpl1(mesh: H.Mesh | str, mode="batched", rtol=1e-5, maxits=10000, verbose=False, pc=None) -> Result:
     """PROGRAM TetraMeshPoissonEquation (tetrapoissonparallelimpl1.F) on one rank / one GPU."""
     if isinstance(mesh, str):
         mesh = H.read_mesh(mesh)
-    return _run(L.POISSON_TET, mesh, H.POISSON_ELEMDATA, H.TIMEDATA, mode, rtol, maxits, verbose)   # :822-824
+    return _run(L.POISSON_TET, mesh, H.POISSON_ELEMDATA, H.TIMEDATA, mode, rtol, maxits, verbose, pc)   # :822-824
 
 
-def tetraelasticityparallelimpl1(mesh: H.Mesh | str, mode="batched", rtol=1e-5, maxits=10000, verbose=False) -> Result:
+def tetraelasticityparallelimpl1(mesh: H.Mesh | str, mode="batched", rtol=1e-5, maxits=10000, verbose=False, pc=None) -> Result:
     """PROGRAM of tetraelasticityparallelimpl1.F (body force only; DESIGN.md 'deviations')."""
     if isinstance(mesh, str):
         mesh = H.read_mesh(mesh)
-    return _run(L.ELAST_TET, mesh, H.ELAST_ELEMDATA, H.TIMEDATA, mode, rtol, maxits, verbose)       # :894-902
+    return _run(L.ELAST_TET, mesh, H.ELAST_ELEMDATA, H.TIMEDATA, mode, rtol, maxits, verbose, pc)       # :894-902
 
 
-def triapoissonserialimpl1(mesh: H.Mesh | str, rtol=1e-5, maxits=10000, verbose=False) -> Result:
+def triapoissonserialimpl1(mesh: H.Mesh | str, rtol=1e-5, maxits=10000, verbose=False, pc=None) -> Result:
     """PROGRAM of triapoissonserialimpl1.F: inline Ke = area*B*B^T (:573-594), Laplace."""
     if isinstance(mesh, str):
         mesh = H.read_mesh(mesh)
-    return _run(L.POISSON_TRIA_INLINE, mesh, None, H.TIMEDATA, "batched", rtol, maxits, verbose)
+    return _run(L.POISSON_TRIA_INLINE, mesh, None, H.TIMEDATA, "batched", rtol, maxits, verbose, pc)
 
 
-def triapoissonparallelimpl1(mesh: H.Mesh | str, mode="batched", rtol=1e-5, maxits=10000, verbose=False) -> Result:
+def triapoissonparallelimpl1(mesh: H.Mesh | str, mode="batched", rtol=1e-5, maxits=10000, verbose=False, pc=None) -> Result:
     """PROGRAM of triapoissonparallelimpl1.F on one rank: the module routine
     StiffnessResidualPoissonLinearTria (:862), kx = ky = 1, no source (next row 8f.1)."""
     if isinstance(mesh, str):
         mesh = H.read_mesh(mesh)
-    return _run(L.POISSON_TRIA, mesh, np.array([1.0, 1.0]), H.TIMEDATA, mode, rtol, maxits, verbose)
+    return _run(L.POISSON_TRIA, mesh, np.array([1.0, 1.0]), H.TIMEDATA, mode, rtol, maxits, verbose, pc)
 
 
-def triaelasticityparallelimpl1(mesh: H.Mesh | str, mode="batched", rtol=1e-5, maxits=10000, verbose=False) -> Result:
+def triaelasticityparallelimpl1(mesh: H.Mesh | str, mode="batched", rtol=1e-5, maxits=10000, verbose=False, pc=None) -> Result:
     """PROGRAM of triaelasticityparallelimpl1.F on one rank with its intended semantics (the committed
     driver USEs a module that does not exist and reads thick/bforce uninitialised: SURVEY A.3#7, 8f.1):
     plane stress, E = 240.565, nu = 0.3 (REAL(4) literals), unit thickness, nodal forces from ForceBC."""
     if isinstance(mesh, str):
         mesh = H.read_mesh(mesh)
-    return _run(L.ELAST_TRIA, mesh, H.ELAST2D_ELEMDATA, H.TIMEDATA, mode, rtol, maxits, verbose)
+    return _run(L.ELAST_TRIA, mesh, H.ELAST2D_ELEMDATA, H.TIMEDATA, mode, rtol, maxits, verbose, pc)

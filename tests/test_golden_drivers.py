@@ -99,7 +99,7 @@ def test_driver_bookkeeping_matches_the_reference_run(case, side, tmp_path):
 
 
 # ---------------------------------------------------------------------------------------
-def _gpu_rank(rank, world, port, case, out_dir):
+def _gpu_rank(rank, world, port, case, out_dir, pc=None):
     import faulthandler
     faulthandler.dump_traceback_later(240, exit=True)
     import torch
@@ -116,7 +116,7 @@ def _gpu_rank(rank, world, port, case, out_dir):
         mesh, ndof = _mesh(case, rank_dir)
         kind = pf.POISSON_TET if ndof == 1 else pf.ELAST_TET
         _, epid, npid = _partition(fx, mesh)
-        res = D.run_parallel(kind, mesh, epid, npid, dist, torch, rtol=1e-12, staged=True)
+        res = D.run_parallel(kind, mesh, epid, npid, dist, torch, rtol=1e-12, staged=True, pc=pc)
         if rank == 0:
             res.write_outputs(out_dir)
     finally:
@@ -124,24 +124,26 @@ def _gpu_rank(rank, world, port, case, out_dir):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pc", [None, "gamg"])
 @pytest.mark.parametrize("case", CASES)
-def test_gpu_driver_harness_reproduces_temp_dat(case, tmp_path):
+def test_gpu_driver_harness_reproduces_temp_dat(case, pc, tmp_path):
     """The build's own counterpart of the driver (pfemfort_amd.drivers) on the GPU writes the same temp.dat as the
-    reference program did: integer columns bit-exact, values <= 1e-8."""
+    reference program did: integer columns bit-exact, values <= 1e-8 -- with the default point Jacobi and with
+    -pc_type gamg (on several ranks: block Jacobi over the ranks, one multigrid hierarchy per rank)."""
     import pfemfort_amd as pf
     fx = _load(case)
     world = int(fx["nranks"])
     if world == 1:
         mesh, ndof = _mesh(case, tmp_path)
         drv = pf.tetrapoissonparallelimpl1 if ndof == 1 else pf.tetraelasticityparallelimpl1
-        drv(mesh, rtol=1e-12).write_outputs(str(tmp_path))
+        drv(mesh, rtol=1e-12, pc=pc).write_outputs(str(tmp_path))
     else:
         import socket
         import torch.multiprocessing as mp
         with socket.socket() as so:
             so.bind(("127.0.0.1", 0))
             port = so.getsockname()[1]
-        mp.spawn(_gpu_rank, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+        mp.spawn(_gpu_rank, args=(world, port, case, str(tmp_path), pc), nprocs=world, join=True)
     got = np.loadtxt(tmp_path / "temp.dat")
     want = fx["temp"]
     assert got.shape == want.shape
