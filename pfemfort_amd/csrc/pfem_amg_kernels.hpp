@@ -670,9 +670,12 @@ __global__ void __launch_bounds__(kBlock) k_pc_copy(int64_t n, const double *__r
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) p[i] = z[i];
 }
 // alpha = beta/(p,w); x += alpha p; r -= alpha w.  A breakdown (p,w) <= 0 is handed to the dots kernel through ctl->pad_.
+// With z0 set the kernel also does step 0 of the V-cycle's pre-smoothing on the assembled matrix (zero guess:
+// z0 = dd0 = D^-1 r / theta over the first n_pc rows, what k_amg_cheb_first would compute from the r written here).
 __global__ void __launch_bounds__(kBlock) k_pc_update(CgCtl *ctl, int it, int64_t n, const double *part_pw, int nparts, const double *reduced_pw,
                                                        const double *__restrict__ p, const double *__restrict__ w, double *__restrict__ x,
-                                                       double *__restrict__ r)
+                                                       double *__restrict__ r, int64_t n_pc, const double *__restrict__ dinv,
+                                                       const double *__restrict__ lam, double ratio, double *__restrict__ z0, double *__restrict__ dd0)
 {
     __shared__ double sm[4];
     if (ctl->flag != 0) return;
@@ -682,10 +685,44 @@ __global__ void __launch_bounds__(kBlock) k_pc_update(CgCtl *ctl, int it, int64_
         return;
     }
     const double alpha = ctl->beta[it & 1] / pw;
+    const double c_first = z0 ? cheb_coef(lam[0], ratio, 0).c_first : 0.0;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
         x[i] = __builtin_fma(alpha, p[i], x[i]);
-        r[i] = __builtin_fma(-alpha, w[i], r[i]);
+        const double ri = __builtin_fma(-alpha, w[i], r[i]);
+        r[i] = ri;
+        if (z0 && i < n_pc) {
+            const double di = c_first * dinv[i] * ri;
+            if (dd0) dd0[i] = di;
+            z0[i] = di;
+        }
     }
+}
+// last step of the V-cycle's post-smoothing on the assembled matrix when its degree is 1 (z += D^-1 (r - t) / theta, t = A z)
+// together with the CG's (r,z), (z,z) over the owned rows: k_amg_cheb_first + k_pc_dots in one pass, same partial sums
+__global__ void __launch_bounds__(kBlock) k_pc_post_dots(const CgCtl *ctl, int64_t n, int64_t n_owned, const double *__restrict__ r,
+                                                          const double *__restrict__ t, const double *__restrict__ dinv,
+                                                          const double *__restrict__ lam, double ratio, double *__restrict__ z, double *part_rz,
+                                                          double *part_zz)
+{
+    __shared__ double sm[4];
+    if (ctl && ctl->flag != 0) return;
+    if (ctl && ctl->pad_ != 0) {
+        if (threadIdx.x == 0) { part_rz[blockIdx.x] = 0.0; part_zz[blockIdx.x] = -1.0; }
+        return;
+    }
+    const double c_first = cheb_coef(lam[0], ratio, 0).c_first;
+    double rz = 0.0, zz = 0.0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        if (i < n_owned) {
+            const double ri = r[i];
+            const double zi = z[i] + c_first * dinv[i] * (ri - t[i]);
+            z[i] = zi;
+            rz = __builtin_fma(ri, zi, rz);
+            zz = __builtin_fma(zi, zi, zz);
+        }
+    }
+    const double a = block_sum(rz, sm), c = block_sum(zz, sm);
+    if (threadIdx.x == 0) { part_rz[blockIdx.x] = a; part_zz[blockIdx.x] = c; }
 }
 __global__ void __launch_bounds__(kBlock) k_pc_dots(const CgCtl *ctl, int64_t n, int64_t n_owned, const double *__restrict__ r,
                                                      const double *__restrict__ z, double *part_rz, double *part_zz)
