@@ -200,6 +200,7 @@ def test_beam_on_eight_ranks_is_cut_across_its_length():
     assert pt["axis"] == "y" and sorted(set(pt["hex_layers_per_rank"])) == [37, 38] and sum(pt["hex_layers_per_rank"]) == 300
     assert pt["face_nodes"] == 51 * 51 and pt["face_bytes_per_neighbour"] == 51 * 51 * 3 * 8 == 62424
     assert d["config"]["free_dofs"] == 2340900 and d["scaling"] == "strong" and d["converged_reason"] == 2
-    assert d["preconditioner"]["name"] == "gamg" and d["iterations"] < 2600
+    # (block Jacobi over eight slabs of a slender beam, node-wise aggregates per slab: 763 iterations when measured)
+    assert d["preconditioner"]["name"] == "gamg" and d["iterations"] < 1500
     # rank 0 holds the clamped end: its owned rows move little; the line reports the owned maximum
     assert 0 < d["max_displacement_magnitude_owned_rows"] < 0.83
