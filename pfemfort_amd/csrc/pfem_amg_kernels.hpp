@@ -148,10 +148,11 @@ __global__ void __launch_bounds__(kBlock) k_amg_run_scatter(int64_t n, const uin
     if (i == n) start[rank[n]] = n;
 }
 __global__ void __launch_bounds__(kBlock) k_amg_run_sums(int64_t m, const int64_t *__restrict__ start, const double *__restrict__ svals,
-                                                          double *__restrict__ sums)
+                                                          const uint64_t *__restrict__ ukeys, double *__restrict__ sums)
 {
     const int64_t u = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (u >= m) return;
+    if (ukeys[u] == ~0ull) { sums[u] = 0.0; return; }      // the run of the padding entries (it can be millions long) is dropped anyway
     double a = 0.0;
     for (int64_t q = start[u]; q < start[u + 1]; ++q) a += svals[q];
     sums[u] = a;

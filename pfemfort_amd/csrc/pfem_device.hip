@@ -143,6 +143,8 @@ struct DevBuf {
         p = nullptr;
         n = 0;
     }
+    // keep the block when it is large enough already (work buffers that are reused level after level)
+    int reserve(size_t count) { return (p && n >= count) ? PFEM_OK : alloc(count); }
     int alloc(size_t count)
     {
         release();
