@@ -341,6 +341,7 @@ __global__ void __launch_bounds__(1024) k_amg_max(const double *__restrict__ par
 
 // coarsest operator (n <= kAmgDense rows) -> dense, inverted in LDS by Gauss-Jordan without pivoting (SPD), one block
 constexpr int kAmgDense = 128;
+__device__ __forceinline__ void amg_gauss_jordan(double *M, double *colp, int n, double *__restrict__ inv);
 __global__ void __launch_bounds__(1024) k_amg_dense_inverse(SellDev A, double *__restrict__ inv)
 {
     extern __shared__ double M[];                   // n x n
@@ -354,6 +355,19 @@ __global__ void __launch_bounds__(1024) k_amg_dense_inverse(SellDev A, double *_
         for (int k = 0; k < len; ++k) M[r * n + A.cols[base + 64LL * k]] = A.vals[base + 64LL * k];
     }
     __syncthreads();
+    amg_gauss_jordan(M, colp, n, inv);
+}
+// the same from a dense n x n matrix in memory (several ranks: the last level's operator summed over the ranks)
+__global__ void __launch_bounds__(1024) k_amg_dense_inverse_of(const double *__restrict__ dense, int n, double *__restrict__ inv)
+{
+    extern __shared__ double M[];
+    __shared__ double colp[kAmgDense];
+    for (int q = threadIdx.x; q < n * n; q += 1024) M[q] = dense[q];
+    __syncthreads();
+    amg_gauss_jordan(M, colp, n, inv);
+}
+__device__ __forceinline__ void amg_gauss_jordan(double *M, double *colp, int n, double *__restrict__ inv)
+{
     for (int p = 0; p < n; ++p) {
         const double piv = 1.0 / M[p * n + p];
         __syncthreads();
@@ -372,6 +386,79 @@ __global__ void __launch_bounds__(1024) k_amg_dense_inverse(SellDev A, double *_
     }
     for (int q = threadIdx.x; q < n * n; q += 1024) inv[q] = M[q];
 }
+// ---- coupled hierarchy on several ranks: pieces of the numeric phase that need the neighbours' shares ----
+// this rank's share of the diagonal and of the absolute row sums (both are summed over the holders afterwards; the sum of
+// the shares' absolute values bounds the absolute value of the summed entries, so the bound stays a bound)
+__global__ void __launch_bounds__(kBlock) k_amg_diag_abs(SellDev A, double *__restrict__ diag, double *__restrict__ rowabs)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (r >= A.n_rows) return;
+    const int64_t base = A.slice_off[r >> 6] + (r & 63);
+    const int len = A.rowlen[r];
+    double d = 0.0, s = 0.0;
+    for (int k = 0; k < len; ++k) {
+        const double v = A.vals[base + 64LL * k];
+        if (A.cols[base + 64LL * k] == static_cast<int32_t>(r)) d += v;
+        s += fabs(v);
+    }
+    diag[r] = d;
+    rowabs[r] = s;
+}
+__global__ void __launch_bounds__(kBlock) k_amg_dinv_ratio(int64_t n, const double *__restrict__ diag, const double *__restrict__ rowabs,
+                                                            double *__restrict__ dinv, double *__restrict__ part_max)
+{
+    __shared__ double sm[4];
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    double ratio = 0.0;
+    if (r < n) {
+        const double d = diag[r];
+        const bool ok = d > 0.0;
+        dinv[r] = ok ? 1.0 / d : 1.0;
+        ratio = ok ? rowabs[r] / d : 1.0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ratio = fmax(ratio, __shfl_xor(ratio, o, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = ratio;
+    __syncthreads();
+    if (threadIdx.x == 0) part_max[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+}
+// v[i] = global number of the coarse dof of owned dof i, 0 on the ghosts: after the level's sum-exchange every holder
+// of a dof knows its aggregate (numbers stay far below 2^53: exact in a double)
+__global__ void __launch_bounds__(kBlock) k_amg_gid_vector(int64_t n, int64_t n_loc, const int32_t *__restrict__ agg, int64_t off, double *__restrict__ v)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n_loc) v[i] = i < n ? static_cast<double>(off + agg[i]) : 0.0;
+}
+// this rank's share of the last level's operator into the dense global matrix (zeroed before; summed over the ranks after)
+__global__ void __launch_bounds__(kBlock) k_amg_dense_scatter(SellDev A, const int32_t *__restrict__ gid, int n_glob, double *__restrict__ dense)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (r >= A.n_rows) return;
+    const int64_t base = A.slice_off[r >> 6] + (r & 63);
+    const int len = A.rowlen[r];
+    for (int k = 0; k < len; ++k) dense[static_cast<int64_t>(gid[r]) * n_glob + gid[A.cols[base + 64LL * k]]] = A.vals[base + 64LL * k];
+}
+__global__ void __launch_bounds__(kBlock) k_amg_scatter_gid(int64_t n_own, const double *__restrict__ b, const int32_t *__restrict__ gid,
+                                                             double *__restrict__ out, const CgCtl *ctl)
+{
+    if (ctl && ctl->flag != 0) return;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n_own) out[gid[i]] = b[i];
+}
+__global__ void __launch_bounds__(kBlock) k_amg_gather_gid(int64_t n_loc, const double *__restrict__ xg, const int32_t *__restrict__ gid,
+                                                            double *__restrict__ x, const CgCtl *ctl)
+{
+    if (ctl && ctl->flag != 0) return;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n_loc) x[i] = xg[gid[i]];
+}
+__global__ void __launch_bounds__(kBlock) k_amg_zero(int64_t n, double *__restrict__ v, const CgCtl *ctl)
+{
+    if (ctl && ctl->flag != 0) return;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n) v[i] = 0.0;
+}
+
 // x = inv * b (one block, one thread per row; the inverse of an SPD matrix is symmetric: column access is coalesced)
 __global__ void __launch_bounds__(kAmgDense) k_amg_dense_apply(int n, const double *__restrict__ inv, const double *__restrict__ b,
                                                                 double *__restrict__ x, const CgCtl *ctl)
@@ -449,12 +536,25 @@ __global__ void __launch_bounds__(kBlock) k_amg_cheb_next(int64_t n, int step, c
 __global__ void __launch_bounds__(kBlock) k_amg_restrict(int64_t nc, const int32_t *__restrict__ mem_ptr, const int32_t *__restrict__ mem_idx,
                                                           const double *__restrict__ b, const double *__restrict__ t /* null: b IS the residual */,
                                                           double *__restrict__ bc, const double *__restrict__ dinv_c, const double *__restrict__ lam_c,
-                                                          double ratio, double *__restrict__ dd_c, double *__restrict__ x_c, const CgCtl *ctl)
+                                                          double ratio, double *__restrict__ dd_c, double *__restrict__ x_c, const CgCtl *ctl,
+                                                          int32_t n_own = INT32_MAX)
 {
+    // (coupled hierarchy on several ranks: t is this rank's UN-summed share of A x over all its local dofs and b counts
+    // only where the rank owns the dof -- members at or beyond n_own are ghosts --, so that the sum over the ranks of these
+    // partial restrictions is the restriction of the assembled residual; one rank: n_own is out of reach, same bits as ever)
     if (ctl && ctl->flag != 0) return;
     const int64_t a = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (a >= nc) return;
     const int q0 = mem_ptr[a], q1 = mem_ptr[a + 1];
+    if (n_own != INT32_MAX) {
+        double acc = 0.0;
+        for (int q = q0; q < q1; ++q) {
+            const int i = mem_idx[q];
+            acc += (i < n_own ? b[i] : 0.0) - (t ? t[i] : 0.0);
+        }
+        bc[a] = acc;
+        return;
+    }
     double acc = 0.0;
     int q = q0;
     for (; q + 8 <= q1; q += 8) {

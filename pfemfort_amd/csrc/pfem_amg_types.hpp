@@ -2,8 +2,26 @@
 // after DevBuf and before the solver object, which owns one hierarchy.
 #pragma once
 
+// Neighbour plan of one level of a rank-coupled hierarchy (same layout as the solver's own plan for level 0: send list
+// by neighbour, and per distinct shared dof the receive positions of the other holders' partials in rank order)
+struct AmgPlan {
+    std::vector<int> peers;
+    std::vector<int64_t> peer_off{0};
+    std::vector<int32_t> send_lidx;       // host copy: the next level's plan is derived from it
+    int64_t n_send = 0, n_sh = 0;
+    DevBuf<int32_t> d_send_lidx, d_sh_lidx, d_sh_ptr, d_sh_src;
+};
+
 struct AmgLevel {
     int64_t n = 0, n_slices = 0, stored = 0, nnz = 0;
+    // several ranks, coupled hierarchy: the level's matrix has n_loc >= n rows -- the n dofs this rank owns (the domain of
+    // its aggregation) and after them the dofs of neighbours' aggregates that its own fine dofs belong to (ghosts); the
+    // matrix holds this rank's share of every entry (sub-assembled like level 0).  One rank / block mode: n_loc == n.
+    int64_t n_loc = 0;
+    int64_t gid_off = 0;                  // global number of this rank's first owned dof of the level
+    std::vector<int64_t> ghost_gid;       // ascending global numbers of the ghosts
+    AmgPlan plan;                         // levels >= 1 (level 0 uses the solver's)
+    DevBuf<int32_t> gid;                  // last level with a global dense inverse: global number of every local dof
     bool fine = false;                    // level 0: the solver's own matrix (and its SpMV forms)
     // matrix of a coarse level: wave-sliced CSR like the fine one, int32 columns
     DevBuf<int64_t> slice_off, rowptr;
@@ -49,4 +67,10 @@ struct Amg {
     int tail_from = -1;                              // first level of the single-launch tail of the cycle (-1: none)
     bool fused = true;                               // fused SpMV epilogues on the coarse levels + the tail kernel (PFEM_AMG_FUSED=0: off)
     int coarsest_sweeps = 8;                         // Chebyshev degree on the last level when it is too large for the dense inverse
+    // several ranks: one hierarchy ACROSS the ranks (aggregates stay inside a rank's owned dofs, the operators are the
+    // global Galerkin products held sub-assembled, every SpMV of the cycle is followed by the level's neighbour exchange)
+    // instead of one hierarchy per rank (block Jacobi).  Needs every coarse dof to be held by at most two ranks.
+    bool coupled = false;
+    int64_t n_last_global = 0;                       // rows of the last level over all ranks
+    DevBuf<double> dense_glob, bx_glob, lam_all;     // coupled: assembled last-level operator, its right-hand side / solution, bounds of all ranks
 };

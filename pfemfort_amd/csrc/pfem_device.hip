@@ -367,6 +367,7 @@ struct pfem_solver {
     std::vector<int64_t> peer_off;               // [n_peers+1] offsets into the send / receive buffers
     int64_t n_send = 0, n_sh = 0;                // doubles per exchange; distinct shared dofs of this rank
     DevBuf<int32_t> d_send_lidx, d_sh_lidx, d_sh_ptr, d_sh_src;
+    std::vector<int32_t> h_send_lidx;            // host copy of the send list (the coupled gamg hierarchy derives its coarse plans from it)
     DevBuf<double> d_send, d_recv, d_sbuf;       // d_sbuf: [ (p,Ap) | pad | (r,z) | (z,z) ]
     // slices of the SpMV form in use that hold shared rows (run first) / the others (run under the exchange)
     DevBuf<int32_t> d_slices_b, d_slices_i;
@@ -1020,6 +1021,7 @@ int pattern_from_keys(pfem_solver *s, DevBuf<uint64_t> &keys, int64_t nkeys)
     int64_t nnz = num;
     if (nnz > 0) {   // drop the collapsed sentinel, if any
         uint64_t last = 0;
+        PFEM_HIP(hipStreamSynchronize(s->stream));
         PFEM_HIP(hipMemcpy(&last, keys.p + (nnz - 1), sizeof(uint64_t), hipMemcpyDeviceToHost));
         if (last == kNoKey) --nnz;
     }
@@ -1537,6 +1539,7 @@ extern "C" int pfem_get_csr(pfem_solver *s, int64_t *rowptr, int32_t *cols, doub
             DevBuf<int32_t> dc;
             PFEM_TRY(dc.alloc(static_cast<size_t>(s->nnz)));
             hipLaunchKernelGGL(k_sell_to_csr, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->sell(), s->d_rowptr.p, dc.p, static_cast<double *>(nullptr));
+            PFEM_HIP(hipStreamSynchronize(s->stream));       // the blocking copy below is not ordered after the solver's (non-blocking) stream
             PFEM_HIP(hipMemcpy(ic.data(), dc.p, sizeof(int32_t) * s->nnz, hipMemcpyDeviceToHost));
         } else {
             std::copy(cols, cols + s->nnz, ic.begin());
@@ -2257,6 +2260,36 @@ extern "C" int pfem_solver_set_comm_host(pfem_solver *s, int rank, int nranks, p
     return install_backend(s, rank, nranks, b);
 }
 
+namespace {
+// distinct shared dofs of a send list, each with its contributions ordered by rank (own partial = -1 in its place)
+void plan_unpack_lists(int rank, int n_peers, const int *peers, const int64_t *peer_off, const std::vector<int32_t> &send_lidx,
+                       std::vector<int32_t> &sh_lidx, std::vector<int32_t> &sh_ptr, std::vector<int32_t> &sh_src)
+{
+    const int64_t total = n_peers ? peer_off[n_peers] : 0;
+    std::vector<std::pair<int32_t, std::pair<int, int32_t>>> contrib;      // (lidx, (rank, position in recv or -1))
+    contrib.reserve(static_cast<size_t>(total));
+    for (int k = 0; k < n_peers; ++k)
+        for (int64_t i = peer_off[k]; i < peer_off[k + 1]; ++i) contrib.push_back({send_lidx[static_cast<size_t>(i)], {peers[k], static_cast<int32_t>(i)}});
+    std::sort(contrib.begin(), contrib.end());
+    sh_lidx.clear();
+    sh_src.clear();
+    sh_ptr.assign(1, 0);
+    for (size_t a = 0; a < contrib.size();) {
+        size_t b = a;
+        while (b < contrib.size() && contrib[b].first == contrib[a].first) ++b;
+        sh_lidx.push_back(contrib[a].first);
+        bool own_done = false;
+        for (size_t c = a; c < b; ++c) {
+            if (!own_done && contrib[c].second.first > rank) { sh_src.push_back(-1); own_done = true; }
+            sh_src.push_back(contrib[c].second.second);
+        }
+        if (!own_done) sh_src.push_back(-1);
+        sh_ptr.push_back(static_cast<int32_t>(sh_src.size()));
+        a = b;
+    }
+}
+}   // namespace
+
 // The plan in local terms: send list (one segment per neighbour) and, per distinct shared dof, the receive-buffer
 // positions of the other ranks' partials in ascending rank order with this rank's own partial (-1) in its place.
 extern "C" int pfem_solver_set_neighbours(pfem_solver *s, int n_peers, const int *peers, const int64_t *peer_off,
@@ -2287,26 +2320,9 @@ extern "C" int pfem_solver_set_neighbours(pfem_solver *s, int n_peers, const int
             send_lidx[i] = static_cast<int32_t>(s->n_owned + (it - s->ghost_gid.begin()));
         }
     }
-    // distinct shared dofs, each with its contributions ordered by rank
-    std::vector<std::pair<int32_t, std::pair<int, int32_t>>> contrib;      // (lidx, (rank, position in recv or -1))
-    contrib.reserve(static_cast<size_t>(total) * 2);
-    for (int k = 0; k < n_peers; ++k)
-        for (int64_t i = peer_off[k]; i < peer_off[k + 1]; ++i) contrib.push_back({send_lidx[i], {peers[k], static_cast<int32_t>(i)}});
-    std::sort(contrib.begin(), contrib.end());
-    std::vector<int32_t> sh_lidx, sh_ptr{0}, sh_src;
-    for (size_t a = 0; a < contrib.size();) {
-        size_t b = a;
-        while (b < contrib.size() && contrib[b].first == contrib[a].first) ++b;
-        sh_lidx.push_back(contrib[a].first);
-        bool own_done = false;
-        for (size_t c = a; c < b; ++c) {
-            if (!own_done && contrib[c].second.first > s->rank) { sh_src.push_back(-1); own_done = true; }
-            sh_src.push_back(contrib[c].second.second);
-        }
-        if (!own_done) sh_src.push_back(-1);
-        sh_ptr.push_back(static_cast<int32_t>(sh_src.size()));
-        a = b;
-    }
+    std::vector<int32_t> sh_lidx, sh_ptr, sh_src;
+    plan_unpack_lists(s->rank, n_peers, peers, peer_off, send_lidx, sh_lidx, sh_ptr, sh_src);
+    s->h_send_lidx = send_lidx;
     s->peers.assign(peers, peers + n_peers);
     s->peer_off.assign(1, 0);
     if (n_peers) s->peer_off.assign(peer_off, peer_off + n_peers + 1);
@@ -2417,26 +2433,42 @@ namespace {
 
 // v[shared] <- sum over the ranks that hold the dof (ascending rank order), outside the iteration: the compute
 // stream packs, the communication stream exchanges, the compute stream unpacks
-int exchange_sum(pfem_solver *s, double *v, bool second_stream)
+// (a plan by its parts: the solver's own for the matrix, one per coarse level of a coupled gamg hierarchy; all of them
+// go through the solver's send / receive buffers, which the matrix's plan sized -- a coarse level shares fewer dofs)
+struct PlanRef {
+    int np;
+    const int *peers;
+    const int64_t *peer_off;
+    int64_t n_send, n_sh;
+    const int32_t *send_lidx, *sh_lidx, *sh_ptr, *sh_src;
+};
+inline PlanRef plan_of(const pfem_solver *s)
 {
-    if (s->n_send > 0) {
-        hipLaunchKernelGGL(k_pack_send, dim3(grid_for(s->n_send)), dim3(kBlock), 0, s->stream, static_cast<const double *>(v),
-                           static_cast<const int32_t *>(s->d_send_lidx.p), s->n_send, s->d_send.p, static_cast<const CgCtl *>(nullptr));
+    return PlanRef{static_cast<int>(s->peers.size()), s->peers.data(), s->peer_off.data(), s->n_send, s->n_sh,
+                   s->d_send_lidx.p, s->d_sh_lidx.p, s->d_sh_ptr.p, s->d_sh_src.p};
+}
+int exchange_sum(pfem_solver *s, const PlanRef &P, double *v, bool second_stream, const CgCtl *ctl = nullptr)
+{
+    if (P.n_send > 0) {
+        hipLaunchKernelGGL(k_pack_send, dim3(grid_for(P.n_send)), dim3(kBlock), 0, s->stream, static_cast<const double *>(v),
+                           P.send_lidx, P.n_send, s->d_send.p, ctl);
         PFEM_TRY(check_kernel("k_pack_send"));
     }
     // the exchange goes where the iterations will put it (one stream per communicator for the whole solve)
     hipStream_t xs = second_stream ? s->comm_stream : s->stream;
     if (second_stream) PFEM_TRY(stream_follows(s, s->comm_stream, s->stream));
-    PFEM_TRY(s->comm->exchange(static_cast<int>(s->peers.size()), s->peers.data(), s->peer_off.data(), s->d_send.p, s->d_recv.p, xs));
+    PFEM_TRY(s->comm->exchange(P.np, P.peers, P.peer_off, s->d_send.p, s->d_recv.p, xs));
     if (second_stream) PFEM_TRY(stream_follows(s, s->stream, s->comm_stream));
-    if (s->n_sh > 0) {
-        hipLaunchKernelGGL(k_unpack_sum, dim3(grid_for(s->n_sh)), dim3(kBlock), 0, s->stream, v,
-                           static_cast<const int32_t *>(s->d_sh_lidx.p), static_cast<const int32_t *>(s->d_sh_ptr.p),
-                           static_cast<const int32_t *>(s->d_sh_src.p), s->n_sh, static_cast<const double *>(s->d_recv.p),
-                           static_cast<const CgCtl *>(nullptr));
+    if (P.n_sh > 0) {
+        hipLaunchKernelGGL(k_unpack_sum, dim3(grid_for(P.n_sh)), dim3(kBlock), 0, s->stream, v, P.sh_lidx, P.sh_ptr, P.sh_src, P.n_sh,
+                           static_cast<const double *>(s->d_recv.p), ctl);
         PFEM_TRY(check_kernel("k_unpack_sum"));
     }
     return PFEM_OK;
+}
+int exchange_sum(pfem_solver *s, double *v, bool second_stream)
+{
+    return exchange_sum(s, plan_of(s), v, second_stream);
 }
 
 // sbuf[at..at+n) <- sum over the ranks, in order on the compute stream
