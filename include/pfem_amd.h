@@ -320,7 +320,10 @@ int pfem_solver_spmv_bytes(pfem_solver *s, int64_t *format_bytes);
  * Gershgorin bound (degree 1 on the assembled matrix, 2 below), dense inverse at the coarsest level.  The reference's own PCBJACOBI/ILU(0) needs 110 / 1 122
  * iterations on BASELINE configs 3 / 4 and point Jacobi 370 / 5 207; this needs ~20 / ~300 at ~5 SpMV-equivalents each.
  * Aggregates are formed from the values of the first solve after a pattern build and reused while the pattern lives
- * (-pc_gamg_reuse_interpolation true).  Several ranks: block Jacobi over the ranks, one hierarchy per rank on its owned
+ * (-pc_gamg_reuse_interpolation true).  Several ranks: ONE hierarchy across the ranks (what PCGAMG does under MPI) --
+ * aggregates stay inside a rank's owned dofs, coarse operators are the global Galerkin products held sub-assembled like the
+ * matrix, every level has its own neighbour plan -- whenever no coarse dof ends up held by more than two ranks (slab
+ * partitions); otherwise, or with PFEM_AMG_COUPLED=0, block Jacobi over the ranks with one hierarchy per rank on its owned
  * diagonal block as assembled from its own elements (PETSc: -pc_type bjacobi -sub_pc_type gamg).                          */
 #define PFEM_PC_GAMG 2
 int pfem_solver_set_preconditioner(pfem_solver *s, int pc);
@@ -331,6 +334,10 @@ int pfem_solver_amg_info(pfem_solver *s, int max_levels, int *n_levels, int64_t 
                          double *symbolic_ms, double *numeric_ms, int *cheb_degree, int *fine_degree, double *eig_ratio, double *coarse_scale);
 /* coarse dof of every dof of `level` (0 = the assembled matrix); what the oracle's restatement of the cycle is given */
 int pfem_solver_amg_aggregates(pfem_solver *s, int level, int32_t *agg);
+/* several ranks: is the hierarchy of the last solve one across the ranks (1) or one per rank (0); per level (arrays of
+ * max_levels) the global number of this rank's first dof and its local rows (owned + ghosts).  With a coupled hierarchy
+ * pfem_solver_amg_aggregates hands out GLOBAL coarse numbers and pfem_solver_amg_info's rows are the owned ones.       */
+int pfem_solver_amg_layout(pfem_solver *s, int max_levels, int *coupled, int64_t *first_dof, int64_t *local_rows);
 /* -pc_gamg knobs: Chebyshev degree on the coarse levels (1..6, default 2) and on the assembled matrix itself (0 = the same;
  * default 1: there an SpMV is dearest), lmax/lmin of the smoothing interval (default 8), scaling of the coarse-grid
  * correction (default 1.5: the over-correction a piecewise-constant coarse space wants)                              */

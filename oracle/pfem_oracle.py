@@ -341,7 +341,7 @@ def pcg_bjacobi_ilu0(rowptr, cols, vals, b, block_start=None, rtol=1e-5, abstol=
 
 
 def amg_cycle(rowptr, cols, vals, aggregates, cheb_degree=2, eig_ratio=8.0, coarse_scale=1.5, dense_limit=128, coarsest_sweeps=8,
-              fine_degree=1):
+              fine_degree=1, lam_given=None):
     """z = M^-1 r of the product's -pc_type gamg (pfemfort_amd/csrc/pfem_amg.inc), restated in numpy / scipy.sparse GIVEN the
     aggregates (``aggregates[l][i]`` = coarse dof of dof i of level l; the product forms them by pairwise matching and
     hands them over for this check).  Everything else is restated: piecewise-constant prolongation P, Galerkin operators
@@ -365,6 +365,11 @@ def amg_cycle(rowptr, cols, vals, aggregates, cheb_degree=2, eig_ratio=8.0, coar
         d = Al.diagonal()
         dinv.append(1.0 / d)
         lam.append(float((abs(Al) @ np.ones(Al.shape[0]) / d).max()))
+    lam_true = list(lam)
+    if lam_given is not None:
+        # one hierarchy across several ranks: the product sums the absolute values of the RANKS' SHARES of an interface
+        # entry, an upper bound of the absolute value of the entry (the caller checks lam_true <= lam_given)
+        lam = [float(v) for v in lam_given]
     dense = len(levels) > 1 and levels[-1].shape[0] <= dense_limit
     Ainv = np.linalg.inv(levels[-1].toarray()) if dense else None
 
@@ -396,7 +401,9 @@ def amg_cycle(rowptr, cols, vals, aggregates, cheb_degree=2, eig_ratio=8.0, coar
         x = x + coarse_scale * (P[l] @ cycle(l + 1, rc))
         return smooth(l, x, rhs, deg)
 
-    return lambda r: cycle(0, r)
+    apply = lambda r: cycle(0, r)          # noqa: E731
+    apply.lam_true = lam_true
+    return apply
 
 
 def pcg_with(rowptr, cols, vals, b, M, rtol=1e-5, abstol=1e-50, dtol=1e5, maxits=10000):
@@ -440,9 +447,11 @@ def pcg_with(rowptr, cols, vals, b, M, rtol=1e-5, abstol=1e-50, dtol=1e5, maxits
 
 
 def pcg_amg(rowptr, cols, vals, b, aggregates, cheb_degree=2, eig_ratio=8.0, coarse_scale=1.5, rtol=1e-5, abstol=1e-50, dtol=1e5,
-            maxits=10000, dense_limit=128, coarsest_sweeps=8, fine_degree=1):
+            maxits=10000, dense_limit=128, coarsest_sweeps=8, fine_degree=1, lam_given=None, lam_true_out=None):
     """CG preconditioned by one V(1,1) cycle of plain-aggregation multigrid on the whole matrix: amg_cycle + pcg_with."""
-    M = amg_cycle(rowptr, cols, vals, aggregates, cheb_degree, eig_ratio, coarse_scale, dense_limit, coarsest_sweeps, fine_degree)
+    M = amg_cycle(rowptr, cols, vals, aggregates, cheb_degree, eig_ratio, coarse_scale, dense_limit, coarsest_sweeps, fine_degree, lam_given)
+    if lam_true_out is not None:
+        lam_true_out[:] = M.lam_true
     return pcg_with(rowptr, cols, vals, b, M, rtol, abstol, dtol, maxits)
 
 

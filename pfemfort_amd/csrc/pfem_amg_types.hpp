@@ -71,6 +71,7 @@ struct Amg {
     // global Galerkin products held sub-assembled, every SpMV of the cycle is followed by the level's neighbour exchange)
     // instead of one hierarchy per rank (block Jacobi).  Needs every coarse dof to be held by at most two ranks.
     bool coupled = false;
+    bool coupled_refused = false;                    // the partition did not allow it (decided once per pattern, by all ranks together)
     int64_t n_last_global = 0;                       // rows of the last level over all ranks
     DevBuf<double> dense_glob, bx_glob, lam_all;     // coupled: assembled last-level operator, its right-hand side / solution, bounds of all ranks
 };

@@ -3538,6 +3538,23 @@ extern "C" int pfem_solver_amg_aggregates(pfem_solver *s, int level, int32_t *ag
         std::vector<int32_t> in(agg, agg + L.n);
         for (int64_t i = 0; i < L.n; ++i) agg[i] = in[static_cast<size_t>(to_internal(s, i))];
     }
+    if (s->amg->coupled) {                     // one hierarchy across the ranks: global coarse numbers
+        const int64_t off = s->amg->lev[static_cast<size_t>(level) + 1]->gid_off;
+        for (int64_t i = 0; i < L.n; ++i) agg[i] = static_cast<int32_t>(agg[i] + off);
+    }
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_amg_layout(pfem_solver *s, int max_levels, int *coupled, int64_t *first_dof, int64_t *local_rows)
+{
+    if (!s || !coupled) return PFEM_ERR_ARG;
+    *coupled = 0;
+    if (!s->amg || !s->amg->symbolic_ok) return PFEM_OK;
+    *coupled = s->amg->coupled ? 1 : 0;
+    for (size_t l = 0; l < s->amg->lev.size() && static_cast<int>(l) < max_levels; ++l) {
+        if (first_dof) first_dof[l] = s->amg->lev[l]->gid_off;
+        if (local_rows) local_rows[l] = s->amg->lev[l]->n_loc;
+    }
     return PFEM_OK;
 }
 

@@ -242,6 +242,16 @@ class PetscSolver:
         L.check(L.lib().pfem_solver_amg_aggregates(self._h, level, _p(a)), "pfem_solver_amg_aggregates")
         return a
 
+    def amgLayout(self):
+        """Several ranks: {"coupled": one hierarchy across the ranks?, "first_dof": [...], "local_rows": [...]} per level."""
+        mx = 16
+        cp = C.c_int(0)
+        first = np.zeros(mx, np.int64)
+        loc = np.zeros(mx, np.int64)
+        L.check(L.lib().pfem_solver_amg_layout(self._h, mx, C.byref(cp), _p(first), _p(loc)), "pfem_solver_amg_layout")
+        nl = self.amgInfo()["levels"]
+        return {"coupled": bool(cp.value), "first_dof": first[:nl].tolist(), "local_rows": loc[:nl].tolist()}
+
     def spmvRowGroup(self):
         """Rows served by one lane of the current SpMV (3: row-grouped form)."""
         b = C.c_int(0)

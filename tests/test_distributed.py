@@ -245,6 +245,8 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
         kind = pf.POISSON_TET if mesh_args["ndof"] == 1 else pf.ELAST_TET
         if mesh_args.get("overlap"):        # the overlapped form of the iteration (boundary slices, second stream)
             os.environ["PFEM_MULTI_OVERLAP"] = "1"
+        if mesh_args.get("amg_block"):      # -pc_type gamg as block Jacobi over the ranks even where one hierarchy across them is possible
+            os.environ["PFEM_AMG_COUPLED"] = "0"
         if mesh_args.get("reorder"):        # the owned dofs renumbered inside the library (the plan is translated)
             os.environ["PFEM_REORDER"] = "1"
         devgen = mesh_args.get("mode") == "devgen"     # the rank's slab generated on the device (bench.py's path), any axis
@@ -311,6 +313,9 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
         if mesh_args.get("pc") == "gamg":
             # the rank's own hierarchy, for the oracle's restatement: its owned diagonal block as assembled here, its aggregates
             ai = s.amgInfo()
+            lay = s.amgLayout()
+            extra.update(amg_coupled=int(lay["coupled"]), amg_first=np.array(lay["first_dof"]), amg_lam=np.array(ai["lambda_max"]),
+                         amg_local_rows=np.array(lay["local_rows"]))
             rp, cc, vv = s.getCSR()
             no = re - rs
             keep = np.zeros(len(cc), bool)
@@ -347,6 +352,8 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                                                             ("elast", 2, "xslabs", "batched"),
                                                             ("poisson", 2, "slabs", "gamg"), ("poisson", 3, "rcb", "gamg"),
                                                             ("elast", 3, "yslabs", "gamg"), ("poisson", 3, "idle", "gamg_overlap"),
+                                                            ("poisson", 2, "slabs", "gamg_block"), ("elast", 3, "yslabs", "gamg_block"),
+                                                            ("poisson", 3, "xslabs", "gamg"), ("elast", 2, "slabs", "gamg_overlap"),
                                                             ("poisson", 3, "sectors", "reorder"), ("elast", 2, "slabs", "reorder_gamg")])
 def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partition, mode):
     """2-3 ranks share cuda:0 (host-staged exchange over gloo): the product's multi-rank device loop against the
@@ -365,8 +372,11 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
         mesh_args["reorder"] = True
         mode = "gamg" if mode == "reorder_gamg" else "batched"
         mesh_args["mode"] = mode
-    if mode in ("gamg", "gamg_overlap"):   # block Jacobi over the ranks, every block its own multigrid hierarchy (-pc_type gamg)
-        mesh_args["mode"], mesh_args["pc"], mesh_args["overlap"] = ("devgen" if partition == "yslabs" else "batched"), "gamg", mode == "gamg_overlap"
+    if mode in ("gamg", "gamg_overlap", "gamg_block"):
+        # -pc_type gamg on several ranks: one hierarchy across the ranks where the partition allows it (slabs: every coarse dof
+        # has at most two holders), else -- or when asked, "gamg_block" -- block Jacobi over the ranks, every block its own hierarchy
+        mesh_args["mode"], mesh_args["pc"], mesh_args["overlap"] = ("devgen" if partition in ("yslabs", "xslabs") else "batched"), "gamg", mode == "gamg_overlap"
+        mesh_args["amg_block"] = mode == "gamg_block"
     if mode == "devgen":              # bench.py's path: every rank generates its slab (along the partition's axis) on the device
         mesh_args["mode"] = "devgen"
     if world == 3 or mode != "batched":   # the row-group SpMV forms ("auto" keeps systems this small in the row form)
@@ -406,8 +416,43 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
             blocks.append((int(d["rs"]), (d["blk_rowptr"], d["blk_cols"], d["blk_vals"]), aggs))
             deg, ratio, scale, fdeg = np.load(tmp_path / "rank0.npz")["amg_opts"]
         its_jacobi = its_oracle
-        _, its_oracle, reason_oracle, *_ = O.pcg_bjacobi_amg(prob.rowptr, prob.cols, prob.vals, prob.rhs, blocks, rtol=1e-10, cheb_degree=int(deg),
-                                                             eig_ratio=float(ratio), coarse_scale=float(scale), fine_degree=int(fdeg))
+        d0 = np.load(tmp_path / "rank0.npz")
+        coupled = bool(int(d0["amg_coupled"]))
+        ds = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+        assert all(bool(int(d["amg_coupled"])) == coupled for d in ds)
+        if partition in ("slabs", "xslabs", "yslabs", "idle"):
+            assert coupled == (not mesh_args["amg_block"])
+        if coupled:
+            # ONE hierarchy across the ranks: the oracle's restatement of the cycle on the assembled GLOBAL matrix with the
+            # global aggregates the ranks formed (a rank's piece of level l starts at its first dof of that level)
+            nl = int(d0["amg_levels"])
+            assert all(int(d["amg_levels"]) == nl for d in ds)
+            aggs, rows_glob = [], []
+            for l in range(nl):
+                rows_glob.append(sum(int(d["amg_rows"][l]) for d in ds))
+            for l in range(nl - 1):
+                a = np.full(rows_glob[l], -1, np.int64)
+                for d in ds:
+                    f = int(d["amg_first"][l])
+                    a[f:f + int(d["amg_rows"][l])] = d[f"agg{l}"]
+                assert a.min() >= 0 and a.max() == rows_glob[l + 1] - 1 and len(np.unique(a)) == rows_glob[l + 1]
+                aggs.append(a)
+            assert rows_glob[0] == len(prob.rhs) and (rows_glob[-1] <= 128 or nl >= 14)
+            lam = d0["amg_lam"]
+            assert all(np.array_equal(d["amg_lam"], lam) for d in ds)
+            lam_true = [0.0] * nl
+            _, its_oracle, reason_oracle, *_ = O.pcg_amg(prob.rowptr, prob.cols, prob.vals, prob.rhs, aggs, rtol=1e-10, cheb_degree=int(deg),
+                                                         eig_ratio=float(ratio), coarse_scale=float(scale), fine_degree=int(fdeg),
+                                                         lam_given=lam, lam_true_out=lam_true)
+            # the ranks' bound (sum of the shares' absolute values) is one: never below the assembled matrix's row sums, seldom far above
+            assert all(t * (1 - 1e-12) <= g <= 1.6 * t for t, g in zip(lam_true, lam)), (lam_true, lam.tolist())
+            # ... and the count stays near the one-rank hierarchy's, far below block Jacobi over the ranks
+            assert its_oracle < its_jacobi
+        else:
+            _, its_oracle, reason_oracle, *_ = O.pcg_bjacobi_amg(prob.rowptr, prob.cols, prob.vals, prob.rhs, blocks, rtol=1e-10, cheb_degree=int(deg),
+                                                                 eig_ratio=float(ratio), coarse_scale=float(scale), fine_degree=int(fdeg))
+        print(f"gamg {kind_name} x{world} {partition}: {'coupled' if coupled else 'per-rank'} hierarchy, {int(d0['amg_levels'])} levels, "
+              f"{int(d0['its'])} iterations (oracle {its_oracle}, point Jacobi {its_jacobi})")
         assert reason_oracle == 2 and (its_oracle < its_jacobi or kind_name == "elast")     # (tiny beam blocks: no gain to expect)
         its_tol = max(2, its_oracle // 50)          # (runs of hundreds of iterations on the little beam: +-2 %)
     if mode == "pbjacobi":
