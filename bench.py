@@ -210,8 +210,8 @@ def parse_args():
     ap.add_argument("--no-parity-step", action="store_true", help="skip the extra (untimed) step at rtol 1e-10")
     ap.add_argument("--pc", choices=["jacobi", "pbjacobi", "gamg"], default="gamg",
                     help="preconditioner of the CG (PCSetType, solverpetsc.F:206; the reference: PCBJACOBI/ILU(0)).  gamg (default): "
-                         "plain-aggregation multigrid V-cycle, on several ranks block Jacobi over the ranks with one hierarchy per "
-                         "rank; jacobi: the diagonal (north_star's baseline preconditioner; always measured too and reported as "
+                         "plain-aggregation multigrid V-cycle, on several ranks ONE hierarchy across the ranks (slab partitions; "
+                         "PFEM_AMG_COUPLED=0: block Jacobi over the ranks with one hierarchy per rank); jacobi: the diagonal (north_star's baseline preconditioner; always measured too and reported as "
                          "`jacobi_step`); pbjacobi: node-block Jacobi")
     ap.add_argument("--no-jacobi-step", action="store_true", help="skip the extra point-Jacobi measurement reported as `jacobi_step`")
     ap.add_argument("--single-reduction", action="store_true",
@@ -446,6 +446,7 @@ def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=Fa
     R["pc"] = pc
     R["pc_in_effect"] = solver.preconditioner()
     R["amg"] = solver.amgInfo() if R["pc_in_effect"] == "gamg" else None
+    R["amg_layout"] = solver.amgLayout() if R["pc_in_effect"] == "gamg" else None
     R.update(N=int(N), sz=sz, axis=axis, elapsed=elapsed, its=its, reason=reason, rnorm=rnorm, acc=acc, info=info,
              event_overhead_ms=tm["event_overhead_ms"] if tm else 0.0, cinfo=solver.commInfo(),
              fmt_bytes=solver.spmvFormatBytes(), gap_table=solver.spmvGapTable(), bits=solver.spmvColumnBits(),
@@ -619,7 +620,10 @@ def main():
                                  {"pbjacobi": "node-block Jacobi (pbjacobi)", "jacobi": "point Jacobi",
                                   "gamg": "plain-aggregation multigrid V(1,1) cycle (-pc_type gamg: pairwise-matching aggregates, Galerkin coarse "
                                           "operators re-summed in every solve, Chebyshev smoothing, dense bottom solve" +
-                                          ("; block Jacobi over the ranks, one hierarchy per rank" if world > 1 else "") + ")"}[R["pc_in_effect"]] +
+                                          ("" if world == 1 else
+                                           "; ONE hierarchy across the ranks: aggregates inside a rank's owned dofs, global Galerkin operators held "
+                                           "sub-assembled, a neighbour exchange behind every SpMV of the cycle" if (R["amg_layout"] or {}).get("coupled") else
+                                           "; block Jacobi over the ranks, one hierarchy per rank") + ")"}[R["pc_in_effect"]] +
                                  f", zero initial guess, rtol {args.rtol:g} on ||M^-1 r|| (PETSc KSPCG default norm). The reference's PETSc run "
                                  "used KSPCG + PCBJACOBI (per-rank ILU(0), solverpetsc.F:187,206), which is NOT reproduced: "
                                  "iteration counts are not comparable with a PETSc run of the reference; north_star's CG + point Jacobi is "
@@ -648,7 +652,9 @@ def main():
                                 "numeric_setup_ms_per_solve_inside_the_timer": R["amg"]["numeric_ms"],
                                 "symbolic_setup_ms_once_per_pattern": R["amg"]["symbolic_ms"],
                                 "symbolic_setup_where": "first solve after a pattern build (a warm-up step; with --warmup 0 the first timed step)",
-                                "scope": "rank 0's block" if world > 1 else "the whole matrix"} if R["amg"] else {"name": R["pc_in_effect"]}),
+                                "hierarchy": ("one rank" if world == 1 else "one across the ranks" if R["amg_layout"]["coupled"] else "one per rank (block Jacobi over the ranks)"),
+                                "scope": ("the whole matrix" if world == 1 else "rank 0's owned rows of every level of the global hierarchy"
+                                          if R["amg_layout"]["coupled"] else "rank 0's block")} if R["amg"] else {"name": R["pc_in_effect"]}),
             "jacobi_step": ({"preconditioner": "point Jacobi (north_star's)", "steps": Jac["steps"], "warmup": Jac["warmup"],
                              "ms_per_step": Jac["ms_per_step"], "dof_per_s": Jac["N"] / (Jac["ms_per_step"] * 1e-3), "iterations": Jac["its"],
                              "converged_reason": Jac["reason"], "ms_per_iteration": Jac["ms_per_iteration"], Jac["check_name"]: Jac["check"],
