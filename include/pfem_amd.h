@@ -334,10 +334,13 @@ int pfem_solver_amg_info(pfem_solver *s, int max_levels, int *n_levels, int64_t 
                          double *symbolic_ms, double *numeric_ms, int *cheb_degree, int *fine_degree, double *eig_ratio, double *coarse_scale);
 /* coarse dof of every dof of `level` (0 = the assembled matrix); what the oracle's restatement of the cycle is given */
 int pfem_solver_amg_aggregates(pfem_solver *s, int level, int32_t *agg);
-/* several ranks: is the hierarchy of the last solve one across the ranks (1) or one per rank (0); per level (arrays of
- * max_levels) the global number of this rank's first dof and its local rows (owned + ghosts).  With a coupled hierarchy
- * pfem_solver_amg_aggregates hands out GLOBAL coarse numbers and pfem_solver_amg_info's rows are the owned ones.       */
-int pfem_solver_amg_layout(pfem_solver *s, int max_levels, int *coupled, int64_t *first_dof, int64_t *local_rows);
+/* several ranks: is the hierarchy of the last solve one across the ranks (1) or one per rank (0); how many of its levels
+ * are distributed over the ranks (the levels after them -- at most PFEM_AMG_REPLICATE_ROWS rows over all ranks, default
+ * 32768 -- are assembled on every rank, which carries the rest of the cycle alone); per level (arrays of max_levels) the
+ * global number of this rank's first dof and its local rows (owned + ghosts; replicated levels: 0 and all rows).  With a
+ * coupled hierarchy pfem_solver_amg_aggregates hands out GLOBAL coarse numbers and pfem_solver_amg_info's rows are the
+ * owned ones on the distributed levels, all rows on the replicated ones.                                                */
+int pfem_solver_amg_layout(pfem_solver *s, int max_levels, int *coupled, int *distributed_levels, int64_t *first_dof, int64_t *local_rows);
 /* -pc_gamg knobs: Chebyshev degree on the coarse levels (1..6, default 2) and on the assembled matrix itself (0 = the same;
  * default 1: there an SpMV is dearest), lmax/lmin of the smoothing interval (default 8), scaling of the coarse-grid
  * correction (default 1.5: the over-correction a piecewise-constant coarse space wants)                              */

@@ -438,6 +438,51 @@ __global__ void __launch_bounds__(kBlock) k_amg_dense_scatter(SellDev A, const i
     const int len = A.rowlen[r];
     for (int k = 0; k < len; ++k) dense[static_cast<int64_t>(gid[r]) * n_glob + gid[A.cols[base + 64LL * k]]] = A.vals[base + 64LL * k];
 }
+// ---- coupled hierarchy, the step to the replicated levels: this rank's entries of the level with GLOBAL row / column
+// numbers (as doubles: they travel through the all-reduce that concatenates the ranks' lists), row by row
+__global__ void __launch_bounds__(kBlock) k_amg_emit_global_entries(SellDev A, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ gid,
+                                                                     double *__restrict__ rows, double *__restrict__ cols, int32_t *__restrict__ slot)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (r >= A.n_rows) return;
+    const int64_t base = A.slice_off[r >> 6] + (r & 63);
+    const int len = A.rowlen[r];
+    const int64_t p0 = rowptr[r];
+    for (int k = 0; k < len; ++k) {
+        rows[p0 + k] = static_cast<double>(gid[r]);
+        cols[p0 + k] = static_cast<double>(gid[A.cols[base + 64LL * k]]);
+        slot[p0 + k] = static_cast<int32_t>(base + 64LL * k);
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_amg_keys_from_pairs(int64_t n, const double *__restrict__ rows, const double *__restrict__ cols,
+                                                                 uint64_t *__restrict__ keys, int32_t *__restrict__ pos)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = (static_cast<uint64_t>(rows[i] + 0.5) << 32) | static_cast<uint64_t>(cols[i] + 0.5);
+    pos[i] = static_cast<int32_t>(i);
+}
+__global__ void __launch_bounds__(kBlock) k_amg_pack_values(int64_t n, const double *__restrict__ vals, const int32_t *__restrict__ slot,
+                                                             double *__restrict__ out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n) out[i] = vals[slot[i]];
+}
+// node and component of every owned dof of the level, by global dof number (summed over the ranks afterwards)
+__global__ void __launch_bounds__(kBlock) k_amg_emit_global_nodes(int64_t n_own, const int32_t *__restrict__ gid, const int32_t *__restrict__ node_of,
+                                                                   const int32_t *__restrict__ comp_of, int64_t node_off, double *__restrict__ node_g,
+                                                                   double *__restrict__ comp_g)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n_own) return;
+    node_g[gid[i]] = static_cast<double>(node_off + node_of[i]);
+    comp_g[gid[i]] = static_cast<double>(comp_of[i]);
+}
+__global__ void __launch_bounds__(kBlock) k_amg_round_to_int(int64_t n, const double *__restrict__ in, int32_t *__restrict__ out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n) out[i] = static_cast<int32_t>(in[i] + 0.5);
+}
 __global__ void __launch_bounds__(kBlock) k_amg_scatter_gid(int64_t n_own, const double *__restrict__ b, const int32_t *__restrict__ gid,
                                                              double *__restrict__ out, const CgCtl *ctl)
 {

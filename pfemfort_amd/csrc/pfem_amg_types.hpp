@@ -74,4 +74,12 @@ struct Amg {
     bool coupled_refused = false;                    // the partition did not allow it (decided once per pattern, by all ranks together)
     int64_t n_last_global = 0;                       // rows of the last level over all ranks
     DevBuf<double> dense_glob, bx_glob, lam_all;     // coupled: assembled last-level operator, its right-hand side / solution, bounds of all ranks
+    // coupled: from the level where the whole problem is small (kAmgReplicateRows rows over all ranks) every rank holds the
+    // ASSEMBLED level and carries the rest of the hierarchy alone -- the same on all ranks, no exchange below that point, the
+    // fused kernels of the one-rank cycle, aggregates that cross the ranks' borders.  lev.back() is that level in its
+    // distributed form (its sub-assembled matrix feeds rep->lev[0] in every solve), rep->lev[0] the same level assembled.
+    std::unique_ptr<Amg> rep;
+    DevBuf<double> rep_buf;                          // all ranks' entries of the level, rank after rank (rows | cols at set-up, values in a solve)
+    DevBuf<int32_t> rep_pack_slot;                   // this rank's entries: storage slot of each, row by row
+    int64_t rep_total = 0, rep_off = 0, rep_mine = 0;
 };

@@ -997,7 +997,7 @@ int pattern_from_keys(pfem_solver *s, DevBuf<uint64_t> &keys, int64_t nkeys)
     s->cg_graph_key.clear();               // every array a captured CG iteration points at is about to be replaced
     s->mgraph_key.clear();
     s->slices_fmt = -1;                    // ... and the boundary / interior slice lists belong to the old pattern
-    if (s->amg) s->amg->symbolic_ok = false;   // ... and so does the multigrid hierarchy
+    if (s->amg) { s->amg->symbolic_ok = false; s->amg->coupled_refused = false; }   // ... and so does the multigrid hierarchy
     PFEM_TRY(use_sort_bits(s));
     const int end_bit = s->sort_end_bit;
     DevBuf<uint64_t> sorted;
@@ -2341,6 +2341,7 @@ extern "C" int pfem_solver_set_neighbours(pfem_solver *s, int n_peers, const int
     s->have_plan = true;
     s->slices_fmt = -1;
     s->overlap_agreed = -1;
+    if (s->amg) { s->amg->symbolic_ok = false; s->amg->coupled_refused = false; }      // a coupled hierarchy has the plan built in
     return PFEM_OK;
 }
 
@@ -3503,6 +3504,22 @@ extern "C" int pfem_solver_get_history(pfem_solver *s, double *hist, int n, int 
 }
 
 // ---- -pc_type gamg: what the hierarchy looks like, its aggregates (for the oracle's restatement), its knobs ------------
+namespace {
+// the levels of a hierarchy in the order of the cycle: the distributed ones (one rank: all), then -- coupled hierarchy,
+// from the level small enough -- the ones every rank holds whole
+struct AmgLevelRef { const AmgLevel *L; const AmgLevel *next; bool replicated; };
+std::vector<AmgLevelRef> amg_levels_of(const Amg &M)
+{
+    std::vector<AmgLevelRef> v;
+    const size_t nd = M.rep ? M.lev.size() - 1 : M.lev.size();
+    for (size_t l = 0; l < nd; ++l) v.push_back({M.lev[l].get(), l + 1 < M.lev.size() ? M.lev[l + 1].get() : nullptr, false});
+    if (M.rep)
+        for (size_t l = 0; l < M.rep->lev.size(); ++l)
+            v.push_back({M.rep->lev[l].get(), l + 1 < M.rep->lev.size() ? M.rep->lev[l + 1].get() : nullptr, true});
+    return v;
+}
+}   // namespace
+
 extern "C" int pfem_solver_amg_info(pfem_solver *s, int max_levels, int *n_levels, int64_t *rows, int64_t *nnz, double *lambda_max,
                                     double *symbolic_ms, double *numeric_ms, int *cheb_degree, int *fine_degree, double *eig_ratio, double *coarse_scale)
 {
@@ -3511,9 +3528,10 @@ extern "C" int pfem_solver_amg_info(pfem_solver *s, int max_levels, int *n_level
     if (!s->amg || !s->amg->symbolic_ok) return PFEM_OK;
     PFEM_TRY(use_device(s));
     const Amg &M = *s->amg;
-    *n_levels = static_cast<int>(M.lev.size());
+    const std::vector<AmgLevelRef> lev = amg_levels_of(M);
+    *n_levels = static_cast<int>(lev.size());
     for (int l = 0; l < *n_levels && l < max_levels; ++l) {
-        const AmgLevel &L = *M.lev[static_cast<size_t>(l)];
+        const AmgLevel &L = *lev[static_cast<size_t>(l)].L;
         if (rows) rows[l] = L.n;
         if (nnz) nnz[l] = L.nnz;
         if (lambda_max) PFEM_HIP(hipMemcpy(&lambda_max[l], L.lam.p, sizeof(double), hipMemcpyDeviceToHost));
@@ -3530,31 +3548,40 @@ extern "C" int pfem_solver_amg_info(pfem_solver *s, int max_levels, int *n_level
 extern "C" int pfem_solver_amg_aggregates(pfem_solver *s, int level, int32_t *agg)
 {
     if (!s || !agg || level < 0) return PFEM_ERR_ARG;
-    if (!s->amg || !s->amg->symbolic_ok || static_cast<size_t>(level) + 1 >= s->amg->lev.size()) return PFEM_ERR_STATE;
+    if (!s->amg || !s->amg->symbolic_ok) return PFEM_ERR_STATE;
+    const std::vector<AmgLevelRef> lev = amg_levels_of(*s->amg);
+    if (static_cast<size_t>(level) + 1 >= lev.size()) return PFEM_ERR_STATE;
     PFEM_TRY(use_device(s));
-    const AmgLevel &L = *s->amg->lev[static_cast<size_t>(level)];
+    const AmgLevelRef &R = lev[static_cast<size_t>(level)];
+    const AmgLevel &L = *R.L;
     PFEM_HIP(hipMemcpy(agg, L.agg.p, sizeof(int32_t) * static_cast<size_t>(L.n), hipMemcpyDeviceToHost));
     if (level == 0 && s->reordered) {          // level 0 is indexed by the caller's dofs
         std::vector<int32_t> in(agg, agg + L.n);
         for (int64_t i = 0; i < L.n; ++i) agg[i] = in[static_cast<size_t>(to_internal(s, i))];
     }
-    if (s->amg->coupled) {                     // one hierarchy across the ranks: global coarse numbers
-        const int64_t off = s->amg->lev[static_cast<size_t>(level) + 1]->gid_off;
+    if (s->amg->coupled && !R.replicated) {    // one hierarchy across the ranks: global coarse numbers
+        const int64_t off = R.next->gid_off;
         for (int64_t i = 0; i < L.n; ++i) agg[i] = static_cast<int32_t>(agg[i] + off);
     }
     return PFEM_OK;
 }
 
-extern "C" int pfem_solver_amg_layout(pfem_solver *s, int max_levels, int *coupled, int64_t *first_dof, int64_t *local_rows)
+extern "C" int pfem_solver_amg_layout(pfem_solver *s, int max_levels, int *coupled, int *distributed_levels, int64_t *first_dof, int64_t *local_rows)
 {
     if (!s || !coupled) return PFEM_ERR_ARG;
     *coupled = 0;
+    if (distributed_levels) *distributed_levels = 0;
     if (!s->amg || !s->amg->symbolic_ok) return PFEM_OK;
+    const std::vector<AmgLevelRef> lev = amg_levels_of(*s->amg);
     *coupled = s->amg->coupled ? 1 : 0;
-    for (size_t l = 0; l < s->amg->lev.size() && static_cast<int>(l) < max_levels; ++l) {
-        if (first_dof) first_dof[l] = s->amg->lev[l]->gid_off;
-        if (local_rows) local_rows[l] = s->amg->lev[l]->n_loc;
+    int nd = 0;
+    for (size_t l = 0; l < lev.size(); ++l) {
+        if (!lev[l].replicated && s->amg->coupled) ++nd;
+        if (static_cast<int>(l) >= max_levels) continue;
+        if (first_dof) first_dof[l] = lev[l].replicated ? 0 : lev[l].L->gid_off;
+        if (local_rows) local_rows[l] = lev[l].L->n_loc;
     }
+    if (distributed_levels) *distributed_levels = nd;
     return PFEM_OK;
 }
 

@@ -227,7 +227,7 @@ class PetscSolver:
 
     def amgInfo(self):
         """The multigrid hierarchy of the last ``gamg`` solve: rows / nonzeros / eigenvalue bound per level, phase times."""
-        mx = 16
+        mx = 32
         nl = C.c_int(0); rows = (C.c_int64 * mx)(); nnz = (C.c_int64 * mx)(); lam = (C.c_double * mx)()
         sym = C.c_double(0); num = C.c_double(0); deg = C.c_int(0); fdeg = C.c_int(0); ratio = C.c_double(0); scale = C.c_double(0)
         L.check(L.lib().pfem_solver_amg_info(self._h, mx, C.byref(nl), rows, nnz, lam, C.byref(sym), C.byref(num), C.byref(deg),
@@ -243,14 +243,15 @@ class PetscSolver:
         return a
 
     def amgLayout(self):
-        """Several ranks: {"coupled": one hierarchy across the ranks?, "first_dof": [...], "local_rows": [...]} per level."""
-        mx = 16
-        cp = C.c_int(0)
+        """Several ranks: {"coupled": one hierarchy across the ranks?, "distributed_levels": how many of its levels are spread
+        over the ranks (the rest is held whole by every rank), "first_dof": [...], "local_rows": [...]} per level."""
+        mx = 32
+        cp, nd = C.c_int(0), C.c_int(0)
         first = np.zeros(mx, np.int64)
         loc = np.zeros(mx, np.int64)
-        L.check(L.lib().pfem_solver_amg_layout(self._h, mx, C.byref(cp), _p(first), _p(loc)), "pfem_solver_amg_layout")
+        L.check(L.lib().pfem_solver_amg_layout(self._h, mx, C.byref(cp), C.byref(nd), _p(first), _p(loc)), "pfem_solver_amg_layout")
         nl = self.amgInfo()["levels"]
-        return {"coupled": bool(cp.value), "first_dof": first[:nl].tolist(), "local_rows": loc[:nl].tolist()}
+        return {"coupled": bool(cp.value), "distributed_levels": nd.value, "first_dof": first[:nl].tolist(), "local_rows": loc[:nl].tolist()}
 
     def spmvRowGroup(self):
         """Rows served by one lane of the current SpMV (3: row-grouped form)."""

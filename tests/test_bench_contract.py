@@ -163,7 +163,7 @@ def test_plain_invocation_with_two_gpus_launches_its_own_ranks():
     assert c["transport"] == "gloo-host-hooks" and c["fallback_reason"] is None and c["spmv_form"] == "in order"
     assert [(x["rank"], x["device_index"], x["solver_device"]) for x in c["ranks"]] == [(0, 0, 0), (1, 0, 0)]
     assert len({x["pid"] for x in c["ranks"]}) == 2 and c["distinct_devices"] == 1
-    assert d["preconditioner"]["name"] == "gamg" and d["preconditioner"]["scope"] == "rank 0's block" and d["jacobi_step"]["iterations"] > 2 * d["iterations"]
+    assert d["preconditioner"]["name"] == "gamg" and d["preconditioner"]["hierarchy"] == "one across the ranks" and d["jacobi_step"]["iterations"] > 2 * d["iterations"]
     e = d["per_iteration_efficiency"]
     assert e["value"] > 0 and e["n1_free_dofs"] == 7880599 and "profiles/r03" in e["n1_source"]
     sc = d["strong_cfg5"]

@@ -247,6 +247,8 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
             os.environ["PFEM_MULTI_OVERLAP"] = "1"
         if mesh_args.get("amg_block"):      # -pc_type gamg as block Jacobi over the ranks even where one hierarchy across them is possible
             os.environ["PFEM_AMG_COUPLED"] = "0"
+        if mesh_args.get("amg_distributed"):    # every level of the coupled hierarchy spread over the ranks (test meshes are small enough
+            os.environ["PFEM_AMG_REPLICATE_ROWS"] = "0"      # for every rank to hold level 1 whole, which is what happens by default)
         if mesh_args.get("reorder"):        # the owned dofs renumbered inside the library (the plan is translated)
             os.environ["PFEM_REORDER"] = "1"
         devgen = mesh_args.get("mode") == "devgen"     # the rank's slab generated on the device (bench.py's path), any axis
@@ -314,7 +316,7 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
             # the rank's own hierarchy, for the oracle's restatement: its owned diagonal block as assembled here, its aggregates
             ai = s.amgInfo()
             lay = s.amgLayout()
-            extra.update(amg_coupled=int(lay["coupled"]), amg_first=np.array(lay["first_dof"]), amg_lam=np.array(ai["lambda_max"]),
+            extra.update(amg_coupled=int(lay["coupled"]), amg_distributed=lay["distributed_levels"], amg_first=np.array(lay["first_dof"]), amg_lam=np.array(ai["lambda_max"]),
                          amg_local_rows=np.array(lay["local_rows"]))
             rp, cc, vv = s.getCSR()
             no = re - rs
@@ -354,6 +356,8 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                                                             ("elast", 3, "yslabs", "gamg"), ("poisson", 3, "idle", "gamg_overlap"),
                                                             ("poisson", 2, "slabs", "gamg_block"), ("elast", 3, "yslabs", "gamg_block"),
                                                             ("poisson", 3, "xslabs", "gamg"), ("elast", 2, "slabs", "gamg_overlap"),
+                                                            ("poisson", 2, "slabs", "gamg_distributed"), ("elast", 3, "yslabs", "gamg_distributed"),
+                                                            ("poisson", 3, "idle", "gamg_distributed"),
                                                             ("poisson", 3, "sectors", "reorder"), ("elast", 2, "slabs", "reorder_gamg")])
 def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partition, mode):
     """2-3 ranks share cuda:0 (host-staged exchange over gloo): the product's multi-rank device loop against the
@@ -372,11 +376,12 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
         mesh_args["reorder"] = True
         mode = "gamg" if mode == "reorder_gamg" else "batched"
         mesh_args["mode"] = mode
-    if mode in ("gamg", "gamg_overlap", "gamg_block"):
+    if mode in ("gamg", "gamg_overlap", "gamg_block", "gamg_distributed"):
         # -pc_type gamg on several ranks: one hierarchy across the ranks where the partition allows it (slabs: every coarse dof
         # has at most two holders), else -- or when asked, "gamg_block" -- block Jacobi over the ranks, every block its own hierarchy
         mesh_args["mode"], mesh_args["pc"], mesh_args["overlap"] = ("devgen" if partition in ("yslabs", "xslabs") else "batched"), "gamg", mode == "gamg_overlap"
         mesh_args["amg_block"] = mode == "gamg_block"
+        mesh_args["amg_distributed"] = mode == "gamg_distributed"     # no replicated levels: every level keeps its neighbour plan, global dense bottom
     if mode == "devgen":              # bench.py's path: every rank generates its slab (along the partition's axis) on the device
         mesh_args["mode"] = "devgen"
     if world == 3 or mode != "batched":   # the row-group SpMV forms ("auto" keeps systems this small in the row form)
@@ -425,16 +430,24 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
         if coupled:
             # ONE hierarchy across the ranks: the oracle's restatement of the cycle on the assembled GLOBAL matrix with the
             # global aggregates the ranks formed (a rank's piece of level l starts at its first dof of that level)
-            nl = int(d0["amg_levels"])
-            assert all(int(d["amg_levels"]) == nl for d in ds)
+            nl, nd = int(d0["amg_levels"]), int(d0["amg_distributed"])
+            assert all(int(d["amg_levels"]) == nl and int(d["amg_distributed"]) == nd for d in ds)
+            # (test meshes: level 1 is small enough to be replicated -- the little beam's is even below the dense limit, where
+            # the global dense inverse takes over and nothing is left to replicate)
+            assert (nd == nl) if mesh_args["amg_distributed"] else ((1 <= nd < nl) if kind_name == "poisson" else nd == nl == 2)
             aggs, rows_glob = [], []
-            for l in range(nl):
-                rows_glob.append(sum(int(d["amg_rows"][l]) for d in ds))
+            for l in range(nl):          # distributed levels: the ranks' owned rows add up; replicated levels: every rank holds all rows
+                rows_glob.append(sum(int(d["amg_rows"][l]) for d in ds) if l < nd else int(d0["amg_rows"][l]))
+                assert l < nd or all(int(d["amg_rows"][l]) == rows_glob[l] for d in ds)
             for l in range(nl - 1):
-                a = np.full(rows_glob[l], -1, np.int64)
-                for d in ds:
-                    f = int(d["amg_first"][l])
-                    a[f:f + int(d["amg_rows"][l])] = d[f"agg{l}"]
+                if l < nd:
+                    a = np.full(rows_glob[l], -1, np.int64)
+                    for d in ds:
+                        f = int(d["amg_first"][l])
+                        a[f:f + int(d["amg_rows"][l])] = d[f"agg{l}"]
+                else:                    # the replicated part of the hierarchy is the same on every rank
+                    a = d0[f"agg{l}"].astype(np.int64)
+                    assert all(np.array_equal(d[f"agg{l}"], a) for d in ds)
                 assert a.min() >= 0 and a.max() == rows_glob[l + 1] - 1 and len(np.unique(a)) == rows_glob[l + 1]
                 aggs.append(a)
             assert rows_glob[0] == len(prob.rhs) and (rows_glob[-1] <= 128 or nl >= 14)
@@ -446,12 +459,14 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
                                                          lam_given=lam, lam_true_out=lam_true)
             # the ranks' bound (sum of the shares' absolute values) is one: never below the assembled matrix's row sums, seldom far above
             assert all(t * (1 - 1e-12) <= g <= 1.6 * t for t, g in zip(lam_true, lam)), (lam_true, lam.tolist())
+            assert all(abs(g - t) <= 1e-12 * t for t, g in zip(lam_true[nd:], lam[nd:]))        # assembled levels: the bound itself
             # ... and the count stays near the one-rank hierarchy's, far below block Jacobi over the ranks
             assert its_oracle < its_jacobi
         else:
             _, its_oracle, reason_oracle, *_ = O.pcg_bjacobi_amg(prob.rowptr, prob.cols, prob.vals, prob.rhs, blocks, rtol=1e-10, cheb_degree=int(deg),
                                                                  eig_ratio=float(ratio), coarse_scale=float(scale), fine_degree=int(fdeg))
-        print(f"gamg {kind_name} x{world} {partition}: {'coupled' if coupled else 'per-rank'} hierarchy, {int(d0['amg_levels'])} levels, "
+        print(f"gamg {kind_name} x{world} {partition} {mode}: {'coupled' if coupled else 'per-rank'} hierarchy, {int(d0['amg_levels'])} levels "
+              f"({int(d0['amg_distributed'])} distributed), "
               f"{int(d0['its'])} iterations (oracle {its_oracle}, point Jacobi {its_jacobi})")
         assert reason_oracle == 2 and (its_oracle < its_jacobi or kind_name == "elast")     # (tiny beam blocks: no gain to expect)
         its_tol = max(2, its_oracle // 50)          # (runs of hundreds of iterations on the little beam: +-2 %)
@@ -506,7 +521,7 @@ def _rccl_worker(rank, world, port, out_dir):
         import pfemfort_amd as pf
         from pfemfort_amd import distributed as PD
         from pfemfort_amd import host as H
-        mesh = H.gen_box_tets(-1, 1, 6, -1, 1, 5, -1, 1, 7)
+        mesh = H.gen_box_tets(-1, 1, 12, -1, 1, 10, -1, 1, 14)
         dm = H.dof_numbering(mesh.nNode, 1, mesh.bc_node, mesh.bc_dof, mesh.bc_val)
         conn, xyz = H.renumber_mesh(mesh, dm)
         edof = H.elem_dof_array(conn, dm.NodeDofArrayNew)
@@ -519,7 +534,13 @@ def _rccl_worker(rank, world, port, out_dir):
         s.assemble(H.POISSON_ELEMDATA, H.TIMEDATA)
         os.environ["PFEM_FORCE_MULTI"] = "1"                          # one rank, but through the multi-rank loop
         its, reason, _ = s.factoriseAndSolve()
-        np.savez(os.path.join(out_dir, "rccl.npz"), its=its, reason=reason, x=s.getSolution(), bad=bad)
+        x = s.getSolution()
+        # the same through -pc_type gamg's multi-rank form: the hierarchy ACROSS the ranks (here one), whose set-up and cycle
+        # all-reduce vectors of other lengths (level sizes, eigenvalue bounds, the dense bottom operator and its right-hand side)
+        s.setPreconditioner("gamg")
+        its_g, reason_g, _ = s.factoriseAndSolve()
+        np.savez(os.path.join(out_dir, "rccl.npz"), its=its, reason=reason, x=x, bad=bad, its_g=its_g, reason_g=reason_g, x_g=s.getSolution(),
+                 coupled=int(s.amgLayout()["coupled"]), levels=s.amgInfo()["levels"])
         s.free()
     finally:
         dist.destroy_process_group()
@@ -536,10 +557,13 @@ def test_rccl_backend_world_size_1(tmp_path):
     from pfemfort_amd import host as H
     mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
     d = np.load(tmp_path / "rccl.npz")
-    ref = pf.tetrapoissonparallelimpl1(H.gen_box_tets(-1, 1, 6, -1, 1, 5, -1, 1, 7), rtol=1e-10)
+    ref = pf.tetrapoissonparallelimpl1(H.gen_box_tets(-1, 1, 12, -1, 1, 10, -1, 1, 14), rtol=1e-10)
     assert int(d["bad"]) == 0
     assert int(d["reason"]) == 2 and abs(int(d["its"]) - ref.its) <= 1
     assert np.abs(d["x"] - ref.soln_free).max() <= 1e-9
+    ref_g = pf.tetrapoissonparallelimpl1(H.gen_box_tets(-1, 1, 12, -1, 1, 10, -1, 1, 14), rtol=1e-10, pc="gamg")      # the one-rank loop
+    assert int(d["coupled"]) == 1 and int(d["levels"]) >= 2 and int(d["reason_g"]) == 2 and abs(int(d["its_g"]) - ref_g.its) <= 1
+    assert np.abs(d["x_g"] - ref_g.soln_free).max() <= 1e-9
 
 
 def test_neighbour_plan_against_brute_force_random_layouts():
