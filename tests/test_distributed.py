@@ -382,6 +382,9 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
         mesh_args["mode"], mesh_args["pc"], mesh_args["overlap"] = ("devgen" if partition in ("yslabs", "xslabs") else "batched"), "gamg", mode == "gamg_overlap"
         mesh_args["amg_block"] = mode == "gamg_block"
         mesh_args["amg_distributed"] = mode == "gamg_distributed"     # no replicated levels: every level keeps its neighbour plan, global dense bottom
+        if kind_name == "elast" and partition == "yslabs" and mode == "gamg":
+            # a longer beam: its level 1 (3 dofs per aggregate) is above the dense limit and gets replicated, nodes and all
+            mesh_args["box"], mesh_args["long_beam"] = (-0.5, 0.5, 4, 0.0, 4.0, 16, -0.5, 0.5, 4), True
     if mode == "devgen":              # bench.py's path: every rank generates its slab (along the partition's axis) on the device
         mesh_args["mode"] = "devgen"
     if world == 3 or mode != "batched":   # the row-group SpMV forms ("auto" keeps systems this small in the row form)
@@ -433,8 +436,8 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
             nl, nd = int(d0["amg_levels"]), int(d0["amg_distributed"])
             assert all(int(d["amg_levels"]) == nl and int(d["amg_distributed"]) == nd for d in ds)
             # (test meshes: level 1 is small enough to be replicated -- the little beam's is even below the dense limit, where
-            # the global dense inverse takes over and nothing is left to replicate)
-            assert (nd == nl) if mesh_args["amg_distributed"] else ((1 <= nd < nl) if kind_name == "poisson" else nd == nl == 2)
+            # the global dense inverse takes over and nothing is left to replicate; the longer beam's is not)
+            assert (nd == nl) if mesh_args["amg_distributed"] else ((1 <= nd < nl) if (kind_name == "poisson" or mesh_args.get("long_beam")) else nd == nl == 2)
             aggs, rows_glob = [], []
             for l in range(nl):          # distributed levels: the ranks' owned rows add up; replicated levels: every rank holds all rows
                 rows_glob.append(sum(int(d["amg_rows"][l]) for d in ds) if l < nd else int(d0["amg_rows"][l]))
