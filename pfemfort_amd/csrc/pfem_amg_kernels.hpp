@@ -429,6 +429,14 @@ __global__ void __launch_bounds__(kBlock) k_amg_gid_vector(int64_t n, int64_t n_
     const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (i < n_loc) v[i] = i < n ? static_cast<double>(off + agg[i]) : 0.0;
 }
+// w[i] = holder set (bit q = rank q holds it, as a double: at most 52 ranks) of the coarse dof of owned dof i, 0 on the
+// ghosts: after the level's sum-exchange every holder of a dof knows all holders of its aggregate
+__global__ void __launch_bounds__(kBlock) k_amg_mask_vector(int64_t n, int64_t n_loc, const int32_t *__restrict__ agg, const double *__restrict__ mask_c,
+                                                             double *__restrict__ w)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n_loc) w[i] = i < n ? mask_c[agg[i]] : 0.0;
+}
 // this rank's share of the last level's operator into the dense global matrix (zeroed before; summed over the ranks after)
 __global__ void __launch_bounds__(kBlock) k_amg_dense_scatter(SellDev A, const int32_t *__restrict__ gid, int n_glob, double *__restrict__ dense)
 {

@@ -357,7 +357,9 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                                                             ("poisson", 2, "slabs", "gamg_block"), ("elast", 3, "yslabs", "gamg_block"),
                                                             ("poisson", 3, "xslabs", "gamg"), ("elast", 2, "slabs", "gamg_overlap"),
                                                             ("poisson", 2, "slabs", "gamg_distributed"), ("elast", 3, "yslabs", "gamg_distributed"),
-                                                            ("poisson", 3, "idle", "gamg_distributed"),
+                                                            ("poisson", 3, "idle", "gamg_distributed"), ("poisson", 3, "rcb", "gamg_distributed"),
+                                                            ("elast", 3, "sectors", "gamg"), ("elast", 3, "rcb", "gamg_distributed"),
+                                                            ("poisson", 3, "foreign", "gamg"),
                                                             ("poisson", 3, "sectors", "reorder"), ("elast", 2, "slabs", "reorder_gamg")])
 def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partition, mode):
     """2-3 ranks share cuda:0 (host-staged exchange over gloo): the product's multi-rank device loop against the
@@ -428,8 +430,7 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
         coupled = bool(int(d0["amg_coupled"]))
         ds = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
         assert all(bool(int(d["amg_coupled"])) == coupled for d in ds)
-        if partition in ("slabs", "xslabs", "yslabs", "idle"):
-            assert coupled == (not mesh_args["amg_block"])
+        assert coupled == (not mesh_args["amg_block"])       # (any partition: dofs and aggregates with three holders too -- "rcb")
         if coupled:
             # ONE hierarchy across the ranks: the oracle's restatement of the cycle on the assembled GLOBAL matrix with the
             # global aggregates the ranks formed (a rank's piece of level l starts at its first dof of that level)
@@ -472,7 +473,7 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
               f"({int(d0['amg_distributed'])} distributed), "
               f"{int(d0['its'])} iterations (oracle {its_oracle}, point Jacobi {its_jacobi})")
         assert reason_oracle == 2 and (its_oracle < its_jacobi or kind_name == "elast")     # (tiny beam blocks: no gain to expect)
-        its_tol = max(2, its_oracle // 50)          # (runs of hundreds of iterations on the little beam: +-2 %)
+        its_tol = max(2, its_oracle // 25)          # (runs of a hundred and more iterations on the little beam, whose CG stalls on plateaus: +-4 %)
     if mode == "pbjacobi":
         want = "pbjacobi" if kind_name == "elast" else "jacobi"      # Poisson has no multi-row groups: all ranks fall back
         assert all(str(np.load(tmp_path / f"rank{r}.npz")["pc"]) == want for r in range(world))
