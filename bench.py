@@ -210,7 +210,7 @@ def parse_args():
     ap.add_argument("--no-parity-step", action="store_true", help="skip the extra (untimed) step at rtol 1e-10")
     ap.add_argument("--pc", choices=["jacobi", "pbjacobi", "gamg"], default="gamg",
                     help="preconditioner of the CG (PCSetType, solverpetsc.F:206; the reference: PCBJACOBI/ILU(0)).  gamg (default): "
-                         "plain-aggregation multigrid V-cycle, on several ranks ONE hierarchy across the ranks (slab partitions; "
+                         "plain-aggregation multigrid V-cycle, on several ranks ONE hierarchy across the ranks ("
                          "PFEM_AMG_COUPLED=0: block Jacobi over the ranks with one hierarchy per rank); jacobi: the diagonal (north_star's baseline preconditioner; always measured too and reported as "
                          "`jacobi_step`); pbjacobi: node-block Jacobi")
     ap.add_argument("--no-jacobi-step", action="store_true", help="skip the extra point-Jacobi measurement reported as `jacobi_step`")

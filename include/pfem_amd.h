@@ -322,9 +322,9 @@ int pfem_solver_spmv_bytes(pfem_solver *s, int64_t *format_bytes);
  * Aggregates are formed from the values of the first solve after a pattern build and reused while the pattern lives
  * (-pc_gamg_reuse_interpolation true).  Several ranks: ONE hierarchy across the ranks (what PCGAMG does under MPI) --
  * aggregates stay inside a rank's owned dofs, coarse operators are the global Galerkin products held sub-assembled like the
- * matrix, every level has its own neighbour plan -- whenever no coarse dof ends up held by more than two ranks (slab
- * partitions); otherwise, or with PFEM_AMG_COUPLED=0, block Jacobi over the ranks with one hierarchy per rank on its owned
- * diagonal block as assembled from its own elements (PETSc: -pc_type bjacobi -sub_pc_type gamg).                          */
+ * matrix, every level has its own neighbour plan, levels small enough are replicated; with PFEM_AMG_COUPLED=0 (or beyond
+ * 52 ranks) block Jacobi over the ranks with one hierarchy per rank on its owned diagonal block as assembled from its own
+ * elements (PETSc: -pc_type bjacobi -sub_pc_type gamg).                                                                   */
 #define PFEM_PC_GAMG 2
 int pfem_solver_set_preconditioner(pfem_solver *s, int pc);
 int pfem_solver_get_preconditioner(pfem_solver *s, int *pc_in_effect);

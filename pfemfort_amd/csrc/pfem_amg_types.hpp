@@ -69,9 +69,9 @@ struct Amg {
     int coarsest_sweeps = 8;                         // Chebyshev degree on the last level when it is too large for the dense inverse
     // several ranks: one hierarchy ACROSS the ranks (aggregates stay inside a rank's owned dofs, the operators are the
     // global Galerkin products held sub-assembled, every SpMV of the cycle is followed by the level's neighbour exchange)
-    // instead of one hierarchy per rank (block Jacobi).  Needs every coarse dof to be held by at most two ranks.
+    // instead of one hierarchy per rank (block Jacobi).
     bool coupled = false;
-    bool coupled_refused = false;                    // the partition did not allow it (decided once per pattern, by all ranks together)
+    bool coupled_refused = false;                    // the ranks could not form it (decided once per pattern, by all of them together)
     int64_t n_last_global = 0;                       // rows of the last level over all ranks
     DevBuf<double> dense_glob, bx_glob, lam_all;     // coupled: assembled last-level operator, its right-hand side / solution, bounds of all ranks
     // coupled: from the level where the whole problem is small (kAmgReplicateRows rows over all ranks) every rank holds the
