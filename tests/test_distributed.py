@@ -314,6 +314,12 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
             extra = {"x2": s.getSolution(), "its2": its2, "reason2": reason2}
         if mesh_args.get("pc") == "gamg":
             # the rank's own hierarchy, for the oracle's restatement: its owned diagonal block as assembled here, its aggregates
+            if mesh_args.get("mode", "batched") in ("batched", "devgen"):
+                # the same values assembled again, solved again: aggregates, plans and merge maps are reused, every number is redone
+                # (Galerkin sums, the replicated level's values through the all-reduce, bounds, bottom inverse) -- and comes out the same
+                s.assemble(ed, H.TIMEDATA)
+                its_b, reason_b, _ = s.factoriseAndSolve()
+                assert (its_b, reason_b) == (its, reason) and np.array_equal(s.getSolution(), x1)
             ai = s.amgInfo()
             lay = s.amgLayout()
             extra.update(amg_coupled=int(lay["coupled"]), amg_distributed=lay["distributed_levels"], amg_first=np.array(lay["first_dof"]), amg_lam=np.array(ai["lambda_max"]),
