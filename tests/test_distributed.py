@@ -365,7 +365,8 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                                                             ("poisson", 2, "slabs", "gamg_distributed"), ("elast", 3, "yslabs", "gamg_distributed"),
                                                             ("poisson", 3, "idle", "gamg_distributed"), ("poisson", 3, "rcb", "gamg_distributed"),
                                                             ("elast", 3, "sectors", "gamg"), ("elast", 3, "rcb", "gamg_distributed"),
-                                                            ("poisson", 3, "foreign", "gamg"),
+                                                            ("poisson", 3, "foreign", "gamg"), ("poisson", 5, "sectors", "gamg_distributed"),
+                                                            ("elast", 4, "rcb", "gamg"), ("poisson", 6, "rcb", "gamg"),
                                                             ("poisson", 3, "sectors", "reorder"), ("elast", 2, "slabs", "reorder_gamg")])
 def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partition, mode):
     """2-3 ranks share cuda:0 (host-staged exchange over gloo): the product's multi-rank device loop against the
