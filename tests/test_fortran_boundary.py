@@ -131,3 +131,27 @@ def test_fortran_host_program_pc_type_pbjacobi_and_unknown_options(tmp_path):
     (tmp_path / "petsc_options.dat").write_text("-pc_type ilu\n")
     r2 = _run(exe, tmp_path, 1)
     assert r2.returncode != 0 and "-pc_type ilu is not available" in (r2.stdout + r2.stderr).replace("  ", " ")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_fortran_host_program_under_mpiexec_with_pc_type_gamg(tmp_path, golden_dir, world):
+    """`-pc_type gamg` from the options file with the Fortran host program under mpiexec: the ranks (sharing the GPU, MPI
+    host hooks of pfem_mpi.cpp) form ONE multigrid hierarchy across them on the reference-style partition of the tet10
+    mesh (node-index blocks: interface dofs with several holders); same solution as the oracle's, about the
+    iterations of the one-rank hierarchy, far fewer than point Jacobi."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    mesh = H.read_mesh(f"{golden_dir}/input/tet10")
+    dm, npid = _prepare(mesh, 1, world, tmp_path / "problem.txt")
+    (tmp_path / "petsc_options.dat").write_text("-ksp_type cg\n-pc_type gamg\n")
+    r = _run(_exe(True), tmp_path, world, rtol="1e-10", env_extra={"PFEM_CHECK_MODE": "device"})
+    assert r.returncode == 0 and "PC = gamg" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = open(tmp_path / "solution.txt").read().split()
+    its, reason = int(lines[0]), int(lines[1])
+    u = np.array(lines[2:], dtype=float)
+    prob = O.setup_problem(O.POISSON_TET, O.Mesh(mesh.xyz, mesh.conn, mesh.bc_node, mesh.bc_dof, mesh.bc_val), nParts=world, node_proc_id=npid)
+    x = spl.spsolve(sp.csr_matrix((prob.vals, prob.cols, prob.rowptr)).tocsc(), prob.rhs)
+    _, its_j, *_ = O.pcg_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs, rtol=1e-10)
+    assert reason == 2 and np.abs(u - x).max() <= 1e-8 * max(1.0, np.abs(x).max())
+    assert its < 0.6 * its_j and its <= 30          # (one rank: 22; one hierarchy per rank would need 35-50)
