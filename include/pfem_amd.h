@@ -343,7 +343,7 @@ int pfem_solver_amg_aggregates(pfem_solver *s, int level, int32_t *agg);
 int pfem_solver_amg_layout(pfem_solver *s, int max_levels, int *coupled, int *distributed_levels, int64_t *first_dof, int64_t *local_rows);
 /* -pc_gamg knobs: Chebyshev degree on the coarse levels (1..6, default 2) and on the assembled matrix itself (0 = the same;
  * default 1: there an SpMV is dearest), lmax/lmin of the smoothing interval (default 8), scaling of the coarse-grid
- * correction (default 1.5: the over-correction a piecewise-constant coarse space wants)                              */
+ * correction (the over-correction a piecewise-constant coarse space wants; until set: 1.5, and 1.8 for 3-dof nodes)   */
 int pfem_solver_set_amg_options(pfem_solver *s, int cheb_degree, int fine_degree, double eig_ratio, double coarse_scale);
 /* KSPCGUseSingleReduction / -ksp_cg_single_reduction (PETSc option of the KSPCG the reference creates, solverpetsc.F:187;
  * off by default there and here): the Chronopoulos-Gear form of the same iteration -- s = A z instead of w = A p,

@@ -56,9 +56,11 @@ struct Amg {
     int cheb_degree = 2;
     int fine_degree = 1;                             // Chebyshev degree on level 0 (0: cheb_degree), the level where an SpMV is dearest:
                                                      // measured 200^3 52 -> 41 ms, beam 321 -> 279 ms against degree 2 everywhere
+    bool coarse_scale_given = false;                 // set through pfem_solver_set_amg_options / PFEM_AMG_COARSE_SCALE; else 1.5, 1.8 for 3-dof nodes
     double eig_ratio = 8.0, coarse_scale = 1.5;       // over-correction of the piecewise-constant coarse space (Braess 1995 takes 1.8).
                                                      // measured 1.5 -> 1.8: 200^3 equal, the beam 228 -> 189 ms, the 9^3 tet10 mesh WORSE
-                                                     // (26 against 22 iterations): 1.5 is the robust middle
+                                                     // (26 against 22 iterations): 1.5 is the robust middle for scalar problems; with
+                                                     // 3 dofs per node 1.8 is the default (beam 205 -> 169 iterations, half-size beam 191 -> 155)
     // the V-cycle as a hipGraph (one rank): ~100 dependent launches, most of them on levels too small to fill the chip
     hipGraphExec_t graph = nullptr;
     std::vector<uint64_t> graph_key;

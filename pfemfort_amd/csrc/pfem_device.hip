@@ -3595,6 +3595,7 @@ extern "C" int pfem_solver_set_amg_options(pfem_solver *s, int cheb_degree, int 
     s->amg->graph_key.clear();
     s->amg->eig_ratio = eig_ratio;
     s->amg->coarse_scale = coarse_scale;
+    s->amg->coarse_scale_given = true;
     return PFEM_OK;
 }
 
