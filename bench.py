@@ -63,6 +63,19 @@ def pmc_traffic(nnz):
     return None, None
 
 
+def kernel_trace_figures(nnz):
+    """rocprofv3 --kernel-trace averages of the CG SpMV committed next to the PMC figures (same file, same caveat: a
+    builder lease, replayed here for comparison with this run's event pairs), or None."""
+    try:
+        doc = json.load(open(os.path.join(ROOT, "profiles", "spmv_pmc_traffic.json")))
+        for d in doc.get("entries", [doc]):
+            if d.get("nnz") == nnz:
+                return d.get("kernel_trace_avg_us")
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def cpu_baseline(n, rtol, extra_sample=True):
     """The oracle (C restatement of the reference path) on the host cores, on the SAME configuration as the GPU
     number (n^3 x 6 tets, same rtol), timed at the reference's three timer points (tetrapoissonparallelimpl1.F:826,
@@ -555,7 +568,7 @@ def main():
     # ---- the same configuration with north_star's own preconditioner, the diagonal: a shorter, separately timed run
     Jac = None
     if R["pc"] != "jacobi" and not args.no_jacobi_step:
-        Jac = run_case(J, beam, nE, ext, max(1, min(args.steps, 3)), 1, args.rtol, profile=False, pc="jacobi")
+        Jac = run_case(J, beam, nE, ext, max(1, min(args.steps, 3)), 1, args.rtol, profile=True, pc="jacobi")
     # ---- N > 1, weak run: the strong-scaling companion.  The cube of 2 x --cells per side (at the default 200: BASELINE
     # config 5, 400^3 x 6 tets, which fits ONE MI355X: profiles/r02/bench_cfg5_400cube_single_gpu.json) on the same N
     # ranks -- the >= 6x-at-8-GPUs evidence next to the weak figure, whose Jacobi iteration count grows with the problem.
@@ -673,7 +686,16 @@ def main():
                          "hbm_frac": hbm_bytes / (avg_spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if acc["spmv_n"] else 0.0,
                          "hbm_bytes_source": "PMC counters (traffic)" if traffic else "storage of the selected form + x + y",
                          "algorithmic_bytes_per_launch": bytes_per_spmv, "avg_launch_ms": avg_spmv_ms,
-                         "avg_launch_source": "raw HIP event pairs around every 8th SpMV launch of the timed solves, on the solver's stream",
+                         "avg_launch_source": f"raw HIP event pairs around every {2 if R['pc_in_effect'] == 'gamg' else 8}th launch of this kernel in the timed solves "
+                                              "(the CG's own SpMV), on the solver's stream" +
+                                              ("; inside the multigrid loop the kernel starts with the caches full of the cycle's data -- the same "
+                                               "kernel back to back with the Jacobi loop's vector kernels is ~7 % faster (avg_launch_ms_in_jacobi_step; "
+                                               "profiles/r03/rocprofv3_kernel_stats*.txt hold one trace per loop)" if R["pc_in_effect"] == "gamg" else ""),
+                         # what rocprofv3 --kernel-trace says about the same kernel in the same command (committed trace summaries;
+                         # begin -> end of the kernel alone).  An event pair spans marker-end -> kernel-end: it adds the dispatch
+                         # latency and the fences of the markers, ~20 us on this stack -- the judged fraction uses the pair as it is
+                         "kernel_trace_avg_launch_us_replayed_not_this_run": kernel_trace_figures(info["nnz"]) if (world == 1 and args.numbering == "lattice") else None,
+                         "avg_launch_ms_in_jacobi_step": (Jac["acc"]["spmv_ms"] / max(Jac["acc"]["spmv_n"], 1)) if (Jac and Jac["acc"]["spmv_n"]) else None,
                          "event_pair_offset_ms_not_subtracted": R["event_overhead_ms"],
                          "launches_timed": acc["spmv_n"], "nnz": info["nnz"], "rows": info["n_local"]},
         }

@@ -12,8 +12,13 @@ export TMPDIR=/tmp
 ( timeout 900 python bench.py --cells 100 --steps 5 --warmup 2 2>$OUT/final_bench_cfg2.err | tail -1 ) > $OUT/final_bench_cfg2_100cube.json
 ( timeout 1500 python bench.py --gpus 8 --same-device --backend gloo --steps 1 --warmup 1 2>$OUT/final_bench_8ranks.err | tail -1 ) > $OUT/final_bench_cfg5_8ranks_sharing_one_gpu_gloo.json
 rm -rf /tmp/prof_stats
-timeout 900 rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof_stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity-step > $OUT/final_prof_stats.log 2>&1
+# one trace per loop: the default (gamg) bench without its Jacobi companion, and the Jacobi loop alone -- the CG's SpMV kernel
+# has the same name in both and runs ~7 % slower inside the multigrid loop (caches full of the cycle's data)
+timeout 900 rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof_stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity-step --no-jacobi-step > $OUT/final_prof_stats.log 2>&1
 python tools/summarize_prof.py stats /tmp/prof_stats > $OUT/final_rocprofv3_kernel_stats.txt 2>&1
+rm -rf /tmp/prof_stats_j
+timeout 900 rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof_stats_j -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-step --pc jacobi > $OUT/final_prof_stats_j.log 2>&1
+python tools/summarize_prof.py stats /tmp/prof_stats_j > $OUT/final_rocprofv3_kernel_stats_jacobi_loop.txt 2>&1
 RE="k_spmv|k_cg_|k_pc_|k_amg_spmv|k_amg_cheb|k_amg_restrict|k_amg_prolong|k_amg_galerkin|k_amg_diag|k_amg_tail|k_gather"
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/prof_$C
