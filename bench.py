@@ -688,12 +688,13 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_spmv, "avg_launch_ms": avg_spmv_ms,
                          "avg_launch_source": f"raw HIP event pairs around every {2 if R['pc_in_effect'] == 'gamg' else 8}th launch of this kernel in the timed solves "
                                               "(the CG's own SpMV), on the solver's stream" +
-                                              ("; inside the multigrid loop the kernel starts with the caches full of the cycle's data -- the same "
-                                               "kernel back to back with the Jacobi loop's vector kernels is ~7 % faster (avg_launch_ms_in_jacobi_step; "
-                                               "profiles/r03/rocprofv3_kernel_stats*.txt hold one trace per loop)" if R["pc_in_effect"] == "gamg" else ""),
-                         # what rocprofv3 --kernel-trace says about the same kernel in the same command (committed trace summaries;
-                         # begin -> end of the kernel alone).  An event pair spans marker-end -> kernel-end: it adds the dispatch
-                         # latency and the fences of the markers, ~20 us on this stack -- the judged fraction uses the pair as it is
+                                              ("; the same kernel in the Jacobi step of this line: avg_launch_ms_in_jacobi_step; "
+                                               "profiles/r03/rocprofv3_kernel_stats*.txt hold one kernel trace per loop" if R["pc_in_effect"] == "gamg" else ""),
+                         # what rocprofv3 --kernel-trace says about the same kernel in the same command (committed trace summaries).
+                         # The events are bound to the dispatch itself (hipExtLaunchKernelGGL), and still read ~20 us more than the
+                         # trace: under the tracer dispatches run one at a time, on the plain stream the kernel's first waves share
+                         # the device with the last waves of the kernel before it (events without the system-scope fence: no change,
+                         # tools/r03/aj.sh).  The judged fraction uses the pair as it is, the lower of the two figures
                          "kernel_trace_avg_launch_us_replayed_not_this_run": kernel_trace_figures(info["nnz"]) if (world == 1 and args.numbering == "lattice") else None,
                          "avg_launch_ms_in_jacobi_step": (Jac["acc"]["spmv_ms"] / max(Jac["acc"]["spmv_n"], 1)) if (Jac and Jac["acc"]["spmv_n"]) else None,
                          "event_pair_offset_ms_not_subtracted": R["event_overhead_ms"],
