@@ -207,3 +207,31 @@ def test_amg_pcg_restatement(tet10):
     # stopping rule: zero right-hand side, iteration limit
     assert O.pcg_amg(prob.rowptr, prob.cols, prob.vals, 0 * prob.rhs, aggs)[1:3] == (0, 3)
     assert O.pcg_amg(prob.rowptr, prob.cols, prob.vals, prob.rhs, aggs, rtol=1e-14, maxits=3)[1:3] == (3, -3)
+
+
+def test_mpi_restatement_of_the_cpu_baseline_equals_the_serial_oracle():
+    """oracle/pfem_oracle_mpi (bench.py's cpu_baseline with one MPI rank per core): slabs of node planes, the oracle's element
+    routine, distributed Jacobi-PCG -- same matrix size, same iteration count, same residual norm and nodal error as the
+    serial oracle on the whole mesh, on 1, 3 and 5 ranks."""
+    import json
+    import shutil
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "pfem_oracle_mpi")
+    launcher = next((c for c in ("/opt/conda/bin/mpiexec", shutil.which("mpiexec")) if c and os.path.exists(c)), None)
+    if not launcher or not os.path.exists(exe):
+        pytest.skip("no MPI here (make -C oracle mpi builds the program where one is installed)")
+    m = 12
+    mesh = O.gen_box_tets(-1, 1, m, -1, 1, m, -1, 1, m)
+    dm = O.dof_numbering(mesh.nNode, 1, mesh.bc_node, mesh.bc_dof, mesh.bc_val)
+    edof = O.elem_dof_array(mesh.conn, dm.NodeDofArrayNew)
+    rowptr, cols = O.csr_pattern(edof, dm.size_global)
+    vals, rhs = O.assemble(O.POISSON_TET, mesh.xyz, mesh.conn, edof, dm.solnApplied, O.POISSON_ELEMDATA, dm.size_global, rowptr, cols)
+    x, its, reason, rn, _ = O.pcg_jacobi(rowptr, cols, vals, rhs, rtol=1e-10)
+    for ranks in (1, 3, 5):
+        r = subprocess.run([launcher, "-n", str(ranks), exe, str(m), "1e-10", "10000", "1"], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, OMP_NUM_THREADS="1"))
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert (d["ranks"], d["free_dofs"], d["nnz"]) == (ranks, dm.size_global, len(cols))
+        assert (d["iterations"], d["converged_reason"]) == (its, reason) and abs(d["rnorm"] - rn) <= 1e-9 * rn
+        assert d["max_nodal_error"] < 2e-3           # P1 elements on a 12^3 mesh against u = x^2+y^2+z^2
