@@ -36,6 +36,10 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert cb["kind"] == "port" and cb["unit"] == "DOF/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
     # the same configuration as the GPU number, at the reference's three timer points
     assert "40^3" in cb["sample"] and abs(cb["total_s"] - cb["assembly_s"] - cb["solve_s"]) < 1e-9 and cb["its"] == d["jacobi_step"]["iterations"]
+    if "mpi_one_rank_per_core" in cb:          # where an MPI is installed: the reference's mpirun restated, next to the OpenMP port
+        m, o = cb["mpi_one_rank_per_core"], cb["openmp_port"]
+        assert m["iterations"] == o["its"] == cb["its"] and m["converged_reason"] == 2 and m["free_dofs"] == d["config"]["free_dofs"]
+        assert cb["value"] == max(m["value"], o["value"]) and 1 <= m["ranks"] <= 39
     assert d["parity_tolerance_step"]["rtol"] == 1e-10 and d["parity_tolerance_step"]["max_nodal_error"] < 1e-6
     # the default preconditioner is the multigrid V-cycle; north_star's point Jacobi is measured next to it
     pcb, js = d["preconditioner"], d["jacobi_step"]
