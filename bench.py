@@ -740,6 +740,11 @@ def main():
                                 "numeric_setup_ms_per_solve_inside_the_timer": R["amg"]["numeric_ms"],
                                 "symbolic_setup_ms_once_per_pattern": R["amg"]["symbolic_ms"],
                                 "symbolic_setup_where": "first solve after a pattern build (a warm-up step; with --warmup 0 the first timed step)",
+                                "distributed_levels": R["amg_layout"]["distributed_levels"] if world > 1 else None,
+                                "communication_per_cycle": ({"neighbour_exchanges": R["amg_layout"]["exchanges_per_cycle"],
+                                                             "all_reduces": R["amg_layout"]["allreduces_per_cycle"],
+                                                             "note": "enqueued by one V-cycle, next to the CG's own exchange and two all-reduces per iteration"}
+                                                            if world > 1 else None),
                                 "hierarchy": ("one rank" if world == 1 else "one across the ranks" if R["amg_layout"]["coupled"] else "one per rank (block Jacobi over the ranks)"),
                                 "scope": ("the whole matrix" if world == 1 else "rank 0's owned rows of every level of the global hierarchy"
                                           if R["amg_layout"]["coupled"] else "rank 0's block")} if R["amg"] else {"name": R["pc_in_effect"]}),

@@ -341,6 +341,9 @@ int pfem_solver_amg_aggregates(pfem_solver *s, int level, int32_t *agg);
  * coupled hierarchy pfem_solver_amg_aggregates hands out GLOBAL coarse numbers and pfem_solver_amg_info's rows are the
  * owned ones on the distributed levels, all rows on the replicated ones.                                                */
 int pfem_solver_amg_layout(pfem_solver *s, int max_levels, int *coupled, int *distributed_levels, int64_t *first_dof, int64_t *local_rows);
+/* several ranks: neighbour exchanges and all-reduces ONE V-cycle of the last solve enqueued (next to the CG's own exchange
+ * and two all-reduces per iteration); 0 / 0 on one rank                                                                */
+int pfem_solver_amg_comm_counts(pfem_solver *s, int *exchanges_per_cycle, int *allreduces_per_cycle);
 /* -pc_gamg knobs: Chebyshev degree on the coarse levels (1..6, default 2) and on the assembled matrix itself (0 = the same;
  * default 1: there an SpMV is dearest), lmax/lmin of the smoothing interval (default 8), scaling of the coarse-grid
  * correction (the over-correction a piecewise-constant coarse space wants; until set: 1.5, and 1.8 for 3-dof nodes)   */

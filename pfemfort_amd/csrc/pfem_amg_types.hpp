@@ -84,4 +84,5 @@ struct Amg {
     DevBuf<double> rep_buf;                          // all ranks' entries of the level, rank after rank (rows | cols at set-up, values in a solve)
     DevBuf<int32_t> rep_pack_slot;                   // this rank's entries: storage slot of each, row by row
     int64_t rep_total = 0, rep_off = 0, rep_mine = 0;
+    int cycle_exchanges = 0, cycle_allreduces = 0;   // coupled: neighbour exchanges / all-reduces one V-cycle enqueues (counted by the last cycle)
 };

@@ -3585,6 +3585,19 @@ extern "C" int pfem_solver_amg_layout(pfem_solver *s, int max_levels, int *coupl
     return PFEM_OK;
 }
 
+extern "C" int pfem_solver_amg_comm_counts(pfem_solver *s, int *exchanges_per_cycle, int *allreduces_per_cycle)
+{
+    if (!s || !exchanges_per_cycle || !allreduces_per_cycle) return PFEM_ERR_ARG;
+    *exchanges_per_cycle = *allreduces_per_cycle = 0;
+    if (s->amg && s->amg->symbolic_ok && s->amg->coupled) {
+        *exchanges_per_cycle = s->amg->cycle_exchanges;
+        *allreduces_per_cycle = s->amg->cycle_allreduces;
+    } else if (s->amg && s->amg->symbolic_ok && s->nranks > 1) {
+        *exchanges_per_cycle = 1;              // one hierarchy per rank: the owners' z to the ghost holders
+    }
+    return PFEM_OK;
+}
+
 extern "C" int pfem_solver_set_amg_options(pfem_solver *s, int cheb_degree, int fine_degree, double eig_ratio, double coarse_scale)
 {
     if (!s || cheb_degree < 1 || cheb_degree > 6 || fine_degree < 0 || fine_degree > 6 || !(eig_ratio > 1.0) || !(coarse_scale > 0.0)) return PFEM_ERR_ARG;

@@ -251,7 +251,10 @@ class PetscSolver:
         loc = np.zeros(mx, np.int64)
         L.check(L.lib().pfem_solver_amg_layout(self._h, mx, C.byref(cp), C.byref(nd), _p(first), _p(loc)), "pfem_solver_amg_layout")
         nl = self.amgInfo()["levels"]
-        return {"coupled": bool(cp.value), "distributed_levels": nd.value, "first_dof": first[:nl].tolist(), "local_rows": loc[:nl].tolist()}
+        ex, ar = C.c_int(0), C.c_int(0)
+        L.check(L.lib().pfem_solver_amg_comm_counts(self._h, C.byref(ex), C.byref(ar)), "pfem_solver_amg_comm_counts")
+        return {"coupled": bool(cp.value), "distributed_levels": nd.value, "first_dof": first[:nl].tolist(), "local_rows": loc[:nl].tolist(),
+                "exchanges_per_cycle": ex.value, "allreduces_per_cycle": ar.value}
 
     def spmvRowGroup(self):
         """Rows served by one lane of the current SpMV (3: row-grouped form)."""

@@ -322,7 +322,8 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                 assert (its_b, reason_b) == (its, reason) and np.array_equal(s.getSolution(), x1)
             ai = s.amgInfo()
             lay = s.amgLayout()
-            extra.update(amg_coupled=int(lay["coupled"]), amg_distributed=lay["distributed_levels"], amg_first=np.array(lay["first_dof"]), amg_lam=np.array(ai["lambda_max"]),
+            extra.update(amg_coupled=int(lay["coupled"]), amg_distributed=lay["distributed_levels"], amg_exchanges=lay["exchanges_per_cycle"],
+                         amg_allreduces=lay["allreduces_per_cycle"], amg_first=np.array(lay["first_dof"]), amg_lam=np.array(ai["lambda_max"]),
                          amg_local_rows=np.array(lay["local_rows"]))
             rp, cc, vv = s.getCSR()
             no = re - rs
@@ -473,6 +474,13 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
             assert all(abs(g - t) <= 1e-12 * t for t, g in zip(lam_true[nd:], lam[nd:]))        # assembled levels: the bound itself
             # ... and the count stays near the one-rank hierarchy's, far below block Jacobi over the ranks
             assert its_oracle < its_jacobi
+            # what the library says one cycle costs in communication is what the hooks saw (two ranks: both take part in every
+            # exchange; two solves + the set-up's exchanges, a few per level)
+            ex, ar = int(d0["amg_exchanges"]), int(d0["amg_allreduces"])
+            assert ex >= nd and ar == (1 if rows_glob[-1] <= 128 or nd < nl else 0)
+            if world == 2:
+                n_x = sum(1 for k in d0["log"] if k[0] == "x")
+                assert 2 * int(d0["its"]) * (1 + ex) <= n_x <= 2 * (int(d0["its"]) + 2) * (1 + ex) + 40 * nl
         else:
             _, its_oracle, reason_oracle, *_ = O.pcg_bjacobi_amg(prob.rowptr, prob.cols, prob.vals, prob.rhs, blocks, rtol=1e-10, cheb_degree=int(deg),
                                                                  eig_ratio=float(ratio), coarse_scale=float(scale), fine_degree=int(fdeg))
