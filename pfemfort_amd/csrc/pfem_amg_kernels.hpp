@@ -287,8 +287,32 @@ __global__ void __launch_bounds__(kBlock) k_amg_galerkin(int64_t nnz_c, const in
 {
     const int64_t c = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (c >= nnz_c) return;
+    // (a coarse entry sums 4 fine entries on average and ~46 on the diagonal of a 2x2x2 brick: slots first, then all
+    // values -- eight gathers in flight instead of a chain of dependent pairs; added in the same ascending order)
     double a = 0.0;
-    for (int64_t q = src_ptr[c]; q < src_ptr[c + 1]; ++q) a += fine_vals[src_slot[q]];
+    int64_t q = src_ptr[c];
+    const int64_t q1 = src_ptr[c + 1];
+    for (; q + 8 <= q1; q += 8) {
+        int32_t sl[8];
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sl[k] = src_slot[q + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = fine_vals[sl[k]];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a += v[k];
+    }
+    if (q < q1) {
+        int32_t sl[8];
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sl[k] = q + k < q1 ? src_slot[q + k] : -1;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = sl[k] >= 0 ? fine_vals[sl[k]] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (sl[k] >= 0) a += v[k];
+    }
     coarse_vals[dst[c]] = a;
 }
 
