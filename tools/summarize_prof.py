@@ -1,6 +1,6 @@
 """Condense rocprofv3 CSV output into the small text summaries committed under profiles/.
 
-  python tools/summarize_prof.py stats <dir>            -> per-kernel count / avg / total from *kernel_stats.csv
+  python tools/summarize_prof.py stats <dir> [rows]     -> per-kernel count / avg / total from *kernel_stats.csv (top 25)
   python tools/summarize_prof.py pmc <dir> <COUNTER>    -> per-kernel average of a PMC counter per dispatch
 """
 import csv
@@ -19,7 +19,7 @@ def short(name):
     return name[:90]
 
 
-def stats(d):
+def stats(d, top=25):
     files = find(d, "*kernel_stats.csv")
     if not files:
         # fall back to the raw trace
@@ -38,7 +38,7 @@ def stats(d):
     rows.sort(key=lambda r: -r[2])
     tot = sum(r[2] for r in rows) or 1.0
     print(f"{'kernel':92s} {'calls':>8s} {'avg_us':>10s} {'total_ms':>10s} {'%':>6s}")
-    for name, calls, total, avg in rows[:25]:
+    for name, calls, total, avg in rows[:top]:
         print(f"{short(name):92s} {calls:8d} {avg / 1e3:10.2f} {total / 1e6:10.2f} {100 * total / tot:6.2f}")
 
 
@@ -57,6 +57,6 @@ def pmc(d, counter):
 
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
-        stats(sys.argv[2])
+        stats(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 25)
     else:
         pmc(sys.argv[2], sys.argv[3])
