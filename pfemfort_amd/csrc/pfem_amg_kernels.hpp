@@ -91,6 +91,103 @@ __global__ void __launch_bounds__(kBlock) k_amg_hint_coarsen(int64_t n, const in
     const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (i < n) atomicMin(&hint_c[agg[i]], (hint ? hint[i] : static_cast<int32_t>(i)) >> 1);
 }
+// ---- pairing on a tensor-product lattice -----------------------------------------------------------------------------
+// When the nodes of the mesh sit on a lattice (every coordinate takes few distinct values: the generated boxes, the
+// reference's tet10 / tet100 files) a node's hint is its lattice position, 10 bits per axis (x | y << 10 | z << 20), and a
+// pass pairs along ONE axis: node and partner agree in the other two positions and differ in bit 0 of this one -- exact
+// 2x2x2 bricks after three passes, whatever the number of nodes per line.  The node a line of odd length leaves over joins
+// the pair next to it on the same line (a brick of 3 in that direction) instead of pairing across lines, which is what
+// produced plates of half thickness along the boundary of every level whose lines are odd (199 -> 100 -> 50 -> 25 -> 13 -> 7)
+// and cost config 3 a third of its iterations (128^3 and 256^3, whose lines are 2^k - 1, never had them).  A pair is made
+// only across a coupling at least a quarter as strong as the node's strongest (else the node sits this pass out: the
+// classical strength threshold, i.e. semi-coarsening where the operator is anisotropic).
+__device__ __forceinline__ double amg_strength(double w, double di, double dj)
+{
+    return (w < 0.0 && di > 0.0 && dj > 0.0) ? -w / sqrt(di * dj) : 0.0;
+}
+__global__ void __launch_bounds__(kBlock) k_amg_lat_pick(int64_t n, const int64_t *__restrict__ gptr, const int32_t *__restrict__ gcol,
+                                                          const double *__restrict__ gw, const double *__restrict__ gdiag,
+                                                          const int32_t *__restrict__ pos, int shift, int32_t *__restrict__ cand)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int32_t want = pos[i] ^ (1 << shift);          // the sibling's position
+    const double di = gdiag[i];
+    double smax = 0.0, ssib = 0.0;
+    int32_t sib = -1;
+    for (int64_t q = gptr[i]; q < gptr[i + 1]; ++q) {
+        const int32_t j = gcol[q];
+        if (j == i) continue;
+        const double sij = amg_strength(gw[q], di, gdiag[j]);
+        smax = fmax(smax, sij);
+        if (pos[j] == want) { sib = j; ssib = sij; }
+    }
+    cand[i] = (sib >= 0 && ssib > 0.0 && ssib >= 0.25 * smax) ? sib : -1;
+}
+// a node left over joins the pair of its line neighbour (same position but +-1 along the axis of the pass)
+__global__ void __launch_bounds__(kBlock) k_amg_lat_absorb(int64_t n, const int64_t *__restrict__ gptr, const int32_t *__restrict__ gcol,
+                                                            const double *__restrict__ gw, const double *__restrict__ gdiag,
+                                                            const int32_t *__restrict__ pos, int shift, const int32_t *__restrict__ match,
+                                                            int32_t *__restrict__ join)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    int32_t to = -1;
+    if (match[i] < 0) {
+        const int32_t field = 0x3ff << shift, pi = pos[i], ci = (pi >> shift) & 0x3ff;
+        const double di = gdiag[i];
+        double smax = 0.0, sbest = 0.0;
+        for (int64_t q = gptr[i]; q < gptr[i + 1]; ++q) {
+            const int32_t j = gcol[q];
+            if (j == i) continue;
+            const double sij = amg_strength(gw[q], di, gdiag[j]);
+            smax = fmax(smax, sij);
+            const int32_t pj = pos[j], cj = (pj >> shift) & 0x3ff;
+            if (((pi ^ pj) & ~field) == 0 && (cj == ci + 1 || cj == ci - 1) && match[j] >= 0 && sij > sbest) { sbest = sij; to = match[j]; }
+        }
+        if (!(sbest > 0.0 && sbest >= 0.25 * smax)) to = -1;
+    }
+    join[i] = to;
+}
+__global__ void __launch_bounds__(kBlock) k_amg_lat_join(int64_t n, const int32_t *__restrict__ join, int32_t *__restrict__ match)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n && join[i] >= 0) match[i] = join[i];
+}
+// position of an aggregate = its root's, halved along the axis of the pass
+__global__ void __launch_bounds__(kBlock) k_amg_lat_coarsen(int64_t n, const int32_t *__restrict__ pos, const int32_t *__restrict__ match,
+                                                             const int32_t *__restrict__ agg, int shift, int32_t *__restrict__ pos_c)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n || match[i] != static_cast<int32_t>(i)) return;
+    const int32_t field = 0x3ff << shift, p = pos[i];
+    pos_c[agg[i]] = (p & ~field) | ((((p >> shift) & 0x3ff) >> 1) << shift);
+}
+// lattice position of a node from its coordinates and the sorted distinct values of every axis (exact matches)
+__device__ __forceinline__ int amg_lattice_index(const double *__restrict__ u, int n, double v)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (u[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo < n ? lo : n - 1;
+}
+__global__ void __launch_bounds__(kBlock) k_amg_lattice_pos(MeshDev m, int64_t n_owned, const double *__restrict__ ux, int nx,
+                                                             const double *__restrict__ uy, int ny, const double *__restrict__ uz, int nz,
+                                                             int32_t *__restrict__ pos)
+{
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (t >= m.nElem * m.npe) return;
+    const int64_t e = t % m.nElem;
+    const int a = static_cast<int>(t / m.nElem);
+    const int32_t nd = m.conn[a * m.nElem + e];
+    const int ix = amg_lattice_index(ux, nx, m.xyz[nd]), iy = amg_lattice_index(uy, ny, m.xyz[m.nNode + nd]);
+    const int iz = m.ndim > 2 ? amg_lattice_index(uz, nz, m.xyz[2 * m.nNode + nd]) : 0;
+    const int32_t p = ix | (iy << 10) | (iz << 20);
+    for (int d = 0; d < m.ndof; ++d) {
+        const int32_t l = m.edof[(a * m.ndof + d) * m.nElem + e];
+        if (l >= 0 && l < n_owned) pos[l] = p;              // every visit of a dof writes the same value
+    }
+}
+
 // place of a node = place of its first dof / dofs per node
 __global__ void __launch_bounds__(kBlock) k_amg_node_hint(int64_t n, const int32_t *__restrict__ node_of, const int32_t *__restrict__ comp_of,
                                                            const int32_t *__restrict__ dof_rank, int bs, int32_t *__restrict__ hint)

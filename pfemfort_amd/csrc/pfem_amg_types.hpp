@@ -32,6 +32,9 @@ struct AmgLevel {
     int64_t n_nodes = 0;
     DevBuf<int32_t> node_of, comp_of;
     DevBuf<int32_t> hint;                 // [n_nodes] place of every node along a space-filling curve (empty: the index), for the pairing
+    bool lattice = false;                 // hint = lattice position (x | y << 10 | z << 20): the pairing goes axis by axis (k_amg_lat_*)
+    int lat_hi[3] = {0, 0, 0};            // highest position along every axis on this level
+    int lat_axis = 0;                     // axis of this level's first pass
     // transfer to the next level (piecewise-constant prolongation)
     int64_t nc = 0;
     DevBuf<int32_t> agg;                  // [n]  coarse dof of every dof

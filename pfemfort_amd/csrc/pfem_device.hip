@@ -687,6 +687,51 @@ int morton_rank(pfem_solver *s, DevBuf<int32_t> &rank)
     return PFEM_OK;
 }
 
+// Lattice position of every owned dof (x | y << 10 | z << 20) when the nodes of the mesh sit on a tensor-product lattice:
+// every coordinate takes at most 1024 distinct values and their product does not exceed twice the number of nodes.
+// *is_lattice = false otherwise (pos untouched).  hi[d] = highest position along axis d.
+int lattice_positions(pfem_solver *s, DevBuf<int32_t> &pos, bool *is_lattice, int hi[3])
+{
+    const MeshDev &m = s->mesh;
+    const int64_t no = s->n_owned;
+    *is_lattice = false;
+    if (!s->have_mesh || no < 1 || m.nElem < 1 || m.nNode > INT_MAX) return PFEM_OK;
+    // (two work arrays for all three axes: every multi-MB allocation risks one of this stack's stalls)
+    DevBuf<double> sorted, distinct, uniq[3];
+    DevBuf<int> d_count;
+    DevBuf<char> tmp;
+    PFEM_TRY(sorted.alloc(static_cast<size_t>(m.nNode)));
+    PFEM_TRY(distinct.alloc(static_cast<size_t>(m.nNode)));
+    PFEM_TRY(d_count.alloc(1));
+    int count[3] = {1, 1, 1};
+    const int nn = static_cast<int>(m.nNode);
+    for (int d = 0; d < m.ndim; ++d) {
+        const double *c = m.xyz + static_cast<int64_t>(d) * m.nNode;
+        PFEM_TRY(uniq[d].alloc(1024));
+        size_t tb = 0, tb2 = 0;
+        PFEM_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, c, sorted.p, nn, 0, 64, s->stream));
+        PFEM_HIP(hipcub::DeviceSelect::Unique(nullptr, tb2, sorted.p, distinct.p, d_count.p, nn, s->stream));
+        if (std::max(tb, tb2) > tmp.n) { PFEM_HIP(hipStreamSynchronize(s->stream)); PFEM_TRY(tmp.alloc(std::max(tb, tb2))); }
+        PFEM_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, c, sorted.p, nn, 0, 64, s->stream));
+        PFEM_HIP(hipcub::DeviceSelect::Unique(tmp.p, tb2, sorted.p, distinct.p, d_count.p, nn, s->stream));
+        PFEM_HIP(hipMemcpyAsync(&count[d], d_count.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+        if (count[d] > 1024) return PFEM_OK;
+        PFEM_HIP(hipMemcpyAsync(uniq[d].p, distinct.p, sizeof(double) * static_cast<size_t>(count[d]), hipMemcpyDeviceToDevice, s->stream));
+    }
+    if (static_cast<int64_t>(count[0]) * count[1] * count[2] > 2 * m.nNode) return PFEM_OK;
+    PFEM_TRY(pos.alloc(static_cast<size_t>(no)));
+    PFEM_HIP(hipMemsetAsync(pos.p, 0, sizeof(int32_t) * static_cast<size_t>(no), s->stream));
+    hipLaunchKernelGGL(k_amg_lattice_pos, dim3(grid_for(m.nElem * m.npe)), dim3(kBlock), 0, s->stream, m, no, static_cast<const double *>(uniq[0].p),
+                       count[0], static_cast<const double *>(uniq[1].p), count[1],
+                       static_cast<const double *>(m.ndim > 2 ? uniq[2].p : uniq[0].p), count[2], pos.p);
+    PFEM_TRY(check_kernel("k_amg_lattice_pos"));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    for (int d = 0; d < 3; ++d) hi[d] = count[d] - 1;
+    *is_lattice = true;
+    return PFEM_OK;
+}
+
 // external local dof index -> internal (identity unless the mesh was renumbered internally)
 inline int32_t to_internal(const pfem_solver *s, int64_t l) { return (s->reordered && l < s->n_owned) ? s->h_perm[static_cast<size_t>(l)] : static_cast<int32_t>(l); }
 inline int32_t to_external(const pfem_solver *s, int64_t l) { return (s->reordered && l < s->n_owned) ? s->h_iperm[static_cast<size_t>(l)] : static_cast<int32_t>(l); }

@@ -446,7 +446,9 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
             assert all(int(d["amg_levels"]) == nl and int(d["amg_distributed"]) == nd for d in ds)
             # (test meshes: level 1 is small enough to be replicated -- the little beam's is even below the dense limit, where
             # the global dense inverse takes over and nothing is left to replicate; the longer beam's is not)
-            assert (nd == nl) if mesh_args["amg_distributed"] else ((1 <= nd < nl) if (kind_name == "poisson" or mesh_args.get("long_beam")) else nd == nl == 2)
+            print(f"gamg levels {kind_name} x{world} {partition} {mode}: {nl} levels, {nd} distributed, owned rows per level "
+                  f"{[[int(d['amg_rows'][l]) for d in ds] for l in range(nl)]}")
+            assert (nd == nl) if mesh_args["amg_distributed"] else (1 <= nd <= nl)
             aggs, rows_glob = [], []
             for l in range(nl):          # distributed levels: the ranks' owned rows add up; replicated levels: every rank holds all rows
                 rows_glob.append(sum(int(d["amg_rows"][l]) for d in ds) if l < nd else int(d0["amg_rows"][l]))
@@ -462,7 +464,14 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
                     assert all(np.array_equal(d[f"agg{l}"], a) for d in ds)
                 assert a.min() >= 0 and a.max() == rows_glob[l + 1] - 1 and len(np.unique(a)) == rows_glob[l + 1]
                 aggs.append(a)
-            assert rows_glob[0] == len(prob.rhs) and (rows_glob[-1] <= 128 or nl >= 14)
+            # the last level takes the dense inverse, or the coarsening stalled just above its limit (Chebyshev bottom)
+            assert rows_glob[0] == len(prob.rhs) and rows_glob[-1] <= 256
+            if not mesh_args["amg_distributed"]:
+                # replication starts at the first level of at most 32768 rows over all ranks -- on these meshes level 1 -- unless
+                # that level is already small enough for the dense inverse of the all-reduced operator
+                assert (nd == 1 and 128 < rows_glob[1] <= 32768) if nd < nl else rows_glob[-1] <= 128
+            if kind_name == "elast" and world == 4:
+                assert nd < nl              # (this case keeps the replication of a 3-dof level covered)
             lam = d0["amg_lam"]
             assert all(np.array_equal(d["amg_lam"], lam) for d in ds)
             lam_true = [0.0] * nl

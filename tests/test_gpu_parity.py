@@ -851,7 +851,9 @@ def test_gamg_solve_equals_oracle_restatement(case, tet10, beam, tria20, golden_
     bs = 3 if case == "beam" else 1
     for a, n_c in zip(aggs, rows[1:]):
         cnt = np.bincount(a)
-        assert len(cnt) == n_c and cnt.min() >= 1 and cnt.max() <= 8
+        # (three passes of pairing: at most 8; on the beam's lattice the node a line of odd length leaves over joins the pair next
+        # to it: bricks of up to 3 along every axis)
+        assert len(cnt) == n_c and cnt.min() >= 1 and cnt.max() <= (27 if case == "beam" else 8)
     if case == "beam":                          # the three dofs of a node share their aggregate, one coarse dof per component
         a0 = aggs[0].reshape(-1, 3)
         assert np.array_equal(a0[:, 1], a0[:, 0] + 1) and np.array_equal(a0[:, 2], a0[:, 0] + 2) and not (a0[:, 0] % 3).any()
