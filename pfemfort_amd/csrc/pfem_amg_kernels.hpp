@@ -163,6 +163,30 @@ __global__ void __launch_bounds__(kBlock) k_amg_lat_coarsen(int64_t n, const int
     const int32_t field = 0x3ff << shift, p = pos[i];
     pos_c[agg[i]] = (p & ~field) | ((((p >> shift) & 0x3ff) >> 1) << shift);
 }
+// distinct values of one coordinate: every node drops its value into a small open-addressing table (a lattice has a few
+// hundred distinct values per axis, so almost every probe finds its value already there); *overflow when the table fills
+constexpr int kLatticeTable = 4096;
+__global__ void __launch_bounds__(kBlock) k_amg_distinct(const double *__restrict__ c, int64_t n, unsigned long long *__restrict__ table,
+                                                          int *__restrict__ overflow)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double v = c[i] + 0.0;                                  // -0.0 -> +0.0
+    const unsigned long long key = static_cast<unsigned long long>(__double_as_longlong(v));
+    if (key == ~0ull) { *overflow = 1; return; }                   // (the empty marker is a NaN pattern: not a coordinate)
+    unsigned h = static_cast<unsigned>((key * 0x9E3779B97F4A7C15ull) >> 52) & (kLatticeTable - 1);
+    for (int probe = 0; probe < kLatticeTable; ++probe) {
+        const unsigned long long cur = table[h];
+        if (cur == key) return;
+        if (cur == ~0ull) {
+            const unsigned long long old = atomicCAS(&table[h], ~0ull, key);
+            if (old == ~0ull || old == key) return;
+        }
+        h = (h + 1) & (kLatticeTable - 1);
+    }
+    *overflow = 1;
+}
+
 // lattice position of a node from its coordinates and the sorted distinct values of every axis (exact matches)
 __device__ __forceinline__ int amg_lattice_index(const double *__restrict__ u, int n, double v)
 {

@@ -696,28 +696,35 @@ int lattice_positions(pfem_solver *s, DevBuf<int32_t> &pos, bool *is_lattice, in
     const int64_t no = s->n_owned;
     *is_lattice = false;
     if (!s->have_mesh || no < 1 || m.nElem < 1 || m.nNode > INT_MAX) return PFEM_OK;
-    // (two work arrays for all three axes: every multi-MB allocation risks one of this stack's stalls)
-    DevBuf<double> sorted, distinct, uniq[3];
-    DevBuf<int> d_count;
-    DevBuf<char> tmp;
-    PFEM_TRY(sorted.alloc(static_cast<size_t>(m.nNode)));
-    PFEM_TRY(distinct.alloc(static_cast<size_t>(m.nNode)));
-    PFEM_TRY(d_count.alloc(1));
+    // distinct values per axis through a 4096-slot hash table on the device (no O(n) work arrays, no sort: every multi-MB
+    // allocation risks one of this stack's stalls), sorted on the host
+    DevBuf<double> uniq[3];
+    DevBuf<unsigned long long> table;
+    DevBuf<int> d_over;
+    PFEM_TRY(table.alloc(kLatticeTable));
+    PFEM_TRY(d_over.alloc(1));
     int count[3] = {1, 1, 1};
-    const int nn = static_cast<int>(m.nNode);
+    std::vector<unsigned long long> h_table(kLatticeTable);
     for (int d = 0; d < m.ndim; ++d) {
         const double *c = m.xyz + static_cast<int64_t>(d) * m.nNode;
         PFEM_TRY(uniq[d].alloc(1024));
-        size_t tb = 0, tb2 = 0;
-        PFEM_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, c, sorted.p, nn, 0, 64, s->stream));
-        PFEM_HIP(hipcub::DeviceSelect::Unique(nullptr, tb2, sorted.p, distinct.p, d_count.p, nn, s->stream));
-        if (std::max(tb, tb2) > tmp.n) { PFEM_HIP(hipStreamSynchronize(s->stream)); PFEM_TRY(tmp.alloc(std::max(tb, tb2))); }
-        PFEM_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, c, sorted.p, nn, 0, 64, s->stream));
-        PFEM_HIP(hipcub::DeviceSelect::Unique(tmp.p, tb2, sorted.p, distinct.p, d_count.p, nn, s->stream));
-        PFEM_HIP(hipMemcpyAsync(&count[d], d_count.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        PFEM_HIP(hipMemsetAsync(table.p, 0xff, sizeof(unsigned long long) * kLatticeTable, s->stream));
+        PFEM_HIP(hipMemsetAsync(d_over.p, 0, sizeof(int), s->stream));
+        hipLaunchKernelGGL(k_amg_distinct, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, c, m.nNode, table.p, d_over.p);
+        PFEM_TRY(check_kernel("k_amg_distinct"));
+        int over = 0;
+        PFEM_HIP(hipMemcpyAsync(&over, d_over.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        PFEM_HIP(hipMemcpyAsync(h_table.data(), table.p, sizeof(unsigned long long) * kLatticeTable, hipMemcpyDeviceToHost, s->stream));
         PFEM_HIP(hipStreamSynchronize(s->stream));
-        if (count[d] > 1024) return PFEM_OK;
-        PFEM_HIP(hipMemcpyAsync(uniq[d].p, distinct.p, sizeof(double) * static_cast<size_t>(count[d]), hipMemcpyDeviceToDevice, s->stream));
+        if (over) return PFEM_OK;
+        std::vector<double> vals;
+        for (unsigned long long k : h_table)
+            if (k != ~0ull) { double v; std::memcpy(&v, &k, sizeof v); vals.push_back(v); }
+        if (vals.empty() || vals.size() > 1024) return PFEM_OK;
+        std::sort(vals.begin(), vals.end());
+        count[d] = static_cast<int>(vals.size());
+        PFEM_HIP(hipMemcpyAsync(uniq[d].p, vals.data(), sizeof(double) * vals.size(), hipMemcpyHostToDevice, s->stream));
+        PFEM_HIP(hipStreamSynchronize(s->stream));          // (vals goes out of scope)
     }
     if (static_cast<int64_t>(count[0]) * count[1] * count[2] > 2 * m.nNode) return PFEM_OK;
     PFEM_TRY(pos.alloc(static_cast<size_t>(no)));
