@@ -315,10 +315,11 @@ int pfem_solver_spmv_bytes(pfem_solver *s, int64_t *format_bytes);
 #define PFEM_PC_NODE_BLOCK_JACOBI 1
 /* GAMG (PETSc: -pc_type gamg, reachable from the reference through KSPSetFromOptions / petsc_options.dat,
  * solverpetsc.F:191-206): plain-aggregation algebraic multigrid, one V(1,1) cycle per CG iteration -- aggregates of up to
- * 8 nodes from three passes of pairwise matching on the strength graph, piecewise-constant prolongation (one coarse
+ * 8 nodes from three passes of pairing (along the axes of the mesh's lattice when it has one, else pairwise matching on the
+ * strength graph), piecewise-constant prolongation (one coarse
  * vector per dof component), Galerkin coarse operators re-summed in every solve, Chebyshev smoothing on D^-1 A with a
  * Gershgorin bound (degree 1 on the assembled matrix, 2 below), dense inverse at the coarsest level.  The reference's own PCBJACOBI/ILU(0) needs 110 / 1 122
- * iterations on BASELINE configs 3 / 4 and point Jacobi 370 / 5 207; this needs ~20 / ~300 at ~5 SpMV-equivalents each.
+ * iterations on BASELINE configs 3 / 4 and point Jacobi 370 / 5 207; this needs 12 / 169 at ~5 SpMV-equivalents each.
  * Aggregates are formed from the values of the first solve after a pattern build and reused while the pattern lives
  * (-pc_gamg_reuse_interpolation true).  Several ranks: ONE hierarchy across the ranks (what PCGAMG does under MPI) --
  * aggregates stay inside a rank's owned dofs, coarse operators are the global Galerkin products held sub-assembled like the
