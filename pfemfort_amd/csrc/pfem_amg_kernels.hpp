@@ -187,6 +187,55 @@ __global__ void __launch_bounds__(kBlock) k_amg_distinct(const double *__restric
     *overflow = 1;
 }
 
+// ---- coordinates handed down a coupled hierarchy: a coarse node sits at the minimum corner of its aggregate (exact and
+// independent of any order of evaluation -- the level that is replicated on every rank finds ITS lattice from them)
+__device__ __forceinline__ unsigned long long amg_sortable(double v)
+{
+    const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v + 0.0));
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double amg_unsortable(unsigned long long k)
+{
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double(static_cast<long long>(b));
+}
+__global__ void __launch_bounds__(kBlock) k_amg_node_xyz(MeshDev m, int64_t n_owned, const int32_t *__restrict__ node_of, int64_t n_nodes,
+                                                          double *__restrict__ xyz)
+{
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (t >= m.nElem * m.npe) return;
+    const int64_t e = t % m.nElem;
+    const int a = static_cast<int>(t / m.nElem);
+    const int32_t nd = m.conn[a * m.nElem + e];
+    const int32_t l = m.edof[(a * m.ndof) * m.nElem + e];          // first dof of the node
+    if (l < 0 || l >= n_owned) return;
+    const int64_t node = node_of ? node_of[l] : l;
+    if (node >= n_nodes) return;
+    for (int d = 0; d < 3; ++d) xyz[d * n_nodes + node] = d < m.ndim ? m.xyz[static_cast<int64_t>(d) * m.nNode + nd] : 0.0;
+}
+__global__ void __launch_bounds__(kBlock) k_amg_xyz_min(int64_t nn, const int32_t *__restrict__ node_agg, const double *__restrict__ xyz, int64_t na,
+                                                         unsigned long long *__restrict__ keys)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= nn) return;
+    for (int d = 0; d < 3; ++d) atomicMin(&keys[d * na + node_agg[i]], amg_sortable(xyz[d * nn + i]));
+}
+__global__ void __launch_bounds__(kBlock) k_amg_xyz_decode(int64_t n, const unsigned long long *__restrict__ keys, double *__restrict__ xyz)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n) xyz[i] = amg_unsortable(keys[i]);
+}
+// owned nodes' coordinates into the global array of the replicated level (zeroed before, summed over the ranks after)
+__global__ void __launch_bounds__(kBlock) k_amg_emit_global_xyz(int64_t n_nodes_own, const int32_t *__restrict__ gid /* null: node_off + i */,
+                                                                 int64_t node_off, const double *__restrict__ xyz, int64_t n_glob,
+                                                                 double *__restrict__ out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n_nodes_own) return;
+    const int64_t g = gid ? gid[i] : node_off + i;
+    for (int d = 0; d < 3; ++d) out[d * n_glob + g] = xyz[d * n_nodes_own + i];
+}
+
 // lattice position of a node from its coordinates and the sorted distinct values of every axis (exact matches)
 __device__ __forceinline__ int amg_lattice_index(const double *__restrict__ u, int n, double v)
 {

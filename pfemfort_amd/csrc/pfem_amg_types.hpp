@@ -35,6 +35,7 @@ struct AmgLevel {
     bool lattice = false;                 // hint = lattice position (x | y << 10 | z << 20): the pairing goes axis by axis (k_amg_lat_*)
     int lat_hi[3] = {0, 0, 0};            // highest position along every axis on this level
     int lat_axis = 0;                     // axis of this level's first pass
+    DevBuf<double> xyz;                   // coupled hierarchy with a lattice: [3 x n_nodes] a corner of every node's aggregate (see k_amg_xyz_min)
     // transfer to the next level (piecewise-constant prolongation)
     int64_t nc = 0;
     DevBuf<int32_t> agg;                  // [n]  coarse dof of every dof
