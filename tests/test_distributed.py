@@ -394,7 +394,7 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
         mesh_args["amg_distributed"] = mode == "gamg_distributed"     # no replicated levels: every level keeps its neighbour plan, global dense bottom
         if kind_name == "elast" and partition == "yslabs" and mode == "gamg":
             # a longer beam: its level 1 (3 dofs per aggregate) is above the dense limit and gets replicated, nodes and all
-            mesh_args["box"], mesh_args["long_beam"] = (-0.5, 0.5, 4, 0.0, 4.0, 16, -0.5, 0.5, 4), True
+            mesh_args["box"], mesh_args["long_beam"] = (-0.5, 0.5, 6, 0.0, 6.0, 24, -0.5, 0.5, 6), True
     if mode == "devgen":              # bench.py's path: every rank generates its slab (along the partition's axis) on the device
         mesh_args["mode"] = "devgen"
     if world == 3 or mode != "batched":   # the row-group SpMV forms ("auto" keeps systems this small in the row form)
@@ -470,7 +470,7 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
                 # replication starts at the first level of at most 32768 rows over all ranks -- on these meshes level 1 -- unless
                 # that level is already small enough for the dense inverse of the all-reduced operator
                 assert (nd == 1 and 128 < rows_glob[1] <= 32768) if nd < nl else rows_glob[-1] <= 128
-            if kind_name == "elast" and world == 4:
+            if mesh_args.get("long_beam"):
                 assert nd < nl              # (this case keeps the replication of a 3-dof level covered)
             lam = d0["amg_lam"]
             assert all(np.array_equal(d["amg_lam"], lam) for d in ds)
