@@ -346,7 +346,7 @@ int pfem_solver_amg_layout(pfem_solver *s, int max_levels, int *coupled, int *di
  * and two all-reduces per iteration); 0 / 0 on one rank                                                                */
 int pfem_solver_amg_comm_counts(pfem_solver *s, int *exchanges_per_cycle, int *allreduces_per_cycle);
 /* -pc_gamg knobs: Chebyshev degree on the coarse levels (1..6, default 2) and on the assembled matrix itself (0 = the same;
- * default 1: there an SpMV is dearest), lmax/lmin of the smoothing interval (default 8), scaling of the coarse-grid
+ * default 1: there an SpMV is dearest), lmax/lmin of the smoothing interval (until set: 16, and 8 for 3-dof nodes), scaling of the coarse-grid
  * correction (the over-correction a piecewise-constant coarse space wants; until set: 1.5, and 1.8 for 3-dof nodes)   */
 int pfem_solver_set_amg_options(pfem_solver *s, int cheb_degree, int fine_degree, double eig_ratio, double coarse_scale);
 /* KSPCGUseSingleReduction / -ksp_cg_single_reduction (PETSc option of the KSPCG the reference creates, solverpetsc.F:187;

@@ -60,6 +60,8 @@ struct Amg {
     int cheb_degree = 2;
     int fine_degree = 1;                             // Chebyshev degree on level 0 (0: cheb_degree), the level where an SpMV is dearest:
                                                      // measured 200^3 52 -> 41 ms, beam 321 -> 279 ms against degree 2 everywhere
+    bool eig_ratio_given = false;                    // likewise the smoothing interval: until set, lmax/16 .. lmax on scalar problems (with the lattice's
+                                                     // hierarchy 3-7 % faster than /8 at 100^3, 160^3, 200^3), lmax/8 with 3 dofs per node (the beam: /16 costs 12 %)
     bool coarse_scale_given = false;                 // set through pfem_solver_set_amg_options / PFEM_AMG_COARSE_SCALE; else 1.5, 1.8 for 3-dof nodes
     double eig_ratio = 8.0, coarse_scale = 1.5;       // over-correction of the piecewise-constant coarse space (Braess 1995 takes 1.8).
                                                      // measured 1.5 -> 1.8: 200^3 equal, the beam 228 -> 189 ms, the 9^3 tet10 mesh WORSE

@@ -3659,6 +3659,7 @@ extern "C" int pfem_solver_set_amg_options(pfem_solver *s, int cheb_degree, int 
     s->amg->fine_degree = fine_degree;
     s->amg->graph_key.clear();
     s->amg->eig_ratio = eig_ratio;
+    s->amg->eig_ratio_given = true;
     s->amg->coarse_scale = coarse_scale;
     s->amg->coarse_scale_given = true;
     return PFEM_OK;
