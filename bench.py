@@ -706,7 +706,8 @@ def main():
                        "elements": 6 * nEx * nEy * nEz, "nodes": (nEx + 1) * (nEy + 1) * (nEz + 1), "free_dofs": int(N),
                        "solver": f"CG{' (single-reduction form)' if args.single_reduction else ''} + " +
                                  {"pbjacobi": "node-block Jacobi (pbjacobi)", "jacobi": "point Jacobi",
-                                  "gamg": "plain-aggregation multigrid V(1,1) cycle (-pc_type gamg: pairwise-matching aggregates, Galerkin coarse "
+                                  "gamg": "plain-aggregation multigrid V(1,1) cycle (-pc_type gamg: aggregates of 2x2x2 nodes paired along the axes of the mesh's "
+                                          "lattice -- by matching on the strength graph where there is none --, Galerkin coarse "
                                           "operators re-summed in every solve, Chebyshev smoothing, dense bottom solve" +
                                           ("" if world == 1 else
                                            "; ONE hierarchy across the ranks: aggregates inside a rank's owned dofs, global Galerkin operators held "
@@ -740,6 +741,7 @@ def main():
                                 "numeric_setup_ms_per_solve_inside_the_timer": R["amg"]["numeric_ms"],
                                 "symbolic_setup_ms_once_per_pattern": R["amg"]["symbolic_ms"],
                                 "symbolic_setup_where": "first solve after a pattern build (a warm-up step; with --warmup 0 the first timed step)",
+                                "levels_paired_on_the_lattice": R["amg_layout"]["lattice_levels"],
                                 "distributed_levels": R["amg_layout"]["distributed_levels"] if world > 1 else None,
                                 "communication_per_cycle": ({"neighbour_exchanges": R["amg_layout"]["exchanges_per_cycle"],
                                                              "all_reduces": R["amg_layout"]["allreduces_per_cycle"],

@@ -345,6 +345,9 @@ int pfem_solver_amg_layout(pfem_solver *s, int max_levels, int *coupled, int *di
 /* several ranks: neighbour exchanges and all-reduces ONE V-cycle of the last solve enqueued (next to the CG's own exchange
  * and two all-reduces per iteration); 0 / 0 on one rank                                                                */
 int pfem_solver_amg_comm_counts(pfem_solver *s, int *exchanges_per_cycle, int *allreduces_per_cycle);
+/* how many levels of the last hierarchy were coarsened by pairing on the mesh's lattice (the others: by matching on the
+ * strength graph); 0 when the mesh has no lattice or came without coordinates                                          */
+int pfem_solver_amg_pairing(pfem_solver *s, int *lattice_levels);
 /* -pc_gamg knobs: Chebyshev degree on the coarse levels (1..6, default 2) and on the assembled matrix itself (0 = the same;
  * default 1: there an SpMV is dearest), lmax/lmin of the smoothing interval (until set: 16, and 8 for 3-dof nodes), scaling of the coarse-grid
  * correction (the over-correction a piecewise-constant coarse space wants; until set: 1.5, and 1.8 for 3-dof nodes)   */

@@ -114,6 +114,7 @@ SIGNATURES = {
     "pfem_solver_amg_aggregates": [_P, _I, _P],
     "pfem_solver_amg_layout": [_P, _I, _P, _P, _P, _P],
     "pfem_solver_amg_comm_counts": [_P, _P, _P],
+    "pfem_solver_amg_pairing": [_P, _P],
     "pfem_solver_set_amg_options": [_P, _I, _I, _D, _D],
     "pfem_eval_elems": [_P, _P, _P, _P, _P],
     "pfem_rhs_add_values": [_P, _L, _P, _P],

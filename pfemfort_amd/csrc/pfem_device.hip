@@ -3637,6 +3637,16 @@ extern "C" int pfem_solver_amg_layout(pfem_solver *s, int max_levels, int *coupl
     return PFEM_OK;
 }
 
+extern "C" int pfem_solver_amg_pairing(pfem_solver *s, int *lattice_levels)
+{
+    if (!s || !lattice_levels) return PFEM_ERR_ARG;
+    *lattice_levels = 0;
+    if (!s->amg || !s->amg->symbolic_ok) return PFEM_OK;
+    for (const AmgLevelRef &r : amg_levels_of(*s->amg))
+        if (r.L->lattice && r.next) ++*lattice_levels;
+    return PFEM_OK;
+}
+
 extern "C" int pfem_solver_amg_comm_counts(pfem_solver *s, int *exchanges_per_cycle, int *allreduces_per_cycle)
 {
     if (!s || !exchanges_per_cycle || !allreduces_per_cycle) return PFEM_ERR_ARG;

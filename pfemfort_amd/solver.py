@@ -253,8 +253,10 @@ class PetscSolver:
         nl = self.amgInfo()["levels"]
         ex, ar = C.c_int(0), C.c_int(0)
         L.check(L.lib().pfem_solver_amg_comm_counts(self._h, C.byref(ex), C.byref(ar)), "pfem_solver_amg_comm_counts")
+        lat = C.c_int(0)
+        L.check(L.lib().pfem_solver_amg_pairing(self._h, C.byref(lat)), "pfem_solver_amg_pairing")
         return {"coupled": bool(cp.value), "distributed_levels": nd.value, "first_dof": first[:nl].tolist(), "local_rows": loc[:nl].tolist(),
-                "exchanges_per_cycle": ex.value, "allreduces_per_cycle": ar.value}
+                "exchanges_per_cycle": ex.value, "allreduces_per_cycle": ar.value, "lattice_levels": lat.value}
 
     def spmvRowGroup(self):
         """Rows served by one lane of the current SpMV (3: row-grouped form)."""
