@@ -118,6 +118,14 @@ def test_poisson_cube_full_size(n, N, nnz):
     info = s.amgInfo()
     assert reason_g == 2 and its_g <= its // 8 and np.abs(ug - u).max() <= 2e-8 and np.abs(ug - exact).max() < 2e-7
     assert info["rows"][0] == N and info["rows"][1] < N / 6 and sum(info["nnz"]) < 1.25 * nnz
+    # the mesh has a lattice: the hierarchy is the geometric one, bricks of 2 along every axis on every level (199^3 -> 100^3 ->
+    # 50^3 -> ... at 200 cells), whatever the number of nodes per line
+    m = round(N ** (1.0 / 3.0))
+    want = [m ** 3]
+    while want[-1] > 128:
+        m = (m + 1) // 2
+        want.append(m ** 3)
+    assert info["rows"] == want and s.amgLayout()["lattice_levels"] == len(want) - 1
     its_g2, _, _ = s.factoriseAndSolve()
     assert its_g2 == its_g and np.array_equal(s.getSolution(), ug)
 
