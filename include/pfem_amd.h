@@ -335,6 +335,15 @@ int pfem_solver_amg_info(pfem_solver *s, int max_levels, int *n_levels, int64_t 
                          double *symbolic_ms, double *numeric_ms, int *cheb_degree, int *fine_degree, double *eig_ratio, double *coarse_scale);
 /* coarse dof of every dof of `level` (0 = the assembled matrix); what the oracle's restatement of the cycle is given */
 int pfem_solver_amg_aggregates(pfem_solver *s, int level, int32_t *agg);
+/* Displacement problems (as many dofs per node as space dimensions: the tetra / tria elasticity kinds), one rank, mesh on the
+ * device: the coarse space carries the RIGID-BODY MODES of every aggregate (PETSc: MatSetNearNullSpace / PCSetCoordinates
+ * ahead of PCGAMG; tetraelasticityparallelimpl1.F:894-902, 993) -- dim translations and 3 (plane: 1) rotations about the
+ * aggregate's centroid, so a coarse node has 6 (3) dofs; the beam of BASELINE config 4 needs ~25 iterations instead of 169.
+ * What the transfer from `level` to the next one looks like: *rbm = 1 when it carries rotations, dofs per node on this
+ * level and the next, the space dimension, and (optional, [3 x n_nodes] as x | y | z) the coordinates of this level's
+ * nodes (level 0: the mesh nodes in dof order; below: the centroids of the aggregates).  With *rbm = 1
+ * pfem_solver_amg_aggregates reports the TRANSLATION part: dof c of node i belongs to coarse dof coarse_bs * aggregate(i) + c. */
+int pfem_solver_amg_transfer(pfem_solver *s, int level, int *rbm, int *fine_bs, int *coarse_bs, int *dim, int64_t *n_nodes, double *node_xyz);
 /* several ranks: is the hierarchy of the last solve one across the ranks (1) or one per rank (0); how many of its levels
  * are distributed over the ranks (the levels after them -- at most PFEM_AMG_REPLICATE_ROWS rows over all ranks, default
  * 32768 -- are assembled on every rank, which carries the rest of the cycle alone); per level (arrays of max_levels) the
@@ -352,6 +361,7 @@ int pfem_solver_amg_pairing(pfem_solver *s, int *lattice_levels);
  * default 1: there an SpMV is dearest), lmax/lmin of the smoothing interval (until set: 16, and 8 for 3-dof nodes), scaling of the coarse-grid
  * correction (the over-correction a piecewise-constant coarse space wants; until set: 1.5, and 1.8 for 3-dof nodes)   */
 int pfem_solver_set_amg_options(pfem_solver *s, int cheb_degree, int fine_degree, double eig_ratio, double coarse_scale);
+/* (eig_ratio <= 0 / coarse_scale <= 0: that knob stays automatic -- picked per kind of problem at the next symbolic phase) */
 /* KSPCGUseSingleReduction / -ksp_cg_single_reduction (PETSc option of the KSPCG the reference creates, solverpetsc.F:187;
  * off by default there and here): the Chronopoulos-Gear form of the same iteration -- s = A z instead of w = A p,
  * (p,Ap) by recurrence -- so that (z,r), (z,s), (z,z) are reduced together: ONE all-reduce per iteration on several

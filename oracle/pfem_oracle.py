@@ -340,11 +340,57 @@ def pcg_bjacobi_ilu0(rowptr, cols, vals, b, block_start=None, rtol=1e-5, abstol=
     return x, its.value, reason.value, rn.value
 
 
+def rbm_prolongator(node_agg, xyz, dim, fine_bs):
+    """Tentative prolongator with the rigid-body modes of every aggregate (the product: pfem_amg_rbm.hpp; PETSc reaches the
+    same coarse space through MatSetNearNullSpace / PCSetCoordinates ahead of PCGAMG, tetraelasticityparallelimpl1.F:894-902).
+    ``node_agg[i]`` = aggregate of node i, ``xyz`` [3, n_nodes] the nodes' coordinates, nodes of ``fine_bs`` dofs (dim
+    displacements, then -- below the assembled matrix -- the rotations).  A coarse node has dim translations T and 3 (plane: 1)
+    rotations W about the aggregate's centroid:  u_i = T + W x r_i,  w_i = W.  Aggregates whose nodes do not span enough
+    space for the rotations to be independent (collinear in space, single in the plane; assembled matrix only) keep their
+    translations: their offsets are 0.  Returns (P as scipy CSR, centroids [3, n_aggregates])."""
+    import scipy.sparse as sp
+    node_agg = np.asarray(node_agg, dtype=np.int64)
+    xyz = np.asarray(xyz, dtype=np.float64).reshape(3, -1)
+    nn, na = len(node_agg), int(node_agg.max()) + 1
+    nr = 3 if dim == 3 else 1
+    cb = dim + nr
+    cnt = np.bincount(node_agg, minlength=na).astype(np.float64)
+    cen = np.stack([np.bincount(node_agg, weights=xyz[d], minlength=na) / cnt for d in range(3)])
+    r = xyz - cen[:, node_agg]
+    if fine_bs == dim:
+        S = {(a, b): np.bincount(node_agg, weights=r[a] * r[b], minlength=na) for a in range(3) for b in range(a, 3)}
+        tr = S[0, 0] + S[1, 1] + S[2, 2]
+        if dim == 3:
+            m2 = (S[0, 0] * S[1, 1] - S[0, 1] ** 2) + (S[0, 0] * S[2, 2] - S[0, 2] ** 2) + (S[1, 1] * S[2, 2] - S[1, 2] ** 2)
+            ok = (tr > 0.0) & (m2 > 1e-8 * tr * tr)
+        else:
+            ok = tr > 0.0
+        r = r * ok[node_agg]
+    node = np.arange(nn)
+    rows, cols_, vals_ = [], [], []
+
+    def put(c, a, v):
+        rows.append(node * fine_bs + c); cols_.append(node_agg * cb + a); vals_.append(np.broadcast_to(v, (nn,)).astype(np.float64))
+    for c in range(dim):
+        put(c, c, 1.0)
+    if dim == 3:          # u = W x r
+        put(0, 4, r[2]); put(0, 5, -r[1])
+        put(1, 5, r[0]); put(1, 3, -r[2])
+        put(2, 3, r[1]); put(2, 4, -r[0])
+    else:
+        put(0, 2, -r[1]); put(1, 2, r[0])
+    if fine_bs > dim:
+        for k in range(nr):
+            put(dim + k, dim + k, 1.0)
+    P = sp.csr_matrix((np.concatenate(vals_), (np.concatenate(rows), np.concatenate(cols_))), shape=(nn * fine_bs, na * cb))
+    return P, cen
+
+
 def amg_cycle(rowptr, cols, vals, aggregates, cheb_degree=2, eig_ratio=8.0, coarse_scale=1.5, dense_limit=128, coarsest_sweeps=8,
               fine_degree=1, lam_given=None):
     """z = M^-1 r of the product's -pc_type gamg (pfemfort_amd/csrc/pfem_amg.inc), restated in numpy / scipy.sparse GIVEN the
     aggregates (``aggregates[l][i]`` = coarse dof of dof i of level l; the product forms them by pairwise matching and
-    hands them over for this check).  Everything else is restated: piecewise-constant prolongation P, Galerkin operators
+    hands them over for this check; an entry may also be a prolongator itself, see rbm_prolongator).  Everything else is restated: piecewise-constant prolongation P, Galerkin operators
     P^T A P, Chebyshev smoothing of degree ``cheb_degree`` (``fine_degree`` on the matrix itself) on D^-1 A over [lmax/eig_ratio, lmax] with the Gershgorin bound
     lmax = max_i sum_j |a_ij| / a_ii, one symmetric V(1,1) cycle with the coarse correction scaled by ``coarse_scale``, a
     dense solve on the last level when it has at most ``dense_limit`` rows (else Chebyshev of degree ``coarsest_sweeps``).
@@ -354,17 +400,30 @@ def amg_cycle(rowptr, cols, vals, aggregates, cheb_degree=2, eig_ratio=8.0, coar
     A = sp.csr_matrix((np.asarray(vals, dtype=np.float64), np.asarray(cols), np.asarray(rowptr)), shape=(N, N))
     levels = [A]
     P = []
+    rbm = False
     for agg in aggregates:
-        agg = np.asarray(agg, dtype=np.int64)
-        nc = int(agg.max()) + 1
-        Pl = sp.csr_matrix((np.ones(len(agg)), (np.arange(len(agg)), agg)), shape=(len(agg), nc))
+        if sp.issparse(agg):          # an explicit prolongator (rbm_prolongator): Galerkin product with it; the rotation dofs of an
+            Pl = agg.tocsr()          # aggregate without extent are idle dofs with a unit diagonal
+            rbm = True
+            Ac = (Pl.T @ levels[-1] @ Pl).tocsr()
+            dg = Ac.diagonal()
+            if (dg == 0.0).any():
+                Ac = (Ac + sp.diags((dg == 0.0).astype(np.float64))).tocsr()
+        else:
+            agg = np.asarray(agg, dtype=np.int64)
+            nc = int(agg.max()) + 1
+            Pl = sp.csr_matrix((np.ones(len(agg)), (np.arange(len(agg)), agg)), shape=(len(agg), nc))
+            Ac = (Pl.T @ levels[-1] @ Pl).tocsr()
         P.append(Pl)
-        levels.append((Pl.T @ levels[-1] @ Pl).tocsr())
+        levels.append(Ac)
     dinv, lam = [], []
     for Al in levels:
         d = Al.diagonal()
         dinv.append(1.0 / d)
         lam.append(float((abs(Al) @ np.ones(Al.shape[0]) / d).max()))
+        if rbm:     # second bound, on D^-1/2 A D^-1/2 (independent of the scaling of the rotation dofs); the smaller one counts
+            sq = 1.0 / np.sqrt(d)
+            lam[-1] = min(lam[-1], float(((abs(Al) @ sq) * sq).max()))
     lam_true = list(lam)
     if lam_given is not None:
         # one hierarchy across several ranks: the product sums the absolute values of the RANKS' SHARES of an interface

@@ -112,6 +112,7 @@ SIGNATURES = {
     "pfem_solver_set_cg_single_reduction": [_P, _I],
     "pfem_solver_amg_info": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "pfem_solver_amg_aggregates": [_P, _I, _P],
+    "pfem_solver_amg_transfer": [_P, _I, _P, _P, _P, _P, _P, _P],
     "pfem_solver_amg_layout": [_P, _I, _P, _P, _P, _P],
     "pfem_solver_amg_comm_counts": [_P, _P, _P],
     "pfem_solver_amg_pairing": [_P, _P],

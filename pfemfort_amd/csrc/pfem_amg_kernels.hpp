@@ -898,6 +898,10 @@ __global__ void __launch_bounds__(kBlock) k_amg_spmv_ep(SellDev A, const double 
     }
 }
 
+}  // namespace pfem
+#include "pfem_amg_rbm.hpp"          // (after cheb_coef, before the tail kernel that uses its transfer)
+namespace pfem {
+
 // ---------------------------------------------------------------------------
 // The bottom of the cycle in ONE launch: every level of at most kAmgTailRows rows is walked by a single workgroup
 // (block-wide barriers instead of kernel boundaries).  At 200^3 that is 3 of the 8 levels (644, 235, 169 rows): 30
@@ -913,6 +917,11 @@ struct AmgTailLevel {
     double *x, *dd, *t, *r, *b;
     const int32_t *agg, *mem_ptr, *mem_idx;
     int64_t n, nc;
+    // transfer with rigid-body modes (pfem_amg_rbm.hpp): mem_* list nodes then
+    int rbm_dim, fb;
+    int64_t nn;
+    const int32_t *node_agg;
+    const double *roff;
 };
 struct AmgTail {
     int nlev, deg, coarsest_deg, dense_n;
@@ -963,6 +972,24 @@ __device__ inline void tail_smooth(const AmgTailLevel &L, const double *b, bool 
         r_in = L.r;
     }
 }
+// transfer with rigid-body modes inside the tail (a tail level has as many dofs per node as the level below it)
+__device__ inline void tail_rbm_restrict(const AmgTailLevel &L, const AmgTailLevel &C)
+{
+    const int64_t nc_nodes = C.n / L.fb;
+    for (int64_t a = threadIdx.x; a < nc_nodes; a += 1024) {
+        double out[6];
+        if (L.rbm_dim == 3) rbm_restrict_node<6, 3>(a, L.mem_ptr, L.mem_idx, L.roff, L.nn, L.b, L.t, L.nn, out);
+        else rbm_restrict_node<3, 2>(a, L.mem_ptr, L.mem_idx, L.roff, L.nn, L.b, L.t, L.nn, out);
+        for (int k = 0; k < L.fb; ++k) C.b[L.fb * a + k] = out[k];
+    }
+}
+__device__ inline void tail_rbm_prolong(const AmgTailLevel &L, const AmgTailLevel &C, double scale)
+{
+    for (int64_t i = threadIdx.x; i < L.nn; i += 1024) {
+        if (L.rbm_dim == 3) rbm_prolong_node<6, 3>(i, L.node_agg, L.roff, L.nn, C.x, scale, L.x);
+        else rbm_prolong_node<3, 2>(i, L.node_agg, L.roff, L.nn, C.x, scale, L.x);
+    }
+}
 __global__ void __launch_bounds__(1024) k_amg_tail(AmgTail T, const CgCtl *ctl)
 {
     if (ctl && ctl->flag != 0) return;
@@ -986,6 +1013,8 @@ __global__ void __launch_bounds__(1024) k_amg_tail(AmgTail T, const CgCtl *ctl)
         const AmgTailLevel &C = T.lev[l + 1];
         tail_smooth(L, L.b, true, T.deg, T.ratio);
         tail_spmv(L.A, L.x, L.t);
+        if (L.rbm_dim) tail_rbm_restrict(L, C);
+        else
         for (int64_t a = threadIdx.x; a < C.n; a += 1024) {
             double acc = 0.0;
             for (int q = L.mem_ptr[a]; q < L.mem_ptr[a + 1]; ++q) {
@@ -999,6 +1028,8 @@ __global__ void __launch_bounds__(1024) k_amg_tail(AmgTail T, const CgCtl *ctl)
     for (int l = nl - 2; l >= 0; --l) {
         const AmgTailLevel &L = T.lev[l];
         const AmgTailLevel &C = T.lev[l + 1];
+        if (L.rbm_dim) tail_rbm_prolong(L, C, T.scale);
+        else
         for (int64_t i = threadIdx.x; i < L.n; i += 1024) L.x[i] = __builtin_fma(T.scale, C.x[L.agg[i]], L.x[i]);
         __syncthreads();
         tail_smooth(L, L.b, false, T.deg, T.ratio);

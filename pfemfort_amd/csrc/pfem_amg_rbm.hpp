@@ -1,0 +1,440 @@
+// pfem_amg_rbm.hpp -- gfx950 kernels of the rigid-body-mode coarse space of -pc_type gamg for problems with DIM displacement
+// dofs per node (tetraelasticityparallelimpl1.F:894-902, 993: the reference's beam; PETSc reaches the same space through
+// MatSetNearNullSpace / PCSetCoordinates).  Host side and the why: pfem_amg.inc ("rigid-body modes").
+//
+// A level whose dofs come in nodes of FB dofs each (FB = DIM on the assembled matrix, FB = CB below it) is coarsened into
+// nodes of CB = DIM + NR dofs: DIM translations T and NR rotations W (3 in space, 1 in the plane) about the aggregate's
+// centroid.  For a fine node at offset r from the centroid of its aggregate
+//      u = T + W x r          (plane: u = T + Wz (-ry, rx))            and, when the fine node carries rotations itself,  w = W,
+// i.e. P_i = [ I  S(r_i) ; 0  I ] with S(r) W = W x r.  Everything is node-block arithmetic on the wave-sliced scalar
+// storage: a level is "block regular" (k_rbm_check_blocks): the FB rows of a node have the same length, and their columns
+// come in runs of FB consecutive dofs of one node, so entry (c, d) of node block (i, jj) sits at a closed-form slot.
+#pragma once
+
+namespace pfem {
+
+template <int DIM> struct RbmDims { static constexpr int NR = DIM == 3 ? 3 : 1; static constexpr int CB = DIM + NR; };
+
+// g[0..NR) += S(r)^T f  (f: DIM forces on a node at offset r -> moments about the centroid: r x f)
+template <int DIM>
+__device__ __forceinline__ void rbm_moment(const double *r, const double *f, double *g)
+{
+    if (DIM == 3) {
+        g[0] += r[1] * f[2] - r[2] * f[1];
+        g[1] += r[2] * f[0] - r[0] * f[2];
+        g[2] += r[0] * f[1] - r[1] * f[0];
+    } else {
+        g[0] += r[0] * f[1] - r[1] * f[0];
+    }
+}
+// u[0..DIM) = W x r
+template <int DIM>
+__device__ __forceinline__ void rbm_spin(const double *r, const double *w, double *u)
+{
+    if (DIM == 3) {
+        u[0] = w[1] * r[2] - w[2] * r[1];
+        u[1] = w[2] * r[0] - w[0] * r[2];
+        u[2] = w[0] * r[1] - w[1] * r[0];
+    } else {
+        u[0] = -w[0] * r[1];
+        u[1] = w[0] * r[0];
+    }
+}
+
+__device__ __forceinline__ int64_t rbm_row_base(const SellDev &A, int64_t row) { return A.slice_off[row >> 6] + (row & 63); }
+
+// ---- symbolic phase ------------------------------------------------------------------------------------------------
+// Is the level block regular?  One thread per node: the bs rows of node i have one length, a multiple of bs, and entry
+// bs*jj + d of row bs*i + c is dof d of the node whose dof 0 entry bs*jj of row bs*i names.  deg[i] = blocks in node row i.
+__global__ void __launch_bounds__(kBlock) k_rbm_check_blocks(SellDev A, int bs, int64_t n_nodes, int64_t *__restrict__ deg, int *__restrict__ bad)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i > n_nodes) return;
+    if (i == n_nodes) { deg[i] = 0; return; }
+    const int64_t row0 = static_cast<int64_t>(bs) * i;
+    const int len = A.rowlen[row0];
+    bool ok = len % bs == 0;
+    for (int c = 1; c < bs; ++c) ok = ok && A.rowlen[row0 + c] == len;
+    if (ok) {
+        for (int c = 0; c < bs; ++c) {
+            const int64_t base = rbm_row_base(A, row0 + c);
+            for (int k = 0; k < len; k += bs) {
+                const int32_t c0 = A.cols[base + 64LL * k];
+                ok = ok && c0 % bs == 0 && c0 < bs * n_nodes;
+                for (int d = 1; d < bs; ++d) ok = ok && A.cols[base + 64LL * (k + d)] == c0 + d;
+            }
+        }
+        if (ok && bs > 1) {       // the rows of a node name the same nodes
+            const int64_t b0 = rbm_row_base(A, row0), b1 = rbm_row_base(A, row0 + 1);
+            for (int k = 0; k < len; k += bs) ok = ok && A.cols[b0 + 64LL * k] == A.cols[b1 + 64LL * k];
+        }
+    }
+    deg[i] = ok ? len / bs : 0;
+    if (!ok) *bad = 1;
+}
+
+// node graph of a block-regular level: columns, the node row of every block, and the strength weights of the pairing
+// (Frobenius norm of the DIM x DIM displacement part of a node block: -norm off the diagonal, norm on it -- what
+// k_amg_graph_from_keys makes of the squared entries)
+__global__ void __launch_bounds__(kBlock) k_rbm_graph_fill(SellDev A, int bs, int dim, int64_t n_nodes, const int64_t *__restrict__ gptr,
+                                                            int32_t *__restrict__ gcol, int32_t *__restrict__ brow, double *__restrict__ gw,
+                                                            double *__restrict__ gdiag)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n_nodes) return;
+    const int64_t row0 = static_cast<int64_t>(bs) * i;
+    const int64_t q0 = gptr[i];
+    const int deg = static_cast<int>(gptr[i + 1] - q0);
+    bool have_diag = false;
+    for (int jj = 0; jj < deg; ++jj) {
+        double s2 = 0.0;
+        int32_t j = 0;
+        for (int c = 0; c < dim; ++c) {
+            const int64_t base = rbm_row_base(A, row0 + c);
+            if (c == 0) j = A.cols[base + 64LL * (bs * jj)] / bs;
+            for (int d = 0; d < dim; ++d) {
+                const double v = A.vals[base + 64LL * (bs * jj + d)];
+                s2 += v * v;
+            }
+        }
+        gcol[q0 + jj] = j;
+        brow[q0 + jj] = static_cast<int32_t>(i);
+        if (j == i) { gdiag[i] = sqrt(s2); gw[q0 + jj] = 0.0; have_diag = true; }
+        else gw[q0 + jj] = -sqrt(s2);
+    }
+    if (!have_diag) gdiag[i] = 0.0;
+}
+
+// dof -> (node, component) of a level whose dofs come bs to the node
+__global__ void __launch_bounds__(kBlock) k_rbm_node_comp(int64_t n, int bs, int32_t *__restrict__ node_of, int32_t *__restrict__ comp_of)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    node_of[i] = static_cast<int32_t>(i / bs);
+    comp_of[i] = static_cast<int32_t>(i % bs);
+}
+// coarse dof that carries the same component of the same aggregate (the translation part of P: what pfem_solver_amg_aggregates reports)
+__global__ void __launch_bounds__(kBlock) k_rbm_dof_agg(int64_t n, int bs, int cb, const int32_t *__restrict__ node_agg, int32_t *__restrict__ agg)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n) agg[i] = cb * node_agg[i / bs] + static_cast<int32_t>(i % bs);
+}
+
+// coordinates of the nodes of the assembled matrix: node of dof l = l / ndof (checked by the caller through the element
+// dof array: a node's dofs are consecutive, all free or all constrained)
+__global__ void __launch_bounds__(kBlock) k_rbm_mesh_xyz(MeshDev m, int64_t n_nodes, double *__restrict__ xyz, int *__restrict__ bad)
+{
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (t >= m.nElem * m.npe) return;
+    const int64_t e = t % m.nElem;
+    const int a = static_cast<int>(t / m.nElem);
+    const int32_t nd = m.conn[a * m.nElem + e];
+    const int32_t l0 = m.edof[(a * m.ndof) * m.nElem + e];
+    bool ok = true;
+    for (int d = 1; d < m.ndof; ++d) {
+        const int32_t l = m.edof[(a * m.ndof + d) * m.nElem + e];
+        ok = ok && (l0 < 0 ? l < 0 : l == l0 + d);
+    }
+    if (l0 >= 0) ok = ok && l0 % m.ndof == 0 && l0 / m.ndof < n_nodes;
+    if (!ok) { *bad = 1; return; }
+    if (l0 < 0) return;
+    const int64_t node = l0 / m.ndof;
+    for (int d = 0; d < 3; ++d) xyz[d * n_nodes + node] = d < m.ndim ? m.xyz[static_cast<int64_t>(d) * m.nNode + nd] : 0.0;
+}
+
+// centroid of every aggregate (members in ascending order: one fixed sum) and whether its nodes span enough space for the
+// rotations to be independent of the translations and of each other: in space the nodes must not be collinear (the sum of
+// the principal 2x2 minors of sum r r^T must not vanish), in the plane there must be two of them.  A degenerate aggregate
+// keeps its translations only (its nodes get the offset 0, so its rotation columns vanish; k_rbm_galerkin puts 1 on the
+// diagonal of the empty rows).
+__global__ void __launch_bounds__(kBlock) k_rbm_centroids(int64_t na, int dim, int64_t nn, const int32_t *__restrict__ mem_ptr,
+                                                           const int32_t *__restrict__ mem_idx, const double *__restrict__ xyz, int64_t nn_c,
+                                                           double *__restrict__ cen, int32_t *__restrict__ rot_ok, int check)
+{
+    const int64_t a = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (a >= na) return;
+    const int q0 = mem_ptr[a], q1 = mem_ptr[a + 1];
+    double c[3] = {0.0, 0.0, 0.0};
+    for (int q = q0; q < q1; ++q) {
+        const int64_t i = mem_idx[q];
+        for (int d = 0; d < 3; ++d) c[d] += xyz[d * nn + i];
+    }
+    const double inv = q1 > q0 ? 1.0 / static_cast<double>(q1 - q0) : 0.0;
+    for (int d = 0; d < 3; ++d) { c[d] *= inv; cen[d * nn_c + a] = c[d]; }
+    int ok = 1;
+    if (check) {
+        double sxx = 0, syy = 0, szz = 0, sxy = 0, sxz = 0, syz = 0;
+        for (int q = q0; q < q1; ++q) {
+            const int64_t i = mem_idx[q];
+            const double x = xyz[i] - c[0], y = xyz[nn + i] - c[1], z = xyz[2 * nn + i] - c[2];
+            sxx += x * x; syy += y * y; szz += z * z; sxy += x * y; sxz += x * z; syz += y * z;
+        }
+        const double tr = sxx + syy + szz;
+        if (dim == 3) {
+            const double m2 = (sxx * syy - sxy * sxy) + (sxx * szz - sxz * sxz) + (syy * szz - syz * syz);
+            ok = tr > 0.0 && m2 > 1e-8 * tr * tr;
+        } else {
+            ok = tr > 0.0;
+        }
+    }
+    rot_ok[a] = ok;
+}
+// offset of every node from the centroid of its aggregate (0 in a degenerate aggregate)
+__global__ void __launch_bounds__(kBlock) k_rbm_offsets(int64_t nn, const int32_t *__restrict__ node_agg, const double *__restrict__ xyz,
+                                                         int64_t nn_c, const double *__restrict__ cen, const int32_t *__restrict__ rot_ok,
+                                                         double *__restrict__ roff)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= nn) return;
+    const int32_t a = node_agg[i];
+    const bool ok = rot_ok[a] != 0;
+    for (int d = 0; d < 3; ++d) roff[d * nn + i] = ok ? xyz[d * nn + i] - cen[d * nn_c + a] : 0.0;
+}
+
+// coarse node block of every fine node block: key (agg(i) << 32 | agg(j)), payload the block's index (sorted afterwards;
+// the radix sort is stable, so the blocks of one coarse block stay in ascending order: one fixed sum)
+__global__ void __launch_bounds__(kBlock) k_rbm_emit_block_keys(int64_t nblk, const int32_t *__restrict__ brow, const int32_t *__restrict__ gcol,
+                                                                 const int32_t *__restrict__ node_agg, uint64_t *__restrict__ keys,
+                                                                 int32_t *__restrict__ idx)
+{
+    const int64_t q = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (q >= nblk) return;
+    keys[q] = (static_cast<uint64_t>(static_cast<uint32_t>(node_agg[brow[q]])) << 32) | static_cast<uint32_t>(node_agg[gcol[q]]);
+    idx[q] = static_cast<int32_t>(q);
+}
+__global__ void __launch_bounds__(kBlock) k_rbm_split_keys(int64_t n, const uint64_t *__restrict__ ukeys, int32_t *__restrict__ brow,
+                                                            int32_t *__restrict__ gcol)
+{
+    const int64_t q = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (q >= n) return;
+    brow[q] = static_cast<int32_t>(ukeys[q] >> 32);
+    gcol[q] = static_cast<int32_t>(ukeys[q] & 0xffffffffu);
+}
+// scalar row pointer of a block-regular level from its node graph
+__global__ void __launch_bounds__(kBlock) k_rbm_rowptr(int64_t n_nodes, int bs, const int64_t *__restrict__ gptr, int64_t *__restrict__ rowptr)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t n = n_nodes * bs;
+    if (r > n) return;
+    if (r == n) { rowptr[r] = gptr[n_nodes] * bs * bs; return; }
+    const int64_t i = r / bs;
+    const int a = static_cast<int>(r % bs);
+    rowptr[r] = gptr[i] * bs * bs + static_cast<int64_t>(a) * bs * (gptr[i + 1] - gptr[i]);
+}
+// its columns in the wave-sliced storage (padding: the own row, as everywhere)
+__global__ void __launch_bounds__(kBlock) k_rbm_fill_cols(int64_t n_rows, int64_t n_slices, int bs, const int64_t *__restrict__ slice_off,
+                                                           const int64_t *__restrict__ gptr, const int32_t *__restrict__ gcol,
+                                                           int32_t *__restrict__ cols)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t s = r >> 6;
+    if (s >= n_slices) return;
+    const int64_t off = slice_off[s] + (r & 63);
+    const int width = static_cast<int>((slice_off[s + 1] - slice_off[s]) >> 6);
+    int64_t q0 = 0;
+    int len = 0;
+    if (r < n_rows) { q0 = gptr[r / bs]; len = static_cast<int>(gptr[r / bs + 1] - q0) * bs; }
+    const int32_t pad = r < n_rows ? static_cast<int32_t>(r) : 0;
+    for (int k = 0; k < width; ++k) cols[off + 64LL * k] = k < len ? bs * gcol[q0 + k / bs] + k % bs : pad;
+}
+
+// ---- numeric phase: Galerkin product with the rigid-body prolongator, one thread per coarse node block ------------------
+// C(I,J) = sum over the fine blocks (i,j), i in I, j in J, of  P_i^T F_ij P_j.  A fine block is read row by row:
+// row m of G = F P_j is formed from row m of F, then added to the rows of C that row m of P_i^T feeds.
+template <int FB, int DIM>
+__global__ void __launch_bounds__(kBlock) k_rbm_galerkin(int64_t nblk_c, const int64_t *__restrict__ src_ptr, const int32_t *__restrict__ src_blk,
+                                                          SellDev F, const int64_t *__restrict__ f_gptr, const int32_t *__restrict__ f_gcol,
+                                                          const int32_t *__restrict__ f_brow, const double *__restrict__ roff, int64_t nn,
+                                                          SellDev C, const int64_t *__restrict__ c_gptr, const int32_t *__restrict__ c_brow,
+                                                          const int32_t *__restrict__ c_gcol)
+{
+    constexpr int NR = RbmDims<DIM>::NR, CB = RbmDims<DIM>::CB;
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (c >= nblk_c) return;
+    double acc[CB][CB];
+#pragma unroll
+    for (int a = 0; a < CB; ++a)
+#pragma unroll
+        for (int b = 0; b < CB; ++b) acc[a][b] = 0.0;
+    for (int64_t p = src_ptr[c]; p < src_ptr[c + 1]; ++p) {
+        const int64_t q = src_blk[p];
+        const int64_t i = f_brow[q];
+        const int64_t j = f_gcol[q];
+        const int jj = static_cast<int>(q - f_gptr[i]);
+        double ri[3], rj[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { ri[d] = roff[d * nn + i]; rj[d] = roff[d * nn + j]; }
+#pragma unroll
+        for (int m = 0; m < FB; ++m) {
+            const int64_t base = rbm_row_base(F, FB * i + m) + 64LL * (FB * jj);
+            double f[FB], g[CB];
+#pragma unroll
+            for (int d = 0; d < FB; ++d) f[d] = F.vals[base + 64LL * d];
+            // g = f P_j :  translations as they are, rotations  (f S(r_j))_k = f . (e_k x r_j)  [+ the fine rotations]
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) g[d] = f[d];
+            {
+                double mom[NR];
+#pragma unroll
+                for (int k = 0; k < NR; ++k) mom[k] = 0.0;
+                rbm_moment<DIM>(rj, f, mom);
+#pragma unroll
+                for (int k = 0; k < NR; ++k) g[DIM + k] = FB > DIM ? mom[k] + f[DIM + k] : mom[k];
+            }
+            // acc += (row m of P_i)^T g
+            if (m < DIM) {
+#pragma unroll
+                for (int b = 0; b < CB; ++b) acc[m][b] += g[b];
+                // rotations: P_i[m, DIM + k] = (e_k x r_i)_m
+                if (DIM == 3) {
+                    const int m1 = (m + 1) % 3, m2 = (m + 2) % 3;
+                    // (e_k x r)_m: k = m1 -> e_m1 x r has component m equal to  r[m2] * eps(m1, m2, m) = +r[m2]  (cyclic m1,m2,m)
+                    //              k = m2 -> e_m2 x r has component m equal to  r[m1] * eps(m2, m1, m) = -r[m1]
+#pragma unroll
+                    for (int b = 0; b < CB; ++b) {
+                        acc[DIM + m1][b] += ri[m2] * g[b];
+                        acc[DIM + m2][b] -= ri[m1] * g[b];
+                    }
+                } else {
+                    const double w = m == 0 ? -ri[1] : ri[0];
+#pragma unroll
+                    for (int b = 0; b < CB; ++b) acc[DIM][b] += w * g[b];
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < CB; ++b) acc[m][b] += g[b];
+            }
+        }
+    }
+    const int64_t I = c_brow[c];
+    const int jc = static_cast<int>(c - c_gptr[I]);
+    const bool diag_block = c_gcol[c] == I;
+#pragma unroll
+    for (int a = 0; a < CB; ++a) {
+        const int64_t base = rbm_row_base(C, CB * I + a) + 64LL * (CB * jc);
+#pragma unroll
+        for (int b = 0; b < CB; ++b) {
+            double v = acc[a][b];
+            if (FB == DIM && diag_block && a == b && a >= DIM && v == 0.0) v = 1.0;      // rotation of a degenerate aggregate: an idle dof
+            C.vals[base + 64LL * b] = v;
+        }
+    }
+}
+
+// second bound of lambda_max(D^-1 A): Gershgorin on the symmetrically scaled matrix, max_i sum_j |a_ij| sqrt(dinv_i dinv_j).
+// Unlike the row sums of D^-1 A it does not depend on the scaling of the basis -- the rotation dofs of a coarse node carry a
+// length^2 against the translations, which makes the plain bound several times too large there (35 against 3.4 on the
+// second level of the beam) and the Chebyshev interval useless.  Both are bounds; the smaller one is taken.
+__global__ void __launch_bounds__(kBlock) k_rbm_bound_sym(SellDev A, int32_t col_limit, const double *__restrict__ dinv, double *__restrict__ rowsum,
+                                                           double *__restrict__ part_max)
+{
+    __shared__ double sm[4];
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    double s = 0.0;
+    if (r < A.n_rows) {
+        const int64_t base = rbm_row_base(A, r);
+        const int len = A.rowlen[r];
+        for (int k = 0; k < len; ++k) {
+            const int32_t c = A.cols[base + 64LL * k];
+            if (c < col_limit) s += fabs(A.vals[base + 64LL * k]) * sqrt(dinv[c]);
+        }
+        s *= sqrt(dinv[r]);
+        if (rowsum) rowsum[r] = s;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_xor(s, o, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part_max[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+}
+__global__ void k_rbm_min2(const double *__restrict__ a, double *__restrict__ lam)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) lam[0] = fmin(lam[0], a[0]);
+}
+
+// ---- cycle: restriction and prolongation with the rigid-body prolongator ----------------------------------------------
+// one coarse node: bc = sum over its member nodes of P_i^T res_i, members in ascending order
+template <int FB, int DIM>
+__device__ __forceinline__ void rbm_restrict_node(int64_t a, const int32_t *__restrict__ mem_ptr, const int32_t *__restrict__ mem_idx,
+                                                  const double *__restrict__ roff, int64_t nn, const double *__restrict__ b, const double *__restrict__ t,
+                                                  int64_t n_own_nodes, double *out)
+{
+    constexpr int NR = RbmDims<DIM>::NR, CB = RbmDims<DIM>::CB;
+#pragma unroll
+    for (int k = 0; k < CB; ++k) out[k] = 0.0;
+    const int q0 = mem_ptr[a], q1 = mem_ptr[a + 1];
+    for (int q = q0; q < q1; ++q) {
+        const int64_t i = mem_idx[q];
+        double f[FB], r[3];
+#pragma unroll
+        for (int d = 0; d < FB; ++d) {
+            const double bv = i < n_own_nodes ? b[FB * i + d] : 0.0;          // (coupled hierarchy: b counts where the rank owns the node)
+            f[d] = t ? bv - t[FB * i + d] : bv;
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) r[d] = roff[d * nn + i];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) out[d] += f[d];
+        double mom[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) mom[k] = 0.0;
+        rbm_moment<DIM>(r, f, mom);
+#pragma unroll
+        for (int k = 0; k < NR; ++k) out[DIM + k] += FB > DIM ? mom[k] + f[DIM + k] : mom[k];
+    }
+}
+template <int FB, int DIM>
+__global__ void __launch_bounds__(kBlock) k_rbm_restrict(int64_t nc_nodes, const int32_t *__restrict__ mem_ptr, const int32_t *__restrict__ mem_idx,
+                                                          const double *__restrict__ roff, int64_t nn, const double *__restrict__ b,
+                                                          const double *__restrict__ t, double *__restrict__ bc, const double *__restrict__ dinv_c,
+                                                          const double *__restrict__ lam_c, double ratio, double *__restrict__ dd_c,
+                                                          double *__restrict__ x_c, const CgCtl *ctl, int64_t n_own_nodes)
+{
+    constexpr int CB = RbmDims<DIM>::CB;
+    if (ctl && ctl->flag != 0) return;
+    const int64_t a = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (a >= nc_nodes) return;
+    double out[CB];
+    rbm_restrict_node<FB, DIM>(a, mem_ptr, mem_idx, roff, nn, b, t, n_own_nodes, out);
+    const double c_first = dd_c ? cheb_coef(lam_c[0], ratio, 0).c_first : 0.0;
+#pragma unroll
+    for (int k = 0; k < CB; ++k) {
+        bc[CB * a + k] = out[k];
+        if (dd_c) {          // step 0 of the next level's pre-smoothing (zero guess), as k_amg_restrict does it
+            const double di = c_first * dinv_c[CB * a + k] * out[k];
+            dd_c[CB * a + k] = di;
+            x_c[CB * a + k] = di;
+        }
+    }
+}
+// x_i += scale * P_i xc_I, one fine node
+template <int FB, int DIM>
+__device__ __forceinline__ void rbm_prolong_node(int64_t i, const int32_t *__restrict__ node_agg, const double *__restrict__ roff, int64_t nn,
+                                                 const double *__restrict__ xc, double scale, double *__restrict__ x)
+{
+    constexpr int NR = RbmDims<DIM>::NR, CB = RbmDims<DIM>::CB;
+    const int64_t a = node_agg[i];
+    double r[3], w[NR], u[DIM];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) r[d] = roff[d * nn + i];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) w[k] = xc[CB * a + DIM + k];
+    rbm_spin<DIM>(r, w, u);
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) x[FB * i + d] = __builtin_fma(scale, xc[CB * a + d] + u[d], x[FB * i + d]);
+    if (FB > DIM) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) x[FB * i + DIM + k] = __builtin_fma(scale, w[k], x[FB * i + DIM + k]);
+    }
+}
+template <int FB, int DIM>
+__global__ void __launch_bounds__(kBlock) k_rbm_prolong(int64_t nn_active, const int32_t *__restrict__ node_agg, const double *__restrict__ roff,
+                                                         int64_t nn, const double *__restrict__ xc, double scale, double *__restrict__ x,
+                                                         const CgCtl *ctl)
+{
+    if (ctl && ctl->flag != 0) return;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < nn_active; i += static_cast<int64_t>(gridDim.x) * kBlock)
+        rbm_prolong_node<FB, DIM>(i, node_agg, roff, nn, xc, scale, x);
+}
+
+}  // namespace pfem

@@ -45,6 +45,17 @@ struct AmgLevel {
     DevBuf<int64_t> src_ptr;              // [nnz_c+1]
     DevBuf<int32_t> src_slot;             // storage slots of this level's matrix, grouped by coarse entry
     DevBuf<int64_t> dst_slot;             // [nnz_c] storage slot in the next level's matrix
+    // rigid-body-mode coarse space (pfem_amg_rbm.hpp): the level's dofs come `bs` to the node (block regular), the next level
+    // has dim + (dim == 3 ? 3 : 1) per aggregate.  With rbm set, mem_ptr / mem_idx list the member NODES of every coarse node
+    // and src_ptr / src_slot the fine node BLOCKS of every coarse node block; agg keeps the translation part of P.
+    int dim = 0;                          // space dimension when the level may take the rigid-body transfer (0: not a candidate)
+    bool rbm = false;                     // the transfer to the next level carries rotations
+    DevBuf<double> cen;                   // [3 x n_nodes] node coordinates (level 0: mesh nodes; below: centroids of the aggregates)
+    DevBuf<double> roff;                  // [3 x n_nodes] offset of every node from the centroid of its aggregate
+    DevBuf<int32_t> node_agg;             // [n_nodes] aggregate (coarse node) of every node
+    DevBuf<int64_t> gptr;                 // [n_nodes + 1] node graph = block pattern of the level's matrix ...
+    DevBuf<int32_t> gcol, brow;           // ... column node and row node of every block
+    int64_t nblk = 0;
     // smoother and work vectors (x and dd are SpMV inputs: on level 0 they carry the guard bands of the fast SpMV forms)
     DevBuf<double> dinv, t, r, b, x_store, dd_store, lam, part_max;
     double *x = nullptr, *dd = nullptr;
@@ -90,5 +101,7 @@ struct Amg {
     DevBuf<double> rep_buf;                          // all ranks' entries of the level, rank after rank (rows | cols at set-up, values in a solve)
     DevBuf<int32_t> rep_pack_slot;                   // this rank's entries: storage slot of each, row by row
     int64_t rep_total = 0, rep_off = 0, rep_mine = 0;
+    bool rbm = false;                                // some level carries rigid-body modes: eigenvalue bounds on the symmetrically scaled operators
+    DevBuf<double> lam2;                             // ... scratch of that second bound
     int cycle_exchanges = 0, cycle_allreduces = 0;   // coupled: neighbour exchanges / all-reduces one V-cycle enqueues (counted by the last cycle)
 };

@@ -3618,6 +3618,34 @@ extern "C" int pfem_solver_amg_aggregates(pfem_solver *s, int level, int32_t *ag
     return PFEM_OK;
 }
 
+extern "C" int pfem_solver_amg_transfer(pfem_solver *s, int level, int *rbm, int *fine_bs, int *coarse_bs, int *dim, int64_t *n_nodes, double *node_xyz)
+{
+    if (!s || level < 0 || !rbm || !fine_bs || !coarse_bs || !dim || !n_nodes) return PFEM_ERR_ARG;
+    if (!s->amg || !s->amg->symbolic_ok) return PFEM_ERR_STATE;
+    const std::vector<AmgLevelRef> lev = amg_levels_of(*s->amg);
+    if (static_cast<size_t>(level) >= lev.size()) return PFEM_ERR_STATE;
+    const AmgLevel &L = *lev[static_cast<size_t>(level)].L;
+    *rbm = L.rbm ? 1 : 0;
+    *fine_bs = L.bs;
+    *coarse_bs = lev[static_cast<size_t>(level)].next ? lev[static_cast<size_t>(level)].next->bs : 0;
+    *dim = L.dim;
+    *n_nodes = L.n_nodes;
+    if (node_xyz) {
+        if (!L.cen.p) return PFEM_ERR_STATE;
+        PFEM_TRY(use_device(s));
+        PFEM_HIP(hipMemcpy(node_xyz, L.cen.p, sizeof(double) * static_cast<size_t>(3 * L.n_nodes), hipMemcpyDeviceToHost));
+        if (level == 0 && s->reordered && L.bs > 0) {          // level 0 is indexed by the caller's dofs
+            const int64_t nn = L.n_nodes;
+            std::vector<double> in(node_xyz, node_xyz + 3 * nn);
+            for (int64_t i = 0; i < nn; ++i) {
+                const int64_t j = to_internal(s, i * L.bs) / L.bs;
+                for (int d = 0; d < 3; ++d) node_xyz[d * nn + i] = in[static_cast<size_t>(d * nn + j)];
+            }
+        }
+    }
+    return PFEM_OK;
+}
+
 extern "C" int pfem_solver_amg_layout(pfem_solver *s, int max_levels, int *coupled, int *distributed_levels, int64_t *first_dof, int64_t *local_rows)
 {
     if (!s || !coupled) return PFEM_ERR_ARG;
@@ -3662,16 +3690,17 @@ extern "C" int pfem_solver_amg_comm_counts(pfem_solver *s, int *exchanges_per_cy
 
 extern "C" int pfem_solver_set_amg_options(pfem_solver *s, int cheb_degree, int fine_degree, double eig_ratio, double coarse_scale)
 {
-    if (!s || cheb_degree < 1 || cheb_degree > 6 || fine_degree < 0 || fine_degree > 6 || !(eig_ratio > 1.0) || !(coarse_scale > 0.0)) return PFEM_ERR_ARG;
+    // (eig_ratio <= 0 / coarse_scale <= 0: keep that knob automatic)
+    if (!s || cheb_degree < 1 || cheb_degree > 6 || fine_degree < 0 || fine_degree > 6 || (eig_ratio > 0.0 && !(eig_ratio > 1.0))) return PFEM_ERR_ARG;
     if (!s->amg) s->amg.reset(new (std::nothrow) Amg());
     if (!s->amg) return PFEM_ERR_NOMEM;
     s->amg->cheb_degree = cheb_degree;
     s->amg->fine_degree = fine_degree;
     s->amg->graph_key.clear();
-    s->amg->eig_ratio = eig_ratio;
-    s->amg->eig_ratio_given = true;
-    s->amg->coarse_scale = coarse_scale;
-    s->amg->coarse_scale_given = true;
+    s->amg->eig_ratio_given = eig_ratio > 0.0;
+    if (eig_ratio > 0.0) s->amg->eig_ratio = eig_ratio;
+    s->amg->coarse_scale_given = coarse_scale > 0.0;
+    if (coarse_scale > 0.0) s->amg->coarse_scale = coarse_scale;
     return PFEM_OK;
 }
 

@@ -220,10 +220,25 @@ class PetscSolver:
         L.check(L.lib().pfem_solver_get_preconditioner(self._h, C.byref(b)), "pfem_solver_get_preconditioner")
         return ("jacobi", "pbjacobi", "gamg")[b.value]
 
-    def setAmgOptions(self, cheb_degree=2, fine_degree=1, eig_ratio=8.0, coarse_scale=1.5):
+    def setAmgOptions(self, cheb_degree=2, fine_degree=1, eig_ratio=None, coarse_scale=None):
         """-pc_gamg knobs: Chebyshev degree on the coarse levels / on the assembled matrix (0: the same), lmax/lmin of the
-        smoothing interval, scaling of the coarse-grid correction."""
-        L.check(L.lib().pfem_solver_set_amg_options(self._h, cheb_degree, fine_degree, eig_ratio, coarse_scale), "pfem_solver_set_amg_options")
+        smoothing interval, scaling of the coarse-grid correction (``None``: that knob stays automatic -- 16 / 1.5 for scalar
+        problems, 8 / 1.5 with rigid-body modes, 8 / 1.8 for 3-dof nodes without them)."""
+        L.check(L.lib().pfem_solver_set_amg_options(self._h, cheb_degree, fine_degree, -1.0 if eig_ratio is None else eig_ratio,
+                                                    -1.0 if coarse_scale is None else coarse_scale), "pfem_solver_set_amg_options")
+
+    def amgTransfer(self, level, xyz=False):
+        """The transfer from ``level`` to the next: {"rbm": carries rotations?, "fine_bs", "coarse_bs", "dim", "n_nodes"} and, with
+        ``xyz``, the level's node coordinates [3, n_nodes]."""
+        rbm, fb, cb, dim = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        nn = C.c_int64(0)
+        L.check(L.lib().pfem_solver_amg_transfer(self._h, level, C.byref(rbm), C.byref(fb), C.byref(cb), C.byref(dim), C.byref(nn), None), "pfem_solver_amg_transfer")
+        out = {"rbm": bool(rbm.value), "fine_bs": fb.value, "coarse_bs": cb.value, "dim": dim.value, "n_nodes": nn.value}
+        if xyz:
+            a = np.empty((3, nn.value), np.float64)
+            L.check(L.lib().pfem_solver_amg_transfer(self._h, level, C.byref(rbm), C.byref(fb), C.byref(cb), C.byref(dim), C.byref(nn), _p(a)), "pfem_solver_amg_transfer")
+            out["xyz"] = a
+        return out
 
     def amgInfo(self):
         """The multigrid hierarchy of the last ``gamg`` solve: rows / nonzeros / eigenvalue bound per level, phase times."""

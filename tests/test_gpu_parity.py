@@ -787,6 +787,32 @@ def test_row_forms_beyond_16bit_gaps(table, monkeypatch):
 # ---------------------------------------------------------------------------------------------------------------
 # -pc_type gamg: plain-aggregation multigrid as the preconditioner of the CG (pfem_amg.inc)
 # ---------------------------------------------------------------------------------------------------------------
+def _transfers(s, info=None):
+    """What the oracle's cycle is given, level by level: the aggregates the device formed (coarse dof of every dof) or, where the
+    transfer carries rigid-body modes, the oracle's OWN prolongator built from the node aggregates and the node coordinates
+    (level 0: the mesh nodes; below: the centroids the oracle computed itself, compared with the device's)."""
+    info = info or s.amgInfo()
+    out, cen = [], None
+    for l in range(info["levels"] - 1):
+        a = s.amgAggregates(l, info["rows"][l])
+        tr = s.amgTransfer(l)
+        if not tr["rbm"]:
+            out.append(a)
+            cen = None
+            continue
+        fb, cb, dim = tr["fine_bs"], tr["coarse_bs"], tr["dim"]
+        assert cb == dim + (3 if dim == 3 else 1) and fb in (dim, cb) and info["rows"][l] == fb * tr["n_nodes"]
+        a2 = a.reshape(-1, fb)
+        assert not (a2[:, 0] % cb).any() and all(np.array_equal(a2[:, c], a2[:, 0] + c) for c in range(fb))     # translation part of P
+        dev_xyz = s.amgTransfer(l, xyz=True)["xyz"]
+        if cen is None:
+            cen = dev_xyz
+        assert np.abs(cen - dev_xyz).max() <= 1e-12 * max(1.0, np.abs(dev_xyz).max())
+        P, cen = O.rbm_prolongator(a2[:, 0] // cb, cen, dim, fb)
+        out.append(P)
+    return out
+
+
 def _gamg_vs_oracle(s, rtol=1e-10):
     """Solve with gamg on the device, then restate the SAME solve on the CPU (oracle.pcg_amg) with the aggregates the
     device formed: iteration count, residual history and solution."""
@@ -795,7 +821,7 @@ def _gamg_vs_oracle(s, rtol=1e-10):
     its, reason, rn = s.factoriseAndSolve()
     assert s.preconditioner() == "gamg"
     info = s.amgInfo()
-    aggs = [s.amgAggregates(l, info["rows"][l]) for l in range(info["levels"] - 1)]
+    aggs = _transfers(s, info)
     rowptr, cols, vals = s.getCSR()
     xo, ito, ro, rno, hist = O.pcg_amg(rowptr, cols, vals, s.getRHS(), aggs, cheb_degree=info["cheb_degree"], fine_degree=info["fine_degree"], eig_ratio=info["eig_ratio"],
                                        coarse_scale=info["coarse_scale"], rtol=rtol)
@@ -851,15 +877,18 @@ def test_gamg_solve_equals_oracle_restatement(case, tet10, beam, tria20, golden_
         assert info["levels"] == 1 and its <= its_j
         return
     assert info["levels"] >= 2 and all(10 * b <= 8 * a for a, b in zip(rows, rows[1:])) and rows[-1] <= 128
-    bs = 3 if case == "beam" else 1
-    for a, n_c in zip(aggs, rows[1:]):
+    rbm = [s.amgTransfer(l)["rbm"] for l in range(info["levels"] - 1)]
+    assert all(rbm) if case in ("beam", "cook") else not any(rbm)       # displacement problems: rigid-body modes on every level
+    for l, (a, n_c) in enumerate(zip(aggs, rows[1:])):
+        if rbm[l]:        # nodes per aggregate (every coarse node has dim translations + rotations)
+            tr = s.amgTransfer(l)
+            cnt = np.bincount(s.amgAggregates(l, rows[l]).reshape(-1, tr["fine_bs"])[:, 0] // tr["coarse_bs"])
+            assert len(cnt) * tr["coarse_bs"] == n_c and cnt.min() >= 1 and cnt.max() <= (27 if case == "beam" else 8)
+            continue
         cnt = np.bincount(a)
         # (three passes of pairing: at most 8; on the beam's lattice the node a line of odd length leaves over joins the pair next
         # to it: bricks of up to 3 along every axis)
-        assert len(cnt) == n_c and cnt.min() >= 1 and cnt.max() <= (27 if case == "beam" else 8)
-    if case == "beam":                          # the three dofs of a node share their aggregate, one coarse dof per component
-        a0 = aggs[0].reshape(-1, 3)
-        assert np.array_equal(a0[:, 1], a0[:, 0] + 1) and np.array_equal(a0[:, 2], a0[:, 0] + 2) and not (a0[:, 0] % 3).any()
+        assert len(cnt) == n_c and cnt.min() >= 1 and cnt.max() <= 8
     lat = s.amgLayout()["lattice_levels"]       # generated boxes and the reference's tet10 file sit on a lattice, Cook's membrane does not
     assert (lat >= 1) if case in ("tet10", "cube30", "beam", "tria20", "aniso") else (lat == 0 or case == "compat")
     if case == "aniso":       # the weak axes are passed over: the passes of the first level pair along z (19 -> 10 -> 5 -> 3 per column,
