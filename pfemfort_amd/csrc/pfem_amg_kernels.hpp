@@ -910,6 +910,7 @@ namespace pfem {
 // the tail took 294 us per cycle, MORE than the 40 launches it replaced (profiles/r03/rocprofv3_kernel_stats_gamg_tail4096.txt).
 // ---------------------------------------------------------------------------
 constexpr int kAmgTailRows = 1024;
+constexpr int64_t kAmgTailNnz = 32768;
 constexpr int kAmgTailLevels = 8;
 struct AmgTailLevel {
     SellDev A;

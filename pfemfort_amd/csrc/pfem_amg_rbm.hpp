@@ -241,6 +241,9 @@ __global__ void __launch_bounds__(kBlock) k_rbm_fill_cols(int64_t n_rows, int64_
 // ---- numeric phase: Galerkin product with the rigid-body prolongator, one thread per coarse node block ------------------
 // C(I,J) = sum over the fine blocks (i,j), i in I, j in J, of  P_i^T F_ij P_j.  A fine block is read row by row:
 // row m of G = F P_j is formed from row m of F, then added to the rows of C that row m of P_i^T feeds.
+constexpr int kRbmLanes = 8;          // lanes that share one coarse block (its fine blocks dealt out round-robin, sums combined by a fixed
+                                      // butterfly): a diagonal block sums 64 fine blocks, a corner block one -- with one lane per coarse
+                                      // block a wave waited for its longest list (k_rbm_galerkin<3,3> 1.29 ms at config 4)
 template <int FB, int DIM>
 __global__ void __launch_bounds__(kBlock) k_rbm_galerkin(int64_t nblk_c, const int64_t *__restrict__ src_ptr, const int32_t *__restrict__ src_blk,
                                                           SellDev F, const int64_t *__restrict__ f_gptr, const int32_t *__restrict__ f_gcol,
@@ -249,14 +252,17 @@ __global__ void __launch_bounds__(kBlock) k_rbm_galerkin(int64_t nblk_c, const i
                                                           const int32_t *__restrict__ c_gcol)
 {
     constexpr int NR = RbmDims<DIM>::NR, CB = RbmDims<DIM>::CB;
-    const int64_t c = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (c >= nblk_c) return;
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t c = t / kRbmLanes;
+    const int g = static_cast<int>(t % kRbmLanes);
+    const bool live = c < nblk_c;
     double acc[CB][CB];
 #pragma unroll
     for (int a = 0; a < CB; ++a)
 #pragma unroll
         for (int b = 0; b < CB; ++b) acc[a][b] = 0.0;
-    for (int64_t p = src_ptr[c]; p < src_ptr[c + 1]; ++p) {
+    const int64_t p1 = live ? src_ptr[c + 1] : 0;
+    for (int64_t p = live ? src_ptr[c] + g : 0; p < p1; p += kRbmLanes) {
         const int64_t q = src_blk[p];
         const int64_t i = f_brow[q];
         const int64_t j = f_gcol[q];
@@ -264,53 +270,67 @@ __global__ void __launch_bounds__(kBlock) k_rbm_galerkin(int64_t nblk_c, const i
         double ri[3], rj[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) { ri[d] = roff[d * nn + i]; rj[d] = roff[d * nn + j]; }
+        double f[FB][FB];
 #pragma unroll
         for (int m = 0; m < FB; ++m) {
             const int64_t base = rbm_row_base(F, FB * i + m) + 64LL * (FB * jj);
-            double f[FB], g[CB];
 #pragma unroll
-            for (int d = 0; d < FB; ++d) f[d] = F.vals[base + 64LL * d];
-            // g = f P_j :  translations as they are, rotations  (f S(r_j))_k = f . (e_k x r_j)  [+ the fine rotations]
+            for (int d = 0; d < FB; ++d) f[m][d] = F.vals[base + 64LL * d];
+        }
 #pragma unroll
-            for (int d = 0; d < DIM; ++d) g[d] = f[d];
+        for (int m = 0; m < FB; ++m) {
+            double gr[CB];
+            // gr = (row m of F) P_j :  translations as they are, rotations  f . (e_k x r_j) = (r_j x f)_k  [+ the fine rotations]
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) gr[d] = f[m][d];
             {
                 double mom[NR];
 #pragma unroll
                 for (int k = 0; k < NR; ++k) mom[k] = 0.0;
-                rbm_moment<DIM>(rj, f, mom);
+                rbm_moment<DIM>(rj, f[m], mom);
 #pragma unroll
-                for (int k = 0; k < NR; ++k) g[DIM + k] = FB > DIM ? mom[k] + f[DIM + k] : mom[k];
+                for (int k = 0; k < NR; ++k) gr[DIM + k] = FB > DIM ? mom[k] + f[m][DIM + k] : mom[k];
             }
-            // acc += (row m of P_i)^T g
+            // acc += (row m of P_i)^T gr
             if (m < DIM) {
 #pragma unroll
-                for (int b = 0; b < CB; ++b) acc[m][b] += g[b];
-                // rotations: P_i[m, DIM + k] = (e_k x r_i)_m
+                for (int b = 0; b < CB; ++b) acc[m][b] += gr[b];
                 if (DIM == 3) {
+                    // P_i[m, DIM + k] = (e_k x r_i)_m:  k = m+1 -> +r[m+2],  k = m+2 -> -r[m+1]  (indices mod 3)
                     const int m1 = (m + 1) % 3, m2 = (m + 2) % 3;
-                    // (e_k x r)_m: k = m1 -> e_m1 x r has component m equal to  r[m2] * eps(m1, m2, m) = +r[m2]  (cyclic m1,m2,m)
-                    //              k = m2 -> e_m2 x r has component m equal to  r[m1] * eps(m2, m1, m) = -r[m1]
 #pragma unroll
                     for (int b = 0; b < CB; ++b) {
-                        acc[DIM + m1][b] += ri[m2] * g[b];
-                        acc[DIM + m2][b] -= ri[m1] * g[b];
+                        acc[DIM + m1][b] += ri[m2] * gr[b];
+                        acc[DIM + m2][b] -= ri[m1] * gr[b];
                     }
                 } else {
                     const double w = m == 0 ? -ri[1] : ri[0];
 #pragma unroll
-                    for (int b = 0; b < CB; ++b) acc[DIM][b] += w * g[b];
+                    for (int b = 0; b < CB; ++b) acc[DIM][b] += w * gr[b];
                 }
             } else {
 #pragma unroll
-                for (int b = 0; b < CB; ++b) acc[m][b] += g[b];
+                for (int b = 0; b < CB; ++b) acc[m][b] += gr[b];
             }
         }
     }
+    // the lanes of a coarse block combine their sums (fixed butterfly: the same bits in every run)
+#pragma unroll
+    for (int a = 0; a < CB; ++a)
+#pragma unroll
+        for (int b = 0; b < CB; ++b) {
+            double v = acc[a][b];
+#pragma unroll
+            for (int o = kRbmLanes / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            acc[a][b] = v;
+        }
+    if (!live) return;
     const int64_t I = c_brow[c];
     const int jc = static_cast<int>(c - c_gptr[I]);
     const bool diag_block = c_gcol[c] == I;
 #pragma unroll
     for (int a = 0; a < CB; ++a) {
+        if (a % kRbmLanes != g) continue;                   // lane g writes row g of the block
         const int64_t base = rbm_row_base(C, CB * I + a) + 64LL * (CB * jc);
 #pragma unroll
         for (int b = 0; b < CB; ++b) {
@@ -318,6 +338,67 @@ __global__ void __launch_bounds__(kBlock) k_rbm_galerkin(int64_t nblk_c, const i
             if (FB == DIM && diag_block && a == b && a >= DIM && v == 0.0) v = 1.0;      // rotation of a degenerate aggregate: an idle dof
             C.vals[base + 64LL * b] = v;
         }
+    }
+}
+
+// ---- cycle: the coarse-level SpMV + vector step (k_amg_spmv_ep) on a block-regular level.  The column of entry CB*kk + d of
+// a row is CB * (kk-th neighbour of its node) + d: one node index per CB x CB values instead of one column per value
+// (8.1 instead of 12 bytes per nonzero), and the CB values of x it multiplies are contiguous.  Same products in the same
+// order as k_amg_spmv_ep / k_spmv: same bits.
+template <int MODE, int CB>
+__global__ void __launch_bounds__(kBlock) k_rbm_spmv_ep(SellDev A, const int64_t *__restrict__ gptr, const int32_t *__restrict__ gcol,
+                                                         const double *__restrict__ xin, const double *r_in, const double *__restrict__ dinv,
+                                                         const double *__restrict__ lam, double ratio, int step, int add_dd0, double *r_out,
+                                                         double *dd_out, double *x, const CgCtl *ctl)
+{
+    if (ctl && ctl->flag != 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t s = (static_cast<int64_t>(blockIdx.x) << 2) + wave;
+    if (s >= A.n_slices) return;
+    const int64_t off = A.slice_off[s];
+    const int nb = static_cast<int>((A.slice_off[s + 1] - off) >> 6) / CB;          // node blocks in the longest row of the slice
+    const int64_t i = (s << 6) + lane;
+    const bool live = i < A.n_rows;
+    const int64_t node = live ? i / CB : 0;
+    const int64_t q0 = live ? gptr[node] : 0;
+    const int deg = live ? static_cast<int>(gptr[node + 1] - q0) : 0;
+    const double *__restrict__ vp = A.vals + off + lane;
+    const int32_t own = static_cast<int32_t>(node * CB);
+    double acc = 0.0;
+    int kk = 0;
+    for (; kk + 2 <= nb; kk += 2) {
+        const int32_t c0 = kk < deg ? CB * gcol[q0 + kk] : own;           // (beyond the row's end the values are the padding zeros)
+        const int32_t c1 = kk + 1 < deg ? CB * gcol[q0 + kk + 1] : own;
+        double v[2 * CB], xv[2 * CB];
+#pragma unroll
+        for (int d = 0; d < 2 * CB; ++d) v[d] = vp[64 * (CB * kk + d)];
+#pragma unroll
+        for (int d = 0; d < CB; ++d) { xv[d] = xin[c0 + d]; xv[CB + d] = xin[c1 + d]; }
+#pragma unroll
+        for (int d = 0; d < 2 * CB; ++d) acc = __builtin_fma(v[d], xv[d], acc);
+    }
+    for (; kk < nb; ++kk) {
+        const int32_t c0 = kk < deg ? CB * gcol[q0 + kk] : own;
+#pragma unroll
+        for (int d = 0; d < CB; ++d) acc = __builtin_fma(vp[64 * (CB * kk + d)], xin[c0 + d], acc);
+    }
+    if (!live) return;
+    if (MODE == kEpResid) {
+        r_out[i] = r_in[i] - acc;
+    } else if (MODE == kEpFirstRes) {
+        const double ri = r_in[i] - acc;
+        r_out[i] = ri;
+        dd_out[i] = cheb_coef(lam[0], ratio, 0).c_first * dinv[i] * ri;
+    } else if (MODE == kEpNextLast) {
+        const ChebCoef c = cheb_coef(lam[0], ratio, step);
+        const double ri = r_in[i] - acc;
+        const double d0 = xin[i];
+        const double di = __builtin_fma(c.c_dd, d0, c.c_r * dinv[i] * ri);
+        double xv = x[i];
+        if (add_dd0) xv += d0;
+        x[i] = xv + di;
+    } else {                  // plain product
+        r_out[i] = acc;
     }
 }
 
