@@ -191,6 +191,91 @@ __global__ void __launch_bounds__(kBlock) k_rbm_offsets(int64_t nn, const int32_
     for (int d = 0; d < 3; ++d) roff[d * nn + i] = ok ? xyz[d * nn + i] - cen[d * nn_c + a] : 0.0;
 }
 
+// ---- the same on several ranks (one hierarchy across the ranks): a rank forms aggregates inside its owned nodes; the ghost
+// nodes learn theirs through the level's sum-exchanges (the dof-level aggregate numbers as ever, then the centroid and the
+// rotation verdict of the aggregate: the owner sends them on the node's displacement dofs, the ghosts send zeros)
+__global__ void __launch_bounds__(kBlock) k_rbm_node_agg_from_dofs(int64_t nn, int bs, int cb, const int32_t *__restrict__ agg, int32_t *__restrict__ node_agg)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < nn) node_agg[i] = agg[bs * i] / cb;
+}
+// v[bs*i + d] = centroid coordinate d of the aggregate of owned node i (d < dim), w[bs*i] = its rotation verdict; 0 elsewhere
+__global__ void __launch_bounds__(kBlock) k_rbm_centroid_vectors(int64_t nn, int64_t nn_own, int bs, int dim, const int32_t *__restrict__ node_agg,
+                                                                  int64_t nn_c, const double *__restrict__ cen, const int32_t *__restrict__ rot_ok,
+                                                                  double *__restrict__ v, double *__restrict__ w)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= nn) return;
+    const bool own = i < nn_own;
+    const int32_t a = own ? node_agg[i] : 0;
+    for (int d = 0; d < bs; ++d) {
+        v[bs * i + d] = (own && d < dim) ? cen[d * nn_c + a] : 0.0;
+        w[bs * i + d] = (own && d == 0) ? static_cast<double>(rot_ok[a]) : 0.0;
+    }
+}
+// offsets of all local nodes; a ghost node takes the centroid it received and hands it on to its (ghost) aggregate
+__global__ void __launch_bounds__(kBlock) k_rbm_offsets_coupled(int64_t nn, int64_t nn_own, int bs, int dim, const int32_t *__restrict__ node_agg,
+                                                                 const double *__restrict__ xyz, int64_t nn_c, double *__restrict__ cen,
+                                                                 const int32_t *__restrict__ rot_ok, const double *__restrict__ v,
+                                                                 const double *__restrict__ w, double undo, double *__restrict__ roff)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= nn) return;
+    const int32_t a = node_agg[i];
+    if (i < nn_own) {
+        const bool ok = rot_ok[a] != 0;
+        for (int d = 0; d < 3; ++d) roff[d * nn + i] = ok ? xyz[d * nn + i] - cen[d * nn_c + a] : 0.0;
+        return;
+    }
+    const bool ok = undo * w[bs * i] > 0.5;
+    for (int d = 0; d < 3; ++d) {
+        const double c = d < dim ? undo * v[bs * i + d] : 0.0;
+        cen[d * nn_c + a] = c;                        // (every ghost member of the aggregate writes the same value)
+        roff[d * nn + i] = ok ? xyz[d * nn + i] - c : 0.0;
+    }
+}
+// strength graph of the pairing on several ranks: the owned nodes' rows of the node graph without their ghost columns
+__global__ void __launch_bounds__(kBlock) k_rbm_owned_degree(int64_t nn_own, const int64_t *__restrict__ gptr, const int32_t *__restrict__ gcol,
+                                                              int64_t *__restrict__ deg)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i > nn_own) return;
+    int64_t n = 0;
+    if (i < nn_own)
+        for (int64_t q = gptr[i]; q < gptr[i + 1]; ++q) n += gcol[q] < nn_own;
+    deg[i] = n;
+}
+__global__ void __launch_bounds__(kBlock) k_rbm_owned_graph(int64_t nn_own, const int64_t *__restrict__ gptr, const int32_t *__restrict__ gcol,
+                                                             const double *__restrict__ gw, const int64_t *__restrict__ optr,
+                                                             int32_t *__restrict__ ocol, double *__restrict__ ow)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= nn_own) return;
+    int64_t o = optr[i];
+    for (int64_t q = gptr[i]; q < gptr[i + 1]; ++q)
+        if (gcol[q] < nn_own) { ocol[o] = gcol[q]; ow[o] = gw[q]; ++o; }
+}
+// owned coarse nodes' centroids by global node number into the array every rank gets through an all-reduce (zeroed before)
+__global__ void __launch_bounds__(kBlock) k_rbm_emit_global_cen(int64_t na_own, int64_t node_off, int64_t nn_c, const double *__restrict__ cen,
+                                                                 int64_t n_glob, double *__restrict__ out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= na_own) return;
+    for (int d = 0; d < 3; ++d) out[d * n_glob + node_off + i] = cen[d * nn_c + i];
+}
+// |.| row sums of the symmetrically scaled operator from the ranks' shares (summed over the holders afterwards), block maximum
+__global__ void __launch_bounds__(kBlock) k_rbm_block_max(int64_t n, const double *__restrict__ v, double *__restrict__ part_max)
+{
+    __shared__ double sm[4];
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    double s = r < n ? v[r] : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_xor(s, o, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part_max[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+}
+
 // coarse node block of every fine node block: key (agg(i) << 32 | agg(j)), payload the block's index (sorted afterwards;
 // the radix sort is stable, so the blocks of one coarse block stay in ascending order: one fixed sum)
 __global__ void __launch_bounds__(kBlock) k_rbm_emit_block_keys(int64_t nblk, const int32_t *__restrict__ brow, const int32_t *__restrict__ gcol,
@@ -249,7 +334,7 @@ __global__ void __launch_bounds__(kBlock) k_rbm_galerkin(int64_t nblk_c, const i
                                                           SellDev F, const int64_t *__restrict__ f_gptr, const int32_t *__restrict__ f_gcol,
                                                           const int32_t *__restrict__ f_brow, const double *__restrict__ roff, int64_t nn,
                                                           SellDev C, const int64_t *__restrict__ c_gptr, const int32_t *__restrict__ c_brow,
-                                                          const int32_t *__restrict__ c_gcol)
+                                                          const int32_t *__restrict__ c_gcol, int64_t c_own_nodes)
 {
     constexpr int NR = RbmDims<DIM>::NR, CB = RbmDims<DIM>::CB;
     const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -335,7 +420,8 @@ __global__ void __launch_bounds__(kBlock) k_rbm_galerkin(int64_t nblk_c, const i
 #pragma unroll
         for (int b = 0; b < CB; ++b) {
             double v = acc[a][b];
-            if (FB == DIM && diag_block && a == b && a >= DIM && v == 0.0) v = 1.0;      // rotation of a degenerate aggregate: an idle dof
+            // rotation of a degenerate aggregate: an idle dof with a unit diagonal (several ranks: the owner's share carries it)
+            if (FB == DIM && diag_block && a == b && a >= DIM && v == 0.0 && I < c_own_nodes) v = 1.0;
             C.vals[base + 64LL * b] = v;
         }
     }

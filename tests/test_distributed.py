@@ -333,7 +333,10 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
             brp = np.concatenate([[0], np.cumsum([keep[rp[i]:rp[i + 1]].sum() for i in range(no)])]).astype(np.int64)
             extra.update(blk_rowptr=brp, blk_cols=cc[:rp[no]][keep[:rp[no]]], blk_vals=vv[:rp[no]][keep[:rp[no]]], amg_levels=ai["levels"],
                          amg_rows=np.array(ai["rows"]), amg_opts=np.array([ai["cheb_degree"], ai["eig_ratio"], ai["coarse_scale"], ai["fine_degree"]]),
-                         **{f"agg{l}": s.amgAggregates(l, ai["rows"][l]) for l in range(ai["levels"] - 1)})
+                         **{f"agg{l}": s.amgAggregates(l, ai["rows"][l]) for l in range(ai["levels"] - 1)},
+                         # rigid-body modes: [rbm, dofs per node, dofs per coarse node, dimension] of every transfer
+                         amg_transfer=np.array([[int(t["rbm"]), t["fine_bs"], t["coarse_bs"], t["dim"]]
+                                                for t in (s.amgTransfer(l) for l in range(ai["levels"] - 1))]).reshape(-1, 4))
         info = s.commInfo()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=x1, rs=rs, re=re, its=its, reason=reason,
                  pc=s.preconditioner(), calls=hooks.calls, log=np.array([f"{k}{c}" for k, c in hooks.log]),
@@ -462,6 +465,25 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
                 else:                    # the replicated part of the hierarchy is the same on every rank
                     a = d0[f"agg{l}"].astype(np.int64)
                     assert all(np.array_equal(d[f"agg{l}"], a) for d in ds)
+                tr = d0["amg_transfer"][l]
+                assert all(np.array_equal(d["amg_transfer"], d0["amg_transfer"]) for d in ds)
+                if tr[0]:
+                    # rigid-body modes: the oracle's OWN prolongator from the global node aggregates (the device reports the
+                    # translation part of P) and the node coordinates -- the mesh's free nodes in the partition's numbering on
+                    # level 0, below it the centroids the oracle computed itself
+                    fb, cb, dim = int(tr[1]), int(tr[2]), int(tr[3])
+                    a2 = a.reshape(-1, fb)
+                    assert not (a2[:, 0] % cb).any() and all(np.array_equal(a2[:, c], a2[:, 0] + c) for c in range(fb))
+                    if l == 0:
+                        nda = prob.dm.NodeDofArrayNew.reshape(-1, fb)
+                        free = np.where(nda[:, 0] >= 0)[0]
+                        assert np.array_equal(nda[free, 0], fb * np.arange(len(free)))
+                        cen = np.zeros((3, len(free)))
+                        cen[:prob.xyz_new.shape[0]] = prob.xyz_new[:, free]
+                    P, cen = O.rbm_prolongator(a2[:, 0] // cb, cen, dim, fb)
+                    assert P.shape[1] == rows_glob[l + 1]
+                    aggs.append(P)
+                    continue
                 assert a.min() >= 0 and a.max() == rows_glob[l + 1] - 1 and len(np.unique(a)) == rows_glob[l + 1]
                 aggs.append(a)
             # the last level takes the dense inverse, or the coarsening stalled just above its limit (Chebyshev bottom)
