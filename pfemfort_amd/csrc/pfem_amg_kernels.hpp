@@ -163,6 +163,122 @@ __global__ void __launch_bounds__(kBlock) k_amg_lat_coarsen(int64_t n, const int
     const int32_t field = 0x3ff << shift, p = pos[i];
     pos_c[agg[i]] = (p & ~field) | ((((p >> shift) & 0x3ff) >> 1) << shift);
 }
+// ---- bricks in one step (scalar problems on a lattice whose couplings along the axes are all strong) ---------------------
+// The three passes above end in exact bricks when every sibling pair is accepted: brick = position >> shift per axis.  This
+// path forms them directly from the positions -- no aggregate graphs, no sort of them -- after ONE check on the level's own
+// matrix that the passes would indeed accept every pair: the coupling to the sibling along each halved axis, where the
+// sibling exists, is at least a quarter of the node's strongest (else the pass-by-pass pairing takes the level as before:
+// anisotropic operators keep their semi-coarsening).  Couplings must stay inside neighbouring bricks (|offset| <= 1).
+struct LatBricks {
+    int shift[3];          // halvings of every axis on this level (the passes' axis sequence, simulated on the host)
+    int nb[3];             // bricks along every axis
+};
+__device__ __forceinline__ int lat_brick_linear(const LatBricks &B, int32_t pos)
+{
+    const int bx = (pos & 0x3ff) >> B.shift[0], by = ((pos >> 10) & 0x3ff) >> B.shift[1], bz = ((pos >> 20) & 0x3ff) >> B.shift[2];
+    return bx + B.nb[0] * (by + B.nb[1] * bz);
+}
+// one thread per row: sibling couplings strong enough?  every coupling within reach of the 27 neighbouring bricks?  marks the row's brick
+__global__ void __launch_bounds__(kBlock) k_lat_check(SellDev A, const int32_t *__restrict__ pos, const double *__restrict__ diag, LatBricks B,
+                                                       int32_t *__restrict__ brick_flag, int *__restrict__ fail)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= A.n_rows) return;
+    const int64_t base = A.slice_off[i >> 6] + (i & 63);
+    const int len = A.rowlen[i];
+    const int32_t pi = pos[i];
+    const double di = diag[i];
+    const int bix = (pi & 0x3ff) >> B.shift[0], biy = ((pi >> 10) & 0x3ff) >> B.shift[1], biz = ((pi >> 20) & 0x3ff) >> B.shift[2];
+    double smax = 0.0, ssib[3] = {-1.0, -1.0, -1.0};
+    bool far = false;
+    for (int k = 0; k < len; ++k) {
+        const int32_t j = A.cols[base + 64LL * k];
+        if (j == static_cast<int32_t>(i)) continue;
+        const int32_t pj = pos[j];
+        const double sij = amg_strength(A.vals[base + 64LL * k], di, diag[j]);
+        smax = fmax(smax, sij);
+        const int x = pi ^ pj;
+        if (x == 1) ssib[0] = sij;
+        else if (x == (1 << 10)) ssib[1] = sij;
+        else if (x == (1 << 20)) ssib[2] = sij;
+        const int dx = ((pj & 0x3ff) >> B.shift[0]) - bix, dy = (((pj >> 10) & 0x3ff) >> B.shift[1]) - biy, dz = (((pj >> 20) & 0x3ff) >> B.shift[2]) - biz;
+        far = far || dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1;
+    }
+    bool weak = false;
+    for (int a = 0; a < 3; ++a)
+        if (B.shift[a] > 0 && ssib[a] >= 0.0 && !(ssib[a] > 0.0 && ssib[a] >= 0.25 * smax)) weak = true;
+    if (weak || far) *fail = 1;
+    brick_flag[lat_brick_linear(B, pi)] = 1;
+}
+// aggregate of every node = rank of its brick among the occupied ones (ascending in z, y, x: coarse columns come out ascending
+// by offset code); an aggregate's position on the coarser lattice = its brick's coordinates
+__global__ void __launch_bounds__(kBlock) k_lat_assign(int64_t n, const int32_t *__restrict__ pos, LatBricks B, const int32_t *__restrict__ brick_rank,
+                                                        int32_t *__restrict__ agg, int32_t *__restrict__ pos_c)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int32_t p = pos[i];
+    const int bx = (p & 0x3ff) >> B.shift[0], by = ((p >> 10) & 0x3ff) >> B.shift[1], bz = ((p >> 20) & 0x3ff) >> B.shift[2];
+    const int32_t a = brick_rank[bx + B.nb[0] * (by + B.nb[1] * bz)];
+    agg[i] = a;
+    pos_c[a] = bx | (by << 10) | (bz << 20);                // (every member writes the same value)
+}
+// Galerkin maps without 64-bit keys: coarse entry of a stored fine entry = 27 * agg(row) + offset code of the column's brick
+// (25 bits at config 3: four radix passes instead of eight); padding slots get the sentinel n_keys
+__global__ void __launch_bounds__(kBlock) k_lat_emit_keys(SellDev A, const int32_t *__restrict__ pos, const int32_t *__restrict__ agg, LatBricks B,
+                                                           uint32_t sentinel, uint32_t *__restrict__ keys, int32_t *__restrict__ slots)
+{
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (t >= A.n_slices * 64) return;
+    const int64_t sl = t >> 6;
+    const int64_t off = A.slice_off[sl];
+    const int width = static_cast<int>((A.slice_off[sl + 1] - off) >> 6);
+    const bool live = t < A.n_rows;
+    const int len = live ? A.rowlen[t] : 0;
+    const int32_t pi = live ? pos[t] : 0;
+    const uint32_t a27 = live ? 27u * static_cast<uint32_t>(agg[t]) : 0u;
+    const int bix = (pi & 0x3ff) >> B.shift[0], biy = ((pi >> 10) & 0x3ff) >> B.shift[1], biz = ((pi >> 20) & 0x3ff) >> B.shift[2];
+    for (int k = 0; k < width; ++k) {
+        const int64_t q = off + 64LL * k + (t & 63);
+        uint32_t key = sentinel;
+        if (k < len) {
+            const int32_t pj = pos[A.cols[q]];
+            const int dx = ((pj & 0x3ff) >> B.shift[0]) - bix, dy = (((pj >> 10) & 0x3ff) >> B.shift[1]) - biy, dz = (((pj >> 20) & 0x3ff) >> B.shift[2]) - biz;
+            key = a27 + static_cast<uint32_t>((dx + 1) + 3 * (dy + 1) + 9 * (dz + 1));
+        }
+        keys[q] = key;
+        slots[q] = static_cast<int32_t>(q);
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_lat_run_heads(int64_t n, const uint32_t *__restrict__ skeys, int32_t *__restrict__ head)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n) head[i] = (i == 0 || skeys[i] != skeys[i - 1]) ? 1 : 0;
+    if (i == n) head[n] = 0;
+}
+// run starts + the coarse entry's (row << 32 | col) key: col = the aggregate of the brick at the coded offset from the row's
+__global__ void __launch_bounds__(kBlock) k_lat_run_scatter(int64_t n, const uint32_t *__restrict__ skeys, const int32_t *__restrict__ head,
+                                                             const int32_t *__restrict__ rank, uint32_t sentinel, const int32_t *__restrict__ pos_c,
+                                                             LatBricks B, const int32_t *__restrict__ brick_rank, uint64_t *__restrict__ ukeys,
+                                                             int64_t *__restrict__ start)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n && head[i]) {
+        const uint32_t key = skeys[i];
+        start[rank[i]] = i;
+        if (key == sentinel) {
+            ukeys[rank[i]] = ~0ull;
+        } else {
+            const uint32_t I = key / 27u, code = key % 27u;
+            const int32_t pc = pos_c[I];
+            const int bx = (pc & 0x3ff) + static_cast<int>(code % 3u) - 1, by = ((pc >> 10) & 0x3ff) + static_cast<int>((code / 3u) % 3u) - 1,
+                      bz = ((pc >> 20) & 0x3ff) + static_cast<int>(code / 9u) - 1;
+            const int32_t J = brick_rank[bx + B.nb[0] * (by + B.nb[1] * bz)];
+            ukeys[rank[i]] = (static_cast<uint64_t>(I) << 32) | static_cast<uint32_t>(J);
+        }
+    }
+    if (i == n) start[rank[n]] = n;
+}
 // distinct values of one coordinate: every node drops its value into a small open-addressing table (a lattice has a few
 // hundred distinct values per axis, so almost every probe finds its value already there); *overflow when the table fills
 constexpr int kLatticeTable = 4096;
@@ -258,6 +374,27 @@ __global__ void __launch_bounds__(kBlock) k_amg_lattice_pos(MeshDev m, int64_t n
     for (int d = 0; d < m.ndof; ++d) {
         const int32_t l = m.edof[(a * m.ndof + d) * m.nElem + e];
         if (l >= 0 && l < n_owned) pos[l] = p;              // every visit of a dof writes the same value
+    }
+}
+
+// lattice position of every owned dof from the node -> row table of the assembly (one thread per mesh node)
+__global__ void __launch_bounds__(kBlock) k_amg_lattice_pos_nodes(int64_t nNode, int ndim, int ndof, const double *__restrict__ xyz,
+                                                                   const int32_t *__restrict__ node_row, int64_t n_owned, const double *__restrict__ ux,
+                                                                   int nx, const double *__restrict__ uy, int ny, const double *__restrict__ uz, int nz,
+                                                                   int32_t *__restrict__ pos)
+{
+    const int64_t nd = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (nd >= nNode) return;
+    int32_t p = -1;
+    for (int d = 0; d < ndof; ++d) {
+        const int32_t l = node_row[nd * ndof + d];
+        if (l < 0 || l >= n_owned) continue;
+        if (p < 0) {
+            const int ix = amg_lattice_index(ux, nx, xyz[nd]), iy = amg_lattice_index(uy, ny, xyz[nNode + nd]);
+            const int iz = ndim > 2 ? amg_lattice_index(uz, nz, xyz[2 * nNode + nd]) : 0;
+            p = ix | (iy << 10) | (iz << 20);
+        }
+        pos[l] = p;
     }
 }
 
