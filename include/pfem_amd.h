@@ -346,7 +346,7 @@ int pfem_solver_amg_aggregates(pfem_solver *s, int level, int32_t *agg);
 int pfem_solver_amg_transfer(pfem_solver *s, int level, int *rbm, int *fine_bs, int *coarse_bs, int *dim, int64_t *n_nodes, double *node_xyz);
 /* several ranks: is the hierarchy of the last solve one across the ranks (1) or one per rank (0); how many of its levels
  * are distributed over the ranks (the levels after them -- at most PFEM_AMG_REPLICATE_ROWS rows over all ranks, default
- * 32768 -- are assembled on every rank, which carries the rest of the cycle alone); per level (arrays of max_levels) the
+ * 150000 -- are assembled on every rank, which carries the rest of the cycle alone); per level (arrays of max_levels) the
  * global number of this rank's first dof and its local rows (owned + ghosts; replicated levels: 0 and all rows).  With a
  * coupled hierarchy pfem_solver_amg_aggregates hands out GLOBAL coarse numbers and pfem_solver_amg_info's rows are the
  * owned ones on the distributed levels, all rows on the replicated ones.                                                */

@@ -881,17 +881,55 @@ __device__ __forceinline__ ChebCoef cheb_coef(double lmax, double ratio, int ste
     return c;
 }
 
+// One hierarchy across the ranks: a product t = A x is the sum of the holders' shares.  The kernel that USES t takes the
+// sum on the fly for the shared dofs (what k_unpack_sum would have written into t first: own share and received shares
+// added in ascending rank order, same bits) -- one launch less per exchange.  row_sh[i] = index of dof i among the shared
+// dofs of the level's plan or -1; sh_ptr / sh_src as in k_unpack_sum.
+struct ShareSum {
+    const int32_t *row_sh, *sh_ptr, *sh_src;
+    const double *recv;
+};
+__device__ __forceinline__ double share_sum(const ShareSum &S, int64_t i, double own)
+{
+    if (!S.row_sh) return own;
+    const int32_t j = S.row_sh[i];
+    if (j < 0) return own;
+    double acc = 0.0;
+    for (int32_t k = S.sh_ptr[j]; k < S.sh_ptr[j + 1]; ++k) {
+        const int32_t q = S.sh_src[k];
+        acc += q < 0 ? own : S.recv[q];
+    }
+    return acc;
+}
+// the other end: a shared dof's value goes to every position of the send buffer that names it (the receive positions of
+// sh_src ARE the send positions: both buffers have one segment per neighbour with the same lists)
+__device__ __forceinline__ void share_pack(const ShareSum &S, double *__restrict__ send, int64_t i, double v)
+{
+    if (!S.row_sh) return;
+    const int32_t j = S.row_sh[i];
+    if (j < 0) return;
+    for (int32_t k = S.sh_ptr[j]; k < S.sh_ptr[j + 1]; ++k) {
+        const int32_t q = S.sh_src[k];
+        if (q >= 0) send[q] = v;
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_amg_fill_row_sh(int64_t n_sh, const int32_t *__restrict__ sh_lidx, int32_t *__restrict__ row_sh)
+{
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (j < n_sh) row_sh[sh_lidx[j]] = static_cast<int32_t>(j);
+}
+
 // step 0.  zero_guess: r = b, x = dd = D^-1 b / theta.  Else t = A x on entry: r = b - t (stored when more steps follow),
 // dd = D^-1 r / theta, x += dd.
 __global__ void __launch_bounds__(kBlock) k_amg_cheb_first(int64_t n, const double *__restrict__ b, const double *__restrict__ t,
                                                             const double *__restrict__ dinv, const double *__restrict__ lam, double ratio,
                                                             double *__restrict__ r_out, double *__restrict__ dd, double *__restrict__ x,
-                                                            const CgCtl *ctl)
+                                                            const CgCtl *ctl, ShareSum S = ShareSum{nullptr, nullptr, nullptr, nullptr})
 {
     if (ctl && ctl->flag != 0) return;
     const ChebCoef c = cheb_coef(lam[0], ratio, 0);
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
-        const double ri = t ? b[i] - t[i] : b[i];
+        const double ri = t ? b[i] - share_sum(S, i, t[i]) : b[i];
         const double di = c.c_first * dinv[i] * ri;
         if (r_out) r_out[i] = ri;
         if (dd) dd[i] = di;                  // null when no step follows (degree 1): nobody reads it
@@ -903,12 +941,12 @@ __global__ void __launch_bounds__(kBlock) k_amg_cheb_first(int64_t n, const doub
 __global__ void __launch_bounds__(kBlock) k_amg_cheb_next(int64_t n, int step, const double *r_in, const double *__restrict__ t,
                                                            const double *__restrict__ dinv, const double *__restrict__ lam, double ratio,
                                                            double *r_out, const double *dd_in, double *dd_out,      // in / out may be one array
-                                                           double *__restrict__ x, const CgCtl *ctl)
+                                                           double *__restrict__ x, const CgCtl *ctl, ShareSum S = ShareSum{nullptr, nullptr, nullptr, nullptr})
 {
     if (ctl && ctl->flag != 0) return;
     const ChebCoef c = cheb_coef(lam[0], ratio, step);
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
-        const double ri = r_in[i] - t[i];
+        const double ri = r_in[i] - share_sum(S, i, t[i]);
         const double di = __builtin_fma(c.c_dd, dd_in[i], c.c_r * dinv[i] * ri);
         if (r_out) r_out[i] = ri;
         if (dd_out) dd_out[i] = di;
@@ -923,7 +961,8 @@ __global__ void __launch_bounds__(kBlock) k_amg_restrict(int64_t nc, const int32
                                                           const double *__restrict__ b, const double *__restrict__ t /* null: b IS the residual */,
                                                           double *__restrict__ bc, const double *__restrict__ dinv_c, const double *__restrict__ lam_c,
                                                           double ratio, double *__restrict__ dd_c, double *__restrict__ x_c, const CgCtl *ctl,
-                                                          int32_t n_own = INT32_MAX)
+                                                          int32_t n_own = INT32_MAX, ShareSum S = ShareSum{nullptr, nullptr, nullptr, nullptr},
+                                                          double *__restrict__ send = nullptr)
 {
     // (coupled hierarchy on several ranks: t is this rank's UN-summed share of A x over all its local dofs and b counts
     // only where the rank owns the dof -- members at or beyond n_own are ghosts --, so that the sum over the ranks of these
@@ -939,6 +978,7 @@ __global__ void __launch_bounds__(kBlock) k_amg_restrict(int64_t nc, const int32
             acc += (i < n_own ? b[i] : 0.0) - (t ? t[i] : 0.0);
         }
         bc[a] = acc;
+        share_pack(S, send, a, acc);         // the coarse vector is what travels (pfem_amg.inc: amg_apply_coupled)
         return;
     }
     double acc = 0.0;
@@ -1033,6 +1073,37 @@ __global__ void __launch_bounds__(kBlock) k_amg_spmv_ep(SellDev A, const double 
         if (add_dd0) xv += d0;
         x[i] = xv + di;
     }
+}
+
+// coarse-level product of a hierarchy across the ranks: y = (this rank's share of A) x, the shared rows also into the send buffer
+__global__ void __launch_bounds__(kBlock) k_amg_spmv_pack(SellDev A, const double *__restrict__ xin, double *__restrict__ y, ShareSum S,
+                                                           double *__restrict__ send, const CgCtl *ctl)
+{
+    if (ctl && ctl->flag != 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t s = (static_cast<int64_t>(blockIdx.x) << 2) + wave;
+    if (s >= A.n_slices) return;
+    const int64_t off = A.slice_off[s];
+    const int width = static_cast<int>((A.slice_off[s + 1] - off) >> 6);
+    const int32_t *__restrict__ cp = A.cols + off + lane;
+    const double *__restrict__ vp = A.vals + off + lane;
+    double acc = 0.0;
+    int k = 0;
+    for (; k + 4 <= width; k += 4) {
+        int c[4];
+        double v[4], xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c[j] = cp[64 * (k + j)]; v[j] = vp[64 * (k + j)]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = xin[c[j]];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_fma(v[j], xv[j], acc);
+    }
+    for (; k < width; ++k) acc = __builtin_fma(vp[64 * k], xin[cp[64 * k]], acc);
+    const int64_t i = (s << 6) + lane;
+    if (i >= A.n_rows) return;
+    y[i] = acc;
+    share_pack(S, send, i, acc);
 }
 
 }  // namespace pfem

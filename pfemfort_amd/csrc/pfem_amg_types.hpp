@@ -10,6 +10,7 @@ struct AmgPlan {
     std::vector<int32_t> send_lidx;       // host copy: the next level's plan is derived from it
     int64_t n_send = 0, n_sh = 0;
     DevBuf<int32_t> d_send_lidx, d_sh_lidx, d_sh_ptr, d_sh_src;
+    DevBuf<int32_t> d_row_sh;             // [n_loc] index of every local dof among the plan's shared dofs, -1: not shared (fused pack / unpack)
 };
 
 struct AmgLevel {
@@ -90,6 +91,7 @@ struct Amg {
     // global Galerkin products held sub-assembled, every SpMV of the cycle is followed by the level's neighbour exchange)
     // instead of one hierarchy per rank (block Jacobi).
     bool coupled = false;
+    bool coupled_fused = true;                       // pack as the coarse SpMV's / the restriction's epilogue, unpack-sum inside the vector step (PFEM_AMG_COUPLED_FUSED=0: separate kernels)
     bool coupled_refused = false;                    // the ranks could not form it (decided once per pattern, by all of them together)
     int64_t n_last_global = 0;                       // rows of the last level over all ranks
     DevBuf<double> dense_glob, bx_glob, lam_all;     // coupled: assembled last-level operator, its right-hand side / solution, bounds of all ranks

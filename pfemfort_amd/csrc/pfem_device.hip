@@ -367,6 +367,7 @@ struct pfem_solver {
     std::vector<int64_t> peer_off;               // [n_peers+1] offsets into the send / receive buffers
     int64_t n_send = 0, n_sh = 0;                // doubles per exchange; distinct shared dofs of this rank
     DevBuf<int32_t> d_send_lidx, d_sh_lidx, d_sh_ptr, d_sh_src;
+    DevBuf<int32_t> d_row_sh;                    // [n_loc] index among the shared dofs or -1 (built on demand: the coupled gamg cycle's fused unpack)
     std::vector<int32_t> h_send_lidx;            // host copy of the send list (the coupled gamg hierarchy derives its coarse plans from it)
     DevBuf<double> d_send, d_recv, d_sbuf;       // d_sbuf: [ (p,Ap) | pad | (r,z) | (z,z) ]
     // slices of the SpMV form in use that hold shared rows (run first) / the others (run under the exchange)
@@ -822,6 +823,12 @@ extern "C" int pfem_mesh_upload(pfem_solver *s, int kind, int64_t nElem, const i
     PFEM_TRY(maybe_reorder(s, edof, xyz));
     s->have_mesh = true;
     s->have_pattern = false;
+    // a neighbour plan set before this upload names dofs in the previous mesh's (internal) numbering: it has to be set again
+    s->have_plan = false;
+    s->overlap_agreed = -1;
+    s->h_send_lidx.clear();
+    s->d_row_sh.release();
+    if (s->amg) s->amg->symbolic_ok = false;
     s->tm.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return PFEM_OK;
 }
@@ -2386,6 +2393,7 @@ extern "C" int pfem_solver_set_neighbours(pfem_solver *s, int n_peers, const int
     s->n_send = total;
     s->n_sh = static_cast<int64_t>(sh_lidx.size());
     PFEM_TRY(s->d_send_lidx.alloc(send_lidx.size()));
+    s->d_row_sh.release();          // (rebuilt on demand for the new plan)
     PFEM_TRY(s->d_sh_lidx.alloc(sh_lidx.size()));
     PFEM_TRY(s->d_sh_ptr.alloc(sh_ptr.size()));
     PFEM_TRY(s->d_sh_src.alloc(sh_src.size()));
@@ -2499,11 +2507,14 @@ struct PlanRef {
     const int64_t *peer_off;
     int64_t n_send, n_sh;
     const int32_t *send_lidx, *sh_lidx, *sh_ptr, *sh_src;
+    const int32_t *row_sh = nullptr;      // (optional) dof -> index among the shared dofs
 };
+// the transport alone (pack and unpack-sum are the caller's: fused into its kernels)
+int exchange_only(pfem_solver *s, const PlanRef &P, bool second_stream);
 inline PlanRef plan_of(const pfem_solver *s)
 {
     return PlanRef{static_cast<int>(s->peers.size()), s->peers.data(), s->peer_off.data(), s->n_send, s->n_sh,
-                   s->d_send_lidx.p, s->d_sh_lidx.p, s->d_sh_ptr.p, s->d_sh_src.p};
+                   s->d_send_lidx.p, s->d_sh_lidx.p, s->d_sh_ptr.p, s->d_sh_src.p, s->d_row_sh.p};
 }
 int exchange_sum(pfem_solver *s, const PlanRef &P, double *v, bool second_stream, const CgCtl *ctl = nullptr)
 {
@@ -2522,6 +2533,14 @@ int exchange_sum(pfem_solver *s, const PlanRef &P, double *v, bool second_stream
                            static_cast<const double *>(s->d_recv.p), ctl);
         PFEM_TRY(check_kernel("k_unpack_sum"));
     }
+    return PFEM_OK;
+}
+int exchange_only(pfem_solver *s, const PlanRef &P, bool second_stream)
+{
+    hipStream_t xs = second_stream ? s->comm_stream : s->stream;
+    if (second_stream) PFEM_TRY(stream_follows(s, s->comm_stream, s->stream));
+    PFEM_TRY(s->comm->exchange(P.np, P.peers, P.peer_off, s->d_send.p, s->d_recv.p, xs));
+    if (second_stream) PFEM_TRY(stream_follows(s, s->stream, s->comm_stream));
     return PFEM_OK;
 }
 int exchange_sum(pfem_solver *s, double *v, bool second_stream)

@@ -62,13 +62,16 @@ def main():
     assert s.commSelftest(4096) == 0
     out = {"what": "rank-coupled gamg cycle with the rank as its own neighbour over RCCL (timing only; sums wrong by construction)",
            "cells": [n, n, nz], "free_dofs": N, "one_rank_loop": single}
-    for tag, env in (("coupled_replicated_bottom", None), ("coupled_all_levels_distributed", "0")):
+    lay_keys = ("exchanges_per_cycle", "allreduces_per_cycle")
+    for tag, env in (("coupled_replicated_bottom", None), ("coupled_replicated_from_150000_rows", "150000"),
+                     ("coupled_replicated_from_1000000_rows", "1000000"), ("coupled_all_levels_distributed", "0")):
         if env is None:
             os.environ.pop("PFEM_AMG_REPLICATE_ROWS", None)
         else:
             os.environ["PFEM_AMG_REPLICATE_ROWS"] = env
         s.setNeighbours(np.array([0], np.int32), np.array([0, len(gid)], np.int64), gid)      # (drops the hierarchy: rebuilt with the new setting)
         out[tag] = run(tag)
+        out[tag].update({k: s.amgLayout()[k] for k in lay_keys})
     print(json.dumps(out))
     s.free()
     dist.destroy_process_group()
