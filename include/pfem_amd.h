@@ -464,15 +464,31 @@ typedef int (*pfem_host_exchange_fn)(void *ctx, int n_peers, const int *peers, c
                                      const double *send, double *recv);
 int pfem_solver_set_comm_host(pfem_solver *s, int rank, int nranks, pfem_host_allreduce_fn allreduce,
                               pfem_host_exchange_fn exchange, void *ctx);
+/* Peer memory: the ranks map each other's receive boxes (hipIpcGetMemHandle / hipIpcOpenMemHandle) and their kernels write a
+ * neighbour's segment straight into its box, one release / acquire flag per (rank, neighbour) pair; small all-reduces the same
+ * way (every rank sums the boxes in rank order: identical bits).  Replaces the VecScatter / MPI_Allreduce inside KSPSolve
+ * (solverpetsc.F:476) without a collective library and without the host in the data path.  Works between processes that SHARE
+ * one device -- where RCCL refuses a second rank -- and is what the ranks-on-one-GPU tests run the device path with; between
+ * devices it needs peer-mapped memory the runtime keeps coherent (not available to the builder: RCCL stays the default for
+ * one rank per GPU).  The host hooks carry the bring-up (memory handles through `allreduce`), the teardown barrier and
+ * all-reduces of more than 65536 doubles (symbolic phases); `exchange` is unused and may be NULL.  At most 16 ranks;
+ * a neighbour's segment may hold PFEM_PEER_CAP_DOUBLES doubles (default 2^20).  Waits are bounded (10 s): a lost rank
+ * surfaces as PFEM_ERR_COMM after the solve instead of a hung device.                                                    */
+int pfem_solver_set_comm_peer(pfem_solver *s, int rank, int nranks, pfem_host_allreduce_fn allreduce,
+                              pfem_host_exchange_fn exchange, void *ctx);
 /* Transport self-test (collective, no mesh needed): stamped buffers of `count` doubles to every other rank (to itself
  * when there is one rank) through the backend's exchange, then an all-reduce of a known vector; *bad = wrong entries. */
 int pfem_solver_comm_selftest(pfem_solver *s, int64_t count, int64_t *bad);
+/* Transport timing (collective, no mesh needed): `reps` back-to-back exchanges of `count` doubles with every other rank (with
+ * itself when there is one rank), then `reps` all-reduces of 4 doubles, each series between two events on the solver's stream
+ * (for the host backend the time includes its staging); milliseconds per call.                                           */
+int pfem_solver_comm_bench(pfem_solver *s, int64_t count, int reps, double *ms_per_exchange, double *ms_per_allreduce);
 /* what the last solve exchanged per iteration: number of neighbours, doubles sent to all of them together, and
  * how many of the SpMV's slices hold shared rows (they run first) out of how many                                  */
 int pfem_solver_comm_info(pfem_solver *s, int *n_peers, int64_t *doubles_per_exchange, int64_t *boundary_slices,
                           int64_t *total_slices);
 /* What carries the multi-rank solve, as the transport reports it (replaces what `-log_view` / MPI_Comm_size would tell a
- * PETSc user, solverpetsc.F:447-476): backend name ("rccl", "host", "none"), ncclCommCount / ncclCommCuDevice /
+ * PETSc user, solverpetsc.F:447-476): backend name ("rccl", "host", "peer-ipc", "none"), ncclCommCount / ncclCommCuDevice /
  * ncclGetVersion of the bound communicators (-1 for host hooks), the device the solver runs on, and the form of the
  * multi-rank SpMV all ranks agreed on for the current plan (0 in order, 1 overlapped, -1 before the first solve).     */
 int pfem_solver_comm_describe(pfem_solver *s, char *backend, int backend_len, int *backend_ranks, int *backend_device,

@@ -340,6 +340,51 @@ def pcg_bjacobi_ilu0(rowptr, cols, vals, b, block_start=None, rtol=1e-5, abstol=
     return x, its.value, reason.value, rn.value
 
 
+def lattice_brick_aggregates(xyz_nodes, xyz_free, dense_limit=128, passes=3, max_levels=13):
+    """The aggregates of -pc_type gamg on a scalar problem whose mesh nodes sit on a tensor-product lattice with strong
+    couplings along every axis (the product: amg_bricks_level / k_lat_* in pfemfort_amd/csrc), restated from the COORDINATES
+    alone: a node's position = ranks of its coordinates among the distinct values of ALL mesh nodes (``xyz_nodes`` [dim, nNode]);
+    a level halves ``passes`` axes in turn -- x, y, z, x, ... skipping an axis without extent, the turn carried on to the next
+    level --, an aggregate is a brick of positions, numbered in ascending (z, y, x) order of the occupied bricks; a brick's
+    position on the next level is its brick coordinate.  ``xyz_free`` [dim, n]: the coordinates of the free nodes in dof order.
+    Returns the list of aggregate maps, level by level, until a level has at most ``dense_limit`` dofs or stops shrinking by 20 %."""
+    xyz_nodes = np.atleast_2d(np.asarray(xyz_nodes, dtype=np.float64))
+    xyz_free = np.atleast_2d(np.asarray(xyz_free, dtype=np.float64))
+    dim, n = xyz_free.shape
+    pos = np.zeros((3, n), np.int64)
+    hi = [0, 0, 0]
+    for d in range(dim):
+        u = np.unique(xyz_nodes[d] + 0.0)
+        pos[d] = np.searchsorted(u, xyz_free[d])
+        assert np.array_equal(u[pos[d]], xyz_free[d])
+        hi[d] = len(u) - 1
+    aggs, axis = [], 0
+    while n > dense_limit and len(aggs) + 1 < max_levels:
+        shift = [0, 0, 0]
+        for _ in range(passes):
+            k = 0
+            while k < 3 and hi[axis] < 1:
+                axis = (axis + 1) % 3
+                k += 1
+            if k == 3:
+                break
+            shift[axis] += 1
+            hi[axis] >>= 1
+            axis = (axis + 1) % 3
+        if not any(shift):
+            break
+        b = [pos[d] >> shift[d] for d in range(3)]
+        nb = [int(b[d].max()) + 1 for d in range(3)]
+        lin = b[0] + nb[0] * (b[1] + nb[1] * b[2])
+        occ, agg = np.unique(lin, return_inverse=True)
+        if len(occ) * 10 > n * 8:
+            break
+        aggs.append(agg.astype(np.int64))
+        pos = np.stack([occ % nb[0], (occ // nb[0]) % nb[1], occ // (nb[0] * nb[1])])
+        n = len(occ)
+    return aggs
+
+
 def rbm_prolongator(node_agg, xyz, dim, fine_bs):
     """Tentative prolongator with the rigid-body modes of every aggregate (the product: pfem_amg_rbm.hpp; PETSc reaches the
     same coarse space through MatSetNearNullSpace / PCSetCoordinates ahead of PCGAMG, tetraelasticityparallelimpl1.F:894-902).

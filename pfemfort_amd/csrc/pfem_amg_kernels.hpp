@@ -292,6 +292,8 @@ __global__ void __launch_bounds__(kBlock) k_amg_distinct(const double *__restric
     if (key == ~0ull) { *overflow = 1; return; }                   // (the empty marker is a NaN pattern: not a coordinate)
     unsigned h = static_cast<unsigned>((key * 0x9E3779B97F4A7C15ull) >> 52) & (kLatticeTable - 1);
     for (int probe = 0; probe < kLatticeTable; ++probe) {
+        // (a mesh without a lattice fills the table at once: nobody needs to walk it to the end to learn that again)
+        if ((probe & 63) == 0 && __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
         const unsigned long long cur = table[h];
         if (cur == key) return;
         if (cur == ~0ull) {

@@ -83,7 +83,13 @@ struct Amg {
     hipGraphExec_t graph = nullptr;
     std::vector<uint64_t> graph_key;
     bool graph_off = false;
-    ~Amg() { if (graph) (void)hipGraphExecDestroy(graph); }
+    hipEvent_t ev_num0 = nullptr, ev_num1 = nullptr;   // around the numeric phase of a solve (created once)
+    ~Amg()
+    {
+        if (graph) (void)hipGraphExecDestroy(graph);
+        if (ev_num0) (void)hipEventDestroy(ev_num0);
+        if (ev_num1) (void)hipEventDestroy(ev_num1);
+    }
     int tail_from = -1;                              // first level of the single-launch tail of the cycle (-1: none)
     bool fused = true;                               // fused SpMV epilogues on the coarse levels + the tail kernel (PFEM_AMG_FUSED=0: off)
     int coarsest_sweeps = 8;                         // Chebyshev degree on the last level when it is too large for the dense inverse

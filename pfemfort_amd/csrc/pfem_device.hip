@@ -27,6 +27,7 @@
 #include "pfem_internal.hpp"
 #include "pfem_kernels.hpp"
 #include "pfem_amg_kernels.hpp"
+#include "pfem_peer.hpp"
 
 using namespace pfem;
 
@@ -194,6 +195,8 @@ struct CommBackend {
     virtual int allreduce(double *d, int64_t n, hipStream_t st) = 0;
     // d_send[off[k]..off[k+1]) -> peers[k]; the same range of d_recv <- peers[k]
     virtual int exchange(int np, const int *peers, const int64_t *off, const double *d_send, double *d_recv, hipStream_t st) = 0;
+    // after a solve (streams idle): did the transport see an error it could not report from inside a stream?
+    virtual int health() { return PFEM_OK; }
 };
 
 // ---------------------------------------------------------------------------
@@ -2231,6 +2234,150 @@ struct HostBackend final : CommBackend {
     }
 };
 
+// ---- peer memory (pfem_peer.hpp): the ranks map each other's receive boxes (hipIpc*), kernels write into them directly -----
+// Between the processes that share one device (the ranks-on-one-GPU tests: the device-side path at world size >= 2 that RCCL
+// refuses there) and between devices whose runtime maps peer memory.  The host hooks bootstrap it (the memory handles travel
+// through the all-reduce hook) and carry what does not fit a box (all-reduces beyond kPeerAllreduceCap doubles: the symbolic
+// phase's lists; exchanges always fit -- the box is sized at bring-up, PFEM_PEER_CAP_DOUBLES per neighbour).
+struct PeerBackend final : CommBackend {
+    static constexpr int64_t kPeerAllreduceCap = 65536;
+    HostBackend host;
+    int rank = 0, nranks = 1, device = 0;
+    void *base = nullptr;
+    std::vector<void *> mapped;                    // peers' regions in this address space (nullptr for the own one)
+    PeerWorld W{};
+    std::vector<unsigned long long> xe;            // per pair: exchange messages so far
+    unsigned long long ae = 0;
+    int *d_arrive = nullptr;
+    bool up = false;
+    PeerBackend(pfem_host_allreduce_fn a, pfem_host_exchange_fn e, void *c) : host(a, e, c) {}
+    ~PeerBackend() override
+    {
+        (void)hipDeviceSynchronize();
+        // nobody may still be writing an acknowledgement into this rank's region when it goes: the ranks leave together
+        if (up && host.ar) { double one = 1.0; (void)host.ar(host.ctx, &one, 1); }
+        for (void *p : mapped)
+            if (p) (void)hipIpcCloseMemHandle(p);
+        if (base) (void)hipFree(base);
+        if (d_arrive) (void)hipFree(d_arrive);
+    }
+    const char *name() const override { return "peer-ipc"; }
+    void describe(int *ranks, int *dev, int *version) const override { *ranks = nranks; *dev = device; *version = -1; }
+    static size_t pad(size_t b) { return (b + 255) / 256 * 256; }
+    void carve(char *b, PeerMail &m) const
+    {
+        const size_t fl = pad(sizeof(unsigned long long) * static_cast<size_t>(nranks));
+        m.xflag = reinterpret_cast<unsigned long long *>(b);
+        m.xack = reinterpret_cast<unsigned long long *>(b + fl);
+        m.aflag = reinterpret_cast<unsigned long long *>(b + 2 * fl);
+        m.aack = reinterpret_cast<unsigned long long *>(b + 3 * fl);
+        m.err = reinterpret_cast<int *>(b + 4 * fl);
+        m.xbox = reinterpret_cast<double *>(b + 4 * fl + 256);
+        m.abox = m.xbox + 2 * static_cast<int64_t>(nranks) * W.cap_x;
+    }
+    int init(int r, int n, int dev)
+    {
+        rank = r; nranks = n; device = dev;
+        if (n > kPeerMaxRanks) { set_last_error("peer transport: at most 16 ranks"); return PFEM_ERR_ARG; }
+        if (n > 1 && !host.ar) { set_last_error("peer transport needs the host all-reduce hook for its bring-up"); return PFEM_ERR_ARG; }
+        const char *e = std::getenv("PFEM_PEER_CAP_DOUBLES");
+        double cap = static_cast<double>(e && std::atoll(e) > 0 ? std::atoll(e) : (1LL << 20));
+        W.rank = r; W.nranks = n; W.cap_a = kPeerAllreduceCap;
+        // (the ranks agree on the largest request: the layout of a region must be the same on both ends of a pair)
+        if (n > 1) {
+            std::vector<double> v(static_cast<size_t>(n), 0.0);
+            v[static_cast<size_t>(r)] = cap;
+            if (host.ar(host.ctx, v.data(), n) != 0) return PFEM_ERR_COMM;
+            cap = *std::max_element(v.begin(), v.end());
+        }
+        W.cap_x = static_cast<int64_t>(cap);
+        const size_t fl = pad(sizeof(unsigned long long) * static_cast<size_t>(n));
+        const size_t bytes = 4 * fl + 256 + sizeof(double) * 2 * static_cast<size_t>(n) * static_cast<size_t>(W.cap_x + W.cap_a);
+        int rc_local = PFEM_OK;
+        hipIpcMemHandle_t mine;
+        std::memset(&mine, 0, sizeof mine);
+        if (hipMalloc(&base, bytes) != hipSuccess || hipMemset(base, 0, bytes) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&d_arrive), sizeof(int)) != hipSuccess ||
+            hipMemset(d_arrive, 0, sizeof(int)) != hipSuccess) {
+            (void)hipGetLastError();
+            rc_local = PFEM_ERR_NOMEM;
+        } else if (n > 1 && hipIpcGetMemHandle(&mine, base) != hipSuccess) {
+            set_last_error(std::string("hipIpcGetMemHandle: ") + hipGetErrorString(hipGetLastError()));
+            rc_local = PFEM_ERR_COMM;
+        }
+        (void)hipDeviceSynchronize();
+        // handles (and every rank's verdict so far) to all ranks: one byte per double through the all-reduce hook
+        constexpr size_t HB = sizeof(hipIpcMemHandle_t);
+        std::vector<double> hb(static_cast<size_t>(n) * (HB + 1), 0.0);
+        for (size_t i = 0; i < HB; ++i) hb[static_cast<size_t>(r) * (HB + 1) + i] = static_cast<double>(reinterpret_cast<const unsigned char *>(&mine)[i]);
+        hb[static_cast<size_t>(r) * (HB + 1) + HB] = rc_local == PFEM_OK ? 0.0 : 1.0;
+        if (n > 1 && host.ar(host.ctx, hb.data(), static_cast<int64_t>(hb.size())) != 0) return PFEM_ERR_COMM;
+        bool any_bad = false;
+        for (int q = 0; q < n; ++q) any_bad = any_bad || hb[static_cast<size_t>(q) * (HB + 1) + HB] != 0.0;
+        if (any_bad) { if (rc_local == PFEM_OK) set_last_error("peer transport: another rank could not export its memory"); return rc_local != PFEM_OK ? rc_local : PFEM_ERR_COMM; }
+        mapped.assign(static_cast<size_t>(n), nullptr);
+        double bad_open = 0.0;
+        for (int q = 0; q < n; ++q) {
+            char *b = static_cast<char *>(base);
+            if (q != r) {
+                hipIpcMemHandle_t h;
+                for (size_t i = 0; i < HB; ++i) reinterpret_cast<unsigned char *>(&h)[i] = static_cast<unsigned char>(hb[static_cast<size_t>(q) * (HB + 1) + i]);
+                void *p = nullptr;
+                if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+                    set_last_error(std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(hipGetLastError()));
+                    bad_open = 1.0;
+                    continue;
+                }
+                mapped[static_cast<size_t>(q)] = p;
+                b = static_cast<char *>(p);
+            }
+            carve(b, W.m[q]);
+        }
+        if (n > 1 && host.ar(host.ctx, &bad_open, 1) != 0) return PFEM_ERR_COMM;        // (also the barrier: every region is mapped before its first use)
+        if (bad_open != 0.0) return PFEM_ERR_COMM;
+        xe.assign(static_cast<size_t>(n), 0);
+        up = true;
+        return PFEM_OK;
+    }
+    int allreduce(double *d, int64_t n, hipStream_t st) override
+    {
+        if (nranks == 1) return PFEM_OK;
+        if (n > W.cap_a) return host.allreduce(d, n, st);          // (every rank sees the same n: the same path everywhere)
+        ++ae;
+        const unsigned blocks = static_cast<unsigned>(std::max<int64_t>(nranks, std::min<int64_t>(64, (n + 1023) / 1024)));
+        hipLaunchKernelGGL(k_peer_allreduce, dim3(blocks), dim3(1024), 0, st, W, ae, d, n, d_arrive);
+        hipLaunchKernelGGL(k_peer_allreduce_ack, dim3(1), dim3(64), 0, st, W, ae, d_arrive);
+        return check_kernel("k_peer_allreduce");
+    }
+    int exchange(int np, const int *peers, const int64_t *off, const double *d_send, double *d_recv, hipStream_t st) override
+    {
+        if (np == 0) return PFEM_OK;
+        if (np > kPeerMaxRanks) { set_last_error("peer transport: more than 16 neighbours"); return PFEM_ERR_COMM; }
+        PeerExchangeArgs X{};
+        X.np = np;
+        for (int k = 0; k < np; ++k) {
+            if (peers[k] < 0 || peers[k] >= nranks) return PFEM_ERR_ARG;
+            if (off[k + 1] - off[k] > W.cap_x) {
+                set_last_error("peer transport: a neighbour's segment of " + std::to_string(off[k + 1] - off[k]) + " doubles exceeds the box (PFEM_PEER_CAP_DOUBLES = " +
+                               std::to_string(W.cap_x) + ")");
+                return PFEM_ERR_COMM;
+            }
+            X.peers[k] = peers[k];
+            X.off[k] = off[k];
+            X.epoch[k] = ++xe[static_cast<size_t>(peers[k])];
+        }
+        X.off[np] = off[np];
+        hipLaunchKernelGGL(k_peer_exchange, dim3(static_cast<unsigned>(np)), dim3(1024), 0, st, W, X, d_send, d_recv);
+        return check_kernel("k_peer_exchange");
+    }
+    int health() override
+    {
+        int e = 0;
+        if (base && hipMemcpy(&e, W.m[rank].err, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return PFEM_ERR_HIP;
+        if (e) { set_last_error("peer transport: a wait for a neighbour's flag timed out (10 s)"); return PFEM_ERR_COMM; }
+        return PFEM_OK;
+    }
+};
+
 int ensure_comm_stream(pfem_solver *s)
 {
     if (!s->comm_stream) {
@@ -2311,6 +2458,18 @@ extern "C" int pfem_solver_set_comm_rccl(pfem_solver *s, int rank, int nranks, c
         delete b;
         return rc;
     }
+    return install_backend(s, rank, nranks, b);
+}
+
+extern "C" int pfem_solver_set_comm_peer(pfem_solver *s, int rank, int nranks, pfem_host_allreduce_fn allreduce,
+                                         pfem_host_exchange_fn exchange, void *ctx)
+{
+    if (!s || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !allreduce)) return PFEM_ERR_ARG;
+    PFEM_TRY(use_device(s));
+    PeerBackend *b = new (std::nothrow) PeerBackend(allreduce, exchange, ctx);
+    if (!b) return PFEM_ERR_NOMEM;
+    const int rc = b->init(rank, nranks, s->device);
+    if (rc != PFEM_OK) { b->up = false; delete b; return rc; }
     return install_backend(s, rank, nranks, b);
 }
 
@@ -2457,6 +2616,49 @@ extern "C" int pfem_solver_comm_selftest(pfem_solver *s, int64_t count, int64_t 
         if (red_out[j] != want[j]) ++nbad;
     *bad = nbad;
     return PFEM_OK;
+}
+
+extern "C" int pfem_solver_comm_bench(pfem_solver *s, int64_t count, int reps, double *ms_per_exchange, double *ms_per_allreduce)
+{
+    if (!s || count < 1 || reps < 1 || !ms_per_exchange || !ms_per_allreduce) return PFEM_ERR_ARG;
+    if (!s->comm) return PFEM_ERR_STATE;
+    PFEM_TRY(use_device(s));
+    PFEM_TRY(ensure_comm_stream(s));
+    std::vector<int> peers;
+    for (int q = 0; q < s->nranks; ++q)
+        if (q != s->rank || s->nranks == 1) peers.push_back(q);
+    const int np = static_cast<int>(peers.size());
+    std::vector<int64_t> off(static_cast<size_t>(np) + 1, 0);
+    for (int k = 0; k < np; ++k) off[k + 1] = off[k] + count;
+    const size_t tot = static_cast<size_t>(off[np]);
+    DevBuf<double> d_send, d_recv, d_red;
+    PFEM_TRY(d_send.alloc(tot));
+    PFEM_TRY(d_recv.alloc(tot));
+    PFEM_TRY(d_red.alloc(4));
+    PFEM_HIP(hipMemsetAsync(d_send.p, 0, sizeof(double) * tot, s->stream));
+    PFEM_HIP(hipMemsetAsync(d_red.p, 0, sizeof(double) * 4, s->stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    PFEM_HIP(hipEventCreate(&e0));
+    PFEM_HIP(hipEventCreate(&e1));
+    PFEM_HIP(hipEventCreate(&e2));
+    int rc = PFEM_OK;
+    for (int warm = 0; warm < 2 && rc == PFEM_OK; ++warm) {            // (first pass: warm-up)
+        if (hipEventRecord(e0, s->stream) != hipSuccess) rc = PFEM_ERR_HIP;
+        for (int r = 0; r < reps && rc == PFEM_OK; ++r) rc = s->comm->exchange(np, peers.data(), off.data(), d_send.p, d_recv.p, s->stream);
+        if (rc == PFEM_OK && hipEventRecord(e1, s->stream) != hipSuccess) rc = PFEM_ERR_HIP;
+        for (int r = 0; r < reps && rc == PFEM_OK; ++r) rc = s->comm->allreduce(d_red.p, 4, s->stream);
+        if (rc == PFEM_OK && hipEventRecord(e2, s->stream) != hipSuccess) rc = PFEM_ERR_HIP;
+        if (rc == PFEM_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = PFEM_ERR_HIP;
+    }
+    float a = 0.f, b = 0.f;
+    if (rc == PFEM_OK && (hipEventElapsedTime(&a, e0, e1) != hipSuccess || hipEventElapsedTime(&b, e1, e2) != hipSuccess)) rc = PFEM_ERR_HIP;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(e2);
+    PFEM_TRY(rc);
+    *ms_per_exchange = a / reps;
+    *ms_per_allreduce = b / reps;
+    return s->comm->health();
 }
 
 extern "C" int pfem_solver_comm_info(pfem_solver *s, int *n_peers, int64_t *doubles_per_exchange, int64_t *boundary_slices,
@@ -3543,6 +3745,7 @@ extern "C" int pfem_solver_solve(pfem_solver *s, int *its, int *reason, double *
     PFEM_TRY(run_pcg(s));
     PFEM_HIP(hipEventRecord(s->ev1, s->stream));
     PFEM_TRY(elapsed(s, &s->tm.solve_ms));
+    if (s->comm) PFEM_TRY(s->comm->health());
     if (its) *its = s->last_its;
     if (reason) *reason = s->last_reason;
     if (rnorm) *rnorm = s->last_rnorm;

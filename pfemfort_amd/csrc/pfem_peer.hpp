@@ -1,0 +1,136 @@
+// pfem_peer.hpp -- device kernels of the peer-memory transport (pfem_solver_set_comm_peer): neighbour exchange and small
+// all-reduces through receive buffers that the ranks map into each other's address space (hipIpcGetMemHandle /
+// hipIpcOpenMemHandle), with one release/acquire flag per (rank, neighbour) pair -- what the VecScatter inside KSPSolve does
+// for the reference (solverpetsc.F:476), without a collective library and without the host in the data path.  SURVEY 8(e):
+// the messages are 62 KB ... 1.3 MB faces and a few scalars, latency-bound; a direct write + flag is the shortest path.
+//
+// Visibility (cdna_hip_programming.md G16): payload stores -> system-scope fence -> flag store (release); the consumer polls
+// the flag with acquire loads, fences, then reads the payload.  Per-XCD L2s are not coherent with each other, so both
+// fences are needed even between two processes on ONE device.  Every wait is bounded (kPeerSpinTicks of the 100 MHz
+// wall clock); a timeout sets the error word the host reads after the solve instead of hanging the device.
+#pragma once
+
+namespace pfem {
+
+constexpr unsigned long long kPeerSpinTicks = 1000000000ull;      // 10 s at 100 MHz
+
+struct PeerMail {                 // one rank's mailbox as a peer sees it (all device pointers, mapped into THIS process)
+    unsigned long long *xflag;    // [nranks] epoch of the last exchange message that has landed, by source rank
+    unsigned long long *xack;     // [nranks] epoch of MY message to that rank that it has consumed (written by that rank)
+    unsigned long long *aflag;    // [nranks] all-reduce epoch that has landed, by source rank
+    unsigned long long *aack;     // [nranks] all-reduce epoch that rank has consumed
+    int *err;                     // timeout / protocol error
+    double *xbox;                 // [2][nranks][cap_x] exchange payload by epoch parity and source rank
+    double *abox;                 // [2][nranks][cap_a] all-reduce payload
+};
+constexpr int kPeerMaxRanks = 16;
+struct PeerWorld {
+    PeerMail m[kPeerMaxRanks];    // m[rank] = this rank's own mailbox (local pointers)
+    int rank, nranks;
+    int64_t cap_x, cap_a;
+};
+
+__device__ __forceinline__ bool peer_wait(const unsigned long long *flag, unsigned long long want, int *err)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > kPeerSpinTicks) { *err = 1; return false; }
+    }
+    return true;
+}
+
+// one block per neighbour: wait for the slot, write my segment into the neighbour's box, flag; wait for its segment, copy it
+// out, acknowledge.  epoch[k] = this pair's message number (starts at 1).
+struct PeerExchangeArgs {
+    int np;
+    int peers[kPeerMaxRanks];
+    int64_t off[kPeerMaxRanks + 1];
+    unsigned long long epoch[kPeerMaxRanks];
+};
+__global__ void __launch_bounds__(1024) k_peer_exchange(PeerWorld W, PeerExchangeArgs X, const double *__restrict__ send, double *__restrict__ recv)
+{
+    __shared__ int ok_s;
+    const int k = blockIdx.x;
+    if (k >= X.np) return;
+    const int q = X.peers[k], r = W.rank;
+    const unsigned long long e = X.epoch[k];
+    const int64_t cnt = X.off[k + 1] - X.off[k];
+    const PeerMail &mine = W.m[r], &his = W.m[q];
+    if (threadIdx.x == 0) ok_s = (e < 3 || peer_wait(&mine.xack[q], e - 2, mine.err)) ? 1 : 0;       // the slot of epoch e - 2 is free again
+    __syncthreads();
+    if (!ok_s) return;
+    double *dst = his.xbox + (static_cast<int64_t>(e & 1) * W.nranks + r) * W.cap_x;
+    const double *src = send + X.off[k];
+    for (int64_t i = threadIdx.x; i < cnt; i += 1024) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&his.xflag[r], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        ok_s = peer_wait(&mine.xflag[q], e, mine.err) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!ok_s) return;
+    __threadfence_system();
+    const double *box = mine.xbox + (static_cast<int64_t>(e & 1) * W.nranks + q) * W.cap_x;
+    double *out = recv + X.off[k];
+    for (int64_t i = threadIdx.x; i < cnt; i += 1024) out[i] = __builtin_nontemporal_load(box + i);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&his.xack[r], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// in-place sum of n <= cap_a doubles over the ranks: every rank pushes its vector into every rank's box (its own too), then
+// sums the boxes in rank order -- the same additions in the same order everywhere: identical bits on all ranks.
+// Phase 1 (nranks blocks): push + flag.  Phase 2 (same launch, after all flags): grid-stride sum.  e = all-reduce number.
+__global__ void __launch_bounds__(1024) k_peer_allreduce(PeerWorld W, unsigned long long e, double *__restrict__ d, int64_t n, int *arrive)
+{
+    __shared__ int ok_s;
+    const int r = W.rank, nr = W.nranks;
+    const PeerMail &mine = W.m[r];
+    if (static_cast<int>(blockIdx.x) < nr) {
+        const int q = blockIdx.x;
+        const PeerMail &his = W.m[q];
+        if (threadIdx.x == 0) ok_s = (e < 3 || peer_wait(&mine.aack[q], e - 2, mine.err)) ? 1 : 0;
+        __syncthreads();
+        if (ok_s) {
+            double *dst = his.abox + (static_cast<int64_t>(e & 1) * nr + r) * W.cap_a;
+            for (int64_t i = threadIdx.x; i < n; i += 1024) dst[i] = d[i];
+            __threadfence_system();
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(&his.aflag[r], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    // every block waits for all contributions (and for this rank's own pushes to have read d: the block-level arrival count)
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        for (int q = 0; q < nr && ok; ++q) ok = peer_wait(&mine.aflag[q], e, mine.err) ? 1 : 0;
+        if (static_cast<int>(blockIdx.x) < nr) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (ok) {
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < nr) {      // all pushes of this rank have read d
+                __builtin_amdgcn_s_sleep(2);
+                if (wall_clock64() - t0 > kPeerSpinTicks) { *mine.err = 1; ok = 0; break; }
+            }
+        }
+        ok_s = ok;
+    }
+    __syncthreads();
+    if (!ok_s) return;
+    __threadfence_system();
+    const double *box = mine.abox + static_cast<int64_t>(e & 1) * nr * W.cap_a;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 1024 + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 1024) {
+        double a = 0.0;
+        for (int q = 0; q < nr; ++q) a += __builtin_nontemporal_load(box + q * W.cap_a + i);
+        d[i] = a;
+    }
+}
+// after the sum: tell every rank its box of this epoch has been read (separate launch: all blocks of the sum are done)
+__global__ void k_peer_allreduce_ack(PeerWorld W, unsigned long long e, int *arrive)
+{
+    const int q = threadIdx.x;
+    if (q == 0) *arrive = 0;
+    if (q < W.nranks) __hip_atomic_store(&W.m[q].aack[W.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+}  // namespace pfem

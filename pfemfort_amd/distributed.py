@@ -104,15 +104,20 @@ def broadcast_rccl_id(dist, group=None, make_id=rccl_unique_id):
     return msg[1]
 
 
-def attach(solver, dist, torch=None, staged=False, group=None, make_id=rccl_unique_id):
+def attach(solver, dist, torch=None, staged=False, group=None, make_id=rccl_unique_id, peer=False):
     """Wire a solver that already holds its mesh (or, compat path, its pattern) to the process group: neighbour
     plan + communication backend.  ``staged=False``: RCCL inside the library (one rank per GPU).
     ``staged=True``: host hooks over the group (gloo; several ranks may share a GPU); ``group``: a gloo subgroup when
-    the default group is not one.  Returns the HostHooks object (staged) or None."""
+    the default group is not one.  ``peer=True``: peer memory mapped through hipIpc* (ranks that share a GPU, device-side data
+    path; the hooks over the group carry the bring-up).  Returns the HostHooks object (staged / peer) or None."""
     rank, world = dist.get_rank(), dist.get_world_size()
     peers, off, gid = plan_for(solver, dist, group)
     hooks = None
-    if staged:
+    if peer:          # peer memory (hipIpc*): the data path stays on the device; the hooks carry the bring-up
+        hooks = HostHooks(dist, torch, group)
+        solver.setCommPeer(rank, world, hooks.allreduce, hooks.exchange)
+        solver._keep.append(hooks)
+    elif staged:
         hooks = HostHooks(dist, torch, group)
         solver.setCommHost(rank, world, hooks.allreduce, hooks.exchange)
         solver._keep.append(hooks)

@@ -369,11 +369,25 @@ class PetscSolver:
         self._keep.extend([a, e])
         L.check(L.lib().pfem_solver_set_comm_host(self._h, rank, nranks, a, e, None), "pfem_solver_set_comm_host")
 
+    def setCommPeer(self, rank, nranks, allreduce_cb, exchange_cb=None):
+        """Peer-memory transport (ranks map each other's receive boxes through hipIpc*; kernels write into them directly): the
+        device-side path between processes that share a GPU.  The host hooks carry the bring-up and oversized all-reduces."""
+        a = L.HOST_ALLREDUCE_FN(allreduce_cb) if allreduce_cb is not None else L.HOST_ALLREDUCE_FN()
+        e = L.HOST_EXCHANGE_FN(exchange_cb) if exchange_cb is not None else L.HOST_EXCHANGE_FN()
+        self._keep.extend([a, e])
+        L.check(L.lib().pfem_solver_set_comm_peer(self._h, rank, nranks, a, e, None), "pfem_solver_set_comm_peer")
+
     def commSelftest(self, count=1000):
         """Collective transport check (stamped exchange with every other rank + a known all-reduce): wrong entries."""
         bad = C.c_int64(0)
         L.check(L.lib().pfem_solver_comm_selftest(self._h, count, C.byref(bad)), "pfem_solver_comm_selftest")
         return bad.value
+
+    def commBench(self, count, reps=200):
+        """Collective transport timing: (ms per exchange of ``count`` doubles with every other rank, ms per all-reduce of 4 doubles)."""
+        a, b = C.c_double(0), C.c_double(0)
+        L.check(L.lib().pfem_solver_comm_bench(self._h, count, reps, C.byref(a), C.byref(b)), "pfem_solver_comm_bench")
+        return a.value, b.value
 
     def commInfo(self):
         npe = C.c_int(0); d = C.c_int64(0); b = C.c_int64(0); t = C.c_int64(0)

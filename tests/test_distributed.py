@@ -271,12 +271,12 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
         ed = H.ELAST_ELEMDATA if kind == pf.ELAST_TET else H.POISSON_ELEMDATA
         if devgen:
             s.generateBoxMesh(kind, *mesh_args["box"], bc_mode=mesh_args["bc_mode"], nparts=world, part=rank, axis=axis)
-            hooks = PD.attach(s, dist, torch, staged=True)
+            hooks = PD.attach(s, dist, torch, staged=True, peer=bool(mesh_args.get("peer")))
             s.buildPattern()
             s.assemble(ed, H.TIMEDATA)
         elif mesh_args.get("mode", "batched") == "batched":
             s.uploadMesh(kind, conn_loc, xyz_new, edof_g, dm.solnApplied)
-            hooks = PD.attach(s, dist, torch, staged=True)
+            hooks = PD.attach(s, dist, torch, staged=True, peer=bool(mesh_args.get("peer")))
             s.buildPattern()
             s.assemble(ed, H.TIMEDATA)
         else:
@@ -287,7 +287,7 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
             for e in range(conn_loc.shape[1]):
                 s.MatSetValues(edof_g[:, e], edof_g[:, e], np.zeros(nsize * nsize), INSERT_VALUES)
             s.setZero()
-            hooks = PD.attach(s, dist, torch, staged=True)
+            hooks = PD.attach(s, dist, torch, staged=True, peer=bool(mesh_args.get("peer")))
             fn = H.StiffnessResidualElasticityLinearTetra if kind == pf.ELAST_TET else H.StiffnessResidualPoissonLinearTetra
             for e in range(conn_loc.shape[1]):
                 nd = conn_loc[:, e]
@@ -339,7 +339,7 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                                                 for t in (s.amgTransfer(l) for l in range(ai["levels"] - 1))]).reshape(-1, 4))
         info = s.commInfo()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=x1, rs=rs, re=re, its=its, reason=reason,
-                 pc=s.preconditioner(), calls=hooks.calls, log=np.array([f"{k}{c}" for k, c in hooks.log]),
+                 pc=s.preconditioner(), calls=hooks.calls, log=np.array([f"{k}{c}" for k, c in hooks.log]), transport=s.commDescribe()["backend"],
                  n_peers=info["n_peers"], n_send=info["doubles_per_exchange"], slices_b=info["boundary_slices"],
                  slices=info["total_slices"], **extra)
         s.free()
@@ -372,10 +372,10 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                                                             ("poisson", 3, "foreign", "gamg"), ("poisson", 5, "sectors", "gamg_distributed"),
                                                             ("elast", 4, "rcb", "gamg"), ("poisson", 6, "rcb", "gamg"),
                                                             ("poisson", 3, "sectors", "reorder"), ("elast", 2, "slabs", "reorder_gamg")])
-def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partition, mode):
+def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partition, mode, peer=False):
     """2-3 ranks share cuda:0 (host-staged exchange over gloo): the product's multi-rank device loop against the
     ORACLE -- a direct solve of the oracle-assembled global system in the partition's new numbering, and the oracle's
-    Jacobi-PCG iteration count."""
+    Jacobi-PCG iteration count.  ``peer``: the same over the peer-memory transport (see test_gpu_peer_memory_transport)."""
     import scipy.sparse as sp
     import scipy.sparse.linalg as spl
     import torch.multiprocessing as mp
@@ -385,6 +385,7 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
                  {"box": (-0.5, 0.5, 3, 0.0, 3.0, 8, -0.5, 0.5, 6), "bc_mode": 1, "ndof": 3})
     mesh_args["partition"] = partition
     mesh_args["mode"] = mode
+    mesh_args["peer"] = peer
     if mode in ("reorder", "reorder_gamg"):     # internal Morton renumbering forced on: neighbour plan, solution, CSR in the caller's numbering
         mesh_args["reorder"] = True
         mode = "gamg" if mode == "reorder_gamg" else "batched"
@@ -509,7 +510,7 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
             # exchange; two solves + the set-up's exchanges, a few per level)
             ex, ar = int(d0["amg_exchanges"]), int(d0["amg_allreduces"])
             assert ex >= nd and ar == (1 if rows_glob[-1] <= 128 or nd < nl else 0)
-            if world == 2:
+            if world == 2 and not peer:
                 n_x = sum(1 for k in d0["log"] if k[0] == "x")
                 assert 2 * int(d0["its"]) * (1 + ex) <= n_x <= 2 * (int(d0["its"]) + 2) * (1 + ex) + 40 * nl
         else:
@@ -536,8 +537,12 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
         assert int(d["reason"]) == 2 and abs(int(d["its"]) - its_oracle) <= its_tol
         # per iteration: one exchange and two all-reduces; every rank issued the same KIND of call in the same order
         idle = int(d["n_peers"]) == 0                        # a rank without neighbours has nothing to exchange
-        assert int(d["calls"]) >= (2 if idle else 3) * int(d["its"]) if not single else True
-        if single:                                           # ONE all-reduce per step; steps = its + 1 (the last one judges)
+        assert str(d["transport"]) == ("peer-ipc" if peer else "host")
+        if peer:                                              # the hooks saw the bring-up and the oversized all-reduces only
+            assert int(d["calls"]) < 3 * int(d["its"]) or int(d["its"]) < 8
+        else:
+            assert int(d["calls"]) >= (2 if idle else 3) * int(d["its"]) if not single else True
+        if single and not peer:                              # ONE all-reduce per step; steps = its + 1 (the last one judges)
             n_all = sum(1 for s in d["log"] if s[0] == "a")
             setup_allreduces = 0                              # point Jacobi: the set-up exchanges need no all-reduce
             assert n_all - setup_allreduces <= int(d["its"]) + 1 + 32     # + the tail of the last 32-step chunk
@@ -546,7 +551,7 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
         kinds0 = [s[0] for s in np.load(tmp_path / "rank0.npz")["log"]]
         if idle:
             kinds0 = [k for k in kinds0 if k == "a"]
-        assert kinds == kinds0
+        assert kinds == kinds0 or peer
         if partition == "idle" and r == world - 1:      # an idle rank owns nothing and shares nothing, but takes part in
             assert int(d["n_peers"]) == 0 and int(d["re"]) == int(d["rs"])       # every all-reduce and agrees on the verdict
         else:
@@ -560,6 +565,24 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
     if mesh_args.get("resolve"):
         u2 = lu.solve(prob.rhs + 0.25)
         assert np.abs(got2 - u2).max() <= 1e-8 * max(1.0, np.abs(u2).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind_name,world,partition,mode", [("poisson", 2, "slabs", "batched"), ("elast", 3, "sectors", "batched"),
+                                                            ("poisson", 2, "slabs", "compat"), ("elast", 2, "slabs", "pbjacobi"),
+                                                            ("poisson", 3, "idle", "batched"), ("elast", 3, "sectors", "overlap"),
+                                                            ("poisson", 3, "rcb", "single_overlap"), ("elast", 3, "yslabs", "devgen"),
+                                                            ("poisson", 2, "slabs", "gamg"), ("elast", 3, "yslabs", "gamg"),
+                                                            ("poisson", 3, "idle", "gamg_overlap"), ("poisson", 3, "rcb", "gamg_distributed"),
+                                                            ("elast", 3, "sectors", "gamg"), ("poisson", 6, "rcb", "gamg"),
+                                                            ("elast", 2, "slabs", "reorder_gamg")])
+def test_gpu_peer_memory_transport(tmp_path, kind_name, world, partition, mode):
+    """The same multi-rank cases with the DEVICE-SIDE transport between the ranks that share cuda:0: every rank maps the
+    others' receive boxes (hipIpcGetMemHandle / hipIpcOpenMemHandle), exchange and small all-reduces are kernels that write
+    into the neighbour's box and flag it (pfem_solver_set_comm_peer) -- no host in the data path, which RCCL cannot offer
+    with two ranks on one device.  Against the oracle's direct solve and iteration count like the host-staged runs; the
+    host hooks see the bring-up only."""
+    test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partition, mode, peer=True)
 
 
 @pytest.mark.gpu

@@ -129,7 +129,7 @@ def _gpu_rank(rank, world, port, case, out_dir, pc=None):
 def test_gpu_driver_harness_reproduces_temp_dat(case, pc, tmp_path):
     """The build's own counterpart of the driver (pfemfort_amd.drivers) on the GPU writes the same temp.dat as the
     reference program did: integer columns bit-exact, values <= 1e-8 -- with the default point Jacobi and with
-    -pc_type gamg (on several ranks: block Jacobi over the ranks, one multigrid hierarchy per rank)."""
+    -pc_type gamg (on several ranks: ONE multigrid hierarchy across the ranks, the library's multi-rank default)."""
     import pfemfort_amd as pf
     fx = _load(case)
     world = int(fx["nranks"])

@@ -172,3 +172,24 @@ def test_elasticity_beam_config4():
     full[H.assy_for_soln(dm.NodeDofArrayNew)] = u
     disp = np.linalg.norm(full.reshape(-1, 3), axis=1)
     assert abs(disp.max() - 0.82) < 0.01                    # docs/beam3Dtet5030050-nproc80-soln.jpg: 0.82
+    its_j = its
+    # -pc_type gamg at this size, with the rigid-body modes of every aggregate in the coarse space: the same converged answer as
+    # point Jacobi (both to rtol 1e-10: 13 000 against a few dozen iterations), every transfer carrying rotations, 6 dofs per
+    # coarse node; at the reference's tolerance the count that took config 4 from 169 (translations only) to ~18
+    s.setTolerances(rtol=1e-10, maxits=100000)
+    its_j10, reason, _ = s.factoriseAndSolve()
+    uj = s.getSolution()
+    assert reason == 2
+    s.setPreconditioner("gamg")
+    its_g10, reason, _ = s.factoriseAndSolve()
+    ug = s.getSolution()
+    assert reason == 2 and its_g10 <= 60 and np.abs(ug - uj).max() <= 1e-6 * np.abs(uj).max(), (its_g10, its_j10)
+    info = s.amgInfo()
+    tr = [s.amgTransfer(l) for l in range(info["levels"] - 1)]
+    assert all(t["rbm"] and t["coarse_bs"] == 6 and t["dim"] == 3 for t in tr) and tr[0]["fine_bs"] == 3 and all(t["fine_bs"] == 6 for t in tr[1:])
+    assert info["rows"][:2] == [2340900, 558750]           # 6 x (25 x 149 x 25) bricks of 2 (3 at the odd end of a line)
+    s.setTolerances(rtol=1e-5, maxits=100000)
+    its_g, reason, _ = s.factoriseAndSolve()
+    assert reason == 2 and its_g <= 30 and its_g * 100 < its_j, (its_g, its_j)
+    full[H.assy_for_soln(dm.NodeDofArrayNew)] = s.getSolution()
+    assert abs(np.linalg.norm(full.reshape(-1, 3), axis=1).max() - 0.82) < 0.01

@@ -899,6 +899,33 @@ def test_gamg_solve_equals_oracle_restatement(case, tet10, beam, tria20, golden_
     assert all(1.0 < lam < 8.0 for lam in info["lambda_max"])
 
 
+@pytest.mark.parametrize("case", ["tet10", "cube30", "tria20", "odd"])
+def test_gamg_lattice_bricks_equal_the_oracles_own(case, tet10, tria20):
+    """On a lattice with strong couplings along every axis the aggregates are bricks of positions.  The oracle restates them
+    from the node COORDINATES alone (O.lattice_brick_aggregates: no device data), level by level down the hierarchy: the
+    device's aggregate maps are equal to them entry for entry, so the oracle's cycle on these cases is fed nothing the device
+    made -- and its solve still matches the device's iteration for iteration."""
+    kind, mesh, ed = {"tet10": (pf.POISSON_TET, tet10, H.POISSON_ELEMDATA),
+                      "cube30": (pf.POISSON_TET, H.gen_box_tets(-1, 1, 30, -1, 1, 30, -1, 1, 30), H.POISSON_ELEMDATA),
+                      "tria20": (pf.POISSON_TRIA_INLINE, tria20, None),
+                      "odd": (pf.POISSON_TET, H.gen_box_tets(0, 2.3, 23, 0, 1.7, 17, 0, 1.2, 12), H.POISSON_ELEMDATA)}[case]      # cubic cells, lines of 22, 16, 11 free nodes
+    s, dm = _device_problem(kind, mesh, ed)
+    s.setPreconditioner("gamg")
+    s.setTolerances(rtol=1e-10, maxits=10000)
+    its, reason, _ = s.factoriseAndSolve()
+    info = s.amgInfo()
+    dev = [s.amgAggregates(l, info["rows"][l]) for l in range(info["levels"] - 1)]
+    free = np.where(dm.NodeDofArrayNew.reshape(-1) >= 0)[0]
+    xyz_new = mesh.xyz[:, dm.node_map_get_old]
+    own = O.lattice_brick_aggregates(xyz_new, xyz_new[:, free])
+    assert len(own) == len(dev) >= 1 and all(np.array_equal(a, b) for a, b in zip(own, dev))
+    assert s.amgLayout()["lattice_levels"] == len(dev)
+    rowptr, cols, vals = s.getCSR()
+    xo, ito, ro, _, hist = O.pcg_amg(rowptr, cols, vals, s.getRHS(), own, cheb_degree=info["cheb_degree"], fine_degree=info["fine_degree"],
+                                     eig_ratio=info["eig_ratio"], coarse_scale=info["coarse_scale"], rtol=1e-10)
+    assert (reason, ro) == (2, 2) and abs(its - ito) <= 1 and np.abs(s.getSolution() - xo).max() <= 1e-9 * max(1.0, np.abs(xo).max())
+
+
 def test_gamg_reasons_and_reuse():
     """KSP reasons through the gamg loop (0 iterations on b = 0, the iteration limit), a second solve with NEW values on
     the same pattern (aggregates reused, Galerkin sums redone: the solution scales with the operator), and a new pattern
