@@ -733,6 +733,17 @@ def main():
             # of the preconditioner, which the timed steps reuse like they reuse the sparsity pattern): the figure to compare
             # with a single run of the reference driver, whose KSPSolve timer contains its PCSetUp
             "first_step_ms_including_once_per_pattern_setup": R["first_step_ms"],
+            # the same as a rate: DOF/s of ONE run of the reference driver's timed section on a fresh pattern (assembly + KSPSolve with
+            # its PCSetUp, tetrapoissonparallelimpl1.F:826-902); `value` is the rate of every later step on the same pattern
+            "cold_value": (N / (R["first_step_ms"] * 1e-3)) if R.get("first_step_ms") else None,
+            # how to quote this line: three rates of the same configuration, never the first alone
+            "headline": {"value_warm_step_default_solver": N * args.steps / R["elapsed"],
+                         "cold_value_first_step_with_preconditioner_setup": (N / (R["first_step_ms"] * 1e-3)) if R.get("first_step_ms") else None,
+                         "north_star_cg_point_jacobi": (Jac["N"] / (Jac["ms_per_step"] * 1e-3)) if Jac else None,
+                         "unit": "DOF/s", "default_solver": R["pc_in_effect"],
+                         "solver_default_at_the_boundary": "the C ABI, the Python drivers and the Fortran modules default to -pc_type jacobi (north_star's "
+                                                           "solver); one line `-pc_type gamg` in petsc_options.dat -- where the reference's own run "
+                                                           "takes its KSP options from (tetrapoissonparallelimpl1.F:168) -- selects what this line's `value` ran"},
             "parity_tolerance_step": R["parity"],
             "preconditioner": ({"name": R["pc_in_effect"], "levels": R["amg"]["levels"], "rows_per_level": R["amg"]["rows"],
                                 "nnz_per_level": R["amg"]["nnz"], "gershgorin_lambda_max": R["amg"]["lambda_max"],

@@ -284,6 +284,10 @@ struct pfem_solver {
     DevBuf<int64_t> d_rslice_off, d_rslice_doff;
     DevBuf<uint32_t> d_rdwords;
     DevBuf<double> d_rvals;
+    // the gather assembly writes the relative-group copy itself (k_gather_poisson_tet4): union entry of every stored entry of
+    // the row form (0xff: none), and whether the copy holds the values of the last assembly (else k_rel_vals re-packs it)
+    DevBuf<uint8_t> d_relk;
+    bool rel_vals_current = false;
     bool use_rel() const
     {
         return relgrouped && !use_grouped() &&
@@ -1406,6 +1410,7 @@ int zero_values(pfem_solver *s, bool rows_overwritten = false)
         PFEM_HIP(hipMemsetAsync(s->d_vals.p, 0, sizeof(double) * static_cast<size_t>(std::max<int64_t>(s->stored, 1)), s->stream));
     PFEM_HIP(hipMemsetAsync(s->d_rhs.p, 0, sizeof(double) * static_cast<size_t>(std::max<int64_t>(s->n_loc, 1)), s->stream));
     s->rhs_summed = false;
+    s->rel_vals_current = false;            // (whoever writes the values next says so again if it writes both forms)
     return PFEM_OK;
 }
 
@@ -1429,6 +1434,7 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
     // setZero, solverpetsc.F:222-246 (the value array needs no clearing when every row is stored whole by the gather
     // kernels; hub rows, if any, are accumulated with atomics and do)
     PFEM_TRY(zero_values(s, gather && (use_lds || elast_rows) && s->n_hubs == 0));
+    bool wrote_rel = false;
     if (gather) {
         // gather form: one thread per node, no atomics, bit-reproducible
         const dim3 grid(grid_for(m.nNode)), block(kBlock);
@@ -1460,8 +1466,14 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
         case PFEM_POISSON_TET:
             if (use_lds && s->d_node4.p && !std::getenv("PFEM_DEBUG_GATHER_SOA")) {
                 PFEM_TRY(allow_lds(reinterpret_cast<const void *>(&k_gather_poisson_tet4)));
+                // (the relative-group copy of the values the CG's SpMV streams is written here too when that form is in use and the
+                // whole matrix is assembled by this kernel: k_rel_vals' 1.9 GB re-pack per solve -- 0.66 ms at config 3 -- goes away)
+                const bool both = s->use_rel() && s->d_relk.p && s->n_hubs == 0 && !std::getenv("PFEM_DEBUG_NO_REL_DIRECT");
                 hipLaunchKernelGGL(k_gather_poisson_tet4, xgrid, rblock, rlds, s->stream, m.nNode, A, s->d_rhs.p, prm, ip, ic, irec, nrow,
-                                   static_cast<const double4 *>(s->d_node4.p), s->d_err.p, xcd_per);
+                                   static_cast<const double4 *>(s->d_node4.p), s->d_err.p, xcd_per,
+                                   both ? static_cast<const uint8_t *>(s->d_relk.p) : nullptr, both ? static_cast<const int64_t *>(s->d_rslice_off.p) : nullptr,
+                                   both ? s->d_rvals.p : nullptr);
+                wrote_rel = both;
             } else {
                 PFEM_GATHER(PFEM_POISSON_TET);
             }
@@ -1513,6 +1525,7 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
     if (!err && s->assembly_mode == PFEM_ASSEMBLY_GATHER && s->have_incidence) err = s->geom_err;
     if (err) return err;
     s->host_values_dirty = false;
+    s->rel_vals_current = wrote_rel;
     s->status = PFEM_ASSEMBLY_OK;
     return PFEM_OK;
 }
@@ -1879,9 +1892,34 @@ int build_rel_groups(pfem_solver *s)
     s->relgrouped = true;
     s->rel_gap32 = gap32;
     s->rel_dict = dict;
+    // union entry of every stored entry of the row form, for an assembly that writes this copy itself; the explicit zeros of the
+    // copy (offsets a row lacks) are set here once and never written again
+    s->rel_vals_current = false;
+    s->d_relk.release();
+    if (s->max_row_len > 0 && !std::getenv("PFEM_DEBUG_NO_REL_DIRECT")) {
+        PFEM_TRY(s->d_relk.alloc(static_cast<size_t>(std::max<int64_t>(s->stored, 1))));
+        PFEM_HIP(hipMemsetAsync(s->d_relk.p, 0xff, static_cast<size_t>(std::max<int64_t>(s->stored, 1)), s->stream));
+        PFEM_HIP(hipMemsetAsync(s->d_rvals.p, 0, sizeof(double) * static_cast<size_t>(std::max<int64_t>(tot_e, 1)) * kRelRows, s->stream));
+        PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
+        const dim3 vg(static_cast<unsigned>(s->n_rslices));
+        if (gap32) hipLaunchKernelGGL(k_rel_slot_map<kGap32>, vg, dim3(kBlock), 0, s->stream, s->sell(), s->sellr(), s->d_relk.p, s->d_err.p);
+        else if (dict) hipLaunchKernelGGL(k_rel_slot_map<kGapDict16>, vg, dim3(kBlock), 0, s->stream, s->sell(), s->sellr(), s->d_relk.p, s->d_err.p);
+        else hipLaunchKernelGGL(k_rel_slot_map<kGapLit16>, vg, dim3(kBlock), 0, s->stream, s->sell(), s->sellr(), s->d_relk.p, s->d_err.p);
+        PFEM_TRY(check_kernel("k_rel_slot_map"));
+        int wide = 0;
+        PFEM_TRY(fetch_err(s, &wide));
+        PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
+        if (wide) s->d_relk.release();          // a union of more than 255 offsets: the re-pack kernel stays
+    }
     return PFEM_OK;
 }
 
+// before a solve / a product: is the SpMV's own copy of the values behind the row form?  (Always, unless the gather assembly
+// wrote the relative-group copy itself and nothing has touched the values since.)
+inline void mark_group_vals(pfem_solver *s)
+{
+    s->group_vals_stale = !(s->use_rel() && s->rel_vals_current);
+}
 // grouped copy of the current matrix values (the row form is what assembly writes)
 int refresh_group_vals(pfem_solver *s)
 {
@@ -2039,7 +2077,7 @@ extern "C" int pfem_spmv(pfem_solver *s, const double *x, double *y)
         for (int64_t i = 0; i < s->n_owned; ++i) xi[static_cast<size_t>(s->h_perm[static_cast<size_t>(i)])] = x[i];
     }
     PFEM_HIP(hipMemcpyAsync(s->d_p.p, s->reordered ? xi.data() : x, nb, hipMemcpyHostToDevice, s->stream));
-    s->group_vals_stale = true;
+    mark_group_vals(s);
     PFEM_TRY(refresh_group_vals(s));
     launch_spmv<false>(s, s->d_p.p, s->d_w.p, 0, nullptr, nullptr);
     PFEM_TRY(check_kernel("k_spmv"));
@@ -2051,7 +2089,7 @@ extern "C" int pfem_bench_spmv(pfem_solver *s, int reps, double *ms_per_launch)
     if (!s || reps < 1 || !ms_per_launch) return PFEM_ERR_ARG;
     if (!s->have_pattern) return PFEM_ERR_STATE;
     PFEM_TRY(use_device(s));
-    s->group_vals_stale = true;
+    mark_group_vals(s);
     PFEM_TRY(refresh_group_vals(s));
     // warm-up launch, then `reps` timed ones with x = rhs (copied into the guarded SpMV input vector)
     PFEM_HIP(hipMemcpyAsync(s->d_p.p, s->d_rhs.p, sizeof(double) * static_cast<size_t>(s->n_loc), hipMemcpyDeviceToDevice, s->stream));
@@ -2913,7 +2951,7 @@ int run_pcg(pfem_solver *s)
     const int64_t n = s->n_loc;
     // test knob PFEM_FORCE_MULTI: a single rank with a backend and an (empty) plan takes the multi-rank loop too
     const bool multi = s->nranks > 1 || (s->comm && s->have_plan && std::getenv("PFEM_FORCE_MULTI"));
-    s->group_vals_stale = true;            // the row form may have been re-assembled since the last solve
+    mark_group_vals(s);                    // the row form may have been re-assembled since the last solve
     PFEM_TRY(refresh_group_vals(s));
     // Two forms of the multi-rank iteration.  In order: whole SpMV, pack, exchange, all-reduce ... on the compute stream:
     // costs the exchange itself.  Overlapped: the slices with shared rows first, the exchange on the communication stream
@@ -3385,7 +3423,7 @@ int run_pcg_single(pfem_solver *s)
 {
     const int64_t n = s->n_loc;
     const bool multi = s->nranks > 1 || (s->comm && s->have_plan && std::getenv("PFEM_FORCE_MULTI"));
-    s->group_vals_stale = true;
+    mark_group_vals(s);
     PFEM_TRY(refresh_group_vals(s));
     bool overlap = false;
     PFEM_TRY(agree_overlap(s, multi, &overlap));
@@ -3731,6 +3769,7 @@ extern "C" int pfem_solver_solve(pfem_solver *s, int *its, int *reason, double *
             DevBuf<double> dv;
             PFEM_TRY(dv.alloc(static_cast<size_t>(s->nnz)));
             PFEM_HIP(hipMemcpyAsync(dv.p, s->h_vals.data(), sizeof(double) * s->nnz, hipMemcpyHostToDevice, s->stream));
+            s->rel_vals_current = false;
             hipLaunchKernelGGL(k_csr_vals_to_sell, dim3(grid_for(s->n_loc)), dim3(kBlock), 0, s->stream, s->sell(), s->d_rowptr.p, dv.p);
             PFEM_TRY(check_kernel("k_csr_vals_to_sell"));
             PFEM_HIP(hipStreamSynchronize(s->stream));

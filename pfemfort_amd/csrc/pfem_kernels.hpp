@@ -793,7 +793,9 @@ __global__ void __launch_bounds__(kBlock) k_gather_poisson_tet4(int64_t nNode, S
                                                                  const int4 *__restrict__ inc_rec,
                                                                  const int32_t *__restrict__ node_row,
                                                                  const double4 *__restrict__ node4, int *err,
-                                                                 unsigned xcd_per)
+                                                                 unsigned xcd_per, const uint8_t *__restrict__ relk = nullptr,
+                                                                 const int64_t *__restrict__ rslice_off = nullptr,
+                                                                 double *__restrict__ rvals = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];
     const int T = blockDim.x;
@@ -866,6 +868,18 @@ __global__ void __launch_bounds__(kBlock) k_gather_poisson_tet4(int64_t nNode, S
             acc[k * T] += Kcol[j];
         }
     }
+    if (rvals) {
+        // both forms: the row form, and the relative-group copy the CG's SpMV streams (k_spmvr: group g = row / 4, plane row % 4,
+        // union entry relk[slot] of the group's slice -- the explicit zeros of that copy were set when the map was built)
+        const int64_t g = row >> 2;
+        double *rp = rvals + 4 * rslice_off[g >> 6] + (g & 63) + 64 * (row & 3);          // (4 = kRelRows, asserted at k_rel_slot_map)
+        for (int k = 0; k < len; ++k) {
+            const int64_t q = base + (static_cast<int64_t>(k) << 6);
+            const double v = acc[k * T];
+            A.vals[q] = v;
+            rp[4LL * 64 * relk[q]] = v;
+        }
+    } else
     for (int k = 0; k < len; ++k) A.vals[base + (static_cast<int64_t>(k) << 6)] = acc[k * T];
     rhs[row] = facc;
 }
@@ -2142,6 +2156,41 @@ __global__ void __launch_bounds__(kBlock) k_rel_vals(SellDev A, SellRDev G, doub
         while (j < len && A.cols[base + 64LL * j] < c) ++j;
         if (j < len && A.cols[base + 64LL * j] == c) { v = A.vals[base + 64LL * j]; ++j; }   // ++j: pads repeat c
         op[static_cast<int64_t>(kRelRows) * k * 64] = v;
+    }
+}
+
+// union entry (place in the relative-group form) of every stored entry of the row form: relk[slot] = k, for an assembly
+// that writes both forms (same walk as k_rel_vals); *wide when a union has more than 255 offsets
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_rel_slot_map(SellDev A, SellRDev G, uint8_t *__restrict__ relk, int *__restrict__ wide)
+{
+    constexpr bool GAP32 = MODE == kGap32;
+    static_assert(kRelRows == 4, "k_gather_poisson_tet4 writes the relative-group copy with 4 rows per group");
+    const int64_t gs = blockIdx.x;
+    if (gs >= G.n_gslices) return;
+    const int lane = threadIdx.x & 63, p = threadIdx.x >> 6;
+    const int64_t g = (gs << 6) + lane;
+    const int64_t off = G.gslice_off[gs];
+    const int width = static_cast<int>((G.gslice_off[gs + 1] - off) >> 6);
+    if (width > 255) { *wide = 1; return; }
+    const uint32_t *wp = G.dwords + G.gslice_doff[gs] + lane;
+    const int64_t r = g * kRelRows + p;
+    const bool live = g < G.n_groups && r < A.n_rows;
+    const int len = live ? A.rowlen[r] : 0;
+    const int64_t base = live ? A.slice_off[r >> 6] + (r & 63) : 0;
+    int64_t c = G.col0[g] + p;
+    int j = 0;
+    for (int k = 0; k < width; ++k) {
+        if (k > 0) {
+            if (GAP32) c += wp[64LL * (k - 1)];
+            else {
+                const uint32_t w = wp[64LL * ((k - 1) >> 1)];
+                const uint32_t code = ((k - 1) & 1) ? (w >> 16) : (w & 0xffffu);
+                c += (MODE == kGapDict16 && (code & 0x8000u)) ? G.gap_table[code & (kGapTable - 1)] : code;
+            }
+        }
+        while (j < len && A.cols[base + 64LL * j] < c) ++j;
+        if (j < len && A.cols[base + 64LL * j] == c) { relk[base + 64LL * j] = static_cast<uint8_t>(k); ++j; }
     }
 }
 

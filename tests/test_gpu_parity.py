@@ -1031,7 +1031,8 @@ def test_internal_renumbering_is_invisible_at_the_boundary(kind_name, monkeypatc
         its_g, reason_g, _ = s.factoriseAndSolve()
         ug = s.getSolution()
         agg0 = s.amgAggregates(0, dm.size_global)
-        out[reorder] = dict(rowptr=rowptr, cols=cols, vals=vals, rhs=s.getRHS(), y=s.spmv(x), edof=edof_l, its=its, u=u, its_g=its_g, ug=ug,
+        tr0 = s.amgTransfer(0)
+        out[reorder] = dict(tr0=tr0, rowptr=rowptr, cols=cols, vals=vals, rhs=s.getRHS(), y=s.spmv(x), edof=edof_l, its=its, u=u, its_g=its_g, ug=ug,
                             agg0=agg0, bits=s.spmvColumnBits(), reasons=(reason, reason_g))
         s.free()
     a, b = out["0"], out["auto"]
@@ -1046,4 +1047,9 @@ def test_internal_renumbering_is_invisible_at_the_boundary(kind_name, monkeypatc
     assert np.abs(a["u"] - b["u"]).max() <= 1e-8 * max(1.0, np.abs(a["u"]).max())
     assert np.abs(b["ug"] - b["u"]).max() <= 1e-8 * max(1.0, np.abs(a["u"]).max())
     # the aggregates are indexed by the caller's dofs; the multigrid solve is at least as good as on the scrambled numbering
-    assert b["bits"] == 16 and b["its_g"] <= a["its_g"] + 2 and len(np.unique(b["agg0"])) == b["agg0"].max() + 1
+    assert b["bits"] == 16 and b["its_g"] <= a["its_g"] + 2
+    if b["tr0"]["rbm"]:      # rigid-body modes: the map names the translation dofs of the aggregates (3 of every coarse node's 6)
+        cb = b["tr0"]["coarse_bs"]
+        assert cb == 6 and set(np.unique(b["agg0"] % cb)) == {0, 1, 2} and len(np.unique(b["agg0"] // cb)) == b["agg0"].max() // cb + 1
+    else:
+        assert len(np.unique(b["agg0"])) == b["agg0"].max() + 1
