@@ -787,7 +787,7 @@ def main():
                          # The events are bound to the dispatch itself (hipExtLaunchKernelGGL), and still read ~20 us more than the
                          # trace: under the tracer dispatches run one at a time, on the plain stream the kernel's first waves share
                          # the device with the last waves of the kernel before it (events without the system-scope fence: no change,
-                         # tools/r03/aj.sh).  The judged fraction uses the pair as it is, the lower of the two figures
+                         # round-3 lease script aj.sh, in the history).  The judged fraction uses the pair as it is, the lower of the two figures
                          "kernel_trace_avg_launch_us_replayed_not_this_run": kernel_trace_figures(info["nnz"]) if (world == 1 and args.numbering == "lattice") else None,
                          "avg_launch_ms_in_jacobi_step": (Jac["acc"]["spmv_ms"] / max(Jac["acc"]["spmv_n"], 1)) if (Jac and Jac["acc"]["spmv_n"]) else None,
                          "event_pair_offset_ms_not_subtracted": R["event_overhead_ms"],
