@@ -209,6 +209,85 @@ def test_amg_pcg_restatement(tet10):
     assert O.pcg_amg(prob.rowptr, prob.cols, prob.vals, prob.rhs, aggs, rtol=1e-14, maxits=3)[1:3] == (3, -3)
 
 
+def test_lattice_brick_aggregates_restatement(tet10):
+    """O.lattice_brick_aggregates (what the device's `bricks in one step` is compared with): from the node coordinates alone,
+    a hierarchy of bricks -- 2x2x2 nodes per aggregate, the node an odd line leaves over in a thin brick of its own, every
+    level aligned with the lattice of ALL mesh nodes (the Dirichlet planes count: the first free node of a line sits at
+    position 1 and stays alone) --; the cycle built on it converges in a fraction of point Jacobi's iterations; a plane problem
+    halves x, y, x, then y, x, y."""
+    prob = O.setup_problem(O.POISSON_TET, tet10)
+    free = np.where(prob.dm.NodeDofArrayNew.reshape(-1) >= 0)[0]
+    aggs = O.lattice_brick_aggregates(prob.xyz_new, prob.xyz_new[:, free])
+    i = np.arange(729)               # free node i sits at position (1 + i % 9, 1 + (i // 9) % 9, 1 + i // 81): position 0 is the Dirichlet plane
+    brick = ((i // 81 + 1) // 2) * 25 + (((i // 9) % 9 + 1) // 2) * 5 + (i % 9 + 1) // 2
+    assert len(aggs) == 1 and np.array_equal(aggs[0], brick)          # 729 -> 125 (<= 128: the dense bottom)
+    mesh = O.gen_box_tets(-1, 1, 30, -1, 1, 30, -1, 1, 30)
+    p30 = O.setup_problem(O.POISSON_TET, mesh)
+    free = np.where(p30.dm.NodeDofArrayNew.reshape(-1) >= 0)[0]
+    aggs = O.lattice_brick_aggregates(p30.xyz_new, p30.xyz_new[:, free])
+    assert [len(a) for a in aggs] == [29 ** 3, 15 ** 3, 8 ** 3] and [int(a.max()) + 1 for a in aggs] == [15 ** 3, 8 ** 3, 4 ** 3]
+    cnt = np.bincount(aggs[0])
+    assert cnt.max() == 8 and cnt.min() == 1 and (cnt == 8).sum() == 14 ** 3          # 29 = 14 pairs + one left over, per axis
+    x, its, reason, *_ = O.pcg_amg(p30.rowptr, p30.cols, p30.vals, p30.rhs, aggs, eig_ratio=16.0, rtol=1e-10)
+    _, its_j, *_ = O.pcg_jacobi(p30.rowptr, p30.cols, p30.vals, p30.rhs, rtol=1e-10)
+    assert reason == 2 and its < its_j // 4
+    # the plane: 19 x 19 free nodes of the tria20x20 mesh: x, y, x halved on the first level (aggregates of 4 x 2 nodes)
+    g = np.meshgrid(np.arange(21.0), np.arange(21.0), indexing="ij")
+    xy = np.stack([g[0].ravel(), g[1].ravel()])
+    inner = (xy[0] > 0) & (xy[0] < 20) & (xy[1] > 0) & (xy[1] < 20)
+    a2 = O.lattice_brick_aggregates(xy, xy[:, inner])
+    assert len(a2[0]) == 361 and np.bincount(a2[0]).max() == 8 and int(a2[0].max()) + 1 == 5 * 10
+
+
+def test_rigid_body_prolongator_restatement():
+    """O.rbm_prolongator: the columns of an aggregate span its rigid-body motions -- a motion T + W x (x - c) of the whole mesh
+    is reproduced exactly from the coarse vector (T + W x c_I, W) of every aggregate, on the level of the assembled matrix
+    (3 dofs per node) and on a level of 6-dof nodes; an aggregate of collinear nodes keeps its translations only.  With these
+    prolongators the cycle needs a small fraction of the iterations the translations alone need on a slender beam."""
+    rng = np.random.default_rng(5)
+    n = 60
+    xyz = rng.standard_normal((3, n))
+    agg = np.repeat(np.arange(n // 6), 6)
+    P, cen = O.rbm_prolongator(agg, xyz, 3, 3)
+    assert P.shape == (3 * n, 6 * (n // 6))
+    T, W = np.array([0.3, -1.2, 0.7]), np.array([0.5, 0.25, -2.0])
+    coarse = np.concatenate([np.concatenate([T + np.cross(W, cen[:, a]), W]) for a in range(n // 6)])
+    u = (T[:, None] + np.cross(W, xyz.T).T).T.ravel()
+    assert np.abs(P @ coarse - u).max() <= 1e-13
+    # the next level: nodes of 6 dofs (the centroids), aggregates of 5
+    agg2 = np.repeat(np.arange(2), 5)
+    P2, cen2 = O.rbm_prolongator(agg2, cen, 3, 6)
+    coarse2 = np.concatenate([np.concatenate([T + np.cross(W, cen2[:, a]), W]) for a in range(2)])
+    assert np.abs(P2 @ coarse2 - coarse).max() <= 1e-13
+    # three collinear nodes: no rotations (offsets 0), translations intact
+    line = np.stack([np.arange(3.0), 2 * np.arange(3.0), np.zeros(3)])
+    Pl, _ = O.rbm_prolongator(np.zeros(3, int), line, 3, 3)
+    assert abs(Pl[:, 3:]).sum() == 0 and np.array_equal(Pl[:, :3].toarray(), np.tile(np.eye(3), (3, 1)))
+    # plane: 2 + 1 modes
+    xy = np.vstack([rng.standard_normal((2, 8)), np.zeros((1, 8))])
+    Pp, cp = O.rbm_prolongator(np.repeat([0, 1], 4), xy, 2, 2)
+    wz = 0.8
+    up = np.stack([T[0] - wz * xy[1], T[1] + wz * xy[0]]).T.ravel()
+    cz = np.concatenate([[T[0] - wz * cp[1, a], T[1] + wz * cp[0, a], wz] for a in range(2)])
+    assert Pp.shape == (16, 6) and np.abs(Pp @ cz - up).max() <= 1e-13
+    # a slender clamped beam: bricks of nodes, with and without the rotations
+    mesh = O.gen_box_tets(-0.5, 0.5, 4, 0.0, 6.0, 24, -0.5, 0.5, 4, bc_mode=1, ndof=3)
+    prob = O.setup_problem(O.ELAST_TET, mesh)
+    nd = prob.dm.NodeDofArrayNew.reshape(-1, 3)
+    free = np.where(nd[:, 0] >= 0)[0]
+    x0 = prob.xyz_new[:, free]
+    node_aggs = O.lattice_brick_aggregates(prob.xyz_new, x0, dense_limit=20)
+    Ps, xs, fb = [], x0, 3
+    for a in node_aggs:
+        Pk, xs = O.rbm_prolongator(a, xs, 3, fb)
+        Ps.append(Pk)
+        fb = 6
+    dof_aggs = [np.repeat(3 * a, 3) + np.tile(np.arange(3), len(a)) for a in node_aggs]
+    _, its_r, reason_r, *_ = O.pcg_amg(prob.rowptr, prob.cols, prob.vals, prob.rhs, Ps, eig_ratio=16.0)
+    _, its_t, reason_t, *_ = O.pcg_amg(prob.rowptr, prob.cols, prob.vals, prob.rhs, dof_aggs, eig_ratio=8.0, coarse_scale=1.8)
+    assert (reason_r, reason_t) == (2, 2) and 3 * its_r < its_t, (its_r, its_t)
+
+
 def test_mpi_restatement_of_the_cpu_baseline_equals_the_serial_oracle():
     """oracle/pfem_oracle_mpi (bench.py's cpu_baseline with one MPI rank per core): slabs of node planes, the oracle's element
     routine, distributed Jacobi-PCG -- same matrix size, same iteration count, same residual norm and nodal error as the
