@@ -366,7 +366,8 @@ int pfem_solver_set_amg_options(pfem_solver *s, int cheb_degree, int fine_degree
  * off by default there and here): the Chronopoulos-Gear form of the same iteration -- s = A z instead of w = A p,
  * (p,Ap) by recurrence -- so that (z,r), (z,s), (z,z) are reduced together: ONE all-reduce per iteration on several
  * ranks instead of two, at the price of two more vectors of traffic per iteration and one more SpMV per solve.  Point
- * Jacobi only (node-block Jacobi keeps the two-reduction loop).  on = 1 / 0, or -1: the environment variable
+ * Jacobi, and -pc_type gamg with ONE hierarchy across several ranks (two all-reduces per iteration instead of three: the
+ * cycle keeps its own); node-block Jacobi and gamg on one rank keep the two-reduction loop.  on = 1 / 0, or -1: the environment variable
  * PFEM_CG_SINGLE_REDUCTION decides (default off).  Same stopping rule and reasons; iterates agree with the default
  * loop to rounding.                                                                                                    */
 int pfem_solver_set_cg_single_reduction(pfem_solver *s, int on);

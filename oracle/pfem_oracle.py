@@ -550,13 +550,62 @@ def pcg_with(rowptr, cols, vals, b, M, rtol=1e-5, abstol=1e-50, dtol=1e5, maxits
     return x, maxits, -3, hist[-1], np.array(hist)
 
 
+def pcg_with_single_reduction(rowptr, cols, vals, b, M, rtol=1e-5, abstol=1e-50, dtol=1e5, maxits=10000):
+    """The single-reduction form of pcg_with (PETSc: KSPCGUseSingleReduction; the product: k_pcg1_step): s = A z, (p,Ap) by the
+    recurrence (z,s) - beta^2 (p,Ap)_old, so that (z,s), (r,z), (z,z) are reduced together; step k judges iterate k from
+    ||z_k|| before advancing.  Same iterates as pcg_with up to rounding.  Returns (x, its, reason, rnorm, history)."""
+    import scipy.sparse as sp
+    N = len(rowptr) - 1
+    A = sp.csr_matrix((np.asarray(vals, dtype=np.float64), np.asarray(cols), np.asarray(rowptr)), shape=(N, N))
+    b = _f64(b)
+    x = np.zeros(N)
+    r = b.copy()
+    p = np.zeros(N)
+    w = np.zeros(N)
+    hist = []
+    beta_old = dpi_old = 0.0
+    rn0 = ttol = 0.0
+    for it in range(0, maxits + 2):
+        z = M(r)
+        s = A @ z
+        zs, rz, zz = float(z @ s), float(r @ z), float(z @ z)
+        rn = float(np.sqrt(zz))
+        hist.append(rn)
+        if it == 0:
+            rn0, ttol = rn, max(rtol * rn, abstol)
+            if rn <= abstol:
+                return x, 0, 3, rn, np.array(hist)
+        elif rn <= ttol:
+            return x, it, 2, rn, np.array(hist)
+        elif rn >= dtol * rn0:
+            return x, it, -4, rn, np.array(hist)
+        if rz < 0.0:
+            return x, it, -8, rn, np.array(hist)
+        if it >= maxits:
+            return x, it, -3, rn, np.array(hist)
+        if it == 0:
+            beta, dpi = 0.0, zs
+        else:
+            beta = rz / beta_old
+            dpi = zs - rz * rz * dpi_old / (beta_old * beta_old)
+        if not dpi > 0.0:
+            return x, it + 1, -10, rn, np.array(hist)
+        alpha = rz / dpi
+        p = z + beta * p
+        w = s + beta * w
+        x += alpha * p
+        r -= alpha * w
+        beta_old, dpi_old = rz, dpi
+    return x, maxits, -3, hist[-1], np.array(hist)
+
+
 def pcg_amg(rowptr, cols, vals, b, aggregates, cheb_degree=2, eig_ratio=8.0, coarse_scale=1.5, rtol=1e-5, abstol=1e-50, dtol=1e5,
-            maxits=10000, dense_limit=128, coarsest_sweeps=8, fine_degree=1, lam_given=None, lam_true_out=None):
+            maxits=10000, dense_limit=128, coarsest_sweeps=8, fine_degree=1, lam_given=None, lam_true_out=None, single_reduction=False):
     """CG preconditioned by one V(1,1) cycle of plain-aggregation multigrid on the whole matrix: amg_cycle + pcg_with."""
     M = amg_cycle(rowptr, cols, vals, aggregates, cheb_degree, eig_ratio, coarse_scale, dense_limit, coarsest_sweeps, fine_degree, lam_given)
     if lam_true_out is not None:
         lam_true_out[:] = M.lam_true
-    return pcg_with(rowptr, cols, vals, b, M, rtol, abstol, dtol, maxits)
+    return (pcg_with_single_reduction if single_reduction else pcg_with)(rowptr, cols, vals, b, M, rtol, abstol, dtol, maxits)
 
 
 def pcg_bjacobi_amg(rowptr, cols, vals, b, blocks, rtol=1e-5, abstol=1e-50, dtol=1e5, maxits=10000, **amg):

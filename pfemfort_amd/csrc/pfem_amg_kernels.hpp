@@ -1316,6 +1316,65 @@ __global__ void __launch_bounds__(kBlock) k_pc_post_dots(const CgCtl *ctl, int64
     const double a = block_sum(rz, sm), c = block_sum(zz, sm);
     if (threadIdx.x == 0) { part_rz[blockIdx.x] = a; part_zz[blockIdx.x] = c; }
 }
+// Single-reduction form of the loop (KSPCGUseSingleReduction; k_cg1_step with a STORED z = M^-1 r from the V-cycle): step `it`
+// judges iterate `it` from (z,z), then p = z + b p, w = s + b w (s = A z), x += a p, r -= a w with
+// b = (r,z)/(r,z)_old, (p,Ap) = (z,s) - b^2 (p,Ap)_old, a = (r,z)/(p,Ap): ONE all-reduce of [(z,s), (r,z), (z,z)] per iteration.
+__global__ void __launch_bounds__(kBlock) k_pcg1_step(CgCtl *ctl, int it, int64_t n, const double *reduced /* [(z,s), (r,z), (z,z)] */,
+                                                       const double *part_zs, int n_zs, const double *part_rz, const double *part_zz, int nparts,
+                                                       const double *__restrict__ z, const double *__restrict__ sv, double *__restrict__ p,
+                                                       double *__restrict__ w, double *__restrict__ x, double *__restrict__ r, double rtol,
+                                                       double abstol, double dtol, double *hist, int hist_cap, int maxits)
+{
+    __shared__ double sm[4];
+    if (ctl->flag != 0) return;
+    double zs, rz, zz;
+    if (reduced) { zs = reduced[0]; rz = reduced[1]; zz = reduced[2]; }
+    else { zs = sum_partials(part_zs, n_zs, sm); rz = sum_partials(part_rz, nparts, sm); zz = sum_partials(part_zz, nparts, sm); }
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    const double rn = sqrt(zz);
+    int flag = 0;
+    if (it == 0 && rn <= abstol) flag = 3;
+    else if (it > 0 && rn <= ctl->ttol) flag = 2;
+    else if (it > 0 && rn >= ctl->dtol * ctl->rn0) flag = -4;
+    else if (rz < 0.0) flag = -8;
+    else if (it >= maxits) flag = -3;
+    if (lead) {
+        if (it == 0) { ctl->rn0 = rn; ctl->ttol = fmax(rtol * rn, abstol); ctl->dtol = dtol; }
+        ctl->rn = rn;
+        if (it < hist_cap) hist[it] = rn;
+    }
+    if (flag != 0) {
+        if (lead) ctl_publish(ctl, flag, it);
+        return;
+    }
+    double b = 0.0, dpi = zs;
+    if (it > 0) {
+        const double beta_old = ctl->beta[(it + 1) & 1], dpi_old = ctl->dpi[(it + 1) & 1];
+        b = rz / beta_old;
+        dpi = zs - rz * rz * dpi_old / (beta_old * beta_old);
+    }
+    if (!(dpi > 0.0)) {                          // KSP_DIVERGED_INDEFINITE_MAT: x is not advanced
+        if (lead) ctl_publish(ctl, -10, it + 1);
+        return;
+    }
+    const double a = rz / dpi;
+    if (lead) {
+        ctl->beta[it & 1] = rz;
+        ctl->dpi[it & 1] = dpi;
+        ctl->alpha = a;
+        ctl_publish(ctl, 0, it);
+    }
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const double zi = z[i], si = sv[i];
+        const double pi = it ? __builtin_fma(b, p[i], zi) : zi;
+        const double wi = it ? __builtin_fma(b, w[i], si) : si;
+        p[i] = pi;
+        w[i] = wi;
+        x[i] = __builtin_fma(a, pi, x[i]);
+        r[i] = __builtin_fma(-a, wi, r[i]);
+    }
+}
+
 __global__ void __launch_bounds__(kBlock) k_pc_dots(const CgCtl *ctl, int64_t n, int64_t n_owned, const double *__restrict__ r,
                                                      const double *__restrict__ z, double *part_rz, double *part_zz)
 {

@@ -371,7 +371,8 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                                                             ("elast", 3, "sectors", "gamg"), ("elast", 3, "rcb", "gamg_distributed"),
                                                             ("poisson", 3, "foreign", "gamg"), ("poisson", 5, "sectors", "gamg_distributed"),
                                                             ("elast", 4, "rcb", "gamg"), ("poisson", 6, "rcb", "gamg"),
-                                                            ("poisson", 3, "sectors", "reorder"), ("elast", 2, "slabs", "reorder_gamg")])
+                                                            ("poisson", 3, "sectors", "reorder"), ("elast", 2, "slabs", "reorder_gamg"),
+                                                            ("poisson", 2, "slabs", "gamg_single"), ("elast", 3, "yslabs", "gamg_single")])
 def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partition, mode, peer=False):
     """2-3 ranks share cuda:0 (host-staged exchange over gloo): the product's multi-rank device loop against the
     ORACLE -- a direct solve of the oracle-assembled global system in the partition's new numbering, and the oracle's
@@ -390,6 +391,9 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
         mesh_args["reorder"] = True
         mode = "gamg" if mode == "reorder_gamg" else "batched"
         mesh_args["mode"] = mode
+    if mode == "gamg_single":          # the hierarchy across the ranks inside the single-reduction form of the loop: 2 all-reduces per iteration
+        mesh_args["single"] = True
+        mode = "gamg"
     if mode in ("gamg", "gamg_overlap", "gamg_block", "gamg_distributed"):
         # -pc_type gamg on several ranks: one hierarchy across the ranks where the partition allows it (slabs: every coarse dof
         # has at most two holders), else -- or when asked, "gamg_block" -- block Jacobi over the ranks, every block its own hierarchy
@@ -500,7 +504,7 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
             lam_true = [0.0] * nl
             _, its_oracle, reason_oracle, *_ = O.pcg_amg(prob.rowptr, prob.cols, prob.vals, prob.rhs, aggs, rtol=1e-10, cheb_degree=int(deg),
                                                          eig_ratio=float(ratio), coarse_scale=float(scale), fine_degree=int(fdeg),
-                                                         lam_given=lam, lam_true_out=lam_true)
+                                                         lam_given=lam, lam_true_out=lam_true, single_reduction=single)
             # the ranks' bound (sum of the shares' absolute values) is one: never below the assembled matrix's row sums, seldom far above
             assert all(t * (1 - 1e-12) <= g <= 1.6 * t for t, g in zip(lam_true, lam)), (lam_true, lam.tolist())
             assert all(abs(g - t) <= 1e-12 * t for t, g in zip(lam_true[nd:], lam[nd:]))        # assembled levels: the bound itself
@@ -521,6 +525,8 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
               f"{int(d0['its'])} iterations (oracle {its_oracle}, point Jacobi {its_jacobi})")
         assert reason_oracle == 2 and (its_oracle < its_jacobi or kind_name == "elast")     # (tiny beam blocks: no gain to expect)
         its_tol = max(2, its_oracle // 25)          # (runs of a hundred and more iterations on the little beam, whose CG stalls on plateaus: +-4 %)
+        if single:                                   # (p,Ap) by recurrence: the plateaus of the little beam end an iteration or three apart
+            its_tol = max(4, its_oracle // 12)
     if mode == "pbjacobi":
         want = "pbjacobi" if kind_name == "elast" else "jacobi"      # Poisson has no multi-row groups: all ranks fall back
         assert all(str(np.load(tmp_path / f"rank{r}.npz")["pc"]) == want for r in range(world))
@@ -542,7 +548,13 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
             assert int(d["calls"]) < 3 * int(d["its"]) or int(d["its"]) < 8
         else:
             assert int(d["calls"]) >= (2 if idle else 3) * int(d["its"]) if not single else True
-        if single and not peer:                              # ONE all-reduce per step; steps = its + 1 (the last one judges)
+        if single and not peer and mesh_args.get("pc") == "gamg":
+            # the multigrid loop in its single-reduction form: the CG's ONE all-reduce + the cycle's own (the replicated level's
+            # right-hand side / the global dense bottom) per step; the two-reduction loop makes three
+            n_all = sum(1 for s in d["log"] if s[0] == "a")
+            steps = int(d["its"]) + 1
+            assert 2 * steps <= n_all <= 2 * (steps + 4) + 150       # + the tail of the last chunk of 4 + the collectives of the symbolic and numeric set-up
+        elif single and not peer:                            # ONE all-reduce per step; steps = its + 1 (the last one judges)
             n_all = sum(1 for s in d["log"] if s[0] == "a")
             setup_allreduces = 0                              # point Jacobi: the set-up exchanges need no all-reduce
             assert n_all - setup_allreduces <= int(d["its"]) + 1 + 32     # + the tail of the last 32-step chunk
