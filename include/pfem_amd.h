@@ -314,12 +314,13 @@ int pfem_solver_spmv_bytes(pfem_solver *s, int64_t *format_bytes);
 #define PFEM_PC_JACOBI 0
 #define PFEM_PC_NODE_BLOCK_JACOBI 1
 /* GAMG (PETSc: -pc_type gamg, reachable from the reference through KSPSetFromOptions / petsc_options.dat,
- * solverpetsc.F:191-206): plain-aggregation algebraic multigrid, one V(1,1) cycle per CG iteration -- aggregates of up to
- * 8 nodes from three passes of pairing (along the axes of the mesh's lattice when it has one, else pairwise matching on the
- * strength graph), piecewise-constant prolongation (one coarse
- * vector per dof component), Galerkin coarse operators re-summed in every solve, Chebyshev smoothing on D^-1 A with a
- * Gershgorin bound (degree 1 on the assembled matrix, 2 below), dense inverse at the coarsest level.  The reference's own PCBJACOBI/ILU(0) needs 110 / 1 122
- * iterations on BASELINE configs 3 / 4 and point Jacobi 370 / 5 207; this needs 12 / 169 at ~5 SpMV-equivalents each.
+ * solverpetsc.F:191-206): aggregation algebraic multigrid, one V(1,1) cycle per CG iteration -- aggregates of up to 8 nodes
+ * (on a lattice with strong couplings along its axes: bricks of node positions formed in one step; else three passes of
+ * pairing along the lattice's axes, or pairwise matching on the strength graph), Galerkin coarse operators re-summed in
+ * every solve, Chebyshev smoothing on D^-1 A with a Gershgorin bound (degree 1 on the assembled matrix, 2 below), dense
+ * inverse at the coarsest level.  Coarse space: one vector per dof component (piecewise constant) for scalar problems; the
+ * rigid-body modes of every aggregate for displacement problems (pfem_solver_amg_transfer).  The reference's own
+ * PCBJACOBI/ILU(0) needs 110 / 1 122 iterations on BASELINE configs 3 / 4 and point Jacobi 370 / 5 207; this needs 12 / 18.
  * Aggregates are formed from the values of the first solve after a pattern build and reused while the pattern lives
  * (-pc_gamg_reuse_interpolation true).  Several ranks: ONE hierarchy across the ranks (what PCGAMG does under MPI) --
  * aggregates stay inside a rank's owned dofs, coarse operators are the global Galerkin products held sub-assembled like the
@@ -335,12 +336,12 @@ int pfem_solver_amg_info(pfem_solver *s, int max_levels, int *n_levels, int64_t 
                          double *symbolic_ms, double *numeric_ms, int *cheb_degree, int *fine_degree, double *eig_ratio, double *coarse_scale);
 /* coarse dof of every dof of `level` (0 = the assembled matrix); what the oracle's restatement of the cycle is given */
 int pfem_solver_amg_aggregates(pfem_solver *s, int level, int32_t *agg);
-/* Displacement problems (as many dofs per node as space dimensions: the tetra / tria elasticity kinds), one rank, mesh on the
+/* Displacement problems (as many dofs per node as space dimensions: the tetra / tria elasticity kinds), mesh on the
  * device: the coarse space carries the RIGID-BODY MODES of every aggregate (PETSc: MatSetNearNullSpace / PCSetCoordinates
  * ahead of PCGAMG; tetraelasticityparallelimpl1.F:894-902, 993) -- dim translations and 3 (plane: 1) rotations about the
- * aggregate's centroid, so a coarse node has 6 (3) dofs; the beam of BASELINE config 4 needs ~25 iterations instead of 169.
- * What the transfer from `level` to the next one looks like: *rbm = 1 when it carries rotations, dofs per node on this
- * level and the next, the space dimension, and (optional, [3 x n_nodes] as x | y | z) the coordinates of this level's
+ * aggregate's centroid, so a coarse node has 6 (3) dofs; the beam of BASELINE config 4 needs 18 iterations instead of 169.
+ * What the transfer from `level` to the next one looks like (one rank, and the hierarchy across several): *rbm = 1 when it
+ * carries rotations, dofs per node on this level and the next, the space dimension, and (optional, [3 x n_nodes] as x | y | z) the coordinates of this level's
  * nodes (level 0: the mesh nodes in dof order; below: the centroids of the aggregates).  With *rbm = 1
  * pfem_solver_amg_aggregates reports the TRANSLATION part: dof c of node i belongs to coarse dof coarse_bs * aggregate(i) + c. */
 int pfem_solver_amg_transfer(pfem_solver *s, int level, int *rbm, int *fine_bs, int *coarse_bs, int *dim, int64_t *n_nodes, double *node_xyz);
