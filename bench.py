@@ -537,7 +537,7 @@ def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=Fa
     R["amg_layout"] = solver.amgLayout() if R["pc_in_effect"] == "gamg" else None
     R.update(N=int(N), sz=sz, axis=axis, elapsed=elapsed, its=its, reason=reason, rnorm=rnorm, acc=acc, info=info,
              event_overhead_ms=tm["event_overhead_ms"] if tm else 0.0, cinfo=solver.commInfo(),
-             fmt_bytes=solver.spmvFormatBytes(), gap_table=solver.spmvGapTable(), bits=solver.spmvColumnBits(),
+             fmt_bytes=solver.spmvFormatBytes(), gap_table=solver.spmvGapTable(), gap_escapes=solver.spmvGapEscapes(), bits=solver.spmvColumnBits(),
              row_group=solver.spmvRowGroup(), final=solver.commDescribe() if world > 1 else None,
              ms_per_step=elapsed / steps * 1e3, ms_per_iteration=acc["sol_ms"] / steps / max(its, 1))
     R.pop("xyz_free", None)
@@ -681,9 +681,9 @@ def main():
                      " (wave-sliced CSR SpMV + (p,Ap) partials; 4 consecutive rows per lane share one relative column stream of "
                      f"{bits}-bit gaps{tnote}, x read as 32-B quads), rank 0"}.get(
             R["row_group"],
-            (f"pfem::k_spmv16<true, {tname}>" if bits == 16 else "pfem::k_spmv<true>") +
+            ("pfem::k_spmv16e<true>" if (bits == 16 and R.get("gap_escapes")) else f"pfem::k_spmv16<true, {tname}>" if bits == 16 else "pfem::k_spmv<true>") +
             " (wave-sliced CSR SpMV + (p,Ap) partials; %d-bit column %s%s), rank 0"
-            % (bits, "gaps" if bits == 16 else "indices", tnote))
+            % (bits, "gaps" if bits == 16 else "indices", " with escapes to the int32 columns" if R.get("gap_escapes") else tnote))
         axis_name = "xyz"[R["axis"]]
         cross = [m + 1 for d, m in enumerate(nE) if d != R["axis"]]
         partition = None

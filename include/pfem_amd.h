@@ -301,6 +301,10 @@ int pfem_solver_get_spmv_row_group(pfem_solver *s, int *rows_per_lane);
  * table of distinct large gaps when the 16-bit DICTIONARY form is in use (codes >= 0x8000 index the table; at most
  * 256 distinct gaps of 32768 and more), 0 otherwise (literal 16-bit gaps, 32-bit gaps, or another form).            */
 int pfem_solver_get_spmv_gap_table(pfem_solver *s, int *entries);
+/* 1 when the row form streams 16-bit gaps WITH ESCAPES (k_spmv16e: the code 0xffff sends a column to the matrix's int32 column
+ * array -- numberings whose far neighbours are too many and too irregular for the table: partition-renumbered and
+ * curve-ordered meshes; taken when at most a quarter of the entries escape), else 0.  Same bits as every other form.     */
+int pfem_solver_get_spmv_gap_escapes(pfem_solver *s, int *in_use);
 /* bytes one launch of the selected SpMV form moves at best: its own storage (values, gap words / columns, offsets)
  * + x + y, each touched once.  (The judged figure 12 nnz + 20 N of SURVEY 8d is the plain int32-CSR equivalent.)   */
 int pfem_solver_spmv_bytes(pfem_solver *s, int64_t *format_bytes);

@@ -253,6 +253,7 @@ struct pfem_solver {
     DevBuf<double> d_vals;
     // SpMV-only 16-bit column-gap representation (k_spmv16), when every gap fits
     bool cols16 = false;
+    bool cols16_escape = false;    // ... with the code 0xffff standing for "read this column from the int32 array" (k_spmv16e; row form only)
     int spmv_format = PFEM_SPMV_AUTO;
     DevBuf<int32_t> d_col0;
     DevBuf<uint32_t> d_dwords;
@@ -1663,6 +1664,7 @@ namespace {
 int build_cols16(pfem_solver *s)
 {
     s->cols16 = false;
+    s->cols16_escape = false;
     s->row_dict = false;
     if (s->n_slices == 0) return PFEM_OK;
     DevBuf<int64_t> words;
@@ -1708,7 +1710,30 @@ int build_cols16(pfem_solver *s)
             s->row_dict = overflow == 0;
         }
     }
-    if (overflow) {     // some gap needs more than 16 bits and the table does not apply: keep the int32 kernel
+    if (overflow && !std::getenv("PFEM_DEBUG_NO_GAP_ESCAPES")) {
+        // Large gaps too many and too irregular for the table (partition-renumbered and curve-ordered numberings: every line of
+        // a part ends at a neighbour a million rows away): literal 16-bit gaps with an ESCAPE code -- 0xffff = "this column
+        // comes from the int32 column array", which the matrix holds anyway --, taken when at most a quarter of the entries
+        // escape (10 + 4 f bytes per nonzero against 12)
+        DevBuf<unsigned long long> d_esc;
+        PFEM_TRY(d_esc.alloc(1));
+        PFEM_HIP(hipMemsetAsync(d_esc.p, 0, sizeof(unsigned long long), s->stream));
+        hipLaunchKernelGGL(k_cols16_fill_escape, dim3(grid_for(s->n_slices * 64)), dim3(kBlock), 0, s->stream, s->sell(), s->d_slice_doff.p,
+                           s->d_col0.p, s->d_dwords.p, d_esc.p);
+        PFEM_TRY(check_kernel("k_cols16_fill_escape"));
+        unsigned long long esc = 0;
+        PFEM_HIP(hipMemcpyAsync(&esc, d_esc.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+        if (std::getenv("PFEM_SPMV_VERBOSE"))
+            std::fprintf(stderr, "  16-bit gaps with escapes: %.2f %% of the stored entries escape to their int32 column\n",
+                         100.0 * static_cast<double>(esc) / static_cast<double>(std::max<int64_t>(s->stored, 1)));
+        if (4 * esc <= static_cast<unsigned long long>(s->stored)) {
+            s->cols16 = true;
+            s->cols16_escape = true;
+            return PFEM_OK;
+        }
+    }
+    if (overflow) {     // some gap needs more than 16 bits and neither the table nor the escape form applies: keep the int32 kernel
         s->d_col0.release();
         s->d_dwords.release();
         s->d_slice_doff.release();
@@ -1726,7 +1751,7 @@ int build_groups(pfem_solver *s)
     s->n_groups = 0;
     s->group_vals_stale = true;
     const int64_t n = s->n_loc;
-    if (!s->cols16 || n < 2 || n > INT_MAX) return PFEM_OK;
+    if (!s->cols16 || s->cols16_escape || n < 2 || n > INT_MAX) return PFEM_OK;
     DevBuf<int32_t> run_start;
     DevBuf<char> flag, temp;
     DevBuf<int> d_num;
@@ -1854,6 +1879,10 @@ int build_rel_groups(pfem_solver *s)
     // form, (8 + 4) with int32 columns
     const double rel_bytes = static_cast<double>(tot_e) * (8.0 * kRelRows + (gap32 ? 4.0 : 2.0));
     const double row_bytes = static_cast<double>(s->stored) * (s->cols16 ? 10.0 : 12.0);
+    if (std::getenv("PFEM_SPMV_VERBOSE"))
+        std::fprintf(stderr, "  relative row groups: %lld union entries for %lld stored (%.2f per 4 rows' entry), %s gaps, %.0f MB against %.0f MB in the row form%s\n",
+                     static_cast<long long>(tot_e), static_cast<long long>(s->stored), 4.0 * tot_e / std::max<int64_t>(s->stored, 1),
+                     gap32 ? "32-bit" : (dict ? "16-bit + table" : "16-bit"), rel_bytes / 1e6, row_bytes / 1e6, (overflow & 2) ? " (first column outside int32)" : "");
     if ((overflow & 2) || rel_bytes > 0.95 * row_bytes) {
         s->d_rslice_off.release();
         s->d_rslice_doff.release();
@@ -1973,7 +2002,10 @@ void launch_spmv(pfem_solver *s, const double *x, double *y, int64_t n_dot, doub
         else hipLaunchKernelGGL((k_spmvr<WITH_DOT, false>), grid, block, 0, s->stream, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
     } else if (s->cols16 && s->spmv_format != PFEM_SPMV_INT32) {
         Sell16Dev C{s->d_col0.p, s->d_dwords.p, s->d_slice_doff.p, s->d_row_gap_table.p};
-        if (s->row_dict) {
+        if (s->cols16_escape) {
+            if (e0) hipExtLaunchKernelGGL((k_spmv16e<WITH_DOT>), grid, block, 0, s->stream, e0, e1, 0, A, C, x, y, n_dot, partial, ctl, sel);
+            else hipLaunchKernelGGL((k_spmv16e<WITH_DOT>), grid, block, 0, s->stream, A, C, x, y, n_dot, partial, ctl, sel);
+        } else if (s->row_dict) {
             if (e0) hipExtLaunchKernelGGL((k_spmv16<WITH_DOT, true>), grid, block, 0, s->stream, e0, e1, 0, A, C, x, y, n_dot, partial, ctl, sel);
             else hipLaunchKernelGGL((k_spmv16<WITH_DOT, true>), grid, block, 0, s->stream, A, C, x, y, n_dot, partial, ctl, sel);
         } else if (e0) hipExtLaunchKernelGGL((k_spmv16<WITH_DOT, false>), grid, block, 0, s->stream, e0, e1, 0, A, C, x, y, n_dot, partial, ctl, sel);
@@ -1991,6 +2023,14 @@ extern "C" int pfem_solver_get_spmv_format(pfem_solver *s, int *bits_per_column)
     if (!s || !bits_per_column) return PFEM_ERR_ARG;
     if (s->use_rel()) *bits_per_column = s->rel_gap32 ? 32 : 16;
     else *bits_per_column = (s->cols16 && s->spmv_format != PFEM_SPMV_INT32) ? 16 : 32;
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_get_spmv_gap_escapes(pfem_solver *s, int *in_use)
+{
+    if (!s || !in_use) return PFEM_ERR_ARG;
+    if (!s->have_pattern) return PFEM_ERR_STATE;
+    *in_use = (!s->use_rel() && !s->use_grouped() && s->cols16 && s->cols16_escape && s->spmv_format != PFEM_SPMV_INT32) ? 1 : 0;
     return PFEM_OK;
 }
 

@@ -1505,6 +1505,121 @@ __global__ void __launch_bounds__(kBlock) k_spmv16(SellDev A, Sell16Dev C, const
     }
 }
 
+// The same with ESCAPES: a gap that does not fit 16 bits is stored as 0xffff and the column is read from the matrix's own
+// int32 column array instead -- numberings whose far neighbours are many and irregular (the reference's partition
+// renumbering: every line of a part ends at a neighbour a million rows away; curve-ordered meshes) keep 10 bytes per nonzero
+// for all but the escaping entries.  Same products in the same order as k_spmv / k_spmv16.
+__global__ void __launch_bounds__(kBlock) k_cols16_fill_escape(SellDev A, const int64_t *slice_doff, int32_t *col0, uint32_t *dwords,
+                                                                unsigned long long *escapes)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t s = r >> 6;
+    if (s >= A.n_slices) return;
+    const int lane = static_cast<int>(r & 63);
+    const int64_t off = A.slice_off[s];
+    const int width = static_cast<int>((A.slice_off[s + 1] - off) >> 6);
+    const int len = r < A.n_rows ? A.rowlen[r] : 0;
+    const int32_t *cp = A.cols + off + lane;
+    int prev = len > 0 ? cp[0] : 0;
+    col0[r] = prev;
+    uint32_t *wp = dwords + slice_doff[s] + lane;
+    unsigned esc = 0;
+    for (int j = 0; 2 * j + 1 < width; ++j) {
+        uint32_t w = 0;
+        for (int h = 0; h < 2; ++h) {
+            const int k = 2 * j + 1 + h;
+            uint32_t gap = 0;                      // pads: gap 0 (the product is with a stored zero)
+            if (k < len) {
+                const int c = cp[64 * k];
+                const int64_t g = static_cast<int64_t>(c) - prev;
+                if (g < 0 || g >= 0xffff) { gap = 0xffffu; ++esc; }
+                else gap = static_cast<uint32_t>(g);
+                prev = c;
+            }
+            w |= gap << (16 * h);
+        }
+        wp[64LL * j] = w;
+    }
+    if (esc) atomicAdd(escapes, static_cast<unsigned long long>(esc));
+}
+template <int W>
+__device__ __forceinline__ void spmv16e_trip(const double *__restrict__ vp, const uint32_t *__restrict__ wp, const int32_t *__restrict__ cp,
+                                             const double *__restrict__ x, int &j, int &c, double &acc)
+{
+    uint32_t w[W];
+    double v[2 * W], xv[2 * W];
+#pragma unroll
+    for (int t = 0; t < W; ++t) w[t] = __builtin_nontemporal_load(wp + 64 * (j + t));
+#pragma unroll
+    for (int t = 0; t < 2 * W; ++t) v[t] = __builtin_nontemporal_load(vp + 64 * (2 * j + 1 + t));
+    // the escaped columns first, all of them in flight together (their addresses do not depend on the running column), then the
+    // running sum: a load inside the sum would wait for memory once per escape
+    int e[2 * W];
+#pragma unroll
+    for (int t = 0; t < 2 * W; ++t) {
+        const uint32_t code = (t & 1) ? (w[t >> 1] >> 16) : (w[t >> 1] & 0xffffu);
+        e[t] = 0;
+        if (code == 0xffffu) e[t] = __builtin_nontemporal_load(cp + 64 * (2 * j + 1 + t));
+    }
+    int cc = c;
+#pragma unroll
+    for (int t = 0; t < 2 * W; ++t) {
+        const uint32_t code = (t & 1) ? (w[t >> 1] >> 16) : (w[t >> 1] & 0xffffu);
+        cc = code == 0xffffu ? e[t] : cc + static_cast<int>(code);
+        xv[t] = x[cc];
+    }
+#pragma unroll
+    for (int t = 0; t < 2 * W; ++t) acc = __builtin_fma(v[t], xv[t], acc);
+    c = cc;
+    j += W;
+}
+template <bool WITH_DOT>
+__global__ void __launch_bounds__(kBlock) k_spmv16e(SellDev A, Sell16Dev C, const double *__restrict__ x, double *__restrict__ y,
+                                                     int64_t n_dot, double *partial, const CgCtl *ctl, SliceSel sel)
+{
+    __shared__ double sm[4];
+    if (WITH_DOT && ctl->flag != 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t s = pick_slice(sel, (static_cast<int64_t>(blockIdx.x) << 2) + wave, A.n_slices);
+    double dot = 0.0;
+    if (s < A.n_slices) {
+        const int64_t off = A.slice_off[s];
+        const int width = static_cast<int>((A.slice_off[s + 1] - off) >> 6);
+        const double *__restrict__ vp = A.vals + off + lane;
+        const int32_t *__restrict__ cp = A.cols + off + lane;
+        const uint32_t *__restrict__ wp = C.dwords + C.slice_doff[s] + lane;
+        int c = __builtin_nontemporal_load(C.col0 + (s << 6) + lane);
+        double acc = 0.0;
+        if (width > 0) acc = __builtin_nontemporal_load(vp) * x[c];
+        const int nw = width / 2;
+        int j = 0;
+        while (2 * (j + 8) < width) spmv16e_trip<8>(vp, wp, cp, x, j, c, acc);
+        if (2 * (j + 4) < width) spmv16e_trip<4>(vp, wp, cp, x, j, c, acc);
+        if (2 * (j + 2) < width) spmv16e_trip<2>(vp, wp, cp, x, j, c, acc);
+        for (; j < nw; ++j) {
+            const uint32_t w0 = __builtin_nontemporal_load(wp + 64 * j);
+            const uint32_t lo = w0 & 0xffffu, hi = w0 >> 16;
+            const int c0 = lo == 0xffffu ? __builtin_nontemporal_load(cp + 64 * (2 * j + 1)) : c + static_cast<int>(lo);
+            acc = __builtin_fma(__builtin_nontemporal_load(vp + 64 * (2 * j + 1)), x[c0], acc);
+            int c1 = c0;
+            if (2 * j + 2 < width) {
+                c1 = hi == 0xffffu ? __builtin_nontemporal_load(cp + 64 * (2 * j + 2)) : c0 + static_cast<int>(hi);
+                acc = __builtin_fma(__builtin_nontemporal_load(vp + 64 * (2 * j + 2)), x[c1], acc);
+            }
+            c = c1;
+        }
+        const int64_t row = (s << 6) + lane;
+        if (row < A.n_rows) {
+            y[row] = acc;
+            if (WITH_DOT && row < n_dot) dot = x[row] * acc;
+        }
+    }
+    if (WITH_DOT) {
+        const double t = block_sum(dot, sm);
+        if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Row-grouped SpMV (problems with several dofs per node).  Consecutive rows with IDENTICAL column
 // sets -- the dof rows of one node -- form a group of up to kGroupRows rows served by ONE lane: the

@@ -203,6 +203,12 @@ class PetscSolver:
         L.check(L.lib().pfem_solver_get_spmv_gap_table(self._h, C.byref(b)), "pfem_solver_get_spmv_gap_table")
         return b.value
 
+    def spmvGapEscapes(self):
+        """True when the row form streams 16-bit gaps with escapes to the int32 column array (k_spmv16e)."""
+        b = C.c_int(0)
+        L.check(L.lib().pfem_solver_get_spmv_gap_escapes(self._h, C.byref(b)), "pfem_solver_get_spmv_gap_escapes")
+        return bool(b.value)
+
     def setPreconditioner(self, pc):
         """"jacobi" (default; PCJACOBI), "pbjacobi" (node-block Jacobi, PETSc's -pc_type pbjacobi) or "gamg" (plain-aggregation
         multigrid V-cycle, PETSc's -pc_type gamg; one rank)."""

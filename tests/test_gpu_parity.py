@@ -744,14 +744,18 @@ def test_pattern_built_in_element_ranges(name, per_range, request, monkeypatch):
     assert reason == 2
 
 
-@pytest.mark.parametrize("table", [True, False])
+@pytest.mark.parametrize("table", [True, False, "escapes"])
 def test_row_forms_beyond_16bit_gaps(table, monkeypatch):
     """Three dofs per node and a numbering plane of 151 x 151 nodes: the gap to the next plane's columns is 68 403 dofs,
     more than a literal 16-bit gap holds.  The row form and the 3-row form keep their 16-bit streams through the table of
-    distinct large gaps (k_spmv16 / k_spmvg <., true>); without it (round 1, and whenever the table overflows) the solver
-    drops to int32 columns per row.  Same products, same order: bit-identical y; K, F equal the oracle's; the solve agrees."""
+    distinct large gaps (k_spmv16 / k_spmvg <., true>); without it (whenever the table overflows) the row form escapes the large
+    gaps to the int32 column array (k_spmv16e; "escapes"), and without that either (round 1) the solver drops to int32 columns per row.  Same products, same order: bit-identical y; K, F equal the oracle's; the solve agrees."""
+    escapes = table == "escapes"         # no table, but gaps beyond 16 bits may escape to the int32 column (k_spmv16e): 16-bit row form again
+    table = table is True
     if not table:
         monkeypatch.setenv("PFEM_DEBUG_NO_ROW_GAP_TABLE", "1")
+        if not escapes:
+            monkeypatch.setenv("PFEM_DEBUG_NO_GAP_ESCAPES", "1")
     mesh = H.gen_box_tets(-0.5, 0.5, 150, 0.0, 1.0, 150, -0.01, 0.01, 1, bc_mode=1, ndof=3)
     s, dm = _device_problem(pf.ELAST_TET, mesh, H.ELAST_ELEMDATA)
     rng = np.random.default_rng(5)
@@ -766,8 +770,11 @@ def test_row_forms_beyond_16bit_gaps(table, monkeypatch):
         assert s.spmvRowGroup() != 3          # no 3-row form without 16-bit row streams (the relative groups may step in)
     assert np.array_equal(s.spmv(x), y32)
     s.setSpmvFormat("gaps16")                                   # one row per lane
-    assert (s.spmvRowGroup(), s.spmvColumnBits()) == ((1, 16) if table else (1, 32))
+    assert (s.spmvRowGroup(), s.spmvColumnBits()) == ((1, 16) if (table or escapes) else (1, 32))
     assert np.array_equal(s.spmv(x), y32)
+    assert s.spmvGapEscapes() == bool(escapes)
+    if escapes:
+        assert s.spmvGapTable() == 0
     if table:
         nnz = s.matrixInfo()["nnz"]
         s.setSpmvFormat("grouped")                              # ("auto" keeps a system this small in the row form)
