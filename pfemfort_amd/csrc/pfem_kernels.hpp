@@ -215,6 +215,43 @@ __global__ void __launch_bounds__(kBlock) k_morton_keys(MeshDev m, int64_t n_own
         if (l >= 0 && l < n_owned) keys[l] = key;          // every visit of a dof writes the same value
     }
 }
+// ---- the nodes follow their dofs (internal renumbering): a node's key = its smallest internal dof, nodes without dofs last
+__global__ void __launch_bounds__(kBlock) k_node_first_dof(MeshDev m, unsigned long long *__restrict__ key)
+{
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (t >= m.nElem * m.npe) return;
+    const int64_t e = t % m.nElem;
+    const int a = static_cast<int>(t / m.nElem);
+    const int32_t nd = m.conn[a * m.nElem + e];
+    for (int d = 0; d < m.ndof; ++d) {
+        const int32_t l = m.edof[(a * m.ndof + d) * m.nElem + e];
+        if (l >= 0) atomicMin(&key[nd], static_cast<unsigned long long>(l));
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_relabel_nodes(int32_t *__restrict__ conn, int64_t count, const int32_t *__restrict__ nperm)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < count) conn[i] = nperm[conn[i]];
+}
+// out[c][new] = in[c][order[new]] for c < planes (SoA node arrays)
+__global__ void __launch_bounds__(kBlock) k_gather_nodes(int64_t n, int planes, const int32_t *__restrict__ order, const double *__restrict__ in,
+                                                          double *__restrict__ out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int64_t o = order[i];
+    for (int c = 0; c < planes; ++c) out[c * n + i] = in[c * n + o];
+}
+// (node-major arrays: solnApplied[node * ndof + d])
+__global__ void __launch_bounds__(kBlock) k_gather_node_rows(int64_t n, int w, const int32_t *__restrict__ order, const double *__restrict__ in,
+                                                              double *__restrict__ out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int64_t o = order[i];
+    for (int c = 0; c < w; ++c) out[i * w + c] = in[o * w + c];
+}
+
 __global__ void __launch_bounds__(kBlock) k_perm_from_order(int64_t n, const int32_t *__restrict__ order, int32_t *__restrict__ perm)
 {
     const int64_t k = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;

@@ -1030,7 +1030,7 @@ def test_internal_renumbering_is_invisible_at_the_boundary(kind_name, monkeypatc
         rowptr, cols, vals = s.getCSR()
         rng = np.random.default_rng(3)
         x = rng.standard_normal(dm.size_global)
-        _, _, edof_l, _ = s.downloadMesh()
+        conn_d, xyz_d, edof_l, soln_d = s.downloadMesh()
         s.setTolerances(rtol=1e-10, maxits=20000)
         its, reason, _ = s.factoriseAndSolve()
         u = s.getSolution()
@@ -1039,11 +1039,11 @@ def test_internal_renumbering_is_invisible_at_the_boundary(kind_name, monkeypatc
         ug = s.getSolution()
         agg0 = s.amgAggregates(0, dm.size_global)
         tr0 = s.amgTransfer(0)
-        out[reorder] = dict(tr0=tr0, rowptr=rowptr, cols=cols, vals=vals, rhs=s.getRHS(), y=s.spmv(x), edof=edof_l, its=its, u=u, its_g=its_g, ug=ug,
+        out[reorder] = dict(tr0=tr0, conn=conn_d, xyz=xyz_d, soln=soln_d, rowptr=rowptr, cols=cols, vals=vals, rhs=s.getRHS(), y=s.spmv(x), edof=edof_l, its=its, u=u, its_g=its_g, ug=ug,
                             agg0=agg0, bits=s.spmvColumnBits(), reasons=(reason, reason_g))
         s.free()
     a, b = out["0"], out["auto"]
-    for k in ("rowptr", "cols", "vals", "rhs", "edof"):
+    for k in ("rowptr", "cols", "vals", "rhs", "edof", "conn", "xyz", "soln"):        # (the nodes are renumbered inside too: invisible as well)
         assert np.array_equal(a[k], b[k]), k
     prob = O.setup_problem(okind, O.Mesh(mesh.xyz, mesh.conn, mesh.bc_node, mesh.bc_dof, mesh.bc_val))
     assert np.array_equal(b["rowptr"], prob.rowptr) and np.array_equal(b["cols"], prob.cols)
