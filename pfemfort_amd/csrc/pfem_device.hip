@@ -292,6 +292,8 @@ struct pfem_solver {
     // the row form (0xff: none), and whether the copy holds the values of the last assembly (else k_rel_vals re-packs it)
     DevBuf<uint8_t> d_relk;
     bool rel_vals_current = false;
+    DevBuf<int32_t> d_row_group;   // [n_loc] node group of every row (k_spmvg's copy written by the elasticity gather kernel itself)
+    bool grp_vals_current = false;
     bool use_rel() const
     {
         return relgrouped && !use_grouped() &&
@@ -1470,6 +1472,7 @@ int zero_values(pfem_solver *s, bool rows_overwritten = false)
     PFEM_HIP(hipMemsetAsync(s->d_rhs.p, 0, sizeof(double) * static_cast<size_t>(std::max<int64_t>(s->n_loc, 1)), s->stream));
     s->rhs_summed = false;
     s->rel_vals_current = false;            // (whoever writes the values next says so again if it writes both forms)
+    s->grp_vals_current = false;
     return PFEM_OK;
 }
 
@@ -1493,7 +1496,7 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
     // setZero, solverpetsc.F:222-246 (the value array needs no clearing when every row is stored whole by the gather
     // kernels; hub rows, if any, are accumulated with atomics and do)
     PFEM_TRY(zero_values(s, gather && (use_lds || elast_rows) && s->n_hubs == 0));
-    bool wrote_rel = false;
+    bool wrote_rel = false, wrote_grp = false;
     if (gather) {
         // gather form: one thread per node, no atomics, bit-reproducible
         const dim3 grid(grid_for(m.nNode)), block(kBlock);
@@ -1542,7 +1545,13 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
         case PFEM_ELAST_TET:
             PFEM_TRY(allow_lds(reinterpret_cast<const void *>(&k_gather_elast_rows)));
             // (plain block order: the XCD-contiguous one measured 3 % slower on the beam, 1.605 against 1.56 ms)
-            hipLaunchKernelGGL(k_gather_elast_rows, rgrid, rblock, rlds, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, ifl, nrow, s->d_err.p, 0u);
+            {
+                const bool bothg = s->use_grouped() && s->d_row_group.p && s->n_hubs == 0 && !std::getenv("PFEM_DEBUG_NO_REL_DIRECT");
+                hipLaunchKernelGGL(k_gather_elast_rows, rgrid, rblock, rlds, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, ifl, nrow, s->d_err.p, 0u,
+                                   bothg ? static_cast<const int32_t *>(s->d_row_group.p) : nullptr, bothg ? static_cast<const int32_t *>(s->d_group_row0.p) : nullptr,
+                                   bothg ? static_cast<const int64_t *>(s->d_gslice_off.p) : nullptr, bothg ? s->d_gvals.p : nullptr);
+                wrote_grp = bothg;
+            }
             break;
         case PFEM_ELAST_TRIA:
             PFEM_TRY(allow_lds(reinterpret_cast<const void *>(&k_gather_elast2d_rows)));
@@ -1585,6 +1594,7 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
     if (err) return err;
     s->host_values_dirty = false;
     s->rel_vals_current = wrote_rel;
+    s->grp_vals_current = wrote_grp;
     s->status = PFEM_ASSEMBLY_OK;
     return PFEM_OK;
 }
@@ -1883,6 +1893,16 @@ int build_groups(pfem_solver *s)
     PFEM_HIP(hipMemsetAsync(s->d_err.p, 0, sizeof(int), s->stream));
     PFEM_HIP(hipStreamSynchronize(s->stream));
     s->grouped = miss == 0;          // a gap missing from the table: the row form stays (never wrong columns)
+    s->grp_vals_current = false;
+    s->d_row_group.release();
+    if (s->grouped && !std::getenv("PFEM_DEBUG_NO_REL_DIRECT")) {       // for an assembly that writes this copy itself; its zero padding is set here, once
+        PFEM_TRY(s->d_row_group.alloc(static_cast<size_t>(n)));
+        hipLaunchKernelGGL(k_row_group_index, dim3(grid_for(s->n_groups)), dim3(kBlock), 0, s->stream, static_cast<const int32_t *>(s->d_group_row0.p),
+                           s->n_groups, s->d_row_group.p);
+        PFEM_TRY(check_kernel("k_row_group_index"));
+        PFEM_HIP(hipMemsetAsync(s->d_gvals.p, 0, sizeof(double) * static_cast<size_t>(std::max<int64_t>(tot_e, 1)) * kGroupRows, s->stream));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+    }
     return PFEM_OK;
 }
 
@@ -2005,7 +2025,7 @@ int build_rel_groups(pfem_solver *s)
 // wrote the relative-group copy itself and nothing has touched the values since.)
 inline void mark_group_vals(pfem_solver *s)
 {
-    s->group_vals_stale = !(s->use_rel() && s->rel_vals_current);
+    s->group_vals_stale = !((s->use_rel() && s->rel_vals_current) || (s->use_grouped() && s->grp_vals_current));
 }
 // grouped copy of the current matrix values (the row form is what assembly writes)
 int refresh_group_vals(pfem_solver *s)
@@ -3868,6 +3888,7 @@ extern "C" int pfem_solver_solve(pfem_solver *s, int *its, int *reason, double *
             PFEM_TRY(dv.alloc(static_cast<size_t>(s->nnz)));
             PFEM_HIP(hipMemcpyAsync(dv.p, s->h_vals.data(), sizeof(double) * s->nnz, hipMemcpyHostToDevice, s->stream));
             s->rel_vals_current = false;
+            s->grp_vals_current = false;
             hipLaunchKernelGGL(k_csr_vals_to_sell, dim3(grid_for(s->n_loc)), dim3(kBlock), 0, s->stream, s->sell(), s->d_rowptr.p, dv.p);
             PFEM_TRY(check_kernel("k_csr_vals_to_sell"));
             PFEM_HIP(hipStreamSynchronize(s->stream));

@@ -931,7 +931,11 @@ __global__ void __launch_bounds__(kBlock) k_gather_elast_rows(MeshDev m, SellDev
                                                                const int32_t *__restrict__ inc_cnt,
                                                                const int4 *__restrict__ inc_rec,
                                                                const uint16_t *__restrict__ inc_flags,
-                                                               const int32_t *__restrict__ node_row, int *err, unsigned xcd_per)
+                                                               const int32_t *__restrict__ node_row, int *err, unsigned xcd_per,
+                                                               const int32_t *__restrict__ row_group = nullptr,
+                                                               const int32_t *__restrict__ group_row0 = nullptr,
+                                                               const int64_t *__restrict__ gslice_off = nullptr,
+                                                               double *__restrict__ gvals = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];
     const int T = blockDim.x;
@@ -1003,6 +1007,17 @@ __global__ void __launch_bounds__(kBlock) k_gather_elast_rows(MeshDev m, SellDev
         }
         facc += f;
     }
+    if (gvals) {
+        // both forms: the row form, and the node-group copy the CG's SpMV streams (k_spmvg: group = the node's rows, plane =
+        // row - first row of the group; the zero padding of that copy was set when the groups were built)
+        const int64_t g = row_group[row];
+        double *gp = gvals + 3 * gslice_off[g >> 6] + (g & 63) + 64 * (row - group_row0[g]);          // (3 = kGroupRows)
+        for (int k = 0; k < len; ++k) {
+            const double v = acc[k * T];
+            A.vals[base + (static_cast<int64_t>(k) << 6)] = v;
+            gp[3LL * 64 * k] = v;
+        }
+    } else
     for (int k = 0; k < len; ++k) A.vals[base + (static_cast<int64_t>(k) << 6)] = acc[k * T];
     rhs[row] = facc;
 }
