@@ -126,23 +126,80 @@ extern "C" int pfem_device_memory(int device, int64_t *free_bytes, int64_t *tota
 // ---------------------------------------------------------------------------
 namespace {
 
-// (A per-process pool of freed blocks was tried in round 3 against the multi-second hipMalloc stalls of config 5's
-// symbolic phases -- profiles/r03/symbolic_phase_stalls_cfg5.txt -- and dropped: the stalls sit in the FIRST allocation of
-// a size, which a pool cannot avoid.)
+// A per-process pool of freed device blocks.  On this stack hipFree of a multi-GB block followed by hipMalloc of another one
+// now and then takes SECONDS (config 5: the pattern build is 0.78 s in a fresh process and 6.6 s when the same process has
+// built and freed one before -- tools/r04/pattern_time.sh; the symbolic phase of the multigrid set-up caught 1.5 s stalls the
+// same way).  Blocks of 32 MiB and more go back to the pool instead of the driver and are handed out again when a request fits
+// within a factor of two; the pool holds at most PFEM_POOL_GB (default 64) and is emptied by pool_trim() -- at the end of
+// every solve (the set-up phases that churn memory are over by then) and at solver destroy -- and when the device runs out of memory.  hipFree used to synchronise the device on the way: the pool does the same before it
+// takes a block back, so a block is never reused while a kernel of another stream may still touch it.
+struct DevPool {
+    struct Block { void *p; size_t bytes; int device; };
+    std::vector<Block> blocks;
+    size_t held = 0;
+    static constexpr size_t kMinBytes = 32ull << 20;
+    static size_t cap_bytes()
+    {
+        const char *e = std::getenv("PFEM_POOL_GB");
+        const double gb = e ? std::atof(e) : 64.0;
+        return gb > 0.0 ? static_cast<size_t>(gb * (1ull << 30)) : 0;
+    }
+    void *take(size_t bytes, size_t *got)
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        size_t best = blocks.size();
+        for (size_t i = 0; i < blocks.size(); ++i)
+            if (blocks[i].device == dev && blocks[i].bytes >= bytes && blocks[i].bytes <= 2 * bytes && (best == blocks.size() || blocks[i].bytes < blocks[best].bytes)) best = i;
+        if (best == blocks.size()) return nullptr;
+        void *p = blocks[best].p;
+        *got = blocks[best].bytes;
+        held -= blocks[best].bytes;
+        blocks.erase(blocks.begin() + static_cast<std::ptrdiff_t>(best));
+        return p;
+    }
+    bool give(void *p, size_t bytes)
+    {
+        const size_t cap = cap_bytes();
+        if (bytes < kMinBytes || bytes > cap) return false;
+        (void)hipDeviceSynchronize();             // (what hipFree did on its way)
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        blocks.push_back({p, bytes, dev});
+        held += bytes;
+        while (held > cap && !blocks.empty()) {       // oldest first
+            (void)hipFree(blocks.front().p);
+            held -= blocks.front().bytes;
+            blocks.erase(blocks.begin());
+        }
+        return true;
+    }
+    void trim()
+    {
+        for (const Block &b : blocks) (void)hipFree(b.p);
+        blocks.clear();
+        held = 0;
+    }
+    ~DevPool() { blocks.clear(); }                // (process exit: the runtime may be gone already; nothing to hand back)
+};
+inline DevPool &dev_pool() { static DevPool pool; return pool; }
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    size_t held_bytes = 0;       // size of the block behind p (a pooled block may be larger than n elements)
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
-    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
+    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(held_bytes, o.held_bytes); }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p && !dev_pool().give(p, held_bytes)) (void)hipFree(p);
         p = nullptr;
         n = 0;
+        held_bytes = 0;
     }
     // keep the block when it is large enough already (work buffers that are reused level after level)
     int reserve(size_t count) { return (p && n >= count) ? PFEM_OK : alloc(count); }
@@ -150,18 +207,34 @@ struct DevBuf {
     {
         release();
         if (count == 0) count = 1;
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        const size_t bytes = count * sizeof(T);
+        if (bytes >= DevPool::kMinBytes) {
+            size_t got = 0;
+            if (void *q = dev_pool().take(bytes, &got)) {
+                p = static_cast<T *>(q);
+                n = count;
+                held_bytes = got;
+                return PFEM_OK;
+            }
+        }
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), bytes);
+        if (e != hipSuccess && dev_pool().held > 0) {          // out of memory with blocks in the pool: hand them back and try again
+            (void)hipGetLastError();
+            dev_pool().trim();
+            e = hipMalloc(reinterpret_cast<void **>(&p), bytes);
+        }
         if (e != hipSuccess) {
             (void)hipGetLastError();
-            set_last_error("hipMalloc of " + std::to_string(count * sizeof(T)) + " bytes failed: " + hipGetErrorString(e));
+            set_last_error("hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
             p = nullptr;
             return PFEM_ERR_NOMEM;
         }
         n = count;
+        held_bytes = bytes;
         return PFEM_OK;
     }
 };
-inline void pool_trim() {}
+inline void pool_trim() { dev_pool().trim(); }
 
 #include "pfem_amg_types.hpp"
 
@@ -1402,7 +1475,7 @@ extern "C" int pfem_pattern_build(pfem_solver *s)
     PFEM_HIP(hipEventRecord(s->ev1, s->stream));
     PFEM_TRY(elapsed(s, &s->tm.pattern_ms));
     keys.release();
-    pool_trim();                 // the symbolic phase's temporaries go back to the device
+    // (the phase's temporaries stay in the pool: the preconditioner's set-up and the next build take them from there)
     return PFEM_OK;
 }
 
@@ -3879,6 +3952,9 @@ extern "C" int pfem_solver_solve(pfem_solver *s, int *its, int *reason, double *
     }
     if (!s->have_pattern) return PFEM_ERR_STATE;
     PFEM_TRY(use_device(s));
+    // the set-up phases are over when a solve returns (also with an error): what they left in the pool goes back to the
+    // device, which other ranks or other processes may share
+    struct TrimAtExit { ~TrimAtExit() { pool_trim(); } } trim_at_exit;
     PFEM_HIP(hipEventRecord(s->ev0, s->stream));
     if (s->host_values_dirty && !s->have_mesh) {
         // MatAssemblyBegin/End + VecAssemblyBegin/End (solverpetsc.F:447-468): push the

@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 TAG=${1:-suite}
-( timeout 2400 python -m pytest tests -m gpu -x -q --durations=12 2>&1 | tail -40 ) > $OUT/pytest_gpu_$TAG.log 2>&1
+( timeout 2400 python -m pytest tests -m gpu -x -q --durations=12 2>&1 | tail -120 ) > $OUT/pytest_gpu_$TAG.log 2>&1
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ) > $OUT/smoke_$TAG.log 2>&1
 ( timeout 900 python bench.py --steps 20 --warmup 5 2>$OUT/bench_$TAG.err | tail -1 ) > $OUT/bench_$TAG.json
 tail -25 $OUT/pytest_gpu_$TAG.log; cat $OUT/smoke_$TAG.log; cut -c1-400 $OUT/bench_$TAG.json
