@@ -279,6 +279,92 @@ __global__ void __launch_bounds__(kBlock) k_lat_run_scatter(int64_t n, const uin
     }
     if (i == n) start[rank[n]] = n;
 }
+// The same maps without any sort, from the member lists: one thread per COARSE row walks its (at most 8) member rows twice.
+// First walk (k_lat_codes_count): how many stored entries fall into each of the 27 neighbouring bricks -- per-thread counters in
+// LDS, [code][thread] -- giving the row's number of coarse entries and of (entry, slot) pairs; after two scans over the coarse
+// rows the second walk (k_lat_codes_fill) writes the coarse entries' keys (ascending offset code = ascending coarse column: the
+// aggregates are numbered in the bricks' z, y, x order), the start of every entry's slot list, and the slots themselves --
+// member rows ascending, entries of a row ascending: a fixed summation order for the Galerkin product.
+constexpr int kLatCodes = 27;
+__device__ __forceinline__ int lat_code(const LatBricks &B, int32_t pj, int bix, int biy, int biz)
+{
+    const int dx = ((pj & 0x3ff) >> B.shift[0]) - bix, dy = (((pj >> 10) & 0x3ff) >> B.shift[1]) - biy, dz = (((pj >> 20) & 0x3ff) >> B.shift[2]) - biz;
+    return (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1);
+}
+__global__ void __launch_bounds__(kBlock) k_lat_codes_count(SellDev A, const int32_t *__restrict__ pos, LatBricks B, int64_t na,
+                                                             const int32_t *__restrict__ mem_ptr, const int32_t *__restrict__ mem_idx,
+                                                             const int32_t *__restrict__ pos_c, uint16_t *__restrict__ code_cnt,
+                                                             int32_t *__restrict__ n_entries, int32_t *__restrict__ n_pairs, int *__restrict__ too_long)
+{
+    __shared__ uint16_t cnt[kLatCodes][kBlock];
+    const int64_t I = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (I == na) { n_entries[na] = 0; n_pairs[na] = 0; }
+    if (I >= na) return;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int c = 0; c < kLatCodes; ++c) cnt[c][t] = 0;
+    const int32_t pc = pos_c[I];
+    const int bix = pc & 0x3ff, biy = (pc >> 10) & 0x3ff, biz = (pc >> 20) & 0x3ff;
+    int pairs = 0;
+    for (int32_t m = mem_ptr[I]; m < mem_ptr[I + 1]; ++m) {
+        const int64_t i = mem_idx[m];
+        const int64_t base = A.slice_off[i >> 6] + (i & 63);
+        const int len = A.rowlen[i];
+        pairs += len;
+        for (int k = 0; k < len; ++k) ++cnt[lat_code(B, pos[A.cols[base + 64LL * k]], bix, biy, biz)][t];
+    }
+    int entries = 0;
+#pragma unroll
+    for (int c = 0; c < kLatCodes; ++c) {
+        const uint16_t v = cnt[c][t];
+        code_cnt[static_cast<int64_t>(c) * na + I] = v;
+        entries += v != 0;
+    }
+    n_entries[I] = entries;
+    n_pairs[I] = pairs;
+    if (pairs > 0xffff) *too_long = 1;           // (16-bit counters: the sorted form takes the level)
+}
+__global__ void __launch_bounds__(kBlock) k_lat_codes_fill(SellDev A, const int32_t *__restrict__ pos, LatBricks B, int64_t na,
+                                                            const int32_t *__restrict__ mem_ptr, const int32_t *__restrict__ mem_idx,
+                                                            const int32_t *__restrict__ pos_c, const int32_t *__restrict__ brick_rank,
+                                                            const uint16_t *__restrict__ code_cnt, const int32_t *__restrict__ entry_off,
+                                                            const int32_t *__restrict__ pair_off, uint64_t *__restrict__ ukeys,
+                                                            int64_t *__restrict__ src_ptr, int32_t *__restrict__ src_slot)
+{
+    __shared__ uint16_t at[kLatCodes][kBlock];          // next place of every code's run, relative to the row's first pair
+    const int64_t I = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (I >= na) return;
+    const int t = threadIdx.x;
+    const int32_t pc = pos_c[I];
+    const int bix = pc & 0x3ff, biy = (pc >> 10) & 0x3ff, biz = (pc >> 20) & 0x3ff;
+    const int64_t p0 = pair_off[I];
+    int64_t e = entry_off[I];
+    int run = 0;
+#pragma unroll
+    for (int c = 0; c < kLatCodes; ++c) {
+        const int v = code_cnt[static_cast<int64_t>(c) * na + I];
+        at[c][t] = static_cast<uint16_t>(run);
+        if (v != 0) {
+            const int bx = bix + c % 3 - 1, by = biy + (c / 3) % 3 - 1, bz = biz + c / 9 - 1;
+            const int32_t J = brick_rank[bx + B.nb[0] * (by + B.nb[1] * bz)];
+            ukeys[e] = (static_cast<uint64_t>(I) << 32) | static_cast<uint32_t>(J);
+            src_ptr[e] = p0 + run;
+            ++e;
+        }
+        run += v;
+    }
+    if (I == na - 1) src_ptr[e] = p0 + run;
+    for (int32_t m = mem_ptr[I]; m < mem_ptr[I + 1]; ++m) {
+        const int64_t i = mem_idx[m];
+        const int64_t base = A.slice_off[i >> 6] + (i & 63);
+        const int len = A.rowlen[i];
+        for (int k = 0; k < len; ++k) {
+            const int64_t q = base + 64LL * k;
+            const int c = lat_code(B, pos[A.cols[q]], bix, biy, biz);
+            src_slot[p0 + at[c][t]++] = static_cast<int32_t>(q);
+        }
+    }
+}
 // distinct values of one coordinate: every node drops its value into a small open-addressing table (a lattice has a few
 // hundred distinct values per axis, so almost every probe finds its value already there); *overflow when the table fills
 constexpr int kLatticeTable = 4096;

@@ -155,6 +155,7 @@ struct DevPool {
         void *p = blocks[best].p;
         *got = blocks[best].bytes;
         held -= blocks[best].bytes;
+        st_reused += blocks[best].bytes;
         blocks.erase(blocks.begin() + static_cast<std::ptrdiff_t>(best));
         return p;
     }
@@ -167,15 +168,24 @@ struct DevPool {
         (void)hipGetDevice(&dev);
         blocks.push_back({p, bytes, dev});
         held += bytes;
+        st_peak_held = std::max(st_peak_held, held);
         while (held > cap && !blocks.empty()) {       // oldest first
             (void)hipFree(blocks.front().p);
+            st_freed += blocks.front().bytes;
             held -= blocks.front().bytes;
             blocks.erase(blocks.begin());
         }
         return true;
     }
+    // PFEM_POOL_VERBOSE: bytes that went through hipMalloc / came out of the pool / went back through hipFree since the last trim
+    size_t st_malloc = 0, st_reused = 0, st_freed = 0, st_peak_held = 0;
     void trim()
     {
+        static const bool verbose = std::getenv("PFEM_POOL_VERBOSE") != nullptr;
+        if (verbose && (st_malloc || st_reused || st_freed || held))
+            std::fprintf(stderr, "  pool: hipMalloc %.2f GB, reused %.2f GB, hipFree %.2f GB (blocks of %zu MiB+), held at trim %.2f GB in %zu blocks (peak %.2f GB)\n",
+                         st_malloc / 1e9, st_reused / 1e9, st_freed / 1e9, kMinBytes >> 20, held / 1e9, blocks.size(), st_peak_held / 1e9);
+        st_malloc = st_reused = st_freed = st_peak_held = 0;
         for (const Block &b : blocks) (void)hipFree(b.p);
         blocks.clear();
         held = 0;
@@ -196,7 +206,10 @@ struct DevBuf {
     void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(held_bytes, o.held_bytes); }
     void release()
     {
-        if (p && !dev_pool().give(p, held_bytes)) (void)hipFree(p);
+        if (p && !dev_pool().give(p, held_bytes)) {
+            (void)hipFree(p);
+            if (held_bytes >= DevPool::kMinBytes) dev_pool().st_freed += held_bytes;
+        }
         p = nullptr;
         n = 0;
         held_bytes = 0;
@@ -231,6 +244,7 @@ struct DevBuf {
         }
         n = count;
         held_bytes = bytes;
+        if (bytes >= DevPool::kMinBytes) dev_pool().st_malloc += bytes;
         return PFEM_OK;
     }
 };
