@@ -305,6 +305,7 @@ struct pfem_solver {
     DevBuf<int32_t> d_conn, d_edof;
     DevBuf<double> d_xyz, d_soln;
     int sort_end_bit = 64;         // radix-sort bits that matter in a (row << 32 | col) key (use_sort_bits)
+    int64_t inc_total = 0;         // entries of the wave-sliced incidence lists (build_incidence_lists -> build_incidence_records)
     DevBuf<double4> d_node4;       // {x, y, z, solnApplied} per node for the Poisson-tet gather kernel (built with the incidence)
 
     // local numbering
@@ -1296,10 +1297,12 @@ int pattern_from_keys(pfem_solver *s, DevBuf<uint64_t> &keys, int64_t nkeys)
 
 namespace {
 
-// node -> (element, local node) incidence lists, ascending element id, for the gather assembly
-int build_incidence(pfem_solver *s)
+// node -> (element, local node) incidence lists, ascending element id, for the gather assembly (and, before it, for the
+// pattern: pattern_from_incidence).  *built = false: too many incidences for one sort call -- the scatter form remains.
+int build_incidence_lists(pfem_solver *s, bool *built)
 {
     const MeshDev &m = s->mesh;
+    *built = false;
     s->have_incidence = false;
     const int64_t nk = static_cast<int64_t>(m.npe) * m.nElem;
     if (nk == 0 || nk > INT_MAX || m.nElem >= (1LL << 29)) return PFEM_OK;   // scatter form remains available
@@ -1347,6 +1350,16 @@ int build_incidence(pfem_solver *s)
                        static_cast<const int64_t *>(s->d_inc_ptr.p), s->d_inc_ea.p);
     PFEM_TRY(check_kernel("incidence"));
     PFEM_HIP(hipStreamSynchronize(s->stream));
+    s->inc_total = inc_total;
+    *built = true;
+    return PFEM_OK;
+}
+
+// ... and on top of the lists and the pattern: slot map, packed records, hub nodes, block size of the row kernels
+int build_incidence_records(pfem_solver *s)
+{
+    const MeshDev &m = s->mesh;
+    const int64_t inc_total = s->inc_total;
     // slot map: entry index of every (node row, element node) pair, so the numeric kernels never search.  A node whose
     // row is too long for a byte-sized entry index (> 255 entries: a "hub") is only marked: its rows are assembled
     // by a scatter pass restricted to them, every other row keeps the one-writer gather form.
@@ -1412,6 +1425,117 @@ int build_incidence(pfem_solver *s)
     return PFEM_OK;
 }
 
+int build_incidence(pfem_solver *s)
+{
+    bool built = false;
+    PFEM_TRY(build_incidence_lists(s, &built));
+    return built ? build_incidence_records(s) : PFEM_OK;
+}
+
+// The pattern from the incidence lists (k_pattern_rows): per node, the distinct neighbour nodes collected in LDS, twice
+// (lengths, then columns) -- no array of element-matrix keys, no sort of it.  *done = false: left to pattern_from_keys
+// (a node of so many elements that its candidates do not fit the LDS of a 64-thread block, dofs of a node not consecutive).
+int pattern_from_incidence(pfem_solver *s, bool *done)
+{
+    *done = false;
+    const MeshDev &m = s->mesh;
+    const int64_t n = s->n_loc;
+    if (n < 1 || m.nNode < 1) return PFEM_OK;
+    DevBuf<int32_t> node_key;
+    DevBuf<int> d_info;
+    PFEM_TRY(node_key.alloc(static_cast<size_t>(m.nNode)));
+    PFEM_TRY(d_info.alloc(2));
+    PFEM_HIP(hipMemsetAsync(d_info.p, 0, 2 * sizeof(int), s->stream));
+    const int64_t *ip = s->d_inc_ptr.p;
+    const int32_t *ic = s->d_inc_cnt.p, *iea = s->d_inc_ea.p;
+    hipLaunchKernelGGL(k_node_keys, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m, ip, ic, iea, node_key.p, d_info.p);
+    PFEM_TRY(check_kernel("k_node_keys"));
+    int info[2] = {0, 0};
+    PFEM_HIP(hipMemcpyAsync(info, d_info.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    if (info[0] != 0) return PFEM_OK;
+    // distinct neighbours of a node <= (npe - 1) * elements + 1: the LDS bound (two blocks per CU where that fits)
+    const size_t bound = static_cast<size_t>(m.npe - 1) * static_cast<size_t>(info[1]) + 1;
+    int T = 0;
+    for (int t = kBlock; t >= 64 && !T; t >>= 1)
+        if (bound * t * sizeof(int32_t) <= (t > 64 ? kMaxLdsBytes / 2 : kMaxLdsBytes)) T = t;
+    if (!T) return PFEM_OK;
+    const size_t lds = bound * T * sizeof(int32_t);
+    if (lds > 65536) {
+        PFEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pattern_rows<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        PFEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pattern_rows<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    }
+    s->cg_graph_key.clear();               // (as pattern_from_keys: everything that points at the old pattern goes)
+    s->mgraph_key.clear();
+    s->slices_fmt = -1;
+    if (s->amg) { s->amg->symbolic_ok = false; s->amg->coupled_refused = false; }
+    PFEM_TRY(use_sort_bits(s));
+    s->n_slices = (n + 63) / 64;
+    PFEM_TRY(s->d_rowptr.alloc(static_cast<size_t>(n) + 1));
+    PFEM_TRY(s->d_rowlen.alloc(static_cast<size_t>(n)));
+    PFEM_TRY(s->d_slice_off.alloc(static_cast<size_t>(s->n_slices) + 1));
+    PFEM_HIP(hipMemsetAsync(s->d_rowlen.p, 0, sizeof(int32_t) * static_cast<size_t>(n), s->stream));
+    const dim3 pgrid(static_cast<unsigned>((m.nNode + T - 1) / T)), pblock(T);
+    hipLaunchKernelGGL(k_pattern_rows<false>, pgrid, pblock, lds, s->stream, m, ip, ic, iea, static_cast<const int32_t *>(node_key.p), s->d_rowlen.p,
+                       static_cast<const int64_t *>(nullptr), static_cast<int32_t *>(nullptr));
+    PFEM_TRY(check_kernel("k_pattern_rows<false>"));
+    DevBuf<int64_t> wide, slice_entries;
+    DevBuf<char> temp;
+    PFEM_TRY(wide.alloc(static_cast<size_t>(n) + 1));
+    PFEM_TRY(slice_entries.alloc(static_cast<size_t>(s->n_slices) + 1));
+    PFEM_HIP(hipMemsetAsync(wide.p + n, 0, sizeof(int64_t), s->stream));
+    hipLaunchKernelGGL(k_widen_i32, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, static_cast<const int32_t *>(s->d_rowlen.p), n, wide.p);
+    size_t tb = 0;
+    const int n1 = static_cast<int>(n + 1);
+    PFEM_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, wide.p, s->d_rowptr.p, n1, s->stream));
+    PFEM_TRY(temp.alloc(tb));
+    PFEM_HIP(hipcub::DeviceScan::ExclusiveSum(temp.p, tb, wide.p, s->d_rowptr.p, n1, s->stream));
+    hipLaunchKernelGGL(k_slice_sizes, dim3(grid_for(s->n_slices * 64)), dim3(kBlock), 0, s->stream, static_cast<const int64_t *>(s->d_rowptr.p), n,
+                       s->n_slices, s->d_rowlen.p, slice_entries.p);
+    PFEM_TRY(check_kernel("k_slice_sizes"));
+    size_t tb3 = 0;
+    const int nsl = static_cast<int>(s->n_slices + 1);
+    PFEM_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, slice_entries.p, s->d_slice_off.p, nsl, s->stream));
+    if (tb3 > temp.n) { PFEM_HIP(hipStreamSynchronize(s->stream)); PFEM_TRY(temp.alloc(tb3)); }
+    PFEM_HIP(hipcub::DeviceScan::ExclusiveSum(temp.p, tb3, slice_entries.p, s->d_slice_off.p, nsl, s->stream));
+    int64_t stored = 0, nnz = 0;
+    PFEM_HIP(hipMemcpyAsync(&stored, s->d_slice_off.p + s->n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipMemcpyAsync(&nnz, s->d_rowptr.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    if (nnz > INT_MAX) {
+        set_last_error("pfem_pattern_build: more than 2^31-1 distinct matrix entries on one device");
+        return PFEM_ERR_ARG;
+    }
+    s->nnz = nnz;
+    s->stored = stored;
+    {   // widest row (= widest slice) of the pattern
+        std::vector<int64_t> h_off(static_cast<size_t>(s->n_slices) + 1);
+        PFEM_HIP(hipMemcpy(h_off.data(), s->d_slice_off.p, sizeof(int64_t) * h_off.size(), hipMemcpyDeviceToHost));
+        int64_t w = 0;
+        for (int64_t i = 0; i < s->n_slices; ++i) w = std::max(w, (h_off[i + 1] - h_off[i]) >> 6);
+        s->max_row_len = static_cast<int>(w);
+    }
+    PFEM_TRY(s->d_cols.alloc(static_cast<size_t>(std::max<int64_t>(stored, 1))));
+    PFEM_TRY(s->d_vals.alloc(static_cast<size_t>(std::max<int64_t>(stored, 1))));
+    hipLaunchKernelGGL(k_pattern_rows<true>, pgrid, pblock, lds, s->stream, m, ip, ic, iea, static_cast<const int32_t *>(node_key.p), s->d_rowlen.p,
+                       static_cast<const int64_t *>(s->d_slice_off.p), s->d_cols.p);
+    PFEM_TRY(check_kernel("k_pattern_rows<true>"));
+    hipLaunchKernelGGL(k_fill_pad_cols, dim3(grid_for(s->n_slices * 64)), dim3(kBlock), 0, s->stream, n, s->n_slices,
+                       static_cast<const int64_t *>(s->d_slice_off.p), static_cast<const int32_t *>(s->d_rowlen.p), s->d_cols.p);
+    PFEM_TRY(check_kernel("k_fill_pad_cols"));
+    PFEM_HIP(hipMemsetAsync(s->d_vals.p, 0, sizeof(double) * static_cast<size_t>(std::max<int64_t>(stored, 1)), s->stream));
+    PFEM_TRY(alloc_vectors(s));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    PFEM_TRY(build_cols16(s));
+    PFEM_TRY(build_groups(s));
+    PFEM_TRY(build_rel_groups(s));
+    s->have_pattern = true;
+    s->rhs_summed = false;
+    s->status = PFEM_PATTERN_OK;
+    *done = true;
+    return PFEM_OK;
+}
+
 }  // namespace
 
 extern "C" int pfem_pattern_build(pfem_solver *s)
@@ -1426,7 +1550,16 @@ extern "C" int pfem_pattern_build(pfem_solver *s)
     PFEM_HIP(hipEventRecord(s->ev0, s->stream));
     // test knob: elements per range (forces the ranged path on a small mesh)
     const int64_t range_env = [] { const char *e = std::getenv("PFEM_DEBUG_PATTERN_RANGE"); return e ? std::atoll(e) : 0LL; }();
-    if (nkeys <= INT_MAX && range_env <= 0) {
+    // first choice: incidence lists first, the pattern from them (pattern_from_incidence); PFEM_DEBUG_PATTERN_SORT / _RANGE:
+    // the sorted element-matrix keys (the form for patterns without a mesh, and the fallback)
+    bool have_lists = false, from_lists = false;
+    if (range_env <= 0 && !std::getenv("PFEM_DEBUG_PATTERN_SORT")) {
+        PFEM_TRY(build_incidence_lists(s, &have_lists));
+        if (have_lists) PFEM_TRY(pattern_from_incidence(s, &from_lists));
+    }
+    if (from_lists) {
+        // (nothing to sort)
+    } else if (nkeys <= INT_MAX && range_env <= 0) {
         PFEM_TRY(keys.alloc(static_cast<size_t>(std::max<int64_t>(nkeys, 1))));
         if (m.nElem > 0) {
             hipLaunchKernelGGL(k_emit_keys, dim3(grid_for(m.nElem)), dim3(kBlock), 0, s->stream, m, keys.p);
@@ -1484,8 +1617,9 @@ extern "C" int pfem_pattern_build(pfem_solver *s)
         PFEM_HIP(hipStreamSynchronize(s->stream));
         nkeys = total;
     }
-    PFEM_TRY(pattern_from_keys(s, keys, nkeys));
-    PFEM_TRY(build_incidence(s));
+    if (!from_lists) PFEM_TRY(pattern_from_keys(s, keys, nkeys));
+    if (have_lists) PFEM_TRY(build_incidence_records(s));
+    else PFEM_TRY(build_incidence(s));
     PFEM_HIP(hipEventRecord(s->ev1, s->stream));
     PFEM_TRY(elapsed(s, &s->tm.pattern_ms));
     keys.release();

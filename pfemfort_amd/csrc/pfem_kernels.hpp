@@ -577,6 +577,104 @@ __global__ void __launch_bounds__(kBlock) k_inc_fill(const uint64_t *keys, const
     for (int j = 0; j < width; ++j) ea[off + 64LL * j] = j < c ? static_cast<int32_t>(keys[p0 + j] & 0xffffffffu) : -1;
 }
 
+// ---- the pattern from the incidence lists, no sort of element-matrix keys --------------------------------------------
+// The rows of a node share one column set: the free dofs of every node of every incident element.  One thread per node
+// collects the distinct neighbour nodes of its node in LDS (sorted insertion; entry k of thread t at u[k*T + t]) under the
+// key first free dof * 4 + (free dofs - 1): a node's free dofs are consecutive numbers (checked by k_node_keys; what the
+// gather assembly relies on as well), so ascending keys expand to ascending columns.  FILL = false: the length of the
+// node's rows; FILL = true: the columns, straight into the wave-sliced storage.  The sorted form (pattern_from_keys: every
+// entry of every element matrix through a 64-bit radix sort, 768 M keys at config 3) remains for patterns without a mesh and
+// as the fallback (nodes of very many elements, dofs of a node not consecutive).
+__global__ void __launch_bounds__(kBlock) k_node_keys(MeshDev m, const int64_t *__restrict__ inc_ptr, const int32_t *__restrict__ inc_cnt,
+                                                       const int32_t *__restrict__ inc_ea, int32_t *__restrict__ node_key, int *__restrict__ info)
+{
+    const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (n >= m.nNode) return;
+    const int cnt = inc_cnt[n];
+    int32_t key = -1;
+    if (cnt > 0) {
+        atomicMax(info + 1, cnt);
+        const int ea0 = inc_ea[inc_ptr[n >> 6] + (n & 63)];
+        int first = -1, nfree = 0;
+        bool ok = true;
+        for (int q = 0; q < m.ndof; ++q) {
+            const int d = m.edof[static_cast<int64_t>(m.ndof * (ea0 & 3) + q) * m.nElem + (ea0 >> 2)];
+            if (d < 0) continue;
+            if (first < 0) first = d;
+            else ok = ok && d == first + nfree;
+            ++nfree;
+        }
+        if (!ok || first >= (1 << 29) || nfree > 4) atomicMax(info, 1);
+        if (nfree > 0) key = first * 4 + (nfree - 1);
+    }
+    node_key[n] = key;
+}
+template <bool FILL>
+__global__ void __launch_bounds__(kBlock) k_pattern_rows(MeshDev m, const int64_t *__restrict__ inc_ptr, const int32_t *__restrict__ inc_cnt,
+                                                          const int32_t *__restrict__ inc_ea, const int32_t *__restrict__ node_key,
+                                                          int32_t *__restrict__ rowlen, const int64_t *__restrict__ slice_off,
+                                                          int32_t *__restrict__ cols)
+{
+    extern __shared__ int32_t lds_u[];
+    const int T = blockDim.x;
+    const int64_t n = static_cast<int64_t>(blockIdx.x) * T + threadIdx.x;
+    if (n >= m.nNode) return;
+    const int cnt = inc_cnt[n];
+    const int32_t own = node_key[n];
+    if (cnt == 0 || own < 0) return;
+    int32_t *u = lds_u + threadIdx.x;
+    int len = 0;
+    const int64_t beg = inc_ptr[n >> 6] + (n & 63);
+    for (int j = 0; j < cnt; ++j) {
+        const int64_t e = inc_ea[beg + 64LL * j] >> 2;
+        for (int b = 0; b < m.npe; ++b) {
+            const int32_t key = node_key[m.conn[b * m.nElem + e]];
+            if (key < 0) continue;
+            int k = len;
+            while (k > 0 && u[(k - 1) * T] > key) --k;
+            if (k > 0 && u[(k - 1) * T] == key) continue;
+            for (int q = len; q > k; --q) u[q * T] = u[(q - 1) * T];
+            u[k * T] = key;
+            ++len;
+        }
+    }
+    const int first = own >> 2, nfree = (own & 3) + 1;
+    if (!FILL) {
+        int total = 0;
+        for (int k = 0; k < len; ++k) total += (u[k * T] & 3) + 1;
+        for (int q = 0; q < nfree; ++q) rowlen[first + q] = total;
+    } else {
+        for (int q = 0; q < nfree; ++q) {
+            const int64_t r = first + q;
+            int32_t *c = cols + slice_off[r >> 6] + (r & 63);
+            int at = 0;
+            for (int k = 0; k < len; ++k) {
+                const int32_t key = u[k * T];
+                for (int d = 0; d <= (key & 3); ++d) c[64LL * at++] = (key >> 2) + d;
+            }
+        }
+    }
+}
+// padding of the wave-sliced column array: a row's own index (rows past the end: 0), as k_fill_sell leaves it
+__global__ void __launch_bounds__(kBlock) k_fill_pad_cols(int64_t n_rows, int64_t n_slices, const int64_t *__restrict__ slice_off,
+                                                           const int32_t *__restrict__ rowlen, int32_t *__restrict__ cols)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t s = r >> 6;
+    if (s >= n_slices) return;
+    const int64_t off = slice_off[s] + (r & 63);
+    const int width = static_cast<int>((slice_off[s + 1] - slice_off[s]) >> 6);
+    const int len = r < n_rows ? rowlen[r] : 0;
+    const int32_t pad = r < n_rows ? static_cast<int32_t>(r) : 0;
+    for (int k = len; k < width; ++k) cols[off + 64LL * k] = pad;
+}
+// rowptr[i] for i <= n from the row lengths' exclusive scan (int64: more than 2^31 stored entries are legal here)
+__global__ void __launch_bounds__(kBlock) k_widen_i32(const int32_t *__restrict__ in, int64_t n, int64_t *__restrict__ out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
 // Slot map of the gather form, built once per pattern: for incidence t = (node n, element e) the
 // byte b of inc_slots[t] is the entry index k, inside n's matrix rows, of the FIRST free dof of
 // e's local node b (0xff: node b fully constrained).  The rows of one node share their column
