@@ -589,11 +589,16 @@ __global__ void __launch_bounds__(kBlock) k_node_keys(MeshDev m, const int64_t *
                                                        const int32_t *__restrict__ inc_ea, int32_t *__restrict__ node_key, int *__restrict__ info)
 {
     const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const int cnt = n < m.nNode ? inc_cnt[n] : 0;
+    {
+        int c = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c = max(c, __shfl_xor(c, o, 64));              // one atomic per wave
+        if ((threadIdx.x & 63) == 0 && c > 0) atomicMax(info + 1, c);
+    }
     if (n >= m.nNode) return;
-    const int cnt = inc_cnt[n];
     int32_t key = -1;
     if (cnt > 0) {
-        atomicMax(info + 1, cnt);
         const int ea0 = inc_ea[inc_ptr[n >> 6] + (n & 63)];
         int first = -1, nfree = 0;
         bool ok = true;
@@ -775,9 +780,14 @@ __global__ void __launch_bounds__(kBlock) k_max_gather_row(const int32_t *__rest
                                                             int *out)
 {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const int r = node_row[i];
-    if (r >= 0) atomicMax(out, rowlen[r]);
+    int len = 0;
+    if (i < n) {
+        const int r = node_row[i];
+        if (r >= 0) len = rowlen[r];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_xor(len, o, 64));          // one atomic per wave
+    if ((threadIdx.x & 63) == 0 && len > 0) atomicMax(out, len);
 }
 
 // The gather form never evaluates an element whose nodes are all constrained, but the

@@ -744,6 +744,32 @@ def test_pattern_built_in_element_ranges(name, per_range, request, monkeypatch):
     assert reason == 2
 
 
+@pytest.mark.parametrize("name", ["tet10", "beam", "tria20"])
+def test_pattern_from_incidence_lists_equals_the_sorted_keys(name, request, monkeypatch):
+    """The default pattern build collects every node's distinct neighbour nodes from the incidence lists (k_pattern_rows);
+    PFEM_DEBUG_PATTERN_SORT=1 sorts the keys of every element-matrix entry instead (the fallback, and the form of patterns
+    without a mesh).  Same rowptr, same columns, and both equal the oracle's."""
+    mesh = request.getfixturevalue(name)
+    kind, ed = {"tet10": (pf.POISSON_TET, H.POISSON_ELEMDATA), "beam": (pf.ELAST_TET, H.ELAST_ELEMDATA),
+                "tria20": (pf.POISSON_TRIA, H.POISSON_ELEMDATA)}[name]
+    from pfemfort_amd import drivers as D
+    dm, conn_new, xyz_new, edof = D._setup(kind, mesh)
+    prob = O.setup_problem(kind, _omesh(mesh), elemData=ed)
+    got = {}
+    for form in ("lists", "sorted"):
+        if form == "sorted":
+            monkeypatch.setenv("PFEM_DEBUG_PATTERN_SORT", "1")
+        s = pf.PetscSolver().initialise(dm.size_global, dm.size_global)
+        s.uploadMesh(kind, conn_new, xyz_new, edof, dm.solnApplied)
+        s.buildPattern()
+        s.assemble(ed, H.TIMEDATA)
+        got[form] = s.getCSR() + (s.getRHS(),)
+        s.free()
+    for form, (rowptr, cols, vals, rhs) in got.items():
+        assert np.array_equal(rowptr, prob.rowptr) and np.array_equal(cols, prob.cols), form
+        assert np.array_equal(vals, prob.vals) and np.array_equal(rhs, prob.rhs), form
+
+
 @pytest.mark.parametrize("table", [True, False, "escapes"])
 def test_row_forms_beyond_16bit_gaps(table, monkeypatch):
     """Three dofs per node and a numbering plane of 151 x 151 nodes: the gap to the next plane's columns is 68 403 dofs,
