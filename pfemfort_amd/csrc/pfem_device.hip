@@ -126,18 +126,26 @@ extern "C" int pfem_device_memory(int device, int64_t *free_bytes, int64_t *tota
 // ---------------------------------------------------------------------------
 namespace {
 
-// A per-process pool of freed device blocks.  On this stack hipFree of a multi-GB block followed by hipMalloc of another one
-// now and then takes SECONDS (config 5: the pattern build is 0.78 s in a fresh process and 6.6 s when the same process has
-// built and freed one before -- tools/r04/pattern_time.sh; the symbolic phase of the multigrid set-up caught 1.5 s stalls the
-// same way).  Blocks of 32 MiB and more go back to the pool instead of the driver and are handed out again when a request fits
-// within a factor of two; the pool holds at most PFEM_POOL_GB (default 64) and is emptied by pool_trim() -- at the end of
-// every solve (the set-up phases that churn memory are over by then) and at solver destroy -- and when the device runs out of memory.  hipFree used to synchronise the device on the way: the pool does the same before it
-// takes a block back, so a block is never reused while a kernel of another stream may still touch it.
+// A per-process pool of freed device blocks.  Freed device memory is wiped asynchronously on this stack (~25-30 GB/s) and an
+// allocation that lands on memory still being wiped waits for it: after 87 GiB of frees one 12 GiB hipMalloc took 2.9 s
+// (tools/probe_alloc*.py; config 5: the pattern build 0.78 s in a fresh process, 6.6 s when the same process had built and
+// freed one before); a hipFree itself costs 0.15-0.2 ms whatever the size.  Blocks of 64 KiB and more (PFEM_POOL_MIN_KB) go
+// back to the pool instead of the driver and are handed out again when a request fits within a factor of two; the pool holds
+// at most PFEM_POOL_GB (default 64).  pool_trim(false) -- whenever a solve returns: the set-up phases that churn memory are
+// over by then -- hands the blocks of 32 MiB and more back to the device (other ranks or processes may share it) and keeps
+// the small ones, up to 1 GiB of them, for the next set-up; pool_trim(true) -- solver destroy -- empties it, and so does an
+// allocation that fails.  hipFree used to synchronise the device on the way: the pool does the same before it takes a block
+// back, so a block is never reused while a kernel of another stream may still touch it.
 struct DevPool {
     struct Block { void *p; size_t bytes; int device; };
     std::vector<Block> blocks;
     size_t held = 0;
-    static constexpr size_t kMinBytes = 32ull << 20;
+    static constexpr size_t kLargeBytes = 32ull << 20, kSmallKept = 1ull << 30;
+    static size_t min_bytes()
+    {
+        static const size_t v = [] { const char *e = std::getenv("PFEM_POOL_MIN_KB"); return (e ? static_cast<size_t>(std::atoll(e)) : 64) << 10; }();
+        return v;
+    }
     static size_t cap_bytes()
     {
         const char *e = std::getenv("PFEM_POOL_GB");
@@ -162,7 +170,16 @@ struct DevPool {
     bool give(void *p, size_t bytes)
     {
         const size_t cap = cap_bytes();
-        if (bytes < kMinBytes || bytes > cap) return false;
+        if (bytes < min_bytes() || bytes > cap) return false;
+        if (bytes >= kLargeBytes) {
+            // several processes may share the device (ranks of a test or of a development run), each with a pool of its own:
+            // when the device runs short, what this process holds idle goes back at once and the block is not kept
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < total_b / 4) {
+                trim(true);
+                return false;
+            }
+        }
         (void)hipDeviceSynchronize();             // (what hipFree did on its way)
         int dev = 0;
         (void)hipGetDevice(&dev);
@@ -179,16 +196,21 @@ struct DevPool {
     }
     // PFEM_POOL_VERBOSE: bytes that went through hipMalloc / came out of the pool / went back through hipFree since the last trim
     size_t st_malloc = 0, st_reused = 0, st_freed = 0, st_peak_held = 0;
-    void trim()
+    void trim(bool all = true)
     {
         static const bool verbose = std::getenv("PFEM_POOL_VERBOSE") != nullptr;
         if (verbose && (st_malloc || st_reused || st_freed || held))
-            std::fprintf(stderr, "  pool: hipMalloc %.2f GB, reused %.2f GB, hipFree %.2f GB (blocks of %zu MiB+), held at trim %.2f GB in %zu blocks (peak %.2f GB)\n",
-                         st_malloc / 1e9, st_reused / 1e9, st_freed / 1e9, kMinBytes >> 20, held / 1e9, blocks.size(), st_peak_held / 1e9);
+            std::fprintf(stderr, "  pool: hipMalloc %.2f GB, reused %.2f GB, hipFree %.2f GB (blocks of %zu KiB+), held at trim %.2f GB in %zu blocks (peak %.2f GB)\n",
+                         st_malloc / 1e9, st_reused / 1e9, st_freed / 1e9, min_bytes() >> 10, held / 1e9, blocks.size(), st_peak_held / 1e9);
         st_malloc = st_reused = st_freed = st_peak_held = 0;
-        for (const Block &b : blocks) (void)hipFree(b.p);
-        blocks.clear();
-        held = 0;
+        std::vector<Block> keep;
+        size_t kept = 0;
+        for (const Block &b : blocks) {
+            if (!all && b.bytes < kLargeBytes && kept + b.bytes <= kSmallKept) { keep.push_back(b); kept += b.bytes; }
+            else (void)hipFree(b.p);
+        }
+        blocks.swap(keep);
+        held = kept;
     }
     ~DevPool() { blocks.clear(); }                // (process exit: the runtime may be gone already; nothing to hand back)
 };
@@ -208,7 +230,7 @@ struct DevBuf {
     {
         if (p && !dev_pool().give(p, held_bytes)) {
             (void)hipFree(p);
-            if (held_bytes >= DevPool::kMinBytes) dev_pool().st_freed += held_bytes;
+            if (held_bytes >= DevPool::min_bytes()) dev_pool().st_freed += held_bytes;
         }
         p = nullptr;
         n = 0;
@@ -221,12 +243,13 @@ struct DevBuf {
         release();
         if (count == 0) count = 1;
         const size_t bytes = count * sizeof(T);
-        if (bytes >= DevPool::kMinBytes) {
+        if (bytes >= DevPool::min_bytes()) {
             size_t got = 0;
             if (void *q = dev_pool().take(bytes, &got)) {
                 p = static_cast<T *>(q);
                 n = count;
                 held_bytes = got;
+                poison();
                 return PFEM_OK;
             }
         }
@@ -244,11 +267,23 @@ struct DevBuf {
         }
         n = count;
         held_bytes = bytes;
-        if (bytes >= DevPool::kMinBytes) dev_pool().st_malloc += bytes;
+        if (bytes >= DevPool::min_bytes()) dev_pool().st_malloc += bytes;
+        poison();
         return PFEM_OK;
     }
+    // PFEM_DEBUG_POISON=1: every block is handed out full of 0xA5 bytes -- nothing may rely on what fresh or recycled memory
+    // holds (=K: only the K-th allocation of the process, to find the buffer)
+    void poison()
+    {
+        static const char *e = std::getenv("PFEM_DEBUG_POISON");
+        if (!e) return;
+        static long ordinal = 0;
+        const long k = std::atol(e);
+        ++ordinal;
+        if (k <= 1 || k == ordinal) { (void)hipMemset(p, 0xA5, std::max(held_bytes, n * sizeof(T))); (void)hipDeviceSynchronize(); }   // (the slack of a recycled block too)
+    }
 };
-inline void pool_trim() { dev_pool().trim(); }
+inline void pool_trim(bool all) { dev_pool().trim(all); }
 
 #include "pfem_amg_types.hpp"
 
@@ -603,7 +638,7 @@ extern "C" int pfem_solver_destroy(pfem_solver *s)
         if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
-    pool_trim();                 // the solver's buffers really go back to the device
+    pool_trim(true);             // the solver's buffers really go back to the device
     return PFEM_OK;
 }
 
@@ -4102,7 +4137,7 @@ extern "C" int pfem_solver_solve(pfem_solver *s, int *its, int *reason, double *
     PFEM_TRY(use_device(s));
     // the set-up phases are over when a solve returns (also with an error): what they left in the pool goes back to the
     // device, which other ranks or other processes may share
-    struct TrimAtExit { ~TrimAtExit() { pool_trim(); } } trim_at_exit;
+    struct TrimAtExit { ~TrimAtExit() { pool_trim(false); } } trim_at_exit;
     PFEM_HIP(hipEventRecord(s->ev0, s->stream));
     if (s->host_values_dirty && !s->have_mesh) {
         // MatAssemblyBegin/End + VecAssemblyBegin/End (solverpetsc.F:447-468): push the

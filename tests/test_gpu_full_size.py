@@ -141,7 +141,10 @@ def test_elasticity_beam_config4():
     v_sc, f_sc = s.getCSR()[2], s.getRHS()
     s.setAssemblyMode("gather"); s.assemble(H.ELAST_ELEMDATA, H.TIMEDATA)      # row-per-thread LDS form
     v_g, f_g = s.getCSR()[2], s.getRHS()
-    assert np.abs(v_sc - v_g).max() <= 1e-12 * np.abs(v_g).max() and np.abs(f_sc - f_g).max() <= 1e-12 * np.abs(f_g).max()
+    dv, df = np.abs(v_sc - v_g), np.abs(f_sc - f_g)
+    assert dv.max() <= 1e-12 * np.abs(v_g).max() and df.max() <= 1e-12 * np.abs(f_g).max(), (
+        f"scatter against gather: K differs by up to {dv.max():.3e} in {(dv > 1e-12 * np.abs(v_g).max()).sum()} entries "
+        f"(first at {np.argmax(dv > 1e-12 * np.abs(v_g).max())}), F by up to {df.max():.3e}")
     s.assemble(H.ELAST_ELEMDATA, H.TIMEDATA)
     assert np.array_equal(s.getCSR()[2], v_g) and np.array_equal(s.getRHS(), f_g)   # bit-reproducible
     # the oracle at this size (4.5 M elements, 103 M entries): pattern, K and F bit for bit
