@@ -324,12 +324,14 @@ __global__ void __launch_bounds__(kBlock) k_lat_codes_count(SellDev A, const int
     n_pairs[I] = pairs;
     if (pairs > 0xffff) *too_long = 1;           // (16-bit counters: the sorted form takes the level)
 }
+template <bool MAPS>          // MAPS: also the (entry -> slots) lists of the map-driven product (A/B runs)
 __global__ void __launch_bounds__(kBlock) k_lat_codes_fill(SellDev A, const int32_t *__restrict__ pos, LatBricks B, int64_t na,
                                                             const int32_t *__restrict__ mem_ptr, const int32_t *__restrict__ mem_idx,
                                                             const int32_t *__restrict__ pos_c, const int32_t *__restrict__ brick_rank,
                                                             const uint16_t *__restrict__ code_cnt, const int32_t *__restrict__ entry_off,
                                                             const int32_t *__restrict__ pair_off, uint64_t *__restrict__ ukeys,
-                                                            int64_t *__restrict__ src_ptr, int32_t *__restrict__ src_slot)
+                                                            int64_t *__restrict__ src_ptr, int32_t *__restrict__ src_slot,
+                                                            uint8_t *__restrict__ code_of, uint32_t *__restrict__ code_mask)
 {
     __shared__ uint16_t at[kLatCodes][kBlock];          // next place of every code's run, relative to the row's first pair
     const int64_t I = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -348,12 +350,13 @@ __global__ void __launch_bounds__(kBlock) k_lat_codes_fill(SellDev A, const int3
             const int bx = bix + c % 3 - 1, by = biy + (c / 3) % 3 - 1, bz = biz + c / 9 - 1;
             const int32_t J = brick_rank[bx + B.nb[0] * (by + B.nb[1] * bz)];
             ukeys[e] = (static_cast<uint64_t>(I) << 32) | static_cast<uint32_t>(J);
-            src_ptr[e] = p0 + run;
+            if (MAPS) src_ptr[e] = p0 + run;
             ++e;
         }
         run += v;
     }
-    if (I == na - 1) src_ptr[e] = p0 + run;
+    if (MAPS && I == na - 1) src_ptr[e] = p0 + run;
+    uint32_t mask = 0;
     for (int32_t m = mem_ptr[I]; m < mem_ptr[I + 1]; ++m) {
         const int64_t i = mem_idx[m];
         const int64_t base = A.slice_off[i >> 6] + (i & 63);
@@ -361,9 +364,44 @@ __global__ void __launch_bounds__(kBlock) k_lat_codes_fill(SellDev A, const int3
         for (int k = 0; k < len; ++k) {
             const int64_t q = base + 64LL * k;
             const int c = lat_code(B, pos[A.cols[q]], bix, biy, biz);
-            src_slot[p0 + at[c][t]++] = static_cast<int32_t>(q);
+            if (MAPS) src_slot[p0 + at[c][t]++] = static_cast<int32_t>(q);
+            code_of[q] = static_cast<uint8_t>(c);
+            mask |= 1u << c;
         }
     }
+    code_mask[I] = mask;
+}
+// Numeric Galerkin product of a brick level, by coarse ROW: the member rows are walked as in the symbolic phase, every stored
+// value added to its code's accumulator in LDS ([code][thread]), the occupied codes written out in ascending order = the
+// coarse row's entries.  Same additions in the same order as the map-driven k_amg_galerkin (member rows ascending, entries of
+// a row ascending): the same bits, read as 8 + 1 bytes per fine entry along the rows instead of slot gathers per coarse entry.
+constexpr int kLatGalThreads = 128;
+__global__ void __launch_bounds__(kLatGalThreads) k_lat_galerkin(SellDev A, int64_t na, const int32_t *__restrict__ mem_ptr,
+                                                                  const int32_t *__restrict__ mem_idx, const uint8_t *__restrict__ code_of,
+                                                                  const uint32_t *__restrict__ code_mask, const int64_t *__restrict__ c_slice_off,
+                                                                  double *__restrict__ coarse_vals)
+{
+    __shared__ double acc[kLatCodes][kLatGalThreads];
+    const int64_t I = static_cast<int64_t>(blockIdx.x) * kLatGalThreads + threadIdx.x;
+    if (I >= na) return;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int c = 0; c < kLatCodes; ++c) acc[c][t] = 0.0;
+    for (int32_t m = mem_ptr[I]; m < mem_ptr[I + 1]; ++m) {
+        const int64_t i = mem_idx[m];
+        const int64_t base = A.slice_off[i >> 6] + (i & 63);
+        const int len = A.rowlen[i];
+        for (int k = 0; k < len; ++k) {
+            const int64_t q = base + 64LL * k;
+            acc[code_of[q]][t] += A.vals[q];
+        }
+    }
+    double *out = coarse_vals + c_slice_off[I >> 6] + (I & 63);
+    const uint32_t mask = code_mask[I];
+    int r = 0;
+#pragma unroll
+    for (int c = 0; c < kLatCodes; ++c)
+        if (mask & (1u << c)) out[64LL * r++] = acc[c][t];
 }
 // distinct values of one coordinate: every node drops its value into a small open-addressing table (a lattice has a few
 // hundred distinct values per axis, so almost every probe finds its value already there); *overflow when the table fills

@@ -46,6 +46,10 @@ struct AmgLevel {
     DevBuf<int64_t> src_ptr;              // [nnz_c+1]
     DevBuf<int32_t> src_slot;             // storage slots of this level's matrix, grouped by coarse entry
     DevBuf<int64_t> dst_slot;             // [nnz_c] storage slot in the next level's matrix
+    // brick level (k_lat_codes_*): the product by coarse row instead (k_lat_galerkin) -- offset code of every stored entry
+    // of this level's matrix and the occupied codes of every coarse row
+    DevBuf<uint8_t> code_of;              // [stored]
+    DevBuf<uint32_t> code_mask;           // [nc]
     // rigid-body-mode coarse space (pfem_amg_rbm.hpp): the level's dofs come `bs` to the node (block regular), the next level
     // has dim + (dim == 3 ? 3 : 1) per aggregate.  With rbm set, mem_ptr / mem_idx list the member NODES of every coarse node
     // and src_ptr / src_slot the fine node BLOCKS of every coarse node block; agg keeps the translation part of P.
