@@ -750,6 +750,9 @@ def main():
                                 "operator_complexity": sum(R["amg"]["nnz"]) / max(R["amg"]["nnz"][0], 1),
                                 "cheb_degree": R["amg"]["cheb_degree"], "cheb_degree_on_the_assembled_matrix": R["amg"]["fine_degree"], "eig_ratio": R["amg"]["eig_ratio"], "coarse_scale": R["amg"]["coarse_scale"],
                                 "numeric_setup_ms_per_solve_inside_the_timer": R["amg"]["numeric_ms"],
+                                # a solve = numeric set-up + (iterations + 1) cycles: the initial one, then one per iteration
+                                # (`ms_per_iteration` above divides the whole solve by the iterations)
+                                "ms_per_cycle_with_its_cg_iteration": (acc["sol_ms"] / args.steps - R["amg"]["numeric_ms"]) / (its + 1),
                                 "symbolic_setup_ms_once_per_pattern": R["amg"]["symbolic_ms"],
                                 "symbolic_setup_where": "first solve after a pattern build (a warm-up step; with --warmup 0 the first timed step)",
                                 "levels_paired_on_the_lattice": R["amg_layout"]["lattice_levels"],

@@ -141,6 +141,11 @@ struct DevPool {
     std::vector<Block> blocks;
     size_t held = 0;
     static constexpr size_t kLargeBytes = 32ull << 20, kSmallKept = 1ull << 30;
+    static size_t fit()           // a block may be this many times the request (PFEM_POOL_FIT)
+    {
+        static const size_t v = [] { const char *e = std::getenv("PFEM_POOL_FIT"); return e ? std::max<size_t>(1, static_cast<size_t>(std::atoll(e))) : 2; }();
+        return v;
+    }
     static size_t min_bytes()
     {
         static const size_t v = [] { const char *e = std::getenv("PFEM_POOL_MIN_KB"); return (e ? static_cast<size_t>(std::atoll(e)) : 64) << 10; }();
@@ -158,7 +163,7 @@ struct DevPool {
         (void)hipGetDevice(&dev);
         size_t best = blocks.size();
         for (size_t i = 0; i < blocks.size(); ++i)
-            if (blocks[i].device == dev && blocks[i].bytes >= bytes && blocks[i].bytes <= 2 * bytes && (best == blocks.size() || blocks[i].bytes < blocks[best].bytes)) best = i;
+            if (blocks[i].device == dev && blocks[i].bytes >= bytes && blocks[i].bytes <= fit() * bytes && (best == blocks.size() || blocks[i].bytes < blocks[best].bytes)) best = i;
         if (best == blocks.size()) return nullptr;
         void *p = blocks[best].p;
         *got = blocks[best].bytes;
