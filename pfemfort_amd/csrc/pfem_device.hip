@@ -140,6 +140,7 @@ struct DevPool {
     struct Block { void *p; size_t bytes; int device; };
     std::vector<Block> blocks;
     size_t held = 0;
+    std::recursive_mutex mu;          // solvers of one process may live on different host threads
     static constexpr size_t kLargeBytes = 32ull << 20, kSmallKept = 1ull << 30;
     static size_t fit()           // a block may be this many times the request (PFEM_POOL_FIT)
     {
@@ -159,6 +160,7 @@ struct DevPool {
     }
     void *take(size_t bytes, size_t *got)
     {
+        std::lock_guard<std::recursive_mutex> lock(mu);
         int dev = 0;
         (void)hipGetDevice(&dev);
         size_t best = blocks.size();
@@ -174,6 +176,7 @@ struct DevPool {
     }
     bool give(void *p, size_t bytes)
     {
+        std::lock_guard<std::recursive_mutex> lock(mu);
         const size_t cap = cap_bytes();
         if (bytes < min_bytes() || bytes > cap) return false;
         if (bytes >= kLargeBytes) {
@@ -201,8 +204,15 @@ struct DevPool {
     }
     // PFEM_POOL_VERBOSE: bytes that went through hipMalloc / came out of the pool / went back through hipFree since the last trim
     size_t st_malloc = 0, st_reused = 0, st_freed = 0, st_peak_held = 0;
+    void note(size_t mallocd, size_t freed)
+    {
+        std::lock_guard<std::recursive_mutex> lock(mu);
+        st_malloc += mallocd;
+        st_freed += freed;
+    }
     void trim(bool all = true)
     {
+        std::lock_guard<std::recursive_mutex> lock(mu);
         static const bool verbose = std::getenv("PFEM_POOL_VERBOSE") != nullptr;
         if (verbose && (st_malloc || st_reused || st_freed || held))
             std::fprintf(stderr, "  pool: hipMalloc %.2f GB, reused %.2f GB, hipFree %.2f GB (blocks of %zu KiB+), held at trim %.2f GB in %zu blocks (peak %.2f GB)\n",
@@ -235,7 +245,7 @@ struct DevBuf {
     {
         if (p && !dev_pool().give(p, held_bytes)) {
             (void)hipFree(p);
-            if (held_bytes >= DevPool::min_bytes()) dev_pool().st_freed += held_bytes;
+            if (held_bytes >= DevPool::min_bytes()) dev_pool().note(0, held_bytes);
         }
         p = nullptr;
         n = 0;
@@ -272,7 +282,7 @@ struct DevBuf {
         }
         n = count;
         held_bytes = bytes;
-        if (bytes >= DevPool::min_bytes()) dev_pool().st_malloc += bytes;
+        if (bytes >= DevPool::min_bytes()) dev_pool().note(bytes, 0);
         poison();
         return PFEM_OK;
     }
