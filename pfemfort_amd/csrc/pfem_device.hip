@@ -1044,8 +1044,15 @@ extern "C" int pfem_mesh_generate_box_axis(pfem_solver *s, int kind, double x0, 
     if (nNode > INT32_MAX || nElem >= (1LL << 31) / 4 || sl.size_global > INT32_MAX) return PFEM_ERR_ARG;
     PFEM_TRY(use_device(s));
     const auto t0 = std::chrono::steady_clock::now();
+    const bool gen_verbose = std::getenv("PFEM_GEN_VERBOSE") != nullptr;
+    auto mark = [&](const char *what) {
+        if (!gen_verbose) return;
+        (void)hipStreamSynchronize(s->stream);
+        std::fprintf(stderr, "  generate box: %-28s at %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    };
     const int nNx = nEx + 1, nNy = nEy + 1, nNz = nEz + 1;
     const BoxAxes ax = box_axes(x0, x1, nEx, y0, y1, nEy, z0, z1, nEz);
+    mark("axis tables");
     MeshDev &m = s->mesh;
     m.kind = kind;
     m.npe = 4;
@@ -1087,6 +1094,7 @@ extern "C" int pfem_mesh_generate_box_axis(pfem_solver *s, int kind, double x0, 
     PFEM_TRY(s->d_edof.alloc(static_cast<size_t>(ndofs)));
     PFEM_TRY(s->d_xyz.alloc(static_cast<size_t>(3) * nNode));
     PFEM_TRY(s->d_soln.alloc(static_cast<size_t>(ndof) * nNode));
+    mark("allocations");
     BoxDev b{};
     for (int d = 0; d < 3; ++d) {
         b.N[d] = sl.N[d];
@@ -1105,29 +1113,44 @@ extern "C" int pfem_mesh_generate_box_axis(pfem_solver *s, int kind, double x0, 
     const int64_t nHex = nElem / 6;
     hipLaunchKernelGGL(k_box_elems, dim3(grid_for(nHex)), dim3(kBlock), 0, s->stream, b, nHex, s->d_conn.p, s->d_edof.p);
     PFEM_TRY(check_kernel("k_box_elems"));
+    mark("nodes + elements");
 
     // prescribed values of the slab's boundary nodes (bc_mode 0: u = x^2+y^2+z^2 through the float / "%.8f" round trips
     // of genTetra.cpp:510-525, evaluated on the host for the few face nodes; bc_mode 1: zeros, already there)
     if (bc_mode == 0) {
-        std::vector<int64_t> slot;
-        std::vector<double> val;
+        // (each value takes a float round trip and a "%.8f" text round trip: 33 ms of host time for the 240 000 face nodes of
+        // config 3 when done one after the other -- rows of the slab are independent, so the host threads share them)
         const int Ln0 = sl.Ln(0), Ln1 = sl.Ln(1), Ln2 = sl.Ln(2);
-        for (int kl = 0; kl < Ln2; ++kl)
-            for (int jl = 0; jl < Ln1; ++jl) {
-                const int k = off[2] + kl, j = off[1] + jl;
-                const bool edge_row = k == 0 || k == nNz - 1 || j == 0 || j == nNy - 1;
-                auto put = [&](int il) {
-                    const double v = box_dirichlet_value(ax.raw[0][off[0] + il], ax.raw[1][j], ax.raw[2][k]);
-                    const int64_t node = (static_cast<int64_t>(kl) * Ln1 + jl) * Ln0 + il;
-                    for (int d = 0; d < ndof; ++d) { slot.push_back(node * ndof + d); val.push_back(v); }
-                };
-                if (edge_row) {
-                    for (int il = 0; il < Ln0; ++il) put(il);
-                } else {            // only the two x-faces, where the slab reaches them (Ln0 >= 2)
-                    if (off[0] == 0) put(0);
-                    if (off[0] + Ln0 - 1 == nNx - 1) put(Ln0 - 1);
-                }
+        const bool lo_face = off[0] == 0, hi_face = off[0] + Ln0 - 1 == nNx - 1;
+        const int64_t n_rows = static_cast<int64_t>(Ln2) * Ln1;
+        std::vector<int64_t> row_at(static_cast<size_t>(n_rows) + 1, 0);
+        for (int64_t r = 0; r < n_rows; ++r) {
+            const int k = off[2] + static_cast<int>(r / Ln1), j = off[1] + static_cast<int>(r % Ln1);
+            const bool edge_row = k == 0 || k == nNz - 1 || j == 0 || j == nNy - 1;
+            // only the two x-faces, where the slab reaches them (Ln0 >= 2), unless the whole row lies on a face
+            const int64_t nodes = edge_row ? Ln0 : (lo_face ? 1 : 0) + (hi_face ? 1 : 0);
+            row_at[static_cast<size_t>(r) + 1] = row_at[static_cast<size_t>(r)] + nodes * ndof;
+        }
+        std::vector<int64_t> slot(static_cast<size_t>(row_at.back()));
+        std::vector<double> val(slot.size());
+#pragma omp parallel for schedule(static)
+        for (int64_t r = 0; r < n_rows; ++r) {
+            const int kl = static_cast<int>(r / Ln1), jl = static_cast<int>(r % Ln1);
+            const int k = off[2] + kl, j = off[1] + jl;
+            const bool edge_row = k == 0 || k == nNz - 1 || j == 0 || j == nNy - 1;
+            int64_t at = row_at[static_cast<size_t>(r)];
+            auto put = [&](int il) {
+                const double v = box_dirichlet_value(ax.raw[0][off[0] + il], ax.raw[1][j], ax.raw[2][k]);
+                const int64_t node = (static_cast<int64_t>(kl) * Ln1 + jl) * Ln0 + il;
+                for (int d = 0; d < ndof; ++d) { slot[static_cast<size_t>(at)] = node * ndof + d; val[static_cast<size_t>(at)] = v; ++at; }
+            };
+            if (edge_row) {
+                for (int il = 0; il < Ln0; ++il) put(il);
+            } else {
+                if (lo_face) put(0);
+                if (hi_face) put(Ln0 - 1);
             }
+        }
         DevBuf<int64_t> d_slot;
         DevBuf<double> d_val;
         PFEM_TRY(d_slot.alloc(slot.size()));
@@ -1140,6 +1163,7 @@ extern "C" int pfem_mesh_generate_box_axis(pfem_solver *s, int kind, double x0, 
         PFEM_TRY(check_kernel("k_box_bc"));
         PFEM_HIP(hipStreamSynchronize(s->stream));
     }
+    mark("boundary values");
     if (s->n_ghost > 0 || s->row_start > 0) {
         DevBuf<int64_t> d_ghost;
         PFEM_TRY(d_ghost.alloc(static_cast<size_t>(s->n_ghost)));
