@@ -410,9 +410,12 @@ __global__ void __launch_bounds__(kBlock) k_amg_distinct(const double *__restric
                                                           int *__restrict__ overflow)
 {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const double v = c[i] + 0.0;                                  // -0.0 -> +0.0
+    const double v = (i < n ? c[i] : 0.0) + 0.0;                  // -0.0 -> +0.0
     const unsigned long long key = static_cast<unsigned long long>(__double_as_longlong(v));
+    // a lane whose left neighbour holds the same value leaves the table to it (along a line of a lattice two of the three
+    // coordinates are the same for the whole wave)
+    const unsigned long long left = __shfl_up(key, 1, 64);
+    if (i >= n || ((threadIdx.x & 63) != 0 && left == key && i - 1 < n)) return;
     if (key == ~0ull) { *overflow = 1; return; }                   // (the empty marker is a NaN pattern: not a coordinate)
     unsigned h = static_cast<unsigned>((key * 0x9E3779B97F4A7C15ull) >> 52) & (kLatticeTable - 1);
     for (int probe = 0; probe < kLatticeTable; ++probe) {

@@ -890,45 +890,48 @@ int lattice_positions(pfem_solver *s, DevBuf<int32_t> &pos, bool *is_lattice, in
     if (!s->have_mesh || no < 1 || m.nElem < 1 || m.nNode > INT_MAX) return PFEM_OK;
     // distinct values per axis through a 4096-slot hash table on the device (no O(n) work arrays, no sort: every multi-MB
     // allocation risks one of this stack's stalls), sorted on the host
-    DevBuf<double> uniq[3];
+    DevBuf<double> uniq;
     DevBuf<unsigned long long> table;
     DevBuf<int> d_over;
-    PFEM_TRY(table.alloc(kLatticeTable));
-    PFEM_TRY(d_over.alloc(1));
+    PFEM_TRY(table.alloc(3 * kLatticeTable));
+    PFEM_TRY(d_over.alloc(3));
+    PFEM_TRY(uniq.alloc(3 * 1024));
     int count[3] = {1, 1, 1};
-    std::vector<unsigned long long> h_table(kLatticeTable);
+    // the three axes back to back, one trip to the host for all of them
+    PFEM_HIP(hipMemsetAsync(table.p, 0xff, sizeof(unsigned long long) * 3 * kLatticeTable, s->stream));
+    PFEM_HIP(hipMemsetAsync(d_over.p, 0, 3 * sizeof(int), s->stream));
+    for (int d = 0; d < m.ndim; ++d)
+        hipLaunchKernelGGL(k_amg_distinct, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m.xyz + static_cast<int64_t>(d) * m.nNode, m.nNode,
+                           table.p + static_cast<size_t>(d) * kLatticeTable, d_over.p + d);
+    PFEM_TRY(check_kernel("k_amg_distinct"));
+    int over[3] = {0, 0, 0};
+    std::vector<unsigned long long> h_table(3 * kLatticeTable);
+    PFEM_HIP(hipMemcpyAsync(over, d_over.p, 3 * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipMemcpyAsync(h_table.data(), table.p, sizeof(unsigned long long) * h_table.size(), hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    std::vector<double> h_uniq(3 * 1024, 0.0);
     for (int d = 0; d < m.ndim; ++d) {
-        const double *c = m.xyz + static_cast<int64_t>(d) * m.nNode;
-        PFEM_TRY(uniq[d].alloc(1024));
-        PFEM_HIP(hipMemsetAsync(table.p, 0xff, sizeof(unsigned long long) * kLatticeTable, s->stream));
-        PFEM_HIP(hipMemsetAsync(d_over.p, 0, sizeof(int), s->stream));
-        hipLaunchKernelGGL(k_amg_distinct, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, c, m.nNode, table.p, d_over.p);
-        PFEM_TRY(check_kernel("k_amg_distinct"));
-        int over = 0;
-        PFEM_HIP(hipMemcpyAsync(&over, d_over.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
-        PFEM_HIP(hipMemcpyAsync(h_table.data(), table.p, sizeof(unsigned long long) * kLatticeTable, hipMemcpyDeviceToHost, s->stream));
-        PFEM_HIP(hipStreamSynchronize(s->stream));
-        if (over) return PFEM_OK;
+        if (over[d]) return PFEM_OK;
         std::vector<double> vals;
-        for (unsigned long long k : h_table)
+        for (int q = 0; q < kLatticeTable; ++q) {
+            const unsigned long long k = h_table[static_cast<size_t>(d) * kLatticeTable + q];
             if (k != ~0ull) { double v; std::memcpy(&v, &k, sizeof v); vals.push_back(v); }
+        }
         if (vals.empty() || vals.size() > 1024) return PFEM_OK;
         std::sort(vals.begin(), vals.end());
         count[d] = static_cast<int>(vals.size());
-        PFEM_HIP(hipMemcpyAsync(uniq[d].p, vals.data(), sizeof(double) * vals.size(), hipMemcpyHostToDevice, s->stream));
-        PFEM_HIP(hipStreamSynchronize(s->stream));          // (vals goes out of scope)
+        std::copy(vals.begin(), vals.end(), h_uniq.begin() + static_cast<std::ptrdiff_t>(d) * 1024);
     }
     if (static_cast<int64_t>(count[0]) * count[1] * count[2] > 2 * m.nNode) return PFEM_OK;
+    PFEM_HIP(hipMemcpyAsync(uniq.p, h_uniq.data(), sizeof(double) * h_uniq.size(), hipMemcpyHostToDevice, s->stream));
+    const double *u0 = uniq.p, *u1 = uniq.p + 1024, *u2 = m.ndim > 2 ? uniq.p + 2048 : uniq.p;
     PFEM_TRY(pos.alloc(static_cast<size_t>(no)));
     PFEM_HIP(hipMemsetAsync(pos.p, 0, sizeof(int32_t) * static_cast<size_t>(no), s->stream));
     if (s->have_incidence && s->d_node_row.p)         // one thread per node through the assembly's node -> row table (4.0 -> 0.1 ms at config 3) ...
         hipLaunchKernelGGL(k_amg_lattice_pos_nodes, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m.nNode, m.ndim, m.ndof, m.xyz,
-                           static_cast<const int32_t *>(s->d_node_row.p), no, static_cast<const double *>(uniq[0].p), count[0],
-                           static_cast<const double *>(uniq[1].p), count[1], static_cast<const double *>(m.ndim > 2 ? uniq[2].p : uniq[0].p), count[2], pos.p);
+                           static_cast<const int32_t *>(s->d_node_row.p), no, u0, count[0], u1, count[1], u2, count[2], pos.p);
     else                                              // ... else through the elements
-    hipLaunchKernelGGL(k_amg_lattice_pos, dim3(grid_for(m.nElem * m.npe)), dim3(kBlock), 0, s->stream, m, no, static_cast<const double *>(uniq[0].p),
-                       count[0], static_cast<const double *>(uniq[1].p), count[1],
-                       static_cast<const double *>(m.ndim > 2 ? uniq[2].p : uniq[0].p), count[2], pos.p);
+    hipLaunchKernelGGL(k_amg_lattice_pos, dim3(grid_for(m.nElem * m.npe)), dim3(kBlock), 0, s->stream, m, no, u0, count[0], u1, count[1], u2, count[2], pos.p);
     PFEM_TRY(check_kernel("k_amg_lattice_pos"));
     PFEM_HIP(hipStreamSynchronize(s->stream));
     for (int d = 0; d < 3; ++d) hi[d] = count[d] - 1;
