@@ -227,9 +227,9 @@ struct DevPool {
         blocks.swap(keep);
         held = kept;
     }
-    ~DevPool() { blocks.clear(); }                // (process exit: the runtime may be gone already; nothing to hand back)
 };
-inline DevPool &dev_pool() { static DevPool pool; return pool; }
+// (never destroyed: buffers released during process exit still find it, and by then the runtime may be gone -- nothing is handed back)
+inline DevPool &dev_pool() { static DevPool *pool = new DevPool(); return *pool; }
 
 template <class T>
 struct DevBuf {
