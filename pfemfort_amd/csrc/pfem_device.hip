@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <deque>
 #include <map>
@@ -1136,8 +1137,10 @@ extern "C" int pfem_mesh_generate_box_axis(pfem_solver *s, int kind, double x0, 
         }
         std::vector<int64_t> slot(static_cast<size_t>(row_at.back()));
         std::vector<double> val(slot.size());
-#pragma omp parallel for schedule(static)
-        for (int64_t r = 0; r < n_rows; ++r) {
+        // (plain threads that end with the loop, not an OpenMP team: idle OpenMP workers spin for a while after a parallel region,
+        // and the launch-bound loops that follow -- a small problem's CG iterations -- ran 3-5x slower next to them)
+        auto rows_of = [&](int64_t r_begin, int64_t r_end) {
+        for (int64_t r = r_begin; r < r_end; ++r) {
             const int kl = static_cast<int>(r / Ln1), jl = static_cast<int>(r % Ln1);
             const int k = off[2] + kl, j = off[1] + jl;
             const bool edge_row = k == 0 || k == nNz - 1 || j == 0 || j == nNy - 1;
@@ -1152,6 +1155,23 @@ extern "C" int pfem_mesh_generate_box_axis(pfem_solver *s, int kind, double x0, 
             } else {
                 if (lo_face) put(0);
                 if (hi_face) put(Ln0 - 1);
+            }
+        }
+        };
+        {
+            // (work per row is uneven -- whole rows on four faces, two nodes elsewhere: interleaved blocks of rows per thread)
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            const int nt = static_cast<int>(std::min<int64_t>(std::min<unsigned>(hw, 16u), std::max<int64_t>(1, static_cast<int64_t>(slot.size()) / 20000)));
+            if (nt <= 1) {
+                rows_of(0, n_rows);
+            } else {
+                const int64_t block = std::max<int64_t>(1, Ln1);
+                std::vector<std::thread> pool;
+                for (int t = 0; t < nt; ++t)
+                    pool.emplace_back([&, t] {
+                        for (int64_t b = static_cast<int64_t>(t) * block; b < n_rows; b += static_cast<int64_t>(nt) * block) rows_of(b, std::min(n_rows, b + block));
+                    });
+                for (std::thread &th : pool) th.join();
             }
         }
         DevBuf<int64_t> d_slot;
