@@ -891,12 +891,20 @@ int lattice_positions(pfem_solver *s, DevBuf<int32_t> &pos, bool *is_lattice, in
     if (!s->have_mesh || no < 1 || m.nElem < 1 || m.nNode > INT_MAX) return PFEM_OK;
     // distinct values per axis through a 4096-slot hash table on the device (no O(n) work arrays, no sort: every multi-MB
     // allocation risks one of this stack's stalls), sorted on the host
+    const auto lt0 = std::chrono::steady_clock::now();
+    const bool lverbose = std::getenv("PFEM_AMG_VERBOSE") != nullptr;
+    auto lmark = [&](const char *what) {
+        if (!lverbose) return;
+        (void)hipStreamSynchronize(s->stream);
+        std::fprintf(stderr, "    lattice: %-30s at %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lt0).count());
+    };
     DevBuf<double> uniq;
     DevBuf<unsigned long long> table;
     DevBuf<int> d_over;
     PFEM_TRY(table.alloc(3 * kLatticeTable));
     PFEM_TRY(d_over.alloc(3));
     PFEM_TRY(uniq.alloc(3 * 1024));
+    lmark("allocations");
     int count[3] = {1, 1, 1};
     // the three axes back to back, one trip to the host for all of them
     PFEM_HIP(hipMemsetAsync(table.p, 0xff, sizeof(unsigned long long) * 3 * kLatticeTable, s->stream));
@@ -905,11 +913,13 @@ int lattice_positions(pfem_solver *s, DevBuf<int32_t> &pos, bool *is_lattice, in
         hipLaunchKernelGGL(k_amg_distinct, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m.xyz + static_cast<int64_t>(d) * m.nNode, m.nNode,
                            table.p + static_cast<size_t>(d) * kLatticeTable, d_over.p + d);
     PFEM_TRY(check_kernel("k_amg_distinct"));
+    lmark("distinct values");
     int over[3] = {0, 0, 0};
     std::vector<unsigned long long> h_table(3 * kLatticeTable);
     PFEM_HIP(hipMemcpyAsync(over, d_over.p, 3 * sizeof(int), hipMemcpyDeviceToHost, s->stream));
     PFEM_HIP(hipMemcpyAsync(h_table.data(), table.p, sizeof(unsigned long long) * h_table.size(), hipMemcpyDeviceToHost, s->stream));
     PFEM_HIP(hipStreamSynchronize(s->stream));
+    lmark("tables on the host");
     std::vector<double> h_uniq(3 * 1024, 0.0);
     for (int d = 0; d < m.ndim; ++d) {
         if (over[d]) return PFEM_OK;
@@ -935,6 +945,7 @@ int lattice_positions(pfem_solver *s, DevBuf<int32_t> &pos, bool *is_lattice, in
     hipLaunchKernelGGL(k_amg_lattice_pos, dim3(grid_for(m.nElem * m.npe)), dim3(kBlock), 0, s->stream, m, no, u0, count[0], u1, count[1], u2, count[2], pos.p);
     PFEM_TRY(check_kernel("k_amg_lattice_pos"));
     PFEM_HIP(hipStreamSynchronize(s->stream));
+    lmark("positions");
     for (int d = 0; d < 3; ++d) hi[d] = count[d] - 1;
     *is_lattice = true;
     return PFEM_OK;
