@@ -16,6 +16,21 @@
 
 using namespace pfem;
 
+#ifdef _OPENMP
+// The bookkeeping loops below run as OpenMP loops; the GPU work that follows them is often launch-bound (a small problem's CG
+// iterations).  Idle OpenMP workers that spin before they sleep take the cores the HIP runtime's launch path needs: measured
+// 3-5x on the iterations of a 10^6-dof problem for ~0.2 s after a parallel region (profiles/LAB_NOTES.md).  Unless the host
+// has chosen a wait policy itself, the workers of this process sleep at once (read by the OpenMP runtime when it starts,
+// i.e. at the first parallel region after this library was loaded).
+namespace {
+const int g_omp_passive = [] {
+    (void)setenv("OMP_WAIT_POLICY", "passive", 0);
+    (void)setenv("KMP_BLOCKTIME", "0", 0);
+    return 0;
+}();
+}  // namespace
+#endif
+
 // ---------------------------------------------------------------------------
 // 1. per-element compat surface
 // ---------------------------------------------------------------------------
