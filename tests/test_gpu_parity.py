@@ -5,6 +5,9 @@ Ke/Fe bit-exact (the kernels evaluate in the reference's order without FMA contr
 assembled K/F within 1e-12 relative (atomic adds reorder the sums); solution within 1e-8 of
 the converged oracle solution at rtol 1e-10.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -957,6 +960,49 @@ def test_gamg_lattice_bricks_equal_the_oracles_own(case, tet10, tria20):
     xo, ito, ro, _, hist = O.pcg_amg(rowptr, cols, vals, s.getRHS(), own, cheb_degree=info["cheb_degree"], fine_degree=info["fine_degree"],
                                      eig_ratio=info["eig_ratio"], coarse_scale=info["coarse_scale"], rtol=1e-10)
     assert (reason, ro) == (2, 2) and abs(its - ito) <= 1 and np.abs(s.getSolution() - xo).max() <= 1e-9 * max(1.0, np.abs(xo).max())
+
+
+_BRICK_VARIANT = r"""
+import sys, json, hashlib
+import numpy as np
+sys.path.insert(0, {root!r})
+import pfemfort_amd as pf
+from pfemfort_amd import host as H
+n = 24
+sz = H.box_slab_sizes(n, n, n)
+s = pf.PetscSolver().initialise(sz["size_local"], sz["size_global"])
+s.generateBoxMesh(pf.POISSON_TET, -1.0, 1.0, n, -1.0, 1.0, n, -1.0, 1.0, n)
+s.buildPattern()
+s.setPreconditioner("gamg")
+s.setTolerances(rtol=1e-10, maxits=1000)
+s.assemble(H.POISSON_ELEMDATA, H.TIMEDATA)
+its, reason, rnorm = s.factoriseAndSolve()
+info = s.amgInfo()
+x = s.getSolution()
+print(json.dumps(dict(its=its, reason=reason, rnorm=rnorm, rows=info["rows"], nnz=info["nnz"], lam=info["lambda_max"],
+                      x=hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest(), xs=float(np.abs(x).sum()))))
+"""
+
+
+def test_gamg_brick_level_variants_agree():
+    """A brick level's coarse pattern comes from two walks of every coarse row's member rows and its Galerkin product is formed
+    by coarse row (k_lat_codes_*, k_lat_galerkin).  The forms they replaced stay in the library -- the entry -> slot lists
+    (PFEM_AMG_GALERKIN_MAPS=1: the same additions in the same order, so the same bits) and the sorted keys
+    (PFEM_AMG_BRICK_SORT=1: rows too long for the walks' 16-bit counters; the same hierarchy, sums in slot order) -- and are
+    run here, each in a process of its own (the switches are read once)."""
+    import subprocess, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for name, extra in (("default", {}), ("maps", {"PFEM_AMG_GALERKIN_MAPS": "1"}), ("sorted", {"PFEM_AMG_BRICK_SORT": "1"})):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", _BRICK_VARIANT.format(root=root)], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[name] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    d, m, q = out["default"], out["maps"], out["sorted"]
+    assert d["reason"] == 2 and d["its"] < 40 and len(d["rows"]) >= 3
+    assert (m["its"], m["rnorm"], m["x"], m["lam"], m["rows"], m["nnz"]) == (d["its"], d["rnorm"], d["x"], d["lam"], d["rows"], d["nnz"])      # bit for bit
+    assert (q["rows"], q["nnz"], q["reason"]) == (d["rows"], d["nnz"], 2) and abs(q["its"] - d["its"]) <= 1
+    assert np.allclose(q["lam"], d["lam"], rtol=1e-12) and abs(q["xs"] - d["xs"]) <= 1e-8 * d["xs"]
 
 
 def test_gamg_reasons_and_reuse():
