@@ -628,11 +628,14 @@ __global__ void __launch_bounds__(kBlock) k_pattern_rows(MeshDev m, const int64_
     const int32_t own = node_key[n];
     if (cnt == 0 || own < 0) return;
     int32_t *u = lds_u + threadIdx.x;
-    int len = 0;
+    u[0] = own;                                  // the node itself (local node `a` of every incident element: not looked up again)
+    int len = 1;
     const int64_t beg = inc_ptr[n >> 6] + (n & 63);
     for (int j = 0; j < cnt; ++j) {
-        const int64_t e = inc_ea[beg + 64LL * j] >> 2;
+        const int ea = inc_ea[beg + 64LL * j];
+        const int64_t e = ea >> 2;
         for (int b = 0; b < m.npe; ++b) {
+            if (b == (ea & 3)) continue;
             const int32_t key = node_key[m.conn[b * m.nElem + e]];
             if (key < 0) continue;
             int k = len;
