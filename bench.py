@@ -776,6 +776,17 @@ def main():
             "device_memory_gb": {"in_use_rank0_device": round((R["mem"]["total_bytes"] - R["mem"]["free_bytes"]) / 1e9, 2),
                                  "total": round(R["mem"]["total_bytes"] / 1e9, 2)},
             "comm": comm_block(J, R) if world > 1 else None,
+            # the kernel furthest from the HBM roofline, with the bound it really has: FP64 issue (every element's geometry is
+            # evaluated once per incident node, un-contracted as the reference's order demands).  The event time is this
+            # run's; the issue fraction is replayed from the committed SQ counters of the same kernel on the same workload
+            "assembly_kernel": ({"kernel": "pfem::k_gather_poisson_tet4 (gather assembly + the SpMV's relative-group copy)",
+                                 "event_ms_per_step": acc["asm_ms"] / args.steps,
+                                 "bound": "fp64-valu-issue",
+                                 "valu_issue_fraction_replayed_not_this_run": 0.75,
+                                 "valu_issue_source": "profiles/r04/gather_kernels_sq_counters.txt (rocprofv3 --pmc SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE, tools/r04/gather_sq_counters.sh)",
+                                 "hbm_frac_of_compulsory_bytes": (3.75e9 / (acc["asm_ms"] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBPS)
+                                 if (not beam and world == 1 and args.n == 200 and args.numbering == "lattice") else None}
+                                if (not beam and world == 1) else None),
             "roofline": {"bound": "hbm", "kernel": kernel,
                          # the judged figure: plain-CSR algorithmic bytes / measured launch time.  It is an
                          # EFFECTIVE rate: the kernel's compressed form moves fewer bytes (hbm_gbps below)
