@@ -48,6 +48,11 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert js["converged_reason"] == 2 and d["iterations"] < js["iterations"] / 3 and js["max_nodal_error"] < 1e-3
     assert abs(js["speedup_of_value_over_it"] - js["ms_per_step"] / d["ms_per_step"]) < 1e-9
     assert "PCBJACOBI" in d["config"]["solver"] and "gamg" in d["config"]["solver"] and d["setup_breakdown_s"]["generate_mesh_and_numbering_on_device"] >= 0 and d["setup_s_untimed"] < 5
+    # a solve = numeric set-up + (iterations + 1) cycles; the kernel furthest from the HBM roofline travels with its real bound
+    assert 0 < pcb["ms_per_cycle_with_its_cg_iteration"] < d["ms_per_iteration"]
+    ak = d["assembly_kernel"]
+    assert ak["bound"] == "fp64-valu-issue" and ak["event_ms_per_step"] == d["assembly_ms_per_step"] and os.path.exists(os.path.join(ROOT, ak["valu_issue_source"].split(" ")[0]))
+    assert d["cold_value"] > 0 and abs(d["cold_value"] - d["config"]["free_dofs"] / (d["first_step_ms_including_once_per_pattern_setup"] * 1e-3)) <= 1e-6 * d["cold_value"]
 
 
 @pytest.mark.gpu
