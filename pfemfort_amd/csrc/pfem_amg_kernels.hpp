@@ -171,12 +171,17 @@ __global__ void __launch_bounds__(kBlock) k_amg_lat_coarsen(int64_t n, const int
 // anisotropic operators keep their semi-coarsening).  Couplings must stay inside neighbouring bricks (|offset| <= 1).
 struct LatBricks {
     int shift[3];          // halvings of every axis on this level (the passes' axis sequence, simulated on the host)
-    int nb[3];             // bricks along every axis
+    int nb[3];             // bricks along every axis of the box the flag / rank arrays span
+    int lo[3];             // first brick of that box along every axis (one rank: 0; several ranks: the box of this rank's local nodes)
 };
+__device__ __forceinline__ int lat_linear(const LatBricks &B, int bx, int by, int bz)
+{
+    return (bx - B.lo[0]) + B.nb[0] * ((by - B.lo[1]) + B.nb[1] * (bz - B.lo[2]));
+}
 __device__ __forceinline__ int lat_brick_linear(const LatBricks &B, int32_t pos)
 {
     const int bx = (pos & 0x3ff) >> B.shift[0], by = ((pos >> 10) & 0x3ff) >> B.shift[1], bz = ((pos >> 20) & 0x3ff) >> B.shift[2];
-    return bx + B.nb[0] * (by + B.nb[1] * bz);
+    return lat_linear(B, bx, by, bz);
 }
 // one thread per row: sibling couplings strong enough?  every coupling within reach of the 27 neighbouring bricks?  marks the row's brick
 __global__ void __launch_bounds__(kBlock) k_lat_check(SellDev A, const int32_t *__restrict__ pos, const double *__restrict__ diag, LatBricks B,
@@ -219,9 +224,91 @@ __global__ void __launch_bounds__(kBlock) k_lat_assign(int64_t n, const int32_t 
     if (i >= n) return;
     const int32_t p = pos[i];
     const int bx = (p & 0x3ff) >> B.shift[0], by = ((p >> 10) & 0x3ff) >> B.shift[1], bz = ((p >> 20) & 0x3ff) >> B.shift[2];
-    const int32_t a = brick_rank[bx + B.nb[0] * (by + B.nb[1] * bz)];
+    const int32_t a = brick_rank[lat_linear(B, bx, by, bz)];
     agg[i] = a;
     pos_c[a] = bx | (by << 10) | (bz << 20);                // (every member writes the same value)
+}
+// ---- bricks across ranks (one hierarchy over several ranks, amg_bricks_level with `coupled`) -------------------------------
+// Positions are GLOBAL lattice positions, the same on every rank, padded so that the planes where the ownership of the
+// nodes changes sit on multiples of the level's brick size: no brick holds nodes of two owners, and everything above works
+// unchanged on a rank's local nodes (owned first, ghosts after them) once the ghosts' bricks are in the rank table too.
+// box of the positions pos[0..n): out = {min x, min y, min z, max x, max y, max z} (preset to 1023.. / 0..)
+constexpr int kLatBoxBlocks = 512;
+__global__ void __launch_bounds__(kBlock) k_lat_bbox(int64_t n, const int32_t *__restrict__ pos, int *__restrict__ out)
+{
+    // (grid-stride, one set of atomics per wave of a small grid: 7.9 M positions through per-wave atomics on six words took 17 ms)
+    int lo[3] = {1023, 1023, 1023}, hi[3] = {0, 0, 0};
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const int32_t p = pos[i];
+        for (int d = 0; d < 3; ++d) {
+            const int v = (p >> (10 * d)) & 0x3ff;
+            lo[d] = min(lo[d], v);
+            hi[d] = max(hi[d], v);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = min(lo[d], __shfl_xor(lo[d], o, 64));
+            hi[d] = max(hi[d], __shfl_xor(hi[d], o, 64));
+        }
+    if ((threadIdx.x & 63) == 0)
+        for (int d = 0; d < 3; ++d) {
+            atomicMin(&out[d], lo[d]);
+            atomicMax(&out[3 + d], hi[d]);
+        }
+}
+// per-axis renumbering of positions through a table [3][1024] (the padding that aligns the ownership planes)
+__global__ void __launch_bounds__(kBlock) k_lat_remap(int64_t n, const int32_t *__restrict__ in, const int32_t *__restrict__ table,
+                                                       int32_t *__restrict__ out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int32_t p = in[i];
+    out[i] = table[p & 0x3ff] | (table[1024 + ((p >> 10) & 0x3ff)] << 10) | (table[2048 + ((p >> 20) & 0x3ff)] << 20);
+}
+// corner coordinates of the nodes from their positions (coord: [3][1024], the coordinate of every position)
+__global__ void __launch_bounds__(kBlock) k_lat_xyz_from_pos(int64_t nn, const int32_t *__restrict__ pos, const double *__restrict__ coord,
+                                                              double *__restrict__ xyz)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= nn) return;
+    const int32_t p = pos[i];
+    for (int d = 0; d < 3; ++d) xyz[d * nn + i] = coord[1024 * d + ((p >> (10 * d)) & 0x3ff)];
+}
+// owned dofs' positions into the global array of the replicated level (zeroed before, summed over the ranks after)
+__global__ void __launch_bounds__(kBlock) k_lat_emit_global_pos(int64_t n_own, const int32_t *__restrict__ gid, const int32_t *__restrict__ pos,
+                                                                 double *__restrict__ out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n_own) out[gid[i]] = static_cast<double>(pos[i]);
+}
+// ghost nodes [n0, n1): their aggregates came from the owners (amg_couple_level); the bricks they sit in get those numbers
+// in the rank table, and the ghost aggregates their brick coordinates (every member writes the same value)
+__global__ void __launch_bounds__(kBlock) k_lat_ghost_bricks(int64_t n0, int64_t n1, const int32_t *__restrict__ pos, LatBricks B,
+                                                              const int32_t *__restrict__ agg, int32_t *__restrict__ brick_rank,
+                                                              int32_t *__restrict__ pos_c)
+{
+    const int64_t i = n0 + static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n1) return;
+    const int32_t p = pos[i];
+    const int bx = (p & 0x3ff) >> B.shift[0], by = ((p >> 10) & 0x3ff) >> B.shift[1], bz = ((p >> 20) & 0x3ff) >> B.shift[2];
+    const int32_t a = agg[i];
+    brick_rank[lat_linear(B, bx, by, bz)] = a;
+    pos_c[a] = bx | (by << 10) | (bz << 20);
+}
+// diagonal of a matrix whose rows are not in ascending column order (coarse levels of a hierarchy across ranks: ghost
+// columns are numbered behind the owned ones, whatever their brick)
+__global__ void __launch_bounds__(kBlock) k_extract_diag_scan(SellDev A, double *__restrict__ diag)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (r >= A.n_rows) return;
+    const int64_t base = A.slice_off[r >> 6] + (r & 63);
+    const int len = A.rowlen[r];
+    double d = 0.0;
+    for (int k = 0; k < len; ++k)
+        if (A.cols[base + 64LL * k] == static_cast<int32_t>(r)) d += A.vals[base + 64LL * k];
+    diag[r] = d;
 }
 // Galerkin maps without 64-bit keys: coarse entry of a stored fine entry = 27 * agg(row) + offset code of the column's brick
 // (25 bits at config 3: four radix passes instead of eight); padding slots get the sentinel n_keys
@@ -273,7 +360,7 @@ __global__ void __launch_bounds__(kBlock) k_lat_run_scatter(int64_t n, const uin
             const int32_t pc = pos_c[I];
             const int bx = (pc & 0x3ff) + static_cast<int>(code % 3u) - 1, by = ((pc >> 10) & 0x3ff) + static_cast<int>((code / 3u) % 3u) - 1,
                       bz = ((pc >> 20) & 0x3ff) + static_cast<int>(code / 9u) - 1;
-            const int32_t J = brick_rank[bx + B.nb[0] * (by + B.nb[1] * bz)];
+            const int32_t J = brick_rank[lat_linear(B, bx, by, bz)];
             ukeys[rank[i]] = (static_cast<uint64_t>(I) << 32) | static_cast<uint32_t>(J);
         }
     }
@@ -348,7 +435,7 @@ __global__ void __launch_bounds__(kBlock) k_lat_codes_fill(SellDev A, const int3
         at[c][t] = static_cast<uint16_t>(run);
         if (v != 0) {
             const int bx = bix + c % 3 - 1, by = biy + (c / 3) % 3 - 1, bz = biz + c / 9 - 1;
-            const int32_t J = brick_rank[bx + B.nb[0] * (by + B.nb[1] * bz)];
+            const int32_t J = brick_rank[lat_linear(B, bx, by, bz)];
             ukeys[e] = (static_cast<uint64_t>(I) << 32) | static_cast<uint32_t>(J);
             if (MAPS) src_ptr[e] = p0 + run;
             ++e;
@@ -898,6 +985,32 @@ __global__ void __launch_bounds__(kBlock) k_amg_mask_vector(int64_t n, int64_t n
 {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (i < n_loc) w[i] = i < n ? mask_c[agg[i]] : 0.0;
+}
+// the ghosts' side of amg_couple_level on the device: sort keys = the aggregates' global numbers the owners sent (v holds
+// them as doubles; undo = 0.5 in the self-peer timing probe), the local number of every ghost dof's aggregate from the run
+// it falls into (table: whole coarse nodes), and one holder-set mask per run
+__global__ void __launch_bounds__(kBlock) k_amg_ghost_keys(int64_t ng, const double *__restrict__ vg, double undo, uint64_t *__restrict__ keys,
+                                                            int32_t *__restrict__ idx)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= ng) return;
+    keys[i] = static_cast<uint64_t>(static_cast<int64_t>(undo * vg[i] + 0.5));
+    idx[i] = static_cast<int32_t>(i);
+}
+__global__ void __launch_bounds__(kBlock) k_amg_ghost_agg(int64_t ng, const int32_t *__restrict__ sidx, const int32_t *__restrict__ head,
+                                                           const int32_t *__restrict__ rank, const int32_t *__restrict__ table, int32_t nc,
+                                                           int32_t *__restrict__ agg_g)
+{
+    const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (p >= ng) return;
+    const int32_t run = rank[p] + head[p] - 1;
+    agg_g[sidx[p]] = table ? table[run] : nc + run;
+}
+__global__ void __launch_bounds__(kBlock) k_amg_ghost_masks(int64_t m, const int64_t *__restrict__ start, const int32_t *__restrict__ sidx,
+                                                             const double *__restrict__ wg, double *__restrict__ out)
+{
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (k < m) out[k] = wg[sidx[start[k]]];
 }
 // this rank's share of the last level's operator into the dense global matrix (zeroed before; summed over the ranks after)
 __global__ void __launch_bounds__(kBlock) k_amg_dense_scatter(SellDev A, const int32_t *__restrict__ gid, int n_glob, double *__restrict__ dense)

@@ -36,6 +36,14 @@ struct AmgLevel {
     bool lattice = false;                 // hint = lattice position (x | y << 10 | z << 20): the pairing goes axis by axis (k_amg_lat_*)
     int lat_hi[3] = {0, 0, 0};            // highest position along every axis on this level
     int lat_axis = 0;                     // axis of this level's first pass
+    // bricks across ranks (amg_bricks_level, coupled): hint holds the GLOBAL positions of ALL local nodes (owned, then ghosts),
+    // the same numbers on every rank, padded so that every plane where the nodes' owner changes (lat_cuts: first position of
+    // every stretch of one owner, per axis, ascending, [0] = 0) is a multiple of the level's brick size
+    bool lat_global = false;
+    std::vector<int> lat_cuts[3];
+    int lat_box[6] = {0, 0, 0, 0, 0, 0};  // box of the local nodes' positions: lowest x, y, z, highest x, y, z
+    std::vector<double> lat_coord;        // [3 x 1024] coordinate of every position (a brick sits at its lowest corner): the corners a level
+                                          // needs when it leaves the brick path (xyz below) come from here instead of travelling down the levels
     DevBuf<double> xyz;                   // coupled hierarchy with a lattice: [3 x n_nodes] a corner of every node's aggregate (see k_amg_xyz_min)
     // transfer to the next level (piecewise-constant prolongation)
     int64_t nc = 0;

@@ -882,30 +882,22 @@ int morton_rank(pfem_solver *s, DevBuf<int32_t> &rank)
 
 // Lattice position of every owned dof (x | y << 10 | z << 20) when the nodes of the mesh sit on a tensor-product lattice:
 // every coordinate takes at most 1024 distinct values and their product does not exceed twice the number of nodes.
-// *is_lattice = false otherwise (pos untouched).  hi[d] = highest position along axis d.
-int lattice_positions(pfem_solver *s, DevBuf<int32_t> &pos, bool *is_lattice, int hi[3])
+// Two steps (a hierarchy across ranks merges the ranks' values between them, pfem_amg.inc: lattice_positions_global):
+// lattice_distinct -- the sorted distinct values of every axis of THIS rank's mesh nodes (*ok = false: more than 1024);
+// lattice_assign -- the positions of the dofs [0, n_rows) among given values.
+int lattice_distinct(pfem_solver *s, int count[3], std::vector<double> &h_uniq, bool *ok)
 {
     const MeshDev &m = s->mesh;
-    const int64_t no = s->n_owned;
-    *is_lattice = false;
-    if (!s->have_mesh || no < 1 || m.nElem < 1 || m.nNode > INT_MAX) return PFEM_OK;
+    *ok = false;
+    count[0] = count[1] = count[2] = 1;
+    h_uniq.assign(3 * 1024, 0.0);
+    if (!s->have_mesh || s->n_owned < 1 || m.nElem < 1 || m.nNode > INT_MAX) return PFEM_OK;
     // distinct values per axis through a 4096-slot hash table on the device (no O(n) work arrays, no sort: every multi-MB
     // allocation risks one of this stack's stalls), sorted on the host
-    const auto lt0 = std::chrono::steady_clock::now();
-    const bool lverbose = std::getenv("PFEM_AMG_VERBOSE") != nullptr;
-    auto lmark = [&](const char *what) {
-        if (!lverbose) return;
-        (void)hipStreamSynchronize(s->stream);
-        std::fprintf(stderr, "    lattice: %-30s at %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lt0).count());
-    };
-    DevBuf<double> uniq;
     DevBuf<unsigned long long> table;
     DevBuf<int> d_over;
     PFEM_TRY(table.alloc(3 * kLatticeTable));
     PFEM_TRY(d_over.alloc(3));
-    PFEM_TRY(uniq.alloc(3 * 1024));
-    lmark("allocations");
-    int count[3] = {1, 1, 1};
     // the three axes back to back, one trip to the host for all of them
     PFEM_HIP(hipMemsetAsync(table.p, 0xff, sizeof(unsigned long long) * 3 * kLatticeTable, s->stream));
     PFEM_HIP(hipMemsetAsync(d_over.p, 0, 3 * sizeof(int), s->stream));
@@ -913,14 +905,11 @@ int lattice_positions(pfem_solver *s, DevBuf<int32_t> &pos, bool *is_lattice, in
         hipLaunchKernelGGL(k_amg_distinct, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m.xyz + static_cast<int64_t>(d) * m.nNode, m.nNode,
                            table.p + static_cast<size_t>(d) * kLatticeTable, d_over.p + d);
     PFEM_TRY(check_kernel("k_amg_distinct"));
-    lmark("distinct values");
     int over[3] = {0, 0, 0};
     std::vector<unsigned long long> h_table(3 * kLatticeTable);
     PFEM_HIP(hipMemcpyAsync(over, d_over.p, 3 * sizeof(int), hipMemcpyDeviceToHost, s->stream));
     PFEM_HIP(hipMemcpyAsync(h_table.data(), table.p, sizeof(unsigned long long) * h_table.size(), hipMemcpyDeviceToHost, s->stream));
     PFEM_HIP(hipStreamSynchronize(s->stream));
-    lmark("tables on the host");
-    std::vector<double> h_uniq(3 * 1024, 0.0);
     for (int d = 0; d < m.ndim; ++d) {
         if (over[d]) return PFEM_OK;
         std::vector<double> vals;
@@ -933,19 +922,37 @@ int lattice_positions(pfem_solver *s, DevBuf<int32_t> &pos, bool *is_lattice, in
         count[d] = static_cast<int>(vals.size());
         std::copy(vals.begin(), vals.end(), h_uniq.begin() + static_cast<std::ptrdiff_t>(d) * 1024);
     }
-    if (static_cast<int64_t>(count[0]) * count[1] * count[2] > 2 * m.nNode) return PFEM_OK;
-    PFEM_HIP(hipMemcpyAsync(uniq.p, h_uniq.data(), sizeof(double) * h_uniq.size(), hipMemcpyHostToDevice, s->stream));
+    *ok = true;
+    return PFEM_OK;
+}
+int lattice_assign(pfem_solver *s, const std::vector<double> &h_uniq, const int count[3], int64_t n_rows, DevBuf<int32_t> &pos)
+{
+    const MeshDev &m = s->mesh;
+    DevBuf<double> uniq;
+    PFEM_TRY(uniq.alloc(3 * 1024));
+    PFEM_HIP(hipMemcpyAsync(uniq.p, h_uniq.data(), sizeof(double) * 3 * 1024, hipMemcpyHostToDevice, s->stream));
     const double *u0 = uniq.p, *u1 = uniq.p + 1024, *u2 = m.ndim > 2 ? uniq.p + 2048 : uniq.p;
-    PFEM_TRY(pos.alloc(static_cast<size_t>(no)));
-    PFEM_HIP(hipMemsetAsync(pos.p, 0, sizeof(int32_t) * static_cast<size_t>(no), s->stream));
+    PFEM_TRY(pos.alloc(static_cast<size_t>(std::max<int64_t>(n_rows, 1))));
+    PFEM_HIP(hipMemsetAsync(pos.p, 0, sizeof(int32_t) * static_cast<size_t>(std::max<int64_t>(n_rows, 1)), s->stream));
     if (s->have_incidence && s->d_node_row.p)         // one thread per node through the assembly's node -> row table (4.0 -> 0.1 ms at config 3) ...
         hipLaunchKernelGGL(k_amg_lattice_pos_nodes, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m.nNode, m.ndim, m.ndof, m.xyz,
-                           static_cast<const int32_t *>(s->d_node_row.p), no, u0, count[0], u1, count[1], u2, count[2], pos.p);
+                           static_cast<const int32_t *>(s->d_node_row.p), n_rows, u0, count[0], u1, count[1], u2, count[2], pos.p);
     else                                              // ... else through the elements
-    hipLaunchKernelGGL(k_amg_lattice_pos, dim3(grid_for(m.nElem * m.npe)), dim3(kBlock), 0, s->stream, m, no, u0, count[0], u1, count[1], u2, count[2], pos.p);
+    hipLaunchKernelGGL(k_amg_lattice_pos, dim3(grid_for(m.nElem * m.npe)), dim3(kBlock), 0, s->stream, m, n_rows, u0, count[0], u1, count[1], u2, count[2], pos.p);
     PFEM_TRY(check_kernel("k_amg_lattice_pos"));
-    PFEM_HIP(hipStreamSynchronize(s->stream));
-    lmark("positions");
+    PFEM_HIP(hipStreamSynchronize(s->stream));         // (uniq goes out of scope)
+    return PFEM_OK;
+}
+// *is_lattice = false when the mesh has none (pos untouched).  hi[d] = highest position along axis d.
+int lattice_positions(pfem_solver *s, DevBuf<int32_t> &pos, bool *is_lattice, int hi[3])
+{
+    *is_lattice = false;
+    int count[3];
+    std::vector<double> h_uniq;
+    bool ok = false;
+    PFEM_TRY(lattice_distinct(s, count, h_uniq, &ok));
+    if (!ok || static_cast<int64_t>(count[0]) * count[1] * count[2] > 2 * s->mesh.nNode) return PFEM_OK;
+    PFEM_TRY(lattice_assign(s, h_uniq, count, s->n_owned, pos));
     for (int d = 0; d < 3; ++d) hi[d] = count[d] - 1;
     *is_lattice = true;
     return PFEM_OK;
