@@ -73,6 +73,72 @@ __global__ void __launch_bounds__(kBlock) k_rbm_check_blocks(SellDev A, int bs, 
     if (!ok) *bad = 1;
 }
 
+// the same check with one thread per ROW (consecutive lanes read consecutive rows of the wave-sliced storage: the per-node
+// form above walks bs rows per lane, i.e. every line bs times with 1/bs of its lanes -- 1.1 + 1.8 ms on the beam's first two levels)
+__global__ void __launch_bounds__(kBlock) k_rbm_check_rows(SellDev A, int bs, int64_t n_nodes, int64_t *__restrict__ deg, int *__restrict__ bad)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t n_rows = static_cast<int64_t>(bs) * n_nodes;
+    if (r > n_rows) return;
+    if (r == n_rows) { deg[n_nodes] = 0; return; }
+    const int64_t node = r / bs;
+    const int c = static_cast<int>(r - node * bs);
+    const int64_t row0 = node * bs;
+    const int len = A.rowlen[r];
+    bool ok = len % bs == 0 && len == A.rowlen[row0];
+    if (ok) {
+        const int64_t base = rbm_row_base(A, r), base0 = rbm_row_base(A, row0);
+        int32_t c0 = 0;
+        for (int k = 0; k < len; ++k) {
+            const int32_t col = A.cols[base + 64LL * k];
+            const int d = k % bs;
+            if (d == 0) {
+                c0 = col;
+                ok = ok && c0 % bs == 0 && c0 < n_rows && (c == 0 || A.cols[base0 + 64LL * k] == c0);       // the rows of a node name the same nodes
+            } else {
+                ok = ok && col == c0 + d;
+            }
+        }
+    }
+    if (c == 0) deg[node] = ok ? len / bs : 0;
+    if (!ok) *bad = 1;
+}
+// ... and the graph's weights with DIM lanes per node (the DIM displacement rows of the node: adjacent lanes, adjacent rows),
+// 64 / DIM nodes per wave, the rows' partial sums of squares combined by shuffles
+template <int DIM>
+__global__ void __launch_bounds__(kBlock) k_rbm_graph_fill_rows(SellDev A, int bs, int64_t n_nodes, const int64_t *__restrict__ gptr,
+                                                                 int32_t *__restrict__ gcol, int32_t *__restrict__ brow, double *__restrict__ gw,
+                                                                 double *__restrict__ gdiag)
+{
+    constexpr int NPW = 64 / DIM;                        // nodes per wave
+    const int64_t wave = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = wave * NPW + lane / DIM;
+    const int c = lane % DIM;
+    if (lane >= NPW * DIM || i >= n_nodes) return;
+    const int64_t base = rbm_row_base(A, static_cast<int64_t>(bs) * i + c);
+    const int64_t q0 = gptr[i];
+    const int deg = static_cast<int>(gptr[i + 1] - q0);
+    bool have_diag = false;
+    for (int jj = 0; jj < deg; ++jj) {
+        double s2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+            const double v = A.vals[base + 64LL * (bs * jj + d)];
+            s2 += v * v;
+        }
+        const double t1 = __shfl_down(s2, 1, 64), t2 = DIM == 3 ? __shfl_down(s2, 2, 64) : 0.0;
+        if (c == 0) {
+            s2 += t1 + t2;
+            const int32_t j = A.cols[base + 64LL * (bs * jj)] / bs;
+            gcol[q0 + jj] = j;
+            brow[q0 + jj] = static_cast<int32_t>(i);
+            if (j == i) { gdiag[i] = sqrt(s2); gw[q0 + jj] = 0.0; have_diag = true; }
+            else gw[q0 + jj] = -sqrt(s2);
+        }
+    }
+    if (c == 0 && !have_diag) gdiag[i] = 0.0;
+}
 // node graph of a block-regular level: columns, the node row of every block, and the strength weights of the pairing
 // (Frobenius norm of the DIM x DIM displacement part of a node block: -norm off the diagonal, norm on it -- what
 // k_amg_graph_from_keys makes of the squared entries)
@@ -103,6 +169,54 @@ __global__ void __launch_bounds__(kBlock) k_rbm_graph_fill(SellDev A, int bs, in
         else gw[q0 + jj] = -sqrt(s2);
     }
     if (!have_diag) gdiag[i] = 0.0;
+}
+
+// ---- node bricks in one step (amg_node_bricks) ------------------------------------------------------------------------------
+// The pairing passes on a lattice whose lines are full end in bricks that a table per axis describes: position -> brick
+// coordinate (pairs 2k | 2k + 1; the node an odd line leaves over joins the pair next to it, at either end).  One check on
+// the level's node graph replaces the passes and their sorted aggregate graphs: every coupling to a neighbour one position
+// away inside the own brick is at least a quarter of the node's strongest (what a pass asks of a pair, k_amg_lat_pick /
+// k_amg_lat_absorb); else *fail and the passes take the level.
+__global__ void __launch_bounds__(kBlock) k_rbm_lat_check(int64_t nn, const int64_t *__restrict__ gptr, const int32_t *__restrict__ gcol,
+                                                           const double *__restrict__ gw, const double *__restrict__ gdiag,
+                                                           const int32_t *__restrict__ pos, const int32_t *__restrict__ table, int *__restrict__ fail)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= nn) return;
+    const int32_t pi = pos[i];
+    const int px = pi & 0x3ff, py = (pi >> 10) & 0x3ff, pz = (pi >> 20) & 0x3ff;
+    const int bx = table[px], by = table[1024 + py], bz = table[2048 + pz];
+    const double di = gdiag[i];
+    double smax = 0.0, smin_in = 1e300;
+    for (int64_t q = gptr[i]; q < gptr[i + 1]; ++q) {
+        const int32_t j = gcol[q];
+        if (j == static_cast<int32_t>(i)) continue;
+        const double sij = amg_strength(gw[q], di, gdiag[j]);
+        smax = fmax(smax, sij);
+        const int32_t pj = pos[j];
+        const int qx = pj & 0x3ff, qy = (pj >> 10) & 0x3ff, qz = (pj >> 20) & 0x3ff;
+        const int dist = abs(qx - px) + abs(qy - py) + abs(qz - pz);
+        if (dist == 1 && table[qx] == bx && table[1024 + qy] == by && table[2048 + qz] == bz) smin_in = fmin(smin_in, sij);
+    }
+    if (smin_in < 1e300 && !(smin_in > 0.0 && smin_in >= 0.25 * smax)) *fail = 1;
+}
+// aggregate of every node = its brick, numbered in z, y, x order inside the box of bricks (the lines are full: every brick is
+// occupied); blo / nbk: first brick and number of bricks along every axis
+__global__ void __launch_bounds__(kBlock) k_rbm_lat_assign(int64_t nn, const int32_t *__restrict__ pos, const int32_t *__restrict__ table, int blo0,
+                                                            int blo1, int blo2, int nbk0, int nbk1, int32_t *__restrict__ node_agg)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= nn) return;
+    const int32_t p = pos[i];
+    const int bx = table[p & 0x3ff] - blo0, by = table[1024 + ((p >> 10) & 0x3ff)] - blo1, bz = table[2048 + ((p >> 20) & 0x3ff)] - blo2;
+    node_agg[i] = bx + nbk0 * (by + nbk1 * bz);
+}
+__global__ void __launch_bounds__(kBlock) k_rbm_lat_coarse_pos(int64_t na, int blo0, int blo1, int blo2, int nbk0, int nbk1, int32_t *__restrict__ pos_c)
+{
+    const int64_t a = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (a >= na) return;
+    const int bx = static_cast<int>(a % nbk0) + blo0, by = static_cast<int>((a / nbk0) % nbk1) + blo1, bz = static_cast<int>(a / (static_cast<int64_t>(nbk0) * nbk1)) + blo2;
+    pos_c[a] = bx | (by << 10) | (bz << 20);
 }
 
 // dof -> (node, component) of a level whose dofs come bs to the node

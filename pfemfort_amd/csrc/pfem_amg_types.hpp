@@ -42,6 +42,9 @@ struct AmgLevel {
     bool lat_global = false;
     std::vector<int> lat_cuts[3];
     int lat_box[6] = {0, 0, 0, 0, 0, 0};  // box of the local nodes' positions: lowest x, y, z, highest x, y, z
+    // node bricks in one step (rigid-body levels, amg_node_bricks): the box of positions the level's nodes fill completely
+    bool lat_full = false;
+    int lat_tlo[3] = {0, 0, 0}, lat_thi[3] = {0, 0, 0};
     std::vector<double> lat_coord;        // [3 x 1024] coordinate of every position (a brick sits at its lowest corner): the corners a level
                                           // needs when it leaves the brick path (xyz below) come from here instead of travelling down the levels
     DevBuf<double> xyz;                   // coupled hierarchy with a lattice: [3 x n_nodes] a corner of every node's aggregate (see k_amg_xyz_min)

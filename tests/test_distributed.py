@@ -491,6 +491,24 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
                     continue
                 assert a.min() >= 0 and a.max() == rows_glob[l + 1] - 1 and len(np.unique(a)) == rows_glob[l + 1]
                 aggs.append(a)
+            if kind_name == "poisson":
+                # bricks in one step ACROSS the ranks: the oracle forms the aggregates itself, from the coordinates and the dofs'
+                # owners alone (global positions, the planes between the ranks padded onto brick borders, every rank numbering its
+                # own bricks; the replicated levels plain bricks of those positions), and the device's equal them entry for entry --
+                # wherever every rank's dofs fill a box of the lattice; elsewhere (sectors, foreign) the pairing passes keep the level
+                nda = prob.dm.NodeDofArrayNew.reshape(-1)
+                free = np.where(nda >= 0)[0]
+                assert np.array_equal(nda[free], np.arange(len(free)))
+                owner = np.zeros(len(free), np.int64)
+                for r in range(world):
+                    owner[int(prob.dm.row_start[r]):int(prob.dm.row_end[r])] = r
+                own_aggs = O.lattice_brick_aggregates(prob.xyz_new, prob.xyz_new[:, free], owner=owner,
+                                                      replicate_rows=0 if mesh_args["amg_distributed"] else 150000)
+                assert (own_aggs is not None) == (partition in ("slabs", "xslabs", "yslabs", "rcb", "idle")), partition
+                if own_aggs is not None:
+                    assert len(own_aggs) == len(aggs) and all(np.array_equal(x, y) for x, y in zip(own_aggs, aggs)), \
+                        ([len(np.unique(x)) for x in own_aggs], rows_glob)
+                    print(f"bricks across ranks == the oracle's own: {kind_name} x{world} {partition} {mode}, rows per level {rows_glob}")
             # the last level takes the dense inverse, or the coarsening stalled just above its limit (Chebyshev bottom)
             assert rows_glob[0] == len(prob.rhs) and rows_glob[-1] <= 256
             if not mesh_args["amg_distributed"]:
