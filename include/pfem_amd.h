@@ -482,6 +482,11 @@ int pfem_solver_set_comm_host(pfem_solver *s, int rank, int nranks, pfem_host_al
  * surfaces as PFEM_ERR_COMM after the solve instead of a hung device.                                                    */
 int pfem_solver_set_comm_peer(pfem_solver *s, int rank, int nranks, pfem_host_allreduce_fn allreduce,
                               pfem_host_exchange_fn exchange, void *ctx);
+/* Collective teardown step of the communication backend, for all ranks while they can still reach each other (the host mirror's
+ * free() calls it): the peer-memory transport waits here until no rank may still write into another's region.  Destroying a
+ * solver without it is safe but not synchronised (the destructor is deliberately NOT collective).  Idempotent; PFEM_OK without a
+ * backend.  Reference: MPI_Finalize-time destruction of the VecScatter inside KSPDestroy (solverpetsc.F:254-320). */
+int pfem_solver_comm_shutdown(pfem_solver *s);
 /* Transport self-test (collective, no mesh needed): stamped buffers of `count` doubles to every other rank (to itself
  * when there is one rank) through the backend's exchange, then an all-reduce of a known vector; *bad = wrong entries. */
 int pfem_solver_comm_selftest(pfem_solver *s, int64_t count, int64_t *bad);

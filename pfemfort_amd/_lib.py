@@ -135,6 +135,7 @@ SIGNATURES = {
     "pfem_solver_set_comm_host": [_P, _I, _I, HOST_ALLREDUCE_FN, HOST_EXCHANGE_FN, _P],
     "pfem_solver_comm_bench": [_P, C.c_int64, _I, _P, _P],
     "pfem_solver_set_comm_peer": [_P, _I, _I, HOST_ALLREDUCE_FN, HOST_EXCHANGE_FN, _P],
+    "pfem_solver_comm_shutdown": [_P],
     "pfem_solver_comm_info": [_P, _P, _P, _P, _P],
     "pfem_solver_comm_describe": [_P, _P, _I, _P, _P, _P, _P, _P],
     "pfem_solver_comm_selftest": [_P, _L, _P],

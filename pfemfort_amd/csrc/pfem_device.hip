@@ -335,6 +335,10 @@ struct CommBackend {
     virtual int exchange(int np, const int *peers, const int64_t *off, const double *d_send, double *d_recv, hipStream_t st) = 0;
     // after a solve (streams idle): did the transport see an error it could not report from inside a stream?
     virtual int health() { return PFEM_OK; }
+    // a device-side transport stops the running solve through this word (CgCtl::flag of the solver) when one of its waits fails
+    virtual void set_abort_word(int *) {}
+    // collective teardown step of transports that need one (peer memory: a barrier before the regions go); idempotent
+    virtual int shutdown() { return PFEM_OK; }
 };
 
 // ---------------------------------------------------------------------------
@@ -2743,11 +2747,21 @@ struct PeerBackend final : CommBackend {
     int *d_arrive = nullptr;
     bool up = false;
     PeerBackend(pfem_host_allreduce_fn a, pfem_host_exchange_fn e, void *c) : host(a, e, c) {}
+    // collective, on request (pfem_solver_comm_shutdown, called by the host mirror's free() while the process group lives): nobody
+    // is still writing an acknowledgement into a region when it goes.  The destructor itself is NOT collective -- it also runs
+    // from an exception on one rank, from a backend swapped on one rank, from interpreter shutdown after the group has gone,
+    // where a collective would hang or pair with another rank's different call.
+    int shutdown() override
+    {
+        if (!up) return PFEM_OK;
+        (void)hipDeviceSynchronize();
+        up = false;
+        double one = 1.0;
+        return (host.ar && host.ar(host.ctx, &one, 1) != 0) ? PFEM_ERR_COMM : PFEM_OK;
+    }
     ~PeerBackend() override
     {
         (void)hipDeviceSynchronize();
-        // nobody may still be writing an acknowledgement into this rank's region when it goes: the ranks leave together
-        if (up && host.ar) { double one = 1.0; (void)host.ar(host.ctx, &one, 1); }
         for (void *p : mapped)
             if (p) (void)hipIpcCloseMemHandle(p);
         if (base) (void)hipFree(base);
@@ -2865,9 +2879,10 @@ struct PeerBackend final : CommBackend {
     {
         int e = 0;
         if (base && hipMemcpy(&e, W.m[rank].err, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return PFEM_ERR_HIP;
-        if (e) { set_last_error("peer transport: a wait for a neighbour's flag timed out (10 s)"); return PFEM_ERR_COMM; }
+        if (e) { set_last_error("peer transport: a wait for a neighbour's flag timed out (10 s) or the ranks' message counts came apart; the transport is down"); return PFEM_ERR_COMM; }
         return PFEM_OK;
     }
+    void set_abort_word(int *w) override { W.abort_word = w; }
 };
 
 int ensure_comm_stream(pfem_solver *s)
@@ -2963,6 +2978,14 @@ extern "C" int pfem_solver_set_comm_peer(pfem_solver *s, int rank, int nranks, p
     const int rc = b->init(rank, nranks, s->device);
     if (rc != PFEM_OK) { b->up = false; delete b; return rc; }
     return install_backend(s, rank, nranks, b);
+}
+
+extern "C" int pfem_solver_comm_shutdown(pfem_solver *s)
+{
+    if (!s) return PFEM_ERR_ARG;
+    if (!s->comm) return PFEM_OK;
+    PFEM_TRY(use_device(s));
+    return s->comm->shutdown();
 }
 
 extern "C" int pfem_solver_set_comm_host(pfem_solver *s, int rank, int nranks, pfem_host_allreduce_fn allreduce,
@@ -3449,6 +3472,7 @@ int run_pcg(pfem_solver *s)
         s->hist_cap = s->maxits + 2;
     }
     PFEM_HIP(hipMemsetAsync(ctl, 0, sizeof(CgCtl), s->stream));
+    if (s->comm) s->comm->set_abort_word(&ctl->flag);          // (a device-side transport ends the solve through it when a wait fails)
 
     const int32_t *grow0 = s->d_group_row0.p;
     s->block_pc_ok = true;
@@ -3913,6 +3937,7 @@ int run_pcg_single(pfem_solver *s)
         s->hist_cap = s->maxits + 2;
     }
     PFEM_HIP(hipMemsetAsync(ctl, 0, sizeof(CgCtl), s->stream));
+    if (s->comm) s->comm->set_abort_word(&ctl->flag);          // (a device-side transport ends the solve through it when a wait fails)
     // Jacobi: dinv = 1 / diag(A); interface diagonals and rhs are summed over the ranks
     if (n > 0) {
         hipLaunchKernelGGL(k_extract_diag, dim3(grid_for(n)), block, 0, s->stream, A, s->d_dinv.p);

@@ -19,16 +19,23 @@ using namespace pfem;
 #ifdef _OPENMP
 // The bookkeeping loops below run as OpenMP loops; the GPU work that follows them is often launch-bound (a small problem's CG
 // iterations).  Idle OpenMP workers that spin before they sleep take the cores the HIP runtime's launch path needs: measured
-// 3-5x on the iterations of a 10^6-dof problem for ~0.2 s after a parallel region (profiles/LAB_NOTES.md).  Unless the host
-// has chosen a wait policy itself, the workers of this process sleep at once (read by the OpenMP runtime when it starts,
-// i.e. at the first parallel region after this library was loaded).
+// 3-5x on the iterations of a 10^6-dof problem for ~0.2 s after a parallel region (profiles/LAB_NOTES.md).  The workers of
+// THIS library's regions sleep at once: kmp_set_blocktime(0) on the calling thread around the region -- an API of the
+// library's own runtime (LLVM libomp, what hipcc -fopenmp links).  Nothing touches the process environment: round 4 set
+// OMP_WAIT_POLICY / KMP_BLOCKTIME from a static initializer, which also put every other OpenMP user of the process -- the
+// oracle's libgomp in bench.py's cpu_baseline leg, 2.1x slower for it -- on a passive policy, and raced with getenv.
 namespace {
-const int g_omp_passive = [] {
-    (void)setenv("OMP_WAIT_POLICY", "passive", 0);
-    (void)setenv("KMP_BLOCKTIME", "0", 0);
-    return 0;
-}();
+struct OmpQuiet {
+    int old;
+    OmpQuiet() : old(kmp_get_blocktime()) { kmp_set_blocktime(0); }
+    ~OmpQuiet() { kmp_set_blocktime(old); }
+};
 }  // namespace
+#define PFEM_OMP_CAT2(a, b) a##b
+#define PFEM_OMP_CAT(a, b) PFEM_OMP_CAT2(a, b)
+#define PFEM_OMP_QUIET() OmpQuiet PFEM_OMP_CAT(omp_quiet_, __LINE__)
+#else
+#define PFEM_OMP_QUIET() ((void)0)
 #endif
 
 // ---------------------------------------------------------------------------
@@ -174,6 +181,7 @@ extern "C" int pfem_gen_box_tets(double x0, double x1, int nEx, double y0, doubl
         for (int j = 0; j < nNy; ++j) yr[j] = text_round8(ys[j]);
         for (int k = 0; k < nNz; ++k) zr[k] = text_round8(zs[k]);
         double *X = xyz, *Y = xyz + nNode, *Z = xyz + 2 * nNode;
+    PFEM_OMP_QUIET();
 #pragma omp parallel for schedule(static)
         for (int k = 0; k < nNz; ++k)
             for (int j = 0; j < nNy; ++j) {
@@ -191,6 +199,7 @@ extern "C" int pfem_gen_box_tets(double x0, double x1, int nEx, double y0, doubl
         static const int split[6][4] = {{0, 1, 3, 5}, {0, 3, 2, 5}, {2, 3, 7, 5},
                                         {4, 6, 7, 2}, {4, 7, 5, 2}, {0, 4, 5, 2}};
         const int64_t nElem = 6LL * nEx * nEy * (kz1 - kz0);
+    PFEM_OMP_QUIET();
 #pragma omp parallel for schedule(static)
         for (int k = kz0; k < kz1; ++k)
             for (int j = 0; j < nEy; ++j)
@@ -251,6 +260,7 @@ extern "C" int pfem_partition_box_slabs_axis(int nEx, int nEy, int nEz, int axis
         for (int k = lo; k < hi; ++k) layer_part[k] = p;
     }
     if (elem_proc_id) {
+    PFEM_OMP_QUIET();
 #pragma omp parallel for schedule(static)
         for (int k = 0; k < nEz; ++k)
             for (int j = 0; j < nEy; ++j)
@@ -262,6 +272,7 @@ extern "C" int pfem_partition_box_slabs_axis(int nEx, int nEy, int nEz, int axis
     }
     if (node_proc_id) {
         // node plane c is touched by hex layers c-1 and c: the lowest part wins
+    PFEM_OMP_QUIET();
 #pragma omp parallel for schedule(static)
         for (int k = 0; k <= nEz; ++k)
             for (int j = 0; j <= nEy; ++j)
@@ -428,6 +439,7 @@ extern "C" int pfem_renumber_mesh(int64_t nNode, int ndim, int64_t nElem, int np
     if ((nElem > 0 && (!conn_old || !conn_new)) || (nNode > 0 && (!xyz_old || !xyz_new))) return PFEM_ERR_ARG;
     int bad = 0;
     const int64_t nc = static_cast<int64_t>(npElem) * nElem;
+    PFEM_OMP_QUIET();
 #pragma omp parallel for schedule(static) reduction(| : bad) if (nc > 100000)
     for (int64_t i = 0; i < nc; ++i) {
         const int32_t n = conn_old[i];
@@ -436,6 +448,7 @@ extern "C" int pfem_renumber_mesh(int64_t nNode, int ndim, int64_t nElem, int np
     for (int d = 0; d < ndim; ++d) {
         const double *src = xyz_old + static_cast<int64_t>(d) * nNode;
         double *dst = xyz_new + static_cast<int64_t>(d) * nNode;
+    PFEM_OMP_QUIET();
 #pragma omp parallel for schedule(static) reduction(| : bad) if (nNode > 100000)
         for (int64_t i = 0; i < nNode; ++i) {
             const int32_t o = node_map_get_old[i];
@@ -454,6 +467,7 @@ extern "C" int pfem_elem_dof_array(int64_t nElem, int npElem, int ndof, const in
         for (int d = 0; d < ndof; ++d) {
             const int32_t *c = conn_new + static_cast<int64_t>(i) * nElem;
             int32_t *o = edof + static_cast<int64_t>(i * ndof + d) * nElem;
+    PFEM_OMP_QUIET();
 #pragma omp parallel for schedule(static)
             for (int64_t e = 0; e < nElem; ++e) o[e] = NodeDofArrayNew[static_cast<int64_t>(c[e]) * ndof + d];
         }
@@ -597,6 +611,7 @@ void emit_records(std::FILE *f, int64_t n, int max_rec, F fmt)
     std::vector<size_t> used(static_cast<size_t>(nt), 0);
     for (auto &b : bufs) b.resize(static_cast<size_t>(block) * max_rec);
     for (int64_t base = 0; base < n; base += block * nt) {
+    PFEM_OMP_QUIET();
 #pragma omp parallel for schedule(static, 1) num_threads(nt)
         for (int t = 0; t < nt; ++t) {
             const int64_t b = base + t * block, e = std::min(n, b + block);
@@ -720,6 +735,7 @@ std::vector<TextPiece> text_pieces(const char *buf, int64_t len)
     }
     pc[nt - 1].end = len;
     for (int t = 0; t + 1 < nt; ++t) pc[t].end = std::max(pc[t].end, pc[t].begin);
+    PFEM_OMP_QUIET();
 #pragma omp parallel for schedule(static, 1)
     for (int t = 0; t < nt; ++t) {
         TextPiece &q = pc[t];
@@ -815,6 +831,7 @@ extern "C" int pfem_text_table_parse(const char *buf, int64_t len, int64_t rows,
     if (first.back() != rows) return PFEM_ERR_ARG;
     int bad = 0;
     const int np = static_cast<int>(pc.size());
+    PFEM_OMP_QUIET();
 #pragma omp parallel for schedule(static, 1) reduction(| : bad)
     for (int t = 0; t < np; ++t) {
         const char *p = buf + pc[t].begin;

@@ -7,7 +7,14 @@
 // Visibility (cdna_hip_programming.md G16): payload stores -> system-scope fence -> flag store (release); the consumer polls
 // the flag with acquire loads, fences, then reads the payload.  Per-XCD L2s are not coherent with each other, so both
 // fences are needed even between two processes on ONE device.  Every wait is bounded (kPeerSpinTicks of the 100 MHz
-// wall clock); a timeout sets the error word the host reads after the solve instead of hanging the device.
+// wall clock); a timeout sets the error word the host reads after the solve instead of hanging the device -- and, so that the
+// solve does not run on with stale data at 10 s per exchange: the CG's control word (abort_word: every kernel of the iteration
+// leaves at once when it is non-zero) and every later exchange / all-reduce of this rank returns at once (the error word is
+// sticky; the transport is finished, the solve reports PFEM_ERR_COMM).
+// ORDER: all exchanges of a pair of ranks must be enqueued in one order on both (the solver enqueues them on its compute
+// stream or on its communication stream behind an event, never concurrently): message e + 1 of a pair may land while message e
+// is still unread -- it goes to the box of the other parity -- but nothing beyond that; a flag further ahead is a protocol
+// error and is reported as one, not read past.
 #pragma once
 
 namespace pfem {
@@ -24,19 +31,29 @@ struct PeerMail {                 // one rank's mailbox as a peer sees it (all d
     double *abox;                 // [2][nranks][cap_a] all-reduce payload
 };
 constexpr int kPeerMaxRanks = 16;
+constexpr int kPeerAbortReason = -100;     // what the CG's control word says after a transport failure (not a KSPConvergedReason)
 struct PeerWorld {
     PeerMail m[kPeerMaxRanks];    // m[rank] = this rank's own mailbox (local pointers)
     int rank, nranks;
     int64_t cap_x, cap_a;
+    int *abort_word;              // the running solve's control word (CgCtl::flag) or null
 };
+__device__ __forceinline__ void peer_fail(const PeerWorld &W)
+{
+    *W.m[W.rank].err = 1;
+    if (W.abort_word) __hip_atomic_store(W.abort_word, kPeerAbortReason, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
-__device__ __forceinline__ bool peer_wait(const unsigned long long *flag, unsigned long long want, int *err)
+// wait until *flag >= want; false (and the failure recorded) on a timeout or when the flag is more than `ahead` beyond it
+__device__ __forceinline__ bool peer_wait(const PeerWorld &W, const unsigned long long *flag, unsigned long long want, unsigned long long ahead)
 {
     const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+    unsigned long long v;
+    while ((v = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) < want) {
         __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > kPeerSpinTicks) { *err = 1; return false; }
+        if (wall_clock64() - t0 > kPeerSpinTicks) { peer_fail(W); return false; }
     }
+    if (v > want + ahead) { peer_fail(W); return false; }       // the ranks' message counts have come apart
     return true;
 }
 
@@ -57,7 +74,8 @@ __global__ void __launch_bounds__(1024) k_peer_exchange(PeerWorld W, PeerExchang
     const unsigned long long e = X.epoch[k];
     const int64_t cnt = X.off[k + 1] - X.off[k];
     const PeerMail &mine = W.m[r], &his = W.m[q];
-    if (threadIdx.x == 0) ok_s = (e < 3 || peer_wait(&mine.xack[q], e - 2, mine.err)) ? 1 : 0;       // the slot of epoch e - 2 is free again
+    // (a transport that has failed once stays down: no more 10 s waits on flags that will never come)
+    if (threadIdx.x == 0) ok_s = (*mine.err == 0 && (e < 3 || peer_wait(W, &mine.xack[q], e - 2, 1))) ? 1 : 0;       // the slot of epoch e - 2 is free again
     __syncthreads();
     if (!ok_s) return;
     double *dst = his.xbox + (static_cast<int64_t>(e & 1) * W.nranks + r) * W.cap_x;
@@ -67,7 +85,7 @@ __global__ void __launch_bounds__(1024) k_peer_exchange(PeerWorld W, PeerExchang
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_store(&his.xflag[r], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        ok_s = peer_wait(&mine.xflag[q], e, mine.err) ? 1 : 0;
+        ok_s = peer_wait(W, &mine.xflag[q], e, 1) ? 1 : 0;
     }
     __syncthreads();
     if (!ok_s) return;
@@ -91,7 +109,7 @@ __global__ void __launch_bounds__(1024) k_peer_allreduce(PeerWorld W, unsigned l
     if (static_cast<int>(blockIdx.x) < nr) {
         const int q = blockIdx.x;
         const PeerMail &his = W.m[q];
-        if (threadIdx.x == 0) ok_s = (e < 3 || peer_wait(&mine.aack[q], e - 2, mine.err)) ? 1 : 0;
+        if (threadIdx.x == 0) ok_s = (*mine.err == 0 && (e < 3 || peer_wait(W, &mine.aack[q], e - 2, 1))) ? 1 : 0;
         __syncthreads();
         if (ok_s) {
             double *dst = his.abox + (static_cast<int64_t>(e & 1) * nr + r) * W.cap_a;
@@ -103,14 +121,14 @@ __global__ void __launch_bounds__(1024) k_peer_allreduce(PeerWorld W, unsigned l
     }
     // every block waits for all contributions (and for this rank's own pushes to have read d: the block-level arrival count)
     if (threadIdx.x == 0) {
-        int ok = 1;
-        for (int q = 0; q < nr && ok; ++q) ok = peer_wait(&mine.aflag[q], e, mine.err) ? 1 : 0;
+        int ok = *mine.err == 0 ? 1 : 0;
+        for (int q = 0; q < nr && ok; ++q) ok = peer_wait(W, &mine.aflag[q], e, 1) ? 1 : 0;
         if (static_cast<int>(blockIdx.x) < nr) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         if (ok) {
             const unsigned long long t0 = wall_clock64();
             while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < nr) {      // all pushes of this rank have read d
                 __builtin_amdgcn_s_sleep(2);
-                if (wall_clock64() - t0 > kPeerSpinTicks) { *mine.err = 1; ok = 0; break; }
+                if (wall_clock64() - t0 > kPeerSpinTicks) { peer_fail(W); ok = 0; break; }
             }
         }
         ok_s = ok;

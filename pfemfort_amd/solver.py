@@ -69,15 +69,20 @@ class PetscSolver:
         L.check(L.lib().pfem_solver_set_zero(self._h), "PetscSolver%setZero")
 
     # ---- solverpetsc.F:254-278 -------------------------------------------------------
-    def free(self):
+    def free(self, collective=True):
+        """``collective``: the explicit call of a multi-rank run, made by every rank while the process group lives -- the
+        communication backend's teardown step (pfem_solver_comm_shutdown: a barrier of the peer-memory transport) runs first.
+        The garbage collector's call is not collective."""
         if self._h:
+            if collective and self._keep:            # (hooks are kept alive here: a backend was attached)
+                L.lib().pfem_solver_comm_shutdown(self._h)
             L.lib().pfem_solver_destroy(self._h)
             self._h = C.c_void_p(None)
         self._keep.clear()
 
     def __del__(self):
         try:
-            self.free()
+            self.free(collective=False)
         except Exception:
             pass
 

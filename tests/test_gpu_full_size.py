@@ -141,17 +141,29 @@ def test_elasticity_beam_config4():
     v_sc, f_sc = s.getCSR()[2], s.getRHS()
     s.setAssemblyMode("gather"); s.assemble(H.ELAST_ELEMDATA, H.TIMEDATA)      # row-per-thread LDS form
     v_g, f_g = s.getCSR()[2], s.getRHS()
-    dv, df = np.abs(v_sc - v_g), np.abs(f_sc - f_g)
-    assert dv.max() <= 1e-12 * np.abs(v_g).max() and df.max() <= 1e-12 * np.abs(f_g).max(), (
-        f"scatter against gather: K differs by up to {dv.max():.3e} in {(dv > 1e-12 * np.abs(v_g).max()).sum()} entries "
-        f"(first at {np.argmax(dv > 1e-12 * np.abs(v_g).max())}), F by up to {df.max():.3e}")
-    s.assemble(H.ELAST_ELEMDATA, H.TIMEDATA)
-    assert np.array_equal(s.getCSR()[2], v_g) and np.array_equal(s.getRHS(), f_g)   # bit-reproducible
-    # the oracle at this size (4.5 M elements, 103 M entries): pattern, K and F bit for bit
+    # the oracle at this size (4.5 M elements, 103 M entries): pattern, K and F of the gather form bit for bit; the atomic
+    # scatter form (the hub-row fallback) against the ORACLE too, not against gather: sums in another order, <= 1e-12 max|K|
     rowptr, cols, _ = s.getCSR()
     o_rowptr, o_cols, o_vals, o_rhs = _oracle_system(O.ELAST_TET, mesh, O.ELAST_ELEMDATA)
     assert np.array_equal(rowptr, o_rowptr) and np.array_equal(cols, o_cols)
+    dv, df = np.abs(v_sc - o_vals), np.abs(f_sc - o_rhs)
+    tol = 1e-12 * np.abs(o_vals).max()
+    if not (dv.max() <= tol and df.max() <= 1e-12 * np.abs(o_rhs).max()):
+        # a wrong scatter matrix was seen ONCE in round 4 and never again (profiles/LAB_NOTES.md): if it ever comes back, say which
+        # entries, in rows of what length, and whether a contribution was lost or added twice (the difference against the entry)
+        bad = np.nonzero(dv > tol)[0]
+        rows = np.searchsorted(rowptr, bad, side="right") - 1
+        out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        np.savez(os.path.join(out, f"scatter_mismatch_{os.getpid()}.npz"), slot=bad, row=rows, rowlen=np.diff(rowptr)[rows], col=cols[bad],
+                 scatter=v_sc[bad], oracle=o_vals[bad], f_bad=np.nonzero(df > 1e-12 * np.abs(o_rhs).max())[0])
+        raise AssertionError(
+            f"scatter against the oracle: K differs by up to {dv.max():.3e} (max|K| {np.abs(o_vals).max():.3e}) in {len(bad)} entries, rows "
+            f"{rows[:8].tolist()} of lengths {np.diff(rowptr)[rows[:8]].tolist()}, scatter/oracle {(v_sc[bad[:8]] / o_vals[bad[:8]]).tolist()}; "
+            f"F by up to {df.max():.3e}; dumped to gpurun_out/")
     assert np.array_equal(v_g, o_vals) and np.array_equal(f_g, o_rhs)
+    s.assemble(H.ELAST_ELEMDATA, H.TIMEDATA)
+    assert np.array_equal(s.getCSR()[2], v_g) and np.array_equal(s.getRHS(), f_g)   # bit-reproducible
     del v_sc, v_g, rowptr, cols
     N = dm.size_global
     rng = np.random.default_rng(4)

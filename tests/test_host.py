@@ -315,3 +315,20 @@ def test_vtk_writer_numbers_identical_to_printf(tmp_path):
     assert got[:-1] == [" %11d %11d   %.16E" % (i + 1, nN - i, v) for i, v in enumerate(vals)] and got[-1] == ""
     H.write_temp_dat(str(t), vals[:9000])
     assert t.read_text() == "".join("   %.16E\n" % v for v in vals[:9000])
+
+
+def test_library_leaves_the_process_environment_alone():
+    """Round 4's static initializer set OMP_WAIT_POLICY / KMP_BLOCKTIME for the whole process (it slowed the oracle's
+    libgomp in bench.py's cpu_baseline leg 2.1x); the library now quiets its OWN OpenMP regions through its runtime's API."""
+    import ctypes
+    import subprocess
+    import sys
+    code = ("import os, ctypes\n"
+            "os.environ.pop('OMP_WAIT_POLICY', None); os.environ.pop('KMP_BLOCKTIME', None)\n"
+            "import pfemfort_amd\nfrom pfemfort_amd import host as H\n"
+            "H.gen_box_tets(-1, 1, 12, -1, 1, 12, -1, 1, 12)\n"
+            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
+            "print(libc.getenv(b'OMP_WAIT_POLICY'), libc.getenv(b'KMP_BLOCKTIME'))\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("OMP_WAIT_POLICY", "KMP_BLOCKTIME")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "None None", (r.stdout, r.stderr[-500:])
