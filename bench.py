@@ -294,6 +294,18 @@ def parse_args():
                          "concatenated) of a recursive-coordinate-bisection partition, solved on one rank; shuffle: a random "
                          "permutation of the node ids -- the worst case of an unstructured mesh file.  Mesh built on the host and "
                          "uploaded (untimed)")
+    ap.add_argument("--mode", choices=["batched", "compat"], default="batched",
+                    help="compat: the UNCHANGED driver's own path instead of the batched one -- a Fortran host program (tests/native/"
+                         "boundary_check.F90, the build's counterpart of tetrapoissonparallelimpl1.F:786-905) loops over the elements "
+                         "on the host: element routine, MatSetValues(INSERT_VALUES) pass, setZero, MatSetValues / VecSetValues(ADD_VALUES), "
+                         "then the GPU solves.  One process, one GPU; prints its own JSON line (not the driver's contract line)")
+    ap.add_argument("--jitter", type=float, default=0.0,
+                    help="move every node that carries no Dirichlet value by up to this fraction of the cell size (host-generated mesh, "
+                         "uploaded): the coordinates no longer form a lattice, so -pc_type gamg takes the path any unstructured file "
+                         "mesh takes -- matching on the strength graph along a Morton curve instead of bricks.  One rank")
+    ap.add_argument("--no-transport-ab", action="store_true", help="N>1: skip the companion run over the peer-memory transport")
+    ap.add_argument("--transport-ab-timeout", type=float, default=150.0,
+                    help="N>1: seconds the peer-transport companion may take before the line is printed without it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-step", action="store_true", help="skip the extra (untimed) step at rtol 1e-10")
     ap.add_argument("--pc", choices=["jacobi", "pbjacobi", "gamg"], default="gamg",
@@ -343,7 +355,7 @@ class Job:
         self.rccl_dead = False
 
 
-def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=False, pc=None):
+def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=False, pc=None, transport=None, probe_comm=False):
     """One configuration through the whole hot path on this job's ranks: device-generated slab, transport, pattern,
     `warmup` + `steps` steps (assembly + solve) bracketed by barriers; returns everything the JSON line needs."""
     import faulthandler
@@ -371,12 +383,22 @@ def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=Fa
     if args.single_reduction:
         solver.setSingleReduction(True)
     dm_host = mesh_host = None
-    if args.numbering == "lattice" or world > 1:
+    if (args.numbering == "lattice" and args.jitter <= 0.0) or world > 1:
         solver.generateBoxMesh(kind, *box, bc_mode=bc_mode, nparts=world, part=rank, axis=axis)
     else:
         # the same mesh under another node numbering: host generator, renumbering, upload (all untimed setup)
         mesh_host = H.gen_box_tets(*box, bc_mode=bc_mode, ndof=ndof)
-        if args.numbering == "shuffle":
+        if args.jitter > 0.0:
+            # nodes without a Dirichlet value move inside a ball of radius jitter * (smallest cell edge): Kuhn's tetrahedra keep
+            # their orientation up to 0.28 (half their smallest altitude h / sqrt 3), the boundary values stay those of the lattice
+            hmin = min((ext[1] - ext[0]) / nEx, (ext[3] - ext[2]) / nEy, (ext[5] - ext[4]) / nEz)
+            rng = np.random.default_rng(7)
+            d = rng.uniform(-1.0, 1.0, size=mesh_host.xyz.shape) * (args.jitter * hmin / np.sqrt(3.0))
+            d[:, np.unique(mesh_host.bc_node)] = 0.0
+            mesh_host = H.Mesh(mesh_host.xyz + d, mesh_host.conn, mesh_host.bc_node, mesh_host.bc_dof, mesh_host.bc_val, box=mesh_host.box)
+        if args.numbering == "lattice":
+            dm_host = H.dof_numbering(mesh_host.nNode, ndof, mesh_host.bc_node, mesh_host.bc_dof, mesh_host.bc_val)
+        elif args.numbering == "shuffle":
             perm = np.random.default_rng(2024).permutation(mesh_host.nNode).astype(np.int32)      # old id -> shuffled id
             xyz = np.empty_like(mesh_host.xyz)
             xyz[:, perm] = mesh_host.xyz
@@ -397,7 +419,25 @@ def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=Fa
         # RCCL inside the library unless the group is gloo.  If RCCL cannot be brought up or fails the transport self-test
         # on ANY rank, all ranks fall back together to host hooks over a gloo subgroup: slow, but a result.
         why = None
-        if (args.backend != "gloo" and not J.rccl_dead) or (args.simulate_rccl_failure and not J.rccl_dead):
+        if transport == "peer":
+            # the A/B companion of an N > 1 line: the same steps over the peer-memory transport (device-side boxes + flags mapped
+            # through hipIpc*, bring-up over gloo hooks).  Any rank's failure -- bring-up or self-test -- is everybody's: the case
+            # is skipped with the reason, together
+            if J.gloo_group is None and args.backend != "gloo":
+                J.gloo_group = dist.new_group(backend="gloo")
+            try:
+                hooks = PD.attach(solver, dist, torch, staged=True, group=J.gloo_group, peer=True)
+                bad = solver.commSelftest(4096)
+                why = f"self-test: {bad} wrong entries" if bad else None
+            except pf.PfemError as e:
+                why = str(e)
+            votes = [None] * world
+            dist.all_gather_object(votes, why)
+            why = next((v for v in votes if v), None)
+            if why:
+                solver.free(collective=False)
+                return {"skipped": f"peer-memory transport not usable here: {why}"}
+        elif (args.backend != "gloo" and not J.rccl_dead) or (args.simulate_rccl_failure and not J.rccl_dead):
             try:
                 if args.simulate_rccl_failure:
                     raise pf.PfemError(9, "simulated", "--simulate-rccl-failure")
@@ -412,7 +452,7 @@ def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=Fa
             if why:
                 J.rccl_dead = True
                 J.fallback_reason = f"RCCL was not usable: {why}"
-        if args.backend == "gloo" or J.rccl_dead:
+        if transport != "peer" and (args.backend == "gloo" or J.rccl_dead):
             if J.gloo_group is None and args.backend != "gloo":
                 J.gloo_group = dist.new_group(backend="gloo")
             hooks = PD.attach(solver, dist, torch, staged=True, group=J.gloo_group)
@@ -541,6 +581,22 @@ def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=Fa
              row_group=solver.spmvRowGroup(), final=solver.commDescribe() if world > 1 else None,
              ms_per_step=elapsed / steps * 1e3, ms_per_iteration=acc["sol_ms"] / steps / max(its, 1))
     R.pop("xyz_free", None)
+    if world > 1 and probe_comm:
+        # what the links cost, measured in THIS job on THIS transport (collective; SURVEY 8(e)'s message sizes): a face of config 4
+        # (51 x 51 nodes x 3 dofs = 62 KB) and of config 5 (401^2 dofs = 1.29 MB) with the two slab neighbours, the CG's 3 scalars
+        # and the 125 000-row right-hand side of a replicated multigrid level through the all-reduce
+        try:
+            x62, a3 = solver.commBench(7803, 100, allreduce_count=3, slab_neighbours=True)
+            x129, a125 = solver.commBench(160801, 50, allreduce_count=125000, slab_neighbours=True)
+            R["comm_bench"] = {"exchange_62KB_with_slab_neighbours_us": 1e3 * x62, "exchange_1.29MB_with_slab_neighbours_us": 1e3 * x129,
+                               "allreduce_3_doubles_us": 1e3 * a3, "allreduce_125000_doubles_us": 1e3 * a125, "transport": solver.commDescribe()["backend"]}
+        except pf.PfemError as e:
+            R["comm_bench"] = {"skipped": str(e)}
+        if R["pc_in_effect"] == "gamg" and (R["amg_layout"] or {}).get("coupled"):
+            try:
+                R["cycle_profile"] = solver.amgCycleProfile()
+            except pf.PfemError as e:
+                R["cycle_profile"] = {"skipped": str(e)}
     solver.free()
     return R
 
@@ -571,8 +627,83 @@ def comm_block(J, R):
     return out
 
 
+def compat_mode(args):
+    """`--mode compat`: what the reference's unchanged driver costs through the drop-in boundary at this size.
+    The problem is prepared here (host generator + the driver's numbering, untimed), handed to the build's Fortran host program as
+    a binary file, and that program -- a CHILD process, it alone touches the GPU -- runs the reference's call sequence:
+    MatSetValues(INSERT_VALUES) per element (:791-802), setZero, the element loop with StiffnessResidualPoissonLinearTetra +
+    MatSetValues / VecSetValues(ADD_VALUES) (:828-884), factoriseAndSolve (:898-902).  Beside it: the oracle's serial assembly of
+    the same mesh on this host (what the same loop costs without the boundary)."""
+    import subprocess
+    import tempfile
+
+    import numpy as np
+    from oracle import pfem_oracle as O
+    from pfemfort_amd import host as H
+    n = args.n
+    exe = os.path.join(ROOT, "pfemfort_amd", "fortran", "build", "boundary_check")
+    if not os.path.exists(exe):
+        raise SystemExit(f"{exe} is not built (make -C pfemfort_amd/fortran check: needs flang where the tree is built)")
+    beam = args.workload == "beam"
+    ndof = 3 if beam else 1
+    box = (-0.5, 0.5, n // 4, 0.0, 6.0, 3 * n // 2, -0.5, 0.5, n // 4) if beam else (-1, 1, n, -1, 1, n, -1, 1, n)
+    t0 = time.perf_counter()
+    mesh = H.gen_box_tets(*box, bc_mode=1 if beam else 0, ndof=ndof)
+    dm = H.dof_numbering(mesh.nNode, ndof, mesh.bc_node, mesh.bc_dof, mesh.bc_val)
+    conn_new, xyz_new = H.renumber_mesh(mesh, dm)
+    edof = H.elem_dof_array(conn_new, dm.NodeDofArrayNew)
+    ed = np.zeros(6)
+    src = H.ELAST_ELEMDATA if beam else H.POISSON_ELEMDATA
+    ed[:len(src)] = src
+    N = int(dm.size_global)
+    t_prepare = time.perf_counter() - t0
+    # the oracle's serial assembly of the same system (pattern outside its timer, like the INSERT pass here)
+    O.set_threads(1)
+    o_edof = O.elem_dof_array(mesh.conn, dm.NodeDofArrayNew)
+    rowptr, cols = O.csr_pattern(o_edof, N)
+    t0 = time.perf_counter()
+    O.assemble(O.ELAST_TET if beam else O.POISSON_TET, mesh.xyz, mesh.conn, o_edof, dm.solnApplied, O.ELAST_ELEMDATA if beam else O.POISSON_ELEMDATA, N, rowptr, cols)
+    t_oracle = time.perf_counter() - t0
+    del rowptr, cols
+    out = {"mode": "compat", "what": "the reference driver's call sequence through the drop-in boundary: Fortran host loop (element routine + MatSetValues / "
+                                     "VecSetValues per element) -> C ABI, the GPU solves (tests/native/boundary_check.F90 = tetrapoissonparallelimpl1.F:786-905 "
+                                     "without the mesh bookkeeping)",
+           "config": {"workload": f"{box[2]}x{box[5]}x{box[8]}x6 tet {'elasticity beam' if beam else 'Poisson'}", "elements": int(mesh.nElem), "free_dofs": N},
+           "pc": args.pc, "rtol": args.rtol, "prepare_s_untimed": t_prepare, "oracle_serial_assembly_s": t_oracle}
+    with tempfile.TemporaryDirectory() as tmp:
+        with open(os.path.join(tmp, "problem.bin"), "wb") as f:
+            np.array([ndof, mesh.nNode, mesh.nElem, N, 1], np.int32).tofile(f)
+            np.array([N], np.int32).tofile(f)
+            np.zeros(mesh.nElem, np.int32).tofile(f)
+            np.ascontiguousarray(xyz_new.T, np.float64).tofile(f)            # xyz(3, nNode), column by column
+            np.ascontiguousarray((conn_new.T + 1), np.int32).tofile(f)        # conn(4, nElem), 1-based
+            np.ascontiguousarray(edof.T, np.int32).tofile(f)                  # edof(nsize, nElem)
+            np.ascontiguousarray(dm.solnApplied, np.float64).tofile(f)
+            ed.tofile(f)
+        with open(os.path.join(tmp, "petsc_options.dat"), "w") as f:
+            f.write(f"-pc_type {args.pc}\n")
+        runs = []
+        for rep in range(max(1, args.steps)):
+            r = subprocess.run([exe], cwd=tmp, env=dict(os.environ, PFEM_KSP_RTOL=repr(args.rtol)), capture_output=True, text=True, timeout=3000)
+            tline = [ln for ln in r.stdout.splitlines() if ln.startswith("TIMING")]
+            if r.returncode != 0 or not tline:
+                raise SystemExit("the Fortran host program failed:\n" + r.stdout[-2000:] + r.stderr[-2000:])
+            ins, setz, loop, solve = (float(x) for x in tline[-1].split()[1:5])
+            conv = [ln for ln in r.stdout.splitlines() if "Convergence in" in ln or "onvergence" in ln]
+            runs.append({"insert_values_pass_s": ins, "set_zero_pattern_on_device_s": setz, "element_loop_add_values_s": loop, "factorise_and_solve_s": solve,
+                         "reference_timed_region_s": loop + solve, "dof_per_s_reference_timed_region": N / (loop + solve), "solver_line": conv[-1].strip() if conv else None})
+    best = min(runs, key=lambda q: q["reference_timed_region_s"])
+    out.update(best)
+    out["runs"] = runs
+    out["element_loop_vs_oracle_serial_assembly"] = best["element_loop_add_values_s"] / t_oracle
+    print(json.dumps(out))
+    return 0
+
+
 def main():
     args = parse_args()
+    if args.mode == "compat":
+        raise SystemExit(compat_mode(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: this process has not touched the GPU (nothing but argparse so
         # far) and never will -- it starts N fresh rank processes through torch.distributed.run, relays their output and
@@ -643,7 +774,7 @@ def main():
     t_init = time.perf_counter() - t_init
 
     R = run_case(J, beam, nE, ext, args.steps, args.warmup, args.rtol, profile=True,
-                 parity_step=(world == 1 and not args.no_parity_step and not beam))
+                 parity_step=(world == 1 and not args.no_parity_step and not beam), probe_comm=True)
     weak = not (beam or args.strong)
     # ---- the same configuration with north_star's own preconditioner, the diagonal: a shorter, separately timed run
     Jac = None
@@ -673,7 +804,7 @@ def main():
         raw_spmv_ms = acc["spmv_ms"] / max(acc["spmv_n"], 1)
         avg_spmv_ms = max(raw_spmv_ms, 1e-9)
         achieved = bytes_per_spmv / (avg_spmv_ms * 1e-3) / 1e9 if acc["spmv_n"] else 0.0
-        traffic, traffic_source = pmc_traffic(info["nnz"]) if (world == 1 and args.numbering == "lattice") else (None, None)
+        traffic, traffic_source = pmc_traffic(info["nnz"]) if (world == 1 and args.numbering == "lattice" and args.jitter <= 0.0) else (None, None)
         hbm_bytes = traffic if traffic else fmt_bytes
         # names as rocprofv3 prints them: k_spmvr / k_spmvg / k_spmv16 <WITH_DOT, gap table>, k_spmvr32 / k_spmv <WITH_DOT>
         tbl = R["gap_table"]
@@ -726,7 +857,7 @@ def main():
                                       f"{world} slabs of hex layers across {axis_name}, sub-assembled interface rows, neighbour exchange of "
                                       f"{cinfo['doubles_per_exchange']} doubles with {cinfo['n_peers']} neighbour(s) per SpMV "
                                       f"+ {1 if args.single_reduction and args.pc == 'jacobi' else 2} scalar all-reduce(s) per iteration",
-                       "partition": partition, "numbering": args.numbering},
+                       "partition": partition, "numbering": args.numbering, "jitter": args.jitter},
             "iterations": its, "converged_reason": R["reason"], "rnorm": R["rnorm"], R["check_name"]: R["check"],
             "assembly_ms_per_step": acc["asm_ms"] / args.steps, "solve_ms_per_step": acc["sol_ms"] / args.steps,
             "ms_per_iteration": R["ms_per_iteration"],     # weak scaling: iterations grow with the problem
@@ -785,7 +916,7 @@ def main():
                                  "valu_issue_fraction_replayed_not_this_run": 0.75,
                                  "valu_issue_source": "profiles/r04/gather_kernels_sq_counters.txt (rocprofv3 --pmc SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE, tools/r04/gather_sq_counters.sh)",
                                  "hbm_frac_of_compulsory_bytes": (3.75e9 / (acc["asm_ms"] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBPS)
-                                 if (not beam and world == 1 and args.n == 200 and args.numbering == "lattice") else None}
+                                 if (not beam and world == 1 and args.n == 200 and args.numbering == "lattice" and args.jitter <= 0.0) else None}
                                 if (not beam and world == 1) else None),
             "roofline": {"bound": "hbm", "kernel": kernel,
                          # the judged figure: plain-CSR algorithmic bytes / measured launch time.  It is an
@@ -807,7 +938,7 @@ def main():
                          # trace: under the tracer dispatches run one at a time, on the plain stream the kernel's first waves share
                          # the device with the last waves of the kernel before it (events without the system-scope fence: no change,
                          # round-3 lease script aj.sh, in the history).  The judged fraction uses the pair as it is, the lower of the two figures
-                         "kernel_trace_avg_launch_us_replayed_not_this_run": kernel_trace_figures(info["nnz"]) if (world == 1 and args.numbering == "lattice") else None,
+                         "kernel_trace_avg_launch_us_replayed_not_this_run": kernel_trace_figures(info["nnz"]) if (world == 1 and args.numbering == "lattice" and args.jitter <= 0.0) else None,
                          "avg_launch_ms_in_jacobi_step": (Jac["acc"]["spmv_ms"] / max(Jac["acc"]["spmv_n"], 1)) if (Jac and Jac["acc"]["spmv_n"]) else None,
                          "event_pair_offset_ms_not_subtracted": R["event_overhead_ms"],
                          "launches_timed": acc["spmv_n"], "nnz": info["nnz"], "rows": info["n_local"]},
@@ -838,6 +969,44 @@ def main():
                     "bytes_per_neighbour": 8 * S["cinfo"]["doubles_per_exchange"] // max(S["cinfo"]["n_peers"], 1)}
         if world == 1 and not args.no_cpu_baseline and not beam:
             out["cpu_baseline"] = cpu_baseline(n, args.rtol, extra_sample=(n >= 200))
+        if world > 1:
+            out["comm"]["link_latencies"] = R.get("comm_bench")
+            out["comm"]["coupled_cycle"] = R.get("cycle_profile")
+    else:
+        out = None
+    # ---- N > 1: the same steps over the OTHER device-side transport (A/B).  RCCL stays the headline (north_star); the
+    # peer-memory transport (boxes + flags mapped through hipIpc*, fine-grained so that it is legal between devices) has only
+    # ever run between processes sharing one GPU, so the attempt is guarded: every rank arms a timer; if the attempt has not
+    # come back in time, rank 0 prints the line without it -- the one line the driver waits for is never lost to the A/B.
+    if world > 1 and not args.no_transport_ab:
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["comm"]["transports"] = {"peer-ipc": {"skipped": f"the attempt did not come back within {args.transport_ab_timeout:g} s (abandoned; processes ended)"}}
+                json_out.write(json.dumps(out) + "\n")
+                json_out.flush()
+            os._exit(0)
+        guard = threading.Timer(args.transport_ab_timeout, bail)
+        guard.daemon = True
+        guard.start()
+        main_kind = R["final"]["backend"] if R.get("final") else None
+        try:
+            P = run_case(J, beam, nE, ext, max(1, min(args.steps, 3)), 1, args.rtol, profile=False, transport="peer", probe_comm=True)
+        except (pf.PfemError, RuntimeError) as e:           # (a transport that failed mid-run on this rank: its peers time out and report the same)
+            P = {"skipped": f"{type(e).__name__}: {e}"}
+        guard.cancel()
+        if rank == 0:
+            def brief(Q):
+                if "skipped" in Q:
+                    return Q
+                return {"value": Q["N"] * Q["steps"] / Q["elapsed"], "ms_per_step": Q["ms_per_step"], "iterations": Q["its"], "converged_reason": Q["reason"],
+                        "ms_per_iteration": Q["ms_per_iteration"], "steps": Q["steps"], "first_step_ms": Q.get("first_step_ms"),
+                        "link_latencies": Q.get("comm_bench"), "coupled_cycle": Q.get("cycle_profile"),
+                        "host_enqueue_us_per_iteration": 1e3 * Q["acc"]["enq_ms"] / max(Q["acc"]["enq_n"], 1)}
+            out["comm"]["transports"] = {{"rccl": "rccl", "host": "gloo-host-hooks"}.get(main_kind, main_kind): brief(R), "peer-ipc": brief(P),
+                                         "note": "same configuration, fresh solver each; the first entry is the run `value` reports"}
+    if rank == 0:
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     if world > 1:

@@ -116,6 +116,7 @@ SIGNATURES = {
     "pfem_solver_amg_transfer": [_P, _I, _P, _P, _P, _P, _P, _P],
     "pfem_solver_amg_layout": [_P, _I, _P, _P, _P, _P],
     "pfem_solver_amg_comm_counts": [_P, _P, _P],
+    "pfem_solver_amg_cycle_profile": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "pfem_solver_amg_pairing": [_P, _P],
     "pfem_solver_set_amg_options": [_P, _I, _I, _D, _D],
     "pfem_eval_elems": [_P, _P, _P, _P, _P],
@@ -134,6 +135,7 @@ SIGNATURES = {
     "pfem_solver_set_comm_rccl": [_P, _I, _I, _P],
     "pfem_solver_set_comm_host": [_P, _I, _I, HOST_ALLREDUCE_FN, HOST_EXCHANGE_FN, _P],
     "pfem_solver_comm_bench": [_P, C.c_int64, _I, _P, _P],
+    "pfem_solver_comm_bench_sizes": [_P, C.c_int64, C.c_int64, _I, _I, _P, _P],
     "pfem_solver_set_comm_peer": [_P, _I, _I, HOST_ALLREDUCE_FN, HOST_EXCHANGE_FN, _P],
     "pfem_solver_comm_shutdown": [_P],
     "pfem_solver_comm_info": [_P, _P, _P, _P, _P],

@@ -514,6 +514,11 @@ struct pfem_solver {
     int rank = 0, nranks = 1;
     struct CommBackend *comm = nullptr;          // owned
     hipStream_t comm_stream = nullptr;           // every exchange / all-reduce is enqueued here, in one order on all ranks
+    // pfem_solver_amg_cycle_profile: event pairs around every exchange / all-reduce of ONE instrumented V-cycle, tagged with the level
+    struct XSample { int level; int kind; int64_t doubles; hipEvent_t e0, e1; };      // kind 0: neighbour exchange, 1: all-reduce
+    bool xprof_on = false;
+    int xprof_level = 0;
+    std::vector<XSample> xprof;
     std::vector<hipEvent_t> xev;                 // cross-stream events (no timing), used round-robin
     size_t xev_next = 0;
     bool have_plan = false;
@@ -2746,6 +2751,7 @@ struct PeerBackend final : CommBackend {
     unsigned long long ae = 0;
     int *d_arrive = nullptr;
     bool up = false;
+    bool fine = false;                             // the region is fine-grained device memory (what a neighbour on another device needs)
     PeerBackend(pfem_host_allreduce_fn a, pfem_host_exchange_fn e, void *c) : host(a, e, c) {}
     // collective, on request (pfem_solver_comm_shutdown, called by the host mirror's free() while the process group lives): nobody
     // is still writing an acknowledgement into a region when it goes.  The destructor itself is NOT collective -- it also runs
@@ -2767,7 +2773,7 @@ struct PeerBackend final : CommBackend {
         if (base) (void)hipFree(base);
         if (d_arrive) (void)hipFree(d_arrive);
     }
-    const char *name() const override { return "peer-ipc"; }
+    const char *name() const override { return fine ? "peer-ipc" : "peer-ipc-coarse"; }
     void describe(int *ranks, int *dev, int *version) const override { *ranks = nranks; *dev = device; *version = -1; }
     static size_t pad(size_t b) { return (b + 255) / 256 * 256; }
     void carve(char *b, PeerMail &m) const
@@ -2802,7 +2808,16 @@ struct PeerBackend final : CommBackend {
         int rc_local = PFEM_OK;
         hipIpcMemHandle_t mine;
         std::memset(&mine, 0, sizeof mine);
-        if (hipMalloc(&base, bytes) != hipSuccess || hipMemset(base, 0, bytes) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&d_arrive), sizeof(int)) != hipSuccess ||
+        // FINE-GRAINED device memory (PFEM_PEER_FINEGRAINED=0: plain hipMalloc): a neighbour on ANOTHER device writes boxes and
+        // flags over xGMI while this device's kernels poll them -- ordinary (coarse-grained) device memory is only coherent at
+        // kernel boundaries for such writers, so the polls could spin on a stale line; fine-grained memory takes system-scope
+        // acquire / release accesses past the caches.  Between processes that share one device both kinds work (tested with
+        // both); only plain stores / loads and integer atomics touch the region (unsafe-fp-atomics would drop adds here: the
+        // region never enters the block pool, it is freed by hipFree below).
+        static const bool fine_wanted = [] { const char *e = std::getenv("PFEM_PEER_FINEGRAINED"); return e ? std::atoi(e) != 0 : true; }();
+        fine = fine_wanted && hipExtMallocWithFlags(&base, bytes, hipDeviceMallocFinegrained) == hipSuccess;
+        if (!fine) { (void)hipGetLastError(); base = nullptr; }
+        if ((!fine && hipMalloc(&base, bytes) != hipSuccess) || hipMemset(base, 0, bytes) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&d_arrive), sizeof(int)) != hipSuccess ||
             hipMemset(d_arrive, 0, sizeof(int)) != hipSuccess) {
             (void)hipGetLastError();
             rc_local = PFEM_ERR_NOMEM;
@@ -3135,13 +3150,19 @@ extern "C" int pfem_solver_comm_selftest(pfem_solver *s, int64_t count, int64_t 
 
 extern "C" int pfem_solver_comm_bench(pfem_solver *s, int64_t count, int reps, double *ms_per_exchange, double *ms_per_allreduce)
 {
-    if (!s || count < 1 || reps < 1 || !ms_per_exchange || !ms_per_allreduce) return PFEM_ERR_ARG;
+    return pfem_solver_comm_bench_sizes(s, count, 4, reps, 0, ms_per_exchange, ms_per_allreduce);
+}
+
+extern "C" int pfem_solver_comm_bench_sizes(pfem_solver *s, int64_t count, int64_t allreduce_count, int reps, int slab_neighbours,
+                                            double *ms_per_exchange, double *ms_per_allreduce)
+{
+    if (!s || count < 1 || allreduce_count < 1 || reps < 1 || !ms_per_exchange || !ms_per_allreduce) return PFEM_ERR_ARG;
     if (!s->comm) return PFEM_ERR_STATE;
     PFEM_TRY(use_device(s));
     PFEM_TRY(ensure_comm_stream(s));
     std::vector<int> peers;
     for (int q = 0; q < s->nranks; ++q)
-        if (q != s->rank || s->nranks == 1) peers.push_back(q);
+        if ((q != s->rank && (!slab_neighbours || q == s->rank - 1 || q == s->rank + 1)) || s->nranks == 1) peers.push_back(q);
     const int np = static_cast<int>(peers.size());
     std::vector<int64_t> off(static_cast<size_t>(np) + 1, 0);
     for (int k = 0; k < np; ++k) off[k + 1] = off[k] + count;
@@ -3149,9 +3170,9 @@ extern "C" int pfem_solver_comm_bench(pfem_solver *s, int64_t count, int reps, d
     DevBuf<double> d_send, d_recv, d_red;
     PFEM_TRY(d_send.alloc(tot));
     PFEM_TRY(d_recv.alloc(tot));
-    PFEM_TRY(d_red.alloc(4));
+    PFEM_TRY(d_red.alloc(static_cast<size_t>(allreduce_count)));
     PFEM_HIP(hipMemsetAsync(d_send.p, 0, sizeof(double) * tot, s->stream));
-    PFEM_HIP(hipMemsetAsync(d_red.p, 0, sizeof(double) * 4, s->stream));
+    PFEM_HIP(hipMemsetAsync(d_red.p, 0, sizeof(double) * static_cast<size_t>(allreduce_count), s->stream));
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     PFEM_HIP(hipEventCreate(&e0));
     PFEM_HIP(hipEventCreate(&e1));
@@ -3161,7 +3182,7 @@ extern "C" int pfem_solver_comm_bench(pfem_solver *s, int64_t count, int reps, d
         if (hipEventRecord(e0, s->stream) != hipSuccess) rc = PFEM_ERR_HIP;
         for (int r = 0; r < reps && rc == PFEM_OK; ++r) rc = s->comm->exchange(np, peers.data(), off.data(), d_send.p, d_recv.p, s->stream);
         if (rc == PFEM_OK && hipEventRecord(e1, s->stream) != hipSuccess) rc = PFEM_ERR_HIP;
-        for (int r = 0; r < reps && rc == PFEM_OK; ++r) rc = s->comm->allreduce(d_red.p, 4, s->stream);
+        for (int r = 0; r < reps && rc == PFEM_OK; ++r) rc = s->comm->allreduce(d_red.p, allreduce_count, s->stream);
         if (rc == PFEM_OK && hipEventRecord(e2, s->stream) != hipSuccess) rc = PFEM_ERR_HIP;
         if (rc == PFEM_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = PFEM_ERR_HIP;
     }
@@ -3228,6 +3249,23 @@ struct PlanRef {
 };
 // the transport alone (pack and unpack-sum are the caller's: fused into its kernels)
 int exchange_only(pfem_solver *s, const PlanRef &P, bool second_stream);
+// one instrumented cycle (pfem_solver_amg_cycle_profile): an event pair around the transport call
+inline int xprof_begin(pfem_solver *s, int kind, int64_t doubles, hipStream_t st)
+{
+    if (!s->xprof_on) return PFEM_OK;
+    pfem_solver::XSample x{s->xprof_level, kind, doubles, nullptr, nullptr};
+    PFEM_HIP(hipEventCreate(&x.e0));
+    PFEM_HIP(hipEventCreate(&x.e1));
+    PFEM_HIP(hipEventRecord(x.e0, st));
+    s->xprof.push_back(x);
+    return PFEM_OK;
+}
+inline int xprof_end(pfem_solver *s, hipStream_t st)
+{
+    if (!s->xprof_on || s->xprof.empty()) return PFEM_OK;
+    PFEM_HIP(hipEventRecord(s->xprof.back().e1, st));
+    return PFEM_OK;
+}
 inline PlanRef plan_of(const pfem_solver *s)
 {
     return PlanRef{static_cast<int>(s->peers.size()), s->peers.data(), s->peer_off.data(), s->n_send, s->n_sh,
@@ -3243,7 +3281,9 @@ int exchange_sum(pfem_solver *s, const PlanRef &P, double *v, bool second_stream
     // the exchange goes where the iterations will put it (one stream per communicator for the whole solve)
     hipStream_t xs = second_stream ? s->comm_stream : s->stream;
     if (second_stream) PFEM_TRY(stream_follows(s, s->comm_stream, s->stream));
+    PFEM_TRY(xprof_begin(s, 0, P.n_send, xs));
     PFEM_TRY(s->comm->exchange(P.np, P.peers, P.peer_off, s->d_send.p, s->d_recv.p, xs));
+    PFEM_TRY(xprof_end(s, xs));
     if (second_stream) PFEM_TRY(stream_follows(s, s->stream, s->comm_stream));
     if (P.n_sh > 0) {
         hipLaunchKernelGGL(k_unpack_sum, dim3(grid_for(P.n_sh)), dim3(kBlock), 0, s->stream, v, P.sh_lidx, P.sh_ptr, P.sh_src, P.n_sh,
@@ -3256,7 +3296,9 @@ int exchange_only(pfem_solver *s, const PlanRef &P, bool second_stream)
 {
     hipStream_t xs = second_stream ? s->comm_stream : s->stream;
     if (second_stream) PFEM_TRY(stream_follows(s, s->comm_stream, s->stream));
+    PFEM_TRY(xprof_begin(s, 0, P.n_send, xs));
     PFEM_TRY(s->comm->exchange(P.np, P.peers, P.peer_off, s->d_send.p, s->d_recv.p, xs));
+    PFEM_TRY(xprof_end(s, xs));
     if (second_stream) PFEM_TRY(stream_follows(s, s->stream, s->comm_stream));
     return PFEM_OK;
 }
@@ -4435,6 +4477,51 @@ extern "C" int pfem_solver_amg_comm_counts(pfem_solver *s, int *exchanges_per_cy
         *exchanges_per_cycle = 1;              // one hierarchy per rank: the owners' z to the ghost holders
     }
     return PFEM_OK;
+}
+
+// One instrumented V-cycle of the hierarchy across the ranks (collective; after a gamg solve): an event pair around every
+// neighbour exchange and every all-reduce, summed per level -- what the links cost where, for bench.py's N > 1 line.
+extern "C" int pfem_solver_amg_cycle_profile(pfem_solver *s, int max_levels, int *n_levels, int *exchanges, double *exchange_ms,
+                                             int64_t *exchange_doubles, int *allreduces, double *allreduce_ms, int64_t *allreduce_doubles,
+                                             double *cycle_ms)
+{
+    if (!s || max_levels < 1 || !n_levels || !exchanges || !exchange_ms || !exchange_doubles || !allreduces || !allreduce_ms || !allreduce_doubles || !cycle_ms)
+        return PFEM_ERR_ARG;
+    if (!s->amg || !s->amg->symbolic_ok || !s->amg->coupled || !s->comm) return PFEM_ERR_STATE;
+    PFEM_TRY(use_device(s));
+    Amg &M = *s->amg;
+    const int nl = static_cast<int>(M.lev.size());
+    *n_levels = std::min(nl, max_levels);
+    for (int l = 0; l < max_levels; ++l) { exchanges[l] = 0; exchange_ms[l] = 0.0; exchange_doubles[l] = 0; }
+    *allreduces = 0; *allreduce_ms = 0.0; *allreduce_doubles = 0; *cycle_ms = 0.0;
+    hipEvent_t c0 = nullptr, c1 = nullptr;
+    PFEM_HIP(hipEventCreate(&c0));
+    PFEM_HIP(hipEventCreate(&c1));
+    s->xprof.clear();
+    s->xprof_on = true;
+    int rc = PFEM_OK;
+    if (hipEventRecord(c0, s->stream) != hipSuccess) rc = PFEM_ERR_HIP;
+    if (rc == PFEM_OK && !amg_apply_coupled(s, M, s->d_r.p, nullptr, s->overlap_agreed == 1)) rc = PFEM_ERR_COMM;
+    if (rc == PFEM_OK && hipEventRecord(c1, s->stream) != hipSuccess) rc = PFEM_ERR_HIP;
+    s->xprof_on = false;
+    if (hipStreamSynchronize(s->stream) != hipSuccess) rc = rc == PFEM_OK ? PFEM_ERR_HIP : rc;
+    if (s->comm_stream && hipStreamSynchronize(s->comm_stream) != hipSuccess) rc = rc == PFEM_OK ? PFEM_ERR_HIP : rc;
+    float f = 0.f;
+    if (rc == PFEM_OK && hipEventElapsedTime(&f, c0, c1) == hipSuccess) *cycle_ms = f;
+    for (auto &x : s->xprof) {
+        float t = 0.f;
+        if (rc == PFEM_OK && x.e0 && x.e1 && hipEventElapsedTime(&t, x.e0, x.e1) == hipSuccess) {
+            if (x.kind == 0 && x.level < max_levels) { ++exchanges[x.level]; exchange_ms[x.level] += t; exchange_doubles[x.level] += x.doubles; }
+            if (x.kind == 1) { ++*allreduces; *allreduce_ms += t; *allreduce_doubles += x.doubles; }
+        }
+        if (x.e0) (void)hipEventDestroy(x.e0);
+        if (x.e1) (void)hipEventDestroy(x.e1);
+    }
+    s->xprof.clear();
+    (void)hipEventDestroy(c0);
+    (void)hipEventDestroy(c1);
+    PFEM_TRY(rc);
+    return s->comm->health();
 }
 
 extern "C" int pfem_solver_set_amg_options(pfem_solver *s, int cheb_degree, int fine_degree, double eig_ratio, double coarse_scale)

@@ -16,7 +16,7 @@
 
 using namespace pfem;
 
-#ifdef _OPENMP
+#if defined(_OPENMP) && defined(__clang__)       // (the product build: hipcc / LLVM libomp; g++ builds of this file -- the sanitizer test -- have no kmp_* API)
 // The bookkeeping loops below run as OpenMP loops; the GPU work that follows them is often launch-bound (a small problem's CG
 // iterations).  Idle OpenMP workers that spin before they sleep take the cores the HIP runtime's launch path needs: measured
 // 3-5x on the iterations of a 10^6-dof problem for ~0.2 s after a parallel region (profiles/LAB_NOTES.md).  The workers of

@@ -2,6 +2,7 @@
 #pragma once
 
 #include "../../include/pfem_amd.h"
+#include "../../include/pfem_amd_diag.h"      // introspection / measurement entry points (not the boundary)
 #include "pfem_elem.hpp"
 
 #include <algorithm>

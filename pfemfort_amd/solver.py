@@ -284,6 +284,19 @@ class PetscSolver:
         return {"coupled": bool(cp.value), "distributed_levels": nd.value, "first_dof": first[:nl].tolist(), "local_rows": loc[:nl].tolist(),
                 "exchanges_per_cycle": ex.value, "allreduces_per_cycle": ar.value, "lattice_levels": lat.value}
 
+    def amgCycleProfile(self):
+        """One instrumented V-cycle of the hierarchy across the ranks (collective): per level the exchanges, their time and bytes;
+        the cycle's all-reduces; the cycle's time."""
+        mx = 32
+        nl, na = C.c_int(0), C.c_int(0)
+        ex = np.zeros(mx, np.int32); ms = np.zeros(mx, np.float64); dbl = np.zeros(mx, np.int64)
+        ams, adbl, cyc = C.c_double(0), C.c_int64(0), C.c_double(0)
+        L.check(L.lib().pfem_solver_amg_cycle_profile(self._h, mx, C.byref(nl), _p(ex), _p(ms), _p(dbl), C.byref(na), C.byref(ams), C.byref(adbl),
+                                                      C.byref(cyc)), "pfem_solver_amg_cycle_profile")
+        n = nl.value
+        return {"cycle_ms": cyc.value, "exchanges_per_level": ex[:n].tolist(), "exchange_ms_per_level": ms[:n].tolist(),
+                "exchange_bytes_per_level": (8 * dbl[:n]).tolist(), "allreduces": na.value, "allreduce_ms": ams.value, "allreduce_bytes": 8 * adbl.value}
+
     def spmvRowGroup(self):
         """Rows served by one lane of the current SpMV (3: row-grouped form)."""
         b = C.c_int(0)
@@ -394,10 +407,12 @@ class PetscSolver:
         L.check(L.lib().pfem_solver_comm_selftest(self._h, count, C.byref(bad)), "pfem_solver_comm_selftest")
         return bad.value
 
-    def commBench(self, count, reps=200):
-        """Collective transport timing: (ms per exchange of ``count`` doubles with every other rank, ms per all-reduce of 4 doubles)."""
+    def commBench(self, count, reps=200, allreduce_count=4, slab_neighbours=False):
+        """Collective transport timing: (ms per exchange of ``count`` doubles with every other rank -- ``slab_neighbours``: with rank - 1
+        and rank + 1 only --, ms per all-reduce of ``allreduce_count`` doubles)."""
         a, b = C.c_double(0), C.c_double(0)
-        L.check(L.lib().pfem_solver_comm_bench(self._h, count, reps, C.byref(a), C.byref(b)), "pfem_solver_comm_bench")
+        L.check(L.lib().pfem_solver_comm_bench_sizes(self._h, count, allreduce_count, reps, 1 if slab_neighbours else 0, C.byref(a), C.byref(b)),
+                "pfem_solver_comm_bench_sizes")
         return a.value, b.value
 
     def commInfo(self):

@@ -35,24 +35,44 @@ program boundary_check
   integer, allocatable :: sizes(:), owner(:), conn(:,:), edof(:,:), rows(:), nnz_d(:), nnz_o(:), conn_loc(:,:), edof_loc(:,:)
   double precision, allocatable :: xyz(:,:), applied(:), Kl(:,:), Fl(:), zeroK(:,:), valC(:), valDotC(:), coords(:,:)
   character(len=32) :: mode
+  logical :: have_bin
+  integer(kind=8) :: tk0, tk1, tk2, tk3, tk4, tkr
   double precision :: xn(4), yn(4), zn(4), elemData(6), timeData(3), fact
 
   call PetscInitialize("petsc_options.dat", ierr)
   call MPI_Comm_rank(PETSC_COMM_WORLD, me, ierr)
   call MPI_Comm_size(PETSC_COMM_WORLD, nprocs, ierr)
 
-  open(11, file="problem.txt", status="old", action="read")
-  read(11, *) ndof, nNode, nElem, ntot, nranks_file
-  if (nranks_file /= nprocs) stop "problem.txt was prepared for another number of ranks"
+  ! "problem.bin" (the same records as unformatted stream: bench.py --mode compat at config 2's size, where text would
+  ! take minutes to write and read) or "problem.txt"
+  inquire(file="problem.bin", exist=have_bin)
+  if (have_bin) then
+    open(11, file="problem.bin", status="old", action="read", access="stream", form="unformatted")
+    read(11) ndof, nNode, nElem, ntot, nranks_file
+  else
+    open(11, file="problem.txt", status="old", action="read")
+    read(11, *) ndof, nNode, nElem, ntot, nranks_file
+  end if
+  if (nranks_file /= nprocs) stop "the problem file was prepared for another number of ranks"
   nsize = 4 * ndof
   allocate(sizes(nprocs), owner(nElem), conn(4, nElem), edof(nsize, nElem), xyz(3, nNode), applied(nNode * ndof))
-  read(11, *) sizes
-  read(11, *) owner
-  read(11, *) xyz
-  read(11, *) conn
-  read(11, *) edof
-  read(11, *) applied
-  read(11, *) elemData
+  if (have_bin) then
+    read(11) sizes
+    read(11) owner
+    read(11) xyz
+    read(11) conn
+    read(11) edof
+    read(11) applied
+    read(11) elemData
+  else
+    read(11, *) sizes
+    read(11, *) owner
+    read(11, *) xyz
+    read(11, *) conn
+    read(11, *) edof
+    read(11, *) applied
+    read(11, *) elemData
+  end if
   close(11)
   timeData = (/ 0.0d0, 1.0d0, 0.0d0 /)
 
@@ -81,14 +101,18 @@ program boundary_check
   else
 
   ! the pattern: zeros with INSERT_VALUES for every element this rank owns
+  call system_clock(tk0, tkr)
   do e = 1, nElem
     if (owner(e) /= me) cycle
     rows = edof(:, e)
     call MatSetValues(solver%mtx, nsize, rows, nsize, rows, zeroK, INSERT_VALUES, ierr)
   end do
+  call system_clock(tk1)
   call solver%setZero()
+  call system_clock(tk2)
 
   ! the element loop: element routine, matrix block, lifting of the prescribed values, vector
+  ! (what the reference times as "assembly", tetrapoissonparallelimpl1.F:826-893)
   do e = 1, nElem
     if (owner(e) /= me) cycle
     do a = 1, 4
@@ -112,9 +136,15 @@ program boundary_check
     end do
     call VecSetValues(solver%rhsVec, nsize, rows, Fl, ADD_VALUES, ierr)
   end do
+  call system_clock(tk3)
   end if
 
   call solver%factoriseAndSolve()
+  call system_clock(tk4)
+  if (trim(mode) /= "device" .and. me == 0) then
+    ! seconds: INSERT_VALUES pass | setZero (pattern finalised on the device) | element loop with ADD_VALUES | factoriseAndSolve
+    write(*, '(A,4(1X,ES14.6))') "TIMING", dble(tk1 - tk0) / dble(tkr), dble(tk2 - tk1) / dble(tkr), dble(tk3 - tk2) / dble(tkr), dble(tk4 - tk3) / dble(tkr)
+  end if
 
   call VecScatterCreateToAll(solver%solnVec, ctx, vec_seq, ierr)
   call VecScatterBegin(ctx, solver%solnVec, vec_seq, INSERT_VALUES, SCATTER_FORWARD, ierr)

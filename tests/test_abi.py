@@ -12,11 +12,25 @@ from pfemfort_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "pfem_amd.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"^\s*(?:const\s+)?(?:int|char)\s*\*?\s*(pfem_\w+)\s*\(", text, flags=re.M)
+def declared_symbols(headers=("pfem_amd.h", "pfem_amd_diag.h")):
+    names = []
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names += re.findall(r"^\s*(?:const\s+)?(?:int|char)\s*\*?\s*(pfem_\w+)\s*\(", text, flags=re.M)
     return sorted(set(names))
+
+
+def test_boundary_header_holds_the_boundary_only():
+    """include/pfem_amd.h = what a maintainer of the reference binds (INTEGRATION.md maps every entry point to the interface it
+    replaces); introspection, measurement and lab knobs live in include/pfem_amd_diag.h."""
+    boundary, diag = declared_symbols(("pfem_amd.h",)), declared_symbols(("pfem_amd_diag.h",))
+    assert not set(boundary) & set(diag)
+    for word in ("_bench", "_profile", "_selftest", "_info", "_layout", "_aggregates", "get_spmv", "get_timings", "eval_elems"):
+        assert not [n for n in boundary if word in n and n not in ("pfem_device_info", "pfem_solver_print_info")], word
+    integration = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in boundary if n not in integration]
+    assert not missing, f"boundary entry points INTEGRATION.md does not map to a reference interface: {missing}"
 
 
 def test_every_declared_symbol_is_exported_and_bound():
@@ -24,7 +38,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert len(names) >= 45
     L = C.CDLL(_lib.LIB_PATH)
     for n in names:
-        assert hasattr(L, n), f"{n} declared in include/pfem_amd.h but not exported"
+        assert hasattr(L, n), f"{n} declared in include/pfem_amd*.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, set(_lib.SIGNATURES) ^ set(names)
 
 
