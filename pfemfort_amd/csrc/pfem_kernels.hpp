@@ -931,6 +931,39 @@ __global__ void __launch_bounds__(kBlock) k_pack_node4(MeshDev m, double4 *__res
     out[n] = double4{m.xyz[n], m.xyz[m.nNode + n], m.xyz[2 * m.nNode + n], m.ndof == 1 ? m.soln[n] : 0.0};
 }
 
+// one visit of k_gather_poisson_tet4: the element's contribution to the node's row and right-hand side, the node being local
+// node A of the element (self) and c0, c1, c2 the element's other three nodes in their local order
+template <int A>
+__device__ __forceinline__ bool gather_visit(const double4 &self, const double4 &c0, const double4 &c1, const double4 &c2, uint32_t slots,
+                                             const ElemPrm &prm, double *acc, int T, double &facc)
+{
+    const double4 &n0 = A == 0 ? self : c0;
+    const double4 &n1 = A == 1 ? self : (A < 1 ? c0 : c1);
+    const double4 &n2 = A == 2 ? self : (A < 2 ? c1 : c2);
+    const double4 &n3 = A == 3 ? self : c2;
+    const double x[4] = {n0.x, n1.x, n2.x, n3.x}, y[4] = {n0.y, n1.y, n2.y, n3.y}, z[4] = {n0.z, n1.z, n2.z, n3.z};
+    const double ud[4] = {n0.w, n1.w, n2.w, n3.w};
+    bool fixed[4], any_fixed = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        fixed[i] = ((slots >> (8 * i)) & 0xffu) == 0xffu;
+        any_fixed |= fixed[i];
+    }
+    double Krow[4] = {0.0, 0.0, 0.0, 0.0}, Kcol[4], f = 0.0;
+    if (!poisson_tet_node_lean(x, y, z, prm.ed[0], prm.ed[1], prm.ed[2], prm.af, A, any_fixed, Kcol, Krow, f)) return false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)            // Flocal(a) -= Klocal(a,i)*u_D(i)   (:859-870)
+        if (fixed[i]) f = f - Krow[i] * ud[i];
+    facc += f;                             // VecSetValues(ADD_VALUES) :880
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {          // entry (row, dof_j) += Klocal(j,a)   (:851, row-major read)
+        if (fixed[j]) continue;
+        const uint32_t k = (slots >> (8 * j)) & 0xffu;
+        acc[k * T] += Kcol[j];
+    }
+    return true;
+}
+
 // k_gather_scalar<PFEM_POISSON_TET, true> with its two memory habits changed (same arithmetic, same order of additions):
 // the coordinates and the Dirichlet value of a node come from ONE 32-B record (k_pack_node4) instead of four arrays
 // -- the gathers, not the streamed incidence records, were what kept this kernel waiting: 9 scattered 8-B reads per visit
@@ -958,63 +991,51 @@ __global__ void __launch_bounds__(kBlock) k_gather_poisson_tet4(int64_t nNode, S
     double facc = 0.0;
     double *acc = lds_acc + threadIdx.x;
     for (int k = 0; k < len; ++k) acc[k * T] = 0.0;
-    // Two visits ahead: while element t is evaluated, the four node records of element t+1 and the incidence record of
-    // element t+2 are in flight (the node loads depend on the incidence record, the arithmetic on the node loads).
-    const auto node_ids = [n](const int4 &rc, int nd[4]) {
-        const int a = static_cast<int>((static_cast<uint32_t>(rc.x) >> 31) | ((static_cast<uint32_t>(rc.y) >> 31) << 1));
-        const int o[3] = {rc.x & 0x7fffffff, rc.y & 0x7fffffff, rc.z};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = i < a ? i : (i > 0 ? i - 1 : 0);
-            nd[i] = (i == a) ? static_cast<int>(n) : o[q];
-        }
-        return a;
-    };
+    // Two visits ahead: while element t is evaluated, the node records of element t+1 and the incidence record of element
+    // t+2 are in flight (the node loads depend on the incidence record, the arithmetic on the node loads).
+    // Round 5 (SQ counters of round 4: VALU issuing 75 % of the cycles, ~110 of 194 VALU instructions per visit moves and
+    // selects): (1) the node's OWN record is loaded once, a visit gathers its three other nodes only; (2) the visit's body is
+    // compiled once per local index a of the node in the element (gather_visit<A>: which of the four positions is the node's
+    // own is then known at compile time -- no select chains on a) and reached through a switch on a: on lattice numbering the
+    // lanes of a wave walk translated copies of the same elements in the same order, so a is wave-uniform and three of the
+    // four cases are skipped by a scalar branch; at boundaries the cases run one after the other under their lanes' masks.
+    // Same arithmetic in the same order: K and F stay bit-identical to the serial loop.
+    const double4 self = node4[n];
     int4 rc_next = cnt > 0 ? inc_rec[beg] : int4{0, 0, 0, 0};
     int4 rc_next2 = cnt > 1 ? inc_rec[beg + 64] : int4{0, 0, 0, 0};
-    double4 cn[4];
-    {
-        int nd[4];
-        node_ids(rc_next, nd);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) cn[i] = cnt > 0 ? node4[nd[i]] : double4{0.0, 0.0, 0.0, 0.0};
+    double4 co[3];
+    if (cnt > 0) {
+        co[0] = node4[rc_next.x & 0x7fffffff];
+        co[1] = node4[rc_next.y & 0x7fffffff];
+        co[2] = node4[rc_next.z];
+    } else {
+        co[0] = co[1] = co[2] = double4{0.0, 0.0, 0.0, 0.0};
     }
+    bool neg_jac = false;
     for (int64_t t = beg; t < end; t += 64) {
         const int4 rc = rc_next;
-        double x[4], y[4], z[4], ud[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { x[i] = cn[i].x; y[i] = cn[i].y; z[i] = cn[i].z; ud[i] = cn[i].w; }
+        const double4 c0 = co[0], c1 = co[1], c2 = co[2];
         rc_next = rc_next2;
         if (t + 64 < end) {
-            int nd[4];
-            node_ids(rc_next, nd);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) cn[i] = node4[nd[i]];
+            co[0] = node4[rc_next.x & 0x7fffffff];
+            co[1] = node4[rc_next.y & 0x7fffffff];
+            co[2] = node4[rc_next.z];
             if (t + 128 < end) rc_next2 = inc_rec[t + 128];
         }
         const uint32_t slots = static_cast<uint32_t>(rc.w);
         const int a = static_cast<int>((static_cast<uint32_t>(rc.x) >> 31) | ((static_cast<uint32_t>(rc.y) >> 31) << 1));
-        bool fixed[4], any_fixed = false;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            fixed[i] = ((slots >> (8 * i)) & 0xffu) == 0xffu;
-            any_fixed |= fixed[i];
+        bool ok = true;
+        switch (a) {
+        case 0: ok = gather_visit<0>(self, c0, c1, c2, slots, prm, acc, T, facc); break;
+        case 1: ok = gather_visit<1>(self, c0, c1, c2, slots, prm, acc, T, facc); break;
+        case 2: ok = gather_visit<2>(self, c0, c1, c2, slots, prm, acc, T, facc); break;
+        default: ok = gather_visit<3>(self, c0, c1, c2, slots, prm, acc, T, facc); break;
         }
-        double Krow[4] = {0.0, 0.0, 0.0, 0.0}, Kcol[4], f = 0.0;
-        if (!poisson_tet_node_lean(x, y, z, prm.ed[0], prm.ed[1], prm.ed[2], prm.af, a, any_fixed, Kcol, Krow, f)) {
-            atomicMax(err, PFEM_ERR_NEG_JAC);
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)            // Flocal(a) -= Klocal(a,i)*u_D(i)   (:859-870)
-            if (fixed[i]) f = f - Krow[i] * ud[i];
-        facc += f;                             // VecSetValues(ADD_VALUES) :880
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {          // entry (row, dof_j) += Klocal(j,a)   (:851, row-major read)
-            if (fixed[j]) continue;
-            const uint32_t k = (slots >> (8 * j)) & 0xffu;
-            acc[k * T] += Kcol[j];
-        }
+        neg_jac = neg_jac || !ok;
+    }
+    if (neg_jac) {
+        atomicMax(err, PFEM_ERR_NEG_JAC);
+        return;
     }
     if (rvals) {
         // both forms: the row form, and the relative-group copy the CG's SpMV streams (k_spmvr: group g = row / 4, plane row % 4,
