@@ -326,6 +326,8 @@ struct CommBackend {
     virtual ~CommBackend() {}
     virtual const char *name() const = 0;
     virtual bool capturable() const { return false; }      // may its calls be recorded by a HIP stream capture?
+    virtual bool p2p_capturable() const { return false; }  // ... its neighbour exchanges too?  (RCCL of ROCm 7.2: a captured grouped send/recv crashed)
+    virtual int64_t allreduce_capture_limit() const { return INT64_MAX; }      // ... all-reduces up to this many doubles
     // what the transport itself reports: ranks of its communicator (ncclCommCount), the device it is bound to
     // (ncclCommCuDevice), the library version (ncclGetVersion); -1 where the backend has no such notion
     virtual void describe(int *ranks, int *device, int *version) const { *ranks = -1; *device = -1; *version = -1; }
@@ -504,7 +506,11 @@ struct pfem_solver {
     int hist_cap = 0;
 
     // compat (host staging of MatSetValues / VecSetValues)
-    std::vector<uint64_t> h_keys;
+    // compat path, INSERT_VALUES pass: (row, col) keys as the driver hands them over, in chunks (one growing vector copied
+    // 1.5 GB at config 2 on its way to 768 MB)
+    static constexpr size_t kKeyChunk = size_t(1) << 22;
+    std::vector<std::vector<uint64_t>> h_keys;
+    size_t n_keys() const { size_t t = 0; for (const auto &c : h_keys) t += c.size(); return t; }
     std::vector<int64_t> h_rowptr;
     std::vector<int32_t> h_cols;
     std::vector<double> h_vals, h_rhs;
@@ -2741,14 +2747,14 @@ struct HostBackend final : CommBackend {
 // through the all-reduce hook) and carry what does not fit a box (all-reduces beyond kPeerAllreduceCap doubles: the symbolic
 // phase's lists; exchanges always fit -- the box is sized at bring-up, PFEM_PEER_CAP_DOUBLES per neighbour).
 struct PeerBackend final : CommBackend {
-    static constexpr int64_t kPeerAllreduceCap = 65536;
+    static constexpr int64_t kPeerAllreduceCap = 196608;      // (>= the rows of a replicated multigrid level, kAmgReplicateRows: its right-hand side stays on the device path)
     HostBackend host;
     int rank = 0, nranks = 1, device = 0;
     void *base = nullptr;
     std::vector<void *> mapped;                    // peers' regions in this address space (nullptr for the own one)
     PeerWorld W{};
-    std::vector<unsigned long long> xe;            // per pair: exchange messages so far
-    unsigned long long ae = 0;
+    unsigned long long *d_epochs = nullptr;        // [nranks + 1] on the device: exchange messages per pair so far, all-reduces so far
+    int *d_xarrive = nullptr;                      // [2][kPeerMaxRanks] arrival counters of the exchange kernel's blocks (zero between launches)
     int *d_arrive = nullptr;
     bool up = false;
     bool fine = false;                             // the region is fine-grained device memory (what a neighbour on another device needs)
@@ -2772,8 +2778,15 @@ struct PeerBackend final : CommBackend {
             if (p) (void)hipIpcCloseMemHandle(p);
         if (base) (void)hipFree(base);
         if (d_arrive) (void)hipFree(d_arrive);
+        if (d_epochs) (void)hipFree(d_epochs);
+        if (d_xarrive) (void)hipFree(d_xarrive);
     }
     const char *name() const override { return fine ? "peer-ipc" : "peer-ipc-coarse"; }
+    // every call is a plain kernel launch with constant arguments (the message counters live on the device): capturable,
+    // neighbour exchanges included -- as long as the all-reduce fits its box (else the host hooks carry it)
+    bool capturable() const override { return true; }
+    bool p2p_capturable() const override { return true; }
+    int64_t allreduce_capture_limit() const override { return W.cap_a; }
     void describe(int *ranks, int *dev, int *version) const override { *ranks = nranks; *dev = device; *version = -1; }
     static size_t pad(size_t b) { return (b + 255) / 256 * 256; }
     void carve(char *b, PeerMail &m) const
@@ -2817,8 +2830,8 @@ struct PeerBackend final : CommBackend {
         static const bool fine_wanted = [] { const char *e = std::getenv("PFEM_PEER_FINEGRAINED"); return e ? std::atoi(e) != 0 : true; }();
         fine = fine_wanted && hipExtMallocWithFlags(&base, bytes, hipDeviceMallocFinegrained) == hipSuccess;
         if (!fine) { (void)hipGetLastError(); base = nullptr; }
-        if ((!fine && hipMalloc(&base, bytes) != hipSuccess) || hipMemset(base, 0, bytes) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&d_arrive), sizeof(int)) != hipSuccess ||
-            hipMemset(d_arrive, 0, sizeof(int)) != hipSuccess) {
+        if ((!fine && hipMalloc(&base, bytes) != hipSuccess) || hipMemset(base, 0, bytes) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&d_arrive), sizeof(int) * (1 + kPeerMaxRanks)) != hipSuccess ||
+            hipMemset(d_arrive, 0, sizeof(int) * (1 + kPeerMaxRanks)) != hipSuccess) {
             (void)hipGetLastError();
             rc_local = PFEM_ERR_NOMEM;
         } else if (n > 1 && hipIpcGetMemHandle(&mine, base) != hipSuccess) {
@@ -2855,7 +2868,16 @@ struct PeerBackend final : CommBackend {
         }
         if (n > 1 && host.ar(host.ctx, &bad_open, 1) != 0) return PFEM_ERR_COMM;        // (also the barrier: every region is mapped before its first use)
         if (bad_open != 0.0) return PFEM_ERR_COMM;
-        xe.assign(static_cast<size_t>(n), 0);
+        if (hipMalloc(reinterpret_cast<void **>(&d_epochs), sizeof(unsigned long long) * static_cast<size_t>(n + 1)) != hipSuccess ||
+            hipMemset(d_epochs, 0, sizeof(unsigned long long) * static_cast<size_t>(n + 1)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&d_xarrive), sizeof(int) * 2 * kPeerMaxRanks) != hipSuccess ||
+            hipMemset(d_xarrive, 0, sizeof(int) * 2 * kPeerMaxRanks) != hipSuccess) {
+            (void)hipGetLastError();
+            return PFEM_ERR_NOMEM;              // (after the last collective of the bring-up: a rank-local failure; the others find out at the self-test)
+        }
+        (void)hipDeviceSynchronize();
+        W.xepoch = d_epochs;
+        W.aepoch = d_epochs + n;
         up = true;
         return PFEM_OK;
     }
@@ -2863,10 +2885,10 @@ struct PeerBackend final : CommBackend {
     {
         if (nranks == 1) return PFEM_OK;
         if (n > W.cap_a) return host.allreduce(d, n, st);          // (every rank sees the same n: the same path everywhere)
-        ++ae;
-        const unsigned blocks = static_cast<unsigned>(std::max<int64_t>(nranks, std::min<int64_t>(64, (n + 1023) / 1024)));
-        hipLaunchKernelGGL(k_peer_allreduce, dim3(blocks), dim3(1024), 0, st, W, ae, d, n, d_arrive);
-        hipLaunchKernelGGL(k_peer_allreduce_ack, dim3(1), dim3(64), 0, st, W, ae, d_arrive);
+        const int pb = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(8, n / 8192)));       // slices per destination
+        const unsigned blocks = static_cast<unsigned>(std::max<int64_t>(static_cast<int64_t>(nranks) * pb, std::min<int64_t>(64, (n + 1023) / 1024)));
+        hipLaunchKernelGGL(k_peer_allreduce, dim3(blocks), dim3(1024), 0, st, W, d, n, pb, d_arrive);
+        hipLaunchKernelGGL(k_peer_allreduce_ack, dim3(1), dim3(64), 0, st, W, d_arrive);
         return check_kernel("k_peer_allreduce");
     }
     int exchange(int np, const int *peers, const int64_t *off, const double *d_send, double *d_recv, hipStream_t st) override
@@ -2884,10 +2906,11 @@ struct PeerBackend final : CommBackend {
             }
             X.peers[k] = peers[k];
             X.off[k] = off[k];
-            X.epoch[k] = ++xe[static_cast<size_t>(peers[k])];
         }
         X.off[np] = off[np];
-        hipLaunchKernelGGL(k_peer_exchange, dim3(static_cast<unsigned>(np)), dim3(1024), 0, st, W, X, d_send, d_recv);
+        for (int k = 0; k < np; ++k)
+            X.blocks[k] = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(kPeerXBlocks, (off[k + 1] - off[k]) / kPeerXSlice)));
+        hipLaunchKernelGGL(k_peer_exchange, dim3(static_cast<unsigned>(np * kPeerXBlocks)), dim3(1024), 0, st, W, X, d_send, d_recv, d_xarrive);
         return check_kernel("k_peer_exchange");
     }
     int health() override
@@ -4145,28 +4168,56 @@ extern "C" int pfem_mat_set_values(pfem_solver *s, int m, const int *idxm, int n
             for (int j = 0; j < n; ++j) {
                 if (idxn[j] < 0) continue;
                 if (idxn[j] >= s->size_global) return PFEM_ERR_ARG;
-                s->h_keys.push_back((static_cast<uint64_t>(static_cast<uint32_t>(idxm[i])) << 32) | static_cast<uint32_t>(idxn[j]));
+                if (s->h_keys.empty() || s->h_keys.back().size() == pfem_solver::kKeyChunk) {
+                    s->h_keys.emplace_back();
+                    s->h_keys.back().reserve(pfem_solver::kKeyChunk);
+                }
+                s->h_keys.back().push_back((static_cast<uint64_t>(static_cast<uint32_t>(idxm[i])) << 32) | static_cast<uint32_t>(idxn[j]));
             }
         }
         return PFEM_OK;
     }
     if (!v) return PFEM_ERR_ARG;
     if (s->h_rowptr.empty()) return PFEM_ERR_STATE;
+    // (round 5, measured at config 2 through the Fortran host loop: 0.93 s for 6 M elements against 0.43 s for the oracle's serial
+    // assembly.  The column ids are resolved once per call, not once per row; one rank's global ids ARE its local ones; the
+    // element blocks of the drivers are square with idxm == idxn, whose rows reuse the columns' ids.)
+    constexpr int kStack = 64;
+    int64_t cl_stack[kStack];
+    std::vector<int64_t> cl_heap;
+    int64_t *cl = cl_stack;
+    if (n > kStack) { cl_heap.resize(static_cast<size_t>(n)); cl = cl_heap.data(); }
+    const bool one_rank = s->n_owned == s->size_global && s->row_start == 0;
+    for (int j = 0; j < n; ++j) {
+        if (idxn[j] < 0) { cl[j] = -1; continue; }
+        if (idxn[j] >= s->size_global) return PFEM_ERR_PATTERN;
+        cl[j] = one_rank ? idxn[j] : compat_local(s, idxn[j]);
+        if (cl[j] < 0) return PFEM_ERR_PATTERN;
+    }
+    const bool square = m == n && (idxm == idxn || std::equal(idxm, idxm + m, idxn));
+    const int64_t *rowptr = s->h_rowptr.data();
+    const int32_t *cols = s->h_cols.data();
+    double *vals = s->h_vals.data();
     for (int i = 0; i < m; ++i) {
         if (idxm[i] < 0) continue;
         if (idxm[i] >= s->size_global) return PFEM_ERR_ARG;
-        const int64_t r = compat_local(s, idxm[i]);
+        const int64_t r = square ? cl[i] : (one_rank ? idxm[i] : compat_local(s, idxm[i]));
         if (r < 0) return PFEM_ERR_PATTERN;
-        const int32_t *cb = s->h_cols.data() + s->h_rowptr[r], *ce = s->h_cols.data() + s->h_rowptr[r + 1];
+        const int32_t *cb = cols + rowptr[r], *ce = cols + rowptr[r + 1];
+        const double *vrow = v + static_cast<size_t>(i) * n;             // PETSc reads v row-major
         for (int j = 0; j < n; ++j) {
-            if (idxn[j] < 0) continue;
-            const int64_t cl = idxn[j] < s->size_global ? compat_local(s, idxn[j]) : -1;
-            if (cl < 0) return PFEM_ERR_PATTERN;
-            const int32_t *p = std::lower_bound(cb, ce, static_cast<int32_t>(cl));
-            if (p == ce || *p != cl) return PFEM_ERR_PATTERN;
-            double &dst = s->h_vals[static_cast<size_t>(p - s->h_cols.data())];
-            const double val = v[static_cast<size_t>(i) * n + j];      // PETSc reads v row-major
-            if (mode == PFEM_ADD_VALUES) dst += val; else dst = val;
+            if (cl[j] < 0) continue;
+            const int32_t want = static_cast<int32_t>(cl[j]);
+            const int32_t *p = cb;                                       // rows of a P1 mesh hold 15-81 entries: a short branch-free bisection
+            for (std::ptrdiff_t len = ce - cb; len > 0;) {
+                const std::ptrdiff_t half = len >> 1;
+                const bool right = p[half] < want;
+                p = right ? p + half + 1 : p;
+                len = right ? len - half - 1 : half;
+            }
+            if (p == ce || *p != want) return PFEM_ERR_PATTERN;
+            double &dst = vals[p - cols];
+            if (mode == PFEM_ADD_VALUES) dst += vrow[j]; else dst = vrow[j];
         }
     }
     s->host_values_dirty = true;
@@ -4218,28 +4269,36 @@ extern "C" int pfem_solver_set_zero(pfem_solver *s)
         if (compat) {
             if (s->h_keys.empty() && s->size_global > 0) return PFEM_ERR_STATE;
             // MatAssembly of the INSERT_VALUES pass: finalise the recorded pattern on the device
-            const int64_t nk = static_cast<int64_t>(s->h_keys.size());
+            const int64_t nk = static_cast<int64_t>(s->n_keys());
             s->ghost_gid.clear();
             if (s->n_owned < s->size_global) {          // multi-rank: ids outside the owned block become ghosts
                 const int64_t lo = s->row_start, hi = s->row_start + s->n_owned;
-                for (const uint64_t k : s->h_keys) {
-                    const int64_t r = static_cast<int64_t>(k >> 32), c = static_cast<int64_t>(k & 0xffffffffu);
-                    if (r < lo || r >= hi) s->ghost_gid.push_back(r);
-                    if (c < lo || c >= hi) s->ghost_gid.push_back(c);
-                }
+                for (const auto &chunk : s->h_keys)
+                    for (const uint64_t k : chunk) {
+                        const int64_t r = static_cast<int64_t>(k >> 32), c = static_cast<int64_t>(k & 0xffffffffu);
+                        if (r < lo || r >= hi) s->ghost_gid.push_back(r);
+                        if (c < lo || c >= hi) s->ghost_gid.push_back(c);
+                    }
                 std::sort(s->ghost_gid.begin(), s->ghost_gid.end());
                 s->ghost_gid.erase(std::unique(s->ghost_gid.begin(), s->ghost_gid.end()), s->ghost_gid.end());
-                for (uint64_t &k : s->h_keys)
-                    k = (static_cast<uint64_t>(compat_local(s, static_cast<int64_t>(k >> 32))) << 32) |
-                        static_cast<uint64_t>(compat_local(s, static_cast<int64_t>(k & 0xffffffffu)));
+                for (auto &chunk : s->h_keys)
+                    for (uint64_t &k : chunk)
+                        k = (static_cast<uint64_t>(compat_local(s, static_cast<int64_t>(k >> 32))) << 32) |
+                            static_cast<uint64_t>(compat_local(s, static_cast<int64_t>(k & 0xffffffffu)));
             }
             s->n_ghost = static_cast<int64_t>(s->ghost_gid.size());
             s->n_loc = s->n_owned + s->n_ghost;
             if (s->n_loc > INT32_MAX) return PFEM_ERR_ARG;
             DevBuf<uint64_t> keys;
             PFEM_TRY(keys.alloc(static_cast<size_t>(std::max<int64_t>(nk, 1))));
-            if (nk) PFEM_HIP(hipMemcpy(keys.p, s->h_keys.data(), sizeof(uint64_t) * nk, hipMemcpyHostToDevice));
-            std::vector<uint64_t>().swap(s->h_keys);
+            {
+                size_t at = 0;
+                for (const auto &chunk : s->h_keys) {
+                    if (!chunk.empty()) PFEM_HIP(hipMemcpy(keys.p + at, chunk.data(), sizeof(uint64_t) * chunk.size(), hipMemcpyHostToDevice));
+                    at += chunk.size();
+                }
+            }
+            std::vector<std::vector<uint64_t>>().swap(s->h_keys);
             PFEM_TRY(pattern_from_keys(s, keys, nk));
         } else {
             PFEM_TRY(pfem_pattern_build(s));

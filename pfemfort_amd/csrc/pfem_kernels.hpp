@@ -955,12 +955,15 @@ __device__ __forceinline__ bool gather_visit(const double4 &self, const double4 
     for (int i = 0; i < 4; ++i)            // Flocal(a) -= Klocal(a,i)*u_D(i)   (:859-870)
         if (fixed[i]) f = f - Krow[i] * ud[i];
     facc += f;                             // VecSetValues(ADD_VALUES) :880
+    // entry (row, dof_j) += Klocal(j,a)   (:851, row-major read).  The four slots of a visit are four different columns of the
+    // row (the element's four nodes): read them all, then write them all -- one LDS round trip per visit instead of four
+    // dependent ones; every slot still takes exactly one addition per visit, in element order: the same bits
+    double cur[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {          // entry (row, dof_j) += Klocal(j,a)   (:851, row-major read)
-        if (fixed[j]) continue;
-        const uint32_t k = (slots >> (8 * j)) & 0xffu;
-        acc[k * T] += Kcol[j];
-    }
+    for (int j = 0; j < 4; ++j) cur[j] = fixed[j] ? 0.0 : acc[((slots >> (8 * j)) & 0xffu) * T];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (!fixed[j]) acc[((slots >> (8 * j)) & 0xffu) * T] = cur[j] + Kcol[j];
     return true;
 }
 
