@@ -725,6 +725,9 @@ def main():
     import pfemfort_amd as pf
     from pfemfort_amd import host as H
 
+    if int(os.environ.get("RANK", "0")) == 0:      # (the first line of every run says which solver it is: the library's own default differs)
+        print(f"bench.py: KSP = cg, PC = {args.pc} (-pc_type {args.pc}); the library, the Python drivers and the Fortran modules default to "
+              "-pc_type jacobi unless petsc_options.dat / setPreconditioner says otherwise", file=sys.stderr, flush=True)
     J = Job(args)
     world, rank = J.world, J.rank
     if world != args.gpus:

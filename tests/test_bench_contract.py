@@ -81,6 +81,25 @@ def test_bench_two_ranks_sharing_the_device():
     assert d["config"]["partition"]["axis"] == "z" and sum(d["config"]["partition"]["hex_layers_per_rank"]) == side
     assert c["neighbours"] == 1 and c["bytes_per_neighbour"] == 8 * (side - 1) ** 2 and c["samples"] > 0
     assert 0 < c["boundary_slices"] < c["slices"] and c["interface_exchange_ms"] > 0 and c["scalar_allreduce_ms"] > 0
+    # what the ONE 8-GPU run of the driver has to answer, filled here with two ranks sharing the device:
+    # all three headline rates, the links' latencies at the message sizes of configs 4 / 5, the coupled cycle's exchanges per
+    # level with their times, the multigrid's phase times, and the same steps over the other device-side transport
+    assert d["value"] > 0 and d["cold_value"] > 0 and d["jacobi_step"]["ms_per_step"] > d["ms_per_step"]
+    ll = c["link_latencies"]
+    assert ll["transport"] == "host" and all(ll[k] > 0 for k in ("exchange_62KB_with_slab_neighbours_us", "exchange_1.29MB_with_slab_neighbours_us",
+                                                                 "allreduce_3_doubles_us", "allreduce_125000_doubles_us"))
+    cc = c["coupled_cycle"]
+    nl = d["preconditioner"]["levels"]
+    assert cc["cycle_ms"] > 0 and len(cc["exchanges_per_level"]) >= 2 and sum(cc["exchanges_per_level"]) == d["preconditioner"].get("exchanges_per_cycle", sum(cc["exchanges_per_level"]))
+    assert all((n == 0) == (t == 0.0) for n, t in zip(cc["exchanges_per_level"], cc["exchange_ms_per_level"])) and nl >= 2
+    assert d["preconditioner"]["symbolic_setup_ms_once_per_pattern"] > 0 and d["preconditioner"]["numeric_setup_ms_per_solve_inside_the_timer"] > 0
+    tr = c["transports"]
+    assert set(tr) == {"gloo-host-hooks", "peer-ipc", "note"}
+    pe = tr["peer-ipc"]
+    assert "skipped" not in pe, pe
+    assert pe["converged_reason"] == 2 and abs(pe["iterations"] - d["iterations"]) <= 1 and pe["link_latencies"]["transport"] == "peer-ipc"
+    assert pe["coupled_cycle"]["exchanges_per_level"] == cc["exchanges_per_level"]
+    assert pe["host_enqueue_us_per_iteration"] < 0.5 * c["host_enqueue_us_per_iteration"]       # its cycle replays from a hipGraph
 
 
 @pytest.mark.gpu
@@ -95,7 +114,7 @@ def test_config5_at_full_size_with_eight_ranks_sharing_the_device():
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--no-transport-ab", "--steps", "1", "--warmup", "0",
                         "--backend", "gloo", "--same-device", "--pc", "jacobi"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1])
@@ -143,7 +162,7 @@ def test_config5_with_the_default_solver():
     pt = d["parity_tolerance_step"]
     assert pt["converged_reason"] == 2 and pt["max_nodal_error"] < 2e-7 and pt["iterations"] <= 40
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--same-device", "--backend", "gloo", "--steps", "1",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--no-transport-ab", "--same-device", "--backend", "gloo", "--steps", "1",
                         "--warmup", "0", "--no-jacobi-step", "--no-parity-step"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d8 = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1])
@@ -164,7 +183,7 @@ def test_strong_scaling_flag_keeps_the_problem():
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cells", "60", "--strong",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-transport-ab", "--cells", "60", "--strong",
                           "--steps", "1", "--warmup", "0", "--backend", "gloo", "--same-device", "--no-cpu-baseline", "--no-parity-step", "--pc", "jacobi"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-3000:]
@@ -184,7 +203,7 @@ def test_plain_invocation_with_two_gpus_launches_its_own_ranks():
     their exit code.  The line says what carried the run and how to read it: transport and rank count, every rank's
     device, per-iteration efficiency, and the strong-scaling companion block."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo", "--cells", "40"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-transport-ab", "--same-device", "--backend", "gloo", "--cells", "40"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -210,7 +229,7 @@ def test_plain_invocation_reports_a_dead_rank_with_its_exit_code():
     import time
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     t0 = time.time()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo", "--cells", "20",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-transport-ab", "--same-device", "--backend", "gloo", "--cells", "20",
                         "--steps", "1", "--warmup", "0", "--debug-die-rank", "1", "--bringup-timeout", "60"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
@@ -224,7 +243,7 @@ def test_beam_on_eight_ranks_is_cut_across_its_length():
     z-layers with 368 KB faces; the default solve (one multigrid hierarchy across the eight ranks) converges to the same tip
     displacement in about the iterations the one-GPU hierarchy needs (18), a small fraction of point Jacobi's 5 207."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--same-device", "--backend", "gloo",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--no-transport-ab", "--same-device", "--backend", "gloo",
                         "--workload", "beam", "--steps", "1", "--warmup", "0", "--no-jacobi-step", "--no-parity-step"],
                        capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
