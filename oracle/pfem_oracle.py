@@ -356,27 +356,37 @@ def _lat_sim_passes(hi, axis, passes):
     return shift, hi, axis
 
 
-def _lat_pad(cuts, hi, axis, passes):
-    """Positions 0..hi[d] in stretches of one owner starting at cuts[d][k] -> padded positions whose stretches start on
-    multiples of the brick size the level will take (pfem_amg.inc: lat_pad).  (tables, new cuts, new hi) or None."""
+def _lat_pad(cuts, single, hi, occ, axis, passes):
+    """Positions 0..hi[d] in stretches of one owner starting at cuts[d][k] -> padded positions in which no brick of the level holds
+    positions of two stretches (pfem_amg.inc: lat_pad).  The odd position a stretch of odd length leaves over goes to the
+    stretch's START (which then begins on an odd position, behind a free one) when the last odd one went to the end, and the
+    other way round (``single[d][k]`` = 1: the last one went to the start); the first stretch always starts at 0, axes halved
+    twice in a level keep the plain alignment.  (tables, new cuts, new single, new hi) or None."""
     shift = [0, 0, 0]
     for _ in range(5):
-        table, ncuts, nhi = [np.zeros(1024, np.int64) for _ in range(3)], [[], [], []], [0, 0, 0]
+        table, ncuts, nsingle, nhi = [np.zeros(1024, np.int64) for _ in range(3)], [[], [], []], [[], [], []], [0, 0, 0]
         for d in range(3):
             nxt, cs = 0, (list(cuts[d]) or [0])
             for k, start in enumerate(cs):
                 end = cs[k + 1] if k + 1 < len(cs) else hi[d] + 1
+                ln = end - start
+                ln_occ = min(end, occ[1][d] + 1) - max(start, occ[0][d])          # occupied positions: a Dirichlet plane has a position and no dofs
+                prev = single[d][k] if k < len(single[d]) else 0
                 a = 1 << shift[d]
                 base = 0 if k == 0 else (nxt + a - 1) // a * a
+                now = prev if shift[d] == 0 else 0
+                if k > 0 and shift[d] == 1 and ln_occ > 0 and ln_occ % 2 == 1 and prev == 0:
+                    base, now = (nxt + 1) | 1, 1
                 ncuts[d].append(base)
-                if base + (end - start) > 1024:
+                nsingle[d].append(now)
+                if base + ln > 1024:
                     return None
-                table[d][start:end] = base + np.arange(end - start)
-                nxt = base + (end - start)
+                table[d][start:end] = base + np.arange(ln)
+                nxt = base + ln
             nhi[d] = nxt - 1
         s2, _, _ = _lat_sim_passes(nhi, axis, passes)
         if all(s2[d] <= shift[d] for d in range(3)):
-            return table, ncuts, nhi
+            return table, ncuts, nsingle, nhi
         shift = [max(shift[d], s2[d]) for d in range(3)]
     return None
 
@@ -394,7 +404,8 @@ def lattice_brick_aggregates(xyz_nodes, xyz_free, dense_limit=128, passes=3, max
     must fill a box of positions (else None: the product leaves the brick path).  The planes where the owner changes are
     padded onto multiples of the level's brick size, on every level anew, so that no brick holds dofs of two owners; a rank
     numbers its own bricks (z, y, x), rank after rank.  From the first level of at most ``replicate_rows`` dofs (0: never) on,
-    every rank holds the whole level: plain bricks of the (padded) positions again."""
+    every rank holds the whole level: plain bricks again, of the positions with the padding closed up (rank among the occupied
+    positions per axis)."""
     xyz_nodes = np.atleast_2d(np.asarray(xyz_nodes, dtype=np.float64))
     xyz_free = np.atleast_2d(np.asarray(xyz_free, dtype=np.float64))
     dim, n = xyz_free.shape
@@ -421,10 +432,10 @@ def lattice_brick_aggregates(xyz_nodes, xyz_free, dense_limit=128, passes=3, max
         gmax = [max(b[1][d] for b in boxes) for d in range(3)]
         cuts = [sorted({0} | {int(b[0][d]) for b in boxes if b[0][d] > gmin[d]} | {int(b[1][d]) + 1 for b in boxes if b[1][d] < gmax[d]})
                 for d in range(3)]
-        padded = _lat_pad(cuts, hi, 0, passes)
+        padded = _lat_pad(cuts, [[], [], []], hi, (gmin, gmax), 0, passes)
         if padded is None:
             return None
-        table, cuts, hi = padded
+        table, cuts, single, hi = padded
         pos = np.stack([table[d][pos[d]] for d in range(3)])
     while n > dense_limit and len(aggs) + 1 < max_levels:
         shift, hi_c, axis_c = _lat_sim_passes(hi, axis, passes)
@@ -434,7 +445,6 @@ def lattice_brick_aggregates(xyz_nodes, xyz_free, dense_limit=128, passes=3, max
         nb = [(hi[d] >> shift[d]) + 1 for d in range(3)]
         lin = b[0] + nb[0] * (b[1] + nb[1] * b[2])
         if cuts is not None:          # distributed level: the owners number their own bricks, rank after rank
-            assert all(c % (1 << shift[d]) == 0 for d in range(3) for c in cuts[d])
             nbt = nb[0] * nb[1] * nb[2]
             occ, agg = np.unique(owner * nbt + lin, return_inverse=True)
             owner_c, occ = occ // nbt, occ % nbt
@@ -447,12 +457,17 @@ def lattice_brick_aggregates(xyz_nodes, xyz_free, dense_limit=128, passes=3, max
         n, hi, axis = len(occ), hi_c, axis_c
         if cuts is not None:
             owner = owner_c
-            padded = _lat_pad([[c >> shift[d] for c in cuts[d]] for d in range(3)], hi, axis, passes)
+            padded = _lat_pad([[c >> shift[d] for c in cuts[d]] for d in range(3)], single, hi,
+                              ([int(pos[d].min()) for d in range(3)], [int(pos[d].max()) for d in range(3)]), axis, passes)
             assert padded is not None
-            table, cuts, hi = padded
+            table, cuts, single, hi = padded
             pos = np.stack([table[d][pos[d]] for d in range(3)])
             if dense_limit < n <= replicate_rows:
-                cuts = None
+                cuts = None              # every rank holds the level whole from here on: the padding is closed up again --
+                for d in range(3):       # a position becomes its rank among the occupied positions of its axis
+                    u = np.unique(pos[d])
+                    pos[d] = np.searchsorted(u, pos[d])
+                    hi[d] = len(u) - 1
     return aggs
 
 

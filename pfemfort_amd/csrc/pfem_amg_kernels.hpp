@@ -212,7 +212,11 @@ __global__ void __launch_bounds__(kBlock) k_lat_check(SellDev A, const int32_t *
     bool weak = false;
     for (int a = 0; a < 3; ++a)
         if (B.shift[a] > 0 && ssib[a] >= 0.0 && !(ssib[a] > 0.0 && ssib[a] >= 0.25 * smax)) weak = true;
-    if (weak || far) *fail = 1;
+    if (weak || far) {
+        *fail = 1;
+        if (weak) atomicAdd(fail + 1, 1);          // (how many rows, and why: PFEM_AMG_VERBOSE prints them; rows that refuse are few or all)
+        if (far) atomicAdd(fail + 2, 1);
+    }
     brick_flag[lat_brick_linear(B, pi)] = 1;
 }
 // aggregate of every node = rank of its brick among the occupied ones (ascending in z, y, x: coarse columns come out ascending
@@ -275,6 +279,16 @@ __global__ void __launch_bounds__(kBlock) k_lat_xyz_from_pos(int64_t nn, const i
     if (i >= nn) return;
     const int32_t p = pos[i];
     for (int d = 0; d < 3; ++d) xyz[d * nn + i] = coord[1024 * d + ((p >> (10 * d)) & 0x3ff)];
+}
+// which positions of every axis are occupied (used: [3][1024], zeroed)
+__global__ void __launch_bounds__(kBlock) k_lat_mark_used(int64_t n, const int32_t *__restrict__ pos, int32_t *__restrict__ used)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int32_t p = pos[i];
+    used[p & 0x3ff] = 1;
+    used[1024 + ((p >> 10) & 0x3ff)] = 1;
+    used[2048 + ((p >> 20) & 0x3ff)] = 1;
 }
 // owned dofs' positions into the global array of the replicated level (zeroed before, summed over the ranks after)
 __global__ void __launch_bounds__(kBlock) k_lat_emit_global_pos(int64_t n_own, const int32_t *__restrict__ gid, const int32_t *__restrict__ pos,

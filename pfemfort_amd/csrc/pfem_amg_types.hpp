@@ -41,6 +41,9 @@ struct AmgLevel {
     // every stretch of one owner, per axis, ascending, [0] = 0) is a multiple of the level's brick size
     bool lat_global = false;
     std::vector<int> lat_cuts[3];
+    std::vector<char> lat_single[3];      // per stretch: the last odd position of the stretch went to its start (lat_pad alternates)
+    int lat_shift[3] = {0, 0, 0};         // the halvings per axis the padding of this level was made for
+    int lat_occ[6] = {0, 0, 0, 0, 0, 0};  // lowest / highest OCCUPIED position per axis over all ranks (a Dirichlet plane has a position and no dofs)
     int lat_box[6] = {0, 0, 0, 0, 0, 0};  // box of the local nodes' positions: lowest x, y, z, highest x, y, z
     // node bricks in one step (rigid-body levels, amg_node_bricks): the box of positions the level's nodes fill completely
     bool lat_full = false;

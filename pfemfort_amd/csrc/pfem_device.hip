@@ -2841,12 +2841,14 @@ struct PeerBackend final : CommBackend {
         (void)hipDeviceSynchronize();
         // handles (and every rank's verdict so far) to all ranks: one byte per double through the all-reduce hook
         constexpr size_t HB = sizeof(hipIpcMemHandle_t);
-        std::vector<double> hb(static_cast<size_t>(n) * (HB + 1), 0.0);
-        for (size_t i = 0; i < HB; ++i) hb[static_cast<size_t>(r) * (HB + 1) + i] = static_cast<double>(reinterpret_cast<const unsigned char *>(&mine)[i]);
-        hb[static_cast<size_t>(r) * (HB + 1) + HB] = rc_local == PFEM_OK ? 0.0 : 1.0;
+        constexpr size_t HS = HB + 2;                 // + the rank's verdict + its device ordinal (one process per GPU of ONE node: ordinals agree)
+        std::vector<double> hb(static_cast<size_t>(n) * HS, 0.0);
+        for (size_t i = 0; i < HB; ++i) hb[static_cast<size_t>(r) * HS + i] = static_cast<double>(reinterpret_cast<const unsigned char *>(&mine)[i]);
+        hb[static_cast<size_t>(r) * HS + HB] = rc_local == PFEM_OK ? 0.0 : 1.0;
+        hb[static_cast<size_t>(r) * HS + HB + 1] = static_cast<double>(dev);
         if (n > 1 && host.ar(host.ctx, hb.data(), static_cast<int64_t>(hb.size())) != 0) return PFEM_ERR_COMM;
         bool any_bad = false;
-        for (int q = 0; q < n; ++q) any_bad = any_bad || hb[static_cast<size_t>(q) * (HB + 1) + HB] != 0.0;
+        for (int q = 0; q < n; ++q) any_bad = any_bad || hb[static_cast<size_t>(q) * HS + HB] != 0.0;
         if (any_bad) { if (rc_local == PFEM_OK) set_last_error("peer transport: another rank could not export its memory"); return rc_local != PFEM_OK ? rc_local : PFEM_ERR_COMM; }
         mapped.assign(static_cast<size_t>(n), nullptr);
         double bad_open = 0.0;
@@ -2854,10 +2856,30 @@ struct PeerBackend final : CommBackend {
             char *b = static_cast<char *>(base);
             if (q != r) {
                 hipIpcMemHandle_t h;
-                for (size_t i = 0; i < HB; ++i) reinterpret_cast<unsigned char *>(&h)[i] = static_cast<unsigned char>(hb[static_cast<size_t>(q) * (HB + 1) + i]);
+                for (size_t i = 0; i < HB; ++i) reinterpret_cast<unsigned char *>(&h)[i] = static_cast<unsigned char>(hb[static_cast<size_t>(q) * HS + i]);
+                // a neighbour on another device: refuse BEFORE any kernel touches its memory unless the runtime says this device
+                // may (a kernel access to unreachable memory is a fault that ends the process, not an error code)
+                const int dev_q = static_cast<int>(hb[static_cast<size_t>(q) * HS + HB + 1]);
+                if (dev_q != dev) {
+                    int can = 0;
+                    if (hipDeviceCanAccessPeer(&can, dev, dev_q) != hipSuccess || !can) {
+                        (void)hipGetLastError();
+                        set_last_error("peer transport: device " + std::to_string(dev) + " cannot access the memory of device " + std::to_string(dev_q) + " (hipDeviceCanAccessPeer)");
+                        bad_open = 1.0;
+                        continue;
+                    }
+                }
                 void *p = nullptr;
                 if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
                     set_last_error(std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(hipGetLastError()));
+                    bad_open = 1.0;
+                    continue;
+                }
+                unsigned long long probe = 1;          // (an API-level read of the mapped region: an error here is an error code, not a fault)
+                if (hipMemcpy(&probe, p, sizeof probe, hipMemcpyDeviceToHost) != hipSuccess || probe != 0) {
+                    (void)hipGetLastError();
+                    set_last_error("peer transport: the mapped region of rank " + std::to_string(q) + " cannot be read from this device");
+                    (void)hipIpcCloseMemHandle(p);
                     bad_open = 1.0;
                     continue;
                 }
