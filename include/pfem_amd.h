@@ -294,8 +294,8 @@ int pfem_assemble(pfem_solver *s, const double *elemData, const double *timeData
 int pfem_solver_set_preconditioner(pfem_solver *s, int pc);
 int pfem_solver_get_preconditioner(pfem_solver *s, int *pc_in_effect);
 /* -pc_gamg knobs: Chebyshev degree on the coarse levels (1..6, default 2) and on the assembled matrix itself (0 = the same;
- * default 1: there an SpMV is dearest), lmax/lmin of the smoothing interval (until set: 16, and 8 for 3-dof nodes), scaling of the coarse-grid
- * correction (the over-correction a piecewise-constant coarse space wants; until set: 1.5, and 1.8 for 3-dof nodes)   */
+ * default 1: there an SpMV is dearest), lmax/lmin of the smoothing interval (until set: 16, and 8 for 3-dof nodes WITHOUT rigid-body modes), scaling of the coarse-grid
+ * correction (the over-correction a piecewise-constant coarse space wants; until set: 1.5, and 1.8 for 3-dof nodes without rigid-body modes)   */
 int pfem_solver_set_amg_options(pfem_solver *s, int cheb_degree, int fine_degree, double eig_ratio, double coarse_scale);
 /* (eig_ratio <= 0 / coarse_scale <= 0: that knob stays automatic -- picked per kind of problem at the next symbolic phase) */
 /* KSPCGUseSingleReduction / -ksp_cg_single_reduction (PETSc option of the KSPCG the reference creates, solverpetsc.F:187;

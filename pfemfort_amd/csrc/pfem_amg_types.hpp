@@ -86,6 +86,8 @@ struct Amg {
     DevBuf<double> dense_inv;                        // inverse of the coarsest operator (n <= kAmgDense)
     bool dense = false;
     bool symbolic_ok = false;
+    bool galerkin_fresh = false;                     // the symbolic phase has just formed every coarse operator from the CURRENT values (it needs them level
+                                                     // by level): the numeric phase of the same solve does not form them again
     double symbolic_ms = 0.0, numeric_ms = 0.0;
     int cheb_degree = 2;
     int fine_degree = 1;                             // Chebyshev degree on level 0 (0: cheb_degree), the level where an SpMV is dearest:

@@ -138,14 +138,28 @@ namespace {
 // allocation that fails.  hipFree used to synchronise the device on the way: the pool does the same before it takes a block
 // back, so a block is never reused while a kernel of another stream may still touch it.
 struct DevPool {
-    struct Block { void *p; size_t bytes; int device; };
+    // Round 5: blocks are SPLIT.  On some boxes of this pool every hipMalloc costs what wiping its bytes costs (~30 GB/s: the
+    // symbolic phase of config 3 allocates ~1 GB in 61 calls and took 40 ms instead of 6, config 5's 275 instead of 28), while
+    // the pool sat on 6.7 GB of blocks freed by the pattern build that no request "fitted within a factor of two".  A request
+    // now takes the smallest free block that holds it and, when that block is more than fit() times larger, only its front --
+    // the rest stays in the pool as a block of its own.  A hipMalloc'd block that has been split is a ROOT; its pieces coalesce
+    // when they come back, and only a root that is whole again can go back to the driver (the price: a long-lived piece pins
+    // its root; the pieces around it stay usable by this process).
+    struct Block { char *p; size_t bytes; int device; int root; };       // a FREE block; root: index into roots, -1 = an unsplit hipMalloc'd block
+    struct Root { char *base; size_t bytes; int device; bool live; };
     std::vector<Block> blocks;
+    std::vector<Root> roots;
     size_t held = 0;
     std::recursive_mutex mu;          // solvers of one process may live on different host threads
-    static constexpr size_t kLargeBytes = 32ull << 20, kSmallKept = 1ull << 30;
-    static size_t fit()           // a block may be this many times the request (PFEM_POOL_FIT)
+    static constexpr size_t kLargeBytes = 32ull << 20, kSmallKept = 1ull << 30, kSplitAlign = 4096;
+    static size_t fit()           // a block may be this many times the request before it is split (PFEM_POOL_FIT)
     {
         static const size_t v = [] { const char *e = std::getenv("PFEM_POOL_FIT"); return e ? std::max<size_t>(1, static_cast<size_t>(std::atoll(e))) : 2; }();
+        return v;
+    }
+    static bool splitting()       // PFEM_POOL_SPLIT=0: round 4's pool (whole blocks within the fit factor only)
+    {
+        static const bool v = [] { const char *e = std::getenv("PFEM_POOL_SPLIT"); return e ? std::atoi(e) != 0 : true; }();
         return v;
     }
     static size_t min_bytes()
@@ -159,6 +173,19 @@ struct DevPool {
         const double gb = e ? std::atof(e) : 64.0;
         return gb > 0.0 ? static_cast<size_t>(gb * (1ull << 30)) : 0;
     }
+    int root_of(const char *q) const
+    {
+        for (size_t r = 0; r < roots.size(); ++r)
+            if (roots[r].live && q >= roots[r].base && q < roots[r].base + roots[r].bytes) return static_cast<int>(r);
+        return -1;
+    }
+    bool whole(const Block &b) const { return b.root < 0 || (b.p == roots[static_cast<size_t>(b.root)].base && b.bytes == roots[static_cast<size_t>(b.root)].bytes); }
+    void free_whole(const Block &b)          // hipFree of a block that is an unsplit allocation or a root that is whole again
+    {
+        (void)hipFree(b.p);
+        st_freed += b.bytes;
+        if (b.root >= 0) roots[static_cast<size_t>(b.root)].live = false;
+    }
     void *take(size_t bytes, size_t *got)
     {
         std::lock_guard<std::recursive_mutex> lock(mu);
@@ -166,65 +193,119 @@ struct DevPool {
         (void)hipGetDevice(&dev);
         size_t best = blocks.size();
         for (size_t i = 0; i < blocks.size(); ++i)
-            if (blocks[i].device == dev && blocks[i].bytes >= bytes && blocks[i].bytes <= fit() * bytes && (best == blocks.size() || blocks[i].bytes < blocks[best].bytes)) best = i;
+            if (blocks[i].device == dev && blocks[i].bytes >= bytes && (splitting() || blocks[i].bytes <= fit() * bytes) &&
+                (best == blocks.size() || blocks[i].bytes < blocks[best].bytes)) best = i;
         if (best == blocks.size()) return nullptr;
-        void *p = blocks[best].p;
-        *got = blocks[best].bytes;
-        held -= blocks[best].bytes;
-        st_reused += blocks[best].bytes;
+        Block b = blocks[best];
+        const size_t want = (bytes + kSplitAlign - 1) / kSplitAlign * kSplitAlign;
+        if (b.bytes > fit() * bytes && b.bytes >= want + min_bytes()) {
+            // the front of the block goes out, the rest stays; a block split for the first time becomes a root
+            if (b.root < 0) {
+                size_t slot = roots.size();
+                for (size_t r = 0; r < roots.size(); ++r)
+                    if (!roots[r].live) { slot = r; break; }
+                if (slot == roots.size()) roots.push_back(Root{});
+                roots[slot] = Root{b.p, b.bytes, b.device, true};
+                b.root = static_cast<int>(slot);
+            }
+            blocks[best] = Block{b.p + want, b.bytes - want, b.device, b.root};
+            held -= want;
+            st_reused += want;
+            *got = want;
+            return b.p;
+        }
+        *got = b.bytes;
+        held -= b.bytes;
+        st_reused += b.bytes;
         blocks.erase(blocks.begin() + static_cast<std::ptrdiff_t>(best));
-        return p;
+        return b.p;
     }
-    bool give(void *p, size_t bytes)
+    bool give(void *vp, size_t bytes)
     {
         std::lock_guard<std::recursive_mutex> lock(mu);
+        char *p = static_cast<char *>(vp);
+        const int root = root_of(p);
         const size_t cap = cap_bytes();
-        if (bytes < min_bytes() || bytes > cap) return false;
-        if (bytes >= kLargeBytes) {
-            // several processes may share the device (ranks of a test or of a development run), each with a pool of its own:
-            // when the device runs short, what this process holds idle goes back at once and the block is not kept
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < total_b / 4) {
-                trim(true);
-                return false;
+        if (root < 0) {           // an allocation of its own: kept if the pool wants it, else the caller frees it
+            if (bytes < min_bytes() || bytes > cap) return false;
+            if (bytes >= kLargeBytes) {
+                // several processes may share the device (ranks of a test or of a development run), each with a pool of its own:
+                // when the device runs short, what this process holds idle goes back at once and the block is not kept
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < total_b / 4) {
+                    trim(true);
+                    return false;
+                }
             }
         }
         (void)hipDeviceSynchronize();             // (what hipFree did on its way)
         int dev = 0;
         (void)hipGetDevice(&dev);
-        blocks.push_back({p, bytes, dev});
-        held += bytes;
+        Block nb{p, bytes, root >= 0 ? roots[static_cast<size_t>(root)].device : dev, root};
+        if (root >= 0) {          // a piece of a root: joins the free pieces next to it (it is never the caller's to free)
+            for (size_t i = 0; i < blocks.size();) {
+                Block &o = blocks[i];
+                if (o.root == root && (o.p + o.bytes == nb.p || nb.p + nb.bytes == o.p)) {
+                    nb.p = std::min(nb.p, o.p);
+                    nb.bytes += o.bytes;
+                    held -= o.bytes;
+                    blocks.erase(blocks.begin() + static_cast<std::ptrdiff_t>(i));
+                    i = 0;        // (the merged piece may now touch one seen before)
+                } else {
+                    ++i;
+                }
+            }
+        }
+        blocks.push_back(nb);
+        held += nb.bytes;
         st_peak_held = std::max(st_peak_held, held);
-        while (held > cap && !blocks.empty()) {       // oldest first
-            (void)hipFree(blocks.front().p);
-            st_freed += blocks.front().bytes;
-            held -= blocks.front().bytes;
-            blocks.erase(blocks.begin());
+        for (size_t i = 0; held > cap && i < blocks.size();) {       // over the cap: whole blocks go back, oldest first
+            if (whole(blocks[i])) {
+                held -= blocks[i].bytes;
+                free_whole(blocks[i]);
+                blocks.erase(blocks.begin() + static_cast<std::ptrdiff_t>(i));
+            } else {
+                ++i;
+            }
         }
         return true;
     }
     // PFEM_POOL_VERBOSE: bytes that went through hipMalloc / came out of the pool / went back through hipFree since the last trim
-    size_t st_malloc = 0, st_reused = 0, st_freed = 0, st_peak_held = 0;
-    void note(size_t mallocd, size_t freed)
+    size_t st_malloc = 0, st_reused = 0, st_freed = 0, st_peak_held = 0, st_malloc_calls = 0;
+    double st_malloc_ms = 0.0;          // host time inside hipMalloc since the last trim (PFEM_POOL_VERBOSE: where a slow set-up phase went)
+    void note(size_t mallocd, size_t freed, double ms = 0.0)
     {
         std::lock_guard<std::recursive_mutex> lock(mu);
         st_malloc += mallocd;
         st_freed += freed;
+        if (mallocd) { ++st_malloc_calls; st_malloc_ms += ms; }
     }
     void trim(bool all = true)
     {
         std::lock_guard<std::recursive_mutex> lock(mu);
         static const bool verbose = std::getenv("PFEM_POOL_VERBOSE") != nullptr;
-        if (verbose && (st_malloc || st_reused || st_freed || held))
-            std::fprintf(stderr, "  pool: hipMalloc %.2f GB, reused %.2f GB, hipFree %.2f GB (blocks of %zu KiB+), held at trim %.2f GB in %zu blocks (peak %.2f GB)\n",
-                         st_malloc / 1e9, st_reused / 1e9, st_freed / 1e9, min_bytes() >> 10, held / 1e9, blocks.size(), st_peak_held / 1e9);
-        st_malloc = st_reused = st_freed = st_peak_held = 0;
-        std::vector<Block> keep;
-        size_t kept = 0;
-        for (const Block &b : blocks) {
-            if (!all && b.bytes < kLargeBytes && kept + b.bytes <= kSmallKept) { keep.push_back(b); kept += b.bytes; }
-            else (void)hipFree(b.p);
+        if (verbose && (st_malloc || st_reused || st_freed || held)) {
+            size_t pinned = 0, nroots = 0;
+            for (const Root &r : roots)
+                if (r.live) { pinned += r.bytes; ++nroots; }
+            std::fprintf(stderr, "  pool: hipMalloc %.2f GB in %zu calls taking %.1f ms, reused %.2f GB, hipFree %.2f GB (blocks of %zu KiB+), held at trim %.2f GB in %zu blocks (peak %.2f GB), %zu split roots of %.2f GB\n",
+                         st_malloc / 1e9, st_malloc_calls, st_malloc_ms, st_reused / 1e9, st_freed / 1e9, min_bytes() >> 10, held / 1e9, blocks.size(), st_peak_held / 1e9,
+                         nroots, pinned / 1e9);
         }
+        st_malloc = st_reused = st_freed = st_peak_held = st_malloc_calls = 0;
+        st_malloc_ms = 0.0;
+        // whole blocks (unsplit allocations, roots that are whole again) go back: all of them, or the large ones; pieces of a root
+        // some buffer still holds a part of cannot -- they stay usable
+        std::vector<Block> keep;
+        size_t kept = 0, kept_small = 0;
+        for (const Block &b : blocks) {
+            const bool can_free = whole(b);
+            if (can_free && (all || b.bytes >= kLargeBytes || kept_small + b.bytes > kSmallKept)) { free_whole(b); continue; }
+            keep.push_back(b);
+            kept += b.bytes;
+            if (can_free) kept_small += b.bytes;
+        }
+        st_freed = 0;
         blocks.swap(keep);
         held = kept;
     }
@@ -269,6 +350,7 @@ struct DevBuf {
                 return PFEM_OK;
             }
         }
+        const auto t_malloc = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), bytes);
         if (e != hipSuccess && dev_pool().held > 0) {          // out of memory with blocks in the pool: hand them back and try again
             (void)hipGetLastError();
@@ -283,7 +365,8 @@ struct DevBuf {
         }
         n = count;
         held_bytes = bytes;
-        if (bytes >= DevPool::min_bytes()) dev_pool().note(bytes, 0);
+        if (bytes >= DevPool::min_bytes())
+            dev_pool().note(bytes, 0, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_malloc).count());
         poison();
         return PFEM_OK;
     }

@@ -234,7 +234,8 @@ class PetscSolver:
     def setAmgOptions(self, cheb_degree=2, fine_degree=1, eig_ratio=None, coarse_scale=None):
         """-pc_gamg knobs: Chebyshev degree on the coarse levels / on the assembled matrix (0: the same), lmax/lmin of the
         smoothing interval, scaling of the coarse-grid correction (``None``: that knob stays automatic -- 16 / 1.5 for scalar
-        problems, 8 / 1.5 with rigid-body modes, 8 / 1.8 for 3-dof nodes without them)."""
+        problems and for displacement problems with rigid-body modes, 8 / 1.8 for 3-dof nodes without them: what
+        amg_symbolic picks, pfem_amg.inc)."""
         L.check(L.lib().pfem_solver_set_amg_options(self._h, cheb_degree, fine_degree, -1.0 if eig_ratio is None else eig_ratio,
                                                     -1.0 if coarse_scale is None else coarse_scale), "pfem_solver_set_amg_options")
 
