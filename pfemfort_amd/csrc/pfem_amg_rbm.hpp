@@ -219,6 +219,91 @@ __global__ void __launch_bounds__(kBlock) k_rbm_lat_coarse_pos(int64_t na, int b
     pos_c[a] = bx | (by << 10) | (bz << 20);
 }
 
+// The coarse block pattern of a node-brick level without a sort (the analogue of k_lat_codes_*): the aggregates are the bricks of
+// a box, numbered bx + nbk0 (by + nbk1 bz), so the coarse column of a fine block is one of the 27 bricks around its row's brick.
+// One thread per coarse node walks its member nodes' block rows twice: counts per offset code (LDS, [code][thread]) -> the row's
+// coarse blocks and fine blocks; after two scans the keys of the coarse blocks (ascending code = ascending coarse column), the
+// start of every coarse block's list and the fine blocks themselves, member nodes ascending, blocks of a node row ascending --
+// the order the sorted form gives (stable sort of the block index by (coarse row, coarse column)).
+constexpr int kRbmCodes = 27;
+__device__ __forceinline__ int rbm_brick_code(int32_t I, int32_t J, int nbk0, int nbk1)
+{
+    const int ix = I % nbk0, iy = (I / nbk0) % nbk1, iz = I / (nbk0 * nbk1);
+    const int jx = J % nbk0, jy = (J / nbk0) % nbk1, jz = J / (nbk0 * nbk1);
+    const int dx = jx - ix, dy = jy - iy, dz = jz - iz;
+    if (dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1) return -1;
+    return (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1);
+}
+__global__ void __launch_bounds__(kBlock) k_rbm_codes_count(int64_t na, const int32_t *__restrict__ mem_ptr, const int32_t *__restrict__ mem_idx,
+                                                             const int64_t *__restrict__ gptr, const int32_t *__restrict__ gcol,
+                                                             const int32_t *__restrict__ node_agg, int nbk0, int nbk1, uint16_t *__restrict__ code_cnt,
+                                                             int32_t *__restrict__ n_entries, int32_t *__restrict__ n_pairs, int *__restrict__ fail)
+{
+    __shared__ uint16_t cnt[kRbmCodes][kBlock];
+    const int64_t I = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (I == na) { n_entries[na] = 0; n_pairs[na] = 0; }
+    if (I >= na) return;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int c = 0; c < kRbmCodes; ++c) cnt[c][t] = 0;
+    int pairs = 0;
+    for (int32_t m = mem_ptr[I]; m < mem_ptr[I + 1]; ++m) {
+        const int64_t i = mem_idx[m];
+        for (int64_t q = gptr[i]; q < gptr[i + 1]; ++q) {
+            const int c = rbm_brick_code(static_cast<int32_t>(I), node_agg[gcol[q]], nbk0, nbk1);
+            if (c < 0) { *fail = 1; continue; }           // a coupling beyond the neighbouring bricks: the sorted form takes the level
+            ++cnt[c][t];
+            ++pairs;
+        }
+    }
+    int entries = 0;
+#pragma unroll
+    for (int c = 0; c < kRbmCodes; ++c) {
+        const uint16_t v = cnt[c][t];
+        code_cnt[static_cast<int64_t>(c) * na + I] = v;
+        entries += v != 0;
+    }
+    n_entries[I] = entries;
+    n_pairs[I] = pairs;
+    if (pairs > 0xffff) *fail = 1;
+}
+__global__ void __launch_bounds__(kBlock) k_rbm_codes_fill(int64_t na, const int32_t *__restrict__ mem_ptr, const int32_t *__restrict__ mem_idx,
+                                                            const int64_t *__restrict__ gptr, const int32_t *__restrict__ gcol,
+                                                            const int32_t *__restrict__ node_agg, int nbk0, int nbk1,
+                                                            const uint16_t *__restrict__ code_cnt, const int32_t *__restrict__ entry_off,
+                                                            const int32_t *__restrict__ pair_off, uint64_t *__restrict__ ukeys,
+                                                            int64_t *__restrict__ src_ptr, int32_t *__restrict__ src_slot)
+{
+    __shared__ uint16_t at[kRbmCodes][kBlock];
+    const int64_t I = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (I >= na) return;
+    const int t = threadIdx.x;
+    const int ix = static_cast<int>(I % nbk0), iy = static_cast<int>((I / nbk0) % nbk1), iz = static_cast<int>(I / (static_cast<int64_t>(nbk0) * nbk1));
+    const int64_t p0 = pair_off[I];
+    int64_t e = entry_off[I];
+    int run = 0;
+#pragma unroll
+    for (int c = 0; c < kRbmCodes; ++c) {
+        const int v = code_cnt[static_cast<int64_t>(c) * na + I];
+        at[c][t] = static_cast<uint16_t>(run);
+        if (v != 0) {
+            const int32_t J = (ix + c % 3 - 1) + nbk0 * ((iy + (c / 3) % 3 - 1) + nbk1 * (iz + c / 9 - 1));
+            ukeys[e] = (static_cast<uint64_t>(I) << 32) | static_cast<uint32_t>(J);
+            src_ptr[e] = p0 + run;
+            ++e;
+        }
+        run += v;
+    }
+    if (I == na - 1) src_ptr[e] = p0 + run;
+    for (int32_t m = mem_ptr[I]; m < mem_ptr[I + 1]; ++m) {
+        const int64_t i = mem_idx[m];
+        for (int64_t q = gptr[i]; q < gptr[i + 1]; ++q) {
+            const int c = rbm_brick_code(static_cast<int32_t>(I), node_agg[gcol[q]], nbk0, nbk1);
+            src_slot[p0 + at[c][t]++] = static_cast<int32_t>(q);
+        }
+    }
+}
+
 // dof -> (node, component) of a level whose dofs come bs to the node
 __global__ void __launch_bounds__(kBlock) k_rbm_node_comp(int64_t n, int bs, int32_t *__restrict__ node_of, int32_t *__restrict__ comp_of)
 {
