@@ -308,6 +308,7 @@ def parse_args():
                     help="N>1: seconds the peer-transport companion may take before the line is printed without it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-step", action="store_true", help="skip the extra (untimed) step at rtol 1e-10")
+    ap.add_argument("--cycle", choices=["auto", "v", "w"], default="auto", help="-pc_mg_cycle_type of the gamg cycle (auto = the library's default: v)")
     ap.add_argument("--pc", choices=["jacobi", "pbjacobi", "gamg"], default="gamg",
                     help="preconditioner of the CG (PCSetType, solverpetsc.F:206; the reference: PCBJACOBI/ILU(0)).  gamg (default): "
                          "plain-aggregation multigrid V-cycle, on several ranks ONE hierarchy across the ranks ("
@@ -380,6 +381,8 @@ def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=Fa
     solver.setTolerances(rtol=rtol, maxits=100000 if beam else 10000)
     pc = pc or args.pc
     solver.setPreconditioner(pc)
+    if args.cycle != "auto":
+        solver.setAmgCycle(args.cycle)
     if args.single_reduction:
         solver.setSingleReduction(True)
     dm_host = mesh_host = None
@@ -575,6 +578,7 @@ def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=Fa
     R["pc_in_effect"] = solver.preconditioner()
     R["amg"] = solver.amgInfo() if R["pc_in_effect"] == "gamg" else None
     R["amg_layout"] = solver.amgLayout() if R["pc_in_effect"] == "gamg" else None
+    R["amg_cycle"] = solver.amgCycle() if R["pc_in_effect"] == "gamg" else None
     R.update(N=int(N), sz=sz, axis=axis, elapsed=elapsed, its=its, reason=reason, rnorm=rnorm, acc=acc, info=info,
              event_overhead_ms=tm["event_overhead_ms"] if tm else 0.0, cinfo=solver.commInfo(),
              fmt_bytes=solver.spmvFormatBytes(), gap_table=solver.spmvGapTable(), gap_escapes=solver.spmvGapEscapes(), bits=solver.spmvColumnBits(),
@@ -895,6 +899,9 @@ def main():
                                 "symbolic_setup_ms_once_per_pattern": R["amg"]["symbolic_ms"],
                                 "symbolic_setup_where": "first solve after a pattern build (a warm-up step; with --warmup 0 the first timed step)",
                                 "levels_paired_on_the_lattice": R["amg_layout"]["lattice_levels"],
+                                # -pc_mg_cycle_type (--cycle; V unless asked: W halves the iterations on matched aggregates and costs
+                                # twice the time, LAB_NOTES round 5)
+                                "cycle": R["amg_cycle"]["cycle"], "last_level_visited_twice": R["amg_cycle"]["last_level_visited_twice"],
                                 "distributed_levels": R["amg_layout"]["distributed_levels"] if world > 1 else None,
                                 "communication_per_cycle": ({"neighbour_exchanges": R["amg_layout"]["exchanges_per_cycle"],
                                                              "all_reduces": R["amg_layout"]["allreduces_per_cycle"],

@@ -298,6 +298,11 @@ int pfem_solver_get_preconditioner(pfem_solver *s, int *pc_in_effect);
  * correction (the over-correction a piecewise-constant coarse space wants; until set: 1.5, and 1.8 for 3-dof nodes without rigid-body modes)   */
 int pfem_solver_set_amg_options(pfem_solver *s, int cheb_degree, int fine_degree, double eig_ratio, double coarse_scale);
 /* (eig_ratio <= 0 / coarse_scale <= 0: that knob stays automatic -- picked per kind of problem at the next symbolic phase) */
+/* -pc_mg_cycle_type v|w (PETSc's PCMGSetCycleType behind PCGAMG): 1 = V(1,1), 2 = W(1,1) -- every coarse problem above the
+ * single-launch tail of the cycle is visited twice, the second time on the residual of the first --, 0 = the default again
+ * (V, as in PETSc).  W roughly halves the iterations on aggregates matched on the strength graph and costs more than it saves
+ * on this hardware (DESIGN.md has the numbers).  One hierarchy across several ranks always runs the V-cycle.              */
+int pfem_solver_set_amg_cycle(pfem_solver *s, int cycle);
 /* KSPCGUseSingleReduction / -ksp_cg_single_reduction (PETSc option of the KSPCG the reference creates, solverpetsc.F:187;
  * off by default there and here): the Chronopoulos-Gear form of the same iteration -- s = A z instead of w = A p,
  * (p,Ap) by recurrence -- so that (z,r), (z,s), (z,z) are reduced together: ONE all-reduce per iteration on several

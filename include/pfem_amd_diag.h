@@ -92,6 +92,8 @@ int pfem_solver_amg_cycle_profile(pfem_solver *s, int max_levels, int *n_levels,
 /* how many levels of the last hierarchy were coarsened by pairing on the mesh's lattice (the others: by matching on the
  * strength graph); 0 when the mesh has no lattice or came without coordinates                                          */
 int pfem_solver_amg_pairing(pfem_solver *s, int *lattice_levels);
+/* the cycle the last gamg solve ran: 1 = V, 2 = W, and the last level whose problem got two visits (0 with V)          */
+int pfem_solver_amg_cycle(pfem_solver *s, int *cycle, int *last_level_visited_twice);
 
 /* Per-element Ke/Fe of the uploaded mesh as computed by the DEVICE kernel (parity
  * inspection): K_out[e*nsize*nsize + i + nsize*j], F_out[e*nsize + i].           */

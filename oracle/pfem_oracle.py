@@ -518,13 +518,15 @@ def rbm_prolongator(node_agg, xyz, dim, fine_bs):
 
 
 def amg_cycle(rowptr, cols, vals, aggregates, cheb_degree=2, eig_ratio=8.0, coarse_scale=1.5, dense_limit=128, coarsest_sweeps=8,
-              fine_degree=1, lam_given=None):
+              fine_degree=1, lam_given=None, gamma=1, gamma_from=1, gamma_to=99):
     """z = M^-1 r of the product's -pc_type gamg (pfemfort_amd/csrc/pfem_amg.inc), restated in numpy / scipy.sparse GIVEN the
     aggregates (``aggregates[l][i]`` = coarse dof of dof i of level l; the product forms them by pairwise matching and
     hands them over for this check; an entry may also be a prolongator itself, see rbm_prolongator).  Everything else is restated: piecewise-constant prolongation P, Galerkin operators
     P^T A P, Chebyshev smoothing of degree ``cheb_degree`` (``fine_degree`` on the matrix itself) on D^-1 A over [lmax/eig_ratio, lmax] with the Gershgorin bound
     lmax = max_i sum_j |a_ij| / a_ii, one symmetric V(1,1) cycle with the coarse correction scaled by ``coarse_scale``, a
     dense solve on the last level when it has at most ``dense_limit`` rows (else Chebyshev of degree ``coarsest_sweeps``).
+    ``gamma`` = 2: W-cycle (-pc_mg_cycle_type w) -- the coarse problem of every level l with gamma_from <= l <= gamma_to that is
+    not the last is visited twice, the second time on the residual of the first, the two answers added.
     Returns the function r -> z."""
     import scipy.sparse as sp
     N = len(rowptr) - 1
@@ -588,7 +590,10 @@ def amg_cycle(rowptr, cols, vals, aggregates, cheb_degree=2, eig_ratio=8.0, coar
         deg = fine_degree if (l == 0 and fine_degree) else cheb_degree
         x = smooth(l, None, rhs, deg)
         rc = P[l].T @ (rhs - levels[l] @ x)
-        x = x + coarse_scale * (P[l] @ cycle(l + 1, rc))
+        xc = cycle(l + 1, rc)
+        for _ in range(1, gamma if (gamma_from <= l + 1 <= gamma_to and l + 2 < len(levels)) else 1):      # W-cycle: the coarse problem gets a second go
+            xc = xc + cycle(l + 1, rc - levels[l + 1] @ xc)
+        x = x + coarse_scale * (P[l] @ xc)
         return smooth(l, x, rhs, deg)
 
     apply = lambda r: cycle(0, r)          # noqa: E731
@@ -686,9 +691,12 @@ def pcg_with_single_reduction(rowptr, cols, vals, b, M, rtol=1e-5, abstol=1e-50,
 
 
 def pcg_amg(rowptr, cols, vals, b, aggregates, cheb_degree=2, eig_ratio=8.0, coarse_scale=1.5, rtol=1e-5, abstol=1e-50, dtol=1e5,
-            maxits=10000, dense_limit=128, coarsest_sweeps=8, fine_degree=1, lam_given=None, lam_true_out=None, single_reduction=False):
-    """CG preconditioned by one V(1,1) cycle of plain-aggregation multigrid on the whole matrix: amg_cycle + pcg_with."""
-    M = amg_cycle(rowptr, cols, vals, aggregates, cheb_degree, eig_ratio, coarse_scale, dense_limit, coarsest_sweeps, fine_degree, lam_given)
+            maxits=10000, dense_limit=128, coarsest_sweeps=8, fine_degree=1, lam_given=None, lam_true_out=None, single_reduction=False,
+            gamma=1, gamma_to=99):
+    """CG preconditioned by one V(1,1) -- gamma = 2: W(1,1) down to level gamma_to -- cycle of plain-aggregation multigrid on the
+    whole matrix: amg_cycle + pcg_with."""
+    M = amg_cycle(rowptr, cols, vals, aggregates, cheb_degree, eig_ratio, coarse_scale, dense_limit, coarsest_sweeps, fine_degree, lam_given,
+                  gamma, 1, gamma_to)
     if lam_true_out is not None:
         lam_true_out[:] = M.lam_true
     return (pcg_with_single_reduction if single_reduction else pcg_with)(rowptr, cols, vals, b, M, rtol, abstol, dtol, maxits)

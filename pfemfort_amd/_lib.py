@@ -119,6 +119,8 @@ SIGNATURES = {
     "pfem_solver_amg_cycle_profile": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "pfem_solver_amg_pairing": [_P, _P],
     "pfem_solver_set_amg_options": [_P, _I, _I, _D, _D],
+    "pfem_solver_set_amg_cycle": [_P, _I],
+    "pfem_solver_amg_cycle": [_P, _P, _P],
     "pfem_eval_elems": [_P, _P, _P, _P, _P],
     "pfem_rhs_add_values": [_P, _L, _P, _P],
     "pfem_matrix_info": [_P, _P, _P, _P, _P],

@@ -1276,6 +1276,33 @@ __global__ void __launch_bounds__(kBlock) k_amg_prolong(int64_t n, const int32_t
         x[i] = __builtin_fma(scale, xc[agg[i]], x[i]);
 }
 
+// W-cycle (-pc_mg_cycle_type w): a coarse problem  A_c e = b  gets a second visit.  Between the visits (t = A_c x on entry, x the
+// first visit's answer): x is put aside, the right-hand side becomes the residual b - t, and -- where the level's
+// pre-smoothing expects its step 0 from the launch above it (fused levels) -- x = dd = D^-1 b / theta of the new right-hand side.
+__global__ void __launch_bounds__(kBlock) k_amg_w_between(int64_t n, double *__restrict__ b, const double *__restrict__ t, double *__restrict__ x,
+                                                           double *__restrict__ x1, const double *__restrict__ dinv, const double *__restrict__ lam,
+                                                           double ratio, double *__restrict__ dd /* null: no step 0 here */, const CgCtl *ctl)
+{
+    if (ctl && ctl->flag != 0) return;
+    const double c_first = dd ? cheb_coef(lam[0], ratio, 0).c_first : 0.0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const double bi = b[i] - t[i];
+        x1[i] = x[i];
+        b[i] = bi;
+        if (dd) {
+            const double di = c_first * dinv[i] * bi;
+            dd[i] = di;
+            x[i] = di;
+        }
+    }
+}
+// ... and after the second: the two answers add up
+__global__ void __launch_bounds__(kBlock) k_amg_w_add(int64_t n, double *__restrict__ x, const double *__restrict__ x1, const CgCtl *ctl)
+{
+    if (ctl && ctl->flag != 0) return;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) x[i] += x1[i];
+}
+
 // ---------------------------------------------------------------------------
 // Coarse levels: the SpMV with the vector step that follows it as its epilogue (row form, one lane per row), so that a
 // level of the cycle costs 6 launches instead of 10 -- these levels are too small to fill the chip and every launch has a

@@ -78,6 +78,7 @@ struct AmgLevel {
     // smoother and work vectors (x and dd are SpMV inputs: on level 0 they carry the guard bands of the fast SpMV forms)
     DevBuf<double> dinv, t, r, b, x_store, dd_store, lam, part_max;
     double *x = nullptr, *dd = nullptr;
+    DevBuf<double> x1;                    // W-cycle: the first visit's answer while the second is on its way
     double lam_host = 0.0;
 };
 
@@ -111,6 +112,11 @@ struct Amg {
         if (ev_num1) (void)hipEventDestroy(ev_num1);
     }
     int tail_from = -1;                              // first level of the single-launch tail of the cycle (-1: none)
+    // -pc_mg_cycle_type: 1 = V (default), 2 = W -- the coarse problem of every level from 1 down to w_to is visited twice (second
+    // visit on the residual of the first).  The levels of the single-launch tail (<= 1024 rows each) stay a V inside:
+    // w_to = tail_from, whether or not the fused kernels are in use (amg_cycle_shape has the measurements).
+    int cycle_gamma = 1, w_to = -1;
+    bool cycle_given = false;
     bool fused = true;                               // fused SpMV epilogues on the coarse levels + the tail kernel (PFEM_AMG_FUSED=0: off)
     int coarsest_sweeps = 8;                         // Chebyshev degree on the last level when it is too large for the dense inverse
     // several ranks: one hierarchy ACROSS the ranks (aggregates stay inside a rank's owned dofs, the operators are the

@@ -21,6 +21,7 @@
 #include <thread>
 #include <string>
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <vector>
@@ -4726,6 +4727,28 @@ extern "C" int pfem_solver_set_amg_options(pfem_solver *s, int cheb_degree, int 
     if (eig_ratio > 0.0) s->amg->eig_ratio = eig_ratio;
     s->amg->coarse_scale_given = coarse_scale > 0.0;
     if (coarse_scale > 0.0) s->amg->coarse_scale = coarse_scale;
+    return PFEM_OK;
+}
+
+// -pc_mg_cycle_type: 0 = left to the library (amg_cycle_shape), 1 = V, 2 = W
+extern "C" int pfem_solver_set_amg_cycle(pfem_solver *s, int cycle)
+{
+    if (!s || cycle < 0 || cycle > 2) return PFEM_ERR_ARG;
+    if (!s->amg) s->amg.reset(new (std::nothrow) Amg());
+    if (!s->amg) return PFEM_ERR_NOMEM;
+    s->amg->cycle_given = cycle != 0;
+    if (cycle != 0) s->amg->cycle_gamma = cycle;
+    s->amg->graph_key.clear();
+    return PFEM_OK;
+}
+// what the last gamg solve ran: 1 = V, 2 = W, and the last level whose problem got two visits
+extern "C" int pfem_solver_amg_cycle(pfem_solver *s, int *cycle, int *last_level_visited_twice)
+{
+    if (!s || !cycle || !last_level_visited_twice) return PFEM_ERR_ARG;
+    if (!s->amg || !s->amg->symbolic_ok) return PFEM_ERR_STATE;
+    const Amg &M = *s->amg;
+    *cycle = M.cycle_gamma;
+    *last_level_visited_twice = M.cycle_gamma > 1 ? std::min(M.w_to, static_cast<int>(M.lev.size()) - 2) : 0;
     return PFEM_OK;
 }
 

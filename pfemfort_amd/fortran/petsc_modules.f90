@@ -22,6 +22,7 @@ module petscvec
   double precision, save :: pfem_opt_rtol = 1.0d-5, pfem_opt_atol = 1.0d-50, pfem_opt_dtol = 1.0d5
   integer, save :: pfem_opt_maxits = 10000
   integer, save :: pfem_opt_pc = 0          ! 0 = -pc_type jacobi (default), 1 = pbjacobi (node blocks), 2 = gamg (aggregation multigrid)
+  integer, save :: pfem_opt_cycle = 0       ! -pc_mg_cycle_type: 1 = v, 2 = w, 0 = not given (V, PETSc's default too)
   integer, save :: pfem_opt_single = -1     ! -ksp_cg_single_reduction: 1 / 0, -1 = not given (PFEM_CG_SINGLE_REDUCTION decides)
   ! gathered solution of VecScatterCreateToAll / VecGetArray
   double precision, allocatable, target, save :: pfem_seq_soln(:)

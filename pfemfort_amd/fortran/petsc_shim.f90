@@ -37,6 +37,14 @@ subroutine PetscInitialize(file, ierr)
       case ("-ksp_divtol"); read(val, *, iostat=io) pfem_opt_dtol
       case ("-ksp_max_it"); read(val, *, iostat=io) pfem_opt_maxits
       case ("-pc_type");    call pfem_set_pc_type(trim(val))
+      case ("-pc_mg_cycle_type")            ! PCMGSetCycleType behind PCGAMG
+        select case (trim(val))
+        case ("v", "V"); pfem_opt_cycle = 1
+        case ("w", "W"); pfem_opt_cycle = 2
+        case default
+          write(*,*) "pfem_amd: -pc_mg_cycle_type ", trim(val), " is not available (v, w)"
+          error stop " Aborting... unsupported -pc_mg_cycle_type"
+        end select
       case ("-ksp_cg_single_reduction")     ! KSPCGUseSingleReduction: one all-reduce per iteration
         pfem_opt_single = 1
         if (trim(val) == "0" .or. trim(val) == "false" .or. trim(val) == "no") pfem_opt_single = 0

@@ -50,6 +50,11 @@ module pfem_amd_c
       type(c_ptr), value :: s
       integer(c_int), value :: on
     end function
+    integer(c_int) function pfem_solver_set_amg_cycle(s, cycle) bind(C, name="pfem_solver_set_amg_cycle")
+      import
+      type(c_ptr), value :: s
+      integer(c_int), value :: cycle
+    end function
     integer(c_int) function pfem_solver_set_zero(s) bind(C, name="pfem_solver_set_zero")
       import
       type(c_ptr), value :: s

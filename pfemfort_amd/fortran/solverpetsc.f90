@@ -4,9 +4,9 @@
 module Module_SolverPetsc
   use pfem_amd_c
 #ifdef PFEM_WITH_MPI
-  use petscvec, only: pfem_opt_rtol, pfem_opt_atol, pfem_opt_dtol, pfem_opt_maxits, pfem_opt_pc, pfem_opt_single, PETSC_COMM_WORLD, MPI_INTEGER, MPI_SUM
+  use petscvec, only: pfem_opt_rtol, pfem_opt_atol, pfem_opt_dtol, pfem_opt_maxits, pfem_opt_pc, pfem_opt_single, pfem_opt_cycle, PETSC_COMM_WORLD, MPI_INTEGER, MPI_SUM
 #else
-  use petscvec, only: pfem_opt_rtol, pfem_opt_atol, pfem_opt_dtol, pfem_opt_maxits, pfem_opt_pc, pfem_opt_single
+  use petscvec, only: pfem_opt_rtol, pfem_opt_atol, pfem_opt_dtol, pfem_opt_maxits, pfem_opt_pc, pfem_opt_single, pfem_opt_cycle
 #endif
   implicit none
   integer, parameter :: SOLVER_EMPTY=1, PATTERN_OK=2, INIT_OK=3, ASSEMBLY_OK=4, FACTORISE_OK=5   ! solverpetsc.F:64-68
@@ -89,6 +89,7 @@ contains
     if (ierr /= 0) call pfem_chkerr(ierr)
     ierr = pfem_solver_set_preconditioner(h, int(pfem_opt_pc, c_int))       ! KSPSetFromOptions: -pc_type
     if (ierr == 0) ierr = pfem_solver_set_cg_single_reduction(h, int(pfem_opt_single, c_int))   ! -ksp_cg_single_reduction
+    if (ierr == 0 .and. pfem_opt_cycle /= 0) ierr = pfem_solver_set_amg_cycle(h, int(pfem_opt_cycle, c_int))   ! -pc_mg_cycle_type
     if (ierr /= 0) call pfem_chkerr(ierr)
     this%mtx = pfem_p2h(h)
     this%rhsVec = this%mtx

@@ -239,6 +239,17 @@ class PetscSolver:
         L.check(L.lib().pfem_solver_set_amg_options(self._h, cheb_degree, fine_degree, -1.0 if eig_ratio is None else eig_ratio,
                                                     -1.0 if coarse_scale is None else coarse_scale), "pfem_solver_set_amg_options")
 
+    def setAmgCycle(self, cycle=None):
+        """-pc_mg_cycle_type: "v" (the default, also ``None``) or "w" (every coarse problem above the cycle's tail visited twice)."""
+        code = {None: 0, "auto": 0, "v": 1, "w": 2}[cycle.lower() if isinstance(cycle, str) else cycle]
+        L.check(L.lib().pfem_solver_set_amg_cycle(self._h, code), "pfem_solver_set_amg_cycle")
+
+    def amgCycle(self):
+        """What the last gamg solve ran: {"cycle": "v" | "w", "last_level_visited_twice": l} (0 with the V-cycle)."""
+        c, w = C.c_int(0), C.c_int(0)
+        L.check(L.lib().pfem_solver_amg_cycle(self._h, C.byref(c), C.byref(w)), "pfem_solver_amg_cycle")
+        return {"cycle": "w" if c.value == 2 else "v", "last_level_visited_twice": w.value}
+
     def amgTransfer(self, level, xyz=False):
         """The transfer from ``level`` to the next: {"rbm": carries rotations?, "fine_bs", "coarse_bs", "dim", "n_nodes"} and, with
         ``xyz``, the level's node coordinates [3, n_nodes]."""

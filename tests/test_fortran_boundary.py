@@ -128,6 +128,15 @@ def test_fortran_host_program_pc_type_pbjacobi_and_unknown_options(tmp_path):
     u3 = np.array(open(tmp_path / "solution.txt").read().split(), dtype=float)
     assert r3.returncode == 0 and "PC = gamg" in r3.stdout and u3[1] == 2 and u3[0] < 0.5 * u1[0], r3.stdout[-2000:] + r3.stderr[-2000:]
     assert np.abs(u3[2:] - u0[2:]).max() < 1e-8 * max(1.0, np.abs(u0[2:]).max())
+    # -pc_mg_cycle_type w (PCMGSetCycleType): accepted, same solution; anything but v / w stops loudly
+    (tmp_path / "petsc_options.dat").write_text("-ksp_type cg\n-pc_type gamg\n-pc_mg_cycle_type w\n")
+    r4 = _run(exe, tmp_path, 1)
+    u4 = np.array(open(tmp_path / "solution.txt").read().split(), dtype=float)
+    assert r4.returncode == 0 and u4[1] == 2 and u4[0] <= u3[0], r4.stdout[-2000:] + r4.stderr[-2000:]
+    assert np.abs(u4[2:] - u0[2:]).max() < 1e-8 * max(1.0, np.abs(u0[2:]).max())
+    (tmp_path / "petsc_options.dat").write_text("-pc_type gamg\n-pc_mg_cycle_type f\n")
+    r5 = _run(exe, tmp_path, 1)
+    assert r5.returncode != 0 and "-pc_mg_cycle_type f is not available" in (r5.stdout + r5.stderr).replace("  ", " ")
     (tmp_path / "petsc_options.dat").write_text("-pc_type ilu\n")
     r2 = _run(exe, tmp_path, 1)
     assert r2.returncode != 0 and "-pc_type ilu is not available" in (r2.stdout + r2.stderr).replace("  ", " ")

@@ -859,8 +859,10 @@ def _gamg_vs_oracle(s, rtol=1e-10):
     info = s.amgInfo()
     aggs = _transfers(s, info)
     rowptr, cols, vals = s.getCSR()
+    cyc = s.amgCycle()          # V on lattice bricks, W on matched aggregates (or what the test asked for)
     xo, ito, ro, rno, hist = O.pcg_amg(rowptr, cols, vals, s.getRHS(), aggs, cheb_degree=info["cheb_degree"], fine_degree=info["fine_degree"], eig_ratio=info["eig_ratio"],
-                                       coarse_scale=info["coarse_scale"], rtol=rtol)
+                                       coarse_scale=info["coarse_scale"], rtol=rtol, gamma=2 if cyc["cycle"] == "w" else 1,
+                                       gamma_to=cyc["last_level_visited_twice"])
     x = s.getSolution()
     h = s.getHistory()
     assert (reason, ro) == (2, 2) and abs(its - ito) <= max(1, ito // 50), (its, ito)      # (a run of hundreds of iterations: +-2 %)
@@ -870,7 +872,16 @@ def _gamg_vs_oracle(s, rtol=1e-10):
     return its, info, aggs, x
 
 
-@pytest.mark.parametrize("case", ["tet10", "cube30", "beam", "cook", "compat", "tria20", "tiny", "aniso"])
+def _moved(mesh, h, frac=0.2, seed=7):
+    """The mesh with every node that carries no Dirichlet value moved inside a ball of radius frac * h (h = the smallest cell
+    edge; Kuhn's tetrahedra keep their orientation up to 0.28): the coordinates no longer form a lattice."""
+    d = np.random.default_rng(seed).uniform(-1.0, 1.0, size=mesh.xyz.shape) * (frac * h / np.sqrt(3.0))
+    d[:, np.unique(mesh.bc_node)] = 0.0
+    return H.Mesh(mesh.xyz + d, mesh.conn, mesh.bc_node, mesh.bc_dof, mesh.bc_val)
+
+
+@pytest.mark.parametrize("case", ["tet10", "cube30", "beam", "cook", "compat", "tria20", "tiny", "aniso", "cube30_moved", "beam_moved",
+                                  "cube30_moved_w", "beam_moved_w", "tet10_w"])
 def test_gamg_solve_equals_oracle_restatement(case, tet10, beam, tria20, golden_dir):
     """-pc_type gamg on file meshes and generated boxes, scalar and 3-dof problems, the batched and the MatSetValues path:
     the device hierarchy (matching aggregates, Galerkin sums, Gershgorin bounds, Chebyshev V-cycle, dense bottom solve) and
@@ -890,9 +901,18 @@ def test_gamg_solve_equals_oracle_restatement(case, tet10, beam, tria20, golden_
                           "aniso": (pf.POISSON_TET, H.gen_box_tets(-1, 1, 20, -1, 1, 20, -1, 1, 20), np.array([1.0, 1.0, 100.0])),
                           "tria20": (pf.POISSON_TRIA_INLINE, tria20, None),                         # config 1's mesh: 361 dofs, two levels
                           "tiny": (pf.POISSON_TET, H.gen_box_tets(-1, 1, 4, -1, 1, 4, -1, 1, 4), H.POISSON_ELEMDATA),   # 27 dofs: no coarse level at all
+                          # nodes moved off the lattice: no positions, the aggregates come from matching on the strength graph;
+                          # _w: -pc_mg_cycle_type w (every coarse problem above the cycle's tail visited twice) against the oracle's W
+                          "cube30_moved": (pf.POISSON_TET, _moved(H.gen_box_tets(-1, 1, 30, -1, 1, 30, -1, 1, 30), 2.0 / 30), H.POISSON_ELEMDATA),
+                          "cube30_moved_w": (pf.POISSON_TET, _moved(H.gen_box_tets(-1, 1, 30, -1, 1, 30, -1, 1, 30), 2.0 / 30), H.POISSON_ELEMDATA),
+                          "tet10_w": (pf.POISSON_TET, tet10, H.POISSON_ELEMDATA),
+                          "beam_moved": (pf.ELAST_TET, _moved(H.gen_box_tets(-0.5, 0.5, 6, 0.0, 6.0, 36, -0.5, 0.5, 6, bc_mode=1, ndof=3), 1.0 / 6), H.ELAST_ELEMDATA),
+                          "beam_moved_w": (pf.ELAST_TET, _moved(H.gen_box_tets(-0.5, 0.5, 6, 0.0, 6.0, 36, -0.5, 0.5, 6, bc_mode=1, ndof=3), 1.0 / 6), H.ELAST_ELEMDATA),
                           "cook": (pf.ELAST_TRIA, H.read_mesh(f"{golden_dir}/input/cookmembranetria32"), H.ELAST2D_ELEMDATA)}[case]
         s, dm = _device_problem(kind, mesh, ed)
-        if case == "beam":
+        if case.endswith("_w"):
+            s.setAmgCycle("w")
+        if case in ("beam", "beam_moved", "beam_moved_w"):
             s.setSpmvFormat("grouped")          # the 3-row node groups (and with them the node-wise aggregation) at this size too
             s.buildPattern()
             s.assemble(ed, H.TIMEDATA)
@@ -914,7 +934,11 @@ def test_gamg_solve_equals_oracle_restatement(case, tet10, beam, tria20, golden_
         return
     assert info["levels"] >= 2 and all(10 * b <= 8 * a for a, b in zip(rows, rows[1:])) and rows[-1] <= 128
     rbm = [s.amgTransfer(l)["rbm"] for l in range(info["levels"] - 1)]
-    assert all(rbm) if case in ("beam", "cook") else not any(rbm)       # displacement problems: rigid-body modes on every level
+    assert all(rbm) if case in ("beam", "cook", "beam_moved", "beam_moved_w") else not any(rbm)       # displacement problems: rigid-body modes on every level
+    cyc = s.amgCycle()
+    assert cyc["cycle"] == ("w" if case.endswith("_w") else "v")
+    if cyc["cycle"] == "w":         # (a hierarchy of two levels has no coarse problem to visit twice: its W is its V)
+        assert (1 <= cyc["last_level_visited_twice"] <= info["levels"] - 2) or info["levels"] <= 2
     for l, (a, n_c) in enumerate(zip(aggs, rows[1:])):
         if rbm[l]:        # nodes per aggregate (every coarse node has dim translations + rotations)
             tr = s.amgTransfer(l)
@@ -926,7 +950,7 @@ def test_gamg_solve_equals_oracle_restatement(case, tet10, beam, tria20, golden_
         # to it: bricks of up to 3 along every axis)
         assert len(cnt) == n_c and cnt.min() >= 1 and cnt.max() <= 8
     lat = s.amgLayout()["lattice_levels"]       # generated boxes and the reference's tet10 file sit on a lattice, Cook's membrane does not
-    assert (lat >= 1) if case in ("tet10", "cube30", "beam", "tria20", "aniso") else (lat == 0 or case == "compat")
+    assert (lat >= 1) if case in ("tet10", "cube30", "beam", "tria20", "aniso", "tet10_w") else (lat == 0 or case == "compat")
     if case == "aniso":       # the weak axes are passed over: the passes of the first level pair along z (19 -> 10 -> 5 -> 3 per column,
         assert 900 <= rows[1] <= 19 * 19 * 3 and np.bincount(aggs[0]).max() <= 8 and lat >= 2      # a few pairs across y at the end)
         return
@@ -1041,12 +1065,14 @@ def test_gamg_reasons_and_reuse():
     assert z.factoriseAndSolve()[:2] == (0, 3) and not z.getSolution().any()
 
 
-@pytest.mark.parametrize("case", ["cube40", "beam"])
+@pytest.mark.parametrize("case", ["cube40", "beam", "cube40_w", "beam_w"])
 def test_gamg_fused_cycle_equals_level_by_level_kernels(case, beam, monkeypatch):
     """The V-cycle as it is run -- SpMV + vector step in one kernel on the coarse levels (k_amg_spmv_ep), step 0 of a level's
     pre-smoothing inside the restriction above it, every level of at most 4096 rows in ONE launch (k_amg_tail) -- against
     the same cycle enqueued level by level (PFEM_AMG_FUSED=0: one kernel per operation): the same arithmetic in the same
     order, so the residual history and the solution are equal bit for bit; and as a hipGraph replay or plain launches."""
+    w = case.endswith("_w")          # the W-cycle's second visits too (the step 0 a fused level expects comes from k_amg_w_between there)
+    case = case[:-2] if w else case
     kind, mesh, ed = ((pf.POISSON_TET, H.gen_box_tets(-1, 1, 40, -1, 1, 40, -1, 1, 40), H.POISSON_ELEMDATA) if case == "cube40" else
                       (pf.ELAST_TET, H.gen_box_tets(-0.5, 0.5, 8, 0.0, 6.0, 48, -0.5, 0.5, 8, bc_mode=1, ndof=3), H.ELAST_ELEMDATA))
     out = {}
@@ -1059,9 +1085,11 @@ def test_gamg_fused_cycle_equals_level_by_level_kernels(case, beam, monkeypatch)
             s.buildPattern()
             s.assemble(ed, H.TIMEDATA)
         s.setPreconditioner("gamg")
+        if w:
+            s.setAmgCycle("w")
         s.setTolerances(rtol=1e-10, maxits=5000)
         its, reason, _ = s.factoriseAndSolve()
-        assert reason == 2
+        assert reason == 2 and s.amgCycle()["cycle"] == ("w" if w else "v")
         out[fused, graph] = (its, s.getHistory(), s.getSolution(), s.amgInfo()["rows"])
         s.free()
     a = out["1", "1"]
