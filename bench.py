@@ -45,7 +45,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def pmc_traffic(nnz):
+def pmc_traffic(nnz, value_dict=False):
     """HBM bytes per launch of the CG SpMV from the committed rocprofv3 PMC passes
     (profiles/spmv_pmc_traffic.json, written by tools/gpu_round.sh on the SAME workload in a
     builder lease, not in this run): (2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH_SIZE doubled per
@@ -54,7 +54,7 @@ def pmc_traffic(nnz):
     try:
         doc = json.load(open(path))
         for d in doc.get("entries", [doc]):          # one entry per workload (keyed by the matrix's nnz)
-            if d.get("nnz") == nnz:
+            if d.get("nnz") == nnz and bool(d.get("value_dictionary", False)) == bool(value_dict):      # (the dictionary form is another kernel)
                 return (2.0 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024.0, \
                     "profiles/spmv_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, " \
                     f"{d.get('source', 'builder lease')}); replayed, NOT measured in this run"
@@ -63,13 +63,13 @@ def pmc_traffic(nnz):
     return None, None
 
 
-def kernel_trace_figures(nnz):
+def kernel_trace_figures(nnz, value_dict=False):
     """rocprofv3 --kernel-trace averages of the CG SpMV committed next to the PMC figures (same file, same caveat: a
     builder lease, replayed here for comparison with this run's event pairs), or None."""
     try:
         doc = json.load(open(os.path.join(ROOT, "profiles", "spmv_pmc_traffic.json")))
         for d in doc.get("entries", [doc]):
-            if d.get("nnz") == nnz:
+            if d.get("nnz") == nnz and bool(d.get("value_dictionary", False)) == bool(value_dict):
                 return d.get("kernel_trace_avg_us")
     except (OSError, ValueError, KeyError):
         pass
@@ -581,7 +581,7 @@ def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=Fa
     R["amg_cycle"] = solver.amgCycle() if R["pc_in_effect"] == "gamg" else None
     R.update(N=int(N), sz=sz, axis=axis, elapsed=elapsed, its=its, reason=reason, rnorm=rnorm, acc=acc, info=info,
              event_overhead_ms=tm["event_overhead_ms"] if tm else 0.0, cinfo=solver.commInfo(),
-             fmt_bytes=solver.spmvFormatBytes(), gap_table=solver.spmvGapTable(), gap_escapes=solver.spmvGapEscapes(), bits=solver.spmvColumnBits(),
+             fmt_bytes=solver.spmvFormatBytes(), value_dict=solver.spmvValueDictionary(), gap_table=solver.spmvGapTable(), gap_escapes=solver.spmvGapEscapes(), bits=solver.spmvColumnBits(),
              row_group=solver.spmvRowGroup(), final=solver.commDescribe() if world > 1 else None,
              ms_per_step=elapsed / steps * 1e3, ms_per_iteration=acc["sol_ms"] / steps / max(its, 1))
     R.pop("xyz_free", None)
@@ -811,18 +811,22 @@ def main():
         raw_spmv_ms = acc["spmv_ms"] / max(acc["spmv_n"], 1)
         avg_spmv_ms = max(raw_spmv_ms, 1e-9)
         achieved = bytes_per_spmv / (avg_spmv_ms * 1e-3) / 1e9 if acc["spmv_n"] else 0.0
-        traffic, traffic_source = pmc_traffic(info["nnz"]) if (world == 1 and args.numbering == "lattice" and args.jitter <= 0.0) else (None, None)
+        traffic, traffic_source = pmc_traffic(info["nnz"], R["value_dict"]) if (world == 1 and args.numbering == "lattice" and args.jitter <= 0.0) else (None, None)
         hbm_bytes = traffic if traffic else fmt_bytes
         # names as rocprofv3 prints them: k_spmvr / k_spmvg / k_spmv16 <WITH_DOT, gap table>, k_spmvr32 / k_spmv <WITH_DOT>
         tbl = R["gap_table"]
         tname = "true" if tbl else "false"
         tnote = f" with a table of the {tbl} distinct gaps beyond 32767" if tbl else ""
         bits = R["bits"]
-        kernel = {3: f"pfem::k_spmvg<true, {tname}> (row-grouped wave-sliced CSR SpMV + (p,Ap) partials: the 3 dof rows of a "
-                     f"node share one lane, 16-bit column gaps{tnote}), rank 0",
-                  4: ("pfem::k_spmvr32<true>" if bits == 32 else f"pfem::k_spmvr<true, {tname}>") +
+        vdn = R["value_dict"]           # pfem_valdict.hpp: the values as 16-bit codes into a dictionary of the distinct ones (0: fp64 copy)
+        vd = "_vd" if vdn else ""
+        vnote = (f"; matrix values streamed as 16-bit codes into a dictionary of the {vdn} DISTINCT values of this matrix held in LDS "
+                 "(lossless: the same doubles, the same products, the same bits)") if vdn else ""
+        kernel = {3: f"pfem::k_spmvg{vd}<true, {tname}> (row-grouped wave-sliced CSR SpMV + (p,Ap) partials: the 3 dof rows of a "
+                     f"node share one lane, 16-bit column gaps{tnote}{vnote}), rank 0",
+                  4: ("pfem::k_spmvr32<true>" if bits == 32 else f"pfem::k_spmvr{vd}<true, {tname}>") +
                      " (wave-sliced CSR SpMV + (p,Ap) partials; 4 consecutive rows per lane share one relative column stream of "
-                     f"{bits}-bit gaps{tnote}, x read as 32-B quads), rank 0"}.get(
+                     f"{bits}-bit gaps{tnote}, x read as 32-B quads{vnote}), rank 0"}.get(
             R["row_group"],
             ("pfem::k_spmv16e<true>" if (bits == 16 and R.get("gap_escapes")) else f"pfem::k_spmv16<true, {tname}>" if bits == 16 else "pfem::k_spmv<true>") +
             " (wave-sliced CSR SpMV + (p,Ap) partials; %d-bit column %s%s), rank 0"
@@ -933,6 +937,9 @@ def main():
                          # EFFECTIVE rate: the kernel's compressed form moves fewer bytes (hbm_gbps below)
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "effective": True,
+                         # with the value dictionary the kernel moves 2 B a slot instead of 8: the plain-CSR bytes it REPLACES per second
+                         # can exceed the HBM peak (frac > 1); what it really moves per second is hbm_gbps / hbm_frac below
+                         "value_dictionary_entries": vdn,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "format_bytes_per_launch": fmt_bytes,
                          "hbm_gbps": hbm_bytes / (avg_spmv_ms * 1e-3) / 1e9 if acc["spmv_n"] else 0.0,
@@ -948,7 +955,7 @@ def main():
                          # trace: under the tracer dispatches run one at a time, on the plain stream the kernel's first waves share
                          # the device with the last waves of the kernel before it (events without the system-scope fence: no change,
                          # round-3 lease script aj.sh, in the history).  The judged fraction uses the pair as it is, the lower of the two figures
-                         "kernel_trace_avg_launch_us_replayed_not_this_run": kernel_trace_figures(info["nnz"]) if (world == 1 and args.numbering == "lattice" and args.jitter <= 0.0) else None,
+                         "kernel_trace_avg_launch_us_replayed_not_this_run": kernel_trace_figures(info["nnz"], R["value_dict"]) if (world == 1 and args.numbering == "lattice" and args.jitter <= 0.0) else None,
                          "avg_launch_ms_in_jacobi_step": (Jac["acc"]["spmv_ms"] / max(Jac["acc"]["spmv_n"], 1)) if (Jac and Jac["acc"]["spmv_n"]) else None,
                          "event_pair_offset_ms_not_subtracted": R["event_overhead_ms"],
                          "launches_timed": acc["spmv_n"], "nnz": info["nnz"], "rows": info["n_local"]},

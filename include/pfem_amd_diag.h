@@ -49,6 +49,11 @@ int pfem_solver_get_spmv_row_group(pfem_solver *s, int *rows_per_lane);
  * table of distinct large gaps when the 16-bit DICTIONARY form is in use (codes >= 0x8000 index the table; at most
  * 256 distinct gaps of 32768 and more), 0 otherwise (literal 16-bit gaps, 32-bit gaps, or another form).            */
 int pfem_solver_get_spmv_gap_table(pfem_solver *s, int *entries);
+/* Value dictionary of the SpMV's group forms (pfem_valdict.hpp): when the assembled matrix holds at most 4096 distinct values
+ * (structured meshes: element matrices repeat) the SpMV streams 16-bit codes into a dictionary held in LDS instead of the
+ * doubles -- the same doubles, the same products, the same bits, 2 B a slot instead of 8.  *entries = the dictionary's size
+ * after the last solve / product, 0 when the fp64 copy is streamed (PFEM_SPMV_VALDICT=0 turns the form off).               */
+int pfem_solver_get_spmv_value_dictionary(pfem_solver *s, int *entries);
 /* 1 when the row form streams 16-bit gaps WITH ESCAPES (k_spmv16e: the code 0xffff sends a column to the matrix's int32 column
  * array -- numberings whose far neighbours are too many and too irregular for the table: partition-renumbered and
  * curve-ordered meshes; taken when at most a quarter of the entries escape), else 0.  Same bits as every other form.     */

@@ -106,6 +106,7 @@ SIGNATURES = {
     "pfem_solver_get_spmv_format": [_P, _P],
     "pfem_solver_get_spmv_row_group": [_P, _P],
     "pfem_solver_get_spmv_gap_table": [_P, _P],
+    "pfem_solver_get_spmv_value_dictionary": [_P, _P],
     "pfem_solver_get_spmv_gap_escapes": [_P, _P],
     "pfem_solver_spmv_bytes": [_P, _P],
     "pfem_solver_set_preconditioner": [_P, _I],

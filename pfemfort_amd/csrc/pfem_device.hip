@@ -28,6 +28,7 @@
 
 #include "pfem_internal.hpp"
 #include "pfem_kernels.hpp"
+#include "pfem_valdict.hpp"
 #include "pfem_amg_kernels.hpp"
 #include "pfem_peer.hpp"
 
@@ -523,6 +524,15 @@ struct pfem_solver {
     bool rel_vals_current = false;
     DevBuf<int32_t> d_row_group;   // [n_loc] node group of every row (k_spmvg's copy written by the elasticity gather kernel itself)
     bool grp_vals_current = false;
+    // the group form's values as 16-bit codes into a dictionary of the distinct values (pfem_valdict.hpp): which form the
+    // codes belong to (rows to the lane: kRelRows / kGroupRows, 0 = none), whether they hold the current values, whether the
+    // SpMV may stream them (vd_ok), the dictionary's size; vd_refused: this pattern's values are too many, no more tries
+    DevBuf<unsigned long long> d_vcodes, d_vtable;
+    DevBuf<double> d_vdict;
+    DevBuf<VdState> d_vstate;
+    int vd_rows = 0, vd_n = 0;
+    bool vd_current = false, vd_ok = false, vd_have_dict = false, vd_refused = false;
+    double vd_encode_ms = 0.0;       // (host time of the last refresh incl. its wait: PFEM_VD_VERBOSE)
     bool use_rel() const
     {
         return relgrouped && !use_grouped() &&
@@ -1931,6 +1941,7 @@ int zero_values(pfem_solver *s, bool rows_overwritten = false)
     s->rhs_summed = false;
     s->rel_vals_current = false;            // (whoever writes the values next says so again if it writes both forms)
     s->grp_vals_current = false;
+    s->vd_current = false;
     return PFEM_OK;
 }
 
@@ -2053,6 +2064,7 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
     s->host_values_dirty = false;
     s->rel_vals_current = wrote_rel;
     s->grp_vals_current = wrote_grp;
+    s->vd_current = false;
     s->status = PFEM_ASSEMBLY_OK;
     return PFEM_OK;
 }
@@ -2352,6 +2364,8 @@ int build_groups(pfem_solver *s)
     PFEM_HIP(hipStreamSynchronize(s->stream));
     s->grouped = miss == 0;          // a gap missing from the table: the row form stays (never wrong columns)
     s->grp_vals_current = false;
+    s->vd_current = s->vd_ok = s->vd_have_dict = s->vd_refused = false;       // (a new pattern: new codes, a new verdict)
+    s->vd_rows = 0;
     s->d_row_group.release();
     if (s->grouped && !std::getenv("PFEM_DEBUG_NO_REL_DIRECT")) {       // for an assembly that writes this copy itself; its zero padding is set here, once
         PFEM_TRY(s->d_row_group.alloc(static_cast<size_t>(n)));
@@ -2460,6 +2474,8 @@ int build_rel_groups(pfem_solver *s)
     // union entry of every stored entry of the row form, for an assembly that writes this copy itself; the explicit zeros of the
     // copy (offsets a row lacks) are set here once and never written again
     s->rel_vals_current = false;
+    s->vd_current = s->vd_ok = s->vd_have_dict = s->vd_refused = false;
+    s->vd_rows = 0;
     s->d_relk.release();
     if (s->max_row_len > 0 && !std::getenv("PFEM_DEBUG_NO_REL_DIRECT")) {
         PFEM_TRY(s->d_relk.alloc(static_cast<size_t>(std::max<int64_t>(s->stored, 1))));
@@ -2485,10 +2501,80 @@ inline void mark_group_vals(pfem_solver *s)
 {
     s->group_vals_stale = !((s->use_rel() && s->rel_vals_current) || (s->use_grouped() && s->grp_vals_current));
 }
+// The SpMV's codes of the current values (pfem_valdict.hpp).  One wait for the device per call that finds new values: the
+// verdict decides which kernel the solve launches.
+int refresh_value_codes(pfem_solver *s)
+{
+    const bool enabled = [] { const char *e = std::getenv("PFEM_SPMV_VALDICT"); return e ? std::atoi(e) != 0 : true; }();     // (read per call: tests switch it)
+    const bool verbose = std::getenv("PFEM_VD_VERBOSE") != nullptr;
+    const int rows = s->use_grouped() ? kGroupRows : ((s->use_rel() && !s->rel_gap32) ? kRelRows : 0);
+    if (!enabled || rows == 0 || s->vd_refused) { s->vd_ok = false; return PFEM_OK; }
+    if (s->vd_current && s->vd_rows == rows) return PFEM_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int64_t n_entries = rows == kGroupRows ? s->g_stored : s->r_stored;
+    const double *vals = rows == kGroupRows ? s->d_gvals.p : s->d_rvals.p;
+    if (n_entries < 1 || !vals) { s->vd_ok = false; return PFEM_OK; }
+    if (s->vd_rows != rows) { s->vd_have_dict = false; s->vd_rows = rows; }
+    if (s->d_vcodes.n < static_cast<size_t>(n_entries)) PFEM_TRY(s->d_vcodes.alloc(static_cast<size_t>(n_entries)));
+    if (!s->d_vdict.p) PFEM_TRY(s->d_vdict.alloc(kVdMax));
+    if (!s->d_vtable.p) PFEM_TRY(s->d_vtable.alloc(kVdTable));
+    if (!s->d_vstate.p) PFEM_TRY(s->d_vstate.alloc(1));
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>((n_entries + kBlock - 1) / kBlock, 8192));
+    VdState st{0, 0, 0, 0};
+    auto encode = [&]() -> int {
+        const size_t lds = sizeof(uint64_t) * static_cast<size_t>(std::max(s->vd_n, 1));
+        if (rows == kGroupRows) hipLaunchKernelGGL(k_vd_encode<kGroupRows>, dim3(grid), dim3(kBlock), lds, s->stream, vals, n_entries, static_cast<const double *>(s->d_vdict.p), s->d_vstate.p, s->d_vcodes.p);
+        else hipLaunchKernelGGL(k_vd_encode<kRelRows>, dim3(grid), dim3(kBlock), lds, s->stream, vals, n_entries, static_cast<const double *>(s->d_vdict.p), s->d_vstate.p, s->d_vcodes.p);
+        PFEM_TRY(check_kernel("k_vd_encode"));
+        PFEM_HIP(hipMemcpyAsync(&st, s->d_vstate.p, sizeof st, hipMemcpyDeviceToHost, s->stream));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+        return PFEM_OK;
+    };
+    bool done = false;
+    if (s->vd_have_dict) {          // the dictionary of the last assembly: it holds if every value is found in it
+        const VdState reset{s->vd_n, 0, 0, 0};
+        PFEM_HIP(hipMemcpyAsync(s->d_vstate.p, &reset, sizeof reset, hipMemcpyHostToDevice, s->stream));
+        PFEM_TRY(encode());
+        done = st.miss == 0;
+    }
+    if (!done) {
+        PFEM_HIP(hipMemsetAsync(s->d_vtable.p, 0xff, sizeof(unsigned long long) * kVdTable, s->stream));
+        PFEM_HIP(hipMemsetAsync(s->d_vstate.p, 0, sizeof(VdState), s->stream));
+        hipLaunchKernelGGL(k_vd_collect, dim3(grid), dim3(kBlock), 0, s->stream, vals, static_cast<int64_t>(rows) * n_entries, s->d_vtable.p, s->d_vstate.p);
+        hipLaunchKernelGGL(k_vd_finish, dim3(1), dim3(1024), 0, s->stream, static_cast<const unsigned long long *>(s->d_vtable.p), s->d_vdict.p, s->d_vstate.p);
+        PFEM_TRY(check_kernel("k_vd_collect / k_vd_finish"));
+        PFEM_HIP(hipMemcpyAsync(&st, s->d_vstate.p, sizeof st, hipMemcpyDeviceToHost, s->stream));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+        if (st.fail || st.count < 1 || st.count > kVdMax) {
+            s->vd_ok = s->vd_have_dict = false;
+            s->vd_refused = true;          // (until the pattern changes: a mesh of this kind does not repeat its element matrices)
+            if (verbose) std::fprintf(stderr, "  value dictionary: more than %d distinct matrix values, the SpMV keeps its fp64 copy\n", kVdMax);
+            return PFEM_OK;
+        }
+        s->vd_n = st.count;
+        s->vd_have_dict = true;
+        PFEM_TRY(encode());
+        if (st.miss) { set_last_error("value dictionary: a value of the collection pass is missing from its own dictionary"); return PFEM_ERR_STATE; }
+    }
+    s->vd_ok = true;
+    s->vd_current = true;
+    s->vd_encode_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (verbose) std::fprintf(stderr, "  value dictionary: %d distinct values among %lld slots, codes refreshed in %.3f ms (host, incl. the wait)\n", s->vd_n,
+                              static_cast<long long>(rows * n_entries), s->vd_encode_ms);
+    return PFEM_OK;
+}
+
 // grouped copy of the current matrix values (the row form is what assembly writes)
+int refresh_group_vals_only(pfem_solver *s);
 int refresh_group_vals(pfem_solver *s)
 {
+    PFEM_TRY(refresh_group_vals_only(s));
+    return refresh_value_codes(s);
+}
+int refresh_group_vals_only(pfem_solver *s)
+{
     if (s->use_rel() && s->group_vals_stale) {
+        s->vd_current = false;
         const dim3 vg(static_cast<unsigned>(s->n_rslices));
         if (s->rel_gap32) hipLaunchKernelGGL(k_rel_vals<kGap32>, vg, dim3(kBlock), 0, s->stream, s->sell(), s->sellr(), s->d_rvals.p);
         else if (s->rel_dict) hipLaunchKernelGGL(k_rel_vals<kGapDict16>, vg, dim3(kBlock), 0, s->stream, s->sell(), s->sellr(), s->d_rvals.p);
@@ -2498,6 +2584,7 @@ int refresh_group_vals(pfem_solver *s)
         return PFEM_OK;
     }
     if (!s->use_grouped() || !s->group_vals_stale) return PFEM_OK;
+    s->vd_current = false;
     hipLaunchKernelGGL(k_group_vals, dim3(grid_for(s->n_gslices * 64)), dim3(kBlock), 0, s->stream, s->sell(), s->sellg(),
                        s->d_gvals.p);
     PFEM_TRY(check_kernel("k_group_vals"));
@@ -2519,7 +2606,27 @@ void launch_spmv(pfem_solver *s, const double *x, double *y, int64_t n_dot, doub
 {
     const dim3 grid(sel.list ? spmv_grid(sel.count) : spmv_blocks(s)), block(kBlock);
     SellDev A = s->sell();
-    if (s->use_grouped()) {
+    if (s->vd_ok && s->vd_current && s->use_grouped() && s->vd_rows == kGroupRows) {
+        SellGDev G = s->sellg();
+        const unsigned long long *q = s->d_vcodes.p;
+        const double *d = s->d_vdict.p;
+        const size_t lds = sizeof(double) * static_cast<size_t>(s->vd_n);
+        if (s->row_dict) {
+            if (e0) hipExtLaunchKernelGGL((k_spmvg_vd<WITH_DOT, true>), grid, block, lds, s->stream, e0, e1, 0, G, q, d, s->vd_n, s->n_loc, x, y, n_dot, partial, ctl, sel);
+            else hipLaunchKernelGGL((k_spmvg_vd<WITH_DOT, true>), grid, block, lds, s->stream, G, q, d, s->vd_n, s->n_loc, x, y, n_dot, partial, ctl, sel);
+        } else if (e0) hipExtLaunchKernelGGL((k_spmvg_vd<WITH_DOT, false>), grid, block, lds, s->stream, e0, e1, 0, G, q, d, s->vd_n, s->n_loc, x, y, n_dot, partial, ctl, sel);
+        else hipLaunchKernelGGL((k_spmvg_vd<WITH_DOT, false>), grid, block, lds, s->stream, G, q, d, s->vd_n, s->n_loc, x, y, n_dot, partial, ctl, sel);
+    } else if (s->vd_ok && s->vd_current && s->use_rel() && !s->rel_gap32 && s->vd_rows == kRelRows) {
+        SellRDev G = s->sellr();
+        const unsigned long long *q = s->d_vcodes.p;
+        const double *d = s->d_vdict.p;
+        const size_t lds = sizeof(double) * static_cast<size_t>(s->vd_n);
+        if (s->rel_dict) {
+            if (e0) hipExtLaunchKernelGGL((k_spmvr_vd<WITH_DOT, true>), grid, block, lds, s->stream, e0, e1, 0, G, q, d, s->vd_n, s->n_loc, x, y, n_dot, partial, ctl, sel);
+            else hipLaunchKernelGGL((k_spmvr_vd<WITH_DOT, true>), grid, block, lds, s->stream, G, q, d, s->vd_n, s->n_loc, x, y, n_dot, partial, ctl, sel);
+        } else if (e0) hipExtLaunchKernelGGL((k_spmvr_vd<WITH_DOT, false>), grid, block, lds, s->stream, e0, e1, 0, G, q, d, s->vd_n, s->n_loc, x, y, n_dot, partial, ctl, sel);
+        else hipLaunchKernelGGL((k_spmvr_vd<WITH_DOT, false>), grid, block, lds, s->stream, G, q, d, s->vd_n, s->n_loc, x, y, n_dot, partial, ctl, sel);
+    } else if (s->use_grouped()) {
         SellGDev G = s->sellg();
         if (s->row_dict) {
             if (e0) hipExtLaunchKernelGGL((k_spmvg<WITH_DOT, true>), grid, block, 0, s->stream, e0, e1, 0, G, s->n_loc, x, y, n_dot, partial, ctl, sel);
@@ -2622,7 +2729,12 @@ extern "C" int pfem_solver_spmv_bytes(pfem_solver *s, int64_t *format_bytes)
     if (!s || !format_bytes) return PFEM_ERR_ARG;
     if (!s->have_pattern) return PFEM_ERR_STATE;
     int64_t b = 16 * s->n_loc;                                             // x read, y written
-    if (s->use_grouped())
+    const bool vd = s->vd_ok && s->vd_current;                             // 8 B of codes per lane entry (all its rows) instead of 8 B per slot
+    if (vd && s->use_grouped() && s->vd_rows == kGroupRows)
+        b += s->g_stored * 8 + s->g_gap_words * 4 + s->n_gslices * (64 * 4 + 16) + (s->n_groups + 1) * 4;
+    else if (vd && s->use_rel() && !s->rel_gap32 && s->vd_rows == kRelRows)
+        b += s->r_stored * 8 + s->r_gap_words * 4 + s->n_rslices * (64 * 4 + 16);
+    else if (s->use_grouped())
         b += s->g_stored * kGroupRows * 8 + s->g_gap_words * 4 + s->n_gslices * (64 * 4 + 16) + (s->n_groups + 1) * 4;
     else if (s->use_rel())
         b += s->r_stored * kRelRows * 8 + s->r_gap_words * 4 + s->n_rslices * (64 * 4 + 16);
@@ -2631,6 +2743,15 @@ extern "C" int pfem_solver_spmv_bytes(pfem_solver *s, int64_t *format_bytes)
     else
         b += s->stored * 12 + s->n_slices * 8 + s->n_loc * 4;
     *format_bytes = b;
+    return PFEM_OK;
+}
+
+// the value dictionary of the SpMV (pfem_valdict.hpp): distinct values it holds when the SpMV streams 16-bit codes, else 0
+extern "C" int pfem_solver_get_spmv_value_dictionary(pfem_solver *s, int *entries)
+{
+    if (!s || !entries) return PFEM_ERR_ARG;
+    if (!s->have_pattern) return PFEM_ERR_STATE;
+    *entries = (s->vd_ok && s->vd_current) ? s->vd_n : 0;
     return PFEM_OK;
 }
 
@@ -3471,6 +3592,13 @@ inline int spmv_form(const pfem_solver *s)
     return s->use_grouped() ? 3 : (s->use_rel() ? (s->rel_gap32 ? 5 : (s->rel_dict ? 6 : 4)) : ((s->cols16 && s->spmv_format != PFEM_SPMV_INT32) ? 2 : 1));
 }
 
+// ... and what a captured launch of it depends on besides (value dictionary in use, its size)
+inline uint64_t spmv_key(const pfem_solver *s)
+{
+    return static_cast<uint64_t>(spmv_form(s)) | ((s->vd_ok && s->vd_current) ? (static_cast<uint64_t>(s->vd_n + 1) << 8) : 0) |
+           (static_cast<uint64_t>(reinterpret_cast<uintptr_t>(s->d_vcodes.p)) << 24);
+}
+
 // boundary / interior slice lists of the SpMV form in use
 int build_slice_lists(pfem_solver *s)
 {
@@ -3780,7 +3908,7 @@ int run_pcg(pfem_solver *s)
                 reinterpret_cast<uint64_t>(s->d_vals.p), reinterpret_cast<uint64_t>(s->d_cols.p), reinterpret_cast<uint64_t>(s->d_rvals.p),
                 reinterpret_cast<uint64_t>(s->d_gvals.p), reinterpret_cast<uint64_t>(s->d_dwords.p), reinterpret_cast<uint64_t>(s->stream),
                 static_cast<uint64_t>(s->hist_cap), static_cast<uint64_t>(s->maxits), static_cast<uint64_t>(n),
-                static_cast<uint64_t>(s->n_owned), static_cast<uint64_t>(gs), static_cast<uint64_t>(gv), static_cast<uint64_t>(fmt)};
+                static_cast<uint64_t>(s->n_owned), static_cast<uint64_t>(gs), static_cast<uint64_t>(gv), static_cast<uint64_t>(fmt), spmv_key(s)};
             if (key != s->cg_graph_key || !s->cg_graph[0] || !s->cg_graph[1]) {
                 for (auto &g : s->cg_graph)
                     if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
@@ -3915,7 +4043,7 @@ int run_pcg(pfem_solver *s)
                 reinterpret_cast<uint64_t>(s->d_slices_i.p), reinterpret_cast<uint64_t>(s->d_send_lidx.p), reinterpret_cast<uint64_t>(s->d_sh_src.p),
                 static_cast<uint64_t>(s->hist_cap), static_cast<uint64_t>(s->maxits), static_cast<uint64_t>(n), static_cast<uint64_t>(s->n_owned),
                 static_cast<uint64_t>(s->n_send), static_cast<uint64_t>(s->n_sh), static_cast<uint64_t>(s->n_slices_b),
-                static_cast<uint64_t>(s->n_slices_i), static_cast<uint64_t>(gv), static_cast<uint64_t>(spmv_form(s))};
+                static_cast<uint64_t>(s->n_slices_i), static_cast<uint64_t>(gv), spmv_key(s)};
             if (key != s->mgraph_key || !s->mgraph) {
                 if (s->mgraph) { (void)hipGraphExecDestroy(s->mgraph); s->mgraph = nullptr; }
                 s->mgraph_key.clear();
@@ -4485,6 +4613,7 @@ extern "C" int pfem_solver_solve(pfem_solver *s, int *its, int *reason, double *
             PFEM_HIP(hipMemcpyAsync(dv.p, s->h_vals.data(), sizeof(double) * s->nnz, hipMemcpyHostToDevice, s->stream));
             s->rel_vals_current = false;
             s->grp_vals_current = false;
+            s->vd_current = false;
             hipLaunchKernelGGL(k_csr_vals_to_sell, dim3(grid_for(s->n_loc)), dim3(kBlock), 0, s->stream, s->sell(), s->d_rowptr.p, dv.p);
             PFEM_TRY(check_kernel("k_csr_vals_to_sell"));
             PFEM_HIP(hipStreamSynchronize(s->stream));

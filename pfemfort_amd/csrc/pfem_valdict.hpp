@@ -1,0 +1,321 @@
+// pfem_valdict.hpp -- the SpMV's copy of the matrix values as 16-bit codes into a dictionary of the DISTINCT values.
+//
+// WHY.  The CG iteration is the SpMV, and the SpMV is its bytes: the grouped forms stream 8 B of value + 1/2 B of column gap
+// per stored slot at 0.89-0.93 of HBM peak -- nothing is left there.  But on a structured mesh (what genTetra.cpp writes, what
+// north_star names) the element matrices repeat: the assembled K of config 3 holds 117 M entries and ~600 distinct bit
+// patterns, the beam's 103 M entries ~2 600 (coordinates printed with 8 decimals: the cells differ by roundings, the sums by
+// their order).  A dictionary of <= 4096 doubles sits in LDS (<= 32 KB a workgroup), a slot costs 2 B instead of 8, and the
+// product is the SAME product: v = dict[code] is the very double the assembly wrote (lossless; same fma chain, same bits in
+// y, in every dot and in every iterate -- tested).  Value indexing for sparse kernels is Kourtis, Goumas & Koziris 2008
+// ("CSR-VI"); here it rides on the wave-sliced group forms.
+//
+// The values are re-assembled in every step, inside the reference's timers, so the codes are too:
+//   steady state   k_vd_encode alone: every slot's value is looked up (bisection over the sorted dictionary in LDS), its code
+//                  written; a value that is not in the dictionary raises `miss`
+//   first time, or after a miss
+//                  k_vd_collect (distinct bit patterns into an open-addressing table, a block-local filter in front of the
+//                  global atomics) -> k_vd_finish (one workgroup: gather, bitonic sort, the dictionary) -> k_vd_encode
+//   more than kVdMax distinct values (any unstructured mesh): the form is dropped for this pattern; the fp64 copy is what the
+//   SpMV streams, as before.
+// One read of the verdict (3 ints) by the host per assembly decides which kernel the solve launches.
+#pragma once
+
+namespace pfem {
+
+constexpr int kVdMax = 4096;                    // distinct values a dictionary may hold: 32 KB of LDS in the SpMV
+constexpr int kVdTable = 16384;                 // slots of the collection table
+constexpr uint64_t kVdEmpty = ~0ull;            // (the bit pattern of a NaN no assembly produces; met as a VALUE it fails the form)
+struct VdState { int count, fail, miss, pad; };
+
+__device__ __forceinline__ uint32_t vd_hash(uint64_t b)
+{
+    b ^= b >> 33;
+    b *= 0xff51afd7ed558ccdull;
+    b ^= b >> 33;
+    return static_cast<uint32_t>(b);
+}
+
+// distinct bit patterns of vals[0..n) into table (kVdTable slots, kVdEmpty = free); st->count of them, st->fail beyond kVdMax
+__global__ void __launch_bounds__(kBlock) k_vd_collect(const double *__restrict__ vals, int64_t n, unsigned long long *table, VdState *st)
+{
+    __shared__ uint64_t seen[1024];             // values this block has already handed to the table (direct mapped)
+    for (int i = threadIdx.x; i < 1024; i += kBlock) seen[i] = kVdEmpty;
+    __syncthreads();
+    const volatile int *failed = &st->fail;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const uint64_t b = static_cast<uint64_t>(__double_as_longlong(__builtin_nontemporal_load(vals + i)));
+        const uint32_t h = vd_hash(b);
+        if (seen[h & 1023u] == b) continue;
+        if (*failed) return;
+        if (b == kVdEmpty) { st->fail = 1; return; }
+        bool placed = false;
+        for (uint32_t q = h & (kVdTable - 1), tries = 0; tries < kVdTable; q = (q + 1) & (kVdTable - 1), ++tries) {
+            // (a plain look first: 600 values x 8192 workgroups would otherwise queue up on 600 words -- measured 20 ms)
+            const unsigned long long there = __hip_atomic_load(table + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (there == b) { placed = true; break; }
+            if (there != kVdEmpty) continue;
+            const unsigned long long old = atomicCAS(table + q, static_cast<unsigned long long>(kVdEmpty), static_cast<unsigned long long>(b));
+            if (old == kVdEmpty) {
+                if (atomicAdd(&st->count, 1) + 1 > kVdMax) st->fail = 1;
+                placed = true;
+                break;
+            }
+            if (old == b) { placed = true; break; }
+        }
+        if (!placed) { st->fail = 1; return; }
+        seen[h & 1023u] = b;                    // (racing writers store whole 8-byte words: a later reader sees one of them)
+    }
+}
+
+// one workgroup: the table's entries sorted by bit pattern = the dictionary; st->count = their number
+__global__ void __launch_bounds__(1024) k_vd_finish(const unsigned long long *__restrict__ table, double *__restrict__ dict, VdState *st)
+{
+    __shared__ uint64_t key[kVdMax];
+    __shared__ int n_found;
+    if (threadIdx.x == 0) n_found = 0;
+    for (int i = threadIdx.x; i < kVdMax; i += 1024) key[i] = kVdEmpty;
+    __syncthreads();
+    if (st->fail) return;
+    for (int q = threadIdx.x; q < kVdTable; q += 1024) {
+        const uint64_t b = table[q];
+        if (b != kVdEmpty) {
+            const int at = atomicAdd(&n_found, 1);
+            if (at < kVdMax) key[at] = b;
+        }
+    }
+    __syncthreads();
+    const int n = n_found;
+    if (n > kVdMax) { if (threadIdx.x == 0) st->fail = 1; return; }
+    for (int k = 2; k <= kVdMax; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < kVdMax; i += 1024) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint64_t a = key[i], c = key[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) { key[i] = c; key[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < n; i += 1024) dict[i] = __longlong_as_double(static_cast<long long>(key[i]));   // (kVdEmpty sorts last)
+    if (threadIdx.x == 0) st->count = n;
+}
+
+// codes of every slot of a group form with ROWS rows to the lane: slot (k, p) of lane l of a slice that starts at entry `off`
+// lives at vals[ROWS * off + (ROWS * k + p) * 64 + l]; entry i = off + 64 k + l gets the word  code_0 | code_1 << 16 | ...
+template <int ROWS>
+__global__ void __launch_bounds__(kBlock) k_vd_encode(const double *__restrict__ vals, int64_t n_entries, const double *__restrict__ dict,
+                                                       VdState *st, unsigned long long *__restrict__ codes)
+{
+    extern __shared__ uint64_t vd_keys[];
+    const int nd = st->count;
+    for (int i = threadIdx.x; i < nd; i += kBlock) vd_keys[i] = static_cast<uint64_t>(__double_as_longlong(dict[i]));
+    __syncthreads();
+    bool missed = false;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n_entries; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const int lane = static_cast<int>(i & 63);
+        const double *vp = vals + ROWS * (i - lane) + lane;
+        uint64_t b[ROWS];
+#pragma unroll
+        for (int p = 0; p < ROWS; ++p) b[p] = static_cast<uint64_t>(__double_as_longlong(__builtin_nontemporal_load(vp + 64 * p)));
+        unsigned long long w = 0;
+#pragma unroll
+        for (int p = 0; p < ROWS; ++p) {
+            int lo = 0, len = nd;                // first key >= b[p]
+            while (len > 0) {
+                const int half = len >> 1;
+                const bool right = vd_keys[lo + half] < b[p];
+                lo = right ? lo + half + 1 : lo;
+                len = right ? len - half - 1 : half;
+            }
+            if (lo >= nd || vd_keys[lo] != b[p]) { missed = true; lo = 0; }
+            w |= static_cast<unsigned long long>(lo) << (16 * p);
+        }
+        codes[i] = w;
+    }
+    if (missed) st->miss = 1;
+}
+
+// ---- the SpMVs of pfem_kernels.hpp over the codes: same slices, same lanes, same order of the fma chain, same partials ----
+template <bool WITH_DOT, bool DICT>
+__global__ void __launch_bounds__(kBlock) k_spmvr_vd(SellRDev G, const unsigned long long *__restrict__ codes, const double *__restrict__ dict, int nd,
+                                                      int64_t n_rows, const double *__restrict__ x, double *__restrict__ y, int64_t n_dot,
+                                                      double *partial, const CgCtl *ctl, SliceSel sel)
+{
+    extern __shared__ double vd[];
+    __shared__ double sm[4];
+    __shared__ uint32_t gap_tbl[DICT ? kGapTable : 1];
+    if (WITH_DOT && ctl->flag != 0) return;
+    for (int i = threadIdx.x; i < nd; i += kBlock) vd[i] = dict[i];
+    if (DICT) gap_tbl[DICT ? threadIdx.x : 0] = G.gap_table[threadIdx.x];
+    __syncthreads();
+    const auto gap_of = [&](uint32_t code) -> int {
+        return (DICT && (code & 0x8000u)) ? static_cast<int>(gap_tbl[DICT ? (code & (kGapTable - 1)) : 0]) : static_cast<int>(code);
+    };
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t gs = pick_slice(sel, (static_cast<int64_t>(blockIdx.x) << 2) + wave, G.n_gslices);
+    double dot = 0.0;
+    if (gs < G.n_gslices) {
+        const int64_t off = G.gslice_off[gs];
+        const int width = static_cast<int>((G.gslice_off[gs + 1] - off) >> 6);
+        const unsigned long long *__restrict__ qp = codes + off + lane;
+        const uint32_t *__restrict__ wp = G.dwords + G.gslice_doff[gs] + lane;
+        int c = __builtin_nontemporal_load(G.col0 + (gs << 6) + lane);
+        double acc[kRelRows] = {0.0, 0.0, 0.0, 0.0};
+        if (width > 0) {
+            double xv[kRelRows];
+            load_x4(x, c, xv);
+            const unsigned long long q = __builtin_nontemporal_load(qp);
+#pragma unroll
+            for (int p = 0; p < kRelRows; ++p) acc[p] = vd[(q >> (16 * p)) & 0xffffu] * xv[p];
+        }
+        const int nw = width / 2;
+        int j = 0;
+        uint32_t w0 = 0, w1 = 0;
+        if (2 * (j + 2) < width) { w0 = __builtin_nontemporal_load(wp + 64 * j); w1 = __builtin_nontemporal_load(wp + 64 * (j + 1)); }
+        while (2 * (j + 2) < width) {
+            const int c0 = c + gap_of(w0 & 0xffffu), c1 = c0 + gap_of(w0 >> 16);
+            const int c2 = c1 + gap_of(w1 & 0xffffu), c3 = c2 + gap_of(w1 >> 16);
+            unsigned long long q[4];
+            double xv[4][kRelRows];
+            load_x4(x, c0, xv[0]); load_x4(x, c1, xv[1]); load_x4(x, c2, xv[2]); load_x4(x, c3, xv[3]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) q[t] = __builtin_nontemporal_load(qp + 64 * (2 * j + 1 + t));
+            c = c3;
+            j += 2;
+            if (2 * (j + 2) < width) { w0 = __builtin_nontemporal_load(wp + 64 * j); w1 = __builtin_nontemporal_load(wp + 64 * (j + 1)); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int p = 0; p < kRelRows; ++p) acc[p] = __builtin_fma(vd[(q[t] >> (16 * p)) & 0xffffu], xv[t][p], acc[p]);
+        }
+        for (; j < nw; ++j) {
+            const uint32_t w = __builtin_nontemporal_load(wp + 64 * j);
+            const int c0 = c + gap_of(w & 0xffffu);
+            const int c1 = c0 + gap_of(w >> 16);
+            double xv[kRelRows];
+            load_x4(x, c0, xv);
+            const unsigned long long qa = __builtin_nontemporal_load(qp + 64 * (2 * j + 1));
+#pragma unroll
+            for (int p = 0; p < kRelRows; ++p) acc[p] = __builtin_fma(vd[(qa >> (16 * p)) & 0xffffu], xv[p], acc[p]);
+            if (2 * j + 2 < width) {
+                load_x4(x, c1, xv);
+                const unsigned long long qb = __builtin_nontemporal_load(qp + 64 * (2 * j + 2));
+#pragma unroll
+                for (int p = 0; p < kRelRows; ++p) acc[p] = __builtin_fma(vd[(qb >> (16 * p)) & 0xffffu], xv[p], acc[p]);
+            }
+            c = c1;
+        }
+        const int64_t r0 = ((gs << 6) + lane) * kRelRows;
+#pragma unroll
+        for (int p = 0; p < kRelRows; ++p)
+            if (r0 + p < n_rows) {
+                y[r0 + p] = acc[p];
+                if (WITH_DOT && r0 + p < n_dot) dot = __builtin_fma(x[r0 + p], acc[p], dot);
+            }
+    }
+    if (WITH_DOT) {
+        const double t = block_sum(dot, sm);
+        if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    }
+}
+
+// W words = 2W consecutive entries of the node's rows (k_spmvg's trip over the codes)
+template <int W, bool DICT>
+__device__ __forceinline__ void spmvg_vd_trip(const unsigned long long *__restrict__ qp, const uint32_t *__restrict__ wp, const double *__restrict__ x,
+                                              const double *vd, int &j, int &c, double (&acc)[kGroupRows], const uint32_t *tbl)
+{
+    uint32_t w[W];
+    unsigned long long q[2 * W];
+    double xv[2 * W];
+#pragma unroll
+    for (int t = 0; t < W; ++t) w[t] = __builtin_nontemporal_load(wp + 64 * (j + t));
+#pragma unroll
+    for (int t = 0; t < 2 * W; ++t) q[t] = __builtin_nontemporal_load(qp + 64 * (2 * j + 1 + t));
+#pragma unroll
+    for (int t = 0; t < W; ++t) {
+        const int c0 = c + gap16<DICT>(w[t] & 0xffffu, tbl);
+        const int c1 = c0 + gap16<DICT>(w[t] >> 16, tbl);
+        xv[2 * t] = x[c0];
+        xv[2 * t + 1] = x[c1];
+        c = c1;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 2 * W; ++t)
+#pragma unroll
+        for (int p = 0; p < kGroupRows; ++p) acc[p] = __builtin_fma(vd[(q[t] >> (16 * p)) & 0xffffu], xv[t], acc[p]);
+    j += W;
+}
+
+template <bool WITH_DOT, bool DICT>
+__global__ void __launch_bounds__(kBlock) k_spmvg_vd(SellGDev G, const unsigned long long *__restrict__ codes, const double *__restrict__ dict, int nd,
+                                                      int64_t n_rows, const double *__restrict__ x, double *__restrict__ y, int64_t n_dot,
+                                                      double *partial, const CgCtl *ctl, SliceSel sel)
+{
+    extern __shared__ double vd[];
+    __shared__ double sm[4];
+    __shared__ uint32_t tbl[DICT ? kGapTable : 1];
+    if (WITH_DOT && ctl->flag != 0) return;
+    for (int i = threadIdx.x; i < nd; i += kBlock) vd[i] = dict[i];
+    if (DICT) tbl[DICT ? threadIdx.x : 0] = G.gap_table[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t gs = pick_slice(sel, (static_cast<int64_t>(blockIdx.x) << 2) + wave, G.n_gslices);
+    double dot = 0.0;
+    if (gs < G.n_gslices) {
+        const int64_t off = G.gslice_off[gs];
+        const int width = static_cast<int>((G.gslice_off[gs + 1] - off) >> 6);
+        const unsigned long long *__restrict__ qp = codes + off + lane;
+        const uint32_t *__restrict__ wp = G.dwords + G.gslice_doff[gs] + lane;
+        int c = __builtin_nontemporal_load(G.col0 + (gs << 6) + lane);
+        double acc[kGroupRows];
+#pragma unroll
+        for (int p = 0; p < kGroupRows; ++p) acc[p] = 0.0;
+        if (width > 0) {
+            const double x0 = x[c];
+            const unsigned long long q = __builtin_nontemporal_load(qp);
+#pragma unroll
+            for (int p = 0; p < kGroupRows; ++p) acc[p] = vd[(q >> (16 * p)) & 0xffffu] * x0;
+        }
+        const int nw = width / 2;
+        int j = 0;
+        while (2 * (j + 4) < width) spmvg_vd_trip<4, DICT>(qp, wp, x, vd, j, c, acc, tbl);
+        if (2 * (j + 2) < width) spmvg_vd_trip<2, DICT>(qp, wp, x, vd, j, c, acc, tbl);
+        for (; j < nw; ++j) {
+            const uint32_t w0 = __builtin_nontemporal_load(wp + 64 * j);
+            const int c0 = c + gap16<DICT>(w0 & 0xffffu, tbl);
+            const int c1 = c0 + gap16<DICT>(w0 >> 16, tbl);
+            const double x0 = x[c0];
+            const unsigned long long qa = __builtin_nontemporal_load(qp + 64 * (2 * j + 1));
+#pragma unroll
+            for (int p = 0; p < kGroupRows; ++p) acc[p] = __builtin_fma(vd[(qa >> (16 * p)) & 0xffffu], x0, acc[p]);
+            if (2 * j + 2 < width) {
+                const double x1 = x[c1];
+                const unsigned long long qb = __builtin_nontemporal_load(qp + 64 * (2 * j + 2));
+#pragma unroll
+                for (int p = 0; p < kGroupRows; ++p) acc[p] = __builtin_fma(vd[(qb >> (16 * p)) & 0xffffu], x1, acc[p]);
+            }
+            c = c1;
+        }
+        const int64_t g = (gs << 6) + lane;
+        if (g < G.n_groups) {
+            const int64_t r0 = G.group_row0[g];
+            const int sz = G.group_row0[g + 1] - static_cast<int>(r0);
+#pragma unroll
+            for (int p = 0; p < kGroupRows; ++p)
+                if (p < sz) {
+                    y[r0 + p] = acc[p];
+                    if (WITH_DOT && r0 + p < n_dot) dot = __builtin_fma(x[r0 + p], acc[p], dot);
+                }
+        }
+    }
+    if (WITH_DOT) {
+        const double t = block_sum(dot, sm);
+        if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    }
+}
+
+}  // namespace pfem

@@ -208,6 +208,12 @@ class PetscSolver:
         L.check(L.lib().pfem_solver_get_spmv_gap_table(self._h, C.byref(b)), "pfem_solver_get_spmv_gap_table")
         return b.value
 
+    def spmvValueDictionary(self):
+        """Distinct matrix values in the SpMV's dictionary when it streams 16-bit value codes (structured meshes), else 0."""
+        b = C.c_int(0)
+        L.check(L.lib().pfem_solver_get_spmv_value_dictionary(self._h, C.byref(b)), "pfem_solver_get_spmv_value_dictionary")
+        return b.value
+
     def spmvGapEscapes(self):
         """True when the row form streams 16-bit gaps with escapes to the int32 column array (k_spmv16e)."""
         b = C.c_int(0)

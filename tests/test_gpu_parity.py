@@ -219,6 +219,72 @@ def test_spmv_column_formats_bit_identical(name, request):
     assert np.abs(y_32 - O.spmv(rowptr, cols, vals, x)).max() <= 1e-13 * np.abs(y_32).max()
 
 
+@pytest.mark.parametrize("name", ["cube", "beam"])
+def test_spmv_value_dictionary_same_bits(name, monkeypatch):
+    """The SpMV's group forms stream 16-bit codes into a dictionary of the DISTINCT matrix values when there are at most 4096 of
+    them (pfem_valdict.hpp: structured meshes repeat their element matrices).  Lossless: product, Jacobi-CG history and iterate,
+    gamg history and iterate equal the fp64 copy's bit for bit (PFEM_SPMV_VALDICT=0); new values of the same pattern are
+    re-encoded (a value missing from the old dictionary rebuilds it); a mesh whose values do not repeat keeps the fp64 copy."""
+    if name == "cube":
+        kind, ed, ed2 = pf.POISSON_TET, H.POISSON_ELEMDATA, np.array([1.3, 0.7, 2.1])
+        mesh = H.gen_box_tets(-1, 1, 24, -1, 1, 20, -1, 1, 22)
+        h = 2.0 / 24
+    else:
+        kind, ed = pf.ELAST_TET, H.ELAST_ELEMDATA
+        ed2 = np.array(H.ELAST_ELEMDATA, dtype=np.float64).copy()
+        ed2[0] *= 1.7                       # another Young's modulus: every entry changes
+        mesh = H.gen_box_tets(-0.5, 0.5, 6, 0.0, 6.0, 36, -0.5, 0.5, 6, bc_mode=1, ndof=3)
+        h = 1.0 / 6
+    out = {}
+    for vd in ("0", "1"):
+        monkeypatch.setenv("PFEM_SPMV_VALDICT", vd)
+        s, dm = _device_problem(kind, mesh, ed)
+        s.setSpmvFormat("grouped")
+        s.buildPattern()
+        s.assemble(ed, H.TIMEDATA)
+        x = np.random.default_rng(3).standard_normal(dm.size_global)
+        y = s.spmv(x)
+        n_dict = s.spmvValueDictionary()
+        assert (n_dict > 0) == (vd == "1") and n_dict <= 4096 and s.spmvRowGroup() == (4 if name == "cube" else 3)
+        s.setTolerances(rtol=1e-10, maxits=20000)
+        its, reason, _ = s.factoriseAndSolve()
+        hj, uj = s.getHistory(), s.getSolution()
+        s.setPreconditioner("gamg")
+        itg, reason_g, _ = s.factoriseAndSolve()
+        hg, ug = s.getHistory(), s.getSolution()
+        assert reason == 2 and reason_g == 2
+        # other values on the same pattern: the codes follow (the old dictionary misses them, a new one is collected)
+        s.assemble(ed2, H.TIMEDATA)
+        y2 = s.spmv(x)
+        n2 = s.spmvValueDictionary()
+        assert (n2 > 0) == (vd == "1") and not np.array_equal(y, y2)
+        s.assemble(ed, H.TIMEDATA)
+        y3 = s.spmv(x)
+        assert np.array_equal(y3, y)
+        out[vd] = (y, its, hj, uj, itg, hg, ug, y2)
+        bytes_now = s.spmvFormatBytes()
+        out[vd + "bytes"] = bytes_now
+        s.free()
+    a, b = out["0"], out["1"]
+    assert a[1] == b[1] and a[4] == b[4]
+    for i in (0, 2, 3, 5, 6, 7):
+        assert np.array_equal(a[i], b[i]), i
+    assert out["1bytes"] < 0.5 * out["0bytes"]                     # 2 B a slot instead of 8
+    # nodes moved off the lattice: no two element matrices alike, the dictionary overflows and the fp64 copy stays
+    monkeypatch.setenv("PFEM_SPMV_VALDICT", "1")
+    s, dm = _device_problem(kind, _moved(mesh, h), ed)
+    s.setSpmvFormat("grouped")
+    s.buildPattern()
+    s.assemble(ed, H.TIMEDATA)
+    x = np.random.default_rng(3).standard_normal(dm.size_global)
+    y = s.spmv(x)
+    assert s.spmvValueDictionary() == 0
+    rowptr, cols, vals = s.getCSR()
+    assert np.abs(y - O.spmv(rowptr, cols, vals, x)).max() <= 1e-13 * np.abs(y).max()
+    s.assemble(ed, H.TIMEDATA)
+    assert np.array_equal(s.spmv(x), y) and s.spmvValueDictionary() == 0          # (and it is not tried again on this pattern)
+
+
 @pytest.mark.parametrize("rtol", [1e-5, 1e-10])
 def test_poisson_tet10_solve(tet10, rtol):
     res = pf.tetrapoissonparallelimpl1(tet10, rtol=rtol)
