@@ -8,6 +8,8 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out
 export TMPDIR=/tmp
 ( timeout 900 python bench.py --steps 20 --warmup 5 2>$OUT/final_bench_n1.err | tail -1 ) > $OUT/final_bench_n1.json
 ( timeout 900 python bench.py --workload beam --steps 5 --warmup 2 2>$OUT/final_bench_beam.err | tail -1 ) > $OUT/final_bench_beam.json
+( PFEM_SPMV_VALDICT=0 timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>$OUT/final_bench_n1_fp64_values.err | tail -1 ) > $OUT/final_bench_n1_fp64_values.json
+( PFEM_SPMV_VALDICT=0 timeout 900 python bench.py --workload beam --steps 5 --warmup 2 --no-cpu-baseline 2>$OUT/final_bench_beam_fp64_values.err | tail -1 ) > $OUT/final_bench_beam_fp64_values.json
 ( timeout 900 python bench.py --cells 400 --steps 2 --warmup 1 --no-cpu-baseline 2>$OUT/final_bench_cfg5.err | tail -1 ) > $OUT/final_bench_cfg5_single_gpu.json
 ( timeout 900 python bench.py --cells 100 --steps 5 --warmup 2 2>$OUT/final_bench_cfg2.err | tail -1 ) > $OUT/final_bench_cfg2_100cube.json
 ( timeout 1500 python bench.py --gpus 8 --same-device --backend gloo --steps 1 --warmup 1 --no-transport-ab --no-jacobi-step 2>$OUT/final_bench_8ranks.err | tail -1 ) > $OUT/final_bench_cfg5_8ranks_sharing_one_gpu_gloo.json
@@ -27,7 +29,12 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $C --kernel-include-regex "$RE" -f csv -d /tmp/prof_$C -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity-step > $OUT/final_pmc_$C.log 2>&1
   python tools/summarize_prof.py pmc /tmp/prof_$C $C > $OUT/final_rocprofv3_pmc_$C.txt 2>&1
 done
-for f in n1 beam cfg5_single_gpu cfg2_100cube cfg5_8ranks_sharing_one_gpu_gloo; do python3 - <<PY
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/prof_b$C
+  timeout 900 rocprofv3 --pmc $C --kernel-include-regex "k_spmvg" -f csv -d /tmp/prof_b$C -- python3 bench.py --workload beam --steps 1 --warmup 1 --no-cpu-baseline --no-parity-step --no-jacobi-step > $OUT/final_pmc_beam_$C.log 2>&1
+  python tools/summarize_prof.py pmc /tmp/prof_b$C $C > $OUT/final_rocprofv3_pmc_beam_$C.txt 2>&1
+done
+for f in n1 n1_fp64_values beam beam_fp64_values cfg5_single_gpu cfg2_100cube cfg5_8ranks_sharing_one_gpu_gloo; do python3 - <<PY
 import json
 try:
     d=json.load(open("$OUT/final_bench_$f.json"))
@@ -35,4 +42,4 @@ try:
 except Exception as e: print("$f", "ERR", e)
 PY
 done
-head -16 $OUT/final_rocprofv3_kernel_stats.txt; grep -E "k_spmvr<true|k_gather|k_amg_spmv_ep<0>|k_lat_galerkin" $OUT/final_rocprofv3_pmc_FETCH_SIZE.txt $OUT/final_rocprofv3_pmc_WRITE_SIZE.txt
+head -16 $OUT/final_rocprofv3_kernel_stats.txt; grep -E "k_spmvr|k_spmvg|k_gather|k_amg_spmv_ep<0>|k_lat_galerkin" $OUT/final_rocprofv3_pmc_FETCH_SIZE.txt $OUT/final_rocprofv3_pmc_WRITE_SIZE.txt $OUT/final_rocprofv3_pmc_beam_FETCH_SIZE.txt $OUT/final_rocprofv3_pmc_beam_WRITE_SIZE.txt
