@@ -501,7 +501,9 @@ struct pfem_solver {
     DevBuf<double> d_gvals;
     // the grouped forms put 3-4 rows on a lane, i.e. 3-4x fewer waves: AUTO takes them only when the slices still
     // fill the chip several times over (measured: 50^3 Poisson 10.3 vs 8.5 us per SpMV, 100^3 equal, 200^3 -15 %)
-    static constexpr int64_t kMinGroupsAuto = 327680;      // 5120 wave slots x 64 lanes
+    // (round 5: with the values as dictionary codes -- pfem_valdict.hpp -- a group form moves 2.5 B a slot against the row form's
+    // 8.5, so the threshold came down from 5120 wave slots to 2560: 100^3 has 242 575 groups of four rows)
+    static constexpr int64_t kMinGroupsAuto = 163840;      // 2560 wave slots x 64 lanes
     bool use_grouped() const
     {
         return grouped && (spmv_format == PFEM_SPMV_GROUPED || (spmv_format == PFEM_SPMV_AUTO && n_groups >= kMinGroupsAuto));

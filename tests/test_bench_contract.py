@@ -121,7 +121,7 @@ def test_config5_at_full_size_with_eight_ranks_sharing_the_device():
     assert d["config"]["free_dofs"] == 63521199 and d["config"]["elements"] == 384000000 and d["n_gpus"] == 8
     assert d["converged_reason"] == 2 and abs(d["iterations"] - 720) <= 5 and d["max_nodal_error"] < 3e-4
     sc = d["strong_cfg5"]               # N = 8: the weak configuration IS config 5 -- the same run, read against one GPU
-    assert sc["is_baseline_config5"] and sc["same_run_as_value"] and sc["single_gpu_ms_per_step"] > 1900 and sc["preconditioner"] == "jacobi"
+    assert sc["is_baseline_config5"] and sc["same_run_as_value"] and sc["single_gpu_ms_per_step"] > 1000 and sc["preconditioner"] == "jacobi"
     assert abs(sc["speedup_vs_single_gpu"] - sc["single_gpu_ms_per_step"] / d["ms_per_step"]) < 1e-9
     c = d["comm"]
     assert len(c["ranks"]) == 8 and c["distinct_devices"] == 1 and [r["layers"] for r in c["ranks"]] == [[50 * r, 50 * r + 50] for r in range(8)]
