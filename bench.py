@@ -940,6 +940,10 @@ def main():
                          # with the value dictionary the kernel moves 2 B a slot instead of 8: the plain-CSR bytes it REPLACES per second
                          # can exceed the HBM peak (frac > 1); what it really moves per second is hbm_gbps / hbm_frac below
                          "value_dictionary_entries": vdn,
+                         "note": ("frac > 1 is not a measurement error: `achieved` prices the launch in the plain-CSR bytes of SURVEY 8(d) "
+                                  "(12 B per nonzero), and this kernel streams 2 B of value code + 1/2 B of column gap per slot instead of 8 + 1/2 "
+                                  f"(the {vdn} distinct values of the assembled matrix sit in LDS; lossless, same bits). Its real rate is hbm_gbps / hbm_frac; "
+                                  "PFEM_SPMV_VALDICT=0 runs the fp64 copy (0.89-0.95 of the peak in the same bytes)") if vdn else None,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "format_bytes_per_launch": fmt_bytes,
                          "hbm_gbps": hbm_bytes / (avg_spmv_ms * 1e-3) / 1e9 if acc["spmv_n"] else 0.0,
