@@ -579,6 +579,7 @@ def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=Fa
     R["amg"] = solver.amgInfo() if R["pc_in_effect"] == "gamg" else None
     R["amg_layout"] = solver.amgLayout() if R["pc_in_effect"] == "gamg" else None
     R["amg_cycle"] = solver.amgCycle() if R["pc_in_effect"] == "gamg" else None
+    R["amg_vd"] = solver.amgValueDictionaries() if R["pc_in_effect"] == "gamg" else None
     R.update(N=int(N), sz=sz, axis=axis, elapsed=elapsed, its=its, reason=reason, rnorm=rnorm, acc=acc, info=info,
              event_overhead_ms=tm["event_overhead_ms"] if tm else 0.0, cinfo=solver.commInfo(),
              fmt_bytes=solver.spmvFormatBytes(), value_dict=solver.spmvValueDictionary(), gap_table=solver.spmvGapTable(), gap_escapes=solver.spmvGapEscapes(), bits=solver.spmvColumnBits(),
@@ -906,6 +907,8 @@ def main():
                                 # -pc_mg_cycle_type (--cycle; V unless asked: W halves the iterations on matched aggregates and costs
                                 # twice the time, LAB_NOTES round 5)
                                 "cycle": R["amg_cycle"]["cycle"], "last_level_visited_twice": R["amg_cycle"]["last_level_visited_twice"],
+                                # levels whose SpMVs stream 16-bit value codes into a dictionary of the level's distinct values (0: fp64 values)
+                                "value_dictionary_entries_per_level": R["amg_vd"],
                                 "distributed_levels": R["amg_layout"]["distributed_levels"] if world > 1 else None,
                                 "communication_per_cycle": ({"neighbour_exchanges": R["amg_layout"]["exchanges_per_cycle"],
                                                              "all_reduces": R["amg_layout"]["allreduces_per_cycle"],

@@ -54,6 +54,9 @@ int pfem_solver_get_spmv_gap_table(pfem_solver *s, int *entries);
  * doubles -- the same doubles, the same products, the same bits, 2 B a slot instead of 8.  *entries = the dictionary's size
  * after the last solve / product, 0 when the fp64 copy is streamed (PFEM_SPMV_VALDICT=0 turns the form off).               */
 int pfem_solver_get_spmv_value_dictionary(pfem_solver *s, int *entries);
+/* ... and per level of the last gamg hierarchy (scalar coarse levels of >= 2^20 slots on one rank take the form too: the Galerkin
+ * sums over the bricks of a lattice repeat like the element matrices do): entries[l] = the level's dictionary size, 0 = fp64 values */
+int pfem_solver_amg_value_dictionaries(pfem_solver *s, int max_levels, int *n_levels, int *entries);
 /* 1 when the row form streams 16-bit gaps WITH ESCAPES (k_spmv16e: the code 0xffff sends a column to the matrix's int32 column
  * array -- numberings whose far neighbours are too many and too irregular for the table: partition-renumbered and
  * curve-ordered meshes; taken when at most a quarter of the entries escape), else 0.  Same bits as every other form.     */

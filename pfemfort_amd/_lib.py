@@ -107,6 +107,7 @@ SIGNATURES = {
     "pfem_solver_get_spmv_row_group": [_P, _P],
     "pfem_solver_get_spmv_gap_table": [_P, _P],
     "pfem_solver_get_spmv_value_dictionary": [_P, _P],
+    "pfem_solver_amg_value_dictionaries": [_P, _I, _P, _P],
     "pfem_solver_get_spmv_gap_escapes": [_P, _P],
     "pfem_solver_spmv_bytes": [_P, _P],
     "pfem_solver_set_preconditioner": [_P, _I],

@@ -1358,6 +1358,57 @@ __global__ void __launch_bounds__(kBlock) k_amg_spmv_ep(SellDev A, const double 
     }
 }
 
+// the same kernel over 16-bit value codes (pfem_valdict.hpp): v = dict[code], the dictionary in LDS; same products in the same order
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_amg_spmv_ep_vd(SellDev A, const uint16_t *__restrict__ codes, const double *__restrict__ dict, int nd,
+                                                            const double *__restrict__ xin, const double *r_in, const double *__restrict__ dinv,
+                                                            const double *__restrict__ lam, double ratio, int step, int add_dd0, double *r_out,
+                                                            double *dd_out, double *x, const CgCtl *ctl)
+{
+    extern __shared__ double vd[];
+    if (ctl && ctl->flag != 0) return;
+    for (int i = threadIdx.x; i < nd; i += kBlock) vd[i] = dict[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t s = (static_cast<int64_t>(blockIdx.x) << 2) + wave;
+    if (s >= A.n_slices) return;
+    const int64_t off = A.slice_off[s];
+    const int width = static_cast<int>((A.slice_off[s + 1] - off) >> 6);
+    const int32_t *__restrict__ cp = A.cols + off + lane;
+    const uint16_t *__restrict__ qp = codes + off + lane;
+    double acc = 0.0;
+    int k = 0;
+    for (; k + 4 <= width; k += 4) {
+        int c[4];
+        uint16_t q[4];
+        double xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c[j] = cp[64 * (k + j)]; q[j] = qp[64 * (k + j)]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = xin[c[j]];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_fma(vd[q[j]], xv[j], acc);
+    }
+    for (; k < width; ++k) acc = __builtin_fma(vd[qp[64 * k]], xin[cp[64 * k]], acc);
+    const int64_t i = (s << 6) + lane;
+    if (i >= A.n_rows) return;
+    if (MODE == kEpResid) {
+        r_out[i] = r_in[i] - acc;
+    } else if (MODE == kEpFirstRes) {
+        const double ri = r_in[i] - acc;
+        r_out[i] = ri;
+        dd_out[i] = cheb_coef(lam[0], ratio, 0).c_first * dinv[i] * ri;
+    } else {
+        const ChebCoef c = cheb_coef(lam[0], ratio, step);
+        const double ri = r_in[i] - acc;
+        const double d0 = xin[i];
+        const double di = __builtin_fma(c.c_dd, d0, c.c_r * dinv[i] * ri);
+        double xv = x[i];
+        if (add_dd0) xv += d0;
+        x[i] = xv + di;
+    }
+}
+
 // coarse-level product of a hierarchy across the ranks: y = (this rank's share of A) x, the shared rows also into the send buffer
 __global__ void __launch_bounds__(kBlock) k_amg_spmv_pack(SellDev A, const double *__restrict__ xin, double *__restrict__ y, ShareSum S,
                                                            double *__restrict__ send, const CgCtl *ctl)

@@ -77,6 +77,13 @@ struct AmgLevel {
     int64_t nblk = 0;
     // smoother and work vectors (x and dd are SpMV inputs: on level 0 they carry the guard bands of the fast SpMV forms)
     DevBuf<double> dinv, t, r, b, x_store, dd_store, lam, part_max;
+    // values as 16-bit codes into a dictionary of the distinct ones (pfem_valdict.hpp; scalar coarse levels of a one-rank hierarchy
+    // whose Galerkin sums repeat -- bricks of a lattice): the fused SpMVs of the cycle stream 4 + 2 B a slot instead of 4 + 8
+    DevBuf<uint16_t> vcodes;
+    DevBuf<double> vdict;
+    DevBuf<unsigned long long> vtable;
+    int vd_n = 0;
+    bool vd_ok = false, vd_have_dict = false, vd_refused = false;
     double *x = nullptr, *dd = nullptr;
     DevBuf<double> x1;                    // W-cycle: the first visit's answer while the second is on its way
     double lam_host = 0.0;
@@ -137,5 +144,6 @@ struct Amg {
     int64_t rep_total = 0, rep_off = 0, rep_mine = 0;
     bool rbm = false;                                // some level carries rigid-body modes: eigenvalue bounds on the symmetrically scaled operators
     DevBuf<double> lam2;                             // ... scratch of that second bound
+    DevBuf<VdState> vd_states;                       // one verdict per level (amg_value_codes)
     int cycle_exchanges = 0, cycle_allreduces = 0;   // coupled: neighbour exchanges / all-reduces one V-cycle enqueues (counted by the last cycle)
 };

@@ -4861,6 +4861,20 @@ extern "C" int pfem_solver_set_amg_options(pfem_solver *s, int cheb_degree, int 
     return PFEM_OK;
 }
 
+// per level of the last hierarchy: distinct values in the level's dictionary when its SpMVs stream value codes, else 0
+// (level 0 = the assembled matrix: the figure of pfem_solver_get_spmv_value_dictionary)
+extern "C" int pfem_solver_amg_value_dictionaries(pfem_solver *s, int max_levels, int *n_levels, int *entries)
+{
+    if (!s || !n_levels || !entries || max_levels < 1) return PFEM_ERR_ARG;
+    *n_levels = 0;
+    if (!s->amg || !s->amg->symbolic_ok) return PFEM_OK;
+    for (const AmgLevelRef &r : amg_levels_of(*s->amg)) {
+        if (*n_levels >= max_levels) break;
+        entries[(*n_levels)++] = r.L->fine ? ((s->vd_ok && s->vd_current) ? s->vd_n : 0) : (r.L->vd_ok ? r.L->vd_n : 0);
+    }
+    return PFEM_OK;
+}
+
 // -pc_mg_cycle_type: 0 = left to the library (amg_cycle_shape), 1 = V, 2 = W
 extern "C" int pfem_solver_set_amg_cycle(pfem_solver *s, int cycle)
 {

@@ -109,7 +109,8 @@ __global__ void __launch_bounds__(kBlock) k_vd_encode(const double *__restrict__
                                                        VdState *st, unsigned long long *__restrict__ codes)
 {
     extern __shared__ uint64_t vd_keys[];
-    const int nd = st->count;
+    if (st->fail) return;                        // (a collection that overflowed: nothing to encode against)
+    const int nd = min(st->count, kVdMax);
     for (int i = threadIdx.x; i < nd; i += kBlock) vd_keys[i] = static_cast<uint64_t>(__double_as_longlong(dict[i]));
     __syncthreads();
     bool missed = false;
@@ -133,6 +134,32 @@ __global__ void __launch_bounds__(kBlock) k_vd_encode(const double *__restrict__
             w |= static_cast<unsigned long long>(lo) << (16 * p);
         }
         codes[i] = w;
+    }
+    if (missed) st->miss = 1;
+}
+
+// the same for a matrix in the row form (one row to the lane, slot k of lane l at off + 64 k + l): one 16-bit code per slot,
+// in the slot's own place (coarse levels of a brick hierarchy: their Galerkin sums repeat like the element matrices do)
+__global__ void __launch_bounds__(kBlock) k_vd_encode16(const double *__restrict__ vals, int64_t n_slots, const double *__restrict__ dict,
+                                                         VdState *st, uint16_t *__restrict__ codes)
+{
+    extern __shared__ uint64_t vd_keys[];
+    if (st->fail) return;
+    const int nd = min(st->count, kVdMax);
+    for (int i = threadIdx.x; i < nd; i += kBlock) vd_keys[i] = static_cast<uint64_t>(__double_as_longlong(dict[i]));
+    __syncthreads();
+    bool missed = false;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n_slots; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const uint64_t b = static_cast<uint64_t>(__double_as_longlong(__builtin_nontemporal_load(vals + i)));
+        int lo = 0, len = nd;
+        while (len > 0) {
+            const int half = len >> 1;
+            const bool right = vd_keys[lo + half] < b;
+            lo = right ? lo + half + 1 : lo;
+            len = right ? len - half - 1 : half;
+        }
+        if (lo >= nd || vd_keys[lo] != b) { missed = true; lo = 0; }
+        codes[i] = static_cast<uint16_t>(lo);
     }
     if (missed) st->miss = 1;
 }

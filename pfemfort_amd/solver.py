@@ -214,6 +214,14 @@ class PetscSolver:
         L.check(L.lib().pfem_solver_get_spmv_value_dictionary(self._h, C.byref(b)), "pfem_solver_get_spmv_value_dictionary")
         return b.value
 
+    def amgValueDictionaries(self):
+        """Per level of the last gamg hierarchy: distinct values in the level's dictionary when its SpMVs stream 16-bit value codes
+        (0: fp64 values)."""
+        n = C.c_int(0)
+        e = (C.c_int * 32)()
+        L.check(L.lib().pfem_solver_amg_value_dictionaries(self._h, 32, C.byref(n), e), "pfem_solver_amg_value_dictionaries")
+        return list(e[:n.value])
+
     def spmvGapEscapes(self):
         """True when the row form streams 16-bit gaps with escapes to the int32 column array (k_spmv16e)."""
         b = C.c_int(0)

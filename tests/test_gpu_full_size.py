@@ -130,6 +130,49 @@ def test_poisson_cube_full_size(n, N, nnz):
     assert its_g2 == its_g and np.array_equal(s.getSolution(), ug)
 
 
+def test_value_codes_on_the_matrix_and_on_the_coarse_levels_keep_every_bit(monkeypatch):
+    """pfem_valdict.hpp at a size where it is taken by itself (config 2: 242 575 groups of four rows, level 1 of the hierarchy
+    3.4 M slots): the CG SpMV and the fused SpMVs of the coarse levels stream 16-bit codes into dictionaries of the distinct
+    values -- and the gamg solve's residual history, its iterate, the Jacobi solve's and the plain product are the fp64 copy's bit for
+    bit; a second solve on re-assembled values re-uses the dictionaries (no new collection), values of another operator rebuild them."""
+    n = 100
+    sz = H.box_slab_sizes(n, n, n)
+    out = {}
+    for vd in ("0", "1"):
+        monkeypatch.setenv("PFEM_SPMV_VALDICT", vd)
+        s = pf.PetscSolver().initialise(sz["size_local"], sz["size_global"])
+        s.generateBoxMesh(pf.POISSON_TET, -1, 1, n, -1, 1, n, -1, 1, n, bc_mode=0)
+        s.buildPattern()
+        s.assemble(H.POISSON_ELEMDATA, H.TIMEDATA)
+        x = np.random.default_rng(5).standard_normal(sz["size_global"])
+        y = s.spmv(x)
+        s.setTolerances(rtol=1e-10, maxits=5000)
+        s.setPreconditioner("gamg")
+        its, reason, _ = s.factoriseAndSolve()
+        hg, ug = s.getHistory(), s.getSolution()
+        dicts = s.amgValueDictionaries()
+        assert reason == 2
+        if vd == "1":
+            assert s.spmvRowGroup() == 4 and 0 < dicts[0] <= 4096 and 0 < dicts[1] <= 4096 and dicts[-1] == 0, dicts
+        else:
+            assert not any(dicts)
+        s.assemble(H.POISSON_ELEMDATA, H.TIMEDATA)          # the same values again: same codes, same solve
+        its2, _, _ = s.factoriseAndSolve()
+        assert its2 == its and np.array_equal(s.getHistory(), hg) and np.array_equal(s.getSolution(), ug) and s.amgValueDictionaries() == dicts
+        s.assemble(np.array([1.3, 0.7, 2.1]), H.TIMEDATA)   # another operator on the same pattern
+        its3, reason3, _ = s.factoriseAndSolve()
+        h3, u3 = s.getHistory(), s.getSolution()
+        assert reason3 == 2
+        s.setPreconditioner("jacobi")
+        itj, reasonj, _ = s.factoriseAndSolve()
+        out[vd] = (y, its, hg, ug, its3, h3, u3, itj, s.getHistory(), s.getSolution())
+        s.free()
+    a, b = out["0"], out["1"]
+    assert (a[1], a[4], a[7]) == (b[1], b[4], b[7])
+    for i in (0, 2, 3, 5, 6, 8, 9):
+        assert np.array_equal(a[i], b[i]), i
+
+
 def test_elasticity_beam_config4():
     mesh = H.gen_box_tets(-0.5, 0.5, 50, 0.0, 6.0, 300, -0.5, 0.5, 50, bc_mode=1, ndof=3)
     mesh.box_args = (-0.5, 0.5, 50, 0.0, 6.0, 300, -0.5, 0.5, 50, 1, 3)
