@@ -44,6 +44,10 @@ __global__ void __launch_bounds__(kBlock) k_vd_collect(const double *__restrict_
     const volatile int *failed = &st->fail;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
         const uint64_t b = static_cast<uint64_t>(__double_as_longlong(__builtin_nontemporal_load(vals + i)));
+        // neighbouring lanes hold the same slot of neighbouring rows -- on a lattice mostly the same value: only the first lane of
+        // a run looks it up (a lane that is active has an active left neighbour: its index is smaller)
+        const uint64_t left = static_cast<uint64_t>(__shfl_up(static_cast<unsigned long long>(b), 1));
+        if ((threadIdx.x & 63) != 0 && left == b) continue;
         const uint32_t h = vd_hash(b);
         if (seen[h & 1023u] == b) continue;
         if (*failed) return;
