@@ -174,37 +174,47 @@ __global__ void __launch_bounds__(kBlock) k_spmvr_vd(SellRDev G, const unsigned 
                                                       int64_t n_rows, const double *__restrict__ x, double *__restrict__ y, int64_t n_dot,
                                                       double *partial, const CgCtl *ctl, SliceSel sel)
 {
+    const unsigned vblock = blockIdx.x;
     extern __shared__ double vd[];
     __shared__ double sm[4];
     __shared__ uint32_t gap_tbl[DICT ? kGapTable : 1];
     if (WITH_DOT && ctl->flag != 0) return;
+    // A wave's life is a chain of memory latencies (rocprofv3 --pmc: 58 % of the wave cycles waiting; with an XCD-contiguous block
+    // order the fabric traffic falls from 0.59 GB to its ideal 0.36 GB and the time does not move -- LAB_NOTES): slice header ->
+    // first entry -> trips of four entries -> remainder.  So the header, the first entry's operands and the first gap words are requested BEFORE the dictionary is copied to LDS,
+    // the first entry's product is formed under the first trip's loads, and the remainder (<= 3 entries) is ONE trip whose loads
+    // go out together instead of a loop of dependent ones.  Same operands into the same fma chain: same bits.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t gs = pick_slice(sel, (static_cast<int64_t>(vblock) << 2) + wave, G.n_gslices);
+    const bool live = gs < G.n_gslices;
+    int width = 0, nw = 0, c = 0;
+    uint32_t w0 = 0, w1 = 0;
+    const unsigned long long *__restrict__ qp = codes + lane;
+    const uint32_t *__restrict__ wp = G.dwords + lane;
+    double x0[kRelRows] = {0.0, 0.0, 0.0, 0.0};
+    unsigned long long q0 = 0;
+    if (live) {
+        const int64_t off = G.gslice_off[gs];
+        width = static_cast<int>((G.gslice_off[gs + 1] - off) >> 6);
+        nw = width / 2;
+        qp = codes + off + lane;
+        wp = G.dwords + G.gslice_doff[gs] + lane;
+        c = __builtin_nontemporal_load(G.col0 + (gs << 6) + lane);
+        if (nw > 0) w0 = __builtin_nontemporal_load(wp);
+        if (nw > 1) w1 = __builtin_nontemporal_load(wp + 64);
+        if (width > 0) { load_x4(x, c, x0); q0 = __builtin_nontemporal_load(qp); }
+    }
     for (int i = threadIdx.x; i < nd; i += kBlock) vd[i] = dict[i];
     if (DICT) gap_tbl[DICT ? threadIdx.x : 0] = G.gap_table[threadIdx.x];
     __syncthreads();
     const auto gap_of = [&](uint32_t code) -> int {
         return (DICT && (code & 0x8000u)) ? static_cast<int>(gap_tbl[DICT ? (code & (kGapTable - 1)) : 0]) : static_cast<int>(code);
     };
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t gs = pick_slice(sel, (static_cast<int64_t>(blockIdx.x) << 2) + wave, G.n_gslices);
     double dot = 0.0;
-    if (gs < G.n_gslices) {
-        const int64_t off = G.gslice_off[gs];
-        const int width = static_cast<int>((G.gslice_off[gs + 1] - off) >> 6);
-        const unsigned long long *__restrict__ qp = codes + off + lane;
-        const uint32_t *__restrict__ wp = G.dwords + G.gslice_doff[gs] + lane;
-        int c = __builtin_nontemporal_load(G.col0 + (gs << 6) + lane);
+    if (live) {
         double acc[kRelRows] = {0.0, 0.0, 0.0, 0.0};
-        if (width > 0) {
-            double xv[kRelRows];
-            load_x4(x, c, xv);
-            const unsigned long long q = __builtin_nontemporal_load(qp);
-#pragma unroll
-            for (int p = 0; p < kRelRows; ++p) acc[p] = vd[(q >> (16 * p)) & 0xffffu] * xv[p];
-        }
-        const int nw = width / 2;
+        bool first_pending = width > 0;
         int j = 0;
-        uint32_t w0 = 0, w1 = 0;
-        if (2 * (j + 2) < width) { w0 = __builtin_nontemporal_load(wp + 64 * j); w1 = __builtin_nontemporal_load(wp + 64 * (j + 1)); }
         while (2 * (j + 2) < width) {
             const int c0 = c + gap_of(w0 & 0xffffu), c1 = c0 + gap_of(w0 >> 16);
             const int c2 = c1 + gap_of(w1 & 0xffffu), c3 = c2 + gap_of(w1 >> 16);
@@ -215,29 +225,48 @@ __global__ void __launch_bounds__(kBlock) k_spmvr_vd(SellRDev G, const unsigned 
             for (int t = 0; t < 4; ++t) q[t] = __builtin_nontemporal_load(qp + 64 * (2 * j + 1 + t));
             c = c3;
             j += 2;
-            if (2 * (j + 2) < width) { w0 = __builtin_nontemporal_load(wp + 64 * j); w1 = __builtin_nontemporal_load(wp + 64 * (j + 1)); }
+            w0 = j < nw ? __builtin_nontemporal_load(wp + 64 * j) : 0u;              // (the next trip's gaps, or the remainder's)
+            w1 = j + 1 < nw ? __builtin_nontemporal_load(wp + 64 * (j + 1)) : 0u;
             __builtin_amdgcn_sched_barrier(0);
+            if (first_pending) {
+#pragma unroll
+                for (int p = 0; p < kRelRows; ++p) acc[p] = vd[(q0 >> (16 * p)) & 0xffffu] * x0[p];
+                first_pending = false;
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int p = 0; p < kRelRows; ++p) acc[p] = __builtin_fma(vd[(q[t] >> (16 * p)) & 0xffffu], xv[t][p], acc[p]);
         }
-        for (; j < nw; ++j) {
-            const uint32_t w = __builtin_nontemporal_load(wp + 64 * j);
-            const int c0 = c + gap_of(w & 0xffffu);
-            const int c1 = c0 + gap_of(w >> 16);
-            double xv[kRelRows];
-            load_x4(x, c0, xv);
-            const unsigned long long qa = __builtin_nontemporal_load(qp + 64 * (2 * j + 1));
+        const int rem = width - 1 - 2 * j;          // 0 .. 3 entries are left (the same for the whole wave)
+        if (rem > 0) {
+            const int c0 = c + gap_of(w0 & 0xffffu), c1 = c0 + gap_of(w0 >> 16), c2 = c1 + gap_of(w1 & 0xffffu);
+            unsigned long long q[3] = {0, 0, 0};
+            double xv[3][kRelRows];
+            load_x4(x, c0, xv[0]);
+            q[0] = __builtin_nontemporal_load(qp + 64 * (2 * j + 1));
+            if (rem > 1) { load_x4(x, c1, xv[1]); q[1] = __builtin_nontemporal_load(qp + 64 * (2 * j + 2)); }
+            if (rem > 2) { load_x4(x, c2, xv[2]); q[2] = __builtin_nontemporal_load(qp + 64 * (2 * j + 3)); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (first_pending) {
 #pragma unroll
-            for (int p = 0; p < kRelRows; ++p) acc[p] = __builtin_fma(vd[(qa >> (16 * p)) & 0xffffu], xv[p], acc[p]);
-            if (2 * j + 2 < width) {
-                load_x4(x, c1, xv);
-                const unsigned long long qb = __builtin_nontemporal_load(qp + 64 * (2 * j + 2));
-#pragma unroll
-                for (int p = 0; p < kRelRows; ++p) acc[p] = __builtin_fma(vd[(qb >> (16 * p)) & 0xffffu], xv[p], acc[p]);
+                for (int p = 0; p < kRelRows; ++p) acc[p] = vd[(q0 >> (16 * p)) & 0xffffu] * x0[p];
+                first_pending = false;
             }
-            c = c1;
+#pragma unroll
+            for (int p = 0; p < kRelRows; ++p) acc[p] = __builtin_fma(vd[(q[0] >> (16 * p)) & 0xffffu], xv[0][p], acc[p]);
+            if (rem > 1) {
+#pragma unroll
+                for (int p = 0; p < kRelRows; ++p) acc[p] = __builtin_fma(vd[(q[1] >> (16 * p)) & 0xffffu], xv[1][p], acc[p]);
+            }
+            if (rem > 2) {
+#pragma unroll
+                for (int p = 0; p < kRelRows; ++p) acc[p] = __builtin_fma(vd[(q[2] >> (16 * p)) & 0xffffu], xv[2][p], acc[p]);
+            }
+        }
+        if (first_pending) {
+#pragma unroll
+            for (int p = 0; p < kRelRows; ++p) acc[p] = vd[(q0 >> (16 * p)) & 0xffffu] * x0[p];
         }
         const int64_t r0 = ((gs << 6) + lane) * kRelRows;
 #pragma unroll
@@ -249,7 +278,7 @@ __global__ void __launch_bounds__(kBlock) k_spmvr_vd(SellRDev G, const unsigned 
     }
     if (WITH_DOT) {
         const double t = block_sum(dot, sm);
-        if (threadIdx.x == 0) partial[blockIdx.x] = t;
+        if (threadIdx.x == 0) partial[vblock] = t;
     }
 }
 
