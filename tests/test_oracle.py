@@ -231,6 +231,13 @@ def test_lattice_brick_aggregates_restatement(tet10):
     x, its, reason, *_ = O.pcg_amg(p30.rowptr, p30.cols, p30.vals, p30.rhs, aggs, eig_ratio=16.0, rtol=1e-10)
     _, its_j, *_ = O.pcg_jacobi(p30.rowptr, p30.cols, p30.vals, p30.rhs, rtol=1e-10)
     assert reason == 2 and its < its_j // 4
+    # -pc_mg_cycle_type w (gamma = 2: every coarse problem that is not the last visited twice, the second time on the residual of
+    # the first): still a symmetric positive definite preconditioner (CG converges, reason 2), never more iterations than the
+    # V-cycle, the same answer; restricted to level 1 (gamma_to) it lies between the two
+    xw, its_w, reason_w, *_ = O.pcg_amg(p30.rowptr, p30.cols, p30.vals, p30.rhs, aggs, eig_ratio=16.0, rtol=1e-10, gamma=2)
+    xw1, its_w1, reason_w1, *_ = O.pcg_amg(p30.rowptr, p30.cols, p30.vals, p30.rhs, aggs, eig_ratio=16.0, rtol=1e-10, gamma=2, gamma_to=1)
+    assert reason_w == 2 and reason_w1 == 2 and its_w <= its_w1 <= its and its_w < its
+    assert np.abs(xw - x).max() <= 1e-8 * np.abs(x).max() and np.abs(xw1 - x).max() <= 1e-8 * np.abs(x).max()
     # the plane: 19 x 19 free nodes of the tria20x20 mesh: x, y, x halved on the first level (aggregates of 4 x 2 nodes)
     g = np.meshgrid(np.arange(21.0), np.arange(21.0), indexing="ij")
     xy = np.stack([g[0].ravel(), g[1].ravel()])
