@@ -241,11 +241,13 @@ def test_elasticity_beam_config4():
     s.setPreconditioner("gamg")
     its_g10, reason, _ = s.factoriseAndSolve()
     ug = s.getSolution()
-    assert reason == 2 and its_g10 <= 60 and np.abs(ug - uj).max() <= 1e-6 * np.abs(uj).max(), (its_g10, its_j10)
+    assert reason == 2 and its_g10 <= 75 and np.abs(ug - uj).max() <= 1e-6 * np.abs(uj).max(), (its_g10, its_j10)
     info = s.amgInfo()
     tr = [s.amgTransfer(l) for l in range(info["levels"] - 1)]
     assert all(t["rbm"] and t["coarse_bs"] == 6 and t["dim"] == 3 for t in tr) and tr[0]["fine_bs"] == 3 and all(t["fine_bs"] == 6 for t in tr[1:])
-    assert info["rows"][:2] == [2340900, 558750]           # 6 x (25 x 149 x 25) bricks of 2 (3 at the odd end of a line)
+    # level 0 of a displacement problem takes bricks of 4 nodes along an axis of 24 and more (3 from 6 on): 6 x (13 x 75 x 13) --
+    # positions 0..50 give 12 bricks of 4 and one of 3, positions 1..300 one of 3, 73 of 4 and one of 5 --, then bricks of 2
+    assert info["rows"][:3] == [2340900, 6 * 13 * 75 * 13, 6 * 6 * 37 * 6], info["rows"]
     s.setTolerances(rtol=1e-5, maxits=100000)
     its_g, reason, _ = s.factoriseAndSolve()
     assert reason == 2 and its_g <= 30 and its_g * 100 < its_j, (its_g, its_j)
