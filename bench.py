@@ -47,7 +47,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 def pmc_traffic(nnz, value_dict=False):
     """HBM bytes per launch of the CG SpMV from the committed rocprofv3 PMC passes
-    (profiles/spmv_pmc_traffic.json, written by tools/gpu_round.sh on the SAME workload in a
+    (profiles/spmv_pmc_traffic.json, written by tools/r05/collect_final.py from the passes of tools/r05/final.sh on the SAME workload in a
     builder lease, not in this run): (2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH_SIZE doubled per
     MI355X_MICROARCH.md section HBM.  Returns (bytes, source) or (None, None)."""
     path = os.path.join(ROOT, "profiles", "spmv_pmc_traffic.json")
@@ -931,7 +931,7 @@ def main():
                                  "event_ms_per_step": acc["asm_ms"] / args.steps,
                                  "bound": "fp64-valu-issue",
                                  "valu_issue_fraction_replayed_not_this_run": 0.75,
-                                 "valu_issue_source": "profiles/r04/gather_kernels_sq_counters.txt (rocprofv3 --pmc SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE, tools/r04/gather_sq_counters.sh)",
+                                 "valu_issue_source": "profiles/r04/gather_kernels_sq_counters.txt (rocprofv3 --pmc SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE, tools/r04/gather_sq_counters.sh in the history)",
                                  "hbm_frac_of_compulsory_bytes": (3.75e9 / (acc["asm_ms"] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBPS)
                                  if (not beam and world == 1 and args.n == 200 and args.numbering == "lattice" and args.jitter <= 0.0) else None}
                                 if (not beam and world == 1) else None),
