@@ -535,6 +535,18 @@ struct pfem_solver {
     int vd_rows = 0, vd_n = 0;
     bool vd_current = false, vd_ok = false, vd_have_dict = false, vd_refused = false;
     double vd_encode_ms = 0.0;       // (host time of the last refresh incl. its wait: PFEM_VD_VERBOSE)
+    // the inverse diagonal of the Jacobi loop as codes (DinvView): encoded after every k_invert of a solve whose matrix streams
+    // codes, verdict on the device
+    DevBuf<uint16_t> d_dcodes;
+    DevBuf<double> d_ddict;
+    DevBuf<unsigned long long> d_dtable;
+    DevBuf<VdState> d_dstate;
+    bool dinv_codes = false;         // this solve's kernels are given the codes
+    DinvView dinv_view() const
+    {
+        return dinv_codes ? DinvView{d_dinv.p, d_dcodes.p, d_ddict.p, reinterpret_cast<const int *>(d_dstate.p)}
+                          : DinvView{d_dinv.p, nullptr, nullptr, nullptr};
+    }
     bool use_rel() const
     {
         return relgrouped && !use_grouped() &&
@@ -2594,6 +2606,28 @@ int refresh_group_vals_only(pfem_solver *s)
     return PFEM_OK;
 }
 
+// codes of the inverse diagonal for the Jacobi loop (DinvView), enqueued behind k_invert; nobody waits for the verdict
+int encode_dinv(pfem_solver *s, int64_t n)
+{
+    const bool enabled = [] { const char *e = std::getenv("PFEM_SPMV_VALDICT"); return e ? std::atoi(e) != 0 : true; }();
+    s->dinv_codes = false;
+    if (!enabled || !(s->vd_ok && s->vd_current) || n < (1 << 19)) return PFEM_OK;          // (a matrix that repeats its values: so does its diagonal)
+    if (s->d_dcodes.n < static_cast<size_t>(n)) PFEM_TRY(s->d_dcodes.alloc(static_cast<size_t>(n)));
+    if (!s->d_ddict.p) PFEM_TRY(s->d_ddict.alloc(kVdMax));
+    if (!s->d_dtable.p) PFEM_TRY(s->d_dtable.alloc(kVdTable));
+    if (!s->d_dstate.p) PFEM_TRY(s->d_dstate.alloc(1));
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>((n + kBlock - 1) / kBlock, 4096));
+    PFEM_HIP(hipMemsetAsync(s->d_dtable.p, 0xff, sizeof(unsigned long long) * kVdTable, s->stream));
+    PFEM_HIP(hipMemsetAsync(s->d_dstate.p, 0, sizeof(VdState), s->stream));
+    hipLaunchKernelGGL(k_vd_collect, dim3(grid), dim3(kBlock), 0, s->stream, static_cast<const double *>(s->d_dinv.p), n, s->d_dtable.p, s->d_dstate.p);
+    hipLaunchKernelGGL(k_vd_finish, dim3(1), dim3(1024), 0, s->stream, static_cast<const unsigned long long *>(s->d_dtable.p), s->d_ddict.p, s->d_dstate.p);
+    hipLaunchKernelGGL(k_vd_encode16, dim3(grid), dim3(kBlock), sizeof(uint64_t) * kVdMax, s->stream, static_cast<const double *>(s->d_dinv.p), n,
+                       static_cast<const double *>(s->d_ddict.p), s->d_dstate.p, s->d_dcodes.p);
+    PFEM_TRY(check_kernel("inverse diagonal: value codes"));
+    s->dinv_codes = true;
+    return PFEM_OK;
+}
+
 inline unsigned spmv_blocks(const pfem_solver *s)
 {
     return s->use_grouped() ? spmv_grid(s->n_gslices) : (s->use_rel() ? spmv_grid(s->n_rslices) : spmv_grid(s->n_slices));
@@ -3597,7 +3631,7 @@ inline int spmv_form(const pfem_solver *s)
 // ... and what a captured launch of it depends on besides (value dictionary in use, its size)
 inline uint64_t spmv_key(const pfem_solver *s)
 {
-    return static_cast<uint64_t>(spmv_form(s)) | ((s->vd_ok && s->vd_current) ? (static_cast<uint64_t>(s->vd_n + 1) << 8) : 0) |
+    return static_cast<uint64_t>(spmv_form(s)) | ((s->vd_ok && s->vd_current) ? (static_cast<uint64_t>(s->vd_n + 1) << 8) : 0) | (s->dinv_codes ? 1ull << 7 : 0) |
            (static_cast<uint64_t>(reinterpret_cast<uintptr_t>(s->d_vcodes.p)) << 24);
 }
 
@@ -3874,6 +3908,7 @@ int run_pcg(pfem_solver *s)
         hipLaunchKernelGGL(k_invert, dim3(grid_for(n)), block, 0, s->stream, s->d_dinv.p, n);
         PFEM_TRY(check_kernel("k_invert"));
     }
+    PFEM_TRY(encode_dinv(s, n));
 
     hipLaunchKernelGGL(k_cg_init, dim3(gv), block, 0, s->stream, n, s->n_owned, s->d_rhs.p, s->d_dinv.p, s->d_x.p, s->d_r.p,
                        s->d_p.p, part_rz, part_zz);
@@ -3930,10 +3965,10 @@ int run_pcg(pfem_solver *s)
                             pw_n = kFoldBlocks;
                         }
                         hipLaunchKernelGGL(k_cg_update, dim3(gv), block, 0, s->stream, ctl, -1, n, s->n_owned, pw_parts, pw_n,
-                                           static_cast<const double *>(nullptr), s->d_p.p, s->d_w.p, s->d_dinv.p, s->d_x.p, s->d_r.p,
+                                           static_cast<const double *>(nullptr), s->d_p.p, s->d_w.p, s->dinv_view(), s->d_x.p, s->d_r.p,
                                            part_rz, part_zz);
                         hipLaunchKernelGGL(k_cg_direction, dim3(gv), block, 0, s->stream, ctl, -1, n, part_rz, part_zz,
-                                           static_cast<int>(gv), static_cast<const double *>(nullptr), s->d_r.p, s->d_dinv.p, s->d_p.p,
+                                           static_cast<int>(gv), static_cast<const double *>(nullptr), s->d_r.p, s->dinv_view(), s->d_p.p,
                                            s->d_hist.p, s->hist_cap, s->maxits, s->d_x.p);
                     }
                     if (hipStreamEndCapture(s->stream, &graph) != hipSuccess || !graph) { ok = false; break; }
@@ -4008,14 +4043,14 @@ int run_pcg(pfem_solver *s)
     auto multi_iteration = [&](int it_arg, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t *cev) -> int {
         PFEM_TRY(multi_spmv_exchange(e0, e1, e2, e3, cev));
         hipLaunchKernelGGL(k_cg_update, dim3(gv), block, 0, s->stream, ctl, it_arg, n, s->n_owned, static_cast<const double *>(part_pw),
-                           0, static_cast<const double *>(sbuf), s->d_p.p, s->d_w.p, s->d_dinv.p, s->d_x.p, s->d_r.p, part_rz, part_zz);
+                           0, static_cast<const double *>(sbuf), s->d_p.p, s->d_w.p, s->dinv_view(), s->d_x.p, s->d_r.p, part_rz, part_zz);
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, s->stream, static_cast<const double *>(part_rz),
                            static_cast<const double *>(part_zz), static_cast<int>(gv), sbuf + 2, static_cast<const CgCtl *>(ctl));
         if (cev) PFEM_HIP(hipEventRecord(cev[4], s->stream));
         PFEM_TRY(timed([&] { return s->comm->allreduce(sbuf + 2, 2, s->stream); }));
         if (cev) PFEM_HIP(hipEventRecord(cev[5], s->stream));
         hipLaunchKernelGGL(k_cg_direction, dim3(gv), block, dir_lds, s->stream, ctl, it_arg, n, part_rz, part_zz, static_cast<int>(gv),
-                           red2, s->d_r.p, s->d_dinv.p, s->d_p.p, s->d_hist.p, s->hist_cap, s->maxits, s->d_x.p);
+                           red2, s->d_r.p, s->dinv_view(), s->d_p.p, s->d_hist.p, s->hist_cap, s->maxits, s->d_x.p);
         return PFEM_OK;
     };
 
@@ -4168,9 +4203,9 @@ int run_pcg(pfem_solver *s)
                 continue;
             }
             hipLaunchKernelGGL(k_cg_update, dim3(gv), block, 0, s->stream, ctl, it, n, s->n_owned, pw_parts, pw_n,
-                               red_pw, s->d_p.p, s->d_w.p, s->d_dinv.p, s->d_x.p, s->d_r.p, part_rz, part_zz);
+                               red_pw, s->d_p.p, s->d_w.p, s->dinv_view(), s->d_x.p, s->d_r.p, part_rz, part_zz);
             hipLaunchKernelGGL(k_cg_direction, dim3(gv), block, dir_lds, s->stream, ctl, it, n, part_rz, part_zz, static_cast<int>(gv),
-                               red2, s->d_r.p, s->d_dinv.p, s->d_p.p, s->d_hist.p, s->hist_cap, s->maxits, s->d_x.p);
+                               red2, s->d_r.p, s->dinv_view(), s->d_p.p, s->d_hist.p, s->hist_cap, s->maxits, s->d_x.p);
         }
         PFEM_TRY(check_kernel("pcg iteration"));
         s->tm.host_enqueue_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_chunk).count();

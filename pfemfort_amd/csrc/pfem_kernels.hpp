@@ -2107,13 +2107,26 @@ __global__ void __launch_bounds__(kBlock) k_cg_start(CgCtl *ctl, const double *p
     }
 }
 
+// The inverse diagonal as the Jacobi loop's two vector kernels read it: doubles, or -- where the diagonal repeats its values like
+// the matrix does (structured meshes; pfem_valdict.hpp) -- 16-bit codes into a dictionary of the distinct ones: 2 B a row
+// instead of 8 in each of the two kernels of an iteration, 94 MB of 630 at config 3.  The verdict of the encoding stays on the
+// device (state[1]: the collection overflowed, state[2]: a value missing): the kernels branch on it, the host never waits.
+struct DinvView {
+    const double *dinv;
+    const uint16_t *codes;      // null: doubles only
+    const double *dict;
+    const int *state;
+    __device__ __forceinline__ bool coded() const { return codes != nullptr && state[1] == 0 && state[2] == 0; }
+    __device__ __forceinline__ double at(int64_t i, bool use_codes) const { return use_codes ? dict[codes[i]] : dinv[i]; }
+};
+
 // alpha = beta/(p,w); r -= alpha w; partials of (r,z), (z,z), z = r*dinv.  The solution update x += alpha p
 // is done by k_cg_direction, which holds p anyway (alpha travels in ctl): same-box A/B -1.3 % per iteration.
 // `it_arg` < 0 (launches replayed from a hipGraph): the iteration index is taken from the control block.
 __global__ void __launch_bounds__(kBlock) k_cg_update(CgCtl *ctl, int it_arg, int64_t n, int64_t n_owned,
                                                        const double *part_pw, int nparts, const double *reduced_pw,
                                                        const double *__restrict__ p, const double *__restrict__ w,
-                                                       const double *__restrict__ dinv, double *__restrict__ x,
+                                                       DinvView dinv, double *__restrict__ x,
                                                        double *__restrict__ r, double *part_rz, double *part_zz)
 {
     __shared__ double sm[4];
@@ -2132,11 +2145,12 @@ __global__ void __launch_bounds__(kBlock) k_cg_update(CgCtl *ctl, int it_arg, in
     const double alpha = ctl->beta[it & 1] / pw;
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->alpha = alpha;
     double rz = 0.0, zz = 0.0;
+    const bool dc = dinv.coded();
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
          i += static_cast<int64_t>(gridDim.x) * kBlock) {
         const double ri = __builtin_fma(-alpha, w[i], r[i]);
         r[i] = ri;
-        const double zi = ri * dinv[i];
+        const double zi = ri * dinv.at(i, dc);
         if (i < n_owned) { rz = __builtin_fma(ri, zi, rz); zz = __builtin_fma(zi, zi, zz); }
     }
     const double a = block_sum(rz, sm), c = block_sum(zz, sm);
@@ -2147,7 +2161,7 @@ __global__ void __launch_bounds__(kBlock) k_cg_update(CgCtl *ctl, int it_arg, in
 // KSPCG the test follows the update; on a breakdown x is not advanced); convergence test; p = z + (beta_new/beta) p
 __global__ void __launch_bounds__(kBlock) k_cg_direction(CgCtl *ctl, int it_arg, int64_t n, const double *part_rz,
                                                           const double *part_zz, int nparts, const double *reduced,
-                                                          const double *__restrict__ r, const double *__restrict__ dinv,
+                                                          const double *__restrict__ r, DinvView dinv,
                                                           double *__restrict__ p, double *hist, int hist_cap, int maxits, double *__restrict__ x)
 {
     __shared__ double sm[4];
@@ -2183,11 +2197,12 @@ __global__ void __launch_bounds__(kBlock) k_cg_direction(CgCtl *ctl, int it_arg,
         return;
     }
     const double bb = rz / beta_old;
+    const bool dc = dinv.coded();
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
          i += static_cast<int64_t>(gridDim.x) * kBlock) {
         const double pi = p[i];
         __builtin_nontemporal_store(__builtin_fma(alpha, pi, __builtin_nontemporal_load(x + i)), x + i);
-        p[i] = __builtin_fma(bb, pi, r[i] * dinv[i]);
+        p[i] = __builtin_fma(bb, pi, r[i] * dinv.at(i, dc));
     }
 }
 
