@@ -2611,7 +2611,10 @@ int encode_dinv(pfem_solver *s, int64_t n)
 {
     const bool enabled = [] { const char *e = std::getenv("PFEM_SPMV_VALDICT"); return e ? std::atoi(e) != 0 : true; }();
     s->dinv_codes = false;
-    if (!enabled || !(s->vd_ok && s->vd_current) || n < (1 << 19)) return PFEM_OK;          // (a matrix that repeats its values: so does its diagonal)
+    // (a matrix that repeats its values: so does its diagonal.  From 2^21 rows on: the encoding costs ~0.5 ms a solve -- the
+    // one-workgroup sort of the dictionary most of it --, which 191 iterations at 100^3 do not earn back: 8.8 -> 10.0 ms there)
+    const int64_t min_rows = [] { const char *e = std::getenv("PFEM_DINV_CODES_MIN_ROWS"); return e ? std::atoll(e) : static_cast<long long>(1 << 21); }();
+    if (!enabled || !(s->vd_ok && s->vd_current) || n < min_rows) return PFEM_OK;
     if (s->d_dcodes.n < static_cast<size_t>(n)) PFEM_TRY(s->d_dcodes.alloc(static_cast<size_t>(n)));
     if (!s->d_ddict.p) PFEM_TRY(s->d_ddict.alloc(kVdMax));
     if (!s->d_dtable.p) PFEM_TRY(s->d_dtable.alloc(kVdTable));

@@ -138,6 +138,7 @@ def test_value_codes_on_the_matrix_and_on_the_coarse_levels_keep_every_bit(monke
     n = 100
     sz = H.box_slab_sizes(n, n, n)
     out = {}
+    monkeypatch.setenv("PFEM_DINV_CODES_MIN_ROWS", "1")      # (the Jacobi loop's diagonal as codes too: by itself from 2^21 rows on)
     for vd in ("0", "1"):
         monkeypatch.setenv("PFEM_SPMV_VALDICT", vd)
         s = pf.PetscSolver().initialise(sz["size_local"], sz["size_global"])
