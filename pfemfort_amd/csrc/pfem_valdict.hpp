@@ -90,9 +90,11 @@ __global__ void __launch_bounds__(1024) k_vd_finish(const unsigned long long *__
     __syncthreads();
     const int n = n_found;
     if (n > kVdMax) { if (threadIdx.x == 0) st->fail = 1; return; }
-    for (int k = 2; k <= kVdMax; k <<= 1)
+    int m = 2;                               // (the sort runs over the next power of two above n: 601 values -> 1024 slots, 55 stages instead of 78 over 4096)
+    while (m < n) m <<= 1;
+    for (int k = 2; k <= m; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < kVdMax; i += 1024) {
+            for (int i = threadIdx.x; i < m; i += 1024) {
                 const int l = i ^ j;
                 if (l > i) {
                     const uint64_t a = key[i], c = key[l];
