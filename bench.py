@@ -76,6 +76,60 @@ def kernel_trace_figures(nnz, value_dict=False):
     return None
 
 
+def pmc_traffic_live(argv, timeout_s=240.0):
+    """HBM traffic of the CG SpMV measured IN THIS RUN: before this process touches the GPU, two child runs of the same command
+    (one step, no companions) under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` -- separate passes, the counters do not fit
+    one (MI355X_MICROARCH.md, rocprofv3 PMC slots) --, kernel filter on the SpMV family.  Returns a dict
+    {kernel name: {"FETCH_SIZE_KB", "WRITE_SIZE_KB", "dispatches"}} for the kernels of the WITH_DOT = true family (the CG's own
+    product), or a string saying why not.  The program after `--` is python3 itself (never a shell or env hop)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return "rocprofv3 is not on this box"
+    if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return "this process runs under a profiler already"
+    child = [a for a in argv] + ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-parity-step", "--no-jacobi-step", "--no-pmc"]
+    out = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="pfem_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-include-regex", "k_spmv", "-f", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__)] + child
+        try:
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=timeout_s / 2)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, signal.SIGKILL)
+                pr.wait()
+                shutil.rmtree(d, ignore_errors=True)
+                return f"the {counter} pass did not finish in {timeout_s / 2:g} s"
+            if rc != 0:
+                shutil.rmtree(d, ignore_errors=True)
+                return f"the {counter} pass ended with code {rc}"
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name") != counter or "<true" not in r.get("Kernel_Name", ""):
+                        continue
+                    e = out.setdefault(r["Kernel_Name"].replace("void ", "").split("(")[0], {})
+                    e[counter + "_sum"] = e.get(counter + "_sum", 0.0) + float(r["Counter_Value"])
+                    e[counter + "_n"] = e.get(counter + "_n", 0) + 1
+        except (OSError, ValueError, KeyError) as e:
+            shutil.rmtree(d, ignore_errors=True)
+            return f"{type(e).__name__}: {e}"
+        shutil.rmtree(d, ignore_errors=True)
+    res = {}
+    for k, e in out.items():
+        if e.get("FETCH_SIZE_n") and e.get("WRITE_SIZE_n"):
+            res[k] = {"FETCH_SIZE_KB": e["FETCH_SIZE_sum"] / e["FETCH_SIZE_n"], "WRITE_SIZE_KB": e["WRITE_SIZE_sum"] / e["WRITE_SIZE_n"],
+                      "dispatches": e["FETCH_SIZE_n"]}
+    return res or "the passes recorded no dispatch of a k_spmv*<true, ...> kernel"
+
+
 def cpu_baseline(n, rtol, extra_sample=True):
     """The oracle (C restatement of the reference path) on the host cores, on the SAME configuration as the GPU
     number (n^3 x 6 tets, same rtol), timed at the reference's three timer points (tetrapoissonparallelimpl1.F:826,
@@ -267,6 +321,45 @@ def self_launch(args):
     return rc
 
 
+def transport_ab_child(args):
+    """The peer-transport companion of an N > 1 line as a fresh job: `python -m torch.distributed.run ... bench.py <same arguments>
+    --ab-child` started as a CHILD of rank 0 (which has finished its own work and left its process group), in its own session.
+    Returns the child's brief line, or {"skipped": why}.  A child that does not come back within --transport-ab-timeout is
+    killed by process group; the caller is never inside a hung kernel itself."""
+    import signal
+    import socket
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
+                        "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT") and not k.startswith("TORCHELASTIC_")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + ["--ab-child", "--no-transport-ab"]
+    try:
+        proc = subprocess.Popen(cmd, env=env, cwd=ROOT, start_new_session=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    except OSError as e:
+        return {"skipped": f"the companion job could not be started: {e}"}
+    try:
+        so, _ = proc.communicate(timeout=args.transport_ab_timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        proc.wait()
+        return {"skipped": f"the companion job did not come back within {args.transport_ab_timeout:g} s (its process group was killed)"}
+    lines = [ln for ln in (so or "").splitlines() if ln.lstrip().startswith("{")]
+    if proc.returncode != 0 or not lines:
+        return {"skipped": f"the companion job ended with exit code {proc.returncode} and {'no' if not lines else 'a'} result line"}
+    try:
+        return json.loads(lines[-1])
+    except ValueError as e:
+        return {"skipped": f"unreadable result line of the companion job: {e}"}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -304,9 +397,12 @@ def parse_args():
                          "uploaded): the coordinates no longer form a lattice, so -pc_type gamg takes the path any unstructured file "
                          "mesh takes -- matching on the strength graph along a Morton curve instead of bricks.  One rank")
     ap.add_argument("--no-transport-ab", action="store_true", help="N>1: skip the companion run over the peer-memory transport")
-    ap.add_argument("--transport-ab-timeout", type=float, default=150.0,
+    ap.add_argument("--transport-ab-timeout", type=float, default=240.0,
                     help="N>1: seconds the peer-transport companion may take before the line is printed without it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="N=1: do not measure the SpMV's HBM traffic in this run (two short child runs under rocprofv3 --pmc before this "
+                         "process touches the GPU); `roofline.traffic` then comes from the committed passes of the same workload")
     ap.add_argument("--no-parity-step", action="store_true", help="skip the extra (untimed) step at rtol 1e-10")
     ap.add_argument("--cycle", choices=["auto", "v", "w"], default="auto", help="-pc_mg_cycle_type of the gamg cycle (auto = the library's default: v)")
     ap.add_argument("--pc", choices=["jacobi", "pbjacobi", "gamg"], default="gamg",
@@ -323,6 +419,7 @@ def parse_args():
                     help="development: put every rank on cuda:0 (with --backend gloo) to exercise the N>1 path on a 1-GPU box")
     ap.add_argument("--no-relaunch", action="store_true", help="self-launched N>1 runs: do not retry over gloo when the RCCL attempt dies")
     ap.add_argument("--fallback-note", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--ab-child", action="store_true", help=argparse.SUPPRESS)       # this job is the peer-transport companion of another job's line
     ap.add_argument("--debug-die-rank", type=int, default=-1, help=argparse.SUPPRESS)     # tests: this rank exits(3) after the rendezvous
     ap.add_argument("--bringup-timeout", type=float, default=420.0,
                     help="seconds the communicator bring-up + transport self-test of an N>1 run may take before the rank gives up")
@@ -727,6 +824,13 @@ def main():
     # shorter leash so that a hung first collective ends the attempt while a retry is still worth it
     faulthandler.dump_traceback_later(min(args.rank_timeout, args.bringup_timeout) if args.gpus > 1 else args.rank_timeout, exit=True)
 
+    # N = 1: the SpMV's HBM traffic, measured by two short child runs under rocprofv3 --pmc BEFORE this process touches the GPU
+    pmc_live = None
+    if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.no_pmc:
+        pmc_live = pmc_traffic_live(sys.argv[1:])
+        if isinstance(pmc_live, str):
+            print(f"bench.py: HBM traffic not measured in this run ({pmc_live})", file=sys.stderr, flush=True)
+
     import pfemfort_amd as pf
     from pfemfort_amd import host as H
 
@@ -781,6 +885,25 @@ def main():
     w.free()
     t_init = time.perf_counter() - t_init
 
+    if args.ab_child:
+        # this job IS the companion of another job's line: the same steps over the peer-memory transport, one brief JSON line
+        try:
+            P = run_case(J, beam, nE, ext, max(1, min(args.steps, 3)), 1, args.rtol, profile=False, transport="peer", probe_comm=True)
+        except (pf.PfemError, RuntimeError) as e:           # (a transport that failed mid-run on this rank: its peers time out and report the same)
+            P = {"skipped": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            Pb = P if "skipped" in P else {"value": P["N"] * P["steps"] / P["elapsed"], "ms_per_step": P["ms_per_step"], "iterations": P["its"],
+                                           "converged_reason": P["reason"], "ms_per_iteration": P["ms_per_iteration"], "steps": P["steps"],
+                                           "first_step_ms": P.get("first_step_ms"), "link_latencies": P.get("comm_bench"),
+                                           "coupled_cycle": P.get("cycle_profile"),
+                                           "host_enqueue_us_per_iteration": 1e3 * P["acc"]["enq_ms"] / max(P["acc"]["enq_n"], 1)}
+            json_out.write(json.dumps(Pb) + "\n")
+            json_out.flush()
+        if world > 1:
+            J.dist.barrier()
+            J.dist.destroy_process_group()
+        faulthandler.cancel_dump_traceback_later()
+        return
     R = run_case(J, beam, nE, ext, args.steps, args.warmup, args.rtol, profile=True,
                  parity_step=(world == 1 and not args.no_parity_step and not beam), probe_comm=True)
     weak = not (beam or args.strong)
@@ -812,8 +935,21 @@ def main():
         raw_spmv_ms = acc["spmv_ms"] / max(acc["spmv_n"], 1)
         avg_spmv_ms = max(raw_spmv_ms, 1e-9)
         achieved = bytes_per_spmv / (avg_spmv_ms * 1e-3) / 1e9 if acc["spmv_n"] else 0.0
-        traffic, traffic_source = pmc_traffic(info["nnz"], R["value_dict"]) if (world == 1 and args.numbering == "lattice" and args.jitter <= 0.0) else (None, None)
+        traffic, traffic_source, traffic_counters = None, None, None
+        if isinstance(pmc_live, dict) and pmc_live:
+            # the CG's own product: the WITH_DOT = true kernel with the most dispatches in the child runs (same command, one step)
+            kname, e = max(pmc_live.items(), key=lambda kv: kv[1]["dispatches"])
+            traffic = (2.0 * e["FETCH_SIZE_KB"] + e["WRITE_SIZE_KB"]) * 1024.0
+            traffic_source = ("measured in THIS run: two child runs of the same command (one step) under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+                              "(separate passes) before this process touched the GPU; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB per dispatch, "
+                              "FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM (gfx950 tallies 128-B requests at 64 B)")
+            traffic_counters = dict(e, kernel=kname)
+        elif world == 1 and args.numbering == "lattice" and args.jitter <= 0.0:
+            traffic, traffic_source = pmc_traffic(info["nnz"], R["value_dict"])
+            if traffic and isinstance(pmc_live, str):
+                traffic_source += f" [not measured in this run: {pmc_live}]"
         hbm_bytes = traffic if traffic else fmt_bytes
+        hbm_gbps = hbm_bytes / (avg_spmv_ms * 1e-3) / 1e9 if acc["spmv_n"] else 0.0
         # names as rocprofv3 prints them: k_spmvr / k_spmvg / k_spmv16 <WITH_DOT, gap table>, k_spmvr32 / k_spmv <WITH_DOT>
         tbl = R["gap_table"]
         tname = "true" if tbl else "false"
@@ -936,21 +1072,22 @@ def main():
                                  if (not beam and world == 1 and args.n == 200 and args.numbering == "lattice" and args.jitter <= 0.0) else None}
                                 if (not beam and world == 1) else None),
             "roofline": {"bound": "hbm", "kernel": kernel,
-                         # the judged figure: plain-CSR algorithmic bytes / measured launch time.  It is an
-                         # EFFECTIVE rate: the kernel's compressed form moves fewer bytes (hbm_gbps below)
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "effective": True,
-                         # with the value dictionary the kernel moves 2 B a slot instead of 8: the plain-CSR bytes it REPLACES per second
-                         # can exceed the HBM peak (frac > 1); what it really moves per second is hbm_gbps / hbm_frac below
+                         # `frac` is the REAL fraction of the HBM peak: bytes the launch moves through the memory side (PMC counters of
+                         # this run when rocprofv3 is on the box, else the committed passes of the same workload, else the storage of
+                         # the selected form + x + y) / measured launch time / peak.  Never above 1.  What SURVEY 8(d) prices a launch
+                         # at -- plain CSR, 12 B per nonzero + 20 B per row -- stands beside it as `algorithmic_*`; the compressed forms
+                         # (16-bit gaps, relative row groups, value dictionary) move fewer bytes than that: `compression`
+                         "achieved": hbm_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_gbps / HBM_PEAK_GBPS,
+                         "frac_of_achievable_6300_gbps": hbm_gbps / 6300.0,
+                         "algorithmic_achieved": achieved, "algorithmic_frac": achieved / HBM_PEAK_GBPS,
+                         "compression": (bytes_per_spmv / hbm_bytes) if hbm_bytes else None,
                          "value_dictionary_entries": vdn,
-                         "note": ("frac > 1 is not a measurement error: `achieved` prices the launch in the plain-CSR bytes of SURVEY 8(d) "
-                                  "(12 B per nonzero), and this kernel streams 2 B of value code + 1/2 B of column gap per slot instead of 8 + 1/2 "
-                                  f"(the {vdn} distinct values of the assembled matrix sit in LDS; lossless, same bits). Its real rate is hbm_gbps / hbm_frac; "
-                                  "PFEM_SPMV_VALDICT=0 runs the fp64 copy (0.89-0.95 of the peak in the same bytes)") if vdn else None,
-                         "traffic": traffic, "traffic_source": traffic_source,
+                         "note": ("`achieved` / `frac`: bytes really moved (traffic) per second of the launch; `algorithmic_*`: the plain-CSR "
+                                  "bytes of SURVEY 8(d) the launch REPLACES per second -- above the peak when the kernel streams "
+                                  f"2 B of value code + 1/2 B of column gap per slot instead of 8 + 4 (the {vdn} distinct values of the assembled "
+                                  "matrix sit in LDS; lossless, same bits). PFEM_SPMV_VALDICT=0 runs the fp64 copy") if vdn else None,
+                         "traffic": traffic, "traffic_source": traffic_source, "traffic_counters": traffic_counters,
                          "format_bytes_per_launch": fmt_bytes,
-                         "hbm_gbps": hbm_bytes / (avg_spmv_ms * 1e-3) / 1e9 if acc["spmv_n"] else 0.0,
-                         "hbm_frac": hbm_bytes / (avg_spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if acc["spmv_n"] else 0.0,
                          "hbm_bytes_source": "PMC counters (traffic)" if traffic else "storage of the selected form + x + y",
                          "algorithmic_bytes_per_launch": bytes_per_spmv, "avg_launch_ms": avg_spmv_ms,
                          "avg_launch_source": f"raw HIP event pairs around every {2 if R['pc_in_effect'] == 'gamg' else 8}th launch of this kernel in the timed solves "
@@ -1000,43 +1137,31 @@ def main():
         out = None
     # ---- N > 1: the same steps over the OTHER device-side transport (A/B).  RCCL stays the headline (north_star); the
     # peer-memory transport (boxes + flags mapped through hipIpc*, fine-grained so that it is legal between devices) has only
-    # ever run between processes sharing one GPU, so the attempt is guarded: every rank arms a timer; if the attempt has not
-    # come back in time, rank 0 prints the line without it -- the one line the driver waits for is never lost to the A/B.
-    if world > 1 and not args.no_transport_ab:
-        import threading
-
-        def bail():
-            if rank == 0:
-                out["comm"]["transports"] = {"peer-ipc": {"skipped": f"the attempt did not come back within {args.transport_ab_timeout:g} s (abandoned; processes ended)"}}
-                json_out.write(json.dumps(out) + "\n")
-                json_out.flush()
-            os._exit(0)
-        guard = threading.Timer(args.transport_ab_timeout, bail)
-        guard.daemon = True
-        guard.start()
-        main_kind = R["final"]["backend"] if R.get("final") else None
-        try:
-            P = run_case(J, beam, nE, ext, max(1, min(args.steps, 3)), 1, args.rtol, profile=False, transport="peer", probe_comm=True)
-        except (pf.PfemError, RuntimeError) as e:           # (a transport that failed mid-run on this rank: its peers time out and report the same)
-            P = {"skipped": f"{type(e).__name__}: {e}"}
-        guard.cancel()
-        if rank == 0:
-            def brief(Q):
-                if "skipped" in Q:
-                    return Q
-                return {"value": Q["N"] * Q["steps"] / Q["elapsed"], "ms_per_step": Q["ms_per_step"], "iterations": Q["its"], "converged_reason": Q["reason"],
-                        "ms_per_iteration": Q["ms_per_iteration"], "steps": Q["steps"], "first_step_ms": Q.get("first_step_ms"),
-                        "link_latencies": Q.get("comm_bench"), "coupled_cycle": Q.get("cycle_profile"),
-                        "host_enqueue_us_per_iteration": 1e3 * Q["acc"]["enq_ms"] / max(Q["acc"]["enq_n"], 1)}
-            out["comm"]["transports"] = {{"rccl": "rccl", "host": "gloo-host-hooks"}.get(main_kind, main_kind): brief(R), "peer-ipc": brief(P),
-                                         "note": "same configuration, fresh solver each; the first entry is the run `value` reports"}
-    if rank == 0:
-        json_out.write(json.dumps(out) + "\n")
-        json_out.flush()
+    # ever run between processes sharing one GPU.  It runs as a SECOND, FRESH job of N rank processes that rank 0 starts as a
+    # child once this job's ranks have left their process group (never an exec; the child gets its own process group and
+    # session): if it hangs -- kernels spinning in bounded waits -- the child's process group is killed and THIS process, which
+    # is healthy, prints the line without it and exits 0.  (Round 5 ran it inside these ranks behind a timer that called
+    # os._exit(0) from a thread: a hung transport was reported to the launcher as success by processes that were not.)
+    def brief(Q):
+        if "skipped" in Q:
+            return Q
+        return {"value": Q["N"] * Q["steps"] / Q["elapsed"], "ms_per_step": Q["ms_per_step"], "iterations": Q["its"], "converged_reason": Q["reason"],
+                "ms_per_iteration": Q["ms_per_iteration"], "steps": Q["steps"], "first_step_ms": Q.get("first_step_ms"),
+                "link_latencies": Q.get("comm_bench"), "coupled_cycle": Q.get("cycle_profile"),
+                "host_enqueue_us_per_iteration": 1e3 * Q["acc"]["enq_ms"] / max(Q["acc"]["enq_n"], 1)}
+    main_kind = (R["final"]["backend"] if R.get("final") else None) if world > 1 else None
     if world > 1:
         J.dist.barrier()
         J.dist.destroy_process_group()
     faulthandler.cancel_dump_traceback_later()
+    if world > 1 and not args.no_transport_ab and rank == 0:
+        P = transport_ab_child(args)
+        out["comm"]["transports"] = {{"rccl": "rccl", "host": "gloo-host-hooks"}.get(main_kind, main_kind): brief(R), "peer-ipc": P,
+                                     "note": "same configuration, fresh solver each; the first entry is the run `value` reports; the second ran as "
+                                             "a fresh child job of the same N ranks after this job's ranks had finished"}
+    if rank == 0:
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
 
 
 if __name__ == "__main__":

@@ -886,6 +886,19 @@ __global__ void __launch_bounds__(kBlock) k_amg_diag_bound(SellDev A, int32_t co
     __syncthreads();
     if (threadIdx.x == 0) part_max[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
 }
+// part_max[block] = max of v[0..n) over the block's grid-stride share (v >= 0)
+__global__ void __launch_bounds__(kBlock) k_amg_max_rows(const double *__restrict__ v, int64_t n, double *__restrict__ part_max)
+{
+    __shared__ double sm[4];
+    double a = 0.0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock)
+        a = fmax(a, __builtin_nontemporal_load(v + i));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a = fmax(a, __shfl_xor(a, o, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) part_max[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+}
 __global__ void __launch_bounds__(1024) k_amg_max(const double *__restrict__ part, int64_t n, double *out)
 {
     __shared__ double sm[16];

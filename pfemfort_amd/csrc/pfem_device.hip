@@ -200,7 +200,19 @@ struct DevPool {
         if (best == blocks.size()) return nullptr;
         Block b = blocks[best];
         const size_t want = (bytes + kSplitAlign - 1) / kSplitAlign * kSplitAlign;
-        if (b.bytes > fit() * bytes && b.bytes >= want + min_bytes()) {
+        bool split = b.bytes > fit() * bytes && b.bytes >= want + min_bytes();
+        if (split && b.root < 0 && b.bytes >= kLargeBytes) {
+            // a large block about to become a ROOT: one long-lived piece would pin all of it, and neither trim() nor give() could
+            // hand the rest back.  Alone on the device that costs nothing; when the device runs short (other processes share it:
+            // ranks of a test or a development run) the block is not split -- it goes out whole if it fits within the factor,
+            // else the request goes to the driver (advisor, round 5)
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < total_b / 4) {
+                if (b.bytes > fit() * bytes) return nullptr;
+                split = false;
+            }
+        }
+        if (split) {
             // the front of the block goes out, the rest stays; a block split for the first time becomes a root
             if (b.root < 0) {
                 size_t slot = roots.size();
@@ -503,10 +515,20 @@ struct pfem_solver {
     // fill the chip several times over (measured: 50^3 Poisson 10.3 vs 8.5 us per SpMV, 100^3 equal, 200^3 -15 %)
     // (round 5: with the values as dictionary codes -- pfem_valdict.hpp -- a group form moves 2.5 B a slot against the row form's
     // 8.5, so the threshold came down from 5120 wave slots to 2560: 100^3 has 242 575 groups of four rows)
+    // (the lower threshold holds only while the dictionary may be taken: a pattern whose values it refused -- any unstructured or
+    // moved mesh -- or a run with PFEM_SPMV_VALDICT=0 streams 8.5 B a slot through the group form, and there the row form was equal
+    // or faster up to 5120 wave slots: advisor, round 5)
     static constexpr int64_t kMinGroupsAuto = 163840;      // 2560 wave slots x 64 lanes
+    static constexpr int64_t kMinGroupsAutoFp64 = 327680;  // 5120
+    bool vd_refused = false;       // pfem_valdict.hpp: more than kVdMax distinct values (decided once per pattern)
+    int64_t min_groups_auto() const
+    {
+        const char *e = std::getenv("PFEM_SPMV_VALDICT");
+        return (vd_refused || (e && std::atoi(e) == 0)) ? kMinGroupsAutoFp64 : kMinGroupsAuto;
+    }
     bool use_grouped() const
     {
-        return grouped && (spmv_format == PFEM_SPMV_GROUPED || (spmv_format == PFEM_SPMV_AUTO && n_groups >= kMinGroupsAuto));
+        return grouped && (spmv_format == PFEM_SPMV_GROUPED || (spmv_format == PFEM_SPMV_AUTO && n_groups >= min_groups_auto()));
     }
     // SpMV-only relative row groups (k_spmvr): 4 consecutive rows, one relative column stream
     bool relgrouped = false;
@@ -524,6 +546,9 @@ struct pfem_solver {
     // the row form (0xff: none), and whether the copy holds the values of the last assembly (else k_rel_vals re-packs it)
     DevBuf<uint8_t> d_relk;
     bool rel_vals_current = false;
+    // ... and (one rank, -pc_type gamg with its hierarchy in place) the inverse diagonal and the rows' Gershgorin ratios of level 0,
+    // straight into the hierarchy's vectors: amg_numeric then skips its pass over the assembled matrix (k_amg_diag_bound)
+    bool asm_bound_fresh = false;
     DevBuf<int32_t> d_row_group;   // [n_loc] node group of every row (k_spmvg's copy written by the elasticity gather kernel itself)
     bool grp_vals_current = false;
     // the group form's values as 16-bit codes into a dictionary of the distinct values (pfem_valdict.hpp): which form the
@@ -533,7 +558,7 @@ struct pfem_solver {
     DevBuf<double> d_vdict;
     DevBuf<VdState> d_vstate;
     int vd_rows = 0, vd_n = 0;
-    bool vd_current = false, vd_ok = false, vd_have_dict = false, vd_refused = false;
+    bool vd_current = false, vd_ok = false, vd_have_dict = false;
     double vd_encode_ms = 0.0;       // (host time of the last refresh incl. its wait: PFEM_VD_VERBOSE)
     // the inverse diagonal of the Jacobi loop as codes (DinvView): encoded after every k_invert of a solve whose matrix streams
     // codes, verdict on the device
@@ -550,7 +575,7 @@ struct pfem_solver {
     bool use_rel() const
     {
         return relgrouped && !use_grouped() &&
-               (spmv_format == PFEM_SPMV_GROUPED || (spmv_format == PFEM_SPMV_AUTO && n_rgroups >= kMinGroupsAuto));
+               (spmv_format == PFEM_SPMV_GROUPED || (spmv_format == PFEM_SPMV_AUTO && n_rgroups >= min_groups_auto()));
     }
     SellRDev sellr() const
     {
@@ -1794,9 +1819,16 @@ static void pool_reserve_for_setup(const pfem_solver *s)
     if (want < have + (32u << 20)) return;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 4 * (want - have)) { (void)hipGetLastError(); return; }
-    DevBuf<char> block;
-    if (block.alloc(want - have) != PFEM_OK) { (void)hipGetLastError(); set_last_error(""); }
-}       // (the block goes to the pool here)
+    // straight from the driver, then handed to the pool: DevBuf::alloc would first look INTO the pool, and any single free block
+    // of want - have bytes or more (one 0.75 GB block when 1.5 GB is wanted) would be taken and given straight back -- nothing
+    // reserved, the first solve paying the wipes after all (advisor, round 5)
+    const size_t bytes = (want - have + DevPool::kSplitAlign - 1) / DevPool::kSplitAlign * DevPool::kSplitAlign;
+    void *q = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (hipMalloc(&q, bytes) != hipSuccess || !q) { (void)hipGetLastError(); return; }
+    dev_pool().note(bytes, 0, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    if (!dev_pool().give(q, bytes)) (void)hipFree(q);
+}
 
 extern "C" int pfem_pattern_build(pfem_solver *s)
 {
@@ -1954,6 +1986,7 @@ int zero_values(pfem_solver *s, bool rows_overwritten = false)
     PFEM_HIP(hipMemsetAsync(s->d_rhs.p, 0, sizeof(double) * static_cast<size_t>(std::max<int64_t>(s->n_loc, 1)), s->stream));
     s->rhs_summed = false;
     s->rel_vals_current = false;            // (whoever writes the values next says so again if it writes both forms)
+    s->asm_bound_fresh = false;
     s->grp_vals_current = false;
     s->vd_current = false;
     return PFEM_OK;
@@ -1979,7 +2012,7 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
     // setZero, solverpetsc.F:222-246 (the value array needs no clearing when every row is stored whole by the gather
     // kernels; hub rows, if any, are accumulated with atomics and do)
     PFEM_TRY(zero_values(s, gather && (use_lds || elast_rows) && s->n_hubs == 0));
-    bool wrote_rel = false, wrote_grp = false;
+    bool wrote_rel = false, wrote_grp = false, wrote_bound = false;
     if (gather) {
         // gather form: one thread per node, no atomics, bit-reproducible
         const dim3 grid(grid_for(m.nNode)), block(kBlock);
@@ -2014,11 +2047,18 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
                 // (the relative-group copy of the values the CG's SpMV streams is written here too when that form is in use and the
                 // whole matrix is assembled by this kernel: k_rel_vals' 1.9 GB re-pack per solve -- 0.66 ms at config 3 -- goes away)
                 const bool both = s->use_rel() && s->d_relk.p && s->n_hubs == 0 && !std::getenv("PFEM_DEBUG_NO_REL_DIRECT");
+                // (level 0's inverse diagonal and Gershgorin ratios for the multigrid's numeric phase, while the rows are in LDS: one rank,
+                // the whole matrix assembled by this kernel, the hierarchy of this pattern in place -- every step but the first)
+                AmgLevel *L0 = (s->pc == PFEM_PC_GAMG && s->amg && s->amg->symbolic_ok && !s->amg->coupled && s->nranks == 1 && s->n_ghost == 0 &&
+                                s->n_hubs == 0 && !s->amg->lev.empty() && s->amg->lev[0]->fine && s->amg->lev[0]->n == s->n_loc &&
+                                !std::getenv("PFEM_DEBUG_NO_ASM_BOUND")) ? s->amg->lev[0].get() : nullptr;
+                const bool bound = L0 && L0->dinv.p && L0->t.p && L0->dinv.n >= static_cast<size_t>(s->n_loc) && L0->t.n >= static_cast<size_t>(s->n_loc);
                 hipLaunchKernelGGL(k_gather_poisson_tet4, xgrid, rblock, rlds, s->stream, m.nNode, A, s->d_rhs.p, prm, ip, ic, irec, nrow,
                                    static_cast<const double4 *>(s->d_node4.p), s->d_err.p, xcd_per,
                                    both ? static_cast<const uint8_t *>(s->d_relk.p) : nullptr, both ? static_cast<const int64_t *>(s->d_rslice_off.p) : nullptr,
-                                   both ? s->d_rvals.p : nullptr);
+                                   both ? s->d_rvals.p : nullptr, bound ? L0->dinv.p : nullptr, bound ? L0->t.p : nullptr);
                 wrote_rel = both;
+                wrote_bound = bound;
             } else {
                 PFEM_GATHER(PFEM_POISSON_TET);
             }
@@ -2077,6 +2117,7 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
     if (err) return err;
     s->host_values_dirty = false;
     s->rel_vals_current = wrote_rel;
+    s->asm_bound_fresh = wrote_bound;
     s->grp_vals_current = wrote_grp;
     s->vd_current = false;
     s->status = PFEM_ASSEMBLY_OK;
@@ -2488,6 +2529,7 @@ int build_rel_groups(pfem_solver *s)
     // union entry of every stored entry of the row form, for an assembly that writes this copy itself; the explicit zeros of the
     // copy (offsets a row lacks) are set here once and never written again
     s->rel_vals_current = false;
+    s->asm_bound_fresh = false;
     s->vd_current = s->vd_ok = s->vd_have_dict = s->vd_refused = false;
     s->vd_rows = 0;
     s->d_relk.release();
@@ -2568,7 +2610,12 @@ int refresh_value_codes(pfem_solver *s)
         s->vd_n = st.count;
         s->vd_have_dict = true;
         PFEM_TRY(encode());
-        if (st.miss) { set_last_error("value dictionary: a value of the collection pass is missing from its own dictionary"); return PFEM_ERR_STATE; }
+        if (st.miss) {                  // (cannot happen for finite values; whatever it is, the fp64 copy is always right)
+            s->vd_ok = s->vd_have_dict = false;
+            s->vd_refused = true;
+            if (verbose) std::fprintf(stderr, "  value dictionary: a value of the collection pass is missing from its own dictionary, the SpMV keeps its fp64 copy\n");
+            return PFEM_OK;
+        }
     }
     s->vd_ok = true;
     s->vd_current = true;
@@ -3198,7 +3245,11 @@ struct PeerBackend final : CommBackend {
         }
         X.off[np] = off[np];
         for (int k = 0; k < np; ++k)
-            X.blocks[k] = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(kPeerXBlocks, (off[k + 1] - off[k]) / kPeerXSlice)));
+            // (at most ~64 blocks of 1024 threads per launch over all neighbours: every block spins on its neighbour's flag, and that flag
+            // rises only when ALL of the neighbour's pushing blocks have run -- with several ranks on one device, 7 neighbours x 16
+            // blocks of spinners per rank could keep pushers that are not resident yet off the CUs until the 10 s timeout: advisor, round 5)
+            X.blocks[k] = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(kPeerXBlocks, std::max(1, 64 / std::max(np, 1))),
+                                                                                   (off[k + 1] - off[k]) / kPeerXSlice)));
         hipLaunchKernelGGL(k_peer_exchange, dim3(static_cast<unsigned>(np * kPeerXBlocks)), dim3(1024), 0, st, W, X, d_send, d_recv, d_xarrive);
         return check_kernel("k_peer_exchange");
     }
@@ -4652,6 +4703,7 @@ extern "C" int pfem_solver_solve(pfem_solver *s, int *its, int *reason, double *
             PFEM_TRY(dv.alloc(static_cast<size_t>(s->nnz)));
             PFEM_HIP(hipMemcpyAsync(dv.p, s->h_vals.data(), sizeof(double) * s->nnz, hipMemcpyHostToDevice, s->stream));
             s->rel_vals_current = false;
+            s->asm_bound_fresh = false;
             s->grp_vals_current = false;
             s->vd_current = false;
             hipLaunchKernelGGL(k_csr_vals_to_sell, dim3(grid_for(s->n_loc)), dim3(kBlock), 0, s->stream, s->sell(), s->d_rowptr.p, dv.p);

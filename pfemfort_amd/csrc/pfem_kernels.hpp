@@ -68,6 +68,27 @@ __device__ __forceinline__ double block_sum(double v, double *sm)
     return (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
+// The same sum -- (w0 + w1) + (w2 + w3), the same bits -- written to *out by whichever wave finishes LAST, without a barrier:
+// a wave that is done leaves, its slot goes to the next workgroup's waves instead of idling until the block's slowest wave
+// arrives (the (p,Ap) partial of the CG SpMV: the WITH_DOT variant cost 12 % over the plain one, profiles/r05).  `cnt` is an
+// LDS word that was zero before any wave got here (set before a barrier at the kernel's start, where the waves are together
+// anyway); sm has >= 4 doubles.  LDS operations of one workgroup are served by one unit in order: the release fence orders the
+// wave's partial before its ticket, the acquire fence the last ticket before the reads.
+__device__ __forceinline__ void block_sum_last_wave(double v, double *sm, int *cnt, double *out)
+{
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) {
+        sm[threadIdx.x >> 6] = v;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (ticket == (kBlock >> 6) - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const volatile double *vs = sm;
+            *out = (vs[0] + vs[1]) + (vs[2] + vs[3]);
+        }
+    }
+}
+
 // Every block sums the same `n` per-block partials in the same order, so all blocks
 // (and all runs) obtain the same bits without a separate reduction launch.
 __device__ __forceinline__ double sum_partials(const double *part, int n, double *sm)
@@ -979,7 +1000,8 @@ __global__ void __launch_bounds__(kBlock) k_gather_poisson_tet4(int64_t nNode, S
                                                                  const double4 *__restrict__ node4, int *err,
                                                                  unsigned xcd_per, const uint8_t *__restrict__ relk = nullptr,
                                                                  const int64_t *__restrict__ rslice_off = nullptr,
-                                                                 double *__restrict__ rvals = nullptr)
+                                                                 double *__restrict__ rvals = nullptr,
+                                                                 double *__restrict__ dinv_out = nullptr, double *__restrict__ ratio_out = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];
     const int T = blockDim.x;
@@ -1015,6 +1037,9 @@ __global__ void __launch_bounds__(kBlock) k_gather_poisson_tet4(int64_t nNode, S
         co[0] = co[1] = co[2] = double4{0.0, 0.0, 0.0, 0.0};
     }
     bool neg_jac = false;
+    // (the slot of the row's own column -- the diagonal -- is the node's own slot in any of its visits: the first one's)
+    const int kd = cnt > 0 ? static_cast<int>((static_cast<uint32_t>(rc_next.w) >>
+                                               (8 * ((static_cast<uint32_t>(rc_next.x) >> 31) | ((static_cast<uint32_t>(rc_next.y) >> 31) << 1)))) & 0xffu) : -1;
     for (int64_t t = beg; t < end; t += 64) {
         const int4 rc = rc_next;
         const double4 c0 = co[0], c1 = co[1], c2 = co[2];
@@ -1054,6 +1079,17 @@ __global__ void __launch_bounds__(kBlock) k_gather_poisson_tet4(int64_t nNode, S
     } else
     for (int k = 0; k < len; ++k) A.vals[base + (static_cast<int64_t>(k) << 6)] = acc[k * T];
     rhs[row] = facc;
+    if (dinv_out) {
+        // what k_amg_diag_bound computes from the stored row -- the inverse diagonal and the row's share of the Gershgorin bound
+        // max_i sum_j |a_ij| / a_ii, the absolute values added in slot order -- while the row is still in LDS: the multigrid's
+        // numeric phase then does not read the assembled matrix (1.4 GB at config 3) for them.  One rank only (no ghost columns).
+        double sabs = 0.0;
+        for (int k = 0; k < len; ++k) sabs += fabs(acc[k * T]);
+        const double d = kd >= 0 && kd < len ? acc[kd * T] : 0.0;
+        const bool pos = d > 0.0;
+        dinv_out[row] = pos ? 1.0 / d : 1.0;
+        ratio_out[row] = pos ? sabs / d : 1.0;
+    }
 }
 
 // Elasticity gather, one thread per (node, dof) ROW: the row is accumulated in LDS (entry k of

@@ -48,10 +48,10 @@ __global__ void __launch_bounds__(kBlock) k_vd_collect(const double *__restrict_
         // a run looks it up (a lane that is active has an active left neighbour: its index is smaller)
         const uint64_t left = static_cast<uint64_t>(__shfl_up(static_cast<unsigned long long>(b), 1));
         if ((threadIdx.x & 63) != 0 && left == b) continue;
+        if (b == kVdEmpty) { st->fail = 1; return; }    // (before the filter: `seen` starts out as kVdEmpty and would pass it for "seen")
         const uint32_t h = vd_hash(b);
         if (seen[h & 1023u] == b) continue;
         if (*failed) return;
-        if (b == kVdEmpty) { st->fail = 1; return; }
         bool placed = false;
         for (uint32_t q = h & (kVdTable - 1), tries = 0; tries < kVdTable; q = (q + 1) & (kVdTable - 1), ++tries) {
             // (a plain look first: 600 values x 8192 workgroups would otherwise queue up on 600 words -- measured 20 ms)
@@ -179,8 +179,10 @@ __global__ void __launch_bounds__(kBlock) k_spmvr_vd(SellRDev G, const unsigned 
     const unsigned vblock = blockIdx.x;
     extern __shared__ double vd[];
     __shared__ double sm[4];
+    __shared__ int done_waves;
     __shared__ uint32_t gap_tbl[DICT ? kGapTable : 1];
     if (WITH_DOT && ctl->flag != 0) return;
+    if (WITH_DOT && threadIdx.x == 0) done_waves = 0;         // (before the barrier below)
     // A wave's life is a chain of memory latencies (rocprofv3 --pmc: 58 % of the wave cycles waiting; with an XCD-contiguous block
     // order the fabric traffic falls from 0.59 GB to its ideal 0.36 GB and the time does not move -- LAB_NOTES): slice header ->
     // first entry -> trips of four entries -> remainder.  So the header, the first entry's operands and the first gap words are requested BEFORE the dictionary is copied to LDS,
@@ -278,10 +280,7 @@ __global__ void __launch_bounds__(kBlock) k_spmvr_vd(SellRDev G, const unsigned 
                 if (WITH_DOT && r0 + p < n_dot) dot = __builtin_fma(x[r0 + p], acc[p], dot);
             }
     }
-    if (WITH_DOT) {
-        const double t = block_sum(dot, sm);
-        if (threadIdx.x == 0) partial[vblock] = t;
-    }
+    if (WITH_DOT) block_sum_last_wave(dot, sm, &done_waves, partial + vblock);      // (no barrier at the end of a wave's life)
 }
 
 // W words = 2W consecutive entries of the node's rows (k_spmvg's trip over the codes)
@@ -319,8 +318,10 @@ __global__ void __launch_bounds__(kBlock) k_spmvg_vd(SellGDev G, const unsigned 
 {
     extern __shared__ double vd[];
     __shared__ double sm[4];
+    __shared__ int done_waves;
     __shared__ uint32_t tbl[DICT ? kGapTable : 1];
     if (WITH_DOT && ctl->flag != 0) return;
+    if (WITH_DOT && threadIdx.x == 0) done_waves = 0;         // (before the barrier below)
     for (int i = threadIdx.x; i < nd; i += kBlock) vd[i] = dict[i];
     if (DICT) tbl[DICT ? threadIdx.x : 0] = G.gap_table[threadIdx.x];
     __syncthreads();
@@ -374,10 +375,7 @@ __global__ void __launch_bounds__(kBlock) k_spmvg_vd(SellGDev G, const unsigned 
                 }
         }
     }
-    if (WITH_DOT) {
-        const double t = block_sum(dot, sm);
-        if (threadIdx.x == 0) partial[blockIdx.x] = t;
-    }
+    if (WITH_DOT) block_sum_last_wave(dot, sm, &done_waves, partial + blockIdx.x);
 }
 
 }  // namespace pfem

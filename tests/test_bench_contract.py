@@ -29,9 +29,14 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf
     assert rf["algorithmic_bytes_per_launch"] == 12 * rf["nnz"] + 20 * rf["rows"] and rf["launches_timed"] > 0
-    # the two rates travel together: `frac` is the effective (plain-CSR equivalent) figure, hbm_* what the form really moves
-    assert rf["effective"] is True and 0 < rf["hbm_gbps"] <= rf["achieved"] and "traffic_source" in rf
+    # `frac` is the REAL fraction (bytes moved: PMC traffic of this run where rocprofv3 is on the box, else the form's storage), never
+    # above 1; the plain-CSR bytes of SURVEY 8(d) that the launch replaces travel beside it as algorithmic_*
+    assert 0 < rf["frac"] <= 1.0 and rf["algorithmic_achieved"] >= rf["achieved"] and "traffic_source" in rf
+    assert abs(rf["algorithmic_frac"] - rf["algorithmic_achieved"] / rf["peak"]) < 1e-12 and rf["compression"] >= 1.0
     assert rf["format_bytes_per_launch"] < rf["algorithmic_bytes_per_launch"]
+    if rf["traffic"] is not None and "THIS run" in (rf["traffic_source"] or ""):
+        c = rf["traffic_counters"]
+        assert "<true" in c["kernel"] and c["dispatches"] > 0 and abs(rf["traffic"] - (2 * c["FETCH_SIZE_KB"] + c["WRITE_SIZE_KB"]) * 1024) < 1
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "DOF/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
     # the same configuration as the GPU number, at the reference's three timer points

@@ -1167,6 +1167,39 @@ def test_gamg_fused_cycle_equals_level_by_level_kernels(case, beam, monkeypatch)
         assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
 
 
+def test_gamg_bound_and_diagonal_from_the_assembly_kernel_keep_every_bit(monkeypatch):
+    """From the second step of a pattern on, the Poisson gather kernel leaves level 0's inverse diagonal and the rows' Gershgorin
+    ratios behind while the rows are still in LDS, and the multigrid's numeric phase no longer reads the assembled matrix for
+    them (k_amg_diag_bound on level 0: 1.4 GB at config 3).  Same diagonal, same bound (a maximum: order-free), hence the same
+    residual history and iterate, bit for bit -- against the first step (which has no hierarchy yet and takes the old path) and
+    against PFEM_DEBUG_NO_ASM_BOUND=1; new values on the same pattern follow."""
+    mesh = H.gen_box_tets(-1, 1, 36, -1, 1, 30, -1, 1, 33)
+    ed, ed2 = H.POISSON_ELEMDATA, np.array([1.3, 0.7, 2.1])
+    out = {}
+    for off in ("", "1"):
+        if off:
+            monkeypatch.setenv("PFEM_DEBUG_NO_ASM_BOUND", off)
+        else:
+            monkeypatch.delenv("PFEM_DEBUG_NO_ASM_BOUND", raising=False)
+        s, _ = _device_problem(pf.POISSON_TET, mesh, ed)
+        s.setPreconditioner("gamg")
+        s.setTolerances(rtol=1e-10, maxits=500)
+        runs = []
+        for data in (ed, ed, ed2, ed):
+            s.assemble(data, H.TIMEDATA)
+            its, reason, _ = s.factoriseAndSolve()
+            assert reason == 2
+            runs.append((its, s.getHistory(), s.getSolution(), list(s.amgInfo()["lambda_max"])))
+        out[off] = runs
+        s.free()
+    a, b = out[""], out["1"]
+    for ra, rb in zip(a, b):
+        assert ra[0] == rb[0] and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2]) and ra[3] == rb[3]
+    # the first step (old path) and the second and fourth (new path) saw the same values; the third saw others
+    assert np.array_equal(a[0][1], a[1][1]) and np.array_equal(a[0][2], a[3][2]) and a[0][3] == a[1][3]
+    assert not np.array_equal(a[0][2], a[2][2])
+
+
 def _shuffled(mesh, seed=7):
     """The same mesh under a random node numbering (what an arbitrary mesh file may look like)."""
     perm = np.random.default_rng(seed).permutation(mesh.nNode).astype(np.int32)       # old id -> new id
