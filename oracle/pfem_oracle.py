@@ -471,6 +471,133 @@ def lattice_brick_aggregates(xyz_nodes, xyz_free, dense_limit=128, passes=3, max
     return aggs
 
 
+def _node_brick_axis(stretches, fine, halvings, first_max):
+    """One axis of a node-brick level (pfem_amg.inc: node_brick_axis): the occupied positions come in stretches of one owner
+    (inclusive ends; one rank: one stretch); inside a stretch f positions make a brick, aligned on multiples of f, a brick at either
+    end that would hold at most f // 2 positions joined to its neighbour, ``halvings`` times over when f = 2 (level 0 of a
+    displacement problem: f = 3 from an extent of 6 on, 4 from 24 on).  The first stretch keeps brick = position // f, every further
+    stretch goes on where the one before it ended.  Returns (table position -> brick coordinate, the stretches in brick coordinates)."""
+    table, out, base = np.zeros(1024, np.int64), [], 0
+    for k, (s0, s1) in enumerate(stretches):
+        lo, hi, m = s0, s1, np.arange(s0, s1 + 1)
+        extent = s1 - s0 + 1
+        want = 4 if extent >= 24 else (3 if extent >= 6 else 2)
+        f = max(2, min(want, first_max, extent // 2)) if (fine and halvings > 0) else 2
+        for _ in range(1 if f > 2 else halvings):
+            bmin = lo // f + (1 if (f - lo % f) <= f // 2 else 0)
+            bmax = hi // f - (1 if (hi % f + 1) <= f // 2 else 0)
+            pairs = bmin <= bmax
+            m = np.clip(m // f, bmin, bmax) if pairs else m // f
+            lo, hi = (bmin, bmax) if pairs else (lo // f, hi // f)
+        if k == 0:
+            base = lo
+        table[s0:s1 + 1] = m - lo + base
+        out.append((base, base + hi - lo))
+        base += hi - lo + 1
+    return table, out
+
+
+def lattice_node_brick_aggregates(xyz_nodes, xyz_free_nodes, dim=3, owner=None, first_max=4, passes=3, dense_limit=128, max_levels=13,
+                                  replicate_rows=150000):
+    """The NODE aggregates of -pc_type gamg on a displacement problem (rigid-body transfer) whose mesh nodes sit on a lattice whose
+    lines are full (the product: amg_node_bricks / k_rbm_lat_* in pfemfort_amd/csrc), restated from the COORDINATES alone.
+    ``xyz_nodes`` [dim, nNode]: all mesh nodes (a position = rank among the distinct values per axis); ``xyz_free_nodes`` [dim, n]:
+    the free nodes in node order (dofs / dim).  A level halves ``passes`` axes in turn as the scalar bricks do; the bricks of an
+    axis come from _node_brick_axis; aggregates = the bricks of the box, numbered in (z, y, x) order.  A coarse node has
+    dim + (3 if dim == 3 else 1) dofs and sits at its brick coordinate.
+
+    ``owner`` [n] (one hierarchy across ranks, nodes numbered rank after rank): every rank's nodes must fill a box of positions
+    (else None); the bricks are cut where the owner changes, every rank numbers the bricks of its own box, rank after rank.  From
+    the first level of at most ``replicate_rows`` dofs on every rank holds the whole level: positions = ranks among the occupied
+    brick coordinates (what the centroids' distinct values give), one stretch per axis.
+    Returns the list of node-aggregate maps, level by level."""
+    xyz_nodes = np.atleast_2d(np.asarray(xyz_nodes, dtype=np.float64))
+    xf = np.atleast_2d(np.asarray(xyz_free_nodes, dtype=np.float64))
+    n = xf.shape[1]
+    pos = np.zeros((3, n), np.int64)
+    hi = [0, 0, 0]
+    for d in range(xf.shape[0]):
+        u = np.unique(xyz_nodes[d] + 0.0)
+        pos[d] = np.searchsorted(u, xf[d])
+        assert np.array_equal(u[pos[d]], xf[d])
+        hi[d] = len(u) - 1
+    cb = dim + (3 if dim == 3 else 1)
+    bs = dim
+    aggs, axis, fine = [], 0, True
+    stretches = None
+    if owner is not None:
+        owner = np.asarray(owner, dtype=np.int64)
+        assert len(owner) == n and (np.diff(owner) >= 0).all()
+        boxes = []
+        for q in np.unique(owner):
+            sel = owner == q
+            lo, up = pos[:, sel].min(axis=1), pos[:, sel].max(axis=1)
+            if int(np.prod(up - lo + 1)) != int(sel.sum()):
+                return None
+            boxes.append((lo, up))
+        stretches = []
+        for d in range(3):
+            gmin, gmax = min(b[0][d] for b in boxes), max(b[1][d] for b in boxes)
+            cuts = {int(b[0][d]) for b in boxes if b[0][d] > gmin} | {int(b[1][d]) + 1 for b in boxes if b[1][d] < gmax}
+            bnd = sorted({int(gmin), int(gmax) + 1} | {c for c in cuts if gmin < c <= gmax})
+            stretches.append([(bnd[k], bnd[k + 1] - 1) for k in range(len(bnd) - 1)])
+    elif int(np.prod(pos.max(axis=1) - pos.min(axis=1) + 1)) != n:
+        return None
+    while n * bs > dense_limit and len(aggs) + 1 < max_levels:
+        shift, hi_c, axis_c = _lat_sim_passes(hi, axis, passes)
+        if not any(shift):
+            break
+        b, nhi, new_str = [], list(hi_c), []
+        for d in range(3):
+            one = [(int(pos[d].min()), int(pos[d].max()))]
+            table, out = _node_brick_axis(stretches[d] if stretches is not None else one, fine, shift[d], first_max)
+            b.append(table[pos[d]])
+            new_str.append(out)
+            if stretches is not None:
+                nhi[d] = out[-1][1]
+            else:
+                extent = one[0][1] - one[0][0] + 1
+                want = 4 if extent >= 24 else (3 if extent >= 6 else 2)
+                f = max(2, min(want, first_max, extent // 2)) if (fine and shift[d] > 0) else 2
+                if f > 2:
+                    nhi[d] = hi[d] // f
+        b = np.stack(b)
+        if stretches is not None:        # every owner numbers the bricks of its own box (z, y, x), rank after rank
+            agg = np.zeros(n, np.int64)
+            off, owner_c, pos_c = 0, [], []
+            for q in np.unique(owner):
+                sel = owner == q
+                lo, up = b[:, sel].min(axis=1), b[:, sel].max(axis=1)
+                nbk = up - lo + 1
+                agg[sel] = off + (b[0, sel] - lo[0]) + nbk[0] * ((b[1, sel] - lo[1]) + nbk[1] * (b[2, sel] - lo[2]))
+                cnt = int(np.prod(nbk))
+                a = np.arange(cnt)
+                pos_c.append(np.stack([a % nbk[0] + lo[0], (a // nbk[0]) % nbk[1] + lo[1], a // (nbk[0] * nbk[1]) + lo[2]]))
+                owner_c.append(np.full(cnt, q))
+                off += cnt
+            na, pos_c, owner_c = off, np.concatenate(pos_c, axis=1), np.concatenate(owner_c)
+        else:
+            lo, up = b.min(axis=1), b.max(axis=1)
+            nbk = up - lo + 1
+            agg = (b[0] - lo[0]) + nbk[0] * ((b[1] - lo[1]) + nbk[1] * (b[2] - lo[2]))
+            na = int(np.prod(nbk))
+            a = np.arange(na)
+            pos_c, owner_c = np.stack([a % nbk[0] + lo[0], (a // nbk[0]) % nbk[1] + lo[1], a // (nbk[0] * nbk[1]) + lo[2]]), None
+        if na < 1 or na * 10 > n * 8 or na * cb * 10 > n * bs * 8:
+            break
+        aggs.append(agg)
+        pos, n, hi, axis, bs, fine, owner = pos_c, na, nhi, axis_c, cb, False, owner_c
+        if stretches is not None:
+            stretches = new_str
+            if dense_limit < n * bs <= replicate_rows:      # every rank holds the level whole from here on
+                stretches, owner = None, None
+                for d in range(3):
+                    u = np.unique(pos[d])
+                    pos[d] = np.searchsorted(u, pos[d])
+                    hi[d] = len(u) - 1
+    return aggs
+
+
 def rbm_prolongator(node_agg, xyz, dim, fine_bs):
     """Tentative prolongator with the rigid-body modes of every aggregate (the product: pfem_amg_rbm.hpp; PETSc reaches the
     same coarse space through MatSetNearNullSpace / PCSetCoordinates ahead of PCGAMG, tetraelasticityparallelimpl1.F:894-902).

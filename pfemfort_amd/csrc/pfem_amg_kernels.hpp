@@ -1453,6 +1453,44 @@ __global__ void __launch_bounds__(kBlock) k_amg_spmv_pack(SellDev A, const doubl
     share_pack(S, send, i, acc);
 }
 
+// ... the same product over the level's values as 16-bit codes into the dictionary of its distinct ones (amg_value_codes; the
+// levels of a hierarchy ACROSS ranks, round 6: the one-rank cycle's fused kernels have had this since round 5): 4 + 2 bytes per
+// slot instead of 4 + 8, the same doubles into the same fma chain.  S.row_sh == nullptr: no packing (the product before a restriction).
+__global__ void __launch_bounds__(kBlock) k_amg_spmv_pack_vd(SellDev A, const uint16_t *__restrict__ codes, const double *__restrict__ dict, int nd,
+                                                              const double *__restrict__ xin, double *__restrict__ y, ShareSum S,
+                                                              double *__restrict__ send, const CgCtl *ctl)
+{
+    extern __shared__ double vd[];
+    if (ctl && ctl->flag != 0) return;
+    for (int i = threadIdx.x; i < nd; i += kBlock) vd[i] = dict[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t s = (static_cast<int64_t>(blockIdx.x) << 2) + wave;
+    if (s >= A.n_slices) return;
+    const int64_t off = A.slice_off[s];
+    const int width = static_cast<int>((A.slice_off[s + 1] - off) >> 6);
+    const int32_t *__restrict__ cp = A.cols + off + lane;
+    const uint16_t *__restrict__ qp = codes + off + lane;
+    double acc = 0.0;
+    int k = 0;
+    for (; k + 4 <= width; k += 4) {
+        int c[4];
+        uint16_t q[4];
+        double xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c[j] = cp[64 * (k + j)]; q[j] = qp[64 * (k + j)]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = xin[c[j]];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_fma(vd[q[j]], xv[j], acc);
+    }
+    for (; k < width; ++k) acc = __builtin_fma(vd[qp[64 * k]], xin[cp[64 * k]], acc);
+    const int64_t i = (s << 6) + lane;
+    if (i >= A.n_rows) return;
+    y[i] = acc;
+    share_pack(S, send, i, acc);
+}
+
 }  // namespace pfem
 #include "pfem_amg_rbm.hpp"          // (after cheb_coef, before the tail kernel that uses its transfer)
 namespace pfem {

@@ -48,6 +48,11 @@ struct AmgLevel {
     // node bricks in one step (rigid-body levels, amg_node_bricks): the box of positions the level's nodes fill completely
     bool lat_full = false;
     int lat_tlo[3] = {0, 0, 0}, lat_thi[3] = {0, 0, 0};
+    // ... across ranks (round 6): hint = GLOBAL positions of the owned nodes, the same numbers on every rank; lat_str = per axis
+    // the occupied stretches of positions that one owner holds (inclusive ends, ascending; from all-reduced boxes: the same on every
+    // rank); lat_tlo / lat_thi = the box THIS rank's owned nodes fill.  Bricks are cut at the stretches' ends (node_brick_axis).
+    bool lat_nodes_global = false;
+    std::vector<std::pair<int, int>> lat_str[3];
     std::vector<double> lat_coord;        // [3 x 1024] coordinate of every position (a brick sits at its lowest corner): the corners a level
                                           // needs when it leaves the brick path (xyz below) come from here instead of travelling down the levels
     DevBuf<double> xyz;                   // coupled hierarchy with a lattice: [3 x n_nodes] a corner of every node's aggregate (see k_amg_xyz_min)

@@ -181,7 +181,9 @@ __global__ void __launch_bounds__(kBlock) k_spmvr_vd(SellRDev G, const unsigned 
     __shared__ double sm[4];
     __shared__ int done_waves;
     __shared__ uint32_t gap_tbl[DICT ? kGapTable : 1];
-    if (WITH_DOT && ctl->flag != 0) return;
+    // (the CG's verdict: requested here, looked at behind the barrier below -- the wave's first loads go out without waiting for it;
+    // an iteration enqueued after the verdict still leaves before its main loop)
+    const int finished = WITH_DOT ? __builtin_nontemporal_load(&ctl->flag) : 0;
     if (WITH_DOT && threadIdx.x == 0) done_waves = 0;         // (before the barrier below)
     // A wave's life is a chain of memory latencies (rocprofv3 --pmc: 58 % of the wave cycles waiting; with an XCD-contiguous block
     // order the fabric traffic falls from 0.59 GB to its ideal 0.36 GB and the time does not move -- LAB_NOTES): slice header ->
@@ -211,6 +213,7 @@ __global__ void __launch_bounds__(kBlock) k_spmvr_vd(SellRDev G, const unsigned 
     for (int i = threadIdx.x; i < nd; i += kBlock) vd[i] = dict[i];
     if (DICT) gap_tbl[DICT ? threadIdx.x : 0] = G.gap_table[threadIdx.x];
     __syncthreads();
+    if (WITH_DOT && finished != 0) return;
     const auto gap_of = [&](uint32_t code) -> int {
         return (DICT && (code & 0x8000u)) ? static_cast<int>(gap_tbl[DICT ? (code & (kGapTable - 1)) : 0]) : static_cast<int>(code);
     };

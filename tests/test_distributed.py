@@ -512,6 +512,43 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
                         assert not len(bad), (f"level {lv}: {len(bad)} of {len(x)} aggregates differ, first at dof {bad[0]}: oracle {x[bad[:12]].tolist()} "
                                               f"device {y[bad[:12]].tolist()}; rows {rows_glob}")
                     print(f"bricks across ranks == the oracle's own: {kind_name} x{world} {partition} {mode}, rows per level {rows_glob}")
+            if kind_name == "elast" and not mesh_args.get("reorder"):
+                # node bricks in one step ACROSS the ranks (round 6): where every rank's nodes fill a box of the lattice the oracle
+                # forms the node aggregates itself, from the coordinates and the nodes' owners alone (bricks cut where the owner
+                # changes, every rank numbering the bricks of its own box; the replicated levels plain node bricks again), and the
+                # device's equal them entry for entry; elsewhere (sectors, foreign) the pairing passes keep the levels
+                nda = prob.dm.NodeDofArrayNew.reshape(-1, 3)
+                free = np.where(nda[:, 0] >= 0)[0]
+                owner = np.zeros(len(free), np.int64)
+                for r in range(world):
+                    owner[int(prob.dm.row_start[r]) // 3:int(prob.dm.row_end[r]) // 3] = r
+                own_nodes = O.lattice_node_brick_aggregates(prob.xyz_new, prob.xyz_new[:, free], owner=owner,
+                                                            replicate_rows=0 if mesh_args["amg_distributed"] else 150000)
+                if partition in ("slabs", "xslabs", "yslabs", "idle"):
+                    assert own_nodes is not None
+                if partition in ("sectors", "foreign"):
+                    assert own_nodes is None
+                if own_nodes is not None:
+                    tr_all = d0["amg_transfer"]
+                    dev_nodes = []
+                    for l in range(nl - 1):
+                        if not tr_all[l][0]:
+                            break
+                        fb, cb = int(tr_all[l][1]), int(tr_all[l][2])
+                        if l < nd:
+                            a = np.full(rows_glob[l], -1, np.int64)
+                            for d in ds:
+                                f = int(d["amg_first"][l])
+                                a[f:f + int(d["amg_rows"][l])] = d[f"agg{l}"]
+                        else:
+                            a = d0[f"agg{l}"].astype(np.int64)
+                        dev_nodes.append(a.reshape(-1, fb)[:, 0] // cb)
+                    assert len(own_nodes) == len(dev_nodes), ([len(np.unique(x)) for x in own_nodes], rows_glob)
+                    for lv, (x, y) in enumerate(zip(own_nodes, dev_nodes)):
+                        bad = np.nonzero(x != y)[0]
+                        assert not len(bad), (f"level {lv}: {len(bad)} of {len(x)} node aggregates differ, first at node {bad[0]}: oracle "
+                                              f"{x[bad[:12]].tolist()} device {y[bad[:12]].tolist()}; rows {rows_glob}")
+                    print(f"node bricks across ranks == the oracle's own: x{world} {partition} {mode}, rows per level {rows_glob}")
             # the last level takes the dense inverse, or the coarsening stalled just above its limit (Chebyshev bottom)
             assert rows_glob[0] == len(prob.rhs) and rows_glob[-1] <= 256
             if not mesh_args["amg_distributed"]:

@@ -1054,6 +1054,35 @@ def test_gamg_lattice_bricks_equal_the_oracles_own(case, tet10, tria20):
     assert (reason, ro) == (2, 2) and abs(its - ito) <= 1 and np.abs(s.getSolution() - xo).max() <= 1e-9 * max(1.0, np.abs(xo).max())
 
 
+@pytest.mark.parametrize("box", [(8, 48, 8), (6, 36, 6), (12, 30, 7)])
+def test_gamg_node_bricks_equal_the_oracles_own(box):
+    """Displacement problems on a lattice whose lines are full take their NODE aggregates as bricks in one step (amg_node_bricks:
+    3 or 4 nodes to the brick edge on level 0, pairs below, the short brick at the end of a line joined to its neighbour).  The
+    oracle restates them from the node coordinates alone (O.lattice_node_brick_aggregates) and the device's node aggregates equal
+    them entry for entry on every level that carries the rigid-body transfer."""
+    nx, ny, nz = box
+    mesh = H.gen_box_tets(-0.5, 0.5, nx, 0.0, 6.0, ny, -0.5, 0.5, nz, bc_mode=1, ndof=3)
+    s, dm = _device_problem(pf.ELAST_TET, mesh, H.ELAST_ELEMDATA)
+    s.setSpmvFormat("grouped")
+    s.buildPattern()
+    s.assemble(H.ELAST_ELEMDATA, H.TIMEDATA)
+    s.setPreconditioner("gamg")
+    s.setTolerances(rtol=1e-8, maxits=2000)
+    its, reason, _ = s.factoriseAndSolve()
+    assert reason == 2
+    info = s.amgInfo()
+    nda = dm.NodeDofArrayNew.reshape(-1, 3)
+    free = np.where(nda[:, 0] >= 0)[0]
+    xyz_new = mesh.xyz[:, dm.node_map_get_old]
+    own = O.lattice_node_brick_aggregates(xyz_new, xyz_new[:, free])
+    assert own is not None and len(own) == info["levels"] - 1 >= 2, (None if own is None else [len(a) for a in own], info["rows"])
+    for l, a in enumerate(own):
+        tr = s.amgTransfer(l)
+        assert tr["rbm"]
+        dev = s.amgAggregates(l, info["rows"][l]).reshape(-1, tr["fine_bs"])[:, 0] // tr["coarse_bs"]
+        assert np.array_equal(dev, a), (l, np.nonzero(dev != a)[0][:10])
+
+
 _BRICK_VARIANT = r"""
 import sys, json, hashlib
 import numpy as np
