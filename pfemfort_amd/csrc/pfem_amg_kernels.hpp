@@ -492,7 +492,23 @@ __global__ void __launch_bounds__(kLatGalThreads) k_lat_galerkin(SellDev A, int6
         const int64_t i = mem_idx[m];
         const int64_t base = A.slice_off[i >> 6] + (i & 63);
         const int len = A.rowlen[i];
-        for (int k = 0; k < len; ++k) {
+        // (round 6: eight entries' values and codes are requested before the first is added -- the thread is a chain of its
+        // members' rows, 120 entries on level 0, and with one load in flight at a time the launch ran at 2.3 TB/s; the additions
+        // keep their order)
+        int k = 0;
+        for (; k + 8 <= len; k += 8) {
+            double v[8];
+            uint8_t c[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t q = base + 64LL * (k + j);
+                v[j] = __builtin_nontemporal_load(A.vals + q);
+                c[j] = __builtin_nontemporal_load(code_of + q);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[c[j]][t] += v[j];
+        }
+        for (; k < len; ++k) {
             const int64_t q = base + 64LL * k;
             acc[code_of[q]][t] += A.vals[q];
         }
@@ -1511,6 +1527,7 @@ struct AmgTailLevel {
     double *x, *dd, *t, *r, *b;
     const int32_t *agg, *mem_ptr, *mem_idx;
     int64_t n, nc;
+    int64_t stored;       // slots of the level's matrix (k_amg_tail stages the first level's matrix in LDS when it fits)
     // transfer with rigid-body modes (pfem_amg_rbm.hpp): mem_* list nodes then
     int rbm_dim, fb;
     int64_t nn;
@@ -1524,109 +1541,207 @@ struct AmgTail {
     AmgTailLevel lev[kAmgTailLevels];
 };
 
-__device__ inline void tail_spmv(const SellDev &A, const double *x, double *y)
+// Round 6: one workgroup has nothing to hide a latency behind, and every operation of the tail was a chain of dependent global
+// loads (row -> slice offset -> column -> x): the 343- and 64-row levels of config 3 cost 50 us per cycle, more than level 1 with
+// its million rows.  So the tail works out of LDS: every level's vectors (x, dd, t, r, b, dinv: 6 n doubles a level; use_lds) and,
+// when it fits beside them, the FIRST level's matrix -- values, columns, slice offsets (mat_slots = its stored slots, else 0) --,
+// which the cycle reads four times.  TailView = where a level's data live in this launch.  (The kernel's argument stays
+// untouched: a modified copy of it would live in scratch memory, and every field read would be a memory access.)
+struct TailView {
+    double *x, *dd, *t, *r, *b;
+    const double *dinv;
+    const int64_t *slice_off;
+    const int32_t *cols;
+    const double *vals;
+};
+__device__ inline TailView tail_view(const AmgTail &T, int l, int use_lds, int64_t mat_slots, double *lds)
 {
-    for (int64_t i = threadIdx.x; i < A.n_rows; i += 1024) {
-        const int64_t off = A.slice_off[i >> 6];
-        const int width = static_cast<int>((A.slice_off[(i >> 6) + 1] - off) >> 6);
-        const int32_t *cp = A.cols + off + (i & 63);
-        const double *vp = A.vals + off + (i & 63);
+    const AmgTailLevel &L = T.lev[l];
+    TailView V{L.x, L.dd, L.t, L.r, L.b, L.dinv, L.A.slice_off, L.A.cols, L.A.vals};
+    if (use_lds) {
+        int64_t off = 0, tot = 0;
+        for (int q = 0; q < T.nlev; ++q) {
+            if (q < l) off += 6 * T.lev[q].n;
+            tot += 6 * T.lev[q].n;
+        }
+        double *base = lds + off;
+        const int64_t n = L.n;
+        V.x = base; V.dd = base + n; V.t = base + 2 * n; V.r = base + 3 * n; V.b = base + 4 * n; V.dinv = base + 5 * n;
+        if (l == 0 && mat_slots > 0) {
+            double *mv = lds + tot;
+            int64_t *so = reinterpret_cast<int64_t *>(mv + mat_slots);
+            V.vals = mv;
+            V.slice_off = so;
+            V.cols = reinterpret_cast<int32_t *>(so + L.A.n_slices + 1);
+        }
+    }
+    return V;
+}
+__device__ inline void tail_spmv(const TailView &V, int64_t n_rows, const double *x, double *y)
+{
+    for (int64_t i = threadIdx.x; i < n_rows; i += 1024) {
+        const int64_t off = V.slice_off[i >> 6];
+        const int width = static_cast<int>((V.slice_off[(i >> 6) + 1] - off) >> 6);
+        const int32_t *cp = V.cols + off + (i & 63);
+        const double *vp = V.vals + off + (i & 63);
         double acc = 0.0;
-        for (int k = 0; k < width; ++k) acc = __builtin_fma(vp[64 * k], x[cp[64 * k]], acc);
+        int k = 0;
+        for (; k + 8 <= width; k += 8) {          // (columns, values and gathers of eight entries requested together, then the chain in its order)
+            int c[8];
+            double v[8], xv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { c[j] = cp[64 * (k + j)]; v[j] = vp[64 * (k + j)]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[j] = x[c[j]];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = __builtin_fma(v[j], xv[j], acc);
+        }
+        for (; k < width; ++k) acc = __builtin_fma(vp[64 * k], x[cp[64 * k]], acc);
         y[i] = acc;
     }
     __syncthreads();
 }
 // Chebyshev smoothing exactly as amg_smooth enqueues it (k_amg_cheb_first / k_amg_cheb_next)
-__device__ inline void tail_smooth(const AmgTailLevel &L, const double *b, bool zero_guess, int deg, double ratio)
+__device__ inline void tail_smooth(const AmgTailLevel &L, const TailView &V, const double *b, bool zero_guess, int deg, double ratio, double lmax)
 {
-    const double lmax = L.lam[0];
-    if (!zero_guess) tail_spmv(L.A, L.x, L.t);
+    if (!zero_guess) tail_spmv(V, L.n, V.x, V.t);
     const ChebCoef c0 = cheb_coef(lmax, ratio, 0);
     for (int64_t i = threadIdx.x; i < L.n; i += 1024) {
-        const double ri = zero_guess ? b[i] : b[i] - L.t[i];
-        const double di = c0.c_first * L.dinv[i] * ri;
-        if (deg > 1 && !zero_guess) L.r[i] = ri;
-        if (deg > 1) L.dd[i] = di;
-        L.x[i] = zero_guess ? di : L.x[i] + di;
+        const double ri = zero_guess ? b[i] : b[i] - V.t[i];
+        const double di = c0.c_first * V.dinv[i] * ri;
+        if (deg > 1 && !zero_guess) V.r[i] = ri;
+        if (deg > 1) V.dd[i] = di;
+        V.x[i] = zero_guess ? di : V.x[i] + di;
     }
     __syncthreads();
-    const double *r_in = zero_guess ? b : L.r;
+    const double *r_in = zero_guess ? b : V.r;
     for (int k = 1; k < deg; ++k) {
-        tail_spmv(L.A, L.dd, L.t);
+        tail_spmv(V, L.n, V.dd, V.t);
         const ChebCoef c = cheb_coef(lmax, ratio, k);
         const bool more = k + 1 < deg;
         for (int64_t i = threadIdx.x; i < L.n; i += 1024) {
-            const double ri = r_in[i] - L.t[i];
-            const double di = __builtin_fma(c.c_dd, L.dd[i], c.c_r * L.dinv[i] * ri);
-            if (more) { L.r[i] = ri; L.dd[i] = di; }
-            L.x[i] += di;
+            const double ri = r_in[i] - V.t[i];
+            const double di = __builtin_fma(c.c_dd, V.dd[i], c.c_r * V.dinv[i] * ri);
+            if (more) { V.r[i] = ri; V.dd[i] = di; }
+            V.x[i] += di;
         }
         __syncthreads();
-        r_in = L.r;
+        r_in = V.r;
     }
 }
 // transfer with rigid-body modes inside the tail (a tail level has as many dofs per node as the level below it)
-__device__ inline void tail_rbm_restrict(const AmgTailLevel &L, const AmgTailLevel &C)
+__device__ inline void tail_rbm_restrict(const AmgTailLevel &L, const TailView &V, const AmgTailLevel &C, const TailView &VC)
 {
     const int64_t nc_nodes = C.n / L.fb;
     for (int64_t a = threadIdx.x; a < nc_nodes; a += 1024) {
         double out[6];
-        if (L.rbm_dim == 3) rbm_restrict_node<6, 3>(a, L.mem_ptr, L.mem_idx, L.roff, L.nn, L.b, L.t, L.nn, out);
-        else rbm_restrict_node<3, 2>(a, L.mem_ptr, L.mem_idx, L.roff, L.nn, L.b, L.t, L.nn, out);
-        for (int k = 0; k < L.fb; ++k) C.b[L.fb * a + k] = out[k];
+        if (L.rbm_dim == 3) rbm_restrict_node<6, 3>(a, L.mem_ptr, L.mem_idx, L.roff, L.nn, V.b, V.t, L.nn, out);
+        else rbm_restrict_node<3, 2>(a, L.mem_ptr, L.mem_idx, L.roff, L.nn, V.b, V.t, L.nn, out);
+        for (int k = 0; k < L.fb; ++k) VC.b[L.fb * a + k] = out[k];
     }
 }
-__device__ inline void tail_rbm_prolong(const AmgTailLevel &L, const AmgTailLevel &C, double scale)
+__device__ inline void tail_rbm_prolong(const AmgTailLevel &L, const TailView &V, const TailView &VC, double scale)
 {
     for (int64_t i = threadIdx.x; i < L.nn; i += 1024) {
-        if (L.rbm_dim == 3) rbm_prolong_node<6, 3>(i, L.node_agg, L.roff, L.nn, C.x, scale, L.x);
-        else rbm_prolong_node<3, 2>(i, L.node_agg, L.roff, L.nn, C.x, scale, L.x);
+        if (L.rbm_dim == 3) rbm_prolong_node<6, 3>(i, L.node_agg, L.roff, L.nn, VC.x, scale, V.x);
+        else rbm_prolong_node<3, 2>(i, L.node_agg, L.roff, L.nn, VC.x, scale, V.x);
     }
 }
-__global__ void __launch_bounds__(1024) k_amg_tail(AmgTail T, const CgCtl *ctl)
+// The first level's right-hand side comes from global memory (the restriction above wrote it), its answer goes back there (the
+// prolongation above reads it); nothing else of the tail is read by anybody.  Same operations in the same order: same bits.
+// use_lds = 0: everything stays where it is (a tail whose vectors do not fit).
+__global__ void __launch_bounds__(1024) k_amg_tail(const AmgTail T, const CgCtl *ctl, int use_lds, int64_t mat_slots)
 {
+    extern __shared__ double tail_lds[];
     if (ctl && ctl->flag != 0) return;
     const int nl = T.nlev;
+    __shared__ double lam_of[kAmgTailLevels];    // (every level's eigenvalue bound: requested here, with everything else the tail reads first)
+    if (threadIdx.x < static_cast<unsigned>(nl)) lam_of[threadIdx.x] = T.lev[threadIdx.x].lam[0];
+    if (!use_lds) __syncthreads();
+    if (use_lds) {
+        if (mat_slots > 0) {                     // eight slots a thread and trip in flight (the loads do not wait for the LDS stores of the trip before)
+            const AmgTailLevel &L = T.lev[0];
+            const TailView V = tail_view(T, 0, use_lds, mat_slots, tail_lds);
+            double *mv = const_cast<double *>(V.vals);
+            int32_t *mc = const_cast<int32_t *>(V.cols);
+            int64_t *so = const_cast<int64_t *>(V.slice_off);
+            const double *__restrict__ gv = L.A.vals;
+            const int32_t *__restrict__ gc = L.A.cols;
+            for (int64_t q0 = threadIdx.x; q0 < mat_slots; q0 += 8 * 1024) {
+                double v[8];
+                int32_t c[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int64_t q = q0 + 1024 * j;
+                    v[j] = q < mat_slots ? __builtin_nontemporal_load(gv + q) : 0.0;
+                    c[j] = q < mat_slots ? __builtin_nontemporal_load(gc + q) : 0;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int64_t q = q0 + 1024 * j;
+                    if (q < mat_slots) { mv[q] = v[j]; mc[q] = c[j]; }
+                }
+            }
+            for (int64_t q = threadIdx.x; q <= L.A.n_slices; q += 1024) so[q] = L.A.slice_off[q];
+        }
+        for (int l = 0; l < nl; ++l) {
+            const AmgTailLevel &L = T.lev[l];
+            const TailView V = tail_view(T, l, use_lds, mat_slots, tail_lds);
+            double *dv = const_cast<double *>(V.dinv);
+            for (int64_t i = threadIdx.x; i < L.n; i += 1024) {
+                dv[i] = L.dinv[i];
+                if (l == 0) V.b[i] = L.b[i];
+            }
+        }
+        __syncthreads();
+    }
     for (int l = 0; l < nl; ++l) {
         const AmgTailLevel &L = T.lev[l];
+        const TailView V = tail_view(T, l, use_lds, mat_slots, tail_lds);
         if (l == nl - 1) {
             if (T.dense_n > 0) {
                 const int n = T.dense_n;
                 for (int i = threadIdx.x; i < n; i += 1024) {
                     double a = 0.0;
-                    for (int j = 0; j < n; ++j) a = __builtin_fma(T.dense_inv[j * n + i], L.b[j], a);
-                    L.x[i] = a;
+                    for (int j = 0; j < n; ++j) a = __builtin_fma(T.dense_inv[j * n + i], V.b[j], a);
+                    V.x[i] = a;
                 }
                 __syncthreads();
             } else {
-                tail_smooth(L, L.b, true, T.coarsest_deg, T.ratio);
+                tail_smooth(L, V, V.b, true, T.coarsest_deg, T.ratio, lam_of[l]);
             }
             break;
         }
         const AmgTailLevel &C = T.lev[l + 1];
-        tail_smooth(L, L.b, true, T.deg, T.ratio);
-        tail_spmv(L.A, L.x, L.t);
-        if (L.rbm_dim) tail_rbm_restrict(L, C);
+        const TailView VC = tail_view(T, l + 1, use_lds, mat_slots, tail_lds);
+        tail_smooth(L, V, V.b, true, T.deg, T.ratio, lam_of[l]);
+        tail_spmv(V, L.n, V.x, V.t);
+        if (L.rbm_dim) tail_rbm_restrict(L, V, C, VC);
         else
         for (int64_t a = threadIdx.x; a < C.n; a += 1024) {
             double acc = 0.0;
             for (int q = L.mem_ptr[a]; q < L.mem_ptr[a + 1]; ++q) {
                 const int i = L.mem_idx[q];
-                acc += L.b[i] - L.t[i];
+                acc += V.b[i] - V.t[i];
             }
-            C.b[a] = acc;
+            VC.b[a] = acc;
         }
         __syncthreads();
     }
     for (int l = nl - 2; l >= 0; --l) {
         const AmgTailLevel &L = T.lev[l];
-        const AmgTailLevel &C = T.lev[l + 1];
-        if (L.rbm_dim) tail_rbm_prolong(L, C, T.scale);
+        const TailView V = tail_view(T, l, use_lds, mat_slots, tail_lds);
+        const TailView VC = tail_view(T, l + 1, use_lds, mat_slots, tail_lds);
+        if (L.rbm_dim) tail_rbm_prolong(L, V, VC, T.scale);
         else
-        for (int64_t i = threadIdx.x; i < L.n; i += 1024) L.x[i] = __builtin_fma(T.scale, C.x[L.agg[i]], L.x[i]);
+        for (int64_t i = threadIdx.x; i < L.n; i += 1024) V.x[i] = __builtin_fma(T.scale, VC.x[L.agg[i]], V.x[i]);
         __syncthreads();
-        tail_smooth(L, L.b, false, T.deg, T.ratio);
+        tail_smooth(L, V, V.b, false, T.deg, T.ratio, lam_of[l]);
+    }
+    if (use_lds) {
+        const TailView V = tail_view(T, 0, use_lds, mat_slots, tail_lds);
+        double *x_out = T.lev[0].x;
+        for (int64_t i = threadIdx.x; i < T.lev[0].n; i += 1024) x_out[i] = V.x[i];
     }
 }
 

@@ -124,6 +124,7 @@ struct Amg {
         if (ev_num1) (void)hipEventDestroy(ev_num1);
     }
     int tail_from = -1;                              // first level of the single-launch tail of the cycle (-1: none)
+    size_t tail_lds_allowed = 0;                     // dynamic LDS bytes k_amg_tail has been allowed beyond 64 KB (hipFuncSetAttribute, once)
     // -pc_mg_cycle_type: 1 = V (default), 2 = W -- the coarse problem of every level from 1 down to w_to is visited twice (second
     // visit on the residual of the first).  The levels of the single-launch tail (<= 1024 rows each) stay a V inside:
     // w_to = tail_from, whether or not the fused kernels are in use (amg_cycle_shape has the measurements).

@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(kBlock) k_spmvr_vd(SellRDev G, const unsigned 
     uint32_t w0 = 0, w1 = 0;
     const unsigned long long *__restrict__ qp = codes + lane;
     const uint32_t *__restrict__ wp = G.dwords + lane;
-    double x0[kRelRows] = {0.0, 0.0, 0.0, 0.0};
+    double x0[kRelRows] = {0.0, 0.0, 0.0, 0.0}, xself[kRelRows] = {0.0, 0.0, 0.0, 0.0};
     unsigned long long q0 = 0;
     if (live) {
         const int64_t off = G.gslice_off[gs];
@@ -209,6 +209,9 @@ __global__ void __launch_bounds__(kBlock) k_spmvr_vd(SellRDev G, const unsigned 
         if (nw > 0) w0 = __builtin_nontemporal_load(wp);
         if (nw > 1) w1 = __builtin_nontemporal_load(wp + 64);
         if (width > 0) { load_x4(x, c, x0); q0 = __builtin_nontemporal_load(qp); }
+        // (the rows' own x for the (p,Ap) partial: requested with the first loads, not as one more round trip at the end of the
+        // wave's life -- the WITH_DOT variant cost 11 us over the plain one, profiles/r06)
+        if (WITH_DOT) load_x4(x, static_cast<int>(((gs << 6) + lane) * kRelRows), xself);
     }
     for (int i = threadIdx.x; i < nd; i += kBlock) vd[i] = dict[i];
     if (DICT) gap_tbl[DICT ? threadIdx.x : 0] = G.gap_table[threadIdx.x];
@@ -280,7 +283,7 @@ __global__ void __launch_bounds__(kBlock) k_spmvr_vd(SellRDev G, const unsigned 
         for (int p = 0; p < kRelRows; ++p)
             if (r0 + p < n_rows) {
                 y[r0 + p] = acc[p];
-                if (WITH_DOT && r0 + p < n_dot) dot = __builtin_fma(x[r0 + p], acc[p], dot);
+                if (WITH_DOT && r0 + p < n_dot) dot = __builtin_fma(xself[p], acc[p], dot);
             }
     }
     if (WITH_DOT) block_sum_last_wave(dot, sm, &done_waves, partial + vblock);      // (no barrier at the end of a wave's life)

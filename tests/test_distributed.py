@@ -372,7 +372,9 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                                                             ("poisson", 3, "foreign", "gamg"), ("poisson", 5, "sectors", "gamg_distributed"),
                                                             ("elast", 4, "rcb", "gamg"), ("poisson", 6, "rcb", "gamg"),
                                                             ("poisson", 3, "sectors", "reorder"), ("elast", 2, "slabs", "reorder_gamg"),
-                                                            ("poisson", 2, "slabs", "gamg_single"), ("elast", 3, "yslabs", "gamg_single")])
+                                                            ("poisson", 2, "slabs", "gamg_single"), ("elast", 3, "yslabs", "gamg_single"),
+                                                            ("elast", 3, "yslabs", "gamg_cubic"), ("elast", 2, "xslabs", "gamg_cubic"),
+                                                            ("elast", 4, "rcb", "gamg_cubic_distributed")])
 def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partition, mode, peer=False):
     """2-3 ranks share cuda:0 (host-staged exchange over gloo): the product's multi-rank device loop against the
     ORACLE -- a direct solve of the oracle-assembled global system in the partition's new numbering, and the oracle's
@@ -394,13 +396,18 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
     if mode == "gamg_single":          # the hierarchy across the ranks inside the single-reduction form of the loop: 2 all-reduces per iteration
         mesh_args["single"] = True
         mode = "gamg"
+    if mode in ("gamg_cubic", "gamg_cubic_distributed"):
+        # cubic cells: every coupling inside a brick is strong, so the displacement problem takes its NODE bricks in one step across
+        # the ranks (the default beam's cells are 1.5 x longer along y: the check refuses them and the pairing passes keep the level)
+        mesh_args["box"], mesh_args["cubic"] = (-0.5, 0.5, 6, 0.0, 4.0, 24, -0.5, 0.5, 6), True
+        mode = "gamg" if mode == "gamg_cubic" else "gamg_distributed"
     if mode in ("gamg", "gamg_overlap", "gamg_block", "gamg_distributed"):
         # -pc_type gamg on several ranks: one hierarchy across the ranks where the partition allows it (slabs: every coarse dof
         # has at most two holders), else -- or when asked, "gamg_block" -- block Jacobi over the ranks, every block its own hierarchy
         mesh_args["mode"], mesh_args["pc"], mesh_args["overlap"] = ("devgen" if partition in ("yslabs", "xslabs") else "batched"), "gamg", mode == "gamg_overlap"
         mesh_args["amg_block"] = mode == "gamg_block"
         mesh_args["amg_distributed"] = mode == "gamg_distributed"     # no replicated levels: every level keeps its neighbour plan, global dense bottom
-        if kind_name == "elast" and partition == "yslabs" and mode == "gamg":
+        if kind_name == "elast" and partition == "yslabs" and mode == "gamg" and not mesh_args.get("cubic"):
             # a longer beam: its level 1 (3 dofs per aggregate) is above the dense limit and gets replicated, nodes and all
             mesh_args["box"], mesh_args["long_beam"] = (-0.5, 0.5, 6, 0.0, 6.0, 24, -0.5, 0.5, 6), True
     if mode == "devgen":              # bench.py's path: every rank generates its slab (along the partition's axis) on the device
@@ -528,7 +535,12 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
                     assert own_nodes is not None
                 if partition in ("sectors", "foreign"):
                     assert own_nodes is None
-                if own_nodes is not None:
+                # (cells that are not cubic: the device's check of the couplings inside a brick may refuse the bricks -- the passes
+                # keep the level then, with other aggregates; the cases with cubic cells must take them)
+                n1_dev = rows_glob[1] // int(d0["amg_transfer"][0][2]) if d0["amg_transfer"][0][0] else -1
+                if mesh_args.get("cubic"):
+                    assert own_nodes is not None and len(np.unique(own_nodes[0])) == n1_dev, (len(np.unique(own_nodes[0])), rows_glob)
+                if own_nodes is not None and len(np.unique(own_nodes[0])) == n1_dev:
                     tr_all = d0["amg_transfer"]
                     dev_nodes = []
                     for l in range(nl - 1):

@@ -1054,14 +1054,14 @@ def test_gamg_lattice_bricks_equal_the_oracles_own(case, tet10, tria20):
     assert (reason, ro) == (2, 2) and abs(its - ito) <= 1 and np.abs(s.getSolution() - xo).max() <= 1e-9 * max(1.0, np.abs(xo).max())
 
 
-@pytest.mark.parametrize("box", [(8, 48, 8), (6, 36, 6), (12, 30, 7)])
+@pytest.mark.parametrize("box", [(8, 48, 8, 0.5), (6, 36, 6, 0.5), (10, 30, 6, 0.3)])
 def test_gamg_node_bricks_equal_the_oracles_own(box):
     """Displacement problems on a lattice whose lines are full take their NODE aggregates as bricks in one step (amg_node_bricks:
     3 or 4 nodes to the brick edge on level 0, pairs below, the short brick at the end of a line joined to its neighbour).  The
     oracle restates them from the node coordinates alone (O.lattice_node_brick_aggregates) and the device's node aggregates equal
     them entry for entry on every level that carries the rigid-body transfer."""
-    nx, ny, nz = box
-    mesh = H.gen_box_tets(-0.5, 0.5, nx, 0.0, 6.0, ny, -0.5, 0.5, nz, bc_mode=1, ndof=3)
+    nx, ny, nz, hz = box                    # (cubic cells: a brick needs every coupling inside it to be strong)
+    mesh = H.gen_box_tets(-0.5, 0.5, nx, 0.0, ny / nx, ny, -hz, hz, nz, bc_mode=1, ndof=3)
     s, dm = _device_problem(pf.ELAST_TET, mesh, H.ELAST_ELEMDATA)
     s.setSpmvFormat("grouped")
     s.buildPattern()
