@@ -87,6 +87,11 @@ int pfem_solver_amg_transfer(pfem_solver *s, int level, int *rbm, int *fine_bs, 
  * coupled hierarchy pfem_solver_amg_aggregates hands out GLOBAL coarse numbers and pfem_solver_amg_info's rows are the
  * owned ones on the distributed levels, all rows on the replicated ones.                                                */
 int pfem_solver_amg_layout(pfem_solver *s, int max_levels, int *coupled, int *distributed_levels, int64_t *first_dof, int64_t *local_rows);
+/* how the aggregates of every level of the last gamg hierarchy were formed (kind[l], l < *n_levels; the last level: 0):
+ * 1 bricks of the lattice in one step, 2 node bricks in one step (rigid-body transfer), 3 bricks split between their owners
+ * (several ranks whose dofs do not fill boxes), 4 pairing passes along the axes of the lattice, 5 matching on the strength
+ * graph, 6 roots + neighbours (an independent set of the strength graph).                                                 */
+int pfem_solver_amg_aggregation(pfem_solver *s, int max_levels, int *n_levels, int *kind);
 /* several ranks: neighbour exchanges and all-reduces ONE V-cycle of the last solve enqueued (next to the CG's own exchange
  * and two all-reduces per iteration); 0 / 0 on one rank                                                                */
 int pfem_solver_amg_comm_counts(pfem_solver *s, int *exchanges_per_cycle, int *allreduces_per_cycle);

@@ -391,7 +391,7 @@ def _lat_pad(cuts, single, hi, occ, axis, passes):
     return None
 
 
-def lattice_brick_aggregates(xyz_nodes, xyz_free, dense_limit=128, passes=3, max_levels=13, owner=None, replicate_rows=150000):
+def lattice_brick_aggregates(xyz_nodes, xyz_free, dense_limit=128, passes=3, max_levels=13, owner=None, replicate_rows=150000, split=False):
     """The aggregates of -pc_type gamg on a scalar problem whose mesh nodes sit on a tensor-product lattice with strong
     couplings along every axis (the product: amg_bricks_level / k_lat_* in pfemfort_amd/csrc), restated from the COORDINATES
     alone: a node's position = ranks of its coordinates among the distinct values of ALL mesh nodes (``xyz_nodes`` [dim, nNode]);
@@ -405,7 +405,11 @@ def lattice_brick_aggregates(xyz_nodes, xyz_free, dense_limit=128, passes=3, max
     padded onto multiples of the level's brick size, on every level anew, so that no brick holds dofs of two owners; a rank
     numbers its own bricks (z, y, x), rank after rank.  From the first level of at most ``replicate_rows`` dofs (0: never) on,
     every rank holds the whole level: plain bricks again, of the positions with the padding closed up (rank among the occupied
-    positions per axis)."""
+    positions per axis).
+
+    ``split`` (the product: amg_split_bricks): where some rank's dofs do NOT fill a box -- a METIS-like partition -- nothing is
+    padded; a brick may hold dofs of several owners and every owner's part of it is an aggregate of its own, numbered by its
+    owner in (z, y, x) order of the bricks, rank after rank.  (Partitions of boxes take the padded form either way.)"""
     xyz_nodes = np.atleast_2d(np.asarray(xyz_nodes, dtype=np.float64))
     xyz_free = np.atleast_2d(np.asarray(xyz_free, dtype=np.float64))
     dim, n = xyz_free.shape
@@ -421,13 +425,43 @@ def lattice_brick_aggregates(xyz_nodes, xyz_free, dense_limit=128, passes=3, max
     if owner is not None:
         owner = np.asarray(owner, dtype=np.int64)
         assert len(owner) == n and (np.diff(owner) >= 0).all()
-        boxes = []
+        boxes, split_now = [], False
         for q in np.unique(owner):
             sel = owner == q
             lo, up = pos[:, sel].min(axis=1), pos[:, sel].max(axis=1)
             if int(np.prod(up - lo + 1)) != int(sel.sum()):
-                return None
+                if not split:
+                    return None
+                split_now = True
             boxes.append((lo, up))
+        if split_now:
+            while n > dense_limit and len(aggs) + 1 < max_levels:
+                shift, hi_c, axis_c = _lat_sim_passes(hi, axis, passes)
+                if not any(shift):
+                    break
+                b = [pos[d] >> shift[d] for d in range(3)]
+                nb = [(hi[d] >> shift[d]) + 1 for d in range(3)]
+                lin = b[0] + nb[0] * (b[1] + nb[1] * b[2])
+                nbt = nb[0] * nb[1] * nb[2]
+                if owner is not None:
+                    occ, agg = np.unique(owner * nbt + lin, return_inverse=True)
+                    owner_c, occ = occ // nbt, occ % nbt
+                else:
+                    occ, agg = np.unique(lin, return_inverse=True)
+                if len(occ) * 10 > n * 8:
+                    break
+                aggs.append(agg.astype(np.int64))
+                pos = np.stack([occ % nb[0], (occ // nb[0]) % nb[1], occ // (nb[0] * nb[1])])
+                n, hi, axis = len(occ), hi_c, axis_c
+                if owner is not None:
+                    owner = owner_c
+                    if dense_limit < n <= replicate_rows:        # every rank holds the level whole from here on: positions closed up
+                        owner = None
+                        for d in range(3):
+                            u = np.unique(pos[d])
+                            pos[d] = np.searchsorted(u, pos[d])
+                            hi[d] = len(u) - 1
+            return aggs
         gmin = [min(b[0][d] for b in boxes) for d in range(3)]
         gmax = [max(b[1][d] for b in boxes) for d in range(3)]
         cuts = [sorted({0} | {int(b[0][d]) for b in boxes if b[0][d] > gmin[d]} | {int(b[1][d]) + 1 for b in boxes if b[1][d] < gmax[d]})

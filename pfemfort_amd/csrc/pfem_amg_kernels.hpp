@@ -219,6 +219,39 @@ __global__ void __launch_bounds__(kBlock) k_lat_check(SellDev A, const int32_t *
     }
     brick_flag[lat_brick_linear(B, pi)] = 1;
 }
+// The same question for bricks that may hold dofs of several owners (amg_split_bricks: a rank's aggregate = ITS part of a brick):
+// only the owned rows [0, A.n_rows) and their owned columns count -- a sibling another rank owns is not in the aggregate --, and
+// couplings may reach anywhere (the Galerkin maps of such a level come from the sorted keys, not from the 27 offset codes).
+__global__ void __launch_bounds__(kBlock) k_lat_check_split(SellDev A, const int32_t *__restrict__ pos, const double *__restrict__ diag, LatBricks B,
+                                                             int32_t *__restrict__ brick_flag, int *__restrict__ fail)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= A.n_rows) return;
+    const int64_t base = A.slice_off[i >> 6] + (i & 63);
+    const int len = A.rowlen[i];
+    const int32_t pi = pos[i];
+    const double di = diag[i];
+    double smax = 0.0, ssib[3] = {-1.0, -1.0, -1.0};
+    for (int k = 0; k < len; ++k) {
+        const int32_t j = A.cols[base + 64LL * k];
+        if (j == static_cast<int32_t>(i) || j >= A.n_rows) continue;
+        const int32_t pj = pos[j];
+        const double sij = amg_strength(A.vals[base + 64LL * k], di, diag[j]);
+        smax = fmax(smax, sij);
+        const int x = pi ^ pj;
+        if (x == 1) ssib[0] = sij;
+        else if (x == (1 << 10)) ssib[1] = sij;
+        else if (x == (1 << 20)) ssib[2] = sij;
+    }
+    bool weak = false;
+    for (int a = 0; a < 3; ++a)
+        if (B.shift[a] > 0 && ssib[a] >= 0.0 && !(ssib[a] > 0.0 && ssib[a] >= 0.25 * smax)) weak = true;
+    if (weak) {
+        *fail = 1;
+        atomicAdd(fail + 1, 1);
+    }
+    brick_flag[lat_brick_linear(B, pi)] = 1;
+}
 // aggregate of every node = rank of its brick among the occupied ones (ascending in z, y, x: coarse columns come out ascending
 // by offset code); an aggregate's position on the coarser lattice = its brick's coordinates
 __global__ void __launch_bounds__(kBlock) k_lat_assign(int64_t n, const int32_t *__restrict__ pos, LatBricks B, const int32_t *__restrict__ brick_rank,
@@ -279,6 +312,12 @@ __global__ void __launch_bounds__(kBlock) k_lat_xyz_from_pos(int64_t nn, const i
     if (i >= nn) return;
     const int32_t p = pos[i];
     for (int d = 0; d < 3; ++d) xyz[d * nn + i] = coord[1024 * d + ((p >> (10 * d)) & 0x3ff)];
+}
+// owned dofs that got no position (pos < 0: lattice_assign with fill 0xff): *count > 0
+__global__ void __launch_bounds__(kBlock) k_lat_count_unplaced(int64_t n, const int32_t *__restrict__ pos, int *__restrict__ count)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n && pos[i] < 0) atomicAdd(count, 1);
 }
 // which positions of every axis are occupied (used: [3][1024], zeroed)
 __global__ void __launch_bounds__(kBlock) k_lat_mark_used(int64_t n, const int32_t *__restrict__ pos, int32_t *__restrict__ used)

@@ -53,9 +53,17 @@ struct AmgLevel {
     // rank); lat_tlo / lat_thi = the box THIS rank's owned nodes fill.  Bricks are cut at the stretches' ends (node_brick_axis).
     bool lat_nodes_global = false;
     std::vector<std::pair<int, int>> lat_str[3];
+    // scalar bricks across ranks whose owned dofs do NOT fill boxes (a METIS-like partition; round 6): hint = the GLOBAL positions,
+    // unpadded; an aggregate = the part of a brick that one rank owns (amg_split_bricks); the Galerkin maps come from the sorted
+    // keys like those of any other aggregates.  lat_tlo / lat_thi = the box of this rank's OWNED positions.
+    bool lat_split = false;
     std::vector<double> lat_coord;        // [3 x 1024] coordinate of every position (a brick sits at its lowest corner): the corners a level
                                           // needs when it leaves the brick path (xyz below) come from here instead of travelling down the levels
     DevBuf<double> xyz;                   // coupled hierarchy with a lattice: [3 x n_nodes] a corner of every node's aggregate (see k_amg_xyz_min)
+    // how this level's aggregates were formed (pfem_solver_amg_aggregation): 0 none (last level), 1 bricks in one step, 2 node bricks
+    // in one step, 3 bricks split between their owners, 4 pairing passes on the lattice, 5 matching on the strength graph,
+    // 6 roots + neighbours (independent set)
+    int agg_kind = 0;
     // transfer to the next level (piecewise-constant prolongation)
     int64_t nc = 0;
     DevBuf<int32_t> agg;                  // [n]  coarse dof of every dof

@@ -1073,7 +1073,7 @@ int lattice_distinct(pfem_solver *s, int count[3], std::vector<double> &h_uniq, 
     *ok = true;
     return PFEM_OK;
 }
-int lattice_assign(pfem_solver *s, const std::vector<double> &h_uniq, const int count[3], int64_t n_rows, DevBuf<int32_t> &pos)
+int lattice_assign(pfem_solver *s, const std::vector<double> &h_uniq, const int count[3], int64_t n_rows, DevBuf<int32_t> &pos, int fill = 0)
 {
     const MeshDev &m = s->mesh;
     DevBuf<double> uniq;
@@ -1081,7 +1081,8 @@ int lattice_assign(pfem_solver *s, const std::vector<double> &h_uniq, const int 
     PFEM_HIP(hipMemcpyAsync(uniq.p, h_uniq.data(), sizeof(double) * 3 * 1024, hipMemcpyHostToDevice, s->stream));
     const double *u0 = uniq.p, *u1 = uniq.p + 1024, *u2 = m.ndim > 2 ? uniq.p + 2048 : uniq.p;
     PFEM_TRY(pos.alloc(static_cast<size_t>(std::max<int64_t>(n_rows, 1))));
-    PFEM_HIP(hipMemsetAsync(pos.p, 0, sizeof(int32_t) * static_cast<size_t>(std::max<int64_t>(n_rows, 1)), s->stream));
+    // (fill = 0xff: rows that no node of this rank's mesh carries keep -1 -- a rank may own dofs its own elements never touch)
+    PFEM_HIP(hipMemsetAsync(pos.p, fill, sizeof(int32_t) * static_cast<size_t>(std::max<int64_t>(n_rows, 1)), s->stream));
     if (s->have_incidence && s->d_node_row.p)         // one thread per node through the assembly's node -> row table (4.0 -> 0.1 ms at config 3) ...
         hipLaunchKernelGGL(k_amg_lattice_pos_nodes, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m.nNode, m.ndim, m.ndof, m.xyz,
                            static_cast<const int32_t *>(s->d_node_row.p), n_rows, u0, count[0], u1, count[1], u2, count[2], pos.p);
@@ -4845,6 +4846,17 @@ extern "C" int pfem_solver_amg_transfer(pfem_solver *s, int level, int *rbm, int
             }
         }
     }
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_amg_aggregation(pfem_solver *s, int max_levels, int *n_levels, int *kind)
+{
+    if (!s || !n_levels || !kind || max_levels < 0) return PFEM_ERR_ARG;
+    *n_levels = 0;
+    if (!s->amg || !s->amg->symbolic_ok) return PFEM_ERR_STATE;
+    const std::vector<AmgLevelRef> lev = amg_levels_of(*s->amg);
+    *n_levels = static_cast<int>(lev.size());
+    for (size_t l = 0; l < lev.size() && static_cast<int>(l) < max_levels; ++l) kind[l] = lev[l].next ? lev[l].L->agg_kind : 0;
     return PFEM_OK;
 }
 

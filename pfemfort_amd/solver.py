@@ -277,6 +277,16 @@ class PetscSolver:
             out["xyz"] = a
         return out
 
+    def amgAggregation(self):
+        """How every level's aggregates were formed: a list of "bricks" / "node-bricks" / "split-bricks" / "lattice-passes" /
+        "matching" / "roots" per transfer (one fewer than levels)."""
+        mx = 32
+        nl = C.c_int(0)
+        kind = (C.c_int * mx)()
+        L.check(L.lib().pfem_solver_amg_aggregation(self._h, mx, C.byref(nl), kind), "pfem_solver_amg_aggregation")
+        names = {0: "none", 1: "bricks", 2: "node-bricks", 3: "split-bricks", 4: "lattice-passes", 5: "matching", 6: "roots"}
+        return [names.get(kind[l], str(kind[l])) for l in range(max(nl.value - 1, 0))]
+
     def amgInfo(self):
         """The multigrid hierarchy of the last ``gamg`` solve: rows / nonzeros / eigenvalue bound per level, phase times."""
         mx = 32

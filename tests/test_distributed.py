@@ -36,6 +36,17 @@ def _partition(mesh, world, how, H):
         return H.partition_box_slabs(*mesh.box, world, axis="xyz".index(how[0]))
     if how == "rcb":                   # the build's own geometric partitioner (pfem_partition_rcb)
         return H.partition_rcb(mesh, world)
+    if how == "stairs":
+        # z-slabs whose border planes step up by one layer of cells halfway along x: no rank's dofs fill a box of the lattice
+        # (what a METIS partition of a structured mesh looks like locally), yet almost every 2x2x2 brick has one owner
+        nz = mesh.box[2]
+        x0, x1, z0, z1 = mesh.xyz[0].min(), mesh.xyz[0].max(), mesh.xyz[2].min(), mesh.xyz[2].max()
+
+        def part_of(xyz):
+            step = (xyz[0] > 0.5 * (x0 + x1) + 1e-9).astype(np.float64)
+            layer = np.floor((xyz[2] - z0) / (z1 - z0) * nz - 1e-9) - step
+            return np.clip(np.floor(layer * world / nz), 0, world - 1).astype(np.int32)
+        return part_of(mesh.xyz[:, mesh.conn].mean(axis=1)), part_of(mesh.xyz)
     if how == "idle":                  # the last rank gets nothing: no elements, no nodes, no rows
         return H.partition_box_slabs(*mesh.box, world - 1)
     if how == "foreign":               # slabs, but some nodes deep inside slab 0 are OWNED by the last rank, which has no
@@ -335,6 +346,7 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                          amg_rows=np.array(ai["rows"]), amg_opts=np.array([ai["cheb_degree"], ai["eig_ratio"], ai["coarse_scale"], ai["fine_degree"]]),
                          **{f"agg{l}": s.amgAggregates(l, ai["rows"][l]) for l in range(ai["levels"] - 1)},
                          # rigid-body modes: [rbm, dofs per node, dofs per coarse node, dimension] of every transfer
+                         amg_kinds=np.array(s.amgAggregation()),
                          amg_transfer=np.array([[int(t["rbm"]), t["fine_bs"], t["coarse_bs"], t["dim"]]
                                                 for t in (s.amgTransfer(l) for l in range(ai["levels"] - 1))]).reshape(-1, 4))
         info = s.commInfo()
@@ -373,6 +385,7 @@ def _gpu_worker(rank, world, port, mesh_args, out_dir):
                                                             ("elast", 4, "rcb", "gamg"), ("poisson", 6, "rcb", "gamg"),
                                                             ("poisson", 3, "sectors", "reorder"), ("elast", 2, "slabs", "reorder_gamg"),
                                                             ("poisson", 2, "slabs", "gamg_single"), ("elast", 3, "yslabs", "gamg_single"),
+                                                            ("poisson", 3, "stairs", "gamg"), ("poisson", 3, "stairs", "gamg_distributed"),
                                                             ("elast", 3, "yslabs", "gamg_cubic"), ("elast", 2, "xslabs", "gamg_cubic"),
                                                             ("elast", 4, "rcb", "gamg_cubic_distributed")])
 def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partition, mode, peer=False):
@@ -512,9 +525,30 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
                 own_aggs = O.lattice_brick_aggregates(prob.xyz_new, prob.xyz_new[:, free], owner=owner,
                                                       replicate_rows=0 if mesh_args["amg_distributed"] else 150000)
                 assert (own_aggs is not None) == (partition in ("slabs", "xslabs", "yslabs", "rcb", "idle")), partition
+                if own_aggs is None:
+                    # ranks whose dofs do not fill boxes (round 6): the bricks are split between their owners -- the oracle restates
+                    # those aggregates too (owner x brick); the device takes them where every rank's check of its own rows passes and
+                    # the level shrinks (the stairs always; sectors / foreign scatter single dofs and keep the pairing passes)
+                    own_split = O.lattice_brick_aggregates(prob.xyz_new, prob.xyz_new[:, free], owner=owner, split=True,
+                                                           replicate_rows=0 if mesh_args["amg_distributed"] else 150000)
+                    kinds = [str(k) for k in d0["amg_kinds"]]
+                    taken = kinds[0] == "split-bricks"
+                    if partition == "stairs":
+                        assert taken and own_split is not None, (kinds, rows_glob)
+                    if taken:
+                        own_aggs = own_split
+                        print(f"split bricks across ranks: {kind_name} x{world} {partition} {mode}, rows per level {rows_glob}")
                 if own_aggs is not None:
-                    assert len(own_aggs) == len(aggs), ([len(np.unique(x)) for x in own_aggs], rows_glob)
-                    for lv, (x, y) in enumerate(zip(own_aggs, aggs)):
+                    kinds = [str(k) for k in d0["amg_kinds"]]
+                    n_cmp = len(aggs)
+                    if kinds[0] != "split-bricks":
+                        assert len(own_aggs) == len(aggs), ([len(np.unique(x)) for x in own_aggs], rows_glob, kinds)
+                    else:
+                        # (split bricks: the owners' slivers of a brick that the border cuts couple weakly to their siblings on the coarser
+                        # levels, whose check may hand them to the pairing passes: the levels formed as bricks are compared)
+                        n_cmp = next((l for l, k in enumerate(kinds) if k not in ("bricks", "split-bricks")), len(kinds))
+                        assert n_cmp >= 1 and len(own_aggs) >= n_cmp
+                    for lv, (x, y) in enumerate(zip(own_aggs[:n_cmp], aggs[:n_cmp])):
                         bad = np.nonzero(x != y)[0]
                         assert not len(bad), (f"level {lv}: {len(bad)} of {len(x)} aggregates differ, first at dof {bad[0]}: oracle {x[bad[:12]].tolist()} "
                                               f"device {y[bad[:12]].tolist()}; rows {rows_glob}")
@@ -537,14 +571,15 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
                     assert own_nodes is None
                 # (cells that are not cubic: the device's check of the couplings inside a brick may refuse the bricks -- the passes
                 # keep the level then, with other aggregates; the cases with cubic cells must take them)
-                n1_dev = rows_glob[1] // int(d0["amg_transfer"][0][2]) if d0["amg_transfer"][0][0] else -1
+                kinds = [str(k) for k in d0["amg_kinds"]]
+                assert all([str(k) for k in d["amg_kinds"]] == kinds for d in ds)
                 if mesh_args.get("cubic"):
-                    assert own_nodes is not None and len(np.unique(own_nodes[0])) == n1_dev, (len(np.unique(own_nodes[0])), rows_glob)
-                if own_nodes is not None and len(np.unique(own_nodes[0])) == n1_dev:
+                    assert own_nodes is not None and kinds[0] == "node-bricks", kinds
+                if own_nodes is not None and kinds[0] == "node-bricks":
                     tr_all = d0["amg_transfer"]
                     dev_nodes = []
                     for l in range(nl - 1):
-                        if not tr_all[l][0]:
+                        if not tr_all[l][0] or kinds[l] != "node-bricks":
                             break
                         fb, cb = int(tr_all[l][1]), int(tr_all[l][2])
                         if l < nd:
@@ -555,7 +590,9 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
                         else:
                             a = d0[f"agg{l}"].astype(np.int64)
                         dev_nodes.append(a.reshape(-1, fb)[:, 0] // cb)
-                    assert len(own_nodes) == len(dev_nodes), ([len(np.unique(x)) for x in own_nodes], rows_glob)
+                    assert len(own_nodes) >= len(dev_nodes) >= 1, ([len(np.unique(x)) for x in own_nodes], rows_glob, kinds)
+                    if mesh_args.get("cubic"):
+                        assert len(own_nodes) == len(dev_nodes), ([len(np.unique(x)) for x in own_nodes], rows_glob, kinds)
                     for lv, (x, y) in enumerate(zip(own_nodes, dev_nodes)):
                         bad = np.nonzero(x != y)[0]
                         assert not len(bad), (f"level {lv}: {len(bad)} of {len(x)} node aggregates differ, first at node {bad[0]}: oracle "
