@@ -200,12 +200,16 @@ __global__ void __launch_bounds__(kBlock) k_lat_check(SellDev A, const int32_t *
         const int32_t j = A.cols[base + 64LL * k];
         if (j == static_cast<int32_t>(i)) continue;
         const int32_t pj = pos[j];
+        // (a dof at the node's OWN position: the other owners' parts of the same brick of the level above, on a level that every
+        // rank holds whole after bricks were split between their owners -- amg_split_bricks.  It lands in the node's brick
+        // whatever its coupling, and that coupling -- the strongest a sliver has -- is no yardstick for the siblings')
+        if (pj == pi) continue;
         const double sij = amg_strength(A.vals[base + 64LL * k], di, diag[j]);
         smax = fmax(smax, sij);
-        const int x = pi ^ pj;
-        if (x == 1) ssib[0] = sij;
-        else if (x == (1 << 10)) ssib[1] = sij;
-        else if (x == (1 << 20)) ssib[2] = sij;
+        const int x = pi ^ pj;            // (several dofs may sit at the sibling's position too: the strongest of them speaks for it)
+        if (x == 1) ssib[0] = fmax(ssib[0], sij);
+        else if (x == (1 << 10)) ssib[1] = fmax(ssib[1], sij);
+        else if (x == (1 << 20)) ssib[2] = fmax(ssib[2], sij);
         const int dx = ((pj & 0x3ff) >> B.shift[0]) - bix, dy = (((pj >> 10) & 0x3ff) >> B.shift[1]) - biy, dz = (((pj >> 20) & 0x3ff) >> B.shift[2]) - biz;
         far = far || dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1;
     }

@@ -538,6 +538,14 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
                     if taken:
                         own_aggs = own_split
                         print(f"split bricks across ranks: {kind_name} x{world} {partition} {mode}, rows per level {rows_glob}")
+                    if partition == "stairs":
+                        # ... and the hierarchy is as good as the one-rank bricks of the same mesh: iterations within +2 of the
+                        # oracle's own solve with ITS one-rank bricks, nearly the same rows on the first coarse level
+                        one = O.lattice_brick_aggregates(prob.xyz_new, prob.xyz_new[:, free])
+                        _, its_one, reason_one, *_ = O.pcg_amg(prob.rowptr, prob.cols, prob.vals, prob.rhs, one, rtol=1e-10, cheb_degree=int(deg),
+                                                               eig_ratio=float(ratio), coarse_scale=float(scale), fine_degree=int(fdeg))
+                        assert reason_one == 2 and int(d0["its"]) <= its_one + 2, (int(d0["its"]), its_one)
+                        assert rows_glob[1] <= 1.1 * (int(one[0].max()) + 1)
                 if own_aggs is not None:
                     kinds = [str(k) for k in d0["amg_kinds"]]
                     n_cmp = len(aggs)
