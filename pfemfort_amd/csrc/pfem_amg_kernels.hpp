@@ -91,6 +91,144 @@ __global__ void __launch_bounds__(kBlock) k_amg_hint_coarsen(int64_t n, const in
     const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (i < n) atomicMin(&hint_c[agg[i]], (hint ? hint[i] : static_cast<int32_t>(i)) >> 1);
 }
+// ---- roots + neighbours: aggregates from an independent set of the strength graph (round 6) ---------------------------------
+// WHY.  Where a displacement problem's mesh has no lattice, five passes of pairwise matching gave the rigid-body transfer lopsided
+// aggregates (chains of pairs of pairs): the beam with its nodes moved off the lattice took 61 iterations where 4x4x4 bricks take
+// 22, and every pass cost a sorted aggregate graph.  The classical remedy (Vanek, Mandel, Brezina 1996: aggregation by roots)
+// gives compact ones in a few sweeps over the graph and no sort: a ROOT is a node whose priority is the highest within TWO
+// strong hops among the undecided (so roots end up at least three hops apart), its strong neighbours join it at once, nodes two
+// hops from a root wait; rounds repeat until nobody is undecided; then the waiting nodes join the aggregate of their strongest
+// decided neighbour (two sweeps), and whoever is still alone becomes a root.  j is a strong neighbour of i when
+// s_ij >= 1/4 max_k s_ik (the threshold of the pairing).  Priorities are a hash of the node's place along the curve / its index,
+// unique by construction: the outcome depends on nothing but the graph.  state: 0 undecided, 1 root, 2 member, 3 waiting.
+__device__ __forceinline__ double amg_strength(double w, double di, double dj);
+__device__ __forceinline__ unsigned long long mis_prio(int32_t place, int64_t i)
+{
+    unsigned long long h = static_cast<unsigned long long>(static_cast<uint32_t>(place)) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 32;
+    return ((h & 0x7fffffffull) << 32) | static_cast<unsigned long long>(i + 1);
+}
+__global__ void __launch_bounds__(kBlock) k_mis_init(int64_t n, const int64_t *__restrict__ gptr, const int32_t *__restrict__ gcol,
+                                                      const double *__restrict__ gw, const double *__restrict__ gdiag, const int32_t *__restrict__ hint,
+                                                      double *__restrict__ smax, unsigned long long *__restrict__ prio, int32_t *__restrict__ state,
+                                                      int32_t *__restrict__ match)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double di = gdiag[i];
+    double m = 0.0;
+    for (int64_t q = gptr[i]; q < gptr[i + 1]; ++q) {
+        const int32_t j = gcol[q];
+        if (j != i) m = fmax(m, amg_strength(gw[q], di, gdiag[j]));
+    }
+    smax[i] = m;
+    prio[i] = mis_prio(hint ? hint[i] : static_cast<int32_t>(i), i);
+    state[i] = 0;
+    match[i] = -1;
+}
+// out[i] = max over i and its strong neighbours of (FIRST: the priority of the undecided / else: in[j])
+template <bool FIRST>
+__global__ void __launch_bounds__(kBlock) k_mis_spread(int64_t n, const int64_t *__restrict__ gptr, const int32_t *__restrict__ gcol,
+                                                        const double *__restrict__ gw, const double *__restrict__ gdiag, const double *__restrict__ smax,
+                                                        const int32_t *__restrict__ state, const unsigned long long *__restrict__ in,
+                                                        unsigned long long *__restrict__ out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double di = gdiag[i], thr = 0.25 * smax[i];
+    unsigned long long m = FIRST ? (state[i] == 0 ? in[i] : 0ull) : in[i];
+    for (int64_t q = gptr[i]; q < gptr[i + 1]; ++q) {
+        const int32_t j = gcol[q];
+        if (j == i) continue;
+        const double sij = amg_strength(gw[q], di, gdiag[j]);
+        if (!(sij > 0.0 && sij >= thr)) continue;
+        const unsigned long long v = FIRST ? (state[j] == 0 ? in[j] : 0ull) : in[j];
+        m = v > m ? v : m;
+    }
+    out[i] = m;
+}
+__global__ void __launch_bounds__(kBlock) k_mis_roots(int64_t n, const unsigned long long *__restrict__ prio, const unsigned long long *__restrict__ t2,
+                                                       int32_t *__restrict__ state, int32_t *__restrict__ match)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n && state[i] == 0 && prio[i] == t2[i]) { state[i] = 1; match[i] = static_cast<int32_t>(i); }
+}
+// an undecided node next to a root joins it (the strongest such root, the lower index on a tie); cand = the root, else -1
+__global__ void __launch_bounds__(kBlock) k_mis_join_pick(int64_t n, const int64_t *__restrict__ gptr, const int32_t *__restrict__ gcol,
+                                                           const double *__restrict__ gw, const double *__restrict__ gdiag, const double *__restrict__ smax,
+                                                           const int32_t *__restrict__ state, int32_t *__restrict__ cand)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    int32_t best = -1;
+    if (state[i] == 0) {
+        const double di = gdiag[i], thr = 0.25 * smax[i];
+        double sb = 0.0;
+        for (int64_t q = gptr[i]; q < gptr[i + 1]; ++q) {
+            const int32_t j = gcol[q];
+            if (j == i || state[j] != 1) continue;
+            const double sij = amg_strength(gw[q], di, gdiag[j]);
+            if (sij > 0.0 && sij >= thr && (sij > sb || (sij == sb && j < best))) { sb = sij; best = j; }
+        }
+    }
+    cand[i] = best;
+}
+__global__ void __launch_bounds__(kBlock) k_mis_join_commit(int64_t n, const int32_t *__restrict__ cand, int32_t *__restrict__ state, int32_t *__restrict__ match)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n && cand[i] >= 0) { state[i] = 2; match[i] = cand[i]; }
+}
+// an undecided node next to a MEMBER is two hops from a root: it waits (state 3); *left counts the nodes still undecided
+__global__ void __launch_bounds__(kBlock) k_mis_wait(int64_t n, const int64_t *__restrict__ gptr, const int32_t *__restrict__ gcol,
+                                                      const double *__restrict__ gw, const double *__restrict__ gdiag, const double *__restrict__ smax,
+                                                      const int32_t *__restrict__ state, int32_t *__restrict__ cand)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    int32_t w = 0;
+    if (state[i] == 0) {
+        const double di = gdiag[i], thr = 0.25 * smax[i];
+        for (int64_t q = gptr[i]; q < gptr[i + 1] && !w; ++q) {
+            const int32_t j = gcol[q];
+            if (j == i || state[j] != 2) continue;
+            const double sij = amg_strength(gw[q], di, gdiag[j]);
+            if (sij > 0.0 && sij >= thr) w = 1;
+        }
+    }
+    cand[i] = w;
+}
+__global__ void __launch_bounds__(kBlock) k_mis_wait_commit(int64_t n, const int32_t *__restrict__ cand, int32_t *__restrict__ state, int *__restrict__ left)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    if (cand[i]) state[i] = 3;
+    if (left && state[i] == 0) atomicAdd(left, 1);
+}
+// the waiting (and any still undecided) nodes: the aggregate of the strongest decided neighbour (any negative coupling counts here:
+// nobody stays alone for a threshold); cand = that aggregate's root, else -1
+__global__ void __launch_bounds__(kBlock) k_mis_adopt_pick(int64_t n, const int64_t *__restrict__ gptr, const int32_t *__restrict__ gcol,
+                                                            const double *__restrict__ gw, const double *__restrict__ gdiag,
+                                                            const int32_t *__restrict__ state, const int32_t *__restrict__ match, int32_t *__restrict__ cand)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    int32_t best = -1;
+    if (state[i] == 0 || state[i] == 3) {
+        const double di = gdiag[i];
+        double sb = 0.0;
+        int32_t bj = -1;
+        for (int64_t q = gptr[i]; q < gptr[i + 1]; ++q) {
+            const int32_t j = gcol[q];
+            if (j == i || (state[j] != 1 && state[j] != 2)) continue;
+            const double sij = amg_strength(gw[q], di, gdiag[j]);
+            if (sij > 0.0 && (sij > sb || (sij == sb && j < bj))) { sb = sij; bj = j; }
+        }
+        if (bj >= 0) best = match[bj];
+    }
+    cand[i] = best;
+}
 // ---- pairing on a tensor-product lattice -----------------------------------------------------------------------------
 // When the nodes of the mesh sit on a lattice (every coordinate takes few distinct values: the generated boxes, the
 // reference's tet10 / tet100 files) a node's hint is its lattice position, 10 bits per axis (x | y << 10 | z << 20), and a

@@ -1011,7 +1011,9 @@ def test_gamg_solve_equals_oracle_restatement(case, tet10, beam, tria20, golden_
             cnt = np.bincount(s.amgAggregates(l, rows[l]).reshape(-1, tr["fine_bs"])[:, 0] // tr["coarse_bs"])
             # (level 0 of a displacement problem: five passes of pairing, 32 nodes -- on a lattice, where the odd node of a line joins
             # its neighbour's pair, up to 4 x 6 x 3; below: three passes, 8 nodes, on a lattice up to 3 x 3 x 3)
-            assert len(cnt) * tr["coarse_bs"] == n_c and cnt.min() >= 1 and cnt.max() <= (72 if l == 0 else (27 if case == "beam" else 8))
+            # (no lattice: roots + neighbours -- a root, everybody around it, and the leftovers between: compact, no fixed size)
+            kind_l = s.amgAggregation()[l]
+            assert len(cnt) * tr["coarse_bs"] == n_c and cnt.min() >= 1 and cnt.max() <= (96 if kind_l == "roots" else (72 if l == 0 else (27 if case == "beam" else 8)))
             continue
         cnt = np.bincount(a)
         # (three passes of pairing: at most 8; on the beam's lattice the node a line of odd length leaves over joins the pair next
