@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "pfem_internal.hpp"
+#include "pfem_vdhash.hpp"
 #include "pfem_kernels.hpp"
 #include "pfem_valdict.hpp"
 #include "pfem_amg_kernels.hpp"
@@ -555,6 +556,11 @@ struct pfem_solver {
     // codes belong to (rows to the lane: kRelRows / kGroupRows, 0 = none), whether they hold the current values, whether the
     // SpMV may stream them (vd_ok), the dictionary's size; vd_refused: this pattern's values are too many, no more tries
     DevBuf<unsigned long long> d_vcodes, d_vtable;
+    // ... straight from the gather kernel (pfem_vdhash.hpp): the hash table of the dictionary; vd_hash_ok: it belongs to the
+    // current dictionary and every slot of d_vcodes has been encoded against that dictionary at least once (the explicit zeros of
+    // the group form keep their codes); vd_direct_pending: the last assembly wrote the codes itself, its verdict has not been read
+    DevBuf<VdHashEntry> d_vhash;
+    bool vd_hash_ok = false, vd_direct_pending = false;
     DevBuf<double> d_vdict;
     DevBuf<VdState> d_vstate;
     int vd_rows = 0, vd_n = 0;
@@ -1988,6 +1994,7 @@ int zero_values(pfem_solver *s, bool rows_overwritten = false)
     s->rhs_summed = false;
     s->rel_vals_current = false;            // (whoever writes the values next says so again if it writes both forms)
     s->asm_bound_fresh = false;
+    s->vd_direct_pending = false;
     s->grp_vals_current = false;
     s->vd_current = false;
     return PFEM_OK;
@@ -2013,7 +2020,7 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
     // setZero, solverpetsc.F:222-246 (the value array needs no clearing when every row is stored whole by the gather
     // kernels; hub rows, if any, are accumulated with atomics and do)
     PFEM_TRY(zero_values(s, gather && (use_lds || elast_rows) && s->n_hubs == 0));
-    bool wrote_rel = false, wrote_grp = false, wrote_bound = false;
+    bool wrote_rel = false, wrote_grp = false, wrote_bound = false, wrote_codes = false;
     if (gather) {
         // gather form: one thread per node, no atomics, bit-reproducible
         const dim3 grid(grid_for(m.nNode)), block(kBlock);
@@ -2054,11 +2061,23 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
                                 s->n_hubs == 0 && !s->amg->lev.empty() && s->amg->lev[0]->fine && s->amg->lev[0]->n == s->n_loc &&
                                 !std::getenv("PFEM_DEBUG_NO_ASM_BOUND")) ? s->amg->lev[0].get() : nullptr;
                 const bool bound = L0 && L0->dinv.p && L0->t.p && L0->dinv.n >= static_cast<size_t>(s->n_loc) && L0->t.n >= static_cast<size_t>(s->n_loc);
+                // (the SpMV's value CODES instead of the fp64 copy of that form when the last step left a dictionary, its hash table
+                // and a fully encoded code array behind: pfem_vdhash.hpp; PFEM_VD_DIRECT=0: the encode pass of round 5)
+                const bool vd_on = [] { const char *e = std::getenv("PFEM_SPMV_VALDICT"); return e ? std::atoi(e) != 0 : true; }();
+                const bool direct = both && vd_on && s->vd_have_dict && s->vd_hash_ok && s->vd_ok && s->vd_rows == kRelRows && !s->rel_gap32 && s->d_vhash.p &&
+                                    s->d_vcodes.p && s->d_vstate.p && s->d_vcodes.n >= static_cast<size_t>(s->r_stored) && !std::getenv("PFEM_VD_DIRECT_OFF");
+                if (direct) {
+                    const VdState reset{s->vd_n, 0, 0, 0};
+                    PFEM_HIP(hipMemcpyAsync(s->d_vstate.p, &reset, sizeof reset, hipMemcpyHostToDevice, s->stream));
+                }
                 hipLaunchKernelGGL(k_gather_poisson_tet4, xgrid, rblock, rlds, s->stream, m.nNode, A, s->d_rhs.p, prm, ip, ic, irec, nrow,
                                    static_cast<const double4 *>(s->d_node4.p), s->d_err.p, xcd_per,
                                    both ? static_cast<const uint8_t *>(s->d_relk.p) : nullptr, both ? static_cast<const int64_t *>(s->d_rslice_off.p) : nullptr,
-                                   both ? s->d_rvals.p : nullptr, bound ? L0->dinv.p : nullptr, bound ? L0->t.p : nullptr);
-                wrote_rel = both;
+                                   (both && !direct) ? s->d_rvals.p : nullptr, bound ? L0->dinv.p : nullptr, bound ? L0->t.p : nullptr,
+                                   direct ? static_cast<const VdHashEntry *>(s->d_vhash.p) : nullptr,
+                                   direct ? reinterpret_cast<uint16_t *>(s->d_vcodes.p) : nullptr, direct ? s->d_vstate.p : nullptr);
+                wrote_rel = both && !direct;
+                wrote_codes = direct;
                 wrote_bound = bound;
             } else {
                 PFEM_GATHER(PFEM_POISSON_TET);
@@ -2118,6 +2137,7 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
     if (err) return err;
     s->host_values_dirty = false;
     s->rel_vals_current = wrote_rel;
+    s->vd_direct_pending = wrote_codes;
     s->asm_bound_fresh = wrote_bound;
     s->grp_vals_current = wrote_grp;
     s->vd_current = false;
@@ -2421,6 +2441,7 @@ int build_groups(pfem_solver *s)
     s->grouped = miss == 0;          // a gap missing from the table: the row form stays (never wrong columns)
     s->grp_vals_current = false;
     s->vd_current = s->vd_ok = s->vd_have_dict = s->vd_refused = false;       // (a new pattern: new codes, a new verdict)
+    s->vd_hash_ok = s->vd_direct_pending = false;
     s->vd_rows = 0;
     s->d_row_group.release();
     if (s->grouped && !std::getenv("PFEM_DEBUG_NO_REL_DIRECT")) {       // for an assembly that writes this copy itself; its zero padding is set here, once
@@ -2531,7 +2552,9 @@ int build_rel_groups(pfem_solver *s)
     // copy (offsets a row lacks) are set here once and never written again
     s->rel_vals_current = false;
     s->asm_bound_fresh = false;
+    s->vd_direct_pending = false;
     s->vd_current = s->vd_ok = s->vd_have_dict = s->vd_refused = false;
+    s->vd_hash_ok = s->vd_direct_pending = false;
     s->vd_rows = 0;
     s->d_relk.release();
     if (s->max_row_len > 0 && !std::getenv("PFEM_DEBUG_NO_REL_DIRECT")) {
@@ -2556,7 +2579,11 @@ int build_rel_groups(pfem_solver *s)
 // wrote the relative-group copy itself and nothing has touched the values since.)
 inline void mark_group_vals(pfem_solver *s)
 {
-    s->group_vals_stale = !((s->use_rel() && s->rel_vals_current) || (s->use_grouped() && s->grp_vals_current));
+    // (... or nobody will read that copy: the SpMV streams codes that are current -- written by the assembly itself, its verdict
+    // pending, or encoded from a copy that has since been overwritten by nothing)
+    const bool vd_on = [] { const char *e = std::getenv("PFEM_SPMV_VALDICT"); return e ? std::atoi(e) != 0 : true; }();
+    const bool codes_serve = vd_on && s->use_rel() && s->vd_rows == kRelRows && (s->vd_direct_pending || (s->vd_current && s->vd_ok));
+    s->group_vals_stale = !((s->use_rel() && (s->rel_vals_current || codes_serve)) || (s->use_grouped() && s->grp_vals_current));
 }
 // The SpMV's codes of the current values (pfem_valdict.hpp).  One wait for the device per call that finds new values: the
 // verdict decides which kernel the solve launches.
@@ -2603,13 +2630,21 @@ int refresh_value_codes(pfem_solver *s)
         PFEM_HIP(hipMemcpyAsync(&st, s->d_vstate.p, sizeof st, hipMemcpyDeviceToHost, s->stream));
         PFEM_HIP(hipStreamSynchronize(s->stream));
         if (st.fail || st.count < 1 || st.count > kVdMax) {
-            s->vd_ok = s->vd_have_dict = false;
+            s->vd_ok = s->vd_have_dict = s->vd_hash_ok = false;
             s->vd_refused = true;          // (until the pattern changes: a mesh of this kind does not repeat its element matrices)
             if (verbose) std::fprintf(stderr, "  value dictionary: more than %d distinct matrix values, the SpMV keeps its fp64 copy\n", kVdMax);
             return PFEM_OK;
         }
         s->vd_n = st.count;
         s->vd_have_dict = true;
+        s->vd_hash_ok = false;
+        if (rows == kRelRows) {         // the look-up table the assembly kernel uses from the next step on (pfem_vdhash.hpp)
+            if (!s->d_vhash.p) PFEM_TRY(s->d_vhash.alloc(kVdHashSlots));
+            PFEM_HIP(hipMemsetAsync(s->d_vhash.p, 0xff, sizeof(VdHashEntry) * kVdHashSlots, s->stream));
+            hipLaunchKernelGGL(k_vd_hash_build, dim3((kVdMax + kBlock - 1) / kBlock), dim3(kBlock), 0, s->stream, static_cast<const double *>(s->d_vdict.p),
+                               static_cast<const VdState *>(s->d_vstate.p), s->d_vhash.p);
+            PFEM_TRY(check_kernel("k_vd_hash_build"));
+        }
         PFEM_TRY(encode());
         if (st.miss) {                  // (cannot happen for finite values; whatever it is, the fp64 copy is always right)
             s->vd_ok = s->vd_have_dict = false;
@@ -2620,6 +2655,7 @@ int refresh_value_codes(pfem_solver *s)
     }
     s->vd_ok = true;
     s->vd_current = true;
+    s->vd_hash_ok = rows == kRelRows && s->d_vhash.p != nullptr;        // (every slot now carries a code of THIS dictionary)
     s->vd_encode_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (verbose) std::fprintf(stderr, "  value dictionary: %d distinct values among %lld slots, codes refreshed in %.3f ms (host, incl. the wait)\n", s->vd_n,
                               static_cast<long long>(rows * n_entries), s->vd_encode_ms);
@@ -2630,6 +2666,24 @@ int refresh_value_codes(pfem_solver *s)
 int refresh_group_vals_only(pfem_solver *s);
 int refresh_group_vals(pfem_solver *s)
 {
+    if (s->vd_direct_pending) {
+        // the assembly wrote the SpMV's codes itself (k_gather_poisson_tet4 through the dictionary's hash table): one read of its
+        // verdict.  A value the dictionary lacks -- new coefficients, a moved mesh -- and the full path takes over: the fp64 copy of
+        // the group form re-packed from the row form, collection, sort, encode.
+        s->vd_direct_pending = false;
+        const bool enabled = [] { const char *e = std::getenv("PFEM_SPMV_VALDICT"); return e ? std::atoi(e) != 0 : true; }();
+        VdState st{0, 0, 1, 0};
+        PFEM_HIP(hipMemcpyAsync(&st, s->d_vstate.p, sizeof st, hipMemcpyDeviceToHost, s->stream));
+        PFEM_HIP(hipStreamSynchronize(s->stream));
+        if (enabled && !st.miss && !st.fail && s->use_rel() && s->vd_rows == kRelRows) {
+            s->vd_ok = s->vd_current = true;
+            s->group_vals_stale = false;
+            if (std::getenv("PFEM_VD_VERBOSE")) std::fprintf(stderr, "  value dictionary: codes written by the assembly kernel (%d values)\n", s->vd_n);
+            return PFEM_OK;
+        }
+        s->vd_current = false;
+        s->group_vals_stale = true;
+    }
     PFEM_TRY(refresh_group_vals_only(s));
     return refresh_value_codes(s);
 }
@@ -4705,6 +4759,7 @@ extern "C" int pfem_solver_solve(pfem_solver *s, int *its, int *reason, double *
             PFEM_HIP(hipMemcpyAsync(dv.p, s->h_vals.data(), sizeof(double) * s->nnz, hipMemcpyHostToDevice, s->stream));
             s->rel_vals_current = false;
             s->asm_bound_fresh = false;
+            s->vd_direct_pending = false;
             s->grp_vals_current = false;
             s->vd_current = false;
             hipLaunchKernelGGL(k_csr_vals_to_sell, dim3(grid_for(s->n_loc)), dim3(kBlock), 0, s->stream, s->sell(), s->d_rowptr.p, dv.p);

@@ -1001,7 +1001,9 @@ __global__ void __launch_bounds__(kBlock) k_gather_poisson_tet4(int64_t nNode, S
                                                                  unsigned xcd_per, const uint8_t *__restrict__ relk = nullptr,
                                                                  const int64_t *__restrict__ rslice_off = nullptr,
                                                                  double *__restrict__ rvals = nullptr,
-                                                                 double *__restrict__ dinv_out = nullptr, double *__restrict__ ratio_out = nullptr)
+                                                                 double *__restrict__ dinv_out = nullptr, double *__restrict__ ratio_out = nullptr,
+                                                                 const VdHashEntry *__restrict__ vhash = nullptr, uint16_t *__restrict__ codes16 = nullptr,
+                                                                 VdState *__restrict__ vstate = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];
     const int T = blockDim.x;
@@ -1076,6 +1078,21 @@ __global__ void __launch_bounds__(kBlock) k_gather_poisson_tet4(int64_t nNode, S
             A.vals[q] = v;
             rp[4LL * 64 * relk[q]] = v;
         }
+    } else if (codes16) {
+        // the row form, and the relative-group form's CODES (pfem_vdhash.hpp: the dictionary of the last step through its hash
+        // table; word = entry of the group's slice, the row's 16 bits at plane row % 4): no fp64 copy of that form, no encode pass
+        const int64_t g = row >> 2;
+        uint16_t *cp = codes16 + 4 * (rslice_off[g >> 6] + (g & 63)) + (row & 3);
+        bool missed = false;
+        for (int k = 0; k < len; ++k) {
+            const int64_t q = base + (static_cast<int64_t>(k) << 6);
+            const double v = acc[k * T];
+            A.vals[q] = v;
+            int code = vd_hash_find(vhash, static_cast<unsigned long long>(__double_as_longlong(v)));
+            if (code < 0) { missed = true; code = 0; }
+            cp[4LL * 64 * relk[q]] = static_cast<uint16_t>(code);
+        }
+        if (missed) vstate->miss = 1;
     } else
     for (int k = 0; k < len; ++k) A.vals[base + (static_cast<int64_t>(k) << 6)] = acc[k * T];
     rhs[row] = facc;

@@ -19,21 +19,9 @@
 //   SpMV streams, as before.
 // One read of the verdict (3 ints) by the host per assembly decides which kernel the solve launches.
 #pragma once
+#include "pfem_vdhash.hpp"
 
 namespace pfem {
-
-constexpr int kVdMax = 4096;                    // distinct values a dictionary may hold: 32 KB of LDS in the SpMV
-constexpr int kVdTable = 16384;                 // slots of the collection table
-constexpr uint64_t kVdEmpty = ~0ull;            // (the bit pattern of a NaN no assembly produces; met as a VALUE it fails the form)
-struct VdState { int count, fail, miss, pad; };
-
-__device__ __forceinline__ uint32_t vd_hash(uint64_t b)
-{
-    b ^= b >> 33;
-    b *= 0xff51afd7ed558ccdull;
-    b ^= b >> 33;
-    return static_cast<uint32_t>(b);
-}
 
 // distinct bit patterns of vals[0..n) into table (kVdTable slots, kVdEmpty = free); st->count of them, st->fail beyond kVdMax
 __global__ void __launch_bounds__(kBlock) k_vd_collect(const double *__restrict__ vals, int64_t n, unsigned long long *table, VdState *st)
@@ -108,6 +96,26 @@ __global__ void __launch_bounds__(1024) k_vd_finish(const unsigned long long *__
     if (threadIdx.x == 0) st->count = n;
 }
 
+// ---- the codes straight from the assembly kernel (round 6) -------------------------------------------------------------------
+// In the steady state of a time loop the dictionary does not change: the gather kernel has every value of a row in its hands,
+// so it looks the value up itself and writes the code where the encode pass would (k_gather_poisson_tet4): the pass over
+// 118 M slots (0.31 ms at config 3) and the fp64 copy of the relative-group form it reads (945 MB written by the assembly) both
+// go away.  The look-up is a hash table of the dictionary in global memory (L2-resident: kVdHashSlots x 16 B), open addressing,
+// {bit pattern, code}; a value that is not there raises VdState::miss and the next solve falls back to the full path (re-pack
+// of the fp64 copy, collection, sort, encode).  Slots the gather kernel never writes -- the explicit zeros of the group form --
+// keep the codes the last full encode gave them: valid while the dictionary stands.
+__global__ void __launch_bounds__(kBlock) k_vd_hash_build(const double *__restrict__ dict, const VdState *__restrict__ st, VdHashEntry *__restrict__ table)
+{
+    if (st->fail) return;
+    const int n = min(st->count, kVdMax);
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(dict[i]));
+    for (uint32_t h = vd_hash(b) & (kVdHashSlots - 1), tries = 0; tries < kVdHashSlots; h = (h + 1) & (kVdHashSlots - 1), ++tries) {
+        const unsigned long long old = atomicCAS(&table[h].key, static_cast<unsigned long long>(kVdEmpty), b);
+        if (old == kVdEmpty || old == b) { table[h].code = static_cast<unsigned long long>(i); return; }
+    }
+}
 // codes of every slot of a group form with ROWS rows to the lane: slot (k, p) of lane l of a slice that starts at entry `off`
 // lives at vals[ROWS * off + (ROWS * k + p) * 64 + l]; entry i = off + 64 k + l gets the word  code_0 | code_1 << 16 | ...
 template <int ROWS>
