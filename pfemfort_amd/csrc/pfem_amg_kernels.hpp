@@ -658,10 +658,28 @@ __global__ void __launch_bounds__(kBlock) k_lat_codes_fill(SellDev A, const int3
 // coarse row's entries.  Same additions in the same order as the map-driven k_amg_galerkin (member rows ascending, entries of
 // a row ascending): the same bits, read as 8 + 1 bytes per fine entry along the rows instead of slot gathers per coarse entry.
 constexpr int kLatGalThreads = 128;
+// Round 6.  (1) The thread was a chain of dependent loads -- member -> row length / slice offset -> entries, member after
+// member, eight of them, ten waves to the CU (the accumulators' LDS): level 0's product ran at 2.3 TB/s, 460 us of a solve's
+// 1.05 ms of numeric set-up.  Now the members' indices, row lengths and slice offsets are requested together (three round trips
+// for all eight), and a row's entries sixteen at a time; the additions keep their order.  (2) While the coarse row is in the
+// thread's hands it also leaves behind what the rest of the numeric phase would read the coarse matrix for again: the inverse
+// diagonal and the row's share of the Gershgorin bound (k_amg_diag_bound's sums, in slot order: dinv_out / ratio_out; the
+// diagonal is offset code 13, the brick itself), and the row's value CODES against the level's dictionary (k_vd_encode16's
+// look-up through the dictionary's hash table, pfem_vdhash.hpp: vhash / codes / vstate; a value the dictionary lacks raises miss).
+struct LatGalExtra {
+    double *dinv_out, *ratio_out;          // [na] or null
+    const VdHashEntry *vhash;              // or null
+    uint16_t *codes;                       // [coarse stored]
+    VdState *vstate;
+};
+// (Tried and dropped, round 6: the 27 accumulators in REGISTERS -- the code of "entry k of member j" is the same in nearly every lane
+// of a wave on a lattice, so it was read from one lane and the lanes that agree added under a wave-uniform switch, the others in
+// further turns.  Occupancy 10 -> 16 waves a CU and no LDS round trips, yet level 0 took 677 us against 545 and the small levels --
+// all boundary, up to 27 turns an entry -- 110-150 us against 25-35.)
 __global__ void __launch_bounds__(kLatGalThreads) k_lat_galerkin(SellDev A, int64_t na, const int32_t *__restrict__ mem_ptr,
                                                                   const int32_t *__restrict__ mem_idx, const uint8_t *__restrict__ code_of,
                                                                   const uint32_t *__restrict__ code_mask, const int64_t *__restrict__ c_slice_off,
-                                                                  double *__restrict__ coarse_vals)
+                                                                  double *__restrict__ coarse_vals, LatGalExtra X)
 {
     __shared__ double acc[kLatCodes][kLatGalThreads];
     const int64_t I = static_cast<int64_t>(blockIdx.x) * kLatGalThreads + threadIdx.x;
@@ -669,37 +687,62 @@ __global__ void __launch_bounds__(kLatGalThreads) k_lat_galerkin(SellDev A, int6
     const int t = threadIdx.x;
 #pragma unroll
     for (int c = 0; c < kLatCodes; ++c) acc[c][t] = 0.0;
-    for (int32_t m = mem_ptr[I]; m < mem_ptr[I + 1]; ++m) {
-        const int64_t i = mem_idx[m];
-        const int64_t base = A.slice_off[i >> 6] + (i & 63);
-        const int len = A.rowlen[i];
-        // (round 6: eight entries' values and codes are requested before the first is added -- the thread is a chain of its
-        // members' rows, 120 entries on level 0, and with one load in flight at a time the launch ran at 2.3 TB/s; the additions
-        // keep their order)
-        int k = 0;
-        for (; k + 8 <= len; k += 8) {
-            double v[8];
-            uint8_t c[8];
+    const int32_t m0 = mem_ptr[I], m1 = mem_ptr[I + 1];
+    for (int32_t mb = m0; mb < m1; mb += 8) {
+        int32_t mi[8];
+        int len[8];
+        int64_t base[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int64_t q = base + 64LL * (k + j);
-                v[j] = __builtin_nontemporal_load(A.vals + q);
-                c[j] = __builtin_nontemporal_load(code_of + q);
-            }
+        for (int j = 0; j < 8; ++j) mi[j] = mb + j < m1 ? __builtin_nontemporal_load(mem_idx + mb + j) : -1;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[c[j]][t] += v[j];
+        for (int j = 0; j < 8; ++j) {
+            len[j] = mi[j] >= 0 ? A.rowlen[mi[j]] : 0;
+            base[j] = mi[j] >= 0 ? A.slice_off[mi[j] >> 6] + (mi[j] & 63) : 0;
         }
-        for (; k < len; ++k) {
-            const int64_t q = base + 64LL * k;
-            acc[code_of[q]][t] += A.vals[q];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            for (int k0 = 0; k0 < len[j]; k0 += 16) {
+                double v[16];
+                uint8_t c[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const bool in = k0 + e < len[j];
+                    const int64_t q = base[j] + 64LL * (k0 + e);
+                    v[e] = in ? __builtin_nontemporal_load(A.vals + q) : 0.0;
+                    c[e] = in ? __builtin_nontemporal_load(code_of + q) : static_cast<uint8_t>(0);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (k0 + e < len[j]) acc[c[e]][t] += v[e];
+            }
         }
     }
-    double *out = coarse_vals + c_slice_off[I >> 6] + (I & 63);
+    const int64_t out0 = c_slice_off[I >> 6] + (I & 63);
+    double *out = coarse_vals + out0;
     const uint32_t mask = code_mask[I];
     int r = 0;
+    double sabs = 0.0;
+    bool missed = false;
 #pragma unroll
     for (int c = 0; c < kLatCodes; ++c)
-        if (mask & (1u << c)) out[64LL * r++] = acc[c][t];
+        if (mask & (1u << c)) {
+            const double v = acc[c][t];
+            out[64LL * r] = v;
+            sabs += fabs(v);
+            if (X.vhash) {
+                int code = vd_hash_find(X.vhash, static_cast<unsigned long long>(__double_as_longlong(v)));
+                if (code < 0) { missed = true; code = 0; }
+                X.codes[out0 + 64LL * r] = static_cast<uint16_t>(code);
+            }
+            ++r;
+        }
+    if (X.dinv_out) {
+        const double d = (mask & (1u << 13)) ? acc[13][t] : 0.0;
+        const bool pos = d > 0.0;
+        X.dinv_out[I] = pos ? 1.0 / d : 1.0;
+        X.ratio_out[I] = pos ? sabs / d : 1.0;
+    }
+    if (missed) X.vstate->miss = 1;
 }
 // distinct values of one coordinate: every node drops its value into a small open-addressing table (a lattice has a few
 // hundred distinct values per axis, so almost every probe finds its value already there); *overflow when the table fills

@@ -97,6 +97,12 @@ struct AmgLevel {
     DevBuf<unsigned long long> vtable;
     int vd_n = 0;
     bool vd_ok = false, vd_have_dict = false, vd_refused = false;
+    // round 6: the Galerkin product that forms this level's values also writes their codes (k_lat_galerkin through the hash table
+    // of the dictionary, pfem_vdhash.hpp) and leaves the inverse diagonal + the rows' Gershgorin ratios behind
+    DevBuf<VdHashEntry> vhash;
+    bool vd_hash_ok = false;              // vhash belongs to vdict, and every slot of vcodes carries a code of it
+    bool vd_direct = false;               // this solve's codes came from the Galerkin product: verdict in Amg::vd_states, not read yet
+    bool bound_fresh = false;             // dinv and t (ratios) of this level were written by the product that formed its values
     double *x = nullptr, *dd = nullptr;
     DevBuf<double> x1;                    // W-cycle: the first visit's answer while the second is on its way
     double lam_host = 0.0;
