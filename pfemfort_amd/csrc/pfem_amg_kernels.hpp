@@ -1165,10 +1165,12 @@ __global__ void __launch_bounds__(1024) k_amg_dense_inverse(SellDev A, double *_
     const int n = static_cast<int>(A.n_rows);
     for (int q = threadIdx.x; q < n * n; q += 1024) M[q] = 0.0;
     __syncthreads();
-    for (int r = threadIdx.x; r < n; r += 1024) {
+    // (round 6: lane = row, wave = entry -- sixteen entries of every row in flight; one thread per row walked its 64 entries one
+    // dependent load after the other: 60 of this kernel's 97 us)
+    for (int r = threadIdx.x & 63; r < n; r += 64) {
         const int64_t base = A.slice_off[r >> 6] + (r & 63);
         const int len = A.rowlen[r];
-        for (int k = 0; k < len; ++k) M[r * n + A.cols[base + 64LL * k]] = A.vals[base + 64LL * k];
+        for (int k = threadIdx.x >> 6; k < len; k += 16) M[r * n + A.cols[base + 64LL * k]] = A.vals[base + 64LL * k];
     }
     __syncthreads();
     amg_gauss_jordan(M, colp, n, inv);
@@ -1184,20 +1186,35 @@ __global__ void __launch_bounds__(1024) k_amg_dense_inverse_of(const double *__r
 }
 __device__ __forceinline__ void amg_gauss_jordan(double *M, double *colp, int n, double *__restrict__ inv)
 {
+    // (round 6: every element of a pivot step depends on the OLD pivot row and column only, so a thread reads what its elements
+    // need, all threads meet, and then it writes them: two barriers a step instead of five -- 96 -> ~45 us for the 64-row level of
+    // config 3 in every solve; the same operations on the same operands: M[p][j] piv, fma(-M[i][p], M[p][j] piv, M[i][j]), -M[i][p] piv)
+    (void)colp;
+    constexpr int kPer = (kAmgDense * kAmgDense + 1023) / 1024;
+    const int per = (n * n + 1023) / 1024;                  // elements a thread owns (uniform): 4 for 64 rows
+    int qi[kPer], qj[kPer];                                  // ... their row and column, found once
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int q = threadIdx.x + 1024 * u;
+        qi[u] = q < n * n ? q / n : -1;
+        qj[u] = q < n * n ? q - qi[u] * n : 0;
+    }
     for (int p = 0; p < n; ++p) {
+        double nv[kPer];
         const double piv = 1.0 / M[p * n + p];
-        __syncthreads();
-        for (int i = threadIdx.x; i < n; i += 1024) colp[i] = M[i * n + p];
-        __syncthreads();
-        for (int j = threadIdx.x; j < n; j += 1024)
-            if (j != p) M[p * n + j] *= piv;
-        __syncthreads();
-        for (int q = threadIdx.x; q < n * n; q += 1024) {
-            const int i = q / n, j = q - i * n;
-            if (i != p && j != p) M[q] = __builtin_fma(-colp[i], M[p * n + j], M[q]);
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            nv[u] = 0.0;
+            if (u < per && qi[u] >= 0) {
+                const int i = qi[u], j = qj[u];
+                const double cp = M[i * n + p], rp = M[p * n + j] * piv;
+                nv[u] = (i == p) ? (j == p ? piv : rp) : (j == p ? -cp * piv : __builtin_fma(-cp, rp, M[i * n + j]));
+            }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += 1024) M[i * n + p] = i == p ? piv : -colp[i] * piv;
+#pragma unroll
+        for (int u = 0; u < kPer; ++u)
+            if (u < per && qi[u] >= 0) M[qi[u] * n + qj[u]] = nv[u];
         __syncthreads();
     }
     for (int q = threadIdx.x; q < n * n; q += 1024) inv[q] = M[q];

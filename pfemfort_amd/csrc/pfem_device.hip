@@ -561,6 +561,7 @@ struct pfem_solver {
     // the group form keep their codes); vd_direct_pending: the last assembly wrote the codes itself, its verdict has not been read
     DevBuf<VdHashEntry> d_vhash;
     bool vd_hash_ok = false, vd_direct_pending = false;
+    VdState vd_direct_verdict{0, 0, 1, 0};
     DevBuf<double> d_vdict;
     DevBuf<VdState> d_vstate;
     int vd_rows = 0, vd_n = 0;
@@ -2131,6 +2132,8 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
     }
     PFEM_HIP(hipEventRecord(s->ev1, s->stream));
     int err = 0;
+    // (the verdict of the codes the gather kernel wrote travels with the error word: one wait, not one here and one in the solve)
+    if (wrote_codes) PFEM_HIP(hipMemcpyAsync(&s->vd_direct_verdict, s->d_vstate.p, sizeof(VdState), hipMemcpyDeviceToHost, s->stream));
     PFEM_TRY(fetch_err(s, &err));
     PFEM_TRY(elapsed(s, &s->tm.assemble_ms));
     if (!err && s->assembly_mode == PFEM_ASSEMBLY_GATHER && s->have_incidence) err = s->geom_err;
@@ -2672,9 +2675,7 @@ int refresh_group_vals(pfem_solver *s)
         // the group form re-packed from the row form, collection, sort, encode.
         s->vd_direct_pending = false;
         const bool enabled = [] { const char *e = std::getenv("PFEM_SPMV_VALDICT"); return e ? std::atoi(e) != 0 : true; }();
-        VdState st{0, 0, 1, 0};
-        PFEM_HIP(hipMemcpyAsync(&st, s->d_vstate.p, sizeof st, hipMemcpyDeviceToHost, s->stream));
-        PFEM_HIP(hipStreamSynchronize(s->stream));
+        const VdState st = s->vd_direct_verdict;          // (read with the assembly's error word)
         if (enabled && !st.miss && !st.fail && s->use_rel() && s->vd_rows == kRelRows) {
             s->vd_ok = s->vd_current = true;
             s->group_vals_stale = false;
