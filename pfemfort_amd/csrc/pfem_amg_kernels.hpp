@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(kBlock) k_lat_check(SellDev A, const int32_t *
     const double di = diag[i];
     const int bix = (pi & 0x3ff) >> B.shift[0], biy = ((pi >> 10) & 0x3ff) >> B.shift[1], biz = ((pi >> 20) & 0x3ff) >> B.shift[2];
     double smax = 0.0, ssib[3] = {-1.0, -1.0, -1.0};
-    bool far = false;
+    bool far = false, partial = false;
     for (int k = 0; k < len; ++k) {
         const int32_t j = A.cols[base + 64LL * k];
         if (j == static_cast<int32_t>(i)) continue;
@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(kBlock) k_lat_check(SellDev A, const int32_t *
         // (a dof at the node's OWN position: the other owners' parts of the same brick of the level above, on a level that every
         // rank holds whole after bricks were split between their owners -- amg_split_bricks.  It lands in the node's brick
         // whatever its coupling, and that coupling -- the strongest a sliver has -- is no yardstick for the siblings')
-        if (pj == pi) continue;
+        if (pj == pi) { partial = true; continue; }
         const double sij = amg_strength(A.vals[base + 64LL * k], di, diag[j]);
         smax = fmax(smax, sij);
         const int x = pi ^ pj;            // (several dofs may sit at the sibling's position too: the strongest of them speaks for it)
@@ -354,6 +354,9 @@ __global__ void __launch_bounds__(kBlock) k_lat_check(SellDev A, const int32_t *
     bool weak = false;
     for (int a = 0; a < 3; ++a)
         if (B.shift[a] > 0 && ssib[a] >= 0.0 && !(ssib[a] > 0.0 && ssib[a] >= 0.25 * smax)) weak = true;
+    // (a PART of a brick -- somebody else sits at its position -- is a thin cell by construction, and thin cells couple weakly
+    // across their thin side: that says nothing about the brick it completes together with the other parts)
+    if (partial) weak = false;
     if (weak || far) {
         *fail = 1;
         if (weak) atomicAdd(fail + 1, 1);          // (how many rows, and why: PFEM_AMG_VERBOSE prints them; rows that refuse are few or all)

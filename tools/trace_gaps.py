@@ -28,7 +28,7 @@ def main():
     # iterations = stretches between consecutive markers that are close in time (same solve)
     spans = []
     for a, b in zip(idx, idx[1:]):
-        if rows[b][0] - rows[a][0] < 5_000_000:      # < 5 ms apart: same solve
+        if rows[b][0] - rows[a][0] < 2_000_000:      # < 2 ms apart: same solve (an iteration takes 0.2 - 1.5 ms; assembly + set-up between two solves 3 ms and more)
             spans.append((a, b))
     busy = idle = 0
     pair = defaultdict(lambda: [0, 0])
