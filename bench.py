@@ -1063,12 +1063,16 @@ def main():
             # the kernel furthest from the HBM roofline, with the bound it really has: FP64 issue (every element's geometry is
             # evaluated once per incident node, un-contracted as the reference's order demands).  The event time is this
             # run's; the issue fraction is replayed from the committed SQ counters of the same kernel on the same workload
-            "assembly_kernel": ({"kernel": "pfem::k_gather_poisson_tet4 (gather assembly + the SpMV's relative-group copy)",
+            "assembly_kernel": ({"kernel": "pfem::k_gather_poisson_tet4 (gather assembly; in the steady state it also writes the SpMV's 16-bit value codes "
+                                           "and level 0's inverse diagonal + Gershgorin ratios for the multigrid)",
                                  "event_ms_per_step": acc["asm_ms"] / args.steps,
                                  "bound": "fp64-valu-issue",
-                                 "valu_issue_fraction_replayed_not_this_run": 0.75,
-                                 "valu_issue_source": "profiles/r04/gather_kernels_sq_counters.txt (rocprofv3 --pmc SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE, tools/r04/gather_sq_counters.sh in the history)",
-                                 "hbm_frac_of_compulsory_bytes": (3.75e9 / (acc["asm_ms"] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBPS)
+                                 # SQ_ACTIVE_INST_VALU / (32 x GRBM_GUI_ACTIVE) of this kernel on this workload, re-taken in round 6 at commit 16005af
+                                 # (466.1 M / (32 x 21.34 M); round 4: 0.75 with 22 % more VALU instructions per launch)
+                                 "valu_issue_fraction_replayed_not_this_run": 0.68,
+                                 "valu_issue_source": "profiles/r06/gather_and_spmv_sq_counters.txt (rocprofv3 --pmc, separate passes, tools/r06/final.sh)",
+                                 # compulsory bytes per launch: SURVEY 8(d)'s 2.69 GB + the codes (0.24 GB) + the two vectors for the multigrid (0.13 GB)
+                                 "hbm_frac_of_compulsory_bytes": (3.05e9 / (acc["asm_ms"] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBPS)
                                  if (not beam and world == 1 and args.n == 200 and args.numbering == "lattice" and args.jitter <= 0.0) else None}
                                 if (not beam and world == 1) else None),
             "roofline": {"bound": "hbm", "kernel": kernel,

@@ -2020,8 +2020,10 @@ __global__ void __launch_bounds__(kBlock) k_pc_update(CgCtl *ctl, int it, int64_
     }
     const double alpha = ctl->beta[it & 1] / pw;
     const double c_first = z0 ? cheb_coef(lam[0], ratio, 0).c_first : 0.0;
+    const bool defer_x = x == nullptr;           // (the x update rides on k_pc_post_dots_direction, which streams p anyway: alpha travels in the control block)
+    if (defer_x && blockIdx.x == 0 && threadIdx.x == 0) ctl->alpha = alpha;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlock) {
-        x[i] = __builtin_fma(alpha, p[i], x[i]);
+        if (!defer_x) x[i] = __builtin_fma(alpha, p[i], x[i]);
         const double ri = __builtin_fma(-alpha, w[i], r[i]);
         r[i] = ri;
         if (z0 && i < n_pc) {
@@ -2058,6 +2060,99 @@ __global__ void __launch_bounds__(kBlock) k_pc_post_dots(const CgCtl *ctl, int64
     const double a = block_sum(rz, sm), c = block_sum(zz, sm);
     if (threadIdx.x == 0) { part_rz[blockIdx.x] = a; part_zz[blockIdx.x] = c; }
 }
+// k_pc_post_dots + k_cg_direction_b + the x update of k_pc_update in ONE launch (one rank; round 6).  The three kernels streamed
+// r, t, dinv, z | z, p | p, x: z was written by the first only to be read back by the second, and p was read twice.  Here every
+// thread keeps the z of its rows in registers across a grid barrier: phase 1 forms z and the block's (r,z), (z,z) partials;
+// all blocks meet (an arrival counter in the control block, bounded spin: a timeout ends the solve with an error instead of
+// hanging the device); phase 2 sums the partials -- every block the same sums in the same order --, judges convergence exactly as
+// k_cg_direction_b does, and streams p once: x += alpha p (the step k_pc_update left to this launch), p = z + beta p.
+// The grid is sized by the caller so that ALL blocks are resident at once (kCoopBlocksPerCu per CU, checked against the
+// occupancy the runtime reports, with a block to spare); K = rows a thread owns <= kCoopMaxK.
+constexpr int kCoopMaxK = 48;
+constexpr int kCoopBlocksPerCu = 3;
+constexpr unsigned long long kCoopSpinTicks = 300000000ull;          // 3 s at 100 MHz
+__global__ void __launch_bounds__(kBlock, kCoopBlocksPerCu) k_pc_post_dots_direction(CgCtl *ctl, int it, int64_t n, const double *__restrict__ r, const double *__restrict__ t,
+                                                                    const double *__restrict__ dinv, const double *__restrict__ lam, double ratio,
+                                                                    const double *__restrict__ z_in, double *__restrict__ p, double *__restrict__ x,
+                                                                    double *part_rz, double *part_zz, double *hist, int hist_cap, int maxits)
+{
+    __shared__ double sm[4];
+    __shared__ int ok_s;
+    if (ctl_finished_before(ctl, it)) return;
+    const bool breakdown = ctl->pad_ != 0;                    // (flagged by k_pc_update: (p,Ap) <= 0; x was not advanced)
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock, i0 = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const double c_first = cheb_coef(lam[0], ratio, 0).c_first;
+    double zr[kCoopMaxK];
+    double rz = 0.0, zz = 0.0;
+    if (!breakdown) {
+#pragma unroll
+        for (int k = 0; k < kCoopMaxK; ++k) {
+            const int64_t i = i0 + k * stride;
+            zr[k] = 0.0;
+            if (i < n) {
+                const double ri = r[i];
+                const double zi = z_in[i] + c_first * dinv[i] * (ri - t[i]);
+                zr[k] = zi;
+                rz = __builtin_fma(ri, zi, rz);
+                zz = __builtin_fma(zi, zi, zz);
+            }
+        }
+    }
+    const double a = block_sum(rz, sm), c = block_sum(zz, sm);
+    if (threadIdx.x == 0) {
+        part_rz[blockIdx.x] = breakdown ? 0.0 : a;
+        part_zz[blockIdx.x] = breakdown ? -1.0 : c;
+        // ---- grid barrier: arrival it + 1 of gridDim.x blocks each (the control block is zeroed at the start of a solve)
+        __threadfence();
+        const unsigned want = static_cast<unsigned>(it + 1) * gridDim.x;
+        __hip_atomic_fetch_add(&ctl->gbar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = wall_clock64();
+        int ok = 1;
+        while (__hip_atomic_load(&ctl->gbar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > kCoopSpinTicks) { ok = 0; break; }
+        }
+        ok_s = ok;
+    }
+    __syncthreads();
+    if (!ok_s) {                                              // not all blocks were resident: end the solve, do not hang
+        if (threadIdx.x == 0) ctl_publish(ctl, -100, it + 1);
+        return;
+    }
+    const int nparts = static_cast<int>(gridDim.x);
+    const double srz = sum_partials(part_rz, nparts, sm), szz = sum_partials(part_zz, nparts, sm);
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    if (szz < 0.0) {
+        if (lead) ctl_publish(ctl, -10, it + 1);
+        return;
+    }
+    const double rn = sqrt(szz);
+    const double beta_old = ctl->beta[it & 1], alpha = ctl->alpha;
+    int flag = 0;
+    if (rn <= ctl->ttol) flag = 2;
+    else if (rn >= ctl->dtol * ctl->rn0) flag = -4;
+    else if (srz < 0.0) flag = -8;
+    else if (it + 1 >= maxits) flag = -3;
+    // (every block has read beta, alpha, ttol ... before the lead overwrites anything a LATER kernel reads only: beta of the other
+    // parity, rn, the history, the verdict -- nothing this launch still reads)
+    if (lead) {
+        ctl->beta[(it + 1) & 1] = srz;
+        ctl->rn = rn;
+        if (it + 1 < hist_cap) hist[it + 1] = rn;
+        ctl_publish(ctl, flag, it + 1);
+    }
+    const double bb = srz / beta_old;
+#pragma unroll
+    for (int k = 0; k < kCoopMaxK; ++k) {
+        const int64_t i = i0 + k * stride;
+        if (i < n) {
+            const double pi = p[i];
+            x[i] = __builtin_fma(alpha, pi, x[i]);           // the iterate of THIS iteration (also when it is the last)
+            if (flag == 0) p[i] = __builtin_fma(bb, pi, zr[k]);
+        }
+    }
+}
+
 // Single-reduction form of the loop (KSPCGUseSingleReduction; k_cg1_step with a STORED z = M^-1 r from the V-cycle): step `it`
 // judges iterate `it` from (z,z), then p = z + b p, w = s + b w (s = A z), x += a p, r -= a w with
 // b = (r,z)/(r,z)_old, (p,Ap) = (z,s) - b^2 (p,Ap)_old, a = (r,z)/(p,Ap): ONE all-reduce of [(z,s), (r,z), (z,z)] per iteration.

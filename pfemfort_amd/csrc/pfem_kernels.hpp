@@ -1477,6 +1477,8 @@ struct CgCtl {            // device-resident control block of the CG iteration
                           // -2 once the update kernel has seen the solve finished
     int pad_;
     double dpi[2];        // single-reduction form: (p,Ap) by recurrence, ping-pong by iteration parity
+    unsigned gbar;        // arrival counter of the grid barrier in k_pc_post_dots_direction (zeroed with the block at the start of a solve)
+    unsigned gpad_;
 };
 static_assert(offsetof(CgCtl, flag) % 8 == 0 && offsetof(CgCtl, its) == offsetof(CgCtl, flag) + 4, "flag/its share a word");
 
