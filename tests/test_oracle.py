@@ -295,6 +295,71 @@ def test_rigid_body_prolongator_restatement():
     assert (reason_r, reason_t) == (2, 2) and 3 * its_r < its_t, (its_r, its_t)
 
 
+def test_node_brick_and_split_brick_restatements():
+    """Round 6's two restatements.  O.lattice_node_brick_aggregates (what the device's node bricks in one step are compared with):
+    boxes of nodes, 4 to the edge along an axis of 24 and more nodes on level 0 (3 from 6 on), pairs below, the short brick at the
+    end of a line joined to its neighbour; with owners the bricks are cut where the owner changes and no aggregate holds nodes of
+    two ranks; the rigid-body cycle built on them converges like the one on 2x2x2 bricks.  O.lattice_brick_aggregates(split=True)
+    (amg_split_bricks): on a partition whose parts are not boxes an aggregate is one owner's part of a 2x2x2 brick -- the parts of
+    a brick together ARE the one-rank brick."""
+    mesh = O.gen_box_tets(-0.5, 0.5, 8, 0.0, 6.0, 48, -0.5, 0.5, 8, bc_mode=1, ndof=3)
+    prob = O.setup_problem(O.ELAST_TET, mesh)
+    nd = prob.dm.NodeDofArrayNew.reshape(-1, 3)
+    free = np.where(nd[:, 0] >= 0)[0]
+    x0 = prob.xyz_new[:, free]
+    aggs = O.lattice_node_brick_aggregates(prob.xyz_new, x0)
+    # 9 x 48 x 9 free nodes: x, z in bricks of 3 (9 >= 6), y in bricks of 4 (48 >= 24): 3 x 12 x 3 aggregates, then pairs
+    # (level 1: 3 x 12 x 3 coarse nodes in pairs, the third of a line of three joined to the pair: 1 x 6 x 1)
+    assert [int(a.max()) + 1 for a in aggs][:2] == [3 * 12 * 3, 1 * 6 * 1] and len(aggs[0]) == 9 * 48 * 9
+    cnt = np.bincount(aggs[0])
+    # (y positions 1 .. 48 in bricks aligned on multiples of 4: {1,2,3}, {4..7}, ..., {44..47} + the single 48 joined to it)
+    assert sorted(set(cnt.tolist())) == [27, 36, 45]
+    owner = np.minimum(np.arange(len(free)) * 3 // len(free), 2)
+    # (nodes are numbered x fastest, then y, then z: thirds of the numbering are slabs across z -- boxes)
+    own = O.lattice_node_brick_aggregates(prob.xyz_new, x0, owner=owner)
+    assert own is not None and all(len(np.unique(owner[own[0] == a])) == 1 for a in range(int(own[0].max()) + 1))
+    assert int(own[0].max()) + 1 >= int(aggs[0].max()) + 1
+    Ps, xs, fb = [], x0, 3
+    for a in aggs:
+        Pk, xs = O.rbm_prolongator(a, xs, 3, fb)
+        Ps.append(Pk)
+        fb = 6
+    _, its_r, reason_r, *_ = O.pcg_amg(prob.rowptr, prob.cols, prob.vals, prob.rhs, Ps, eig_ratio=16.0)
+    _, its_j, *_ = O.pcg_jacobi(prob.rowptr, prob.cols, prob.vals, prob.rhs)
+    assert reason_r == 2 and its_r < 40 and 10 * its_r < its_j, (its_r, its_j)
+    # an owner set that is no box (one node more to the last rank): no node bricks across the ranks
+    bad = owner.copy()
+    bad[5] = 2
+    assert O.lattice_node_brick_aggregates(prob.xyz_new, x0, owner=np.sort(bad)) is None
+    # ---- split bricks: a staircase partition of a cube
+    cube = O.gen_box_tets(-1, 1, 12, -1, 1, 10, -1, 1, 14)
+    z = cube.xyz[2]
+    step = (cube.xyz[0] > 1e-9).astype(np.float64)
+    layer = np.floor((z + 1.0) / 2.0 * 14 - 1e-9) - step
+    npid = np.clip(np.floor(layer * 3 / 14), 0, 2).astype(np.int32)
+    p3 = O.setup_problem(O.POISSON_TET, cube, nParts=3, node_proc_id=npid)
+    nda = p3.dm.NodeDofArrayNew.reshape(-1)
+    fr = np.where(nda >= 0)[0]
+    own3 = np.zeros(len(fr), np.int64)
+    for r in range(3):
+        own3[int(p3.dm.row_start[r]):int(p3.dm.row_end[r])] = r
+    assert O.lattice_brick_aggregates(p3.xyz_new, p3.xyz_new[:, fr], owner=own3) is None                # the parts are not boxes
+    sp = O.lattice_brick_aggregates(p3.xyz_new, p3.xyz_new[:, fr], owner=own3, split=True, replicate_rows=0)
+    one = O.lattice_brick_aggregates(p3.xyz_new, p3.xyz_new[:, fr])
+    assert sp is not None and len(sp) >= 2
+    # no aggregate holds dofs of two owners; the aggregates that share a one-rank brick make up exactly that brick
+    a0 = sp[0]
+    assert all(len(np.unique(own3[a0 == a])) == 1 for a in range(int(a0.max()) + 1))
+    brick_of = np.full(int(a0.max()) + 1, -1)
+    for i, a in enumerate(a0):
+        assert brick_of[a] in (-1, one[0][i])
+        brick_of[a] = one[0][i]
+    assert int(one[0].max()) + 1 <= int(a0.max()) + 1 <= 1.1 * (int(one[0].max()) + 1)
+    _, its_s, reason_s, *_ = O.pcg_amg(p3.rowptr, p3.cols, p3.vals, p3.rhs, sp, eig_ratio=16.0, rtol=1e-10)
+    _, its_1, reason_1, *_ = O.pcg_amg(p3.rowptr, p3.cols, p3.vals, p3.rhs, one, eig_ratio=16.0, rtol=1e-10)
+    assert (reason_s, reason_1) == (2, 2) and its_s <= its_1 + 2, (its_s, its_1)
+
+
 def test_mpi_restatement_of_the_cpu_baseline_equals_the_serial_oracle():
     """oracle/pfem_oracle_mpi (bench.py's cpu_baseline with one MPI rank per core): slabs of node planes, the oracle's element
     routine, distributed Jacobi-PCG -- same matrix size, same iteration count, same residual norm and nodal error as the
