@@ -773,6 +773,67 @@ __global__ void __launch_bounds__(kBlock) k_rbm_restrict(int64_t nc_nodes, const
         }
     }
 }
+// The same restriction for LARGE aggregates (level 0 of a displacement problem: bricks of 4x4x4 = 64 nodes): kRbmWide lanes share
+// one coarse node.  With a thread per coarse node the 12 675 threads of config 4's level 1 walked 64 members each, one dependent
+// round trip to memory after the other: 97 us per cycle for 37 MB, a sixth of the iteration (profiles/r06/
+// rocprofv3_kernel_stats_beam.txt).  Lane l takes members l, l + kRbmWide, ... in ascending order, the lanes' sums are combined
+// by a fixed butterfly: deterministic, the same on every run and in every caller (the association differs from the one-thread
+// form's: a level uses one form or the other throughout -- amg_rbm_restrict_launch decides from the level's sizes alone).
+constexpr int kRbmWide = 16;
+template <int FB, int DIM>
+__global__ void __launch_bounds__(kBlock) k_rbm_restrict_wide(int64_t nc_nodes, const int32_t *__restrict__ mem_ptr, const int32_t *__restrict__ mem_idx,
+                                                               const double *__restrict__ roff, int64_t nn, const double *__restrict__ b,
+                                                               const double *__restrict__ t, double *__restrict__ bc, const double *__restrict__ dinv_c,
+                                                               const double *__restrict__ lam_c, double ratio, double *__restrict__ dd_c,
+                                                               double *__restrict__ x_c, const CgCtl *ctl, int64_t n_own_nodes)
+{
+    constexpr int NR = RbmDims<DIM>::NR, CB = RbmDims<DIM>::CB;
+    if (ctl && ctl->flag != 0) return;
+    const int64_t gt = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t a = gt / kRbmWide;
+    const int lane = static_cast<int>(gt % kRbmWide);
+    const bool live = a < nc_nodes;
+    double out[CB];
+#pragma unroll
+    for (int k = 0; k < CB; ++k) out[k] = 0.0;
+    if (live) {
+        const int q0 = mem_ptr[a], q1 = mem_ptr[a + 1];
+        for (int q = q0 + lane; q < q1; q += kRbmWide) {
+            const int64_t i = mem_idx[q];
+            double f[FB], r[3];
+#pragma unroll
+            for (int d = 0; d < FB; ++d) {
+                const double bv = i < n_own_nodes ? b[FB * i + d] : 0.0;
+                f[d] = t ? bv - t[FB * i + d] : bv;
+            }
+#pragma unroll
+            for (int d = 0; d < 3; ++d) r[d] = roff[d * nn + i];
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) out[d] += f[d];
+            double mom[NR];
+#pragma unroll
+            for (int k = 0; k < NR; ++k) mom[k] = 0.0;
+            rbm_moment<DIM>(r, f, mom);
+#pragma unroll
+            for (int k = 0; k < NR; ++k) out[DIM + k] += FB > DIM ? mom[k] + f[DIM + k] : mom[k];
+        }
+    }
+#pragma unroll
+    for (int o = kRbmWide / 2; o > 0; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < CB; ++k) out[k] += __shfl_xor(out[k], o, 64);
+    if (!live || lane != 0) return;
+    const double c_first = dd_c ? cheb_coef(lam_c[0], ratio, 0).c_first : 0.0;
+#pragma unroll
+    for (int k = 0; k < CB; ++k) {
+        bc[CB * a + k] = out[k];
+        if (dd_c) {
+            const double di = c_first * dinv_c[CB * a + k] * out[k];
+            dd_c[CB * a + k] = di;
+            x_c[CB * a + k] = di;
+        }
+    }
+}
 // x_i += scale * P_i xc_I, one fine node
 template <int FB, int DIM>
 __device__ __forceinline__ void rbm_prolong_node(int64_t i, const int32_t *__restrict__ node_agg, const double *__restrict__ roff, int64_t nn,

@@ -642,6 +642,10 @@ def test_gpu_ranks_on_one_device_match_oracle(tmp_path, kind_name, world, partit
         its_tol = max(2, its_oracle // 25)          # (runs of a hundred and more iterations on the little beam, whose CG stalls on plateaus: +-4 %)
         if single:                                   # (p,Ap) by recurrence: the plateaus of the little beam end an iteration or three apart
             its_tol = max(4, its_oracle // 12)
+        if kind_name == "elast" and mesh_args.get("pc") == "gamg":
+            # the little beam's count moves with the ORDER of the restriction's sums alone: 49..56 around the oracle's 54 / 55 between
+            # the one-thread and the 16-lane form of k_rbm_restrict (PFEM_RBM_RESTRICT_WIDE=0 / 1, same aggregates, same operators)
+            its_tol = max(its_tol, its_oracle // 10)
     if mode == "pbjacobi":
         want = "pbjacobi" if kind_name == "elast" else "jacobi"      # Poisson has no multi-row groups: all ranks fall back
         assert all(str(np.load(tmp_path / f"rank{r}.npz")["pc"]) == want for r in range(world))
