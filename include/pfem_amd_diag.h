@@ -87,6 +87,9 @@ int pfem_solver_amg_transfer(pfem_solver *s, int level, int *rbm, int *fine_bs, 
  * coupled hierarchy pfem_solver_amg_aggregates hands out GLOBAL coarse numbers and pfem_solver_amg_info's rows are the
  * owned ones on the distributed levels, all rows on the replicated ones.                                                */
 int pfem_solver_amg_layout(pfem_solver *s, int max_levels, int *coupled, int *distributed_levels, int64_t *first_dof, int64_t *local_rows);
+/* the gather form's incidence lists as translated copies of patterns (lists equal up to a shift of the node numbers, as a mesh
+ * numbered along lines has them): number of patterns in use (0: every node reads its own records) and the longest list      */
+int pfem_solver_incidence_patterns(pfem_solver *s, int *count, int *longest);
 /* how the aggregates of every level of the last gamg hierarchy were formed (kind[l], l < *n_levels; the last level: 0):
  * 1 bricks of the lattice in one step, 2 node bricks in one step (rigid-body transfer), 3 bricks split between their owners
  * (several ranks whose dofs do not fill boxes), 4 pairing passes along the axes of the lattice, 5 matching on the strength

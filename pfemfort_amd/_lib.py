@@ -118,6 +118,7 @@ SIGNATURES = {
     "pfem_solver_amg_transfer": [_P, _I, _P, _P, _P, _P, _P, _P],
     "pfem_solver_amg_layout": [_P, _I, _P, _P, _P, _P],
     "pfem_solver_amg_aggregation": [_P, _I, _P, _P],
+    "pfem_solver_incidence_patterns": [_P, _P, _P],
     "pfem_solver_amg_comm_counts": [_P, _P, _P],
     "pfem_solver_amg_cycle_profile": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "pfem_solver_amg_pairing": [_P, _P],

@@ -485,6 +485,10 @@ struct pfem_solver {
     DevBuf<int32_t> d_inc_ea;      // ... entries 4*e + a, ascending element id, entry j of node n at ptr[n/64]+64j+n%64
     DevBuf<int4> d_inc_rec;        // packed {other nodes, slots} record per incidence (replaces ea + slots + elemrec)
     DevBuf<uint16_t> d_inc_flags;  // ... with the constrained-dof bits of the element (kinds with ndof > 1)
+    // the lists as translated copies of a few patterns (k_incpat_*): node -> pattern, pattern -> records relative to the node
+    DevBuf<uint16_t> d_node_pat, d_pat_flags;
+    DevBuf<int4> d_pat_rec;
+    int inc_pat_count = 0, inc_pat_stride = 0;     // count > 0: the form is in use
     DevBuf<int32_t> d_node_row;    // [nNode*ndof] matrix row of every node dof, -1 = no row
     int rows_threads = 0;    // block size of the LDS-row gather kernels (256/128/64), 0 = rows too long
     int gather_row_len = 0;  // longest row the gather kernels own (hub rows excluded)
@@ -1626,6 +1630,62 @@ int build_incidence_lists(pfem_solver *s, bool *built)
     return PFEM_OK;
 }
 
+// the packed records as translated copies of at most kIncPatMax patterns (pfem_kernels.hpp, k_incpat_*): tetrahedra only (the
+// kernels that read the table); PFEM_INC_PATTERNS=0 keeps every node's own records
+int build_incidence_patterns(pfem_solver *s)
+{
+    const MeshDev &m = s->mesh;
+    s->inc_pat_count = s->inc_pat_stride = 0;
+    s->d_node_pat.release();
+    s->d_pat_rec.release();
+    s->d_pat_flags.release();
+    static const bool on = [] { const char *e = std::getenv("PFEM_INC_PATTERNS"); return e ? std::atoi(e) != 0 : true; }();
+    if (!on || m.npe != 4 || m.nNode <= 0 || m.nNode >= (1LL << 30) || s->inc_total <= 0) return PFEM_OK;
+    DevBuf<IncPatSlot> table;
+    DevBuf<IncPatState> st;
+    DevBuf<int32_t> rep, pcnt;
+    PFEM_TRY(table.alloc(kIncPatSlots));
+    PFEM_TRY(st.alloc(1));
+    PFEM_TRY(rep.alloc(kIncPatMax));
+    PFEM_TRY(pcnt.alloc(kIncPatMax));
+    std::vector<IncPatSlot> empty(kIncPatSlots, IncPatSlot{0ull, INT_MAX, -1});
+    PFEM_HIP(hipMemcpyAsync(table.p, empty.data(), sizeof(IncPatSlot) * kIncPatSlots, hipMemcpyHostToDevice, s->stream));
+    PFEM_HIP(hipMemsetAsync(st.p, 0, sizeof(IncPatState), s->stream));
+    const int64_t *ip = s->d_inc_ptr.p;
+    const int32_t *ic = s->d_inc_cnt.p;
+    const int4 *irec = s->d_inc_rec.p;
+    const uint16_t *ifl = m.ndof > 1 ? s->d_inc_flags.p : nullptr;
+    const int32_t *nrow = s->d_node_row.p;
+    hipLaunchKernelGGL(k_incpat_collect, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m.nNode, m.ndof, m.npe, ip, ic, irec, ifl, nrow, table.p, st.p);
+    hipLaunchKernelGGL(k_incpat_number, dim3(1), dim3(kBlock), 0, s->stream, table.p, st.p, rep.p);
+    PFEM_TRY(check_kernel("k_incpat_collect"));
+    IncPatState h{0, 0, 0, 0};
+    PFEM_HIP(hipMemcpyAsync(&h, st.p, sizeof h, hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));          // (the host copy of the empty table lives until here)
+    if (h.overflow || h.count <= 0 || h.count > kIncPatMax || h.stride <= 0) return PFEM_OK;
+    const int64_t n_rec = static_cast<int64_t>(h.count) * h.stride;
+    PFEM_TRY(s->d_pat_rec.alloc(static_cast<size_t>(n_rec)));
+    if (ifl) PFEM_TRY(s->d_pat_flags.alloc(static_cast<size_t>(n_rec)));
+    PFEM_TRY(s->d_node_pat.alloc(static_cast<size_t>(m.nNode)));
+    hipLaunchKernelGGL(k_incpat_fill, dim3(grid_for(n_rec)), dim3(kBlock), 0, s->stream, static_cast<const IncPatState *>(st.p),
+                       static_cast<const int32_t *>(rep.p), m.npe, ip, ic, irec, ifl, s->d_pat_rec.p, ifl ? s->d_pat_flags.p : nullptr, pcnt.p);
+    hipLaunchKernelGGL(k_incpat_assign, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m.nNode, m.ndof, m.npe, ip, ic, irec, ifl, nrow,
+                       static_cast<const IncPatSlot *>(table.p), st.p, static_cast<const int4 *>(s->d_pat_rec.p),
+                       ifl ? static_cast<const uint16_t *>(s->d_pat_flags.p) : nullptr, static_cast<const int32_t *>(pcnt.p), s->d_node_pat.p);
+    PFEM_TRY(check_kernel("k_incpat_assign"));
+    PFEM_HIP(hipMemcpyAsync(&h, st.p, sizeof h, hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    if (h.fail || h.overflow) {
+        s->d_node_pat.release();
+        s->d_pat_rec.release();
+        s->d_pat_flags.release();
+        return PFEM_OK;
+    }
+    s->inc_pat_count = h.count;
+    s->inc_pat_stride = h.stride;
+    return PFEM_OK;
+}
+
 // ... and on top of the lists and the pattern: slot map, packed records, hub nodes, block size of the row kernels
 int build_incidence_records(pfem_solver *s)
 {
@@ -1679,6 +1739,7 @@ int build_incidence_records(pfem_solver *s)
             if (s->rows_threads) break;
         }
     PFEM_HIP(hipStreamSynchronize(s->stream));
+    PFEM_TRY(build_incidence_patterns(s));
     s->d_inc_ea.release();          // the lists the records came from are dropped
     s->d_inc_slots.release();
     s->d_node4.release();
@@ -2031,6 +2092,8 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
         const int4 *irec = s->d_inc_rec.p;
         const uint16_t *ifl = s->d_inc_flags.p;
         const int32_t *nrow = s->d_node_row.p;
+        // (the lists as translated copies of a few patterns, where the mesh's numbering made them so: build_incidence_patterns)
+        const bool pats = s->inc_pat_count > 0 && s->d_node_pat.p && s->d_pat_rec.p && !std::getenv("PFEM_DEBUG_INC_OWN_RECORDS");
         const int T = s->rows_threads > 0 ? s->rows_threads : kBlock;
         const int64_t nthr = static_cast<int64_t>(m.ndof) * m.nNode;
         const dim3 rgrid(static_cast<unsigned>((nthr + T - 1) / T)), rblock(T);
@@ -2076,7 +2139,9 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
                                    both ? static_cast<const uint8_t *>(s->d_relk.p) : nullptr, both ? static_cast<const int64_t *>(s->d_rslice_off.p) : nullptr,
                                    (both && !direct) ? s->d_rvals.p : nullptr, bound ? L0->dinv.p : nullptr, bound ? L0->t.p : nullptr,
                                    direct ? static_cast<const VdHashEntry *>(s->d_vhash.p) : nullptr,
-                                   direct ? reinterpret_cast<uint16_t *>(s->d_vcodes.p) : nullptr, direct ? s->d_vstate.p : nullptr);
+                                   direct ? reinterpret_cast<uint16_t *>(s->d_vcodes.p) : nullptr, direct ? s->d_vstate.p : nullptr,
+                                   pats ? static_cast<const uint16_t *>(s->d_node_pat.p) : nullptr, pats ? static_cast<const int4 *>(s->d_pat_rec.p) : nullptr,
+                                   s->inc_pat_stride);
                 wrote_rel = both && !direct;
                 wrote_codes = direct;
                 wrote_bound = bound;
@@ -2091,9 +2156,12 @@ extern "C" int pfem_assemble(pfem_solver *s, const double *elemData, const doubl
             // (plain block order: the XCD-contiguous one measured 3 % slower on the beam, 1.605 against 1.56 ms)
             {
                 const bool bothg = s->use_grouped() && s->d_row_group.p && s->n_hubs == 0 && !std::getenv("PFEM_DEBUG_NO_REL_DIRECT");
+                const bool patsf = pats && s->d_pat_flags.p;
                 hipLaunchKernelGGL(k_gather_elast_rows, rgrid, rblock, rlds, s->stream, m, A, s->d_rhs.p, prm, ip, ic, irec, ifl, nrow, s->d_err.p, 0u,
                                    bothg ? static_cast<const int32_t *>(s->d_row_group.p) : nullptr, bothg ? static_cast<const int32_t *>(s->d_group_row0.p) : nullptr,
-                                   bothg ? static_cast<const int64_t *>(s->d_gslice_off.p) : nullptr, bothg ? s->d_gvals.p : nullptr);
+                                   bothg ? static_cast<const int64_t *>(s->d_gslice_off.p) : nullptr, bothg ? s->d_gvals.p : nullptr,
+                                   patsf ? static_cast<const uint16_t *>(s->d_node_pat.p) : nullptr, patsf ? static_cast<const int4 *>(s->d_pat_rec.p) : nullptr,
+                                   patsf ? static_cast<const uint16_t *>(s->d_pat_flags.p) : nullptr, s->inc_pat_stride);
                 wrote_grp = bothg;
             }
             break;
@@ -4902,6 +4970,14 @@ extern "C" int pfem_solver_amg_transfer(pfem_solver *s, int level, int *rbm, int
             }
         }
     }
+    return PFEM_OK;
+}
+
+extern "C" int pfem_solver_incidence_patterns(pfem_solver *s, int *count, int *longest)
+{
+    if (!s || !count || !longest) return PFEM_ERR_ARG;
+    *count = s->inc_pat_count;
+    *longest = s->inc_pat_stride;
     return PFEM_OK;
 }
 

@@ -202,7 +202,16 @@ PFEM_HD bool poisson_tet_node_lean(const double x[4], const double y[4], const d
                                    double af, int a, bool need_row, double Kcol[4], double Krow[4], double &Fa)
 {
     TetGeom g;
+#ifdef PFEM_LAB_FREE_GEOMETRY
+    // lab build only (make LAB=1 EXTRA=-DPFEM_LAB_FREE_GEOMETRY, tools/r06/geom.sh): what the gather kernel would cost if an
+    // element's Jacobian, its inverse and the gradients came for nothing -- the upper bound of any scheme that shares them
+    // between the element's four visits.  WRONG matrix, timing only.
+    g.jac = x[1] - x[0] + 1.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { g.gx[i] = y[i]; g.gy[i] = z[i]; g.gz[i] = x[i]; }
+#else
     tet_geometry_lean(x, y, z, g);
+#endif
     if (g.jac < 0.0) return false;
     const double dvol = kGaussWtTet * g.jac;
     double gxa = g.gx[0], gya = g.gy[0], gza = g.gz[0];

@@ -799,6 +799,147 @@ __global__ void __launch_bounds__(kBlock) k_build_inc_rec(MeshDev m, const int64
     }
 }
 
+// ---- incidence lists as TRANSLATED copies of a few patterns ----
+// The packed records are 16 B per visit: 3.1 GB at config 3, two thirds of what the gather kernel fetches from HBM (rocprofv3
+// --pmc: 3.3 GB fetched, 1.5 GB written in 1.48 ms -- and the same kernel with the element geometry for nothing is no faster,
+// profiles/r06/assembly_kernel_bound.txt: the kernel waits for memory, not for its arithmetic).  On a mesh numbered along lines
+// (the reference's boxes; any mesh whose generator numbers a repeated cell the same way) the list of node n is the list of node
+// n + 1 shifted by one: with the other nodes stored RELATIVE to n (the slot bytes are row-relative already) a few hundred
+// distinct lists remain -- interior, and next to each face, edge and corner of the constrained boundary.  The node keeps a 2-byte
+// pattern number; the patterns (kIncPatMax x longest list x 16 B) stay in cache.  Nothing is assumed: every node's list is
+// compared with its pattern word for word when the table is built (k_incpat_assign), a mesh with more patterns than the table
+// holds keeps its own records.  Same records in the same order: the same bits.
+constexpr int kIncPatMax = 1024;                 // patterns (ids are 16 bits)
+constexpr int kIncPatSlots = 4096;               // hash slots, >= 2 x kIncPatMax
+struct IncPatSlot { unsigned long long key; int rep; int id; };
+struct IncPatState { int count, overflow, fail, stride; };
+// other-node word of a record: low 31 bits = node number, or (pattern form) the two's-complement difference to the list's node
+__device__ __forceinline__ int incpat_rel31(int word, int n, bool rel)
+{
+    const uint32_t w = static_cast<uint32_t>(word);
+    return static_cast<int>((rel ? (w & 0x7fffffffu) - static_cast<uint32_t>(n) : w) & 0x7fffffffu) | static_cast<int>(w & 0x80000000u);
+}
+__device__ __forceinline__ int incpat_node(int word, int n) { return n + (static_cast<int>(static_cast<uint32_t>(word) << 1) >> 1); }
+__device__ __forceinline__ unsigned long long incpat_mix(unsigned long long h, unsigned long long v)
+{
+    h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+    h *= 0xff51afd7ed558ccdull;
+    return h ^ (h >> 32);
+}
+// visit t of node n in relative form (npe - 1 other nodes; the unused words of a triangle's record stay as they are)
+__device__ __forceinline__ int4 incpat_record(const int4 rc, int n, int npe)
+{
+    return make_int4(incpat_rel31(rc.x, n, true), incpat_rel31(rc.y, n, true), npe > 3 ? rc.z - n : rc.z, rc.w);
+}
+__device__ __forceinline__ unsigned long long incpat_hash(int64_t n, int cnt, int64_t beg, const int4 *__restrict__ inc_rec,
+                                                          const uint16_t *__restrict__ inc_flags, int npe)
+{
+    unsigned long long h = incpat_mix(0x243f6a8885a308d3ull, static_cast<unsigned long long>(cnt));
+    for (int t = 0; t < cnt; ++t) {
+        const int4 r = incpat_record(inc_rec[beg + 64LL * t], static_cast<int>(n), npe);
+        h = incpat_mix(h, (static_cast<unsigned long long>(static_cast<uint32_t>(r.x)) << 32) | static_cast<uint32_t>(r.y));
+        h = incpat_mix(h, (static_cast<unsigned long long>(static_cast<uint32_t>(r.z)) << 32) | static_cast<uint32_t>(r.w));
+        if (inc_flags) h = incpat_mix(h, inc_flags[beg + 64LL * t]);
+    }
+    return h == 0 ? 1 : h;
+}
+// every node with a row of its own enters its list's hash; the smallest such node of a pattern represents it
+__global__ void __launch_bounds__(kBlock) k_incpat_collect(int64_t nNode, int ndof, int npe, const int64_t *__restrict__ inc_ptr,
+                                                            const int32_t *__restrict__ inc_cnt, const int4 *__restrict__ inc_rec,
+                                                            const uint16_t *__restrict__ inc_flags, const int32_t *__restrict__ node_row,
+                                                            IncPatSlot *table, IncPatState *st)
+{
+    const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (n >= nNode || st->overflow) return;
+    bool has_row = false;
+    for (int p = 0; p < ndof; ++p) has_row |= node_row[n * ndof + p] >= 0;
+    if (!has_row) return;
+    const int cnt = inc_cnt[n];
+    const int64_t beg = inc_ptr[n >> 6] + (n & 63);
+    const unsigned long long h = incpat_hash(n, cnt, beg, inc_rec, inc_flags, npe);
+    uint32_t q = static_cast<uint32_t>(h >> 20) & (kIncPatSlots - 1);
+    for (int tries = 0; tries < kIncPatSlots; ++tries, q = (q + 1) & (kIncPatSlots - 1)) {
+        unsigned long long seen = *reinterpret_cast<volatile unsigned long long *>(&table[q].key);
+        if (seen == 0) {
+            seen = atomicCAS(&table[q].key, 0ull, h);
+            if (seen == 0) {
+                if (atomicAdd(&st->count, 1) >= kIncPatMax) { st->overflow = 1; return; }
+                seen = h;
+            }
+        }
+        if (seen == h) {
+            atomicMin(&table[q].rep, static_cast<int>(n));
+            atomicMax(&st->stride, cnt);
+            return;
+        }
+    }
+    st->overflow = 1;
+}
+// one block: patterns numbered by their representatives (ascending node number -- whatever order the slots were claimed in)
+__global__ void __launch_bounds__(kBlock) k_incpat_number(IncPatSlot *table, IncPatState *st, int32_t *pat_rep)
+{
+    if (st->overflow) return;
+    for (int q = threadIdx.x; q < kIncPatSlots; q += kBlock) {
+        if (table[q].key == 0) continue;
+        const int rep = table[q].rep;
+        int id = 0;
+        for (int j = 0; j < kIncPatSlots; ++j) id += (table[j].key != 0 && table[j].rep < rep) ? 1 : 0;
+        table[q].id = id;
+        pat_rep[id] = rep;
+    }
+}
+// the table: pattern id's visit t at pat_rec[id * stride + t] (+ the element's constrained-dof bits for kinds with ndof > 1)
+__global__ void __launch_bounds__(kBlock) k_incpat_fill(const IncPatState *st, const int32_t *__restrict__ pat_rep, int npe,
+                                                         const int64_t *__restrict__ inc_ptr, const int32_t *__restrict__ inc_cnt,
+                                                         const int4 *__restrict__ inc_rec, const uint16_t *__restrict__ inc_flags,
+                                                         int4 *pat_rec, uint16_t *pat_flags, int32_t *pat_cnt)
+{
+    if (st->overflow) return;
+    const int stride = st->stride, np = min(st->count, kIncPatMax);
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= static_cast<int64_t>(np) * stride) return;
+    const int id = static_cast<int>(i / stride), t = static_cast<int>(i % stride);
+    const int n = pat_rep[id], cnt = inc_cnt[n];
+    const int64_t beg = inc_ptr[n >> 6] + (n & 63);
+    if (t == 0) pat_cnt[id] = cnt;
+    pat_rec[i] = t < cnt ? incpat_record(inc_rec[beg + 64LL * t], n, npe) : make_int4(0, 0, 0, 0);
+    if (pat_flags) pat_flags[i] = t < cnt ? inc_flags[beg + 64LL * t] : 0;
+}
+// every node: its pattern's number, and the word-for-word comparison of its list with the table (a hash collision, or anything
+// else that makes them differ, refuses the form for the whole mesh)
+__global__ void __launch_bounds__(kBlock) k_incpat_assign(int64_t nNode, int ndof, int npe, const int64_t *__restrict__ inc_ptr,
+                                                           const int32_t *__restrict__ inc_cnt, const int4 *__restrict__ inc_rec,
+                                                           const uint16_t *__restrict__ inc_flags, const int32_t *__restrict__ node_row,
+                                                           const IncPatSlot *__restrict__ table, IncPatState *st, const int4 *__restrict__ pat_rec,
+                                                           const uint16_t *__restrict__ pat_flags, const int32_t *__restrict__ pat_cnt,
+                                                           uint16_t *node_pat)
+{
+    const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (n >= nNode || st->overflow) return;
+    node_pat[n] = 0;
+    bool has_row = false;
+    for (int p = 0; p < ndof; ++p) has_row |= node_row[n * ndof + p] >= 0;
+    if (!has_row) return;
+    const int cnt = inc_cnt[n], stride = st->stride;
+    const int64_t beg = inc_ptr[n >> 6] + (n & 63);
+    const unsigned long long h = incpat_hash(n, cnt, beg, inc_rec, inc_flags, npe);
+    uint32_t q = static_cast<uint32_t>(h >> 20) & (kIncPatSlots - 1);
+    int id = -1;
+    for (int tries = 0; tries < kIncPatSlots; ++tries, q = (q + 1) & (kIncPatSlots - 1)) {
+        const unsigned long long key = table[q].key;
+        if (key == h) { id = table[q].id; break; }
+        if (key == 0) break;
+    }
+    bool same = id >= 0 && pat_cnt[id] == cnt;
+    for (int t = 0; same && t < cnt; ++t) {
+        const int4 a = incpat_record(inc_rec[beg + 64LL * t], static_cast<int>(n), npe), b = pat_rec[static_cast<int64_t>(id) * stride + t];
+        same = a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w;
+        if (same && pat_flags) same = inc_flags[beg + 64LL * t] == pat_flags[static_cast<int64_t>(id) * stride + t];
+    }
+    if (!same) { st->fail = 1; return; }
+    node_pat[n] = static_cast<uint16_t>(id);
+}
+
 // longest matrix row among those the gather kernels own (hub rows excluded): sizes their LDS accumulators
 __global__ void __launch_bounds__(kBlock) k_max_gather_row(const int32_t *__restrict__ node_row, int64_t n, const int32_t *__restrict__ rowlen,
                                                             int *out)
@@ -1003,7 +1144,9 @@ __global__ void __launch_bounds__(kBlock) k_gather_poisson_tet4(int64_t nNode, S
                                                                  double *__restrict__ rvals = nullptr,
                                                                  double *__restrict__ dinv_out = nullptr, double *__restrict__ ratio_out = nullptr,
                                                                  const VdHashEntry *__restrict__ vhash = nullptr, uint16_t *__restrict__ codes16 = nullptr,
-                                                                 VdState *__restrict__ vstate = nullptr)
+                                                                 VdState *__restrict__ vstate = nullptr,
+                                                                 const uint16_t *__restrict__ node_pat = nullptr, const int4 *__restrict__ pat_rec = nullptr,
+                                                                 int pat_stride = 0)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];
     const int T = blockDim.x;
@@ -1012,7 +1155,11 @@ __global__ void __launch_bounds__(kBlock) k_gather_poisson_tet4(int64_t nNode, S
     const int row = node_row[n];
     if (row < 0) return;
     const int cnt = inc_cnt[n];
-    const int64_t beg = inc_ptr[n >> 6] + (n & 63), end = beg + 64LL * cnt;
+    // the node's list: its own records (slot t of lane l at beg + 64 t), or -- pat_rec -- its pattern's, the other nodes relative to n
+    const bool rel = pat_rec != nullptr;
+    const int4 *__restrict__ rp = rel ? pat_rec + static_cast<int64_t>(node_pat[n]) * pat_stride : inc_rec + (inc_ptr[n >> 6] + (n & 63));
+    const int rstep = rel ? 1 : 64;
+    const auto other = [&](int word) -> int { return rel ? incpat_node(word, static_cast<int>(n)) : (word & 0x7fffffff); };
     const int64_t base = A.slice_off[row >> 6] + (row & 63);
     const int len = A.rowlen[row];
     double facc = 0.0;
@@ -1028,13 +1175,13 @@ __global__ void __launch_bounds__(kBlock) k_gather_poisson_tet4(int64_t nNode, S
     // four cases are skipped by a scalar branch; at boundaries the cases run one after the other under their lanes' masks.
     // Same arithmetic in the same order: K and F stay bit-identical to the serial loop.
     const double4 self = node4[n];
-    int4 rc_next = cnt > 0 ? inc_rec[beg] : int4{0, 0, 0, 0};
-    int4 rc_next2 = cnt > 1 ? inc_rec[beg + 64] : int4{0, 0, 0, 0};
+    int4 rc_next = cnt > 0 ? rp[0] : int4{0, 0, 0, 0};
+    int4 rc_next2 = cnt > 1 ? rp[rstep] : int4{0, 0, 0, 0};
     double4 co[3];
     if (cnt > 0) {
-        co[0] = node4[rc_next.x & 0x7fffffff];
-        co[1] = node4[rc_next.y & 0x7fffffff];
-        co[2] = node4[rc_next.z];
+        co[0] = node4[other(rc_next.x)];
+        co[1] = node4[other(rc_next.y)];
+        co[2] = node4[rel ? static_cast<int>(n) + rc_next.z : rc_next.z];
     } else {
         co[0] = co[1] = co[2] = double4{0.0, 0.0, 0.0, 0.0};
     }
@@ -1042,15 +1189,15 @@ __global__ void __launch_bounds__(kBlock) k_gather_poisson_tet4(int64_t nNode, S
     // (the slot of the row's own column -- the diagonal -- is the node's own slot in any of its visits: the first one's)
     const int kd = cnt > 0 ? static_cast<int>((static_cast<uint32_t>(rc_next.w) >>
                                                (8 * ((static_cast<uint32_t>(rc_next.x) >> 31) | ((static_cast<uint32_t>(rc_next.y) >> 31) << 1)))) & 0xffu) : -1;
-    for (int64_t t = beg; t < end; t += 64) {
+    for (int v = 0; v < cnt; ++v) {
         const int4 rc = rc_next;
         const double4 c0 = co[0], c1 = co[1], c2 = co[2];
         rc_next = rc_next2;
-        if (t + 64 < end) {
-            co[0] = node4[rc_next.x & 0x7fffffff];
-            co[1] = node4[rc_next.y & 0x7fffffff];
-            co[2] = node4[rc_next.z];
-            if (t + 128 < end) rc_next2 = inc_rec[t + 128];
+        if (v + 1 < cnt) {
+            co[0] = node4[other(rc_next.x)];
+            co[1] = node4[other(rc_next.y)];
+            co[2] = node4[rel ? static_cast<int>(n) + rc_next.z : rc_next.z];
+            if (v + 2 < cnt) rc_next2 = rp[static_cast<int64_t>(v + 2) * rstep];
         }
         const uint32_t slots = static_cast<uint32_t>(rc.w);
         const int a = static_cast<int>((static_cast<uint32_t>(rc.x) >> 31) | ((static_cast<uint32_t>(rc.y) >> 31) << 1));
@@ -1123,7 +1270,9 @@ __global__ void __launch_bounds__(kBlock) k_gather_elast_rows(MeshDev m, SellDev
                                                                const int32_t *__restrict__ row_group = nullptr,
                                                                const int32_t *__restrict__ group_row0 = nullptr,
                                                                const int64_t *__restrict__ gslice_off = nullptr,
-                                                               double *__restrict__ gvals = nullptr)
+                                                               double *__restrict__ gvals = nullptr,
+                                                               const uint16_t *__restrict__ node_pat = nullptr, const int4 *__restrict__ pat_rec = nullptr,
+                                                               const uint16_t *__restrict__ pat_flags = nullptr, int pat_stride = 0)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_acc[];
     const int T = blockDim.x;
@@ -1134,7 +1283,12 @@ __global__ void __launch_bounds__(kBlock) k_gather_elast_rows(MeshDev m, SellDev
     const int row = node_row[tid];
     if (row < 0) return;
     const int cnt = inc_cnt[n];
-    const int64_t beg = inc_ptr[n >> 6] + (n & 63), end = beg + 64LL * cnt;
+    // the node's list: its own records, or its pattern's with the other nodes relative to n (k_incpat_*)
+    const bool rel = pat_rec != nullptr;
+    const int64_t beg = rel ? static_cast<int64_t>(node_pat[n]) * pat_stride : inc_ptr[n >> 6] + (n & 63);
+    const int4 *__restrict__ rp = (rel ? pat_rec : inc_rec) + beg;
+    const uint16_t *__restrict__ fp = (rel ? pat_flags : inc_flags) + beg;
+    const int rstep = rel ? 1 : 64;
     const int64_t base = A.slice_off[row >> 6] + (row & 63);
     const int len = A.rowlen[row];
     double *acc = lds_acc + threadIdx.x;
@@ -1142,12 +1296,13 @@ __global__ void __launch_bounds__(kBlock) k_gather_elast_rows(MeshDev m, SellDev
     const ElastMat mat = elast_material(prm.ed[0], prm.ed[1]);
     const double bf = p == 0 ? prm.ed[3] : (p == 1 ? prm.ed[4] : prm.ed[5]);
     double facc = 0.0;
-    for (int64_t t = beg; t < end; t += 64) {
-        const int4 rc = inc_rec[t];
-        const uint32_t flags = inc_flags[t];
+    for (int v = 0; v < cnt; ++v) {
+        const int4 rc = rp[static_cast<int64_t>(v) * rstep];
+        const uint32_t flags = fp[static_cast<int64_t>(v) * rstep];
         const uint32_t slots = static_cast<uint32_t>(rc.w);
         const int a = static_cast<int>((static_cast<uint32_t>(rc.x) >> 31) | ((static_cast<uint32_t>(rc.y) >> 31) << 1));
-        const int o[3] = {rc.x & 0x7fffffff, rc.y & 0x7fffffff, rc.z};
+        const int o[3] = {rel ? incpat_node(rc.x, static_cast<int>(n)) : (rc.x & 0x7fffffff),
+                          rel ? incpat_node(rc.y, static_cast<int>(n)) : (rc.y & 0x7fffffff), rel ? static_cast<int>(n) + rc.z : rc.z};
         int nd[4];
         double x[4], y[4], z[4];
 #pragma unroll

@@ -277,6 +277,12 @@ class PetscSolver:
             out["xyz"] = a
         return out
 
+    def incidencePatterns(self):
+        """(patterns, longest list) of the gather form's incidence lists stored as translated copies; (0, 0): own records."""
+        n = C.c_int(0); m = C.c_int(0)
+        L.check(L.lib().pfem_solver_incidence_patterns(self._h, C.byref(n), C.byref(m)), "pfem_solver_incidence_patterns")
+        return n.value, m.value
+
     def amgAggregation(self):
         """How every level's aggregates were formed: a list of "bricks" / "node-bricks" / "split-bricks" / "lattice-passes" /
         "matching" / "roots" per transfer (one fewer than levels)."""

@@ -1231,6 +1231,41 @@ def test_gamg_bound_and_diagonal_from_the_assembly_kernel_keep_every_bit(monkeyp
     assert not np.array_equal(a[0][2], a[2][2])
 
 
+@pytest.mark.parametrize("kind_name", ["poisson", "elast"])
+def test_incidence_lists_as_translated_patterns_keep_every_bit(kind_name, monkeypatch):
+    """A box numbered along its lines: the gather kernels read a node's incidence list from the pattern it is a translated copy
+    of (k_incpat_*: interior, faces, edges, corners of the constrained boundary -- a few dozen lists) instead of 16 B per visit
+    of its own (two thirds of the Poisson kernel's HBM fetches).  K and F are the same bits as with every node's own records
+    (PFEM_DEBUG_INC_OWN_RECORDS=1, looked up at every assembly) and as the oracle's serial loop; a mesh under a random numbering
+    has as many patterns as nodes, keeps its own records and assembles the same matrix."""
+    if kind_name == "poisson":
+        kind, ed = pf.POISSON_TET, np.array([1.3, 0.7, 2.1])
+        mesh = H.gen_box_tets(-1, 1, 21, -1, 1, 17, -1, 1, 19)
+    else:
+        kind, ed = pf.ELAST_TET, H.ELAST_ELEMDATA
+        mesh = H.gen_box_tets(-0.5, 0.5, 7, 0.0, 6.0, 30, -0.5, 0.5, 6, bc_mode=1, ndof=3)
+    monkeypatch.delenv("PFEM_DEBUG_INC_OWN_RECORDS", raising=False)
+    s, dm = _device_problem(kind, mesh, ed)
+    n_pat, longest = s.incidencePatterns()
+    assert 1 <= n_pat <= 200 and 1 <= longest <= 24, (n_pat, longest)
+    rowptr, cols, vals = s.getCSR()
+    rhs = s.getRHS()
+    monkeypatch.setenv("PFEM_DEBUG_INC_OWN_RECORDS", "1")
+    s.assemble(ed, H.TIMEDATA)
+    _, _, vals_own = s.getCSR()
+    assert np.array_equal(vals, vals_own) and np.array_equal(rhs, s.getRHS())
+    monkeypatch.delenv("PFEM_DEBUG_INC_OWN_RECORDS")
+    s.assemble(ed, H.TIMEDATA)
+    assert np.array_equal(vals, s.getCSR()[2]) and np.array_equal(rhs, s.getRHS())
+    prob = O.setup_problem(kind, _omesh(mesh), elemData=ed)
+    assert np.array_equal(prob.rowptr, rowptr) and np.array_equal(prob.cols, cols)
+    assert np.array_equal(prob.vals, vals) and np.array_equal(prob.rhs, rhs)
+    s.free()
+    s2, _ = _device_problem(kind, _shuffled(mesh), ed)
+    assert s2.incidencePatterns() == (0, 0)
+    s2.free()
+
+
 def _shuffled(mesh, seed=7):
     """The same mesh under a random node numbering (what an arbitrary mesh file may look like)."""
     perm = np.random.default_rng(seed).permutation(mesh.nNode).astype(np.int32)       # old id -> new id

@@ -55,7 +55,21 @@ def pmc(d, counter):
         print(f"{short(k):92s} {v[0]:10d} {v[1] / v[0]:28.1f}")
 
 
+def pmc_each(d, counter, needle):
+    """every dispatch of the kernels whose name contains `needle`, in dispatch order (first steps differ from later ones)"""
+    rows = []
+    for f in find(d, "*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter and needle in r["Kernel_Name"]:
+                rows.append((int(r["Dispatch_Id"]), short(r["Kernel_Name"])[:60], float(r["Counter_Value"])))
+    for i, k, v in sorted(rows):
+        print(f"{counter} dispatch {i:6d} {k:60s} {v:16.1f}")
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "pmc_each":
+        pmc_each(sys.argv[2], sys.argv[3], sys.argv[4])
+        sys.exit(0)
     if sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 25)
     else:
