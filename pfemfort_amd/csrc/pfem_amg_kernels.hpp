@@ -871,6 +871,45 @@ __global__ void __launch_bounds__(kBlock) k_amg_lattice_pos_nodes(int64_t nNode,
     }
 }
 
+// ---- a lattice by NUMBERING: nodes moved off their lattice sites (a mapped or graded block, a mesh after a moving-mesh step),
+// but numbered like a box -- node n at (n % a, (n / a) % (b / a), n / b).  The strides a, b come from the incidence patterns
+// (lattice_positions_by_numbering); this pass holds every element to them: the nodes of an element lie within one cell of each
+// other along every axis (a stride that only looks right wraps around somewhere and is caught here)
+__global__ void __launch_bounds__(kBlock) k_latnum_check(int64_t nNode, int ndof, int a, int b, int n2, const int64_t *__restrict__ inc_ptr,
+                                                          const int32_t *__restrict__ inc_cnt, const int4 *__restrict__ inc_rec,
+                                                          const int32_t *__restrict__ node_row, int *bad)
+{
+    const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (n >= nNode) return;
+    bool has_row = false;
+    for (int p = 0; p < ndof; ++p) has_row |= node_row[n * ndof + p] >= 0;
+    if (!has_row) return;
+    const int i0 = static_cast<int>(n % a), j0 = static_cast<int>((n % b) / a), k0 = static_cast<int>(n / b);
+    bool ok = k0 < n2;
+    const int cnt = inc_cnt[n];
+    const int64_t beg = inc_ptr[n >> 6] + (n & 63);
+    for (int t = 0; t < cnt && ok; ++t) {
+        const int4 rc = inc_rec[beg + 64LL * t];
+        const int o[3] = {rc.x & 0x7fffffff, rc.y & 0x7fffffff, rc.z};
+        for (int q = 0; q < 3; ++q) {
+            const int di = o[q] % a - i0, dj = (o[q] % b) / a - j0, dk = o[q] / b - k0;
+            ok = ok && di >= -1 && di <= 1 && dj >= -1 && dj <= 1 && dk >= -1 && dk <= 1 && o[q] / b < n2;
+        }
+    }
+    if (!ok) *bad = 1;
+}
+__global__ void __launch_bounds__(kBlock) k_latnum_pos(int64_t nNode, int ndof, int a, int b, const int32_t *__restrict__ node_row, int64_t n_owned,
+                                                        int32_t *__restrict__ pos)
+{
+    const int64_t n = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (n >= nNode) return;
+    const int32_t p = static_cast<int32_t>(n % a) | (static_cast<int32_t>((n % b) / a) << 10) | (static_cast<int32_t>(n / b) << 20);
+    for (int d = 0; d < ndof; ++d) {
+        const int32_t l = node_row[n * ndof + d];
+        if (l >= 0 && l < n_owned) pos[l] = p;
+    }
+}
+
 // place of a node = place of its first dof / dofs per node
 __global__ void __launch_bounds__(kBlock) k_amg_node_hint(int64_t n, const int32_t *__restrict__ node_of, const int32_t *__restrict__ comp_of,
                                                            const int32_t *__restrict__ dof_rank, int bs, int32_t *__restrict__ hint)

@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(kBlock) k_rbm_lat_check(int64_t nn, const int6
         const int dist = abs(qx - px) + abs(qy - py) + abs(qz - pz);
         if (dist == 1 && table[qx] == bx && table[1024 + qy] == by && table[2048 + qz] == bz) smin_in = fmin(smin_in, sij);
     }
-    if (smin_in < 1e300 && !(smin_in > 0.0 && smin_in >= 0.25 * smax)) *fail = 1;
+    if (smin_in < 1e300 && !(smin_in > 0.0 && smin_in >= 0.25 * smax)) atomicAdd(fail, 1);       // (*fail: the number of such nodes)
 }
 // aggregate of every node = its brick, numbered in z, y, x order inside the box of bricks (the lines are full: every brick is
 // occupied); blo / nbk: first brick and number of bricks along every axis

@@ -489,6 +489,7 @@ struct pfem_solver {
     DevBuf<uint16_t> d_node_pat, d_pat_flags;
     DevBuf<int4> d_pat_rec;
     int inc_pat_count = 0, inc_pat_stride = 0;     // count > 0: the form is in use
+    bool lattice_by_numbering = false;             // the last hierarchy's lattice came from the numbering, not from the coordinates
     DevBuf<int32_t> d_node_row;    // [nNode*ndof] matrix row of every node dof, -1 = no row
     int rows_threads = 0;    // block size of the LDS-row gather kernels (256/128/64), 0 = rows too long
     int gather_row_len = 0;  // longest row the gather kernels own (hub rows excluded)
@@ -1103,15 +1104,85 @@ int lattice_assign(pfem_solver *s, const std::vector<double> &h_uniq, const int 
     PFEM_HIP(hipStreamSynchronize(s->stream));         // (uniq goes out of scope)
     return PFEM_OK;
 }
+// The same positions for a mesh whose nodes do NOT sit on a tensor-product lattice but whose NUMBERING is a box's: one rank,
+// tetrahedra, the incidence lists translated copies of a few patterns (build_incidence_patterns).  The other nodes of every
+// list lie at i + j a + k b from the list's node with i, j, k in {-1, 0, 1}: a and b | nNode are looked for among the offsets
+// themselves, then every element is held to them on the device (k_latnum_check).  PFEM_AMG_LATTICE_BY_NUMBERING=0: off.
+int lattice_positions_by_numbering(pfem_solver *s, DevBuf<int32_t> &pos, bool *is_lattice, int hi[3])
+{
+    *is_lattice = false;
+    const MeshDev &m = s->mesh;
+    const bool on = [] { const char *e = std::getenv("PFEM_AMG_LATTICE_BY_NUMBERING"); return e ? std::atoi(e) != 0 : true; }();       // (looked up per hierarchy)
+    if (!on || s->inc_pat_count <= 0 || !s->d_pat_rec.p || !s->d_inc_rec.p || !s->d_node_row.p || m.npe != 4 || m.ndim != 3 || s->nranks != 1 ||
+        s->n_ghost != 0 || m.nNode < 8 || m.nNode >= (1LL << 30))
+        return PFEM_OK;
+    std::vector<int4> rec(static_cast<size_t>(s->inc_pat_count) * s->inc_pat_stride);
+    PFEM_HIP(hipMemcpyAsync(rec.data(), s->d_pat_rec.p, sizeof(int4) * rec.size(), hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    std::vector<int64_t> offs;
+    for (const int4 &r : rec) {
+        const int64_t o[3] = {static_cast<int32_t>(static_cast<uint32_t>(r.x) << 1) >> 1, static_cast<int32_t>(static_cast<uint32_t>(r.y) << 1) >> 1, r.z};
+        if (o[0] == 0 && o[1] == 0 && o[2] == 0) continue;         // (padding behind a shorter list)
+        for (int q = 0; q < 3; ++q) offs.push_back(o[q] < 0 ? -o[q] : o[q]);
+    }
+    std::sort(offs.begin(), offs.end());
+    offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
+    if (offs.empty() || offs.front() == 0 || offs.size() > 13) return PFEM_OK;        // (a node cannot be its own neighbour; 13 = (27 - 1) / 2)
+    const auto fits = [&](int64_t a, int64_t b) {
+        if (a < 2 || b < 2 * a || b % a != 0 || m.nNode % b != 0 || a > 1024 || b / a > 1024 || m.nNode / b > 1024 || m.nNode / b < 2) return false;
+        bool axis[3] = {false, false, false};
+        for (int64_t d : offs) {
+            bool found = false;
+            for (int k = 0; k <= 1 && !found; ++k)
+                for (int j = -1; j <= 1 && !found; ++j)
+                    for (int i = -1; i <= 1 && !found; ++i)
+                        if (i + j * a + k * b == d) { found = true; axis[0] |= i != 0; axis[1] |= j != 0; axis[2] |= k != 0; }
+            if (!found) return false;
+        }
+        return axis[0] && axis[1] && axis[2];
+    };
+    int64_t a = 0, b = 0;
+    for (size_t p = 0; p < offs.size() && !a; ++p)
+        for (size_t q = p + 1; q < offs.size() && !a; ++q)
+            if (fits(offs[p], offs[q])) { a = offs[p]; b = offs[q]; }
+    if (!a) return PFEM_OK;
+    const int n2 = static_cast<int>(m.nNode / b);
+    DevBuf<int> d_bad;
+    PFEM_TRY(d_bad.alloc(1));
+    PFEM_HIP(hipMemsetAsync(d_bad.p, 0, sizeof(int), s->stream));
+    hipLaunchKernelGGL(k_latnum_check, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m.nNode, m.ndof, static_cast<int>(a), static_cast<int>(b), n2,
+                       static_cast<const int64_t *>(s->d_inc_ptr.p), static_cast<const int32_t *>(s->d_inc_cnt.p), static_cast<const int4 *>(s->d_inc_rec.p),
+                       static_cast<const int32_t *>(s->d_node_row.p), d_bad.p);
+    PFEM_TRY(check_kernel("k_latnum_check"));
+    int bad = 0;
+    PFEM_HIP(hipMemcpyAsync(&bad, d_bad.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    if (bad) return PFEM_OK;
+    PFEM_TRY(pos.alloc(static_cast<size_t>(std::max<int64_t>(s->n_owned, 1))));
+    PFEM_HIP(hipMemsetAsync(pos.p, 0, sizeof(int32_t) * static_cast<size_t>(std::max<int64_t>(s->n_owned, 1)), s->stream));
+    hipLaunchKernelGGL(k_latnum_pos, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m.nNode, m.ndof, static_cast<int>(a), static_cast<int>(b),
+                       static_cast<const int32_t *>(s->d_node_row.p), s->n_owned, pos.p);
+    PFEM_TRY(check_kernel("k_latnum_pos"));
+    PFEM_HIP(hipStreamSynchronize(s->stream));
+    hi[0] = static_cast<int>(a) - 1;
+    hi[1] = static_cast<int>(b / a) - 1;
+    hi[2] = n2 - 1;
+    s->lattice_by_numbering = true;
+    *is_lattice = true;
+    return PFEM_OK;
+}
+
 // *is_lattice = false when the mesh has none (pos untouched).  hi[d] = highest position along axis d.
 int lattice_positions(pfem_solver *s, DevBuf<int32_t> &pos, bool *is_lattice, int hi[3])
 {
     *is_lattice = false;
+    s->lattice_by_numbering = false;
     int count[3];
     std::vector<double> h_uniq;
     bool ok = false;
     PFEM_TRY(lattice_distinct(s, count, h_uniq, &ok));
-    if (!ok || static_cast<int64_t>(count[0]) * count[1] * count[2] > 2 * s->mesh.nNode) return PFEM_OK;
+    if (!ok || static_cast<int64_t>(count[0]) * count[1] * count[2] > 2 * s->mesh.nNode)
+        return lattice_positions_by_numbering(s, pos, is_lattice, hi);
     PFEM_TRY(lattice_assign(s, h_uniq, count, s->n_owned, pos));
     for (int d = 0; d < 3; ++d) hi[d] = count[d] - 1;
     *is_lattice = true;

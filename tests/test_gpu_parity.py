@@ -948,13 +948,16 @@ def _moved(mesh, h, frac=0.2, seed=7):
 
 @pytest.mark.parametrize("case", ["tet10", "cube30", "beam", "cook", "compat", "tria20", "tiny", "aniso", "cube30_moved", "beam_moved",
                                   "cube30_moved_w", "beam_moved_w", "tet10_w"])
-def test_gamg_solve_equals_oracle_restatement(case, tet10, beam, tria20, golden_dir):
+def test_gamg_solve_equals_oracle_restatement(case, tet10, beam, tria20, golden_dir, monkeypatch):
     """-pc_type gamg on file meshes and generated boxes, scalar and 3-dof problems, the batched and the MatSetValues path:
     the device hierarchy (matching aggregates, Galerkin sums, Gershgorin bounds, Chebyshev V-cycle, dense bottom solve) and
     its PCG loop against the oracle's restatement given the same aggregates; against a direct solve; fewer iterations than
     point Jacobi; aggregates are what three passes of pairing can produce."""
     import scipy.sparse as sp
     import scipy.sparse.linalg as spl
+    # (the moved boxes keep a box's numbering, which would give them their bricks back -- test_gamg_lattice_by_numbering...; here they
+    # stand for meshes without any lattice: matching on the strength graph)
+    monkeypatch.setenv("PFEM_AMG_LATTICE_BY_NUMBERING", "0")
     if case == "compat":
         res = pf.tetrapoissonparallelimpl1(tet10, mode="compat", rtol=1e-10)
         s, its_j = res.solver, res.its
@@ -1027,6 +1030,57 @@ def test_gamg_solve_equals_oracle_restatement(case, tet10, beam, tria20, golden_
     if case == "cube30":                        # a lattice numbered line by line: mostly 2x2x2 bricks
         assert (np.bincount(aggs[0]) == 8).mean() > 0.7 and its <= 0.3 * its_j
     assert all(1.0 < lam < 8.0 for lam in info["lambda_max"])
+
+
+@pytest.mark.parametrize("kind_name", ["poisson", "elast"])
+def test_gamg_lattice_by_numbering_when_the_nodes_left_their_sites(kind_name, monkeypatch):
+    """A box whose nodes were moved (a mapped block, a mesh after a moving-mesh step) has no lattice of coordinates, but its
+    NUMBERING is still a box's: the incidence lists are translated copies of a few patterns, their offsets give the strides
+    (lattice_positions_by_numbering), every element is held to them, and the hierarchy takes the bricks the unmoved box would
+    take -- the oracle's restatement from the UNMOVED coordinates equals the device's aggregates entry for entry; the cycle on
+    the moved mesh's matrix equals the oracle's given those aggregates.  The same mesh under a random numbering has neither
+    lattice and is left to the passes / matching."""
+    monkeypatch.delenv("PFEM_AMG_LATTICE_BY_NUMBERING", raising=False)
+    if kind_name == "poisson":
+        kind, ed = pf.POISSON_TET, H.POISSON_ELEMDATA
+        mesh0 = H.gen_box_tets(-1, 1, 26, -1, 1, 26, -1, 1, 26)
+        h = 2.0 / 26
+    else:
+        kind, ed = pf.ELAST_TET, H.ELAST_ELEMDATA
+        mesh0 = H.gen_box_tets(-0.5, 0.5, 8, 0.0, 6.0, 48, -0.5, 0.5, 8, bc_mode=1, ndof=3)
+        h = 1.0 / 8
+    mesh = _moved(mesh0, h)
+    s, dm = _device_problem(kind, mesh, ed)
+    if kind_name == "elast":
+        s.setSpmvFormat("grouped")
+        s.buildPattern()
+        s.assemble(ed, H.TIMEDATA)
+    assert s.incidencePatterns()[0] >= 1
+    s.setTolerances(rtol=1e-10, maxits=20000)
+    its, info, aggs, x = _gamg_vs_oracle(s)
+    kinds = s.amgAggregation()
+    assert s.amgLayout()["lattice_levels"] >= 1 and kinds[0] == ("bricks" if kind_name == "poisson" else "node-bricks"), kinds
+    xyz0 = mesh0.xyz[:, dm.node_map_get_old]
+    if kind_name == "poisson":
+        free = np.where(dm.NodeDofArrayNew.reshape(-1) >= 0)[0]
+        own = O.lattice_brick_aggregates(xyz0, xyz0[:, free])
+        dev = aggs
+    else:
+        free = np.where(dm.NodeDofArrayNew.reshape(-1, 3)[:, 0] >= 0)[0]
+        own = O.lattice_node_brick_aggregates(xyz0, xyz0[:, free])
+        dev = []
+        for l in range(info["levels"] - 1):
+            tr = s.amgTransfer(l)
+            dev.append(s.amgAggregates(l, info["rows"][l]).reshape(-1, tr["fine_bs"])[:, 0] // tr["coarse_bs"])
+    assert own is not None and len(own) == len(dev) >= 2 and all(np.array_equal(a, b) for a, b in zip(own, dev)), (kinds, info["rows"])
+    s.free()
+    s2, _ = _device_problem(kind, _shuffled(mesh), ed)
+    s2.setPreconditioner("gamg")
+    s2.setTolerances(rtol=1e-10, maxits=20000)
+    its2, reason2, _ = s2.factoriseAndSolve()
+    assert reason2 == 2 and "bricks" not in s2.amgAggregation() and "node-bricks" not in s2.amgAggregation()
+    assert its <= its2
+    s2.free()
 
 
 @pytest.mark.parametrize("case", ["tet10", "cube30", "tria20", "odd"])
