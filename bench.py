@@ -674,6 +674,8 @@ def run_case(J, beam, nE, ext, steps, warmup, rtol, profile=True, parity_step=Fa
     R["pc"] = pc
     R["pc_in_effect"] = solver.preconditioner()
     R["amg"] = solver.amgInfo() if R["pc_in_effect"] == "gamg" else None
+    R["amg_aggregation"] = solver.amgAggregation() if R["pc_in_effect"] == "gamg" else None
+    R["incidence_patterns"] = solver.incidencePatterns()
     R["amg_layout"] = solver.amgLayout() if R["pc_in_effect"] == "gamg" else None
     R["amg_cycle"] = solver.amgCycle() if R["pc_in_effect"] == "gamg" else None
     R["amg_vd"] = solver.amgValueDictionaries() if R["pc_in_effect"] == "gamg" else None
@@ -1040,6 +1042,8 @@ def main():
                                 "symbolic_setup_ms_once_per_pattern": R["amg"]["symbolic_ms"],
                                 "symbolic_setup_where": "first solve after a pattern build (a warm-up step; with --warmup 0 the first timed step)",
                                 "levels_paired_on_the_lattice": R["amg_layout"]["lattice_levels"],
+                                # how every level's aggregates were formed (pfem_solver_amg_aggregation), rank 0's view
+                                "aggregation": R["amg_aggregation"],
                                 # -pc_mg_cycle_type (--cycle; V unless asked: W halves the iterations on matched aggregates and costs
                                 # twice the time, LAB_NOTES round 5)
                                 "cycle": R["amg_cycle"]["cycle"], "last_level_visited_twice": R["amg_cycle"]["last_level_visited_twice"],
@@ -1066,7 +1070,14 @@ def main():
             "assembly_kernel": ({"kernel": "pfem::k_gather_poisson_tet4 (gather assembly; in the steady state it also writes the SpMV's 16-bit value codes "
                                            "and level 0's inverse diagonal + Gershgorin ratios for the multigrid)",
                                  "event_ms_per_step": acc["asm_ms"] / args.steps,
-                                 "bound": "fp64-valu-issue",
+                                 # what it waits for (profiles/r06/assembly_kernel_bound.txt): not its arithmetic -- the same kernel with the
+                                 # element geometry for nothing is no faster -- but its gathered node records (72 x 32 B per row through the
+                                 # L1) under 4 waves per SIMD; its incidence records come from a cached pattern table where the mesh's
+                                 # numbering repeats (`incidence_patterns` > 0: 2.34 GB moved per launch instead of 5.37)
+                                 "bound": "memory-latency (gathered node records at 4 waves per SIMD)",
+                                 "incidence_patterns": R["incidence_patterns"][0], "longest_incidence_list": R["incidence_patterns"][1],
+                                 "bytes_moved_per_launch_replayed_not_this_run": {"records_from_the_pattern_table": 2.34e9, "every_nodes_own_records": 5.37e9,
+                                                                                  "source": "profiles/r06/assembly_kernel_bound.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per dispatch, tools/r06/incpat2.sh)"},
                                  # SQ_ACTIVE_INST_VALU / (32 x GRBM_GUI_ACTIVE) of this kernel on this workload, re-taken in round 6 at commit 16005af
                                  # (466.1 M / (32 x 21.34 M); round 4: 0.75 with 22 % more VALU instructions per launch)
                                  "valu_issue_fraction_replayed_not_this_run": 0.68,

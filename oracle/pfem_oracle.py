@@ -505,6 +505,48 @@ def lattice_brick_aggregates(xyz_nodes, xyz_free, dense_limit=128, passes=3, max
     return aggs
 
 
+def lattice_by_numbering(conn, n_nodes):
+    """A box's NUMBERING on a mesh of tetrahedra whose nodes need not sit on a lattice (the product: lattice_positions_by_numbering
+    in pfemfort_amd/csrc/pfem_device.hip, k_latnum_check): the other nodes of every element lie at i + j a + k b from each of
+    its nodes with i, j, k in {-1, 0, 1}; a and b are looked for among the (at most 13) distinct absolute differences themselves
+    -- ascending pairs with b a multiple of a and a divisor of the node count, every axis in use -- and every element is held to
+    the positions (n % a, (n % b) / a, n / b): its nodes within one cell of each other along every axis (a box of 6 x 5 x 4 nodes
+    whose cells are cut along e_z - e_y offers b = 24 before b = 30: the first pair that passes this test is taken).
+    ``conn`` [4, nElem].  Returns (a, b, positions [3, n_nodes]) or None."""
+    conn = np.asarray(conn, dtype=np.int64)
+    if conn.shape[0] != 4 or n_nodes < 8:
+        return None
+    diffs = np.unique(np.abs(conn[:, None, :] - conn[None, :, :]))
+    diffs = diffs[diffs > 0]
+    if len(diffs) == 0 or len(diffs) > 13:
+        return None
+
+    def fits(a, b):
+        if a < 2 or b < 2 * a or b % a or n_nodes % b or a > 1024 or b // a > 1024 or n_nodes // b > 1024 or n_nodes // b < 2:
+            return False
+        axis = [False, False, False]
+        for d in diffs:
+            hit = [(i, j, k) for k in (0, 1) for j in (-1, 0, 1) for i in (-1, 0, 1) if i + j * a + k * b == d]
+            if not hit:
+                return False
+            i, j, k = hit[0]
+            axis[0] |= i != 0
+            axis[1] |= j != 0
+            axis[2] |= k != 0
+        return all(axis)
+
+    for p in range(len(diffs)):
+        for q in range(p + 1, len(diffs)):
+            a, b = int(diffs[p]), int(diffs[q])
+            if not fits(a, b):
+                continue
+            pos = np.stack([np.arange(n_nodes) % a, (np.arange(n_nodes) % b) // a, np.arange(n_nodes) // b])
+            pe = pos[:, conn]                              # [3, 4, nElem]
+            if (pe.max(axis=1) - pe.min(axis=1)).max() <= 1:
+                return a, b, pos
+    return None
+
+
 def _node_brick_axis(stretches, fine, halvings, first_max):
     """One axis of a node-brick level (pfem_amg.inc: node_brick_axis): the occupied positions come in stretches of one owner
     (inclusive ends; one rank: one stretch); inside a stretch f positions make a brick, aligned on multiples of f, a brick at either

@@ -1141,23 +1141,27 @@ int lattice_positions_by_numbering(pfem_solver *s, DevBuf<int32_t> &pos, bool *i
         }
         return axis[0] && axis[1] && axis[2];
     };
+    // (a box of 6 x 5 x 4 nodes whose cells are cut along e_z - e_y offers b = 24 before b = 30: the first pair, ascending, that
+    // every element agrees with is taken)
     int64_t a = 0, b = 0;
-    for (size_t p = 0; p < offs.size() && !a; ++p)
-        for (size_t q = p + 1; q < offs.size() && !a; ++q)
-            if (fits(offs[p], offs[q])) { a = offs[p]; b = offs[q]; }
-    if (!a) return PFEM_OK;
-    const int n2 = static_cast<int>(m.nNode / b);
     DevBuf<int> d_bad;
     PFEM_TRY(d_bad.alloc(1));
-    PFEM_HIP(hipMemsetAsync(d_bad.p, 0, sizeof(int), s->stream));
-    hipLaunchKernelGGL(k_latnum_check, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m.nNode, m.ndof, static_cast<int>(a), static_cast<int>(b), n2,
-                       static_cast<const int64_t *>(s->d_inc_ptr.p), static_cast<const int32_t *>(s->d_inc_cnt.p), static_cast<const int4 *>(s->d_inc_rec.p),
-                       static_cast<const int32_t *>(s->d_node_row.p), d_bad.p);
-    PFEM_TRY(check_kernel("k_latnum_check"));
-    int bad = 0;
-    PFEM_HIP(hipMemcpyAsync(&bad, d_bad.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
-    PFEM_HIP(hipStreamSynchronize(s->stream));
-    if (bad) return PFEM_OK;
+    for (size_t p = 0; p < offs.size() && !a; ++p)
+        for (size_t q = p + 1; q < offs.size() && !a; ++q) {
+            if (!fits(offs[p], offs[q])) continue;
+            PFEM_HIP(hipMemsetAsync(d_bad.p, 0, sizeof(int), s->stream));
+            hipLaunchKernelGGL(k_latnum_check, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m.nNode, m.ndof, static_cast<int>(offs[p]),
+                               static_cast<int>(offs[q]), static_cast<int>(m.nNode / offs[q]), static_cast<const int64_t *>(s->d_inc_ptr.p),
+                               static_cast<const int32_t *>(s->d_inc_cnt.p), static_cast<const int4 *>(s->d_inc_rec.p),
+                               static_cast<const int32_t *>(s->d_node_row.p), d_bad.p);
+            PFEM_TRY(check_kernel("k_latnum_check"));
+            int bad = 0;
+            PFEM_HIP(hipMemcpyAsync(&bad, d_bad.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+            PFEM_HIP(hipStreamSynchronize(s->stream));
+            if (!bad) { a = offs[p]; b = offs[q]; }
+        }
+    if (!a) return PFEM_OK;
+    const int n2 = static_cast<int>(m.nNode / b);
     PFEM_TRY(pos.alloc(static_cast<size_t>(std::max<int64_t>(s->n_owned, 1))));
     PFEM_HIP(hipMemsetAsync(pos.p, 0, sizeof(int32_t) * static_cast<size_t>(std::max<int64_t>(s->n_owned, 1)), s->stream));
     hipLaunchKernelGGL(k_latnum_pos, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m.nNode, m.ndof, static_cast<int>(a), static_cast<int>(b),

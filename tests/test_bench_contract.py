@@ -56,7 +56,9 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     # a solve = numeric set-up + (iterations + 1) cycles; the kernel furthest from the HBM roofline travels with its real bound
     assert 0 < pcb["ms_per_cycle_with_its_cg_iteration"] < d["ms_per_iteration"]
     ak = d["assembly_kernel"]
-    assert ak["bound"] == "fp64-valu-issue" and ak["event_ms_per_step"] == d["assembly_ms_per_step"] and os.path.exists(os.path.join(ROOT, ak["valu_issue_source"].split(" ")[0]))
+    assert ak["bound"].startswith("memory-latency") and ak["event_ms_per_step"] == d["assembly_ms_per_step"] and os.path.exists(os.path.join(ROOT, ak["valu_issue_source"].split(" ")[0]))
+    assert ak["incidence_patterns"] >= 1 and os.path.exists(os.path.join(ROOT, ak["bytes_moved_per_launch_replayed_not_this_run"]["source"].split(" ")[0]))
+    assert d["preconditioner"]["aggregation"][0] == "bricks"
     assert d["cold_value"] > 0 and abs(d["cold_value"] - d["config"]["free_dofs"] / (d["first_step_ms_including_once_per_pattern_setup"] * 1e-3)) <= 1e-6 * d["cold_value"]
 
 

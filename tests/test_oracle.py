@@ -386,3 +386,15 @@ def test_mpi_restatement_of_the_cpu_baseline_equals_the_serial_oracle():
         assert (d["ranks"], d["free_dofs"], d["nnz"]) == (ranks, dm.size_global, len(cols))
         assert (d["iterations"], d["converged_reason"]) == (its, reason) and abs(d["rnorm"] - rn) <= 1e-9 * rn
         assert d["max_nodal_error"] < 2e-3           # P1 elements on a 12^3 mesh against u = x^2+y^2+z^2
+
+
+def test_lattice_by_numbering_restatement():
+    """The strides of a box's numbering from the element connectivity alone (the coordinates may be anything): the generated
+    boxes number their nodes along x, then y, then z; under a random numbering no strides fit."""
+    for nx, ny, nz in ((5, 4, 3), (3, 7, 4), (8, 8, 8)):
+        mesh = O.gen_box_tets(0, 1, nx, 0, 1, ny, 0, 1, nz)
+        got = O.lattice_by_numbering(mesh.conn, mesh.nNode)
+        assert got is not None and (got[0], got[1]) == (nx + 1, (nx + 1) * (ny + 1))
+        assert got[2].max(axis=1).tolist() == [nx, ny, nz]
+        perm = np.random.default_rng(3).permutation(mesh.nNode)
+        assert O.lattice_by_numbering(perm[mesh.conn], mesh.nNode) is None
