@@ -868,8 +868,10 @@ __global__ void __launch_bounds__(kBlock) k_incpat_collect(int64_t nNode, int nd
             }
         }
         if (seen == h) {
-            atomicMin(&table[q].rep, static_cast<int>(n));
-            atomicMax(&st->stride, cnt);
+            // (millions of nodes share the interior's pattern: an atomic only where it can change the word -- the smallest node
+            // of a pattern and the longest list are reached after a few of them; 8 M atomics on one address cost 100 ms)
+            if (static_cast<int>(n) < *reinterpret_cast<volatile int *>(&table[q].rep)) atomicMin(&table[q].rep, static_cast<int>(n));
+            if (cnt > *reinterpret_cast<volatile int *>(&st->stride)) atomicMax(&st->stride, cnt);
             return;
         }
     }
