@@ -1732,7 +1732,7 @@ int build_incidence_patterns(pfem_solver *s)
     const uint16_t *ifl = m.ndof > 1 ? s->d_inc_flags.p : nullptr;
     const int32_t *nrow = s->d_node_row.p;
     hipLaunchKernelGGL(k_incpat_collect, dim3(grid_for(m.nNode)), dim3(kBlock), 0, s->stream, m.nNode, m.ndof, m.npe, ip, ic, irec, ifl, nrow, table.p, st.p);
-    hipLaunchKernelGGL(k_incpat_number, dim3(1), dim3(kBlock), 0, s->stream, table.p, st.p, rep.p);
+    hipLaunchKernelGGL(k_incpat_number, dim3(kIncPatSlots / kBlock), dim3(kBlock), 0, s->stream, table.p, st.p, rep.p);
     PFEM_TRY(check_kernel("k_incpat_collect"));
     IncPatState h{0, 0, 0, 0};
     PFEM_HIP(hipMemcpyAsync(&h, st.p, sizeof h, hipMemcpyDeviceToHost, s->stream));

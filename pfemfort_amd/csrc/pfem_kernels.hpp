@@ -877,18 +877,20 @@ __global__ void __launch_bounds__(kBlock) k_incpat_collect(int64_t nNode, int nd
     }
     st->overflow = 1;
 }
-// one block: patterns numbered by their representatives (ascending node number -- whatever order the slots were claimed in)
+// patterns numbered by their representatives (ascending node number -- whatever order the slots were claimed in)
 __global__ void __launch_bounds__(kBlock) k_incpat_number(IncPatSlot *table, IncPatState *st, int32_t *pat_rep)
 {
     if (st->overflow) return;
-    for (int q = threadIdx.x; q < kIncPatSlots; q += kBlock) {
-        if (table[q].key == 0) continue;
-        const int rep = table[q].rep;
-        int id = 0;
-        for (int j = 0; j < kIncPatSlots; ++j) id += (table[j].key != 0 && table[j].rep < rep) ? 1 : 0;
-        table[q].id = id;
-        pat_rep[id] = rep;
-    }
+    __shared__ int reps[kIncPatSlots];                 // (INT_MAX in the empty slots: never below anybody's)
+    for (int j = threadIdx.x; j < kIncPatSlots; j += kBlock) reps[j] = table[j].key != 0 ? table[j].rep : INT_MAX;
+    __syncthreads();
+    const int q = blockIdx.x * kBlock + threadIdx.x;   // (kIncPatSlots / kBlock blocks: a slot to the thread)
+    if (q >= kIncPatSlots || reps[q] == INT_MAX) return;
+    const int rep = reps[q];
+    int id = 0;
+    for (int j = 0; j < kIncPatSlots; ++j) id += reps[j] < rep ? 1 : 0;
+    table[q].id = id;
+    pat_rep[id] = rep;
 }
 // the table: pattern id's visit t at pat_rec[id * stride + t] (+ the element's constrained-dof bits for kinds with ndof > 1)
 __global__ void __launch_bounds__(kBlock) k_incpat_fill(const IncPatState *st, const int32_t *__restrict__ pat_rep, int npe,
