@@ -1078,9 +1078,9 @@ def main():
                                  "incidence_patterns": R["incidence_patterns"][0], "longest_incidence_list": R["incidence_patterns"][1],
                                  "bytes_moved_per_launch_replayed_not_this_run": {"records_from_the_pattern_table": 2.34e9, "every_nodes_own_records": 5.37e9,
                                                                                   "source": "profiles/r06/assembly_kernel_bound.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per dispatch, tools/r06/incpat2.sh)"},
-                                 # SQ_ACTIVE_INST_VALU / (32 x GRBM_GUI_ACTIVE) of this kernel on this workload, re-taken in round 6 at commit 16005af
-                                 # (466.1 M / (32 x 21.34 M); round 4: 0.75 with 22 % more VALU instructions per launch)
-                                 "valu_issue_fraction_replayed_not_this_run": 0.68,
+                                 # SQ_ACTIVE_INST_VALU / (32 x GRBM_GUI_ACTIVE) of this kernel on this workload, re-taken in round 6 at commit 43503de
+                                 # with the pattern table (473.5 M / (32 x 18.47 M); before the table 0.68 = 466.1 M / (32 x 21.34 M); round 4: 0.75)
+                                 "valu_issue_fraction_replayed_not_this_run": 0.80,
                                  "valu_issue_source": "profiles/r06/gather_and_spmv_sq_counters.txt (rocprofv3 --pmc, separate passes, tools/r06/final.sh)",
                                  # compulsory bytes per launch: SURVEY 8(d)'s 2.69 GB + the codes (0.24 GB) + the two vectors for the multigrid (0.13 GB)
                                  "hbm_frac_of_compulsory_bytes": (3.05e9 / (acc["asm_ms"] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBPS)
