@@ -1032,7 +1032,20 @@ def test_gamg_solve_equals_oracle_restatement(case, tet10, beam, tria20, golden_
     assert all(1.0 < lam < 8.0 for lam in info["lambda_max"])
 
 
-@pytest.mark.parametrize("kind_name", ["poisson", "elast"])
+def _waved(mesh, h, box, amp=0.3):
+    """The mesh under a smooth map that is no tensor product (a wavy block: every node moved along all three axes by amp * h times a
+    product of sines of the OTHER coordinates, vanishing on the boundary): no lattice of coordinates, the box's numbering intact."""
+    lo = np.array([box[0], box[2], box[4]])[:, None]
+    ext = np.array([box[1] - box[0], box[3] - box[2], box[5] - box[4]])[:, None]
+    u = (mesh.xyz - lo) / ext                                   # unit cube
+    bubble = np.prod(np.sin(np.pi * u), axis=0)
+    d = np.stack([np.sin(2 * np.pi * u[1]) * np.cos(np.pi * u[2]), np.sin(3 * np.pi * u[2]) * np.cos(np.pi * u[0]),
+                  np.sin(2 * np.pi * u[0]) * np.cos(2 * np.pi * u[1])]) * bubble * (amp * h)
+    d[:, np.unique(mesh.bc_node)] = 0.0
+    return H.Mesh(mesh.xyz + d, mesh.conn, mesh.bc_node, mesh.bc_dof, mesh.bc_val)
+
+
+@pytest.mark.parametrize("kind_name", ["poisson", "elast", "poisson_waved"])
 def test_gamg_lattice_by_numbering_when_the_nodes_left_their_sites(kind_name, monkeypatch):
     """A box whose nodes were moved (a mapped block, a mesh after a moving-mesh step) has no lattice of coordinates, but its
     NUMBERING is still a box's: the incidence lists are translated copies of a few patterns, their offsets give the strides
@@ -1041,7 +1054,7 @@ def test_gamg_lattice_by_numbering_when_the_nodes_left_their_sites(kind_name, mo
     the moved mesh's matrix equals the oracle's given those aggregates.  The same mesh under a random numbering has neither
     lattice and is left to the passes / matching."""
     monkeypatch.delenv("PFEM_AMG_LATTICE_BY_NUMBERING", raising=False)
-    if kind_name == "poisson":
+    if kind_name.startswith("poisson"):
         kind, ed = pf.POISSON_TET, H.POISSON_ELEMDATA
         mesh0 = H.gen_box_tets(-1, 1, 26, -1, 1, 26, -1, 1, 26)
         h = 2.0 / 26
@@ -1049,7 +1062,9 @@ def test_gamg_lattice_by_numbering_when_the_nodes_left_their_sites(kind_name, mo
         kind, ed = pf.ELAST_TET, H.ELAST_ELEMDATA
         mesh0 = H.gen_box_tets(-0.5, 0.5, 8, 0.0, 6.0, 48, -0.5, 0.5, 8, bc_mode=1, ndof=3)
         h = 1.0 / 8
-    mesh = _moved(mesh0, h)
+    # (random displacements inside a ball of 0.2 h; or -- "waved" -- a smooth map that is no tensor product)
+    mesh = _waved(mesh0, h, (-1, 1, -1, 1, -1, 1)) if kind_name.endswith("waved") else _moved(mesh0, h)
+    assert len(np.unique(np.round(mesh.xyz[0], 12))) > 1024       # (no lattice of coordinates: more distinct values than the table takes)
     s, dm = _device_problem(kind, mesh, ed)
     if kind_name == "elast":
         s.setSpmvFormat("grouped")
@@ -1059,9 +1074,9 @@ def test_gamg_lattice_by_numbering_when_the_nodes_left_their_sites(kind_name, mo
     s.setTolerances(rtol=1e-10, maxits=20000)
     its, info, aggs, x = _gamg_vs_oracle(s)
     kinds = s.amgAggregation()
-    assert s.amgLayout()["lattice_levels"] >= 1 and kinds[0] == ("bricks" if kind_name == "poisson" else "node-bricks"), kinds
+    assert s.amgLayout()["lattice_levels"] >= 1 and kinds[0] == ("bricks" if kind_name.startswith("poisson") else "node-bricks"), kinds
     xyz0 = mesh0.xyz[:, dm.node_map_get_old]
-    if kind_name == "poisson":
+    if kind_name.startswith("poisson"):
         free = np.where(dm.NodeDofArrayNew.reshape(-1) >= 0)[0]
         own = O.lattice_brick_aggregates(xyz0, xyz0[:, free])
         dev = aggs
